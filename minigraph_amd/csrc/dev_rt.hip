@@ -1,0 +1,166 @@
+// dev_rt.hip -- HIP runtime plumbing behind the C interface of mga_dev.h (gfx950 only).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include "mga_dev.h"
+#include "dev_common.h"
+
+static __thread char g_err[512];
+static int g_dev_ok = -1;
+
+extern "C" void mga_set_error(const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+	if (mg_verbose >= 1) fprintf(stderr, "[E::minigraph_amd] %s\n", g_err);
+}
+
+extern "C" const char *mga_last_error(void) { return g_err; }
+
+extern "C" int mga_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+extern "C" int mga_dev_init(void)
+{
+	if (g_dev_ok >= 0) return g_dev_ok ? 0 : -1;
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0) {
+		mga_set_error("no HIP device available (%s): the MI355X path cannot run and there is no CPU fallback", hipGetErrorString(e));
+		g_dev_ok = 0;
+		return -1;
+	}
+	// one process per GPU: honour LOCAL_RANK when launched under torch.distributed.run
+	int dev = 0;
+	const char *lr = getenv("MGA_DEVICE");
+	if (lr == 0) lr = getenv("LOCAL_RANK");
+	if (lr) dev = atoi(lr) % n;
+	if (hipSetDevice(dev) != hipSuccess) { mga_set_error("hipSetDevice(%d) failed", dev); g_dev_ok = 0; return -1; }
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, dev) == hipSuccess && mg_verbose >= 3)
+		fprintf(stderr, "[M::minigraph_amd] device %d: %s (%s), %d CUs, %.1f GB\n", dev, prop.name, prop.gcnArchName,
+				prop.multiProcessorCount, prop.totalGlobalMem / 1073741824.0);
+	g_dev_ok = 1;
+	return 0;
+}
+
+extern "C" void *mga_dmalloc(size_t bytes)
+{
+	void *p = 0;
+	if (bytes == 0) bytes = 16;
+	hipError_t e = hipMalloc(&p, bytes);
+	if (e != hipSuccess) { mga_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return 0; }
+	return p;
+}
+
+extern "C" void mga_dfree(void *p) { if (p) (void)hipFree(p); }
+
+extern "C" int mga_h2d(void *d, const void *h, size_t bytes)
+{
+	if (bytes == 0) return 0;
+	MGA_HIP_CHECK(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice));
+	return 0;
+}
+
+extern "C" int mga_d2h(void *h, const void *d, size_t bytes)
+{
+	if (bytes == 0) return 0;
+	MGA_HIP_CHECK(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+extern "C" int mga_dmemset(void *d, int v, size_t bytes)
+{
+	if (bytes == 0) return 0;
+	MGA_HIP_CHECK(hipMemset(d, v, bytes));
+	return 0;
+}
+
+extern "C" int mga_dsync(void)
+{
+	MGA_HIP_CHECK(hipDeviceSynchronize());
+	return 0;
+}
+
+extern "C" void *mga_hmalloc_pinned(size_t bytes)
+{
+	void *p = 0;
+	if (bytes == 0) bytes = 16;
+	if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return 0;
+	return p;
+}
+
+extern "C" void mga_hfree_pinned(void *p) { if (p) (void)hipHostFree(p); }
+
+extern "C" double mga_wtime(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+
+extern "C" int mga_dbuf_reserve(mga_dbuf_t *b, size_t bytes)
+{
+	if (bytes <= b->cap && b->p) return 0;
+	if (b->p) (void)hipFree(b->p);
+	b->p = 0, b->cap = 0;
+	size_t want = bytes + (bytes >> 3) + 256;
+	b->p = mga_dmalloc(want);
+	if (b->p == 0) return -1;
+	b->cap = want;
+	return 0;
+}
+
+extern "C" void mga_dbuf_free(mga_dbuf_t *b)
+{
+	if (b->p) (void)hipFree(b->p);
+	b->p = 0, b->cap = 0;
+}
+
+// ---- exclusive scan int32 -> int64 (single workgroup, 1024 threads; n up to a few million) ----
+__global__ void __launch_bounds__(1024) k_scan_i32_i64(const int32_t *__restrict__ cnt, int64_t n, int64_t *__restrict__ off)
+{
+	__shared__ int64_t wsum[16];
+	__shared__ int64_t carry;
+	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+	if (threadIdx.x == 0) carry = 0;
+	__syncthreads();
+	for (int64_t base = 0; base < n; base += 1024) {
+		int64_t i = base + threadIdx.x;
+		int64_t v = i < n ? (int64_t)cnt[i] : 0, x = v;
+		for (int d = 1; d < 64; d <<= 1) { // inclusive scan inside the wave
+			int64_t y = __shfl_up(x, d);
+			if (lane >= d) x += y;
+		}
+		if (lane == 63) wsum[wid] = x;
+		__syncthreads();
+		if (wid == 0) {
+			int64_t s = lane < 16 ? wsum[lane] : 0, t = s;
+			for (int d = 1; d < 16; d <<= 1) { int64_t y = __shfl_up(t, d); if (lane >= d) t += y; }
+			if (lane < 16) wsum[lane] = t - s; // exclusive prefix of wave sums
+		}
+		__syncthreads();
+		int64_t c = carry;
+		if (i < n) off[i] = c + wsum[wid] + x - v;
+		__syncthreads();
+		if (threadIdx.x == 1023) carry = c + wsum[wid] + x;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) off[n] = carry;
+}
+
+extern "C" int mga_dev_scan_i32_to_i64(const int32_t *d_cnt, int64_t n, int64_t *d_off)
+{
+	hipLaunchKernelGGL(k_scan_i32_i64, dim3(1), dim3(1024), 0, 0, d_cnt, n, d_off);
+	MGA_HIP_CHECK(hipGetLastError());
+	return 0;
+}

@@ -1,0 +1,84 @@
+/*
+ * mga_dev.h -- internal C interface between the host pipeline (C) and the HIP side.
+ * Everything here takes DEVICE pointers unless a parameter is prefixed h_.  Not part of the public ABI.
+ */
+#ifndef MGA_DEV_H
+#define MGA_DEV_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/minigraph_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- runtime plumbing (dev_rt.hip) ---- */
+int  mga_dev_init(void);                       /* 0 ok; <0 no usable GPU (message via mga_last_error) */
+void mga_set_error(const char *fmt, ...);
+void *mga_dmalloc(size_t bytes);               /* NULL on failure */
+void mga_dfree(void *p);
+int  mga_h2d(void *d, const void *h, size_t bytes);
+int  mga_d2h(void *h, const void *d, size_t bytes);
+int  mga_dmemset(void *d, int v, size_t bytes);
+int  mga_dsync(void);
+void *mga_hmalloc_pinned(size_t bytes);        /* pinned host memory for fast PCIe copies */
+void mga_hfree_pinned(void *p);
+double mga_wtime(void);
+
+/* grow-only device buffer */
+typedef struct { void *p; size_t cap; } mga_dbuf_t;
+int  mga_dbuf_reserve(mga_dbuf_t *b, size_t bytes); /* contents are NOT preserved on growth */
+void mga_dbuf_free(mga_dbuf_t *b);
+
+/* exclusive prefix sum of n int32 counts into n+1 int64 offsets, on device */
+int mga_dev_scan_i32_to_i64(const int32_t *d_cnt, int64_t n, int64_t *d_off);
+
+/* ---- sketch (k_sketch.hip) ---- */
+/* pass 1 (d_mz == NULL): d_cnt[i] = number of minimizers of sequence i.
+ * pass 2: writes minimizers of sequence i at d_mz + d_mz_off[i]. */
+int mga_dev_sketch(int n, const char *d_seq, const int64_t *d_off, const uint32_t *d_rid, int w, int k,
+				   int32_t *d_cnt, const int64_t *d_mz_off, mg128_t *d_mz);
+
+/* ---- device replica of the minimizer index (k_seed.hip) ---- */
+typedef struct {
+	uint64_t n_slots;        /* power of two */
+	uint64_t *d_keys;        /* n_slots: minimizer hash, ~0 = empty */
+	uint64_t *d_vals;        /* n_slots: singleton: y ; list: off<<32 | n  (flag in d_keys' top bit? no: see is_list) */
+	uint8_t  *d_islist;      /* n_slots bytes: 1 if d_vals is (off,n) into d_pos */
+	uint64_t *d_pos;         /* position lists, each ascending */
+	int64_t n_pos;
+	int32_t *d_seg_len;      /* n_seg */
+	int32_t n_seg;
+} mga_didx_t;
+
+/* collect_matches: per read counts.  d_occ[m] = occurrence count of minimizer m (all reads, flat),
+ * d_slot[m] = table slot or -1.  d_na[i], d_nmini[i], d_rep_len[i] per read. */
+int mga_dev_seed_count(const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, int max_occ,
+					   int32_t *d_occ, int64_t *d_slot, int32_t *d_na, int32_t *d_nmini, int32_t *d_rep_len);
+/* expand hits into anchors (at d_a + d_a_off[i]), write mini_pos (at d_mini + d_mini_off[i]), sort anchors by x
+ * with the reference's exact permutation */
+int mga_dev_seed_fill(const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, int max_occ,
+					  const int32_t *d_occ, const int64_t *d_slot, const int64_t *d_a_off, mg128_t *d_a,
+					  const int64_t *d_mini_off, int32_t *d_mini, mg128_t *d_tmp);
+
+/* ---- linear chaining (k_lchain.hip) ---- */
+/* per read i with anchors d_a[a_off[i]..a_off[i+1]): chains into d_u (u at d_u + a_off[i], at most n_i entries),
+ * compacted anchors into d_b + a_off[i]; d_nu[i], d_nb[i] = counts.  d_ws: workspace of 40*total_anchors bytes. */
+int mga_dev_lchain(int n, const mg128_t *d_a, const int64_t *d_a_off, const mga_lchain_par_t *par,
+				   uint64_t *d_u, mg128_t *d_b, int32_t *d_nu, int32_t *d_nb, void *d_ws, size_t ws_bytes);
+size_t mga_dev_lchain_ws_bytes(int64_t total_anchors);
+
+/* ---- WFA (k_wfa.hip) ---- */
+typedef struct { int64_t t_off, q_off; int32_t tl, ql; } mga_wfa_prob_t;
+typedef struct { int32_t score, n_cigar; int64_t cig_off; int32_t status, pad; int64_t n_iter; } mga_wfa_res_t;
+enum { MGA_WFA_OK = 0, MGA_WFA_PENDING = 1, MGA_WFA_RETRY_TIER = 2, MGA_WFA_POOL_FULL = 3, MGA_WFA_MAX_ITER = 4 };
+/* solves problems d_list[0..n) (identity when d_list == NULL) in capacity tier 0..2; cigars are appended to d_pool
+ * (capacity pool_cap ops, *d_pool_used bumped atomically); sequences must be padded by >= 8 readable bytes */
+int mga_dev_wfa(int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+				mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
