@@ -34,6 +34,33 @@ class lchain_par_t(C.Structure):
                 ("chn_pen_gap", C.c_float), ("chn_pen_skip", C.c_float)]
 
 
+class idxopt_t(C.Structure):
+    _fields_ = [("w", C.c_int), ("k", C.c_int), ("bucket_bits", C.c_int)]
+
+
+class mapopt_t(C.Structure):  # minigraph.h:51-77
+    _fields_ = [("flag", C.c_uint64), ("mini_batch_size", C.c_int64), ("seed", C.c_int), ("max_qlen", C.c_int),
+                ("pe_ori", C.c_int), ("occ_max1", C.c_int), ("occ_max1_cap", C.c_int), ("occ_max1_frac", C.c_float),
+                ("bw", C.c_int), ("bw_long", C.c_int), ("rmq_size_cap", C.c_int), ("rmq_rescue_size", C.c_int),
+                ("rmq_rescue_ratio", C.c_float), ("max_gap_pre", C.c_int), ("max_gap", C.c_int),
+                ("max_gap_ref", C.c_int), ("max_frag_len", C.c_int), ("div", C.c_float), ("chn_pen_gap", C.c_float),
+                ("chn_pen_skip", C.c_float), ("max_lc_skip", C.c_int), ("max_lc_iter", C.c_int),
+                ("max_gc_skip", C.c_int), ("min_lc_cnt", C.c_int), ("min_lc_score", C.c_int), ("min_gc_cnt", C.c_int),
+                ("min_gc_score", C.c_int), ("gdp_max_ed", C.c_int), ("lc_max_trim", C.c_int), ("lc_max_occ", C.c_int),
+                ("mask_level", C.c_float), ("sub_diff", C.c_int), ("best_n", C.c_int), ("pri_ratio", C.c_float),
+                ("ref_bonus", C.c_int), ("cap_kalloc", C.c_int64), ("min_cov_mapq", C.c_int), ("min_cov_blen", C.c_int)]
+
+
+class ggopt_t(C.Structure):
+    _fields_ = [("flag", C.c_uint64), ("algo", C.c_int), ("min_mapq", C.c_int), ("min_map_len", C.c_int),
+                ("min_depth_len", C.c_int), ("min_var_len", C.c_int), ("match_pen", C.c_int),
+                ("ggs_shrink_pen", C.c_int), ("ggs_min_end_cnt", C.c_int), ("ggs_min_end_frac", C.c_float),
+                ("ggs_max_iden", C.c_float), ("ggs_min_inv_iden", C.c_float)]
+
+
+MG_M_CIGAR = 0x4000000
+
+
 def load():
     global _lib
     if _lib is not None:
@@ -48,6 +75,15 @@ def load():
     L.mga_last_error.restype = C.c_char_p
     L.mga_sketch_batch.argtypes = [C.c_int, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, pp, pp]
     L.mga_wfa_batch.argtypes = [C.c_int, C.c_char_p, C.c_void_p, C.c_char_p, C.c_void_p, pp, pp, pp]
+    L.gfa_read.argtypes = [C.c_char_p]
+    L.gfa_read.restype = C.c_void_p
+    L.gfa_destroy.argtypes = [C.c_void_p]
+    L.mg_opt_set.argtypes = [C.c_char_p, C.POINTER(idxopt_t), C.POINTER(mapopt_t), C.POINTER(ggopt_t)]
+    L.mg_index.argtypes = [C.c_void_p, C.POINTER(idxopt_t), C.c_int, C.POINTER(mapopt_t)]
+    L.mg_index.restype = C.c_void_p
+    L.mg_idx_destroy.argtypes = [C.c_void_p]
+    L.mga_seed_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, pp, pp, pp, pp, pp]
+    L.mga_lchain_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.POINTER(lchain_par_t), pp, pp, pp, pp]
     _lib = L
     return L
 
@@ -101,3 +137,68 @@ def wfa_batch(targets, queries):
     s = _take(sc, n, np.int32)
     c = _take(cg, int(o[-1]), np.uint32)
     return s, [c[o[i]:o[i + 1]] for i in range(n)]
+
+
+class Graph:
+    """gfa_read() + mg_index(): the graph and its minimizer index (host + HBM replica)."""
+
+    def __init__(self, path, preset="lr", cigar=True, n_threads=4):
+        L = load()
+        self.io, self.mo, self.go = idxopt_t(), mapopt_t(), ggopt_t()
+        L.mg_opt_set(None, C.byref(self.io), C.byref(self.mo), C.byref(self.go))
+        if L.mg_opt_set(preset.encode(), C.byref(self.io), C.byref(self.mo), C.byref(self.go)) != 0:
+            raise ValueError("unknown preset %r" % preset)
+        if cigar:
+            self.mo.flag |= MG_M_CIGAR
+        self.g = L.gfa_read(path.encode())
+        if not self.g:
+            raise RuntimeError("gfa_read(%s) failed" % path)
+        self.gi = L.mg_index(self.g, C.byref(self.io), n_threads, C.byref(self.mo))
+        if not self.gi:
+            raise RuntimeError("mg_index failed: %s" % L.mga_last_error().decode())
+
+    def close(self):
+        L = load()
+        if self.gi:
+            L.mg_idx_destroy(self.gi)
+        if self.g:
+            L.gfa_destroy(self.g)
+        self.gi = self.g = None
+
+    def seed_batch(self, mz_list, max_occ=None):
+        """collect_seed_hits for each read's minimizers -> list of (anchors, rep_len, mini_pos)"""
+        L = load()
+        n = len(mz_list)
+        off = np.zeros(n + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(m) for m in mz_list])
+        flat = np.ascontiguousarray(np.concatenate(mz_list)) if n else np.zeros(0, dtype=m128)
+        a, ao, rl, mp, mo = (C.c_void_p() for _ in range(5))
+        _check(L.mga_seed_batch(self.gi, n, flat.ctypes.data, off.ctypes.data,
+                                self.mo.occ_max1 if max_occ is None else max_occ,
+                                C.byref(a), C.byref(ao), C.byref(rl), C.byref(mp), C.byref(mo)), "mga_seed_batch")
+        aoff = _take(ao, n + 1, np.int64)
+        moff = _take(mo, n + 1, np.int64)
+        aa = _take(a, int(aoff[-1]), m128)
+        rep = _take(rl, n, np.int32)
+        mini = _take(mp, int(moff[-1]), np.int32)
+        return [(aa[aoff[i]:aoff[i + 1]], int(rep[i]), mini[moff[i]:moff[i + 1]]) for i in range(n)]
+
+
+def lchain_batch(anchor_list, **kw):
+    """mg_lchain_dp for each read's x-sorted anchors -> list of (u, compacted anchors)"""
+    L = load()
+    n = len(anchor_list)
+    par = lchain_par_t(kw.get("max_dist_x", 5000), kw.get("max_dist_y", 5000), kw.get("bw", 500),
+                       kw.get("max_skip", 25), kw.get("max_iter", 5000), kw.get("min_cnt", 5), kw.get("min_sc", 40),
+                       kw.get("pen_gap", 1.0), kw.get("pen_skip", 0.05))
+    off = np.zeros(n + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(a) for a in anchor_list])
+    flat = np.ascontiguousarray(np.concatenate(anchor_list)) if n else np.zeros(0, dtype=m128)
+    u, uo, b, bo = (C.c_void_p() for _ in range(4))
+    _check(L.mga_lchain_batch(n, flat.ctypes.data, off.ctypes.data, C.byref(par), C.byref(u), C.byref(uo),
+                              C.byref(b), C.byref(bo)), "mga_lchain_batch")
+    uoff = _take(uo, n + 1, np.int64)
+    boff = _take(bo, n + 1, np.int64)
+    uu = _take(u, int(uoff[-1]), np.uint64)
+    bb = _take(b, int(boff[-1]), m128)
+    return [(uu[uoff[i]:uoff[i + 1]], bb[boff[i]:boff[i + 1]]) for i in range(n)]

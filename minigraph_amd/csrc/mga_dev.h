@@ -42,31 +42,32 @@ int mga_dev_sketch(int n, const char *d_seq, const int64_t *d_off, const uint32_
 
 /* ---- device replica of the minimizer index (k_seed.hip) ---- */
 typedef struct {
-	uint64_t n_slots;        /* power of two */
-	uint64_t *d_keys;        /* n_slots: minimizer hash, ~0 = empty */
-	uint64_t *d_vals;        /* n_slots: singleton: y ; list: off<<32 | n  (flag in d_keys' top bit? no: see is_list) */
-	uint8_t  *d_islist;      /* n_slots bytes: 1 if d_vals is (off,n) into d_pos */
+	uint64_t n_slots;        /* power of two = 1<<bits */
+	int32_t bits, n_seg;
+	mg128_t *d_tab;          /* n_slots x {key | MGA_IDX_LIST, value}; key == MGA_IDX_EMPTY: free slot.
+	                            value: the single y, or off<<32 | n into d_pos when MGA_IDX_LIST is set */
 	uint64_t *d_pos;         /* position lists, each ascending */
 	int64_t n_pos;
-	int32_t *d_seg_len;      /* n_seg */
-	int32_t n_seg;
+	int32_t *d_seg_len;      /* n_seg segment lengths */
 } mga_didx_t;
 
-/* collect_matches: per read counts.  d_occ[m] = occurrence count of minimizer m (all reads, flat),
- * d_slot[m] = table slot or -1.  d_na[i], d_nmini[i], d_rep_len[i] per read. */
+/* collect_matches (map-algo.c:58-91), pass 1: probe every minimizer.  Flat per-minimizer outputs
+ * d_occ[m] (occurrence count) and d_val[m] (slot value); per read d_na[i] (anchors), d_nmini[i]
+ * (kept minimizers) and d_rep_len[i]. */
 int mga_dev_seed_count(const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, int max_occ,
-					   int32_t *d_occ, int64_t *d_slot, int32_t *d_na, int32_t *d_nmini, int32_t *d_rep_len);
-/* expand hits into anchors (at d_a + d_a_off[i]), write mini_pos (at d_mini + d_mini_off[i]), sort anchors by x
- * with the reference's exact permutation */
+					   int32_t *d_occ, uint64_t *d_val, int32_t *d_na, int32_t *d_nmini, int32_t *d_rep_len);
+/* collect_seed_hits (map-algo.c:152-192), pass 2: expand hits into anchors at d_a + d_a_off[i], write mini_pos at
+ * d_mini + d_mini_off[i], then sort each read's anchors by x with the reference's exact permutation.
+ * d_tmp: scratch of the same size as d_a. */
 int mga_dev_seed_fill(const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, int max_occ,
-					  const int32_t *d_occ, const int64_t *d_slot, const int64_t *d_a_off, mg128_t *d_a,
+					  const int32_t *d_occ, const uint64_t *d_val, const int64_t *d_a_off, mg128_t *d_a,
 					  const int64_t *d_mini_off, int32_t *d_mini, mg128_t *d_tmp);
 
 /* ---- linear chaining (k_lchain.hip) ---- */
-/* per read i with anchors d_a[a_off[i]..a_off[i+1]): chains into d_u (u at d_u + a_off[i], at most n_i entries),
- * compacted anchors into d_b + a_off[i]; d_nu[i], d_nb[i] = counts.  d_ws: workspace of 40*total_anchors bytes. */
+/* per read i with anchors d_a[a_off[i]..a_off[i+1]) (x-sorted): chains u[] (score<<32|cnt) at d_u + a_off[i],
+ * compacted anchors at d_b + a_off[i]; d_nu[i], d_nb[i] = their counts.  d_ws: mga_dev_lchain_ws_bytes(total) bytes. */
 int mga_dev_lchain(int n, const mg128_t *d_a, const int64_t *d_a_off, const mga_lchain_par_t *par,
-				   uint64_t *d_u, mg128_t *d_b, int32_t *d_nu, int32_t *d_nb, void *d_ws, size_t ws_bytes);
+				   uint64_t *d_u, mg128_t *d_b, int32_t *d_nu, int32_t *d_nb, void *d_ws, size_t ws_bytes, int64_t total_anchors);
 size_t mga_dev_lchain_ws_bytes(int64_t total_anchors);
 
 /* ---- WFA (k_wfa.hip) ---- */

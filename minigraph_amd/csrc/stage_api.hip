@@ -118,3 +118,68 @@ extern "C" int mga_wfa_batch(int n, const char *tseq, const int64_t *t_off, cons
 	*score = h_score, *cigar = h_cig, *cig_off = h_off;
 	return 0;
 }
+
+struct mg_idx_bucket_s_view { mga_didx_t dev; }; // first member of the hidden index struct (mga_host.h)
+
+extern "C" int mga_seed_batch(const mg_idx_t *gi, int n, const mg128_t *mz, const int64_t *mz_off, int max_occ,
+							  mg128_t **a, int64_t **a_off, int32_t **rep_len, int32_t **mini_pos, int64_t **mini_off)
+{
+	*a = 0, *a_off = 0, *rep_len = 0, *mini_pos = 0, *mini_off = 0;
+	if (mga_dev_init() < 0) return -1;
+	if (n <= 0) { *a_off = (int64_t*)calloc(1, 8); *mini_off = (int64_t*)calloc(1, 8); return 0; }
+	const mga_didx_t *ix = &((const mg_idx_bucket_s_view*)gi->B)->dev;
+	const int64_t n_mz = mz_off[n];
+	dptr d_mz, d_mzoff, d_occ, d_val, d_na, d_nmini, d_rep, d_aoff, d_minioff, d_a, d_tmp, d_mini;
+	if (!d_mz.alloc((size_t)n_mz * 16 + 16) || !d_mzoff.alloc((n + 1) * 8) || !d_occ.alloc((size_t)n_mz * 4 + 4) || !d_val.alloc((size_t)n_mz * 8 + 8) ||
+		!d_na.alloc(n * 4) || !d_nmini.alloc(n * 4) || !d_rep.alloc(n * 4) || !d_aoff.alloc((n + 1) * 8) || !d_minioff.alloc((n + 1) * 8)) return -1;
+	if (mga_h2d(d_mz.p, mz, (size_t)n_mz * 16) < 0 || mga_h2d(d_mzoff.p, mz_off, (n + 1) * 8) < 0) return -1;
+	if (mga_dev_seed_count(ix, n, d_mz.as<mg128_t>(), d_mzoff.as<int64_t>(), max_occ, d_occ.as<int32_t>(), d_val.as<uint64_t>(),
+						   d_na.as<int32_t>(), d_nmini.as<int32_t>(), d_rep.as<int32_t>()) < 0) return -1;
+	if (mga_dev_scan_i32_to_i64(d_na.as<int32_t>(), n, d_aoff.as<int64_t>()) < 0) return -1;
+	if (mga_dev_scan_i32_to_i64(d_nmini.as<int32_t>(), n, d_minioff.as<int64_t>()) < 0) return -1;
+	int64_t *h_aoff = (int64_t*)malloc((n + 1) * 8), *h_moff = (int64_t*)malloc((n + 1) * 8);
+	int32_t *h_rep = (int32_t*)malloc(n * 4);
+	if (mga_d2h(h_aoff, d_aoff.p, (n + 1) * 8) < 0 || mga_d2h(h_moff, d_minioff.p, (n + 1) * 8) < 0 || mga_d2h(h_rep, d_rep.p, n * 4) < 0) return -1;
+	const int64_t n_a = h_aoff[n], n_m = h_moff[n];
+	if (!d_a.alloc((size_t)n_a * 16 + 64) || !d_tmp.alloc((size_t)n_a * 16 + 64) || !d_mini.alloc((size_t)n_m * 4 + 16)) return -1;
+	if (mga_dev_seed_fill(ix, n, d_mz.as<mg128_t>(), d_mzoff.as<int64_t>(), max_occ, d_occ.as<int32_t>(), d_val.as<uint64_t>(),
+						  d_aoff.as<int64_t>(), d_a.as<mg128_t>(), d_minioff.as<int64_t>(), d_mini.as<int32_t>(), d_tmp.as<mg128_t>()) < 0) return -1;
+	mg128_t *h_a = (mg128_t*)malloc((size_t)n_a * 16 + 16);
+	int32_t *h_mini = (int32_t*)malloc((size_t)n_m * 4 + 4);
+	if (mga_d2h(h_a, d_a.p, (size_t)n_a * 16) < 0 || mga_d2h(h_mini, d_mini.p, (size_t)n_m * 4) < 0 || mga_dsync() < 0) return -1;
+	*a = h_a, *a_off = h_aoff, *rep_len = h_rep, *mini_pos = h_mini, *mini_off = h_moff;
+	return 0;
+}
+
+extern "C" int mga_lchain_batch(int n, const mg128_t *a, const int64_t *a_off, const mga_lchain_par_t *par,
+								uint64_t **u, int64_t **u_off, mg128_t **b, int64_t **b_off)
+{
+	*u = 0, *u_off = 0, *b = 0, *b_off = 0;
+	if (mga_dev_init() < 0) return -1;
+	if (n <= 0) { *u_off = (int64_t*)calloc(1, 8); *b_off = (int64_t*)calloc(1, 8); return 0; }
+	const int64_t tot = a_off[n];
+	dptr d_a, d_aoff, d_u, d_b, d_nu, d_nb, d_ws;
+	const size_t wsb = mga_dev_lchain_ws_bytes(tot);
+	if (!d_a.alloc((size_t)tot * 16 + 16) || !d_aoff.alloc((n + 1) * 8) || !d_u.alloc((size_t)tot * 8 + 8) || !d_b.alloc((size_t)tot * 16 + 16) ||
+		!d_nu.alloc(n * 4) || !d_nb.alloc(n * 4) || !d_ws.alloc(wsb)) return -1;
+	if (mga_h2d(d_a.p, a, (size_t)tot * 16) < 0 || mga_h2d(d_aoff.p, a_off, (n + 1) * 8) < 0) return -1;
+	if (mga_dev_lchain(n, d_a.as<mg128_t>(), d_aoff.as<int64_t>(), par, d_u.as<uint64_t>(), d_b.as<mg128_t>(), d_nu.as<int32_t>(), d_nb.as<int32_t>(),
+					   d_ws.p, wsb, tot) < 0) return -1;
+	std::vector<int32_t> nu(n), nb(n);
+	std::vector<uint64_t> hu((size_t)tot + 1);
+	std::vector<mg128_t> hb((size_t)tot + 1);
+	if (mga_dsync() < 0 || mga_d2h(nu.data(), d_nu.p, n * 4) < 0 || mga_d2h(nb.data(), d_nb.p, n * 4) < 0 ||
+		mga_d2h(hu.data(), d_u.p, (size_t)tot * 8) < 0 || mga_d2h(hb.data(), d_b.p, (size_t)tot * 16) < 0) return -1;
+	int64_t *uo = (int64_t*)malloc((n + 1) * 8), *bo = (int64_t*)malloc((n + 1) * 8);
+	int64_t tu = 0, tb = 0;
+	for (int i = 0; i < n; ++i) { uo[i] = tu, bo[i] = tb; tu += nu[i], tb += nb[i]; }
+	uo[n] = tu, bo[n] = tb;
+	uint64_t *ou = (uint64_t*)malloc((size_t)tu * 8 + 8);
+	mg128_t *ob = (mg128_t*)malloc((size_t)tb * 16 + 16);
+	for (int i = 0; i < n; ++i) {
+		memcpy(ou + uo[i], hu.data() + a_off[i], (size_t)nu[i] * 8);
+		memcpy(ob + bo[i], hb.data() + a_off[i], (size_t)nb[i] * 16);
+	}
+	*u = ou, *u_off = uo, *b = ob, *b_off = bo;
+	return 0;
+}

@@ -1,0 +1,27 @@
+/* tables.c -- nucleotide tables: nt4 code (sketch.c:9-26) and IUPAC complement (gfa-base.c:509-526),
+ * generated from their definitions rather than stored. */
+#include "mga_host.h"
+
+unsigned char mga_comp_table[256];
+unsigned char mga_nt4_table[256];
+static int g_tables_ready = 0;
+
+void mga_tables_init(void)
+{
+	static const char *pairs = "ATCGBVDHKMRY"; /* complement pairs; S, W, N and every other letter map to themselves; U -> A */
+	int i;
+	if (g_tables_ready) return;
+	for (i = 0; i < 256; ++i) mga_comp_table[i] = (unsigned char)i, mga_nt4_table[i] = 4;
+	for (i = 0; pairs[i]; i += 2) {
+		unsigned char a = (unsigned char)pairs[i], b = (unsigned char)pairs[i+1];
+		mga_comp_table[a] = b, mga_comp_table[b] = a;
+		mga_comp_table[a + 32] = b + 32, mga_comp_table[b + 32] = a + 32;
+	}
+	mga_comp_table['U'] = 'A', mga_comp_table['u'] = 'a';
+	mga_nt4_table['A'] = mga_nt4_table['a'] = 0;
+	mga_nt4_table['C'] = mga_nt4_table['c'] = 1;
+	mga_nt4_table['G'] = mga_nt4_table['g'] = 2;
+	mga_nt4_table['T'] = mga_nt4_table['t'] = mga_nt4_table['U'] = mga_nt4_table['u'] = 3;
+	mga_nt4_table[0] = 0, mga_nt4_table[1] = 1, mga_nt4_table[2] = 2, mga_nt4_table[3] = 3; /* sketch.c:10: codes map to themselves */
+	g_tables_ready = 1;
+}

@@ -189,8 +189,23 @@ class Oracle:
         s = self.lib.mgo_wfa_exact(C.byref(opt), len(ts), ts, len(qs), qs, cig.ctypes.data, cap, C.byref(n), C.byref(it))
         return s, cig[:n.value].copy()
 
-    def idx_build(self, segs):
+    def idx_build(self, segs, w, k):
         n = len(segs)
         arr = (C.c_char_p * n)(*segs)
         lens = (C.c_int32 * n)(*[len(s) for s in segs])
-        return self.lib.mgo_idx_build(n, arr, lens, self._w, self._k)
+        self._seg_len = np.array([len(s) for s in segs], dtype=np.int32)
+        return self.lib.mgo_idx_build(n, arr, lens, w, k)
+
+    def idx_free(self, idx):
+        self.lib.mgo_idx_free(idx)
+
+    def seed_hits(self, idx, mz, max_occ):
+        mz = np.ascontiguousarray(mz)
+        rep, nmp = C.c_int32(0), C.c_int32(0)
+        n_a = self.lib.mgo_collect_seed_hits(idx, self._seg_len.ctypes.data, max_occ, len(mz), mz.ctypes.data, None,
+                                             C.byref(rep), C.byref(nmp), None)
+        a = np.zeros(max(n_a, 1), dtype=m128)
+        mp = np.zeros(max(nmp.value, 1), dtype=np.int32)
+        n_a = self.lib.mgo_collect_seed_hits(idx, self._seg_len.ctypes.data, max_occ, len(mz), mz.ctypes.data,
+                                             a.ctypes.data, C.byref(rep), C.byref(nmp), mp.ctypes.data)
+        return a[:n_a].copy(), rep.value, mp[:nmp.value].copy()

@@ -137,3 +137,105 @@ def test_wfa_roundtrip_property():
             else:
                 raise AssertionError(o)
         assert ti == len(t) and qi == len(q) and pen == sc[i], i
+
+
+# ---------------------------------------------------------------------------------------------
+# seeds + linear chaining against a real (synthetic) graph
+# ---------------------------------------------------------------------------------------------
+import os
+import subprocess
+import tempfile
+
+
+def read_fa(path):
+    seqs, cur = [], []
+    for line in open(path, "rb"):
+        if line.startswith(b">"):
+            if cur:
+                seqs.append(b"".join(cur))
+            cur = []
+        else:
+            cur.append(line.strip())
+    if cur:
+        seqs.append(b"".join(cur))
+    return seqs
+
+
+def read_gfa_segs(path):
+    return [l.split(b"\t")[2] for l in open(path, "rb") if l.startswith(b"S\t")]
+
+
+@pytest.fixture(scope="module")
+def sim():
+    d = tempfile.mkdtemp(prefix="mga_sim_")
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "1500000", "-H", "3", "-n", "300", "-s", "7"],
+                          stderr=subprocess.DEVNULL)
+    # make some minimizers repetitive: append a tandem-ish segment family to the graph
+    return d
+
+
+def test_seed_and_lchain_parity(ora, sim):
+    gfa, reads = os.path.join(sim, "t.gfa"), read_fa(os.path.join(sim, "t.reads.fa"))
+    G = mga.Graph(gfa)
+    try:
+        segs = read_gfa_segs(gfa)
+        oidx = ora.idx_build(segs, 11, 17)
+        mz = mga.sketch_batch(reads, 11, 17)
+        for max_occ in (G.mo.occ_max1, 2):
+            got = G.seed_batch(mz, max_occ=max_occ)
+            exp = [ora.seed_hits(oidx, m, max_occ) for m in mz]
+            for i in range(len(reads)):
+                assert got[i][1] == exp[i][1], ("rep_len", i)
+                assert np.array_equal(got[i][2], exp[i][2]), ("mini_pos", i)
+                assert np.array_equal(got[i][0], exp[i][0]), ("anchors", i)
+        anchors = [e[0] for e in exp]
+        got = G.seed_batch(mz)
+        anchors = [g[0] for g in got]
+        for kw in (dict(), dict(max_skip=2, bw=100), dict(max_iter=20)):
+            lc = mga.lchain_batch(anchors, **kw)
+            for i in range(len(reads)):
+                eu, ea = ora.lchain_dp(anchors[i], **kw)
+                assert np.array_equal(lc[i][0], eu), ("u", i, kw)
+                assert np.array_equal(lc[i][1], ea), ("a", i, kw)
+        ora.idx_free(oidx)
+    finally:
+        G.close()
+
+
+def make_anchors(rng, n, n_chain=3, span=17, noise=0.3, tie_frac=0.0):
+    xs, ys = [], []
+    for c in range(n_chain):
+        r0, q0 = int(rng.integers(0, 200000)), int(rng.integers(0, 3000))
+        rev = int(rng.integers(0, 2))
+        m = max(n // n_chain, 1)
+        dr = rng.integers(1, 60, size=m).cumsum()
+        dq = dr + rng.integers(-3, 4, size=m) * (rng.random(m) < 0.3)
+        for i in range(m):
+            xs.append((rev << 32) | (r0 + int(dr[i])))
+            ys.append((span << 32) | max(span, q0 + int(dq[i])))
+    for i in range(int(n * noise)):
+        xs.append((int(rng.integers(0, 2)) << 32) | int(rng.integers(0, 200000)))
+        ys.append((span << 32) | int(rng.integers(span, 10000)))
+    a = np.zeros(len(xs), dtype=mga.m128)
+    a["x"], a["y"] = np.array(xs, dtype=np.uint64), np.array(ys, dtype=np.uint64)
+    if tie_frac > 0:
+        idx = rng.integers(0, len(a), size=int(len(a) * tie_frac))
+        a["x"][idx] = a["x"][(idx + 1) % len(a)]
+    return a
+
+
+def test_lchain_synthetic_anchor_sets(ora):
+    """ties in x and in score, tiny / large anchor sets, skip + iteration caps"""
+    rng = np.random.default_rng(9)
+    sets = []
+    for it in range(120):
+        n = int(rng.choice([5, 20, 64, 65, 130, 400, 1500, 4000]))
+        a = make_anchors(rng, n, n_chain=int(rng.integers(1, 5)), tie_frac=0.05 if it % 2 else 0.0)
+        sets.append(ora.sort128x(a))
+    sets.append(np.zeros(0, dtype=mga.m128))
+    for kw in (dict(), dict(max_skip=2, bw=100), dict(max_iter=20), dict(min_cnt=2, min_sc=10)):
+        lc = mga.lchain_batch(sets, **kw)
+        for i, a in enumerate(sets):
+            eu, ea = ora.lchain_dp(a, **kw)
+            assert np.array_equal(lc[i][0], eu), ("u", i, kw)
+            assert np.array_equal(lc[i][1], ea), ("a", i, kw)
