@@ -260,6 +260,9 @@ int mg_map_batch(const mg_idx_t *gi, int n, const int *qlens, const char **seqs,
 /* mg_map_files() writing to an arbitrary stream instead of stdout. */
 int mg_map_files_fp(gfa_t *g, int n_fn, const char **fn, const mg_idxopt_t *ipt, const mg_mapopt_t *opt0, int n_threads, FILE *out);
 
+/* same, to a file path (convenience for bindings that cannot pass a FILE*) */
+int mga_map_files_to_path(gfa_t *g, int n_fn, const char **fn, const mg_idxopt_t *ipt, const mg_mapopt_t *opt0, int n_threads, const char *out_path);
+
 /* counters of the last mg_map_batch() calls on this index (for the bench's algorithmic-bytes figure) */
 typedef struct {
 	int64_t n_reads, n_bases, n_mz, n_probe, n_hit, n_anchor_chained;

@@ -84,6 +84,8 @@ def load():
     L.mg_idx_destroy.argtypes = [C.c_void_p]
     L.mga_seed_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, pp, pp, pp, pp, pp]
     L.mga_lchain_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.POINTER(lchain_par_t), pp, pp, pp, pp]
+    L.mga_map_files_to_path.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(idxopt_t),
+                                        C.POINTER(mapopt_t), C.c_int, C.c_char_p]
     _lib = L
     return L
 
@@ -202,3 +204,23 @@ def lchain_batch(anchor_list, **kw):
     uu = _take(u, int(uoff[-1]), np.uint64)
     bb = _take(b, int(boff[-1]), m128)
     return [(uu[uoff[i]:uoff[i + 1]], bb[boff[i]:boff[i + 1]]) for i in range(n)]
+
+
+def map_files(graph_path, read_paths, out_path, preset="lr", cigar=True, n_threads=8, verbose=1):
+    """gfa_read + mg_map_files: the whole `minigraph -cx lr graph reads > out` job through the C ABI."""
+    L = load()
+    io, mo, go = idxopt_t(), mapopt_t(), ggopt_t()
+    L.mg_opt_set(None, C.byref(io), C.byref(mo), C.byref(go))
+    if L.mg_opt_set(preset.encode(), C.byref(io), C.byref(mo), C.byref(go)) != 0:
+        raise ValueError("unknown preset %r" % preset)
+    if cigar:
+        mo.flag |= MG_M_CIGAR
+    C.c_int.in_dll(L, "mg_verbose").value = verbose
+    g = L.gfa_read(graph_path.encode())
+    if not g:
+        raise RuntimeError("gfa_read(%s) failed" % graph_path)
+    fns = (C.c_char_p * len(read_paths))(*[p.encode() for p in read_paths])
+    rc = L.mga_map_files_to_path(g, len(read_paths), fns, C.byref(io), C.byref(mo), n_threads, out_path.encode())
+    L.gfa_destroy(g)
+    if rc != 0:
+        raise RuntimeError("mapping failed: %s" % L.mga_last_error().decode())

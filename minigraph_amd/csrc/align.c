@@ -1,0 +1,259 @@
+/*
+ * align.c -- host half of base alignment: turning a graph chain into gap-filling problems for the
+ * WFA kernel, stitching the returned CIGARs, and the ds:Z difference string.
+ *
+ * Reference: mg_gchain_cigar (galign.c:39-145) calls mwf_wfa_auto() once per pair of consecutive kept
+ * anchors; here that loop is split around the GPU:
+ *   mga_plan_cigar()   walks the anchors exactly like the reference, emits either a ready-made
+ *                      operator (pure match / pure insertion / pure deletion shortcuts, galign.c:98-100)
+ *                      or a WFA problem whose target is spliced from the oriented vertex sequences
+ *                      (galign.c:66-93) into a per-thread byte pool;
+ *   [k_wfa.hip solves every problem of the batch]
+ *   mga_apply_cigar()  replays the plan with the reference's run-merging rules (append_cigar1 /
+ *                      append_cigar, galign.c:11-37) and fills mg_cigar_t (galign.c:127-140).
+ * mga_gen_ds() is mg_gchain_gen_ds (galign.c:147-293).
+ */
+#include <stdio.h>
+#include <assert.h>
+#include "hchain.h"
+#include "align.h"
+
+static inline void pool_item(mga_tpool_t *tp, int32_t op, int32_t val)
+{
+	MGA_GROW(mga_cigitem_t, tp->item, tp->n_item, tp->m_item);
+	tp->item[tp->n_item].op = op, tp->item[tp->n_item].val = val, ++tp->n_item;
+}
+
+static char *pool_target(mga_tpool_t *tp, int64_t len)
+{
+	if (tp->n_t + len + 16 > tp->m_t) { tp->m_t = (tp->n_t + len + 16) * 3 / 2 + 4096; tp->tseq = (char*)realloc(tp->tseq, (size_t)tp->m_t); }
+	return tp->tseq + tp->n_t;
+}
+
+void mga_plan_cigar(const gfa_t *g, const gfa_edseq_t *es, const mg_gchains_t *gt, int32_t gc_idx, int64_t q_base, mga_tpool_t *tp)
+{
+	const mg_gchain_t *gc = &gt->gc[gc_idx];
+	int32_t l0 = gc->off, off_a0 = gt->lc[l0].off, j, j0 = 0, k, l;
+	pool_item(tp, 7, (int32_t)(gt->a[off_a0].y >> 32 & 0xff));
+	for (j = 1; j < gc->n_anchor; ++j) {
+		const mg128_t *q, *p = &gt->a[off_a0 + j];
+		int32_t l_seq, qlen;
+		if ((p->y & MG_SEED_IGNORE) && j != gc->n_anchor - 1) continue;
+		q = &gt->a[off_a0 + j0];
+		for (l = l0; l < gc->off + gc->cnt; ++l) { /* the vertex holding anchor j */
+			const mg_llchain_t *r = &gt->lc[l];
+			if (off_a0 + j >= r->off && off_a0 + j < r->off + r->cnt) break;
+		}
+		assert(l < gc->off + gc->cnt);
+		if (l == l0) l_seq = (int32_t)p->x - (int32_t)q->x;
+		else {
+			l_seq = g->seg[gt->lc[l0].v>>1].len - (int32_t)q->x - 1;
+			for (k = l0 + 1; k < l; ++k) l_seq += es[gt->lc[k].v].len;
+			l_seq += (int32_t)p->x + 1;
+		}
+		qlen = (int32_t)p->y - (int32_t)q->y;
+		assert(l_seq > 0 || qlen > 0);
+		if (l_seq == 0) pool_item(tp, 1, qlen);
+		else if (qlen == 0) pool_item(tp, 2, l_seq);
+		else if (l_seq == qlen && qlen <= (int32_t)(q->y >> 32 & 0xff)) pool_item(tp, 7, qlen);
+		else { /* a gap for the WFA kernel: target spliced across vertices, query = read[q.y+1 .. p.y] */
+			char *seq = pool_target(tp, l_seq);
+			mga_wfa_prob_t *pb;
+			if (l == l0) memcpy(seq, &es[gt->lc[l0].v].seq[(int32_t)q->x + 1], (size_t)l_seq);
+			else {
+				uint32_t v = gt->lc[l0].v;
+				int32_t n = g->seg[v>>1].len - (int32_t)q->x - 1;
+				memcpy(seq, &es[v].seq[(int32_t)q->x + 1], (size_t)n);
+				for (k = l0 + 1; k < l; ++k) {
+					v = gt->lc[k].v;
+					memcpy(&seq[n], es[v].seq, (size_t)es[v].len);
+					n += es[v].len;
+				}
+				memcpy(&seq[n], es[gt->lc[l].v].seq, (size_t)((int32_t)p->x + 1));
+			}
+			MGA_GROW(mga_wfa_prob_t, tp->prob, tp->n_prob, tp->m_prob);
+			pb = &tp->prob[tp->n_prob];
+			pb->t_off = tp->n_t, pb->tl = l_seq;
+			pb->q_off = q_base + (int32_t)q->y + 1, pb->ql = qlen;
+			tp->n_t += l_seq;
+			tp->wfa_t_bases += l_seq, tp->wfa_q_bases += qlen;
+			pool_item(tp, -1, (int32_t)tp->n_prob++);
+		}
+		j0 = j, l0 = l;
+	}
+}
+
+typedef struct { uint64_t *a; int32_t n, m; } cig64_v;
+
+static inline void cig_push1(cig64_v *c, int32_t op, int32_t len) /* append_cigar1, galign.c:11-23 */
+{
+	if (c->n > 0 && (int32_t)(c->a[c->n - 1] & 0xf) == op) c->a[c->n - 1] += (uint64_t)len << 4;
+	else {
+		if (c->n == c->m) { c->m += (c->m >> 1) + 16; c->a = MGA_REALLOC(uint64_t, c->a, c->m); }
+		c->a[c->n++] = (uint64_t)len << 4 | (uint64_t)op;
+	}
+}
+
+int mga_apply_cigar(mg_gchains_t *gt, int32_t gc_idx, const mga_cigitem_t *item, int64_t n_item, int64_t prob_base,
+					const mga_wfa_res_t *res, const uint32_t *pool)
+{
+	mg_gchain_t *gc = &gt->gc[gc_idx];
+	cig64_v c = {0, 0, 0};
+	int64_t t;
+	int32_t j, l, off_a0 = gt->lc[gc->off].off;
+	for (t = 0; t < n_item; ++t) {
+		if (item[t].op >= 0) cig_push1(&c, item[t].op, item[t].val);
+		else {
+			const mga_wfa_res_t *r = &res[prob_base + item[t].val];
+			const uint32_t *cg = pool + r->cig_off;
+			int32_t k;
+			if (r->status != MGA_WFA_OK) { free(c.a); return -1; }
+			if (r->n_cigar == 0) continue;
+			cig_push1(&c, (int32_t)(cg[0] & 0xf), (int32_t)(cg[0] >> 4)); /* append_cigar, galign.c:25-37 */
+			if (c.n + r->n_cigar - 1 > c.m) { c.m = c.n + r->n_cigar - 1 + 16; c.a = MGA_REALLOC(uint64_t, c.a, c.m); }
+			for (k = 0; k < r->n_cigar - 1; ++k) c.a[c.n + k] = cg[1 + k];
+			c.n += r->n_cigar - 1;
+		}
+	}
+	gc->p = (mg_cigar_t*)calloc(1, (size_t)c.n * 8 + sizeof(mg_cigar_t));
+	gc->p->ss = (int32_t)gt->a[off_a0].x + 1 - (int32_t)(gt->a[off_a0].y >> 32 & 0xff);
+	gc->p->ee = (int32_t)gt->a[off_a0 + gc->n_anchor - 1].x + 1;
+	gc->p->n_cigar = c.n;
+	memcpy(gc->p->cigar, c.a, (size_t)c.n * 8);
+	for (j = 0, l = 0; j < gc->p->n_cigar; ++j) {
+		int32_t op = (int32_t)(gc->p->cigar[j] & 0xf), len = (int32_t)(gc->p->cigar[j] >> 4);
+		if (op == 7) gc->p->mlen += len, gc->p->blen += len;
+		else gc->p->blen += len;
+		if (op != 1) gc->p->aplen += len;
+		if (op != 2) l += len;
+	}
+	memset(&gc->ds, 0, sizeof gc->ds);
+	free(c.a);
+	if (!(l == gc->qe - gc->qs && gc->p->aplen == gc->pe - gc->ps)) {
+		fprintf(stderr, "[E::%s] CIGAR inconsistent with chain coordinates (galign.c:140): q %d vs %d, path %d vs %d\n", __func__, l, gc->qe - gc->qs, gc->p->aplen, gc->pe - gc->ps);
+		return -2;
+	}
+	return 0;
+}
+
+/* ---- ds:Z ---- */
+typedef struct { char *s; int64_t l, m; } dstr_t;
+
+static inline void ds_room(dstr_t *s, int64_t extra)
+{
+	if (s->l + extra + 1 > s->m) { s->m = (s->l + extra + 1) * 2; s->s = (char*)realloc(s->s, (size_t)s->m); }
+}
+static inline void ds_c(dstr_t *s, char ch) { ds_room(s, 1); s->s[s->l++] = ch; }
+static inline void ds_int(dstr_t *s, int32_t x)
+{
+	char buf[16];
+	int l = 0;
+	do { buf[l++] = (char)('0' + x % 10); x /= 10; } while (x > 0);
+	ds_room(s, l);
+	while (l > 0) s->s[s->l++] = buf[--l];
+}
+#define NT_LC(ch) ("acgtn"[mga_nt4_table[(uint8_t)(ch)]])
+
+static void ds_indel(dstr_t *s, int64_t len, const char *seq, int64_t ll, int64_t lr) /* write_indel, galign.c:153-180 */
+{
+	int64_t i;
+	if (ll + lr >= len) {
+		ds_c(s, '[');
+		for (i = 0; i < len; ++i) ds_c(s, NT_LC(seq[i]));
+		ds_c(s, ']');
+	} else {
+		int64_t k = 0;
+		if (ll > 0) {
+			ds_c(s, '[');
+			for (i = 0; i < ll; ++i) ds_c(s, NT_LC(seq[k + i]));
+			ds_c(s, ']');
+			k += ll;
+		}
+		for (i = 0; i < len - lr - ll; ++i) ds_c(s, NT_LC(seq[k + i]));
+		k += len - lr - ll;
+		if (lr > 0) {
+			ds_c(s, '[');
+			for (i = 0; i < lr; ++i) ds_c(s, NT_LC(seq[k + i]));
+			ds_c(s, ']');
+		}
+	}
+}
+
+void mga_gen_ds(const gfa_edseq_t *es, const char *qseq, mg_gchains_t *gt) /* mg_gchain_gen_ds, galign.c:182-293 */
+{
+	int32_t i, m_off = 0, *off = 0;
+	dstr_t str = {0, 0, 0};
+	char *seq = 0;
+	int64_t m_seq = 0;
+	for (i = 0; i < gt->n_gc; ++i) {
+		mg_gchain_t *gc = &gt->gc[i];
+		int32_t j, n_off = 0;
+		int64_t x, y, l_seq = 0;
+		if (gc->p == 0) continue;
+		str.l = 0;
+		if (gc->p->aplen + 1 > m_seq) { m_seq = gc->p->aplen + 1; seq = (char*)realloc(seq, (size_t)m_seq); }
+		for (j = 0; j < gc->cnt; ++j) { /* the aligned stretch of the walk */
+			uint32_t v = gt->lc[gc->off + j].v;
+			int32_t st = j > 0 ? 0 : gc->p->ss, en = j < gc->cnt - 1 ? es[v].len : gc->p->ee;
+			memcpy(&seq[l_seq], &es[v].seq[st], (size_t)(en - st));
+			l_seq += en - st;
+		}
+		assert(l_seq == gc->p->aplen);
+		for (j = 0, x = 0, y = gc->qs; j < gc->p->n_cigar; ++j) { /* upper bound on the number of entries */
+			int64_t op = gc->p->cigar[j] & 0xf, len = gc->p->cigar[j] >> 4, zz;
+			if (op == 0 || op == 7 || op == 8) {
+				++n_off;
+				for (zz = 0; zz < len; ++zz)
+					if (mga_nt4_table[(uint8_t)seq[x + zz]] != mga_nt4_table[(uint8_t)qseq[y + zz]]) n_off += 2;
+				x += len, y += len;
+			} else if (op == 1) ++n_off, y += len;
+			else if (op == 2) ++n_off, x += len;
+		}
+		if (n_off > m_off) { m_off = n_off + (n_off >> 1) + 16; off = MGA_REALLOC(int32_t, off, m_off); }
+		for (j = 0, x = 0, y = gc->qs, n_off = 0; j < gc->p->n_cigar; ++j) {
+			int64_t op = gc->p->cigar[j] & 0xf, len = gc->p->cigar[j] >> 4;
+			if (op == 0 || op == 7 || op == 8) {
+				int64_t zz;
+				int32_t l = 0;
+				for (zz = 0; zz < len; ++zz) {
+					uint8_t cx = mga_nt4_table[(uint8_t)seq[x + zz]], cy = mga_nt4_table[(uint8_t)qseq[y + zz]];
+					if (cx != cy) {
+						if (l > 0) { off[n_off++] = (int32_t)str.l; ds_c(&str, ':'); ds_int(&str, l); }
+						off[n_off++] = (int32_t)str.l;
+						ds_c(&str, '*'); ds_c(&str, "acgtn"[cx]); ds_c(&str, "acgtn"[cy]);
+						l = 0;
+					} else ++l;
+				}
+				if (l > 0) { off[n_off++] = (int32_t)str.l; ds_c(&str, ':'); ds_int(&str, l); }
+				x += len, y += len;
+			} else if (op == 1) { /* insertion: micro-homology on either side */
+				int64_t zz, ll, lr;
+				for (zz = 1; zz <= len; ++zz) if (y - zz < gc->qs || qseq[y + len - zz] != qseq[y - zz]) break;
+				lr = zz - 1;
+				for (zz = 0; zz < len; ++zz) if (y + len + zz >= gc->qe || qseq[y + len + zz] != qseq[y + zz]) break;
+				ll = zz;
+				off[n_off++] = (int32_t)str.l;
+				ds_c(&str, '+');
+				ds_indel(&str, len, &qseq[y], ll, lr);
+				y += len;
+			} else if (op == 2) {
+				int64_t zz, ll, lr;
+				for (zz = 1; zz <= len; ++zz) if (x - zz < 0 || seq[x + len - zz] != seq[x - zz]) break;
+				lr = zz - 1;
+				for (zz = 0; zz < len; ++zz) if (x + len + zz >= gc->p->aplen || seq[x + zz] != seq[x + len + zz]) break;
+				ll = zz;
+				off[n_off++] = (int32_t)str.l;
+				ds_c(&str, '-');
+				ds_indel(&str, len, &seq[x], ll, lr);
+				x += len;
+			}
+		}
+		gc->ds.len = (int32_t)str.l;
+		gc->ds.ds = (char*)calloc((size_t)str.l + 1, 1);
+		memcpy(gc->ds.ds, str.s, (size_t)str.l);
+		gc->ds.n_off = n_off;
+		gc->ds.off = MGA_CALLOC(int32_t, n_off > 0 ? n_off : 1);
+		memcpy(gc->ds.off, off, (size_t)n_off * sizeof(int32_t));
+	}
+	free(off); free(str.s); free(seq);
+}

@@ -1,0 +1,19 @@
+/* align.h -- plan/apply interface of the base-alignment host half (align.c) */
+#ifndef MGA_ALIGN_H
+#define MGA_ALIGN_H
+#include "mga_host.h"
+
+typedef struct { int32_t op, val; } mga_cigitem_t; /* op >= 0: ready operator (op, len = val); op == -1: WFA problem #val of this pool */
+
+typedef struct { /* per host thread accumulators of one batch */
+	char *tseq; int64_t n_t, m_t;                  /* spliced target sequences */
+	mga_wfa_prob_t *prob; int64_t n_prob, m_prob;  /* t_off relative to this pool; q_off absolute in the device read buffer */
+	mga_cigitem_t *item; int64_t n_item, m_item;
+	int64_t wfa_t_bases, wfa_q_bases;
+} mga_tpool_t;
+
+void mga_plan_cigar(const gfa_t *g, const gfa_edseq_t *es, const mg_gchains_t *gt, int32_t gc_idx, int64_t q_base, mga_tpool_t *tp);
+int mga_apply_cigar(mg_gchains_t *gt, int32_t gc_idx, const mga_cigitem_t *item, int64_t n_item, int64_t prob_base,
+					const mga_wfa_res_t *res, const uint32_t *pool);
+void mga_gen_ds(const gfa_edseq_t *es, const char *qseq, mg_gchains_t *gt);
+#endif

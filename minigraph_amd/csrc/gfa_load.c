@@ -432,7 +432,7 @@ gfa_t *gfa_read(const char *fn)
 			for (p = line; *p && !isspace((unsigned char)*p); ++p) {}
 			*p = 0;
 			snprintf(nm, sizeof nm, "s%u", g->n_seg + 1);
-			fa_seg = &g->seg[add_seg(g, nm)];
+			{ int32_t sid = add_seg(g, nm); fa_seg = &g->seg[sid]; } /* NB: add_seg may move g->seg */
 			fa_seg->snid = add_sseq(g, line + 1);
 			fa_seg->soff = fa_seg->rank = 0;
 			l_fa = 0;

@@ -1,0 +1,131 @@
+/*
+ * mapfiles.c -- file-level driver: mg_map_files() (reference gmap.c:163-211) on top of mg_map_batch().
+ * Reads FASTA/FASTQ (plain or gzip), upper-cases and converts U->T like the reference (gmap.c:81,
+ * bseq.c:50-58), maps mini-batches of opt->mini_batch_size bases and writes GAF in input order.
+ * I/O itself is out of scope to accelerate; the reader below is a plain line-based parser.
+ */
+#include <zlib.h>
+#include <stdio.h>
+#include <ctype.h>
+#include "mga_host.h"
+
+typedef struct { gzFile fp; char *buf; int beg, end, eof; } rd_t;
+
+static int rd_getc(rd_t *r)
+{
+	if (r->beg >= r->end) {
+		if (r->eof) return -1;
+		r->end = gzread(r->fp, r->buf, 1 << 20), r->beg = 0;
+		if (r->end <= 0) { r->eof = 1, r->end = 0; return -1; }
+	}
+	return (unsigned char)r->buf[r->beg++];
+}
+
+typedef struct { char *s; size_t l, m; } str_t;
+static inline void str_c(str_t *s, int c) { if (s->l + 2 > s->m) { s->m = s->m ? s->m << 1 : 256; s->s = (char*)realloc(s->s, s->m); } s->s[s->l++] = (char)c; s->s[s->l] = 0; }
+
+/* one FASTA/FASTQ record; returns 0, or -1 at EOF.  `last` carries the record marker between calls (kseq semantics) */
+static int read_record(rd_t *r, int *last, str_t *name, str_t *seq)
+{
+	int c;
+	if (*last == 0) {
+		while ((c = rd_getc(r)) >= 0 && c != '>' && c != '@') {}
+		if (c < 0) return -1;
+		*last = c;
+	}
+	name->l = seq->l = 0;
+	while ((c = rd_getc(r)) >= 0 && !isspace(c)) str_c(name, c);
+	if (name->s == 0) str_c(name, 0), name->l = 0;
+	while (c >= 0 && c != '\n') c = rd_getc(r); /* drop the comment */
+	while ((c = rd_getc(r)) >= 0 && c != '>' && c != '+' && c != '@') {
+		if (c == '\n') continue;
+		str_c(seq, c);
+		while ((c = rd_getc(r)) >= 0 && c != '\n') str_c(seq, c);
+	}
+	if (seq->s == 0) str_c(seq, 0), seq->l = 0;
+	if (seq->l > 0 && seq->s[seq->l - 1] == '\r') seq->s[--seq->l] = 0;
+	if (c == '>' || c == '@') *last = c;
+	else *last = 0;
+	if (c == '+') { /* FASTQ: skip the '+' line and as many quality characters as bases */
+		size_t ql = 0;
+		while ((c = rd_getc(r)) >= 0 && c != '\n') {}
+		while (ql < seq->l && (c = rd_getc(r)) >= 0) if (c != '\n' && c != '\r') ++ql;
+		*last = 0;
+	}
+	return 0;
+}
+
+int mg_map_files_fp(gfa_t *g, int n_fn, const char **fn, const mg_idxopt_t *ipt, const mg_mapopt_t *opt0, int n_threads, FILE *out)
+{
+	mg_mapopt_t opt = *opt0;
+	mg_idx_t *gi;
+	int f, ret = 0;
+	kstring_t str = {0, 0, 0};
+	if ((gi = mg_index(g, ipt, n_threads, &opt)) == 0) return -1;
+	for (f = 0; f < n_fn && ret == 0; ++f) {
+		rd_t r;
+		int last = 0, done = 0;
+		str_t name = {0, 0, 0}, seq = {0, 0, 0};
+		memset(&r, 0, sizeof r);
+		r.fp = fn[f] && strcmp(fn[f], "-") ? gzopen(fn[f], "r") : gzdopen(0, "r");
+		if (r.fp == 0) { if (mg_verbose >= 1) fprintf(stderr, "ERROR: failed to open file '%s'\n", fn[f]); ret = -1; break; }
+		r.buf = (char*)malloc(1 << 20);
+		while (!done && ret == 0) {
+			int n = 0, m = 0, i, *qlens = 0;
+			int64_t size = 0;
+			char **seqs = 0, **names = 0;
+			mg_gchains_t **gcs;
+			while (size < opt.mini_batch_size) { /* bseq.c:61-98 */
+				size_t k;
+				if (read_record(&r, &last, &name, &seq) < 0) { done = 1; break; }
+				if (n == m) { m = m ? m << 1 : 256; qlens = MGA_REALLOC(int, qlens, m); seqs = MGA_REALLOC(char*, seqs, m); names = MGA_REALLOC(char*, names, m); }
+				for (k = 0; k < seq.l; ++k) {
+					if (seq.s[k] == 'u' || seq.s[k] == 'U') --seq.s[k];
+					if (seq.s[k] >= 'a' && seq.s[k] <= 'z') seq.s[k] -= 32;
+				}
+				seqs[n] = (char*)malloc(seq.l + 1); memcpy(seqs[n], seq.s, seq.l + 1);
+				names[n] = (char*)malloc(name.l + 1); memcpy(names[n], name.s, name.l + 1);
+				qlens[n++] = (int)seq.l;
+				size += (int64_t)seq.l;
+			}
+			if (n == 0) break;
+			gcs = MGA_CALLOC(mg_gchains_t*, n);
+			if (mg_map_batch(gi, n, qlens, (const char**)seqs, (const char**)names, gcs, &opt, n_threads) < 0) {
+				fprintf(stderr, "[E::%s] %s\n", __func__, mga_last_error());
+				ret = -1;
+			} else {
+				for (i = 0; i < n; ++i) {
+					int32_t ql = qlens[i];
+					mg_write_gaf(&str, gi->g, gcs[i], 1, &ql, names[i], opt.flag, 0);
+					if (str.l) {
+						gi->B->st.gaf_bytes += str.l;
+						if (fwrite(str.s, 1, str.l, out) != str.l) { fprintf(stderr, "[E::%s] failed to write the results\n", __func__); ret = -1; break; }
+					}
+				}
+			}
+			for (i = 0; i < n; ++i) { mg_gchain_free(gcs[i]); free(seqs[i]); free(names[i]); }
+			free(gcs); free(seqs); free(names); free(qlens);
+			if (mg_verbose >= 3) fprintf(stderr, "[M::%s] mapped %d sequences\n", __func__, n);
+		}
+		free(name.s); free(seq.s); free(r.buf);
+		gzclose(r.fp);
+	}
+	free(str.s);
+	mg_idx_destroy(gi);
+	return ret;
+}
+
+int mg_map_files(gfa_t *g, int n_fn, const char **fn, const mg_idxopt_t *ipt, const mg_mapopt_t *opt0, int n_threads)
+{
+	return mg_map_files_fp(g, n_fn, fn, ipt, opt0, n_threads, stdout);
+}
+
+int mga_map_files_to_path(gfa_t *g, int n_fn, const char **fn, const mg_idxopt_t *ipt, const mg_mapopt_t *opt0, int n_threads, const char *out_path)
+{
+	FILE *fp = fopen(out_path, "wb");
+	int ret;
+	if (fp == 0) { mga_set_error("cannot open '%s' for writing", out_path); return -1; }
+	ret = mg_map_files_fp(g, n_fn, fn, ipt, opt0, n_threads, fp);
+	if (fclose(fp) != 0) ret = -1;
+	return ret;
+}

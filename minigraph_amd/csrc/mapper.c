@@ -1,0 +1,443 @@
+/*
+ * mapper.c -- the batched mapping pipeline: mg_map_batch() and the reference-compatible per-read
+ * wrappers mg_map() / mg_map_frag().
+ *
+ * This is the MI355X replacement for kt_for(n_threads, worker_for, ...) -> mg_map_frag() at the
+ * reference's gmap.c:99 / map-algo.c:340-495.  One call maps a whole mini-batch:
+ *
+ *   GPU   reads -> HBM, k_sketch (count + write), k_seed_count / k_seed_fill, k_lchain
+ *   host  per read, on n_threads threads (map-algo.c:407-474): long-join rescue (RMQ chainer), lchain
+ *         records + clean-up, graph chaining with shortest-k / GWFA bridging, parent/filter/MAPQ, and
+ *         the gap list for base alignment
+ *   GPU   k_wfa over every gap of the batch (three capacity tiers)
+ *   host  CIGAR stitching, ds:Z
+ *
+ * The two host halves are exported separately (mga_batch_chain / mga_batch_finish) so that the
+ * host logic is testable on its own; mg_map_batch() is the only caller that matters in production.
+ */
+#include <stdio.h>
+#include <math.h>
+#include <assert.h>
+#include "hchain.h"
+#include "align.h"
+#include "mapper.h"
+
+struct mg_tbuf_s { int dummy; };
+mg_tbuf_t *mg_tbuf_init(void) { return (mg_tbuf_t*)calloc(1, sizeof(mg_tbuf_t)); } /* map-algo.c:14-20: scratch is per batch here */
+void mg_tbuf_destroy(mg_tbuf_t *b) { free(b); }
+
+/* ------------------------------------------------------------------------------------------------ */
+
+typedef struct {
+	int32_t tid;          /* pool that holds this read's plan */
+	int32_t n_gc;
+	int64_t *item_off;    /* n_gc + 1 offsets into the pool's item[] */
+} read_plan_t;
+
+struct mga_batch_s {
+	const mg_idx_t *gi;
+	mg_mapopt_t opt;
+	int n, n_threads;
+	const int *qlens;
+	const char **seqs, **qnames;
+	const int64_t *q_off;   /* offset of read i in the device read buffer */
+	float pen_gap, pen_skip;
+	mg_gchains_t **gcs;
+	read_plan_t *plan;
+	mga_tpool_t *tp;
+	int64_t *tp_prob_base, *tp_t_base;
+	/* stage-1 inputs, valid during mga_batch_chain() only */
+	const int32_t *n_mz, *rep_len, *mini_pos, *nu, *nb;
+	const int64_t *mini_off, *a_off;
+	const uint64_t *u;
+	const mg128_t *a;
+	int a_is_raw;
+	/* stage-2 inputs */
+	const mga_wfa_res_t *res;
+	const uint32_t *pool;
+	int err;
+};
+
+mga_batch_t *mga_batch_init(const mg_idx_t *gi, const mg_mapopt_t *opt, int n, const int *qlens, const char **seqs, const char **qnames,
+							const int64_t *q_off, int n_threads)
+{
+	mga_batch_t *b = MGA_CALLOC(mga_batch_t, 1);
+	float tmp;
+	b->gi = gi, b->opt = *opt, b->n = n, b->qlens = qlens, b->seqs = seqs, b->qnames = qnames, b->q_off = q_off;
+	b->n_threads = n_threads > 0 ? n_threads : 1;
+	tmp = expf(-opt->div * gi->k); /* map-algo.c:388-390 */
+	b->pen_gap = opt->chn_pen_gap * tmp, b->pen_skip = opt->chn_pen_skip * tmp;
+	b->gcs = MGA_CALLOC(mg_gchains_t*, n > 0 ? n : 1);
+	b->plan = MGA_CALLOC(read_plan_t, n > 0 ? n : 1);
+	b->tp = MGA_CALLOC(mga_tpool_t, b->n_threads);
+	b->tp_prob_base = MGA_CALLOC(int64_t, b->n_threads + 1);
+	b->tp_t_base = MGA_CALLOC(int64_t, b->n_threads + 1);
+	return b;
+}
+
+void mga_batch_lchain_par(const mg_idx_t *gi, const mg_mapopt_t *opt, int qlen_max, mga_lchain_par_t *par) /* map-algo.c:377-403 for long reads */
+{
+	float tmp = expf(-opt->div * gi->k);
+	int gap_ref;
+	(void)qlen_max;
+	if (opt->max_gap_ref > 0) gap_ref = opt->max_gap_ref;
+	else if (opt->max_frag_len > 0) gap_ref = opt->max_gap; /* max_frag_len - qlen < max_gap is clamped per read; long reads never set -F */
+	else gap_ref = opt->max_gap;
+	par->max_dist_x = gap_ref, par->max_dist_y = opt->max_gap;
+	par->bw = opt->bw, par->max_skip = opt->max_lc_skip, par->max_iter = opt->max_lc_iter;
+	par->min_cnt = opt->min_lc_cnt, par->min_sc = opt->min_lc_score;
+	par->chn_pen_gap = opt->chn_pen_gap * tmp, par->chn_pen_skip = opt->chn_pen_skip * tmp;
+}
+
+static void chain_worker(void *data, int64_t i, int tid)
+{
+	mga_batch_t *b = (mga_batch_t*)data;
+	const mg_mapopt_t *opt = &b->opt;
+	const mg_idx_t *gi = b->gi;
+	const int qlen = b->qlens[i];
+	const char *seq = b->seqs[i], *qname = b->qnames ? b->qnames[i] : 0;
+	uint32_t hash;
+	int32_t n_lc = 0, n_gc, k;
+	int64_t n_a = 0;
+	uint64_t *u = 0, *u2 = 0;
+	mg128_t *a = 0;
+	mg_lchain_t *lc = 0;
+	mg_gchains_t *gcs;
+
+	b->gcs[i] = 0;
+	if (qlen == 0) return; /* map-algo.c:359-360 */
+	if (opt->max_qlen > 0 && qlen > opt->max_qlen) return;
+	hash = qname ? mga_hash_str(qname) : 0; /* map-algo.c:362-364 */
+	hash ^= mga_hash_u32((uint32_t)qlen) + mga_hash_u32((uint32_t)opt->seed);
+	hash = mga_hash_u32(hash);
+
+	if (b->a_is_raw) { /* MG_M_RMQ: the RMQ chainer is the primary chainer (map-algo.c:397-399) */
+		int64_t na = b->a_off[i + 1] - b->a_off[i];
+		if (na > 0) a = mga_lchain_rmq(opt->max_gap, opt->max_gap_pre, opt->bw, opt->max_lc_skip, opt->rmq_size_cap, opt->min_lc_cnt, opt->min_lc_score,
+									   b->pen_gap, b->pen_skip, na, b->a + b->a_off[i], &n_lc, &u);
+	} else { /* chains of the GPU DP */
+		n_lc = b->nu[i], n_a = b->nb[i];
+		if (n_lc > 0) {
+			u = MGA_MALLOC(uint64_t, n_lc); memcpy(u, b->u + b->a_off[i], (size_t)n_lc * 8);
+			a = MGA_MALLOC(mg128_t, n_a); memcpy(a, b->a + b->a_off[i], (size_t)n_a * 16);
+		}
+	}
+	/* long-join rescue (map-algo.c:407-417) */
+	if (opt->bw_long > opt->bw && (opt->flag & (MG_M_SPLICE | MG_M_SR)) == 0 && n_lc > 1) {
+		int32_t st = (int32_t)a[0].y, en = (int32_t)a[(int32_t)u[0] - 1].y;
+		if (qlen - (en - st) > opt->rmq_rescue_size || qlen - (en - st) > qlen * opt->rmq_rescue_ratio) {
+			mg128_t *a2;
+			for (k = 0, n_a = 0; k < n_lc; ++k) n_a += (int32_t)u[k];
+			free(u); u = 0;
+			mga_ksort_128x(n_a, a);
+			a2 = mga_lchain_rmq(opt->max_gap, opt->max_gap_pre, opt->bw_long, opt->max_lc_skip, opt->rmq_size_cap, opt->min_lc_cnt, opt->min_lc_score,
+								b->pen_gap, b->pen_skip, n_a, a, &n_lc, &u);
+			free(a); a = a2;
+		}
+	}
+	if (n_lc) { /* map-algo.c:423-448 */
+		const int32_t *mini = b->mini_pos + b->mini_off[i];
+		const int32_t n_mini = (int32_t)(b->mini_off[i + 1] - b->mini_off[i]);
+		lc = mga_lchain_gen(hash, qlen, n_lc, u, a);
+		if (n_lc > 1) n_lc = mga_lchain_cleanup(opt, n_lc, lc, a);
+		for (k = 0; k < n_lc; ++k) mga_update_anchors(lc[k].cnt, &a[lc[k].off], n_mini, mini);
+	}
+	free(u); u = 0;
+	n_gc = mga_gchain1_dp(gi->g, &n_lc, lc, qlen, opt->bw_long, opt->bw_long, opt->bw_long, opt->max_gc_skip, opt->ref_bonus,
+						  b->pen_gap, b->pen_skip, opt->mask_level, a, &u2);
+	gcs = mga_gchain_gen(gi->g, gi->es, n_gc, u2, lc, a, hash, opt->min_gc_cnt, opt->min_gc_score, opt->gdp_max_ed, 1, seq);
+	gcs->rep_len = b->rep_len[i];
+	free(a); free(lc); free(u2);
+	mga_gchain_set_parent(opt->mask_level, gcs->n_gc, gcs->gc, opt->sub_diff, 0);
+	mga_gchain_flt_sub(opt->pri_ratio, gi->k * 2, opt->best_n, gcs->n_gc, gcs->gc);
+	mga_gchain_drop_flt(gcs);
+	mga_gchain_set_mapq(gcs, qlen, b->n_mz[i], opt->min_gc_score);
+	b->gcs[i] = gcs;
+	if (opt->flag & MG_M_CIGAR) { /* list the gaps of every chain for the WFA kernel */
+		read_plan_t *pl = &b->plan[i];
+		mga_tpool_t *tp = &b->tp[tid];
+		pl->tid = tid, pl->n_gc = gcs->n_gc;
+		pl->item_off = MGA_MALLOC(int64_t, gcs->n_gc + 1);
+		for (k = 0; k < gcs->n_gc; ++k) {
+			pl->item_off[k] = tp->n_item;
+			mga_plan_cigar(gi->g, gi->es, gcs, k, b->q_off ? b->q_off[i] : 0, tp);
+		}
+		pl->item_off[gcs->n_gc] = tp->n_item;
+	}
+}
+
+int mga_batch_chain(mga_batch_t *b, const int32_t *n_mz, const int32_t *rep_len, const int32_t *mini_pos, const int64_t *mini_off,
+					const int32_t *nu, const int32_t *nb, const uint64_t *u, const mg128_t *a, const int64_t *a_off, int a_is_raw)
+{
+	int t;
+	b->n_mz = n_mz, b->rep_len = rep_len, b->mini_pos = mini_pos, b->mini_off = mini_off;
+	b->nu = nu, b->nb = nb, b->u = u, b->a = a, b->a_off = a_off, b->a_is_raw = a_is_raw;
+	mga_parallel_for(b->n_threads, b->n, chain_worker, b);
+	for (t = 0; t < b->n_threads; ++t) {
+		b->tp_prob_base[t + 1] = b->tp_prob_base[t] + b->tp[t].n_prob;
+		b->tp_t_base[t + 1] = b->tp_t_base[t] + b->tp[t].n_t;
+	}
+	return 0;
+}
+
+int64_t mga_batch_n_wfa(const mga_batch_t *b) { return b->tp_prob_base[b->n_threads]; }
+int64_t mga_batch_wfa_target_bytes(const mga_batch_t *b) { return b->tp_t_base[b->n_threads]; }
+
+void mga_batch_wfa_export(const mga_batch_t *b, mga_wfa_prob_t *prob, char *tseq)
+{
+	int t;
+	int64_t j;
+	for (t = 0; t < b->n_threads; ++t) {
+		const mga_tpool_t *tp = &b->tp[t];
+		memcpy(tseq + b->tp_t_base[t], tp->tseq, (size_t)tp->n_t);
+		for (j = 0; j < tp->n_prob; ++j) {
+			prob[b->tp_prob_base[t] + j] = tp->prob[j];
+			prob[b->tp_prob_base[t] + j].t_off += b->tp_t_base[t];
+		}
+	}
+}
+
+static void finish_worker(void *data, int64_t i, int tid)
+{
+	mga_batch_t *b = (mga_batch_t*)data;
+	mg_gchains_t *gcs = b->gcs[i];
+	read_plan_t *pl = &b->plan[i];
+	int32_t k;
+	(void)tid;
+	if (gcs == 0 || pl->item_off == 0) return;
+	for (k = 0; k < gcs->n_gc; ++k) {
+		const mga_tpool_t *tp = &b->tp[pl->tid];
+		int r = mga_apply_cigar(gcs, k, tp->item + pl->item_off[k], pl->item_off[k + 1] - pl->item_off[k], b->tp_prob_base[pl->tid], b->res, b->pool);
+		if (r < 0) { b->err = r; return; }
+	}
+	mga_gen_ds(b->gi->es, b->seqs[i], gcs);
+}
+
+int mga_batch_finish(mga_batch_t *b, const mga_wfa_res_t *res, const uint32_t *pool)
+{
+	if (!(b->opt.flag & MG_M_CIGAR)) return 0;
+	b->res = res, b->pool = pool, b->err = 0;
+	mga_parallel_for(b->n_threads, b->n, finish_worker, b);
+	if (b->err == -1) mga_set_error("a gap exceeded miniwfa's max_iter (1e8 cells): the k-mer chaining heuristic of mwf_wfa_chain (miniwfa.c:776-822) is not implemented on this path yet");
+	else if (b->err < 0) mga_set_error("stitched CIGAR is inconsistent with the chain coordinates");
+	return b->err;
+}
+
+mg_gchains_t **mga_batch_take_results(mga_batch_t *b) { mg_gchains_t **r = b->gcs; b->gcs = 0; return r; }
+
+void mga_batch_stats(const mga_batch_t *b, mga_stats_t *st)
+{
+	int t;
+	for (t = 0; t < b->n_threads; ++t) st->wfa_t_bases += b->tp[t].wfa_t_bases, st->wfa_q_bases += b->tp[t].wfa_q_bases;
+	st->n_wfa += b->tp_prob_base[b->n_threads];
+}
+
+void mga_batch_destroy(mga_batch_t *b)
+{
+	int i;
+	if (b == 0) return;
+	for (i = 0; i < b->n; ++i) free(b->plan[i].item_off);
+	for (i = 0; i < b->n_threads; ++i) { free(b->tp[i].tseq); free(b->tp[i].prob); free(b->tp[i].item); }
+	if (b->gcs) { for (i = 0; i < b->n; ++i) mg_gchain_free(b->gcs[i]); free(b->gcs); }
+	free(b->plan); free(b->tp); free(b->tp_prob_base); free(b->tp_t_base);
+	free(b);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * device orchestration
+ * ---------------------------------------------------------------------------------------------- */
+
+static struct { /* grow-only device buffers, reused across batches (one GPU per process) */
+	mga_dbuf_t seq, qoff, cnt, mzoff, mz, occ, val, na, nmini, rep, aoff, minioff, a, tmp, mini, u, b, nu, nb, ws;
+	mga_dbuf_t tseq, prob, res, pool, used, list;
+} D;
+
+#define CK(x) do { if ((x) < 0) { rc = -1; goto done; } } while (0)
+
+static int map_chunk(const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs_out,
+					 const mg_mapopt_t *opt, int n_threads)
+{
+	struct mg_idx_bucket_s *B = gi->B;
+	mga_stats_t *st = &B->st;
+	int rc = 0, i, tier;
+	int64_t tot = 0, n_mz, n_a, n_mini, n_prob = 0, n_tb = 0, pool_cap;
+	int64_t *q_off = MGA_MALLOC(int64_t, n + 1), *h_mzoff = 0, *h_aoff = 0, *h_minioff = 0;
+	int32_t *h_nmz = 0, *h_rep = 0, *h_mini = 0, *h_nu = 0, *h_nb = 0, *todo = 0;
+	uint64_t *h_u = 0;
+	mg128_t *h_b = 0;
+	char *h_seq = 0, *h_tseq = 0;
+	mga_wfa_prob_t *h_prob = 0;
+	mga_wfa_res_t *h_res = 0;
+	uint32_t *h_pool = 0;
+	mga_batch_t *b = 0;
+	mga_lchain_par_t par;
+	const int is_rmq = !!(opt->flag & MG_M_RMQ);
+	double t0, t1;
+
+	if (opt->flag & (MG_M_SR | MG_M_HEAP_SORT | MG_M_SPLICE | MG_M_NO_DIAG)) {
+		mga_set_error("mg_map_batch: short-read / splice / -D modes are outside the accelerated long-read path"); rc = -1; goto done;
+	}
+	/* ---- reads -> HBM, back to back, 64 readable bytes of padding at the end (8-byte compares in k_wfa) ---- */
+	tot = 0;
+	for (i = 0; i < n; ++i) { q_off[i] = tot; tot += qlens[i]; }
+	q_off[n] = tot;
+	h_seq = (char*)malloc((size_t)tot + 64);
+	for (i = 0; i < n; ++i) memcpy(h_seq + q_off[i], seqs[i], (size_t)qlens[i]);
+	memset(h_seq + tot, 0, 64);
+	t0 = mga_wtime();
+	CK(mga_dbuf_reserve(&D.seq, (size_t)tot + 64)); CK(mga_dbuf_reserve(&D.qoff, (size_t)(n + 1) * 8));
+	CK(mga_h2d(D.seq.p, h_seq, (size_t)tot + 64)); CK(mga_h2d(D.qoff.p, q_off, (size_t)(n + 1) * 8));
+	/* ---- sketch ---- */
+	CK(mga_dbuf_reserve(&D.cnt, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&D.mzoff, (size_t)(n + 1) * 8));
+	CK(mga_dev_sketch(n, (const char*)D.seq.p, (const int64_t*)D.qoff.p, 0, gi->w, gi->k, (int32_t*)D.cnt.p, 0, 0));
+	CK(mga_dev_scan_i32_to_i64((const int32_t*)D.cnt.p, n, (int64_t*)D.mzoff.p));
+	h_mzoff = MGA_MALLOC(int64_t, n + 1);
+	CK(mga_d2h(h_mzoff, D.mzoff.p, (size_t)(n + 1) * 8));
+	n_mz = h_mzoff[n];
+	CK(mga_dbuf_reserve(&D.mz, (size_t)n_mz * 16 + 16));
+	CK(mga_dev_sketch(n, (const char*)D.seq.p, (const int64_t*)D.qoff.p, 0, gi->w, gi->k, 0, (const int64_t*)D.mzoff.p, (mg128_t*)D.mz.p));
+	CK(mga_dsync());
+	t1 = mga_wtime(); st->t_sketch += t1 - t0; t0 = t1;
+	/* ---- seeds ---- */
+	CK(mga_dbuf_reserve(&D.occ, (size_t)n_mz * 4 + 4)); CK(mga_dbuf_reserve(&D.val, (size_t)n_mz * 8 + 8));
+	CK(mga_dbuf_reserve(&D.na, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&D.nmini, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&D.rep, (size_t)n * 4 + 4));
+	CK(mga_dbuf_reserve(&D.aoff, (size_t)(n + 1) * 8)); CK(mga_dbuf_reserve(&D.minioff, (size_t)(n + 1) * 8));
+	CK(mga_dev_seed_count(&B->dev, n, (const mg128_t*)D.mz.p, (const int64_t*)D.mzoff.p, opt->occ_max1, (int32_t*)D.occ.p, (uint64_t*)D.val.p,
+						  (int32_t*)D.na.p, (int32_t*)D.nmini.p, (int32_t*)D.rep.p));
+	CK(mga_dev_scan_i32_to_i64((const int32_t*)D.na.p, n, (int64_t*)D.aoff.p));
+	CK(mga_dev_scan_i32_to_i64((const int32_t*)D.nmini.p, n, (int64_t*)D.minioff.p));
+	h_aoff = MGA_MALLOC(int64_t, n + 1); h_minioff = MGA_MALLOC(int64_t, n + 1); h_rep = MGA_MALLOC(int32_t, n);
+	CK(mga_d2h(h_aoff, D.aoff.p, (size_t)(n + 1) * 8)); CK(mga_d2h(h_minioff, D.minioff.p, (size_t)(n + 1) * 8)); CK(mga_d2h(h_rep, D.rep.p, (size_t)n * 4));
+	n_a = h_aoff[n], n_mini = h_minioff[n];
+	CK(mga_dbuf_reserve(&D.a, (size_t)n_a * 16 + 64)); CK(mga_dbuf_reserve(&D.tmp, (size_t)n_a * 16 + 64)); CK(mga_dbuf_reserve(&D.mini, (size_t)n_mini * 4 + 16));
+	CK(mga_dev_seed_fill(&B->dev, n, (const mg128_t*)D.mz.p, (const int64_t*)D.mzoff.p, opt->occ_max1, (const int32_t*)D.occ.p, (const uint64_t*)D.val.p,
+						 (const int64_t*)D.aoff.p, (mg128_t*)D.a.p, (const int64_t*)D.minioff.p, (int32_t*)D.mini.p, (mg128_t*)D.tmp.p));
+	CK(mga_dsync());
+	t1 = mga_wtime(); st->t_seed += t1 - t0; t0 = t1;
+	h_nmz = MGA_MALLOC(int32_t, n);
+	for (i = 0; i < n; ++i) h_nmz[i] = (int32_t)(h_mzoff[i + 1] - h_mzoff[i]);
+	h_mini = MGA_MALLOC(int32_t, n_mini + 1);
+	CK(mga_d2h(h_mini, D.mini.p, (size_t)n_mini * 4));
+	/* ---- linear chaining ---- */
+	h_b = MGA_MALLOC(mg128_t, n_a + 1);
+	if (!is_rmq) {
+		size_t wsb = mga_dev_lchain_ws_bytes(n_a);
+		mga_batch_lchain_par(gi, opt, 0, &par);
+		CK(mga_dbuf_reserve(&D.u, (size_t)n_a * 8 + 8)); CK(mga_dbuf_reserve(&D.b, (size_t)n_a * 16 + 16));
+		CK(mga_dbuf_reserve(&D.nu, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&D.nb, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&D.ws, wsb));
+		CK(mga_dev_lchain(n, (const mg128_t*)D.a.p, (const int64_t*)D.aoff.p, &par, (uint64_t*)D.u.p, (mg128_t*)D.b.p, (int32_t*)D.nu.p, (int32_t*)D.nb.p, D.ws.p, wsb, n_a));
+		CK(mga_dsync());
+		h_nu = MGA_MALLOC(int32_t, n); h_nb = MGA_MALLOC(int32_t, n); h_u = MGA_MALLOC(uint64_t, n_a + 1);
+		CK(mga_d2h(h_nu, D.nu.p, (size_t)n * 4)); CK(mga_d2h(h_nb, D.nb.p, (size_t)n * 4));
+		CK(mga_d2h(h_u, D.u.p, (size_t)n_a * 8)); CK(mga_d2h(h_b, D.b.p, (size_t)n_a * 16));
+	} else CK(mga_d2h(h_b, D.a.p, (size_t)n_a * 16));
+	t1 = mga_wtime(); st->t_lchain += t1 - t0; t0 = t1;
+	/* ---- host: graph chaining + gap list ---- */
+	b = mga_batch_init(gi, opt, n, qlens, seqs, qnames, q_off, n_threads);
+	CK(mga_batch_chain(b, h_nmz, h_rep, h_mini, h_minioff, h_nu, h_nb, h_u, h_b, h_aoff, is_rmq));
+	t1 = mga_wtime(); st->t_host_chain += t1 - t0; t0 = t1;
+	/* ---- WFA over all gaps ---- */
+	n_prob = mga_batch_n_wfa(b), n_tb = mga_batch_wfa_target_bytes(b);
+	if ((opt->flag & MG_M_CIGAR) && n_prob > 0) {
+		int64_t m;
+		unsigned long long used = 0;
+		h_prob = MGA_MALLOC(mga_wfa_prob_t, n_prob); h_tseq = (char*)calloc((size_t)n_tb + 64, 1);
+		mga_batch_wfa_export(b, h_prob, h_tseq);
+		h_res = MGA_MALLOC(mga_wfa_res_t, n_prob);
+		CK(mga_dbuf_reserve(&D.tseq, (size_t)n_tb + 64)); CK(mga_dbuf_reserve(&D.prob, (size_t)n_prob * sizeof(mga_wfa_prob_t))); CK(mga_dbuf_reserve(&D.res, (size_t)n_prob * sizeof(mga_wfa_res_t)));
+		CK(mga_dbuf_reserve(&D.used, 64));
+		CK(mga_h2d(D.tseq.p, h_tseq, (size_t)n_tb + 64)); CK(mga_h2d(D.prob.p, h_prob, (size_t)n_prob * sizeof(mga_wfa_prob_t)));
+		pool_cap = (b->tp_t_base[b->n_threads] + n_prob * 8) / 2 + 4096;
+		for (i = 0; i < b->n_threads; ++i) pool_cap += b->tp[i].wfa_q_bases / 2;
+		CK(mga_dbuf_reserve(&D.pool, (size_t)pool_cap * 4)); CK(mga_dmemset(D.used.p, 0, 8));
+		tier = 0, m = n_prob, todo = 0;
+		for (;;) {
+			int64_t j, m2 = 0;
+			int pool_full = 0;
+			if (todo) { CK(mga_dbuf_reserve(&D.list, (size_t)m * 4)); CK(mga_h2d(D.list.p, todo, (size_t)m * 4)); }
+			CK(mga_dev_wfa((int)m, todo ? (const int32_t*)D.list.p : 0, (const mga_wfa_prob_t*)D.prob.p, (const char*)D.tseq.p, (const char*)D.seq.p,
+						   (mga_wfa_res_t*)D.res.p, (uint32_t*)D.pool.p, pool_cap, (unsigned long long*)D.used.p, tier));
+			CK(mga_dsync());
+			CK(mga_d2h(h_res, D.res.p, (size_t)n_prob * sizeof(mga_wfa_res_t)));
+			if (todo == 0) { todo = MGA_MALLOC(int32_t, n_prob); for (j = 0; j < n_prob; ++j) todo[j] = (int32_t)j; }
+			for (j = 0; j < m; ++j) {
+				int32_t s = h_res[todo[j]].status;
+				if (s == MGA_WFA_RETRY_TIER) todo[m2++] = todo[j];
+				else if (s == MGA_WFA_POOL_FULL) pool_full = 1, todo[m2++] = todo[j];
+			}
+			if (m2 == 0) break;
+			if (pool_full) { mga_set_error("WFA CIGAR pool exhausted (capacity %ld ops)", (long)pool_cap); rc = -1; goto done; }
+			if (++tier > 2) { mga_set_error("a WFA problem exceeds the largest capacity tier"); rc = -1; goto done; }
+			m = m2;
+		}
+		CK(mga_d2h(&used, D.used.p, 8));
+		h_pool = MGA_MALLOC(uint32_t, used + 1);
+		CK(mga_d2h(h_pool, D.pool.p, (size_t)used * 4));
+		for (i = 0; i < n_prob; ++i) st->wfa_cells += h_res[i].n_iter;
+	}
+	t1 = mga_wtime(); st->t_wfa += t1 - t0; t0 = t1;
+	/* ---- host: CIGAR stitching + ds ---- */
+	CK(mga_batch_finish(b, h_res, h_pool));
+	t1 = mga_wtime(); st->t_host_post += t1 - t0;
+	{
+		mg_gchains_t **r = mga_batch_take_results(b);
+		for (i = 0; i < n; ++i) gcs_out[i] = r[i];
+		free(r);
+	}
+	st->n_reads += n, st->n_bases += tot, st->n_mz += n_mz, st->n_probe += n_mz, st->n_hit += n_a;
+	for (i = 0; i < n && h_nb; ++i) st->n_anchor_chained += h_nb[i];
+	mga_batch_stats(b, st);
+done:
+	if (b) mga_batch_destroy(b);
+	free(q_off); free(h_mzoff); free(h_aoff); free(h_minioff); free(h_nmz); free(h_rep); free(h_mini); free(h_nu); free(h_nb);
+	free(h_u); free(h_b); free(h_seq); free(h_tseq); free(h_prob); free(h_res); free(h_pool); free(todo);
+	return rc;
+}
+
+int mg_map_batch(const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs,
+				 const mg_mapopt_t *opt, int n_threads)
+{
+	int i, st = 0;
+	if (n <= 0) return 0;
+	if (mga_dev_init() < 0) return -1;
+	for (i = 0; i < n; ++i) gcs[i] = 0;
+	while (st < n) { /* bound device memory: at most ~256 Mbases / 64k reads per launch wave */
+		int en = st;
+		int64_t bases = 0;
+		while (en < n && en - st < 65536 && bases < 256000000) bases += qlens[en++];
+		if (map_chunk(gi, en - st, qlens + st, seqs + st, qnames ? qnames + st : 0, gcs + st, opt, n_threads) < 0) {
+			for (i = 0; i < n; ++i) { mg_gchain_free(gcs[i]); gcs[i] = 0; }
+			return -1;
+		}
+		st = en;
+	}
+	return 0;
+}
+
+void mg_map_frag(const mg_idx_t *gi, int n_segs, const int *qlens, const char **seqs, mg_gchains_t **gcs, mg_tbuf_t *b, const mg_mapopt_t *opt, const char *qname)
+{
+	int i;
+	(void)b;
+	for (i = 0; i < n_segs; ++i) gcs[i] = 0;
+	if (n_segs != 1) { /* multi-segment (paired short reads) is outside the accelerated path: the reference itself returns NULLs for n_segs out of range */
+		if (mg_verbose >= 1) fprintf(stderr, "[E::%s] only single-segment reads are supported by the MI355X path\n", __func__);
+		return;
+	}
+	if (mg_map_batch(gi, 1, qlens, seqs, &qname, gcs, opt, 1) < 0) {
+		fprintf(stderr, "[E::%s] %s\n", __func__, mga_last_error());
+		abort(); /* no CPU fallback */
+	}
+}
+
+mg_gchains_t *mg_map(const mg_idx_t *gi, int qlen, const char *seq, mg_tbuf_t *b, const mg_mapopt_t *opt, const char *qname)
+{
+	mg_gchains_t *gcs;
+	mg_map_frag(gi, 1, &qlen, &seq, &gcs, b, opt, qname);
+	return gcs;
+}
+
+void mga_get_stats(const mg_idx_t *gi, mga_stats_t *st, int reset)
+{
+	*st = gi->B->st;
+	if (reset) memset(&gi->B->st, 0, sizeof(mga_stats_t));
+}

@@ -1,0 +1,395 @@
+/*
+ * rmq.c -- RMQ-tree linear chaining on the host: mg_lchain_rmq (reference lchain.c:221-372).
+ *
+ * Under -x lr this is the long-join rescue (map-algo.c:407-417, fires on roughly half of 10 kb reads);
+ * under -x asm it is the primary chainer.  The algorithm inserts/erases one tree node per anchor and
+ * its result depends on the tie-breaking of the range-minimum query, which in turn depends on the AVL
+ * shape and on WHEN each node's cached subtree minimum is refreshed (krmq.h:151-205).  It is therefore
+ * kept sequential per read (reads run in parallel on host threads) and the tree below performs the same
+ * rebalancing steps and the same minimum refreshes as the reference tree, on an index-based node pool.
+ */
+#include <assert.h>
+#include "mga_host.h"
+#include "hchain.h"
+
+typedef struct {
+	int32_t y;
+	int64_t i;
+	double pri;
+	int32_t c[2];   /* children (pool indices, -1 = none) */
+	int32_t s;      /* node holding the minimum pri of this subtree (with the reference's tie behaviour) */
+	int32_t size;
+	int8_t bal;
+} rq_node_t;
+
+typedef struct {
+	rq_node_t *a;
+	int32_t n, m, free_head;
+} rq_pool_t;
+
+#define RQ_MAXD 64
+#define ND(t, x) ((t)->a[(x)])
+
+static int32_t rq_alloc(rq_pool_t *t)
+{
+	int32_t x;
+	if (t->free_head >= 0) { x = t->free_head; t->free_head = ND(t, x).c[0]; return x; }
+	if (t->n == t->m) { t->m = t->m ? t->m + (t->m >> 1) : 256; t->a = MGA_REALLOC(rq_node_t, t->a, t->m); }
+	return t->n++;
+}
+static void rq_release(rq_pool_t *t, int32_t x) { ND(t, x).c[0] = t->free_head; t->free_head = x; }
+
+static inline int rq_cmp(const rq_pool_t *t, int32_t y, int64_t i, int32_t p) /* lc_elem_cmp, lchain.c:228 */
+{
+	const rq_node_t *q = &ND(t, p);
+	return y < q->y ? -1 : y > q->y ? 1 : (i > q->i) - (i < q->i);
+}
+#define RQ_LT(t, a_, b_) (ND(t, a_).pri < ND(t, b_).pri)
+static inline int32_t rq_csize(const rq_pool_t *t, int32_t p, int d) { int32_t c = ND(t, p).c[d]; return c < 0 ? 0 : ND(t, c).size; }
+
+static inline void rq_refresh(rq_pool_t *t, int32_t p, int32_t q, int32_t r) /* krmq_update_min, krmq.h:153-156 */
+{
+	ND(t, p).s = (q < 0 || RQ_LT(t, p, ND(t, q).s)) ? p : ND(t, q).s;
+	ND(t, p).s = (r < 0 || RQ_LT(t, ND(t, p).s, ND(t, r).s)) ? ND(t, p).s : ND(t, r).s;
+}
+
+static int32_t rq_rot1(rq_pool_t *t, int32_t p, int dir) /* krmq.h:158-169 */
+{
+	int opp = 1 - dir;
+	int32_t q = ND(t, p).c[opp], s = ND(t, p).s, size_p = ND(t, p).size;
+	ND(t, p).size -= ND(t, q).size - rq_csize(t, q, dir);
+	ND(t, q).size = size_p;
+	rq_refresh(t, p, ND(t, p).c[dir], ND(t, q).c[dir]);
+	ND(t, q).s = s;
+	ND(t, p).c[opp] = ND(t, q).c[dir];
+	ND(t, q).c[dir] = p;
+	return q;
+}
+
+static int32_t rq_rot2(rq_pool_t *t, int32_t p, int dir) /* krmq.h:171-192 */
+{
+	int opp = 1 - dir, b1;
+	int32_t q = ND(t, p).c[opp], r = ND(t, q).c[dir], s = ND(t, p).s;
+	int32_t size_x_dir = rq_csize(t, r, dir);
+	ND(t, r).size = ND(t, p).size;
+	ND(t, p).size -= ND(t, q).size - size_x_dir;
+	ND(t, q).size -= size_x_dir + 1;
+	rq_refresh(t, p, ND(t, p).c[dir], ND(t, r).c[dir]);
+	rq_refresh(t, q, ND(t, q).c[opp], ND(t, r).c[opp]);
+	ND(t, r).s = s;
+	ND(t, p).c[opp] = ND(t, r).c[dir];
+	ND(t, r).c[dir] = p;
+	ND(t, q).c[dir] = ND(t, r).c[opp];
+	ND(t, r).c[opp] = q;
+	b1 = dir == 0 ? +1 : -1;
+	if (ND(t, r).bal == b1) ND(t, q).bal = 0, ND(t, p).bal = (int8_t)-b1;
+	else if (ND(t, r).bal == 0) ND(t, q).bal = ND(t, p).bal = 0;
+	else ND(t, q).bal = (int8_t)b1, ND(t, p).bal = 0;
+	ND(t, r).bal = 0;
+	return r;
+}
+
+static void rq_insert(rq_pool_t *t, int32_t *root, int32_t x) /* krmq_insert, krmq.h:194-243; keys are unique here */
+{
+	unsigned char stack[RQ_MAXD];
+	int32_t path[RQ_MAXD], bp = *root, bq = -1, p, q, r = -1;
+	int i, which = 0, top = 0, plen = 0, b1;
+	for (p = bp, q = bq; p >= 0; q = p, p = ND(t, p).c[which]) {
+		int cmp = rq_cmp(t, ND(t, x).y, ND(t, x).i, p);
+		assert(cmp != 0);
+		if (ND(t, p).bal != 0) bq = q, bp = p, top = 0;
+		stack[top++] = which = (cmp > 0);
+		path[plen++] = p;
+	}
+	ND(t, x).bal = 0, ND(t, x).size = 1, ND(t, x).c[0] = ND(t, x).c[1] = -1, ND(t, x).s = x;
+	if (q < 0) *root = x; else ND(t, q).c[which] = x;
+	if (bp < 0) return;
+	for (i = 0; i < plen; ++i) ++ND(t, path[i]).size;
+	for (i = plen - 1; i >= 0; --i) {
+		rq_refresh(t, path[i], ND(t, path[i]).c[0], ND(t, path[i]).c[1]);
+		if (ND(t, path[i]).s != x) break;
+	}
+	for (p = bp, top = 0; p != x; p = ND(t, p).c[stack[top]], ++top)
+		if (stack[top] == 0) --ND(t, p).bal; else ++ND(t, p).bal;
+	if (ND(t, bp).bal > -2 && ND(t, bp).bal < 2) return;
+	which = ND(t, bp).bal < 0;
+	b1 = which == 0 ? +1 : -1;
+	q = ND(t, bp).c[1 - which];
+	if (ND(t, q).bal == b1) { r = rq_rot1(t, bp, which); ND(t, q).bal = ND(t, bp).bal = 0; }
+	else r = rq_rot2(t, bp, which);
+	if (bq < 0) *root = r; else ND(t, bq).c[bp != ND(t, bq).c[0]] = r;
+}
+
+static int32_t rq_find(const rq_pool_t *t, int32_t root, int32_t y, int64_t i)
+{
+	int32_t p = root;
+	while (p >= 0) {
+		int cmp = rq_cmp(t, y, i, p);
+		if (cmp < 0) p = ND(t, p).c[0]; else if (cmp > 0) p = ND(t, p).c[1]; else break;
+	}
+	return p;
+}
+
+/* erase the node with key (y,i); returns its pool index or -1.  krmq_erase, krmq.h:245-323.
+ * Pool slot t->n (never a real node) serves as the reference's stack-allocated "fake" super-root. */
+static int32_t rq_erase(rq_pool_t *t, int32_t *root, int32_t y, int64_t i)
+{
+	int32_t path[RQ_MAXD], p, fake;
+	unsigned char dir[RQ_MAXD];
+	int k, d = 0, cmp;
+	if (t->n == t->m) { t->m += (t->m >> 1) + 16; t->a = MGA_REALLOC(rq_node_t, t->a, t->m); }
+	fake = t->n;
+	ND(t, fake) = ND(t, *root);
+	ND(t, fake).c[0] = *root, ND(t, fake).c[1] = -1;
+	for (cmp = -1, p = fake; cmp; cmp = rq_cmp(t, y, i, p)) {
+		int which = cmp > 0;
+		dir[d] = (unsigned char)which;
+		path[d++] = p;
+		p = ND(t, p).c[which];
+		if (p < 0) return -1;
+	}
+	for (k = 1; k < d; ++k) --ND(t, path[k]).size;
+	if (ND(t, p).c[1] < 0) {
+		ND(t, path[d-1]).c[dir[d-1]] = ND(t, p).c[0];
+	} else {
+		int32_t q = ND(t, p).c[1];
+		if (ND(t, q).c[0] < 0) {
+			ND(t, q).c[0] = ND(t, p).c[0];
+			ND(t, q).bal = ND(t, p).bal;
+			ND(t, path[d-1]).c[dir[d-1]] = q;
+			path[d] = q, dir[d++] = 1;
+			ND(t, q).size = ND(t, p).size - 1;
+		} else {
+			int32_t r;
+			int e = d++;
+			for (;;) {
+				dir[d] = 0;
+				path[d++] = q;
+				r = ND(t, q).c[0];
+				if (ND(t, r).c[0] < 0) break;
+				q = r;
+			}
+			ND(t, r).c[0] = ND(t, p).c[0];
+			ND(t, q).c[0] = ND(t, r).c[1];
+			ND(t, r).c[1] = ND(t, p).c[1];
+			ND(t, r).bal = ND(t, p).bal;
+			ND(t, path[e-1]).c[dir[e-1]] = r;
+			path[e] = r, dir[e] = 1;
+			for (k = e + 1; k < d; ++k) --ND(t, path[k]).size;
+			ND(t, r).size = ND(t, p).size - 1;
+		}
+	}
+	for (k = d - 1; k >= 0; --k) rq_refresh(t, path[k], ND(t, path[k]).c[0], ND(t, path[k]).c[1]);
+	while (--d > 0) {
+		int32_t q = path[d];
+		int which = dir[d], other = 1 - which, b1 = 1, b2 = 2;
+		if (which) b1 = -b1, b2 = -b2;
+		ND(t, q).bal = (int8_t)(ND(t, q).bal + b1);
+		if (ND(t, q).bal == b1) break;
+		else if (ND(t, q).bal == b2) {
+			int32_t r = ND(t, q).c[other];
+			if (ND(t, r).bal == -b1) {
+				ND(t, path[d-1]).c[dir[d-1]] = rq_rot2(t, q, which);
+			} else {
+				ND(t, path[d-1]).c[dir[d-1]] = rq_rot1(t, q, which);
+				if (ND(t, r).bal == 0) { ND(t, r).bal = (int8_t)-b1; ND(t, q).bal = (int8_t)b1; break; }
+				else ND(t, r).bal = ND(t, q).bal = 0;
+			}
+		}
+	}
+	*root = ND(t, fake).c[0];
+	return p;
+}
+
+/* minimum-pri node with key in the CLOSED interval [(lo_y,lo_i), (hi_y,hi_i)]; krmq_rmq, krmq.h:110-149 */
+static int32_t rq_rmq(const rq_pool_t *t, int32_t root, int32_t lo_y, int64_t lo_i, int32_t hi_y, int64_t hi_i)
+{
+	int32_t p = root, path[2][RQ_MAXD], min;
+	int plen[2] = {0, 0}, pcmp[2][RQ_MAXD], i, cmp, lca;
+	if (root < 0) return -1;
+	while (p >= 0) {
+		cmp = rq_cmp(t, lo_y, lo_i, p);
+		path[0][plen[0]] = p, pcmp[0][plen[0]++] = cmp;
+		if (cmp < 0) p = ND(t, p).c[0]; else if (cmp > 0) p = ND(t, p).c[1]; else break;
+	}
+	p = root;
+	while (p >= 0) {
+		cmp = rq_cmp(t, hi_y, hi_i, p);
+		path[1][plen[1]] = p, pcmp[1][plen[1]++] = cmp;
+		if (cmp < 0) p = ND(t, p).c[0]; else if (cmp > 0) p = ND(t, p).c[1]; else break;
+	}
+	for (i = 0; i < plen[0] && i < plen[1]; ++i)
+		if (path[0][i] == path[1][i] && pcmp[0][i] <= 0 && pcmp[1][i] >= 0) break;
+	if (i == plen[0] || i == plen[1]) return -1;
+	lca = i, min = path[0][lca];
+	for (i = lca + 1; i < plen[0]; ++i)
+		if (pcmp[0][i] <= 0) {
+			int32_t c;
+			if (RQ_LT(t, path[0][i], min)) min = path[0][i];
+			c = ND(t, path[0][i]).c[1];
+			if (c >= 0 && RQ_LT(t, ND(t, c).s, min)) min = ND(t, c).s;
+		}
+	for (i = lca + 1; i < plen[1]; ++i)
+		if (pcmp[1][i] >= 0) {
+			int32_t c;
+			if (RQ_LT(t, path[1][i], min)) min = path[1][i];
+			c = ND(t, path[1][i]).c[0];
+			if (c >= 0 && RQ_LT(t, ND(t, c).s, min)) min = ND(t, c).s;
+		}
+	return min;
+}
+
+/* iterator: a root-to-node stack.  krmq_itr_find + krmq_itr_prev (krmq.h:325-362) positioned on the
+ * node `x` that krmq_interval returned as the lower neighbour (greatest key <= query). */
+typedef struct { int32_t stack[RQ_MAXD]; int top; } rq_itr_t;
+
+static void rq_itr_seek(const rq_pool_t *t, int32_t root, int32_t x, rq_itr_t *it)
+{
+	int32_t p = root;
+	it->top = -1;
+	while (p >= 0) {
+		int cmp = rq_cmp(t, ND(t, x).y, ND(t, x).i, p);
+		it->stack[++it->top] = p;
+		if (cmp < 0) p = ND(t, p).c[0]; else if (cmp > 0) p = ND(t, p).c[1]; else break;
+	}
+}
+
+static int rq_itr_prev(const rq_pool_t *t, rq_itr_t *it)
+{
+	int32_t p;
+	if (it->top < 0) return 0;
+	p = ND(t, it->stack[it->top]).c[0];
+	if (p >= 0) {
+		for (; p >= 0; p = ND(t, p).c[1]) it->stack[++it->top] = p;
+		return 1;
+	}
+	do { p = it->stack[it->top--]; } while (it->top >= 0 && p == ND(t, it->stack[it->top]).c[0]);
+	return it->top < 0 ? 0 : 1;
+}
+
+/* greatest node with key <= (y,i), or -1: the `lower` output of krmq_interval (krmq.h:95-108) */
+static int32_t rq_lower(const rq_pool_t *t, int32_t root, int32_t y, int64_t i)
+{
+	int32_t p = root, l = -1;
+	while (p >= 0) {
+		int cmp = rq_cmp(t, y, i, p);
+		if (cmp < 0) p = ND(t, p).c[0];
+		else if (cmp > 0) l = p, p = ND(t, p).c[1];
+		else { l = p; break; }
+	}
+	return l;
+}
+
+static inline int32_t score_simple(const mg128_t *ai, const mg128_t *aj, float pen_gap, float pen_skip, int32_t *exact, int32_t *width) /* lchain.c:234-250 */
+{
+	int32_t dq = (int32_t)ai->y - (int32_t)aj->y, dr, dd, dg, q_span, sc;
+	dr = (int32_t)(ai->x - aj->x);
+	*width = dd = dr > dq ? dr - dq : dq - dr;
+	dg = dr < dq ? dr : dq;
+	q_span = (int32_t)(aj->y >> 32 & 0xff);
+	sc = q_span < dg ? q_span : dg;
+	if (exact) *exact = (dd == 0 && dg <= q_span);
+	if (dd || dq > q_span) {
+		float lin_pen = pen_gap * (float)dd + pen_skip * (float)dg;
+		float log_pen = dd >= 1 ? mga_log2f((float)(dd + 1)) : 0.0f;
+		sc -= (int32_t)(lin_pen + .5f * log_pen);
+	}
+	return sc;
+}
+
+/* in: n x-sorted anchors a[]; out: chains in u[] (malloc'ed, *n_u_ entries) and the compacted anchor array
+ * (malloc'ed, returned).  Same contract as the reference except that a[] is not freed. */
+mg128_t *mga_lchain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_skip, int cap_rmq_size, int min_cnt, int min_sc,
+						float pen_gap, float pen_skip, int64_t n, const mg128_t *a, int *n_u_, uint64_t **u_)
+{
+	int32_t *f, *t, *v, n_u, n_v, max_drop = bw, root = -1, root_inner = -1;
+	int64_t *p, i, i0, st = 0, st_inner = 0;
+	uint64_t *u;
+	rq_pool_t T = {0, 0, 0, -1};
+	mg128_t *ret;
+
+	*u_ = 0, *n_u_ = 0;
+	if (n == 0 || a == 0) return 0;
+	if (max_dist < bw) max_dist = bw;
+	if (max_dist_inner <= 0 || max_dist_inner >= max_dist) max_dist_inner = 0;
+	p = MGA_MALLOC(int64_t, n); f = MGA_MALLOC(int32_t, n); v = MGA_MALLOC(int32_t, n); t = MGA_CALLOC(int32_t, n);
+
+	for (i = i0 = 0; i < n; ++i) {
+		int64_t max_j = -1;
+		int32_t q_span = (int32_t)(a[i].y >> 32 & 0xff), max_f = q_span, q;
+		if (i0 < i && a[i0].x != a[i].x) { /* add in-range anchors (lchain.c:279-293) */
+			int64_t j;
+			for (j = i0; j < i; ++j) {
+				int32_t x = rq_alloc(&T);
+				ND(&T, x).y = (int32_t)a[j].y, ND(&T, x).i = j;
+				ND(&T, x).pri = -(f[j] + 0.5 * pen_gap * ((int32_t)a[j].x + (int32_t)a[j].y));
+				rq_insert(&T, &root, x);
+				if (max_dist_inner > 0) {
+					int32_t r = rq_alloc(&T);
+					ND(&T, r).y = ND(&T, x).y, ND(&T, r).i = j, ND(&T, r).pri = ND(&T, x).pri;
+					rq_insert(&T, &root_inner, r);
+				}
+			}
+			i0 = i;
+		}
+		/* drop active chains out of range (lchain.c:294-302) */
+		while (st < i && (a[i].x >> 32 != a[st].x >> 32 || a[i].x > a[st].x + max_dist || (root >= 0 ? ND(&T, root).size : 0) > cap_rmq_size)) {
+			if (root >= 0 && rq_find(&T, root, (int32_t)a[st].y, st) >= 0) {
+				q = rq_erase(&T, &root, (int32_t)a[st].y, st);
+				if (q >= 0) rq_release(&T, q);
+			}
+			++st;
+		}
+		if (max_dist_inner > 0) { /* lchain.c:303-312 */
+			while (st_inner < i && (a[i].x >> 32 != a[st_inner].x >> 32 || a[i].x > a[st_inner].x + max_dist_inner || (root_inner >= 0 ? ND(&T, root_inner).size : 0) > cap_rmq_size)) {
+				if (root_inner >= 0 && rq_find(&T, root_inner, (int32_t)a[st_inner].y, st_inner) >= 0) {
+					q = rq_erase(&T, &root_inner, (int32_t)a[st_inner].y, st_inner);
+					if (q >= 0) rq_release(&T, q);
+				}
+				++st_inner;
+			}
+		}
+		/* RMQ (lchain.c:313-352) */
+		q = rq_rmq(&T, root, (int32_t)a[i].y - max_dist, INT32_MAX, (int32_t)a[i].y - 1, 0);
+		if (q >= 0) {
+			int32_t sc, exact, width, n_skip = 0;
+			int64_t j = ND(&T, q).i;
+			sc = f[j] + score_simple(&a[i], &a[j], pen_gap, pen_skip, &exact, &width);
+			if (width <= bw && sc > max_f) max_f = sc, max_j = j;
+			if (!exact && root_inner >= 0 && (int32_t)a[i].y > 0) {
+				int32_t lo = rq_lower(&T, root_inner, (int32_t)a[i].y - 1, n);
+				if (lo >= 0) {
+					rq_itr_t itr;
+					rq_itr_seek(&T, root_inner, lo, &itr);
+					while (itr.top >= 0) {
+						int32_t qq = itr.stack[itr.top];
+						if (ND(&T, qq).y < (int32_t)a[i].y - max_dist_inner) break;
+						j = ND(&T, qq).i;
+						sc = f[j] + score_simple(&a[i], &a[j], pen_gap, pen_skip, 0, &width);
+						if (width <= bw) {
+							if (sc > max_f) {
+								max_f = sc, max_j = j;
+								if (n_skip > 0) --n_skip;
+							} else if (t[j] == (int32_t)i) {
+								if (++n_skip > max_chn_skip) break;
+							}
+							if (p[j] >= 0) t[p[j]] = (int32_t)i;
+						}
+						if (!rq_itr_prev(&T, &itr)) break;
+					}
+				}
+			}
+		}
+		f[i] = max_f, p[i] = max_j;
+		v[i] = max_j >= 0 && v[max_j] > max_f ? v[max_j] : max_f;
+	}
+	free(T.a);
+
+	u = mga_chain_backtrack(n, f, p, v, t, min_cnt, min_sc, max_drop, 0, &n_u, &n_v);
+	*n_u_ = n_u, *u_ = u;
+	free(p); free(f); free(t);
+	if (n_u == 0) { free(v); return 0; }
+	ret = mga_compact_a(n_u, u, n_v, v, a);
+	free(v);
+	return ret;
+}
