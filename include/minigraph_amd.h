@@ -263,6 +263,17 @@ int mg_map_files_fp(gfa_t *g, int n_fn, const char **fn, const mg_idxopt_t *ipt,
 /* same, to a file path (convenience for bindings that cannot pass a FILE*) */
 int mga_map_files_to_path(gfa_t *g, int n_fn, const char **fn, const mg_idxopt_t *ipt, const mg_mapopt_t *opt0, int n_threads, const char *out_path);
 
+/* a read set kept resident in HBM across calls (repeated passes over one batch, as the benchmark does) */
+typedef struct mga_reads_s mga_reads_t;
+mga_reads_t *mga_reads_load(const char *fn, int64_t max_reads);   /* FASTA/FASTQ(.gz) -> host copy + HBM copy; NULL on error */
+void mga_reads_free(mga_reads_t *rd);
+int mga_reads_count(const mga_reads_t *rd);
+int64_t mga_reads_bases(const mga_reads_t *rd);
+/* mg_map_batch() + mg_write_gaf() for a resident read set; *gaf is malloc()'ed (release with mga_free) */
+int mga_map_reads(const mg_idx_t *gi, const mga_reads_t *rd, const mg_mapopt_t *opt, int n_threads, char **gaf, int64_t *gaf_len);
+int mga_map_batch_resident(const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs,
+						   const mg_mapopt_t *opt, int n_threads, const char *d_seq, const int64_t *q_off);
+
 /* counters of the last mg_map_batch() calls on this index (for the bench's algorithmic-bytes figure) */
 typedef struct {
 	int64_t n_reads, n_bases, n_mz, n_probe, n_hit, n_anchor_chained;

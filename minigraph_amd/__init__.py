@@ -60,6 +60,14 @@ class ggopt_t(C.Structure):
 
 MG_M_CIGAR = 0x4000000
 
+KERNELS = ["k_sketch", "k_seed_count", "k_seed_fill", "k_lchain", "k_wfa[tier0]", "k_wfa[tier1]", "k_wfa[tier2]", "k_scan"]
+
+
+class stats_t(C.Structure):  # mga_stats_t
+    _fields_ = [(n, C.c_int64) for n in ("n_reads", "n_bases", "n_mz", "n_probe", "n_hit", "n_anchor_chained", "n_wfa",
+                                         "wfa_t_bases", "wfa_q_bases", "wfa_cells", "gaf_bytes")] + \
+               [(n, C.c_double) for n in ("t_sketch", "t_seed", "t_lchain", "t_host_chain", "t_wfa", "t_host_post")]
+
 
 def load():
     global _lib
@@ -86,6 +94,16 @@ def load():
     L.mga_lchain_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.POINTER(lchain_par_t), pp, pp, pp, pp]
     L.mga_map_files_to_path.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(idxopt_t),
                                         C.POINTER(mapopt_t), C.c_int, C.c_char_p]
+    L.mga_reads_load.argtypes = [C.c_char_p, C.c_int64]
+    L.mga_reads_load.restype = C.c_void_p
+    L.mga_reads_free.argtypes = [C.c_void_p]
+    L.mga_reads_count.argtypes = [C.c_void_p]
+    L.mga_reads_bases.argtypes = [C.c_void_p]
+    L.mga_reads_bases.restype = C.c_int64
+    L.mga_map_reads.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(mapopt_t), C.c_int, pp, C.POINTER(C.c_int64)]
+    L.mga_get_stats.argtypes = [C.c_void_p, C.POINTER(stats_t), C.c_int]
+    L.mga_prof_enable.argtypes = [C.c_int]
+    L.mga_prof_get.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     _lib = L
     return L
 
@@ -224,3 +242,46 @@ def map_files(graph_path, read_paths, out_path, preset="lr", cigar=True, n_threa
     L.gfa_destroy(g)
     if rc != 0:
         raise RuntimeError("mapping failed: %s" % L.mga_last_error().decode())
+
+
+class Reads:
+    """mga_reads_load(): a read set resident in host memory and HBM"""
+
+    def __init__(self, path, max_reads=0):
+        L = load()
+        self.h = L.mga_reads_load(path.encode(), max_reads)
+        if not self.h:
+            raise RuntimeError("mga_reads_load failed: %s" % L.mga_last_error().decode())
+        self.n, self.bases = L.mga_reads_count(self.h), L.mga_reads_bases(self.h)
+
+    def close(self):
+        if self.h:
+            load().mga_reads_free(self.h)
+        self.h = None
+
+
+def map_reads(graph, reads, n_threads=8):
+    """one pass of the hot path over a resident read set -> GAF bytes"""
+    L = load()
+    buf, n = C.c_void_p(), C.c_int64(0)
+    _check(L.mga_map_reads(graph.gi, reads.h, C.byref(graph.mo), n_threads, C.byref(buf), C.byref(n)), "mga_map_reads")
+    out = C.string_at(buf, n.value)
+    L.mga_free(buf)
+    return out
+
+
+def get_stats(graph, reset=False):
+    st = stats_t()
+    load().mga_get_stats(graph.gi, C.byref(st), 1 if reset else 0)
+    return {k: getattr(st, k) for k, _ in st._fields_}
+
+
+def prof_enable(on=True):
+    load().mga_prof_enable(1 if on else 0)
+
+
+def prof_get(reset=False):
+    ms = np.zeros(len(KERNELS), dtype=np.float64)
+    cnt = np.zeros(len(KERNELS), dtype=np.int64)
+    load().mga_prof_get(ms.ctypes.data, cnt.ctypes.data, 1 if reset else 0)
+    return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(KERNELS)}

@@ -160,7 +160,60 @@ __global__ void __launch_bounds__(1024) k_scan_i32_i64(const int32_t *__restrict
 
 extern "C" int mga_dev_scan_i32_to_i64(const int32_t *d_cnt, int64_t n, int64_t *d_off)
 {
+	mga_prof_begin(MGA_K_SCAN);
 	hipLaunchKernelGGL(k_scan_i32_i64, dim3(1), dim3(1024), 0, 0, d_cnt, n, d_off);
+	mga_prof_end(MGA_K_SCAN);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;
+}
+
+// ---- per-kernel HIP-event timing (stream 0, where every kernel of this library is launched) ----
+#define PROF_MAX_PENDING 4096
+static struct {
+	int enabled;
+	hipEvent_t ev[PROF_MAX_PENDING][2];
+	int kid[PROF_MAX_PENDING];
+	int n_pending, n_created;
+	double ms[MGA_K_N];
+	int64_t launches[MGA_K_N];
+} g_prof;
+
+extern "C" void mga_prof_enable(int on) { g_prof.enabled = on; }
+
+extern "C" void mga_prof_collect(void)
+{
+	for (int i = 0; i < g_prof.n_pending; ++i) {
+		float ms = 0.f;
+		if (hipEventSynchronize(g_prof.ev[i][1]) == hipSuccess && hipEventElapsedTime(&ms, g_prof.ev[i][0], g_prof.ev[i][1]) == hipSuccess)
+			g_prof.ms[g_prof.kid[i]] += ms, ++g_prof.launches[g_prof.kid[i]];
+	}
+	g_prof.n_pending = 0;
+}
+
+extern "C" void mga_prof_begin(int kid)
+{
+	if (!g_prof.enabled) return;
+	if (g_prof.n_pending == PROF_MAX_PENDING) mga_prof_collect();
+	int i = g_prof.n_pending;
+	if (i >= g_prof.n_created) {
+		if (hipEventCreate(&g_prof.ev[i][0]) != hipSuccess || hipEventCreate(&g_prof.ev[i][1]) != hipSuccess) { g_prof.enabled = 0; return; }
+		g_prof.n_created = i + 1;
+	}
+	g_prof.kid[i] = kid;
+	(void)hipEventRecord(g_prof.ev[i][0], 0);
+}
+
+extern "C" void mga_prof_end(int kid)
+{
+	if (!g_prof.enabled) return;
+	(void)kid;
+	(void)hipEventRecord(g_prof.ev[g_prof.n_pending][1], 0);
+	++g_prof.n_pending;
+}
+
+extern "C" void mga_prof_get(double *ms, int64_t *launches, int reset)
+{
+	mga_prof_collect();
+	for (int k = 0; k < MGA_K_N; ++k) { ms[k] = g_prof.ms[k]; launches[k] = g_prof.launches[k]; }
+	if (reset) { memset(g_prof.ms, 0, sizeof g_prof.ms); memset(g_prof.launches, 0, sizeof g_prof.launches); }
 }

@@ -173,7 +173,9 @@ extern "C" int mga_dev_sketch(int n, const char *d_seq, const int64_t *d_off, co
 {
 	if (n <= 0) return 0;
 	if (w < 1 || w > 255 || k < 1 || k > 28) { mga_set_error("sketch: need 0<w<256 and 0<k<=28 (sketch.c:62), got w=%d k=%d", w, k); return -1; }
+	mga_prof_begin(MGA_K_SKETCH);
 	hipLaunchKernelGGL(k_sketch, dim3(n), dim3(64), 0, 0, n, d_seq, d_off, d_rid, w, k, d_cnt, d_mz_off, d_mz);
+	mga_prof_end(MGA_K_SKETCH);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;
 }

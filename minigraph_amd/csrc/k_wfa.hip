@@ -319,8 +319,10 @@ extern "C" int mga_dev_wfa(int n, const int32_t *d_list, const mga_wfa_prob_t *d
 	if (mga_dbuf_reserve(&g_wfa_ws[tier], (size_t)cfg.ws_stride * g_tier_waves[tier]) < 0) return -1;
 	if (mga_dbuf_reserve(&g_wfa_cnt, 256) < 0) return -1;
 	MGA_HIP_CHECK(hipMemsetAsync(g_wfa_cnt.p, 0, 4, 0));
+	mga_prof_begin(MGA_K_WFA0 + tier);
 	hipLaunchKernelGGL(k_wfa, dim3(waves), dim3(64), 0, 0, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap,
 					   d_pool_used, (char*)g_wfa_ws[tier].p, (int*)g_wfa_cnt.p, cfg);
+	mga_prof_end(MGA_K_WFA0 + tier);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;
 }

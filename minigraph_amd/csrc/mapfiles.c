@@ -55,6 +55,109 @@ static int read_record(rd_t *r, int *last, str_t *name, str_t *seq)
 	return 0;
 }
 
+/* ---- a read set kept resident: host copy + HBM copy (bench.py, repeated passes over one batch) ---- */
+struct mga_reads_s {
+	int n;
+	int *qlens;
+	char **seqs, **names;
+	int64_t *q_off, n_bases;
+	char *d_seq;
+};
+
+mga_reads_t *mga_reads_load(const char *fn, int64_t max_reads)
+{
+	rd_t r;
+	int last = 0, m = 0;
+	str_t name = {0, 0, 0}, seq = {0, 0, 0};
+	mga_reads_t *rd;
+	char *h;
+	int i;
+	if (mga_dev_init() < 0) return 0;
+	memset(&r, 0, sizeof r);
+	r.fp = gzopen(fn, "r");
+	if (r.fp == 0) { mga_set_error("cannot open '%s'", fn); return 0; }
+	r.buf = (char*)malloc(1 << 20);
+	rd = MGA_CALLOC(mga_reads_t, 1);
+	while ((max_reads <= 0 || rd->n < max_reads) && read_record(&r, &last, &name, &seq) == 0) {
+		size_t k;
+		if (rd->n == m) { m = m ? m << 1 : 256; rd->qlens = MGA_REALLOC(int, rd->qlens, m); rd->seqs = MGA_REALLOC(char*, rd->seqs, m); rd->names = MGA_REALLOC(char*, rd->names, m); }
+		for (k = 0; k < seq.l; ++k) {
+			if (seq.s[k] == 'u' || seq.s[k] == 'U') --seq.s[k];
+			if (seq.s[k] >= 'a' && seq.s[k] <= 'z') seq.s[k] -= 32;
+		}
+		rd->seqs[rd->n] = (char*)malloc(seq.l + 1); memcpy(rd->seqs[rd->n], seq.s, seq.l + 1);
+		rd->names[rd->n] = (char*)malloc(name.l + 1); memcpy(rd->names[rd->n], name.s, name.l + 1);
+		rd->qlens[rd->n++] = (int)seq.l;
+		rd->n_bases += (int64_t)seq.l;
+	}
+	free(name.s); free(seq.s); free(r.buf); gzclose(r.fp);
+	rd->q_off = MGA_MALLOC(int64_t, rd->n + 1);
+	h = (char*)calloc((size_t)rd->n_bases + 64, 1);
+	for (i = 0, rd->n_bases = 0; i < rd->n; ++i) { rd->q_off[i] = rd->n_bases; memcpy(h + rd->n_bases, rd->seqs[i], (size_t)rd->qlens[i]); rd->n_bases += rd->qlens[i]; }
+	rd->q_off[rd->n] = rd->n_bases;
+	rd->d_seq = (char*)mga_dmalloc((size_t)rd->n_bases + 64);
+	if (rd->d_seq == 0 || mga_h2d(rd->d_seq, h, (size_t)rd->n_bases + 64) < 0) { free(h); mga_reads_free(rd); return 0; }
+	free(h);
+	return rd;
+}
+
+void mga_reads_free(mga_reads_t *rd)
+{
+	int i;
+	if (rd == 0) return;
+	for (i = 0; i < rd->n; ++i) { free(rd->seqs[i]); free(rd->names[i]); }
+	free(rd->seqs); free(rd->names); free(rd->qlens); free(rd->q_off);
+	mga_dfree(rd->d_seq);
+	free(rd);
+}
+
+int mga_reads_count(const mga_reads_t *rd) { return rd->n; }
+int64_t mga_reads_bases(const mga_reads_t *rd) { return rd->n_bases; }
+
+typedef struct { const mg_idx_t *gi; const mga_reads_t *rd; mg_gchains_t **gcs; uint64_t flag; int n_threads; kstring_t *part; } gafw_t;
+
+static void gaf_worker(void *data, int64_t t, int tid)
+{
+	gafw_t *w = (gafw_t*)data;
+	const int n = w->rd->n;
+	int64_t b = (int64_t)n * t / w->n_threads, e = (int64_t)n * (t + 1) / w->n_threads, i;
+	kstring_t one = {0, 0, 0}, *out = &w->part[t];
+	(void)tid;
+	for (i = b; i < e; ++i) {
+		int32_t ql = w->rd->qlens[i];
+		mg_write_gaf(&one, w->gi->g, w->gcs[i], 1, &ql, w->rd->names[i], w->flag, 0);
+		if (one.l) {
+			if (out->l + one.l + 1 > out->m) { size_t m = ((size_t)out->l + one.l + 1) * 3 / 2; out->m = (unsigned)m; out->s = (char*)realloc(out->s, out->m); }
+			memcpy(out->s + out->l, one.s, one.l); out->l += one.l;
+		}
+	}
+	free(one.s);
+}
+
+/* map a resident read set and format its GAF (input order) into one malloc'ed buffer */
+int mga_map_reads(const mg_idx_t *gi, const mga_reads_t *rd, const mg_mapopt_t *opt, int n_threads, char **gaf, int64_t *gaf_len)
+{
+	mg_gchains_t **gcs = MGA_CALLOC(mg_gchains_t*, rd->n > 0 ? rd->n : 1);
+	gafw_t w;
+	int t, i, rc;
+	int64_t tot = 0;
+	*gaf = 0, *gaf_len = 0;
+	if (n_threads < 1) n_threads = 1;
+	rc = mga_map_batch_resident(gi, rd->n, rd->qlens, (const char**)rd->seqs, (const char**)rd->names, gcs, opt, n_threads, rd->d_seq, rd->q_off);
+	if (rc < 0) { free(gcs); return rc; }
+	w.gi = gi, w.rd = rd, w.gcs = gcs, w.flag = opt->flag, w.n_threads = n_threads;
+	w.part = MGA_CALLOC(kstring_t, n_threads);
+	mga_parallel_for(n_threads, n_threads, gaf_worker, &w);
+	for (t = 0; t < n_threads; ++t) tot += w.part[t].l;
+	*gaf = (char*)malloc((size_t)tot + 1);
+	for (t = 0, tot = 0; t < n_threads; ++t) { memcpy(*gaf + tot, w.part[t].s, w.part[t].l); tot += w.part[t].l; free(w.part[t].s); }
+	(*gaf)[tot] = 0, *gaf_len = tot;
+	gi->B->st.gaf_bytes += tot;
+	for (i = 0; i < rd->n; ++i) mg_gchain_free(gcs[i]);
+	free(gcs); free(w.part);
+	return 0;
+}
+
 int mg_map_files_fp(gfa_t *g, int n_fn, const char **fn, const mg_idxopt_t *ipt, const mg_mapopt_t *opt0, int n_threads, FILE *out)
 {
 	mg_mapopt_t opt = *opt0;

@@ -255,13 +255,13 @@ static struct { /* grow-only device buffers, reused across batches (one GPU per 
 #define CK(x) do { if ((x) < 0) { rc = -1; goto done; } } while (0)
 
 static int map_chunk(const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs_out,
-					 const mg_mapopt_t *opt, int n_threads)
+					 const mg_mapopt_t *opt, int n_threads, const char *d_seq_res, const int64_t *q_off_res)
 {
 	struct mg_idx_bucket_s *B = gi->B;
 	mga_stats_t *st = &B->st;
 	int rc = 0, i, tier;
 	int64_t tot = 0, n_mz, n_a, n_mini, n_prob = 0, n_tb = 0, pool_cap;
-	int64_t *q_off = MGA_MALLOC(int64_t, n + 1), *h_mzoff = 0, *h_aoff = 0, *h_minioff = 0;
+	int64_t *q_off = MGA_MALLOC(int64_t, n + 2), *h_mzoff = 0, *h_aoff = 0, *h_minioff = 0;
 	int32_t *h_nmz = 0, *h_rep = 0, *h_mini = 0, *h_nu = 0, *h_nb = 0, *todo = 0;
 	uint64_t *h_u = 0;
 	mg128_t *h_b = 0;
@@ -277,25 +277,35 @@ static int map_chunk(const mg_idx_t *gi, int n, const int *qlens, const char **s
 	if (opt->flag & (MG_M_SR | MG_M_HEAP_SORT | MG_M_SPLICE | MG_M_NO_DIAG)) {
 		mga_set_error("mg_map_batch: short-read / splice / -D modes are outside the accelerated long-read path"); rc = -1; goto done;
 	}
-	/* ---- reads -> HBM, back to back, 64 readable bytes of padding at the end (8-byte compares in k_wfa) ---- */
-	tot = 0;
-	for (i = 0; i < n; ++i) { q_off[i] = tot; tot += qlens[i]; }
-	q_off[n] = tot;
-	h_seq = (char*)malloc((size_t)tot + 64);
-	for (i = 0; i < n; ++i) memcpy(h_seq + q_off[i], seqs[i], (size_t)qlens[i]);
-	memset(h_seq + tot, 0, 64);
+	/* ---- reads -> HBM, back to back, 64 readable bytes of padding at the end (8-byte compares in k_wfa);
+	 *      skipped when the caller keeps the batch resident (d_seq_res + absolute offsets q_off_res) ---- */
+	const char *d_seq;
 	t0 = mga_wtime();
-	CK(mga_dbuf_reserve(&D.seq, (size_t)tot + 64)); CK(mga_dbuf_reserve(&D.qoff, (size_t)(n + 1) * 8));
-	CK(mga_h2d(D.seq.p, h_seq, (size_t)tot + 64)); CK(mga_h2d(D.qoff.p, q_off, (size_t)(n + 1) * 8));
+	CK(mga_dbuf_reserve(&D.qoff, (size_t)(n + 1) * 8));
+	if (d_seq_res) {
+		memcpy(q_off, q_off_res, (size_t)(n + 1) * 8);
+		tot = q_off[n] - q_off[0];
+		d_seq = d_seq_res;
+	} else {
+		for (i = 0; i < n; ++i) { q_off[i] = tot; tot += qlens[i]; }
+		q_off[n] = tot;
+		h_seq = (char*)malloc((size_t)tot + 64);
+		for (i = 0; i < n; ++i) memcpy(h_seq + q_off[i], seqs[i], (size_t)qlens[i]);
+		memset(h_seq + tot, 0, 64);
+		CK(mga_dbuf_reserve(&D.seq, (size_t)tot + 64));
+		CK(mga_h2d(D.seq.p, h_seq, (size_t)tot + 64));
+		d_seq = (const char*)D.seq.p;
+	}
+	CK(mga_h2d(D.qoff.p, q_off, (size_t)(n + 1) * 8));
 	/* ---- sketch ---- */
 	CK(mga_dbuf_reserve(&D.cnt, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&D.mzoff, (size_t)(n + 1) * 8));
-	CK(mga_dev_sketch(n, (const char*)D.seq.p, (const int64_t*)D.qoff.p, 0, gi->w, gi->k, (int32_t*)D.cnt.p, 0, 0));
+	CK(mga_dev_sketch(n, d_seq, (const int64_t*)D.qoff.p, 0, gi->w, gi->k, (int32_t*)D.cnt.p, 0, 0));
 	CK(mga_dev_scan_i32_to_i64((const int32_t*)D.cnt.p, n, (int64_t*)D.mzoff.p));
 	h_mzoff = MGA_MALLOC(int64_t, n + 1);
 	CK(mga_d2h(h_mzoff, D.mzoff.p, (size_t)(n + 1) * 8));
 	n_mz = h_mzoff[n];
 	CK(mga_dbuf_reserve(&D.mz, (size_t)n_mz * 16 + 16));
-	CK(mga_dev_sketch(n, (const char*)D.seq.p, (const int64_t*)D.qoff.p, 0, gi->w, gi->k, 0, (const int64_t*)D.mzoff.p, (mg128_t*)D.mz.p));
+	CK(mga_dev_sketch(n, d_seq, (const int64_t*)D.qoff.p, 0, gi->w, gi->k, 0, (const int64_t*)D.mzoff.p, (mg128_t*)D.mz.p));
 	CK(mga_dsync());
 	t1 = mga_wtime(); st->t_sketch += t1 - t0; t0 = t1;
 	/* ---- seeds ---- */
@@ -355,7 +365,7 @@ static int map_chunk(const mg_idx_t *gi, int n, const int *qlens, const char **s
 			int64_t j, m2 = 0;
 			int pool_full = 0;
 			if (todo) { CK(mga_dbuf_reserve(&D.list, (size_t)m * 4)); CK(mga_h2d(D.list.p, todo, (size_t)m * 4)); }
-			CK(mga_dev_wfa((int)m, todo ? (const int32_t*)D.list.p : 0, (const mga_wfa_prob_t*)D.prob.p, (const char*)D.tseq.p, (const char*)D.seq.p,
+			CK(mga_dev_wfa((int)m, todo ? (const int32_t*)D.list.p : 0, (const mga_wfa_prob_t*)D.prob.p, (const char*)D.tseq.p, d_seq,
 						   (mga_wfa_res_t*)D.res.p, (uint32_t*)D.pool.p, pool_cap, (unsigned long long*)D.used.p, tier));
 			CK(mga_dsync());
 			CK(mga_d2h(h_res, D.res.p, (size_t)n_prob * sizeof(mga_wfa_res_t)));
@@ -405,7 +415,29 @@ int mg_map_batch(const mg_idx_t *gi, int n, const int *qlens, const char **seqs,
 		int en = st;
 		int64_t bases = 0;
 		while (en < n && en - st < 65536 && bases < 256000000) bases += qlens[en++];
-		if (map_chunk(gi, en - st, qlens + st, seqs + st, qnames ? qnames + st : 0, gcs + st, opt, n_threads) < 0) {
+		if (map_chunk(gi, en - st, qlens + st, seqs + st, qnames ? qnames + st : 0, gcs + st, opt, n_threads, 0, 0) < 0) {
+			for (i = 0; i < n; ++i) { mg_gchain_free(gcs[i]); gcs[i] = 0; }
+			return -1;
+		}
+		st = en;
+	}
+	return 0;
+}
+
+/* same as mg_map_batch() for reads that already sit in HBM: d_seq holds the reads back to back (+64 readable bytes),
+ * q_off[n+1] are their absolute offsets.  This is the region bench.py times ("inputs resident in HBM"). */
+int mga_map_batch_resident(const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs,
+						   const mg_mapopt_t *opt, int n_threads, const char *d_seq, const int64_t *q_off)
+{
+	int i, st = 0;
+	if (n <= 0) return 0;
+	if (mga_dev_init() < 0) return -1;
+	for (i = 0; i < n; ++i) gcs[i] = 0;
+	while (st < n) {
+		int en = st;
+		int64_t bases = 0;
+		while (en < n && en - st < 65536 && bases < 256000000) bases += qlens[en++];
+		if (map_chunk(gi, en - st, qlens + st, seqs + st, qnames ? qnames + st : 0, gcs + st, opt, n_threads, d_seq, q_off + st) < 0) {
 			for (i = 0; i < n; ++i) { mg_gchain_free(gcs[i]); gcs[i] = 0; }
 			return -1;
 		}

@@ -26,6 +26,14 @@ void *mga_hmalloc_pinned(size_t bytes);        /* pinned host memory for fast PC
 void mga_hfree_pinned(void *p);
 double mga_wtime(void);
 
+/* per-kernel HIP-event timing on stream 0 (bench.py reads it through mga_prof_get) */
+enum { MGA_K_SKETCH = 0, MGA_K_SEED_COUNT, MGA_K_SEED_FILL, MGA_K_LCHAIN, MGA_K_WFA0, MGA_K_WFA1, MGA_K_WFA2, MGA_K_SCAN, MGA_K_N };
+void mga_prof_enable(int on);
+void mga_prof_begin(int kid);
+void mga_prof_end(int kid);
+void mga_prof_collect(void);
+void mga_prof_get(double *ms, int64_t *launches, int reset); /* arrays of MGA_K_N */
+
 /* grow-only device buffer */
 typedef struct { void *p; size_t cap; } mga_dbuf_t;
 int  mga_dbuf_reserve(mga_dbuf_t *b, size_t bytes); /* contents are NOT preserved on growth */

@@ -67,14 +67,14 @@ int main(int argc, char *argv[])
 	int64_t G = 2000000, n_reads = 1000, read_len = 10000;
 	int n_chr = 1, H = 3, c, h;
 	double err = 0.10;
-	uint64_t seed = 11;
+	uint64_t seed = 11, read_seed = 0;
 	const char *prefix = 0;
 	char fn[4096];
 	FILE *fgfa, *flin, *frd;
 	str_t *hap; /* hap[h*n_chr + c] */
 	int64_t seg_id = 0, tot_graph = 0, n_bub = 0;
 
-	while ((c = getopt(argc, argv, "p:G:c:H:n:l:e:s:")) >= 0) {
+	while ((c = getopt(argc, argv, "p:G:c:H:n:l:e:s:S:")) >= 0) {
 		if (c == 'p') prefix = optarg;
 		else if (c == 'G') G = atoll(optarg);
 		else if (c == 'c') n_chr = atoi(optarg);
@@ -83,9 +83,10 @@ int main(int argc, char *argv[])
 		else if (c == 'l') read_len = atoll(optarg);
 		else if (c == 'e') err = atof(optarg);
 		else if (c == 's') seed = strtoull(optarg, 0, 10);
+		else if (c == 'S') read_seed = strtoull(optarg, 0, 10);
 	}
 	if (prefix == 0 || H < 1 || n_chr < 1) {
-		fprintf(stderr, "Usage: mgsim -p PREFIX [-G bp=2000000] [-c n_chr=1] [-H n_hap=3] [-n n_reads=1000] [-l read_len=10000] [-e err=0.1] [-s seed=11]\n");
+		fprintf(stderr, "Usage: mgsim -p PREFIX [-G bp=2000000] [-c n_chr=1] [-H n_hap=3] [-n n_reads=1000] [-l read_len=10000] [-e err=0.1] [-s seed=11] [-S read_seed]\n");
 		return 1;
 	}
 	rng_seed(seed);
@@ -154,7 +155,8 @@ int main(int argc, char *argv[])
 	}
 	fclose(fgfa); fclose(flin);
 
-	/* reads */
+	/* reads (optionally from their own stream, so that ranks share one graph but draw different reads) */
+	if (read_seed) rng_seed(read_seed);
 	{
 		int64_t i, tot_hap = 0, *cum = (int64_t*)calloc((size_t)H * n_chr + 1, sizeof(int64_t));
 		char *rd = (char*)malloc(read_len * 2 + 64), *src = (char*)malloc(read_len * 2 + 64);
