@@ -89,6 +89,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import minigraph_amd as mga
+    from minigraph_amd.dist import gather_bytes
     L = mga.load()
     if L.mga_device_count() <= 0:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
@@ -111,15 +112,8 @@ def main():
 
     def step():
         gaf = mga.map_reads(G, R, n_threads=threads)
-        if dist is not None:  # RCCL: gather the GAF bytes of every rank to rank 0
-            n = torch.tensor([len(gaf)], dtype=torch.int64, device="cuda")
-            sizes = [torch.zeros_like(n) for _ in range(world)]
-            dist.all_gather(sizes, n)
-            mx = int(max(int(s.item()) for s in sizes))
-            buf = torch.zeros(mx, dtype=torch.uint8, device="cuda")
-            buf[:len(gaf)] = torch.frombuffer(bytearray(gaf), dtype=torch.uint8).cuda()
-            out = [torch.zeros(mx, dtype=torch.uint8, device="cuda") for _ in range(world)] if rank == 0 else None
-            dist.gather(buf, out, dst=0)
+        if dist is not None:  # RCCL over xGMI: gather the GAF bytes of every rank to rank 0
+            gather_bytes(gaf, dst=0, device="cuda")
         return gaf
 
     def sync():

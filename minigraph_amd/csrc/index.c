@@ -40,6 +40,35 @@ static int cmp_u64(const void *a, const void *b)
 	return x < y ? -1 : x > y;
 }
 
+/* the host-visible part of the index handle: parameters + both orientations of every segment
+ * (gfa_edseq_init, gfa-ed.c:24-42).  No device work; mg_index() completes it with the minimizer table. */
+mg_idx_t *mga_idx_hostpart(gfa_t *g, const mg_idxopt_t *io)
+{
+	mg_idx_t *gi = MGA_CALLOC(mg_idx_t, 1);
+	gfa_edseq_t *es = MGA_MALLOC(gfa_edseq_t, (size_t)g->n_seg * 2 + 1);
+	uint32_t s;
+	int k = io->k, w = io->w, b = io->bucket_bits;
+	mga_tables_init();
+	if (k * 2 < b) b = k * 2; /* mg_idx_init, index.c:19-29 */
+	if (w < 1) w = 1;
+	for (s = 0; s < g->n_seg; ++s) { /* uppercase in place, index.c:215-220 */
+		gfa_seg_t *p = &g->seg[s];
+		int32_t q;
+		if (p->seq) for (q = 0; q < p->len; ++q) if (p->seq[q] >= 'a' && p->seq[q] <= 'z') p->seq[q] -= 32;
+	}
+	for (s = 0; s < g->n_seg; ++s) {
+		const gfa_seg_t *p = &g->seg[s];
+		char *t = (char*)malloc((size_t)p->len + 1);
+		int32_t q;
+		for (q = 0; q < p->len; ++q) t[p->len - q - 1] = (char)mga_comp_table[(uint8_t)p->seq[q]];
+		t[p->len] = 0;
+		es[s<<1].seq = p->seq, es[s<<1|1].seq = t;
+		es[s<<1].len = es[s<<1|1].len = p->len;
+	}
+	gi->g = g, gi->w = w, gi->k = k, gi->b = b, gi->n_seg = (int32_t)g->n_seg, gi->es = es, gi->B = 0;
+	return gi;
+}
+
 mg_idx_t *mg_index(gfa_t *g, const mg_idxopt_t *io, int n_threads, mg_mapopt_t *mo)
 {
 	mg_idx_t *gi;
@@ -137,21 +166,8 @@ mg_idx_t *mg_index(gfa_t *g, const mg_idxopt_t *io, int n_threads, mg_mapopt_t *
 	}
 	free(tab); free(pos); free(seg_len);
 
-	gi = MGA_CALLOC(mg_idx_t, 1);
-	gi->g = g, gi->w = w, gi->k = k, gi->b = b, gi->n_seg = (int32_t)g->n_seg, gi->B = B;
-	{ /* gfa_edseq_init, gfa-ed.c:24-42: both orientations of every segment */
-		gfa_edseq_t *es = MGA_MALLOC(gfa_edseq_t, (size_t)g->n_seg * 2);
-		for (s = 0; s < g->n_seg; ++s) {
-			const gfa_seg_t *p = &g->seg[s];
-			char *t = (char*)malloc((size_t)p->len + 1);
-			int32_t q;
-			for (q = 0; q < p->len; ++q) t[p->len - q - 1] = (char)mga_comp_table[(uint8_t)p->seq[q]];
-			t[p->len] = 0;
-			es[s<<1].seq = p->seq, es[s<<1|1].seq = t;
-			es[s<<1].len = es[s<<1|1].len = p->len;
-		}
-		gi->es = es;
-	}
+	gi = mga_idx_hostpart(g, io);
+	gi->B = B;
 	if (mg_verbose >= 3)
 		fprintf(stderr, "[M::%s::%.3f] indexed the graph: %ld minimizers, %ld distinct, table 2^%d slots\n", __func__, mga_wtime() - t0, (long)n_mz, (long)n_keys, bits);
 	(void)n_threads; (void)n_single;

@@ -64,6 +64,8 @@ struct mg_idx_bucket_s {
 	mga_stats_t st;
 };
 
+mg_idx_t *mga_idx_hostpart(gfa_t *g, const mg_idxopt_t *io);
+
 /* ---- simple parallel-for over [0,n) on n_threads pthreads, dynamic chunks (par.c) ---- */
 typedef void (*mga_for_f)(void *data, int64_t i, int tid);
 void mga_parallel_for(int n_threads, int64_t n, mga_for_f f, void *data);
