@@ -319,10 +319,31 @@ extern "C" int mga_dev_wfa(int n, const int32_t *d_list, const mga_wfa_prob_t *d
 	if (mga_dbuf_reserve(&g_wfa_ws[tier], (size_t)cfg.ws_stride * g_tier_waves[tier]) < 0) return -1;
 	if (mga_dbuf_reserve(&g_wfa_cnt, 256) < 0) return -1;
 	MGA_HIP_CHECK(hipMemsetAsync(g_wfa_cnt.p, 0, 4, 0));
-	mga_prof_begin(MGA_K_WFA0 + tier);
+	mga_prof_begin(MGA_K_WFA0 + 5 + tier);
 	hipLaunchKernelGGL(k_wfa, dim3(waves), dim3(64), 0, 0, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap,
 					   d_pool_used, (char*)g_wfa_ws[tier].p, (int*)g_wfa_cnt.p, cfg);
-	mga_prof_end(MGA_K_WFA0 + tier);
+	mga_prof_end(MGA_K_WFA0 + 5 + tier);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;
+}
+
+extern "C" int mga_dev_wfa_tier(int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+								mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier)
+{
+	if (tier < 4) return mga_dev_wfa_reg(n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier);
+	if (tier == 4) return mga_dev_wfa_lds(n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, 2);
+	return mga_dev_wfa(n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier - 5);
+}
+
+// the band of a 10%-error gap is about as wide as the gap is long ([measured] on the benchmark workload:
+// mean length 76 -> mean score 40 -> band 81), so start where a band of ~1.3x the length fits
+extern "C" int mga_wfa_first_tier(int32_t tl, int32_t ql)
+{
+	const int32_t m = tl > ql ? tl : ql;
+	if (m <= 56) return 0;
+	if (m <= 112) return 1;
+	if (m <= 224) return 2;
+	if (m <= 450) return 3;
+	if (m <= 1024) return 4;
+	return 5;
 }

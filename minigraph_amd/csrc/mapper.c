@@ -259,7 +259,7 @@ static int map_chunk(const mg_idx_t *gi, int n, const int *qlens, const char **s
 {
 	struct mg_idx_bucket_s *B = gi->B;
 	mga_stats_t *st = &B->st;
-	int rc = 0, i, tier;
+	int rc = 0, i;
 	int64_t tot = 0, n_mz, n_a, n_mini, n_prob = 0, n_tb = 0, pool_cap;
 	int64_t *q_off = MGA_MALLOC(int64_t, n + 2), *h_mzoff = 0, *h_aoff = 0, *h_minioff = 0;
 	int32_t *h_nmz = 0, *h_rep = 0, *h_mini = 0, *h_nu = 0, *h_nb = 0, *todo = 0;
@@ -357,28 +357,45 @@ static int map_chunk(const mg_idx_t *gi, int n, const int *qlens, const char **s
 		CK(mga_dbuf_reserve(&D.tseq, (size_t)n_tb + 64)); CK(mga_dbuf_reserve(&D.prob, (size_t)n_prob * sizeof(mga_wfa_prob_t))); CK(mga_dbuf_reserve(&D.res, (size_t)n_prob * sizeof(mga_wfa_res_t)));
 		CK(mga_dbuf_reserve(&D.used, 64));
 		CK(mga_h2d(D.tseq.p, h_tseq, (size_t)n_tb + 64)); CK(mga_h2d(D.prob.p, h_prob, (size_t)n_prob * sizeof(mga_wfa_prob_t)));
-		pool_cap = (b->tp_t_base[b->n_threads] + n_prob * 8) / 2 + 4096;
+		pool_cap = (b->tp_t_base[b->n_threads] + n_prob * 8) / 2 + 4096 + 40000LL * 512; /* + abandoned block tails (<= 512 ops) of every resident wave */
 		for (i = 0; i < b->n_threads; ++i) pool_cap += b->tp[i].wfa_q_bases / 2;
 		CK(mga_dbuf_reserve(&D.pool, (size_t)pool_cap * 4)); CK(mga_dmemset(D.used.p, 0, 8));
-		tier = 0, m = n_prob, todo = 0;
-		for (;;) {
-			int64_t j, m2 = 0;
-			int pool_full = 0;
-			if (todo) { CK(mga_dbuf_reserve(&D.list, (size_t)m * 4)); CK(mga_h2d(D.list.p, todo, (size_t)m * 4)); }
-			CK(mga_dev_wfa((int)m, todo ? (const int32_t*)D.list.p : 0, (const mga_wfa_prob_t*)D.prob.p, (const char*)D.tseq.p, d_seq,
-						   (mga_wfa_res_t*)D.res.p, (uint32_t*)D.pool.p, pool_cap, (unsigned long long*)D.used.p, tier));
-			CK(mga_dsync());
-			CK(mga_d2h(h_res, D.res.p, (size_t)n_prob * sizeof(mga_wfa_res_t)));
-			if (todo == 0) { todo = MGA_MALLOC(int32_t, n_prob); for (j = 0; j < n_prob; ++j) todo[j] = (int32_t)j; }
-			for (j = 0; j < m; ++j) {
-				int32_t s = h_res[todo[j]].status;
-				if (s == MGA_WFA_RETRY_TIER) todo[m2++] = todo[j];
-				else if (s == MGA_WFA_POOL_FULL) pool_full = 1, todo[m2++] = todo[j];
+		{ /* every problem starts in the cheapest tier its length suggests; all first-pass launches are queued back to back,
+		   * then only the (few) problems that outgrew their tier are re-run one tier up */
+			int8_t *tier_of = (int8_t*)malloc((size_t)n_prob);
+			int64_t cnt[MGA_WFA_N_TIER + 1], j, n_left;
+			int pass = 0;
+			todo = MGA_MALLOC(int32_t, n_prob);
+			for (j = 0; j < n_prob; ++j) tier_of[j] = (int8_t)mga_wfa_first_tier(h_prob[j].tl, h_prob[j].ql);
+			n_left = n_prob;
+			CK(mga_dbuf_reserve(&D.list, (size_t)n_prob * 4));
+			while (n_left > 0) {
+				int64_t off = 0, k;
+				memset(cnt, 0, sizeof cnt);
+				for (j = 0; j < n_prob; ++j) if (tier_of[j] >= 0) ++cnt[tier_of[j] + 1];
+				for (k = 0; k < MGA_WFA_N_TIER; ++k) cnt[k + 1] += cnt[k];
+				{ int64_t pos[MGA_WFA_N_TIER]; for (k = 0; k < MGA_WFA_N_TIER; ++k) pos[k] = cnt[k];
+				  for (j = 0; j < n_prob; ++j) if (tier_of[j] >= 0) todo[pos[tier_of[j]]++] = (int32_t)j; }
+				CK(mga_h2d(D.list.p, todo, (size_t)n_left * 4));
+				for (k = 0; k < MGA_WFA_N_TIER; ++k) {
+					int64_t c = cnt[k + 1] - cnt[k];
+					if (c > 0) CK(mga_dev_wfa_tier((int)c, (const int32_t*)D.list.p + cnt[k], (const mga_wfa_prob_t*)D.prob.p, (const char*)D.tseq.p, d_seq,
+											   (mga_wfa_res_t*)D.res.p, (uint32_t*)D.pool.p, pool_cap, (unsigned long long*)D.used.p, (int)k));
+				}
+				(void)off;
+				CK(mga_dsync());
+				CK(mga_d2h(h_res, D.res.p, (size_t)n_prob * sizeof(mga_wfa_res_t)));
+				for (j = 0, n_left = 0; j < n_prob; ++j) {
+					if (tier_of[j] < 0) continue;
+					if (h_res[j].status == MGA_WFA_RETRY_TIER) {
+						if (++tier_of[j] >= MGA_WFA_N_TIER) { free(tier_of); mga_set_error("a WFA problem exceeds the largest capacity tier"); rc = -1; goto done; }
+						++n_left;
+					} else if (h_res[j].status == MGA_WFA_POOL_FULL) { free(tier_of); mga_set_error("WFA CIGAR pool exhausted (capacity %ld ops)", (long)pool_cap); rc = -1; goto done; }
+					else tier_of[j] = -1;
+				}
+				if (++pass > 2 * MGA_WFA_N_TIER) break;
 			}
-			if (m2 == 0) break;
-			if (pool_full) { mga_set_error("WFA CIGAR pool exhausted (capacity %ld ops)", (long)pool_cap); rc = -1; goto done; }
-			if (++tier > 2) { mga_set_error("a WFA problem exceeds the largest capacity tier"); rc = -1; goto done; }
-			m = m2;
+			free(tier_of);
 		}
 		CK(mga_d2h(&used, D.used.p, 8));
 		h_pool = MGA_MALLOC(uint32_t, used + 1);

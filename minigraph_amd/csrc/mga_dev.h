@@ -27,7 +27,8 @@ void mga_hfree_pinned(void *p);
 double mga_wtime(void);
 
 /* per-kernel HIP-event timing on stream 0 (bench.py reads it through mga_prof_get) */
-enum { MGA_K_SKETCH = 0, MGA_K_SEED_COUNT, MGA_K_SEED_FILL, MGA_K_LCHAIN, MGA_K_WFA0, MGA_K_WFA1, MGA_K_WFA2, MGA_K_SCAN, MGA_K_N };
+enum { MGA_K_SKETCH = 0, MGA_K_SEED_COUNT, MGA_K_SEED_FILL, MGA_K_LCHAIN, MGA_K_WFA0 /* +tier: 0-3 register tiers (band 64..512), 4 LDS tier (band 1024), 5-7 HBM tiers */, MGA_K_SCAN = MGA_K_WFA0 + 8, MGA_K_N };
+#define MGA_WFA_N_TIER 8
 void mga_prof_enable(int on);
 void mga_prof_begin(int kid);
 void mga_prof_end(int kid);
@@ -86,6 +87,16 @@ enum { MGA_WFA_OK = 0, MGA_WFA_PENDING = 1, MGA_WFA_RETRY_TIER = 2, MGA_WFA_POOL
  * (capacity pool_cap ops, *d_pool_used bumped atomically); sequences must be padded by >= 8 readable bytes */
 int mga_dev_wfa(int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 				mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier);
+/* the LDS-resident tiers (k_wfa_lds.hip): 0: band<=128, 1: band<=512, 2: band<=1024 */
+int mga_dev_wfa_lds(int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+					mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier);
+/* register-resident tiers (k_wfa_reg.hip): tier t covers a window of 64<<t diagonals */
+int mga_dev_wfa_reg(int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+					mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier);
+/* tier 0..7: register tiers, the LDS tier, then the HBM-resident tiers; a problem failing with MGA_WFA_RETRY_TIER moves up one */
+int mga_wfa_first_tier(int32_t tl, int32_t ql); /* cheapest tier likely to fit, from the sequence lengths */
+int mga_dev_wfa_tier(int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+					 mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier);
 
 #ifdef __cplusplus
 }

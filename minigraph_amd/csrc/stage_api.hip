@@ -58,63 +58,54 @@ extern "C" int mga_wfa_batch(int n, const char *tseq, const int64_t *t_off, cons
 		if (prob[i].tl <= 0 || prob[i].ql <= 0) { mga_set_error("wfa: problem %d has an empty sequence (the caller handles those, galign.c:98-100)", i); return -1; }
 	}
 	dptr d_t, d_q, d_prob, d_res, d_pool, d_used, d_list;
-	int64_t pool_cap = (tt + tq) / 4 + n * 4 + 1024;
+	int64_t pool_cap = (tt + tq) / 4 + n * 4 + 1024 + 40000LL * 512;
 	if (!d_t.alloc(tt + 64) || !d_q.alloc(tq + 64) || !d_prob.alloc((size_t)n * sizeof(mga_wfa_prob_t)) ||
 		!d_res.alloc((size_t)n * sizeof(mga_wfa_res_t)) || !d_used.alloc(8)) return -1;
 	if (mga_h2d(d_t.p, tseq, tt) < 0 || mga_h2d(d_q.p, qseq, tq) < 0 || mga_h2d(d_prob.p, prob.data(), (size_t)n * sizeof(mga_wfa_prob_t)) < 0) return -1;
 	if (mga_dmemset((char*)d_t.p + tt, 0, 64) < 0 || mga_dmemset((char*)d_q.p + tq, 0, 64) < 0) return -1;
 
 	std::vector<mga_wfa_res_t> res(n);
-	std::vector<int32_t> todo(n);
-	std::vector<std::vector<uint32_t> > chunks; // CIGAR pools of successive rounds
-	std::vector<int64_t> chunk_of(n, -1), off_in(n, 0);
-	for (int i = 0; i < n; ++i) todo[i] = i;
-	int tier = 0;
-	while (!todo.empty()) {
-		const int m = (int)todo.size();
-		if (!d_pool.p || true) { mga_dfree(d_pool.p); d_pool.p = 0; if (!d_pool.alloc((size_t)pool_cap * 4)) return -1; }
-		if (mga_dmemset(d_used.p, 0, 8) < 0) return -1;
-		mga_dfree(d_list.p); d_list.p = 0;
-		if (!d_list.alloc((size_t)m * 4) || mga_h2d(d_list.p, todo.data(), (size_t)m * 4) < 0) return -1;
-		if (mga_dev_wfa(m, d_list.as<int32_t>(), d_prob.as<mga_wfa_prob_t>(), d_t.as<char>(), d_q.as<char>(), d_res.as<mga_wfa_res_t>(),
-						d_pool.as<uint32_t>(), pool_cap, (unsigned long long*)d_used.p, tier) < 0) return -1;
-		if (mga_dsync() < 0) return -1;
-		if (mga_d2h(res.data(), d_res.p, (size_t)n * sizeof(mga_wfa_res_t)) < 0) return -1;
-		unsigned long long used = 0;
-		if (mga_d2h(&used, d_used.p, 8) < 0) return -1;
-		int64_t keep = (int64_t)used < pool_cap ? (int64_t)used : pool_cap;
-		chunks.push_back(std::vector<uint32_t>((size_t)keep));
-		if (keep && mga_d2h(chunks.back().data(), d_pool.p, (size_t)keep * 4) < 0) return -1;
-		std::vector<int32_t> next;
-		bool pool_full = false, need_tier = false;
-		for (int j = 0; j < m; ++j) {
-			const int i = todo[j];
-			if (res[i].status == MGA_WFA_OK) chunk_of[i] = (int64_t)chunks.size() - 1, off_in[i] = res[i].cig_off;
-			else if (res[i].status == MGA_WFA_MAX_ITER) chunk_of[i] = -2;
-			else { next.push_back(i); if (res[i].status == MGA_WFA_POOL_FULL) pool_full = true; else need_tier = true; }
+	std::vector<int8_t> tier_of(n);
+	std::vector<int32_t> todo;
+	for (int i = 0; i < n; ++i) tier_of[i] = (int8_t)mga_wfa_first_tier(prob[i].tl, prob[i].ql);
+	if (!d_pool.alloc((size_t)pool_cap * 4) || !d_list.alloc((size_t)n * 4) || mga_dmemset(d_used.p, 0, 8) < 0) return -1;
+	for (int pass = 0;; ++pass) { // first pass: every problem in the tier its length suggests; then only the ones that outgrew it, one tier up
+		int64_t n_left = 0;
+		for (int t = 0; t < MGA_WFA_N_TIER; ++t) {
+			todo.clear();
+			for (int i = 0; i < n; ++i) if (tier_of[i] == t) todo.push_back(i);
+			if (todo.empty()) continue;
+			if (mga_h2d((int32_t*)d_list.p + n_left, todo.data(), todo.size() * 4) < 0) return -1;
+			if (mga_dev_wfa_tier((int)todo.size(), (const int32_t*)d_list.p + n_left, d_prob.as<mga_wfa_prob_t>(), d_t.as<char>(), d_q.as<char>(), d_res.as<mga_wfa_res_t>(),
+								 d_pool.as<uint32_t>(), pool_cap, (unsigned long long*)d_used.p, t) < 0) return -1;
+			n_left += (int64_t)todo.size();
 		}
-		if (pool_full) pool_cap *= 4;
-		if (need_tier && !pool_full) {
-			if (tier == 2) { mga_set_error("wfa: problem exceeds the largest capacity tier"); return -1; }
-			// problems that only ran out of pool keep their tier; the rest moves up
-			std::vector<int32_t> up;
-			for (size_t j = 0; j < next.size(); ++j) if (res[next[j]].status == MGA_WFA_RETRY_TIER) up.push_back(next[j]);
-			next.swap(up);
-			++tier;
-		} else if (need_tier && pool_full) {
-			// rerun everything left in the same tier with the larger pool; tier escalation happens next round
+		if (n_left == 0) break;
+		if (mga_dsync() < 0 || mga_d2h(res.data(), d_res.p, (size_t)n * sizeof(mga_wfa_res_t)) < 0) return -1;
+		bool again = false;
+		for (int i = 0; i < n; ++i) {
+			if (tier_of[i] < 0) continue;
+			if (res[i].status == MGA_WFA_RETRY_TIER) {
+				if (++tier_of[i] >= MGA_WFA_N_TIER) { mga_set_error("wfa: problem exceeds the largest capacity tier"); return -1; }
+				again = true;
+			} else if (res[i].status == MGA_WFA_POOL_FULL) { mga_set_error("wfa: CIGAR pool exhausted"); return -1; }
+			else tier_of[i] = -1;
 		}
-		todo.swap(next);
+		if (!again) break;
 	}
+	unsigned long long used = 0;
+	if (mga_d2h(&used, d_used.p, 8) < 0) return -1;
+	std::vector<uint32_t> hpool((size_t)used + 1);
+	if (used && mga_d2h(hpool.data(), d_pool.p, (size_t)used * 4) < 0) return -1;
 	int32_t *h_score = (int32_t*)malloc((size_t)n * 4);
 	int64_t *h_off = (int64_t*)malloc((size_t)(n + 1) * 8);
 	int64_t tot = 0;
-	for (int i = 0; i < n; ++i) { h_off[i] = tot; h_score[i] = res[i].score; if (chunk_of[i] >= 0) tot += res[i].n_cigar; }
+	for (int i = 0; i < n; ++i) { h_off[i] = tot; h_score[i] = res[i].score; if (res[i].status == MGA_WFA_OK) tot += res[i].n_cigar; }
 	h_off[n] = tot;
 	uint32_t *h_cig = (uint32_t*)malloc((size_t)tot * 4 + 4);
 	for (int i = 0; i < n; ++i)
-		if (chunk_of[i] >= 0 && res[i].n_cigar)
-			memcpy(h_cig + h_off[i], chunks[(size_t)chunk_of[i]].data() + off_in[i], (size_t)res[i].n_cigar * 4);
+		if (res[i].status == MGA_WFA_OK && res[i].n_cigar)
+			memcpy(h_cig + h_off[i], hpool.data() + res[i].cig_off, (size_t)res[i].n_cigar * 4);
 	*score = h_score, *cigar = h_cig, *cig_off = h_off;
 	return 0;
 }
