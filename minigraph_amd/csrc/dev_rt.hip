@@ -7,9 +7,10 @@
 #include <time.h>
 #include "mga_dev.h"
 #include "dev_common.h"
+#include <mutex>
 
 static __thread char g_err[512];
-static int g_dev_ok = -1;
+static int g_dev_ok = -1, g_dev_id = 0;
 
 extern "C" void mga_set_error(const char *fmt, ...)
 {
@@ -49,9 +50,83 @@ extern "C" int mga_dev_init(void)
 	if (hipGetDeviceProperties(&prop, dev) == hipSuccess && mg_verbose >= 3)
 		fprintf(stderr, "[M::minigraph_amd] device %d: %s (%s), %d CUs, %.1f GB\n", dev, prop.name, prop.gcnArchName,
 				prop.multiProcessorCount, prop.totalGlobalMem / 1073741824.0);
-	g_dev_ok = 1;
+	g_dev_ok = 1, g_dev_id = dev;
 	return 0;
 }
+
+extern "C" int mga_dev_bind_thread(void)
+{
+	if (mga_dev_init() < 0) return -1;
+	MGA_HIP_CHECK(hipSetDevice(g_dev_id));
+	return 0;
+}
+
+extern "C" mga_sctx_t *mga_sctx_create(void)
+{
+	if (mga_dev_init() < 0) return 0;
+	mga_sctx_t *sc = (mga_sctx_t*)calloc(1, sizeof(mga_sctx_t));
+	hipStream_t st;
+	if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { free(sc); mga_set_error("hipStreamCreate failed"); return 0; }
+	sc->stream = (void*)st;
+	return sc;
+}
+
+extern "C" void mga_sctx_destroy(mga_sctx_t *sc)
+{
+	if (sc == 0) return;
+	(void)hipStreamSynchronize((hipStream_t)sc->stream);
+	for (int i = 0; i < 8; ++i) mga_dbuf_free(&sc->wfa_ws[i]);
+	mga_dbuf_free(&sc->wfa_cnt);
+	(void)hipStreamDestroy((hipStream_t)sc->stream);
+	free(sc);
+}
+
+extern "C" mga_sctx_t *mga_sctx_default(void)
+{
+	static mga_sctx_t *g_def = 0;
+	if (g_def == 0) g_def = mga_sctx_create();
+	return g_def;
+}
+
+extern "C" int mga_h2d_s(mga_sctx_t *sc, void *d, const void *h, size_t bytes)
+{
+	if (bytes == 0) return 0;
+	MGA_HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, (hipStream_t)sc->stream));
+	return 0;
+}
+
+extern "C" int mga_d2h_s(mga_sctx_t *sc, void *h, const void *d, size_t bytes)
+{
+	if (bytes == 0) return 0;
+	MGA_HIP_CHECK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)sc->stream));
+	return 0;
+}
+
+extern "C" int mga_dmemset_s(mga_sctx_t *sc, void *d, int v, size_t bytes)
+{
+	if (bytes == 0) return 0;
+	MGA_HIP_CHECK(hipMemsetAsync(d, v, bytes, (hipStream_t)sc->stream));
+	return 0;
+}
+
+extern "C" int mga_ssync(mga_sctx_t *sc)
+{
+	MGA_HIP_CHECK(hipStreamSynchronize((hipStream_t)sc->stream));
+	return 0;
+}
+
+extern "C" int mga_hbuf_reserve(mga_hbuf_t *b, size_t bytes)
+{
+	if (bytes <= b->cap && b->p) return 0;
+	if (b->p) (void)hipHostFree(b->p);
+	b->p = 0, b->cap = 0;
+	size_t want = bytes + (bytes >> 2) + 4096;
+	if (hipHostMalloc(&b->p, want, hipHostMallocDefault) != hipSuccess) { b->p = 0; mga_set_error("hipHostMalloc(%zu) failed", want); return -1; }
+	b->cap = want;
+	return 0;
+}
+
+extern "C" void mga_hbuf_free(mga_hbuf_t *b) { if (b->p) (void)hipHostFree(b->p); b->p = 0, b->cap = 0; }
 
 extern "C" void *mga_dmalloc(size_t bytes)
 {
@@ -158,16 +233,16 @@ __global__ void __launch_bounds__(1024) k_scan_i32_i64(const int32_t *__restrict
 	if (threadIdx.x == 0) off[n] = carry;
 }
 
-extern "C" int mga_dev_scan_i32_to_i64(const int32_t *d_cnt, int64_t n, int64_t *d_off)
+extern "C" int mga_dev_scan_i32_to_i64(mga_sctx_t *sc, const int32_t *d_cnt, int64_t n, int64_t *d_off)
 {
-	mga_prof_begin(MGA_K_SCAN);
-	hipLaunchKernelGGL(k_scan_i32_i64, dim3(1), dim3(1024), 0, 0, d_cnt, n, d_off);
-	mga_prof_end(MGA_K_SCAN);
+	mga_prof_begin(sc, MGA_K_SCAN);
+	hipLaunchKernelGGL(k_scan_i32_i64, dim3(1), dim3(1024), 0, (hipStream_t)sc->stream, d_cnt, n, d_off);
+	mga_prof_end(sc, MGA_K_SCAN);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;
 }
 
-// ---- per-kernel HIP-event timing (stream 0, where every kernel of this library is launched) ----
+// ---- per-kernel HIP-event timing, recorded on the stream the kernel is launched on ----
 #define PROF_MAX_PENDING 4096
 static struct {
 	int enabled;
@@ -176,11 +251,13 @@ static struct {
 	int n_pending, n_created;
 	double ms[MGA_K_N];
 	int64_t launches[MGA_K_N];
+	std::mutex mtx;
 } g_prof;
+static __thread int t_prof_slot = -1;
 
 extern "C" void mga_prof_enable(int on) { g_prof.enabled = on; }
 
-extern "C" void mga_prof_collect(void)
+static void prof_collect_locked(void)
 {
 	for (int i = 0; i < g_prof.n_pending; ++i) {
 		float ms = 0.f;
@@ -190,30 +267,38 @@ extern "C" void mga_prof_collect(void)
 	g_prof.n_pending = 0;
 }
 
-extern "C" void mga_prof_begin(int kid)
+extern "C" void mga_prof_collect(void) { std::lock_guard<std::mutex> lk(g_prof.mtx); prof_collect_locked(); }
+
+extern "C" void mga_prof_begin(mga_sctx_t *sc, int kid)
 {
+	t_prof_slot = -1;
 	if (!g_prof.enabled) return;
-	if (g_prof.n_pending == PROF_MAX_PENDING) mga_prof_collect();
+	std::lock_guard<std::mutex> lk(g_prof.mtx);
+	if (g_prof.n_pending == PROF_MAX_PENDING) return; // full: this launch goes untimed (collected at the next mga_prof_get)
 	int i = g_prof.n_pending;
 	if (i >= g_prof.n_created) {
 		if (hipEventCreate(&g_prof.ev[i][0]) != hipSuccess || hipEventCreate(&g_prof.ev[i][1]) != hipSuccess) { g_prof.enabled = 0; return; }
 		g_prof.n_created = i + 1;
 	}
 	g_prof.kid[i] = kid;
-	(void)hipEventRecord(g_prof.ev[i][0], 0);
+	(void)hipEventRecord(g_prof.ev[i][0], (hipStream_t)sc->stream);
+	t_prof_slot = i;
+	++g_prof.n_pending;
 }
 
-extern "C" void mga_prof_end(int kid)
+extern "C" void mga_prof_end(mga_sctx_t *sc, int kid)
 {
-	if (!g_prof.enabled) return;
 	(void)kid;
-	(void)hipEventRecord(g_prof.ev[g_prof.n_pending][1], 0);
-	++g_prof.n_pending;
+	if (t_prof_slot < 0) return;
+	std::lock_guard<std::mutex> lk(g_prof.mtx);
+	(void)hipEventRecord(g_prof.ev[t_prof_slot][1], (hipStream_t)sc->stream);
+	t_prof_slot = -1;
 }
 
 extern "C" void mga_prof_get(double *ms, int64_t *launches, int reset)
 {
-	mga_prof_collect();
+	std::lock_guard<std::mutex> lk(g_prof.mtx);
+	prof_collect_locked();
 	for (int k = 0; k < MGA_K_N; ++k) { ms[k] = g_prof.ms[k]; launches[k] = g_prof.launches[k]; }
 	if (reset) { memset(g_prof.ms, 0, sizeof g_prof.ms); memset(g_prof.launches, 0, sizeof g_prof.launches); }
 }

@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(64) k_lchain(int n_reads, const mg128_t *__res
 
 extern "C" size_t mga_dev_lchain_ws_bytes(int64_t total_anchors) { return (size_t)(total_anchors + 16) * 32; }
 
-extern "C" int mga_dev_lchain(int n, const mg128_t *d_a, const int64_t *d_a_off, const mga_lchain_par_t *par,
+extern "C" int mga_dev_lchain(mga_sctx_t *sc, int n, const mg128_t *d_a, const int64_t *d_a_off, const mga_lchain_par_t *par,
 							  uint64_t *d_u, mg128_t *d_b, int32_t *d_nu, int32_t *d_nb, void *d_ws, size_t ws_bytes, int64_t total_anchors)
 {
 	if (n <= 0) return 0;
@@ -233,9 +233,9 @@ extern "C" int mga_dev_lchain(int n, const mg128_t *d_a, const int64_t *d_a_off,
 	if (ws_bytes < mga_dev_lchain_ws_bytes(total_anchors)) { mga_set_error("lchain: workspace too small"); return -1; }
 	int32_t *ws_i32 = (int32_t*)d_ws;
 	mg128_t *ws_z = (mg128_t*)((char*)d_ws + (size_t)(total_anchors + 8) * 16);
-	mga_prof_begin(MGA_K_LCHAIN);
-	hipLaunchKernelGGL(k_lchain, dim3(n), dim3(64), 0, 0, n, d_a, d_a_off, *par, d_u, d_b, d_nu, d_nb, ws_i32, ws_z);
-	mga_prof_end(MGA_K_LCHAIN);
+	mga_prof_begin(sc, MGA_K_LCHAIN);
+	hipLaunchKernelGGL(k_lchain, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, d_u, d_b, d_nu, d_nb, ws_i32, ws_z);
+	mga_prof_end(sc, MGA_K_LCHAIN);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;
 }

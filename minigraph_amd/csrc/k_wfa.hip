@@ -304,10 +304,8 @@ static const wfa_cfg_t g_tier[3] = {
 };
 static const int g_tier_waves[3] = { 8192, 256, 16 };
 
-static mga_dbuf_t g_wfa_ws[3];
-static mga_dbuf_t g_wfa_cnt;
 
-extern "C" int mga_dev_wfa(int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+extern "C" int mga_dev_wfa(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 						   mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier)
 {
 	if (n <= 0) return 0;
@@ -316,23 +314,23 @@ extern "C" int mga_dev_wfa(int n, const int32_t *d_list, const mga_wfa_prob_t *d
 	cfg.ws_stride = (int64_t)wfa_ws_bytes(cfg);
 	int waves = g_tier_waves[tier];
 	if (waves > n) waves = n;
-	if (mga_dbuf_reserve(&g_wfa_ws[tier], (size_t)cfg.ws_stride * g_tier_waves[tier]) < 0) return -1;
-	if (mga_dbuf_reserve(&g_wfa_cnt, 256) < 0) return -1;
-	MGA_HIP_CHECK(hipMemsetAsync(g_wfa_cnt.p, 0, 4, 0));
-	mga_prof_begin(MGA_K_WFA0 + 5 + tier);
-	hipLaunchKernelGGL(k_wfa, dim3(waves), dim3(64), 0, 0, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap,
-					   d_pool_used, (char*)g_wfa_ws[tier].p, (int*)g_wfa_cnt.p, cfg);
-	mga_prof_end(MGA_K_WFA0 + 5 + tier);
+	if (mga_dbuf_reserve(&sc->wfa_ws[5 + tier], (size_t)cfg.ws_stride * g_tier_waves[tier]) < 0) return -1;
+	if (mga_dbuf_reserve(&sc->wfa_cnt, 256) < 0) return -1;
+	MGA_HIP_CHECK(hipMemsetAsync(sc->wfa_cnt.p, 0, 4, (hipStream_t)sc->stream));
+	mga_prof_begin(sc, MGA_K_WFA0 + 5 + tier);
+	hipLaunchKernelGGL(k_wfa, dim3(waves), dim3(64), 0, (hipStream_t)sc->stream, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap,
+					   d_pool_used, (char*)sc->wfa_ws[5 + tier].p, (int*)sc->wfa_cnt.p, cfg);
+	mga_prof_end(sc, MGA_K_WFA0 + 5 + tier);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;
 }
 
-extern "C" int mga_dev_wfa_tier(int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+extern "C" int mga_dev_wfa_tier(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 								mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier)
 {
-	if (tier < 4) return mga_dev_wfa_reg(n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier);
-	if (tier == 4) return mga_dev_wfa_lds(n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, 2);
-	return mga_dev_wfa(n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier - 5);
+	if (tier < 4) return mga_dev_wfa_reg(sc, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier);
+	if (tier == 4) return mga_dev_wfa_lds(sc, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, 2);
+	return mga_dev_wfa(sc, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier - 5);
 }
 
 // the band of a 10%-error gap is about as wide as the gap is long ([measured] on the benchmark workload:

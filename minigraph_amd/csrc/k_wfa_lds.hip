@@ -297,7 +297,6 @@ static const wfl_tier_t g_ltier[3] = {
 	{  256,  512,  1024,  768,   1024,   4096,   512 << 10 },
 	{  256, 1024,  1024,  256,   2048,   8192,    2 << 20 },
 };
-static mga_dbuf_t g_lws[3], g_lcnt;
 
 static size_t wfl_ws_bytes(const wfl_tier_t &t)
 {
@@ -305,7 +304,7 @@ static size_t wfl_ws_bytes(const wfl_tier_t &t)
 	return (o + 255) & ~(size_t)255;
 }
 
-extern "C" int mga_dev_wfa_lds(int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+extern "C" int mga_dev_wfa_lds(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 							   mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier)
 {
 	if (n <= 0) return 0;
@@ -314,13 +313,13 @@ extern "C" int mga_dev_wfa_lds(int n, const int32_t *d_list, const mga_wfa_prob_
 	wfl_cfg_t cfg = { 4, 4, 2, 15, 1, T.smax, T.cigcap, T.tbcap, 100000000, 0 }; // ring depths 17/3/2 are tied to these penalties (miniwfa.c:11-18)
 	cfg.ws_stride = (int64_t)wfl_ws_bytes(T);
 	int wgs = T.n_wg < n ? T.n_wg : n;
-	if (mga_dbuf_reserve(&g_lws[tier], (size_t)cfg.ws_stride * T.n_wg) < 0) return -1;
-	if (mga_dbuf_reserve(&g_lcnt, 256) < 0) return -1;
-	MGA_HIP_CHECK(hipMemsetAsync(g_lcnt.p, 0, 4, 0));
-	mga_prof_begin(MGA_K_WFA0 + 4);
+	if (mga_dbuf_reserve(&sc->wfa_ws[4], (size_t)cfg.ws_stride * T.n_wg) < 0) return -1;
+	if (mga_dbuf_reserve(&sc->wfa_cnt, 256) < 0) return -1;
+	MGA_HIP_CHECK(hipMemsetAsync(sc->wfa_cnt.p, 0, 4, (hipStream_t)sc->stream));
+	mga_prof_begin(sc, MGA_K_WFA0 + 4);
 	if (tier != 2) { mga_set_error("wfa_lds: only the band-1024 tier is instantiated"); return -1; }
-		hipLaunchKernelGGL((k_wfa_lds<256, 1024, 1024, 2048, 0>), dim3(wgs), dim3(256), 0, 0, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap, d_pool_used, (char*)g_lws[tier].p, (int*)g_lcnt.p, cfg);
-	mga_prof_end(MGA_K_WFA0 + 4);
+		hipLaunchKernelGGL((k_wfa_lds<256, 1024, 1024, 2048, 0>), dim3(wgs), dim3(256), 0, (hipStream_t)sc->stream, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap, d_pool_used, (char*)sc->wfa_ws[4].p, (int*)sc->wfa_cnt.p, cfg);
+	mga_prof_end(sc, MGA_K_WFA0 + 4);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;
 }

@@ -309,9 +309,8 @@ static const wfr_tier_t g_rtier[4] = {
 	{ 4,  4096,  2048,   192 << 10 },
 	{ 8,  2048,  4096,   768 << 10 },
 };
-static mga_dbuf_t g_rws[4], g_rcnt;
 
-extern "C" int mga_dev_wfa_reg(int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+extern "C" int mga_dev_wfa_reg(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 							   mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier)
 {
 	if (n <= 0) return 0;
@@ -321,17 +320,17 @@ extern "C" int mga_dev_wfa_reg(int n, const int32_t *d_list, const mga_wfa_prob_
 	cfg.ws_stride = (int64_t)(((size_t)T.cigcap * 4 + (size_t)T.tbcap + 255) & ~(size_t)255);
 	int waves = T.n_wave < (n + 7) / 8 ? T.n_wave : (n + 7) / 8;
 	if (waves < 1) waves = 1;
-	if (mga_dbuf_reserve(&g_rws[tier], (size_t)cfg.ws_stride * T.n_wave) < 0) return -1;
-	if (mga_dbuf_reserve(&g_rcnt, 256) < 0) return -1;
-	MGA_HIP_CHECK(hipMemsetAsync(g_rcnt.p, 0, 4, 0));
-	mga_prof_begin(MGA_K_WFA0 + tier);
-#define LAUNCH(JJ, SEQ, SM, TBL) hipLaunchKernelGGL((k_wfa_reg<JJ, SEQ, SM, TBL>), dim3(waves), dim3(64), 0, 0, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap, d_pool_used, (char*)g_rws[tier].p, (int*)g_rcnt.p, cfg)
+	if (mga_dbuf_reserve(&sc->wfa_ws[tier], (size_t)cfg.ws_stride * T.n_wave) < 0) return -1;
+	if (mga_dbuf_reserve(&sc->wfa_cnt, 256) < 0) return -1;
+	MGA_HIP_CHECK(hipMemsetAsync(sc->wfa_cnt.p, 0, 4, (hipStream_t)sc->stream));
+	mga_prof_begin(sc, MGA_K_WFA0 + tier);
+#define LAUNCH(JJ, SEQ, SM, TBL) hipLaunchKernelGGL((k_wfa_reg<JJ, SEQ, SM, TBL>), dim3(waves), dim3(64), 0, (hipStream_t)sc->stream, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap, d_pool_used, (char*)sc->wfa_ws[tier].p, (int*)sc->wfa_cnt.p, cfg)
 	if (tier == 0) LAUNCH(1, 128, 64, 2048);
 	else if (tier == 1) LAUNCH(2, 256, 128, 6144);
 	else if (tier == 2) LAUNCH(4, 512, 512, 0);
 	else LAUNCH(8, 1024, 1024, 0);
 #undef LAUNCH
-	mga_prof_end(MGA_K_WFA0 + tier);
+	mga_prof_end(sc, MGA_K_WFA0 + tier);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;
 }

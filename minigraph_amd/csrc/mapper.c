@@ -245,33 +245,39 @@ void mga_batch_destroy(mga_batch_t *b)
 
 /* ------------------------------------------------------------------------------------------------
  * device orchestration
+ *
+ * A batch is cut into chunks of MGA_CHUNK reads.  Two pipeline threads, each with its own HIP stream,
+ * device buffers and pinned staging buffers, pull chunks from a shared counter and run the stage
+ * sequence above on them; while one thread is in a host stage the other one's kernels and copies own
+ * the GPU, so the GPU work of chunk i overlaps the host work of chunk i+1.
  * ---------------------------------------------------------------------------------------------- */
+#include <pthread.h>
 
-static struct { /* grow-only device buffers, reused across batches (one GPU per process) */
+typedef struct {
+	mga_sctx_t *sc;
 	mga_dbuf_t seq, qoff, cnt, mzoff, mz, occ, val, na, nmini, rep, aoff, minioff, a, tmp, mini, u, b, nu, nb, ws;
 	mga_dbuf_t tseq, prob, res, pool, used, list;
-} D;
+	mga_hbuf_t h_b, h_u, h_mini, h_tseq, h_prob, h_res, h_pool, h_seq, h_list; /* pinned staging */
+} pipe_ctx_t;
+
+#define MGA_MAX_PIPE 4
+static pipe_ctx_t g_pipe[MGA_MAX_PIPE]; /* grow-only, reused across batches (one GPU per process) */
 
 #define CK(x) do { if ((x) < 0) { rc = -1; goto done; } } while (0)
 
-static int map_chunk(const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs_out,
-					 const mg_mapopt_t *opt, int n_threads, const char *d_seq_res, const int64_t *q_off_res)
+static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs_out,
+					 const mg_mapopt_t *opt, int n_threads, const char *d_seq_res, const int64_t *q_off_res, mga_stats_t *st)
 {
 	struct mg_idx_bucket_s *B = gi->B;
-	mga_stats_t *st = &B->st;
+	mga_sctx_t *sc = P->sc;
 	int rc = 0, i;
 	int64_t tot = 0, n_mz, n_a, n_mini, n_prob = 0, n_tb = 0, pool_cap;
 	int64_t *q_off = MGA_MALLOC(int64_t, n + 2), *h_mzoff = 0, *h_aoff = 0, *h_minioff = 0;
-	int32_t *h_nmz = 0, *h_rep = 0, *h_mini = 0, *h_nu = 0, *h_nb = 0, *todo = 0;
-	uint64_t *h_u = 0;
-	mg128_t *h_b = 0;
-	char *h_seq = 0, *h_tseq = 0;
-	mga_wfa_prob_t *h_prob = 0;
-	mga_wfa_res_t *h_res = 0;
-	uint32_t *h_pool = 0;
+	int32_t *h_nmz = 0, *h_rep = 0, *h_nu = 0, *h_nb = 0;
 	mga_batch_t *b = 0;
 	mga_lchain_par_t par;
 	const int is_rmq = !!(opt->flag & MG_M_RMQ);
+	const char *d_seq;
 	double t0, t1;
 
 	if (opt->flag & (MG_M_SR | MG_M_HEAP_SORT | MG_M_SPLICE | MG_M_NO_DIAG)) {
@@ -279,132 +285,132 @@ static int map_chunk(const mg_idx_t *gi, int n, const int *qlens, const char **s
 	}
 	/* ---- reads -> HBM, back to back, 64 readable bytes of padding at the end (8-byte compares in k_wfa);
 	 *      skipped when the caller keeps the batch resident (d_seq_res + absolute offsets q_off_res) ---- */
-	const char *d_seq;
 	t0 = mga_wtime();
-	CK(mga_dbuf_reserve(&D.qoff, (size_t)(n + 1) * 8));
+	CK(mga_dbuf_reserve(&P->qoff, (size_t)(n + 1) * 8));
 	if (d_seq_res) {
 		memcpy(q_off, q_off_res, (size_t)(n + 1) * 8);
 		tot = q_off[n] - q_off[0];
 		d_seq = d_seq_res;
 	} else {
+		char *h_seq;
 		for (i = 0; i < n; ++i) { q_off[i] = tot; tot += qlens[i]; }
 		q_off[n] = tot;
-		h_seq = (char*)malloc((size_t)tot + 64);
+		CK(mga_hbuf_reserve(&P->h_seq, (size_t)tot + 64));
+		h_seq = (char*)P->h_seq.p;
 		for (i = 0; i < n; ++i) memcpy(h_seq + q_off[i], seqs[i], (size_t)qlens[i]);
 		memset(h_seq + tot, 0, 64);
-		CK(mga_dbuf_reserve(&D.seq, (size_t)tot + 64));
-		CK(mga_h2d(D.seq.p, h_seq, (size_t)tot + 64));
-		d_seq = (const char*)D.seq.p;
+		CK(mga_dbuf_reserve(&P->seq, (size_t)tot + 64));
+		CK(mga_h2d_s(sc, P->seq.p, h_seq, (size_t)tot + 64));
+		d_seq = (const char*)P->seq.p;
 	}
-	CK(mga_h2d(D.qoff.p, q_off, (size_t)(n + 1) * 8));
+	CK(mga_h2d_s(sc, P->qoff.p, q_off, (size_t)(n + 1) * 8));
 	/* ---- sketch ---- */
-	CK(mga_dbuf_reserve(&D.cnt, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&D.mzoff, (size_t)(n + 1) * 8));
-	CK(mga_dev_sketch(n, d_seq, (const int64_t*)D.qoff.p, 0, gi->w, gi->k, (int32_t*)D.cnt.p, 0, 0));
-	CK(mga_dev_scan_i32_to_i64((const int32_t*)D.cnt.p, n, (int64_t*)D.mzoff.p));
+	CK(mga_dbuf_reserve(&P->cnt, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&P->mzoff, (size_t)(n + 1) * 8));
+	CK(mga_dev_sketch(sc, n, d_seq, (const int64_t*)P->qoff.p, 0, gi->w, gi->k, (int32_t*)P->cnt.p, 0, 0));
+	CK(mga_dev_scan_i32_to_i64(sc, (const int32_t*)P->cnt.p, n, (int64_t*)P->mzoff.p));
 	h_mzoff = MGA_MALLOC(int64_t, n + 1);
-	CK(mga_d2h(h_mzoff, D.mzoff.p, (size_t)(n + 1) * 8));
+	CK(mga_d2h_s(sc, h_mzoff, P->mzoff.p, (size_t)(n + 1) * 8)); CK(mga_ssync(sc));
 	n_mz = h_mzoff[n];
-	CK(mga_dbuf_reserve(&D.mz, (size_t)n_mz * 16 + 16));
-	CK(mga_dev_sketch(n, d_seq, (const int64_t*)D.qoff.p, 0, gi->w, gi->k, 0, (const int64_t*)D.mzoff.p, (mg128_t*)D.mz.p));
-	CK(mga_dsync());
-	t1 = mga_wtime(); st->t_sketch += t1 - t0; t0 = t1;
+	CK(mga_dbuf_reserve(&P->mz, (size_t)n_mz * 16 + 16));
+	CK(mga_dev_sketch(sc, n, d_seq, (const int64_t*)P->qoff.p, 0, gi->w, gi->k, 0, (const int64_t*)P->mzoff.p, (mg128_t*)P->mz.p));
 	/* ---- seeds ---- */
-	CK(mga_dbuf_reserve(&D.occ, (size_t)n_mz * 4 + 4)); CK(mga_dbuf_reserve(&D.val, (size_t)n_mz * 8 + 8));
-	CK(mga_dbuf_reserve(&D.na, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&D.nmini, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&D.rep, (size_t)n * 4 + 4));
-	CK(mga_dbuf_reserve(&D.aoff, (size_t)(n + 1) * 8)); CK(mga_dbuf_reserve(&D.minioff, (size_t)(n + 1) * 8));
-	CK(mga_dev_seed_count(&B->dev, n, (const mg128_t*)D.mz.p, (const int64_t*)D.mzoff.p, opt->occ_max1, (int32_t*)D.occ.p, (uint64_t*)D.val.p,
-						  (int32_t*)D.na.p, (int32_t*)D.nmini.p, (int32_t*)D.rep.p));
-	CK(mga_dev_scan_i32_to_i64((const int32_t*)D.na.p, n, (int64_t*)D.aoff.p));
-	CK(mga_dev_scan_i32_to_i64((const int32_t*)D.nmini.p, n, (int64_t*)D.minioff.p));
+	CK(mga_dbuf_reserve(&P->occ, (size_t)n_mz * 4 + 4)); CK(mga_dbuf_reserve(&P->val, (size_t)n_mz * 8 + 8));
+	CK(mga_dbuf_reserve(&P->na, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&P->nmini, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&P->rep, (size_t)n * 4 + 4));
+	CK(mga_dbuf_reserve(&P->aoff, (size_t)(n + 1) * 8)); CK(mga_dbuf_reserve(&P->minioff, (size_t)(n + 1) * 8));
+	CK(mga_dev_seed_count(sc, &B->dev, n, (const mg128_t*)P->mz.p, (const int64_t*)P->mzoff.p, opt->occ_max1, (int32_t*)P->occ.p, (uint64_t*)P->val.p,
+						  (int32_t*)P->na.p, (int32_t*)P->nmini.p, (int32_t*)P->rep.p));
+	CK(mga_dev_scan_i32_to_i64(sc, (const int32_t*)P->na.p, n, (int64_t*)P->aoff.p));
+	CK(mga_dev_scan_i32_to_i64(sc, (const int32_t*)P->nmini.p, n, (int64_t*)P->minioff.p));
 	h_aoff = MGA_MALLOC(int64_t, n + 1); h_minioff = MGA_MALLOC(int64_t, n + 1); h_rep = MGA_MALLOC(int32_t, n);
-	CK(mga_d2h(h_aoff, D.aoff.p, (size_t)(n + 1) * 8)); CK(mga_d2h(h_minioff, D.minioff.p, (size_t)(n + 1) * 8)); CK(mga_d2h(h_rep, D.rep.p, (size_t)n * 4));
+	CK(mga_d2h_s(sc, h_aoff, P->aoff.p, (size_t)(n + 1) * 8)); CK(mga_d2h_s(sc, h_minioff, P->minioff.p, (size_t)(n + 1) * 8)); CK(mga_d2h_s(sc, h_rep, P->rep.p, (size_t)n * 4));
+	CK(mga_ssync(sc));
+	t1 = mga_wtime(); st->t_sketch += t1 - t0; t0 = t1;
 	n_a = h_aoff[n], n_mini = h_minioff[n];
-	CK(mga_dbuf_reserve(&D.a, (size_t)n_a * 16 + 64)); CK(mga_dbuf_reserve(&D.tmp, (size_t)n_a * 16 + 64)); CK(mga_dbuf_reserve(&D.mini, (size_t)n_mini * 4 + 16));
-	CK(mga_dev_seed_fill(&B->dev, n, (const mg128_t*)D.mz.p, (const int64_t*)D.mzoff.p, opt->occ_max1, (const int32_t*)D.occ.p, (const uint64_t*)D.val.p,
-						 (const int64_t*)D.aoff.p, (mg128_t*)D.a.p, (const int64_t*)D.minioff.p, (int32_t*)D.mini.p, (mg128_t*)D.tmp.p));
-	CK(mga_dsync());
-	t1 = mga_wtime(); st->t_seed += t1 - t0; t0 = t1;
+	CK(mga_dbuf_reserve(&P->a, (size_t)n_a * 16 + 64)); CK(mga_dbuf_reserve(&P->tmp, (size_t)n_a * 16 + 64)); CK(mga_dbuf_reserve(&P->mini, (size_t)n_mini * 4 + 16));
+	CK(mga_dev_seed_fill(sc, &B->dev, n, (const mg128_t*)P->mz.p, (const int64_t*)P->mzoff.p, opt->occ_max1, (const int32_t*)P->occ.p, (const uint64_t*)P->val.p,
+						 (const int64_t*)P->aoff.p, (mg128_t*)P->a.p, (const int64_t*)P->minioff.p, (int32_t*)P->mini.p, (mg128_t*)P->tmp.p));
 	h_nmz = MGA_MALLOC(int32_t, n);
 	for (i = 0; i < n; ++i) h_nmz[i] = (int32_t)(h_mzoff[i + 1] - h_mzoff[i]);
-	h_mini = MGA_MALLOC(int32_t, n_mini + 1);
-	CK(mga_d2h(h_mini, D.mini.p, (size_t)n_mini * 4));
+	CK(mga_hbuf_reserve(&P->h_mini, (size_t)n_mini * 4 + 16));
+	CK(mga_d2h_s(sc, P->h_mini.p, P->mini.p, (size_t)n_mini * 4));
 	/* ---- linear chaining ---- */
-	h_b = MGA_MALLOC(mg128_t, n_a + 1);
+	CK(mga_hbuf_reserve(&P->h_b, (size_t)n_a * 16 + 16));
 	if (!is_rmq) {
 		size_t wsb = mga_dev_lchain_ws_bytes(n_a);
 		mga_batch_lchain_par(gi, opt, 0, &par);
-		CK(mga_dbuf_reserve(&D.u, (size_t)n_a * 8 + 8)); CK(mga_dbuf_reserve(&D.b, (size_t)n_a * 16 + 16));
-		CK(mga_dbuf_reserve(&D.nu, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&D.nb, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&D.ws, wsb));
-		CK(mga_dev_lchain(n, (const mg128_t*)D.a.p, (const int64_t*)D.aoff.p, &par, (uint64_t*)D.u.p, (mg128_t*)D.b.p, (int32_t*)D.nu.p, (int32_t*)D.nb.p, D.ws.p, wsb, n_a));
-		CK(mga_dsync());
-		h_nu = MGA_MALLOC(int32_t, n); h_nb = MGA_MALLOC(int32_t, n); h_u = MGA_MALLOC(uint64_t, n_a + 1);
-		CK(mga_d2h(h_nu, D.nu.p, (size_t)n * 4)); CK(mga_d2h(h_nb, D.nb.p, (size_t)n * 4));
-		CK(mga_d2h(h_u, D.u.p, (size_t)n_a * 8)); CK(mga_d2h(h_b, D.b.p, (size_t)n_a * 16));
-	} else CK(mga_d2h(h_b, D.a.p, (size_t)n_a * 16));
+		CK(mga_dbuf_reserve(&P->u, (size_t)n_a * 8 + 8)); CK(mga_dbuf_reserve(&P->b, (size_t)n_a * 16 + 16));
+		CK(mga_dbuf_reserve(&P->nu, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&P->nb, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&P->ws, wsb));
+		CK(mga_dev_lchain(sc, n, (const mg128_t*)P->a.p, (const int64_t*)P->aoff.p, &par, (uint64_t*)P->u.p, (mg128_t*)P->b.p, (int32_t*)P->nu.p, (int32_t*)P->nb.p, P->ws.p, wsb, n_a));
+		h_nu = MGA_MALLOC(int32_t, n); h_nb = MGA_MALLOC(int32_t, n);
+		CK(mga_hbuf_reserve(&P->h_u, (size_t)n_a * 8 + 8));
+		CK(mga_d2h_s(sc, h_nu, P->nu.p, (size_t)n * 4)); CK(mga_d2h_s(sc, h_nb, P->nb.p, (size_t)n * 4));
+		CK(mga_d2h_s(sc, P->h_u.p, P->u.p, (size_t)n_a * 8)); CK(mga_d2h_s(sc, P->h_b.p, P->b.p, (size_t)n_a * 16));
+	} else CK(mga_d2h_s(sc, P->h_b.p, P->a.p, (size_t)n_a * 16));
+	CK(mga_ssync(sc));
 	t1 = mga_wtime(); st->t_lchain += t1 - t0; t0 = t1;
 	/* ---- host: graph chaining + gap list ---- */
 	b = mga_batch_init(gi, opt, n, qlens, seqs, qnames, q_off, n_threads);
-	CK(mga_batch_chain(b, h_nmz, h_rep, h_mini, h_minioff, h_nu, h_nb, h_u, h_b, h_aoff, is_rmq));
+	CK(mga_batch_chain(b, h_nmz, h_rep, (const int32_t*)P->h_mini.p, h_minioff, h_nu, h_nb, (const uint64_t*)P->h_u.p, (const mg128_t*)P->h_b.p, h_aoff, is_rmq));
 	t1 = mga_wtime(); st->t_host_chain += t1 - t0; t0 = t1;
 	/* ---- WFA over all gaps ---- */
 	n_prob = mga_batch_n_wfa(b), n_tb = mga_batch_wfa_target_bytes(b);
 	if ((opt->flag & MG_M_CIGAR) && n_prob > 0) {
-		int64_t m;
 		unsigned long long used = 0;
-		h_prob = MGA_MALLOC(mga_wfa_prob_t, n_prob); h_tseq = (char*)calloc((size_t)n_tb + 64, 1);
-		mga_batch_wfa_export(b, h_prob, h_tseq);
-		h_res = MGA_MALLOC(mga_wfa_res_t, n_prob);
-		CK(mga_dbuf_reserve(&D.tseq, (size_t)n_tb + 64)); CK(mga_dbuf_reserve(&D.prob, (size_t)n_prob * sizeof(mga_wfa_prob_t))); CK(mga_dbuf_reserve(&D.res, (size_t)n_prob * sizeof(mga_wfa_res_t)));
-		CK(mga_dbuf_reserve(&D.used, 64));
-		CK(mga_h2d(D.tseq.p, h_tseq, (size_t)n_tb + 64)); CK(mga_h2d(D.prob.p, h_prob, (size_t)n_prob * sizeof(mga_wfa_prob_t)));
-		pool_cap = (b->tp_t_base[b->n_threads] + n_prob * 8) / 2 + 4096 + 40000LL * 512; /* + abandoned block tails (<= 512 ops) of every resident wave */
+		mga_wfa_prob_t *h_prob;
+		mga_wfa_res_t *h_res;
+		int32_t *todo;
+		int8_t *tier_of;
+		int64_t cnt[MGA_WFA_N_TIER + 1], j, n_left;
+		int pass = 0;
+		CK(mga_hbuf_reserve(&P->h_prob, (size_t)n_prob * sizeof(mga_wfa_prob_t))); CK(mga_hbuf_reserve(&P->h_tseq, (size_t)n_tb + 64));
+		CK(mga_hbuf_reserve(&P->h_res, (size_t)n_prob * sizeof(mga_wfa_res_t))); CK(mga_hbuf_reserve(&P->h_list, (size_t)n_prob * 4));
+		h_prob = (mga_wfa_prob_t*)P->h_prob.p, h_res = (mga_wfa_res_t*)P->h_res.p, todo = (int32_t*)P->h_list.p;
+		mga_batch_wfa_export(b, h_prob, (char*)P->h_tseq.p);
+		memset((char*)P->h_tseq.p + n_tb, 0, 64);
+		CK(mga_dbuf_reserve(&P->tseq, (size_t)n_tb + 64)); CK(mga_dbuf_reserve(&P->prob, (size_t)n_prob * sizeof(mga_wfa_prob_t))); CK(mga_dbuf_reserve(&P->res, (size_t)n_prob * sizeof(mga_wfa_res_t)));
+		CK(mga_dbuf_reserve(&P->used, 64)); CK(mga_dbuf_reserve(&P->list, (size_t)n_prob * 4));
+		CK(mga_h2d_s(sc, P->tseq.p, P->h_tseq.p, (size_t)n_tb + 64)); CK(mga_h2d_s(sc, P->prob.p, h_prob, (size_t)n_prob * sizeof(mga_wfa_prob_t)));
+		pool_cap = (n_tb + n_prob * 8) / 2 + 4096 + 40000LL * 512; /* + abandoned block tails (<= 512 ops) of every resident wave */
 		for (i = 0; i < b->n_threads; ++i) pool_cap += b->tp[i].wfa_q_bases / 2;
-		CK(mga_dbuf_reserve(&D.pool, (size_t)pool_cap * 4)); CK(mga_dmemset(D.used.p, 0, 8));
-		{ /* every problem starts in the cheapest tier its length suggests; all first-pass launches are queued back to back,
-		   * then only the (few) problems that outgrew their tier are re-run one tier up */
-			int8_t *tier_of = (int8_t*)malloc((size_t)n_prob);
-			int64_t cnt[MGA_WFA_N_TIER + 1], j, n_left;
-			int pass = 0;
-			todo = MGA_MALLOC(int32_t, n_prob);
-			for (j = 0; j < n_prob; ++j) tier_of[j] = (int8_t)mga_wfa_first_tier(h_prob[j].tl, h_prob[j].ql);
-			n_left = n_prob;
-			CK(mga_dbuf_reserve(&D.list, (size_t)n_prob * 4));
-			while (n_left > 0) {
-				int64_t off = 0, k;
-				memset(cnt, 0, sizeof cnt);
-				for (j = 0; j < n_prob; ++j) if (tier_of[j] >= 0) ++cnt[tier_of[j] + 1];
-				for (k = 0; k < MGA_WFA_N_TIER; ++k) cnt[k + 1] += cnt[k];
-				{ int64_t pos[MGA_WFA_N_TIER]; for (k = 0; k < MGA_WFA_N_TIER; ++k) pos[k] = cnt[k];
-				  for (j = 0; j < n_prob; ++j) if (tier_of[j] >= 0) todo[pos[tier_of[j]]++] = (int32_t)j; }
-				CK(mga_h2d(D.list.p, todo, (size_t)n_left * 4));
-				for (k = 0; k < MGA_WFA_N_TIER; ++k) {
-					int64_t c = cnt[k + 1] - cnt[k];
-					if (c > 0) CK(mga_dev_wfa_tier((int)c, (const int32_t*)D.list.p + cnt[k], (const mga_wfa_prob_t*)D.prob.p, (const char*)D.tseq.p, d_seq,
-											   (mga_wfa_res_t*)D.res.p, (uint32_t*)D.pool.p, pool_cap, (unsigned long long*)D.used.p, (int)k));
-				}
-				(void)off;
-				CK(mga_dsync());
-				CK(mga_d2h(h_res, D.res.p, (size_t)n_prob * sizeof(mga_wfa_res_t)));
-				for (j = 0, n_left = 0; j < n_prob; ++j) {
-					if (tier_of[j] < 0) continue;
-					if (h_res[j].status == MGA_WFA_RETRY_TIER) {
-						if (++tier_of[j] >= MGA_WFA_N_TIER) { free(tier_of); mga_set_error("a WFA problem exceeds the largest capacity tier"); rc = -1; goto done; }
-						++n_left;
-					} else if (h_res[j].status == MGA_WFA_POOL_FULL) { free(tier_of); mga_set_error("WFA CIGAR pool exhausted (capacity %ld ops)", (long)pool_cap); rc = -1; goto done; }
-					else tier_of[j] = -1;
-				}
-				if (++pass > 2 * MGA_WFA_N_TIER) break;
+		CK(mga_dbuf_reserve(&P->pool, (size_t)pool_cap * 4)); CK(mga_dmemset_s(sc, P->used.p, 0, 8));
+		/* every problem starts in the cheapest tier its length suggests; all first-pass launches are queued back to back,
+		 * then only the (few) problems that outgrew their tier are re-run one tier up */
+		tier_of = (int8_t*)malloc((size_t)n_prob);
+		for (j = 0; j < n_prob; ++j) tier_of[j] = (int8_t)mga_wfa_first_tier(h_prob[j].tl, h_prob[j].ql);
+		n_left = n_prob;
+		while (n_left > 0) {
+			int64_t k, pos[MGA_WFA_N_TIER];
+			memset(cnt, 0, sizeof cnt);
+			for (j = 0; j < n_prob; ++j) if (tier_of[j] >= 0) ++cnt[tier_of[j] + 1];
+			for (k = 0; k < MGA_WFA_N_TIER; ++k) cnt[k + 1] += cnt[k];
+			for (k = 0; k < MGA_WFA_N_TIER; ++k) pos[k] = cnt[k];
+			for (j = 0; j < n_prob; ++j) if (tier_of[j] >= 0) todo[pos[tier_of[j]]++] = (int32_t)j;
+			if (mga_h2d_s(sc, P->list.p, todo, (size_t)n_left * 4) < 0) { free(tier_of); rc = -1; goto done; }
+			for (k = 0; k < MGA_WFA_N_TIER; ++k) {
+				int64_t c = cnt[k + 1] - cnt[k];
+				if (c > 0 && mga_dev_wfa_tier(sc, (int)c, (const int32_t*)P->list.p + cnt[k], (const mga_wfa_prob_t*)P->prob.p, (const char*)P->tseq.p, d_seq,
+											  (mga_wfa_res_t*)P->res.p, (uint32_t*)P->pool.p, pool_cap, (unsigned long long*)P->used.p, (int)k) < 0) { free(tier_of); rc = -1; goto done; }
 			}
-			free(tier_of);
+			if (mga_d2h_s(sc, h_res, P->res.p, (size_t)n_prob * sizeof(mga_wfa_res_t)) < 0 || mga_ssync(sc) < 0) { free(tier_of); rc = -1; goto done; }
+			for (j = 0, n_left = 0; j < n_prob; ++j) {
+				if (tier_of[j] < 0) continue;
+				if (h_res[j].status == MGA_WFA_RETRY_TIER) {
+					if (++tier_of[j] >= MGA_WFA_N_TIER) { free(tier_of); mga_set_error("a WFA problem exceeds the largest capacity tier"); rc = -1; goto done; }
+					++n_left;
+				} else if (h_res[j].status == MGA_WFA_POOL_FULL) { free(tier_of); mga_set_error("WFA CIGAR pool exhausted (capacity %ld ops)", (long)pool_cap); rc = -1; goto done; }
+				else tier_of[j] = -1;
+			}
+			if (++pass > 2 * MGA_WFA_N_TIER) break;
 		}
-		CK(mga_d2h(&used, D.used.p, 8));
-		h_pool = MGA_MALLOC(uint32_t, used + 1);
-		CK(mga_d2h(h_pool, D.pool.p, (size_t)used * 4));
+		free(tier_of);
+		CK(mga_d2h_s(sc, &used, P->used.p, 8)); CK(mga_ssync(sc));
+		CK(mga_hbuf_reserve(&P->h_pool, (size_t)used * 4 + 16));
+		CK(mga_d2h_s(sc, P->h_pool.p, P->pool.p, (size_t)used * 4)); CK(mga_ssync(sc));
 		for (i = 0; i < n_prob; ++i) st->wfa_cells += h_res[i].n_iter;
 	}
 	t1 = mga_wtime(); st->t_wfa += t1 - t0; t0 = t1;
 	/* ---- host: CIGAR stitching + ds ---- */
-	CK(mga_batch_finish(b, h_res, h_pool));
+	CK(mga_batch_finish(b, (const mga_wfa_res_t*)P->h_res.p, (const uint32_t*)P->h_pool.p));
 	t1 = mga_wtime(); st->t_host_post += t1 - t0;
 	{
 		mg_gchains_t **r = mga_batch_take_results(b);
@@ -416,29 +422,98 @@ static int map_chunk(const mg_idx_t *gi, int n, const int *qlens, const char **s
 	mga_batch_stats(b, st);
 done:
 	if (b) mga_batch_destroy(b);
-	free(q_off); free(h_mzoff); free(h_aoff); free(h_minioff); free(h_nmz); free(h_rep); free(h_mini); free(h_nu); free(h_nb);
-	free(h_u); free(h_b); free(h_seq); free(h_tseq); free(h_prob); free(h_res); free(h_pool); free(todo);
+	free(q_off); free(h_mzoff); free(h_aoff); free(h_minioff); free(h_nmz); free(h_rep); free(h_nu); free(h_nb);
 	return rc;
+}
+
+typedef struct {
+	const mg_idx_t *gi;
+	const mg_mapopt_t *opt;
+	int n, chunk, n_threads;
+	const int *qlens;
+	const char **seqs, **qnames;
+	mg_gchains_t **gcs;
+	const char *d_seq;
+	const int64_t *q_off;
+	volatile int next, err;
+	pthread_mutex_t mtx;
+	char errmsg[512];
+} pipe_job_t;
+
+typedef struct { pipe_job_t *job; pipe_ctx_t *P; mga_stats_t st; } pipe_thr_t;
+
+static void *pipe_worker(void *a)
+{
+	pipe_thr_t *t = (pipe_thr_t*)a;
+	pipe_job_t *J = t->job;
+	if (mga_dev_bind_thread() < 0) { J->err = 1; return 0; }
+	for (;;) {
+		int c = __sync_fetch_and_add(&J->next, 1), st = c * J->chunk, en;
+		if (st >= J->n || J->err) break;
+		en = st + J->chunk < J->n ? st + J->chunk : J->n;
+		if (map_chunk(t->P, J->gi, en - st, J->qlens + st, J->seqs + st, J->qnames ? J->qnames + st : 0, J->gcs + st, J->opt, J->n_threads,
+					  J->d_seq, J->q_off ? J->q_off + st : 0, &t->st) < 0) {
+			pthread_mutex_lock(&J->mtx);
+			if (!J->err) { J->err = 1; snprintf(J->errmsg, sizeof J->errmsg, "%s", mga_last_error()); }
+			pthread_mutex_unlock(&J->mtx);
+			break;
+		}
+	}
+	return 0;
+}
+
+static int env_int(const char *name, int dflt) { const char *s = getenv(name); return s && *s ? atoi(s) : dflt; }
+
+static int map_all(const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs,
+				   const mg_mapopt_t *opt, int n_threads, const char *d_seq, const int64_t *q_off)
+{
+	pipe_job_t J;
+	pipe_thr_t thr[MGA_MAX_PIPE];
+	pthread_t tid[MGA_MAX_PIPE];
+	int i, n_pipe = env_int("MGA_PIPE", 2), n_chunks;
+	if (n <= 0) return 0;
+	if (mga_dev_init() < 0) return -1;
+	for (i = 0; i < n; ++i) gcs[i] = 0;
+	memset(&J, 0, sizeof J);
+	J.gi = gi, J.opt = opt, J.n = n, J.qlens = qlens, J.seqs = seqs, J.qnames = qnames, J.gcs = gcs, J.d_seq = d_seq, J.q_off = q_off;
+	J.chunk = env_int("MGA_CHUNK", 4096);
+	if (J.chunk < 1) J.chunk = 1;
+	n_chunks = (n + J.chunk - 1) / J.chunk;
+	if (n_pipe > MGA_MAX_PIPE) n_pipe = MGA_MAX_PIPE;
+	if (n_pipe > n_chunks) n_pipe = n_chunks;
+	if (n_pipe < 1) n_pipe = 1;
+	J.n_threads = n_threads / n_pipe > 0 ? n_threads / n_pipe : 1;
+	pthread_mutex_init(&J.mtx, 0);
+	for (i = 0; i < n_pipe; ++i) {
+		if (g_pipe[i].sc == 0 && (g_pipe[i].sc = mga_sctx_create()) == 0) return -1;
+		thr[i].job = &J, thr[i].P = &g_pipe[i];
+		memset(&thr[i].st, 0, sizeof(mga_stats_t));
+	}
+	if (n_pipe == 1) pipe_worker(&thr[0]);
+	else {
+		for (i = 0; i < n_pipe; ++i) pthread_create(&tid[i], 0, pipe_worker, &thr[i]);
+		for (i = 0; i < n_pipe; ++i) pthread_join(tid[i], 0);
+	}
+	pthread_mutex_destroy(&J.mtx);
+	for (i = 0; i < n_pipe; ++i) { /* merge the per-thread counters */
+		mga_stats_t *d = &gi->B->st, *s = &thr[i].st;
+		d->n_reads += s->n_reads, d->n_bases += s->n_bases, d->n_mz += s->n_mz, d->n_probe += s->n_probe, d->n_hit += s->n_hit;
+		d->n_anchor_chained += s->n_anchor_chained, d->n_wfa += s->n_wfa, d->wfa_t_bases += s->wfa_t_bases, d->wfa_q_bases += s->wfa_q_bases;
+		d->wfa_cells += s->wfa_cells;
+		d->t_sketch += s->t_sketch, d->t_seed += s->t_seed, d->t_lchain += s->t_lchain, d->t_host_chain += s->t_host_chain, d->t_wfa += s->t_wfa, d->t_host_post += s->t_host_post;
+	}
+	if (J.err) {
+		for (i = 0; i < n; ++i) { mg_gchain_free(gcs[i]); gcs[i] = 0; }
+		mga_set_error("%s", J.errmsg[0] ? J.errmsg : "mapping pipeline failed");
+		return -1;
+	}
+	return 0;
 }
 
 int mg_map_batch(const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs,
 				 const mg_mapopt_t *opt, int n_threads)
 {
-	int i, st = 0;
-	if (n <= 0) return 0;
-	if (mga_dev_init() < 0) return -1;
-	for (i = 0; i < n; ++i) gcs[i] = 0;
-	while (st < n) { /* bound device memory: at most ~256 Mbases / 64k reads per launch wave */
-		int en = st;
-		int64_t bases = 0;
-		while (en < n && en - st < 65536 && bases < 256000000) bases += qlens[en++];
-		if (map_chunk(gi, en - st, qlens + st, seqs + st, qnames ? qnames + st : 0, gcs + st, opt, n_threads, 0, 0) < 0) {
-			for (i = 0; i < n; ++i) { mg_gchain_free(gcs[i]); gcs[i] = 0; }
-			return -1;
-		}
-		st = en;
-	}
-	return 0;
+	return map_all(gi, n, qlens, seqs, qnames, gcs, opt, n_threads, 0, 0);
 }
 
 /* same as mg_map_batch() for reads that already sit in HBM: d_seq holds the reads back to back (+64 readable bytes),
@@ -446,21 +521,7 @@ int mg_map_batch(const mg_idx_t *gi, int n, const int *qlens, const char **seqs,
 int mga_map_batch_resident(const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs,
 						   const mg_mapopt_t *opt, int n_threads, const char *d_seq, const int64_t *q_off)
 {
-	int i, st = 0;
-	if (n <= 0) return 0;
-	if (mga_dev_init() < 0) return -1;
-	for (i = 0; i < n; ++i) gcs[i] = 0;
-	while (st < n) {
-		int en = st;
-		int64_t bases = 0;
-		while (en < n && en - st < 65536 && bases < 256000000) bases += qlens[en++];
-		if (map_chunk(gi, en - st, qlens + st, seqs + st, qnames ? qnames + st : 0, gcs + st, opt, n_threads, d_seq, q_off + st) < 0) {
-			for (i = 0; i < n; ++i) { mg_gchain_free(gcs[i]); gcs[i] = 0; }
-			return -1;
-		}
-		st = en;
-	}
-	return 0;
+	return map_all(gi, n, qlens, seqs, qnames, gcs, opt, n_threads, d_seq, q_off);
 }
 
 void mg_map_frag(const mg_idx_t *gi, int n_segs, const int *qlens, const char **seqs, mg_gchains_t **gcs, mg_tbuf_t *b, const mg_mapopt_t *opt, const char *qname)

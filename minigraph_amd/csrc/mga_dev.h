@@ -26,27 +26,47 @@ void *mga_hmalloc_pinned(size_t bytes);        /* pinned host memory for fast PC
 void mga_hfree_pinned(void *p);
 double mga_wtime(void);
 
-/* per-kernel HIP-event timing on stream 0 (bench.py reads it through mga_prof_get) */
-enum { MGA_K_SKETCH = 0, MGA_K_SEED_COUNT, MGA_K_SEED_FILL, MGA_K_LCHAIN, MGA_K_WFA0 /* +tier: 0-3 register tiers (band 64..512), 4 LDS tier (band 1024), 5-7 HBM tiers */, MGA_K_SCAN = MGA_K_WFA0 + 8, MGA_K_N };
-#define MGA_WFA_N_TIER 8
-void mga_prof_enable(int on);
-void mga_prof_begin(int kid);
-void mga_prof_end(int kid);
-void mga_prof_collect(void);
-void mga_prof_get(double *ms, int64_t *launches, int reset); /* arrays of MGA_K_N */
-
 /* grow-only device buffer */
 typedef struct { void *p; size_t cap; } mga_dbuf_t;
 int  mga_dbuf_reserve(mga_dbuf_t *b, size_t bytes); /* contents are NOT preserved on growth */
 void mga_dbuf_free(mga_dbuf_t *b);
 
+/* ---- stream context: one HIP stream + the per-stream scratch of the WFA kernels.  Every launcher below takes one;
+ * two contexts let the mapping pipeline overlap the GPU work of one chunk with the host work of another. ---- */
+typedef struct mga_sctx_s {
+	void *stream;              /* hipStream_t */
+	mga_dbuf_t wfa_ws[8];      /* per-tier WFA workspaces */
+	mga_dbuf_t wfa_cnt;        /* work-queue counters */
+} mga_sctx_t;
+mga_sctx_t *mga_sctx_create(void);
+void mga_sctx_destroy(mga_sctx_t *sc);
+mga_sctx_t *mga_sctx_default(void);            /* lazily created, used by the stage-level API */
+int  mga_dev_bind_thread(void);                /* hipSetDevice() for threads other than the one that called mga_dev_init */
+int  mga_h2d_s(mga_sctx_t *sc, void *d, const void *h, size_t bytes);   /* async on sc->stream */
+int  mga_d2h_s(mga_sctx_t *sc, void *h, const void *d, size_t bytes);
+int  mga_dmemset_s(mga_sctx_t *sc, void *d, int v, size_t bytes);
+int  mga_ssync(mga_sctx_t *sc);
+typedef struct { void *p; size_t cap; } mga_hbuf_t;                     /* grow-only PINNED host buffer */
+int  mga_hbuf_reserve(mga_hbuf_t *b, size_t bytes);
+void mga_hbuf_free(mga_hbuf_t *b);
+
+/* per-kernel HIP-event timing on the launch stream (bench.py reads it through mga_prof_get) */
+enum { MGA_K_SKETCH = 0, MGA_K_SEED_COUNT, MGA_K_SEED_FILL, MGA_K_LCHAIN, MGA_K_WFA0 /* +tier: 0-3 register tiers (band 64..512), 4 LDS tier (band 1024), 5-7 HBM tiers */, MGA_K_SCAN = MGA_K_WFA0 + 8, MGA_K_N };
+#define MGA_WFA_N_TIER 8
+void mga_prof_enable(int on);
+void mga_prof_begin(mga_sctx_t *sc, int kid);
+void mga_prof_end(mga_sctx_t *sc, int kid);
+void mga_prof_collect(void);
+void mga_prof_get(double *ms, int64_t *launches, int reset); /* arrays of MGA_K_N */
+
+
 /* exclusive prefix sum of n int32 counts into n+1 int64 offsets, on device */
-int mga_dev_scan_i32_to_i64(const int32_t *d_cnt, int64_t n, int64_t *d_off);
+int mga_dev_scan_i32_to_i64(mga_sctx_t *sc, const int32_t *d_cnt, int64_t n, int64_t *d_off);
 
 /* ---- sketch (k_sketch.hip) ---- */
 /* pass 1 (d_mz == NULL): d_cnt[i] = number of minimizers of sequence i.
  * pass 2: writes minimizers of sequence i at d_mz + d_mz_off[i]. */
-int mga_dev_sketch(int n, const char *d_seq, const int64_t *d_off, const uint32_t *d_rid, int w, int k,
+int mga_dev_sketch(mga_sctx_t *sc, int n, const char *d_seq, const int64_t *d_off, const uint32_t *d_rid, int w, int k,
 				   int32_t *d_cnt, const int64_t *d_mz_off, mg128_t *d_mz);
 
 /* ---- device replica of the minimizer index (k_seed.hip) ---- */
@@ -63,19 +83,19 @@ typedef struct {
 /* collect_matches (map-algo.c:58-91), pass 1: probe every minimizer.  Flat per-minimizer outputs
  * d_occ[m] (occurrence count) and d_val[m] (slot value); per read d_na[i] (anchors), d_nmini[i]
  * (kept minimizers) and d_rep_len[i]. */
-int mga_dev_seed_count(const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, int max_occ,
+int mga_dev_seed_count(mga_sctx_t *sc, const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, int max_occ,
 					   int32_t *d_occ, uint64_t *d_val, int32_t *d_na, int32_t *d_nmini, int32_t *d_rep_len);
 /* collect_seed_hits (map-algo.c:152-192), pass 2: expand hits into anchors at d_a + d_a_off[i], write mini_pos at
  * d_mini + d_mini_off[i], then sort each read's anchors by x with the reference's exact permutation.
  * d_tmp: scratch of the same size as d_a. */
-int mga_dev_seed_fill(const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, int max_occ,
+int mga_dev_seed_fill(mga_sctx_t *sc, const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, int max_occ,
 					  const int32_t *d_occ, const uint64_t *d_val, const int64_t *d_a_off, mg128_t *d_a,
 					  const int64_t *d_mini_off, int32_t *d_mini, mg128_t *d_tmp);
 
 /* ---- linear chaining (k_lchain.hip) ---- */
 /* per read i with anchors d_a[a_off[i]..a_off[i+1]) (x-sorted): chains u[] (score<<32|cnt) at d_u + a_off[i],
  * compacted anchors at d_b + a_off[i]; d_nu[i], d_nb[i] = their counts.  d_ws: mga_dev_lchain_ws_bytes(total) bytes. */
-int mga_dev_lchain(int n, const mg128_t *d_a, const int64_t *d_a_off, const mga_lchain_par_t *par,
+int mga_dev_lchain(mga_sctx_t *sc, int n, const mg128_t *d_a, const int64_t *d_a_off, const mga_lchain_par_t *par,
 				   uint64_t *d_u, mg128_t *d_b, int32_t *d_nu, int32_t *d_nb, void *d_ws, size_t ws_bytes, int64_t total_anchors);
 size_t mga_dev_lchain_ws_bytes(int64_t total_anchors);
 
@@ -85,17 +105,17 @@ typedef struct { int32_t score, n_cigar; int64_t cig_off; int32_t status, pad; i
 enum { MGA_WFA_OK = 0, MGA_WFA_PENDING = 1, MGA_WFA_RETRY_TIER = 2, MGA_WFA_POOL_FULL = 3, MGA_WFA_MAX_ITER = 4 };
 /* solves problems d_list[0..n) (identity when d_list == NULL) in capacity tier 0..2; cigars are appended to d_pool
  * (capacity pool_cap ops, *d_pool_used bumped atomically); sequences must be padded by >= 8 readable bytes */
-int mga_dev_wfa(int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+int mga_dev_wfa(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 				mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier);
 /* the LDS-resident tiers (k_wfa_lds.hip): 0: band<=128, 1: band<=512, 2: band<=1024 */
-int mga_dev_wfa_lds(int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+int mga_dev_wfa_lds(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 					mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier);
 /* register-resident tiers (k_wfa_reg.hip): tier t covers a window of 64<<t diagonals */
-int mga_dev_wfa_reg(int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+int mga_dev_wfa_reg(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 					mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier);
 /* tier 0..7: register tiers, the LDS tier, then the HBM-resident tiers; a problem failing with MGA_WFA_RETRY_TIER moves up one */
 int mga_wfa_first_tier(int32_t tl, int32_t ql); /* cheapest tier likely to fit, from the sequence lengths */
-int mga_dev_wfa_tier(int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+int mga_dev_wfa_tier(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 					 mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier);
 
 #ifdef __cplusplus

@@ -24,6 +24,8 @@ extern "C" int mga_sketch_batch(int n, const char *seq, const int64_t *off, cons
 {
 	*mz = 0, *mz_off = 0;
 	if (mga_dev_init() < 0) return -1;
+	mga_sctx_t *SC = mga_sctx_default();
+	if (SC == 0) return -1;
 	if (n <= 0) { *mz_off = (int64_t*)calloc(1, 8); return 0; }
 	const int64_t tot = off[n];
 	dptr d_seq, d_off, d_rid, d_cnt, d_mzoff, d_mz;
@@ -31,15 +33,15 @@ extern "C" int mga_sketch_batch(int n, const char *seq, const int64_t *off, cons
 	if (rid && !d_rid.alloc(n * 4)) return -1;
 	if (mga_h2d(d_seq.p, seq, tot) < 0 || mga_h2d(d_off.p, off, (n + 1) * 8) < 0) return -1;
 	if (rid && mga_h2d(d_rid.p, rid, n * 4) < 0) return -1;
-	if (mga_dev_sketch(n, d_seq.as<char>(), d_off.as<int64_t>(), d_rid.as<uint32_t>(), w, k, d_cnt.as<int32_t>(), 0, 0) < 0) return -1;
-	if (mga_dev_scan_i32_to_i64(d_cnt.as<int32_t>(), n, d_mzoff.as<int64_t>()) < 0) return -1;
+	if (mga_dev_sketch(SC, n, d_seq.as<char>(), d_off.as<int64_t>(), d_rid.as<uint32_t>(), w, k, d_cnt.as<int32_t>(), 0, 0) < 0) return -1;
+	if (mga_dev_scan_i32_to_i64(SC, d_cnt.as<int32_t>(), n, d_mzoff.as<int64_t>()) < 0) return -1;
 	int64_t *h_off = (int64_t*)malloc((n + 1) * 8);
-	if (mga_d2h(h_off, d_mzoff.p, (n + 1) * 8) < 0) { free(h_off); return -1; }
+	if (mga_ssync(SC) < 0 || mga_d2h(h_off, d_mzoff.p, (n + 1) * 8) < 0) { free(h_off); return -1; }
 	const int64_t n_mz = h_off[n];
 	if (!d_mz.alloc((size_t)n_mz * 16 + 16)) { free(h_off); return -1; }
-	if (mga_dev_sketch(n, d_seq.as<char>(), d_off.as<int64_t>(), d_rid.as<uint32_t>(), w, k, 0, d_mzoff.as<int64_t>(), d_mz.as<mg128_t>()) < 0) { free(h_off); return -1; }
+	if (mga_dev_sketch(SC, n, d_seq.as<char>(), d_off.as<int64_t>(), d_rid.as<uint32_t>(), w, k, 0, d_mzoff.as<int64_t>(), d_mz.as<mg128_t>()) < 0) { free(h_off); return -1; }
 	mg128_t *h_mz = (mg128_t*)malloc((size_t)n_mz * 16 + 16);
-	if (mga_d2h(h_mz, d_mz.p, (size_t)n_mz * 16) < 0 || mga_dsync() < 0) { free(h_off); free(h_mz); return -1; }
+	if (mga_ssync(SC) < 0 || mga_d2h(h_mz, d_mz.p, (size_t)n_mz * 16) < 0) { free(h_off); free(h_mz); return -1; }
 	*mz = h_mz, *mz_off = h_off;
 	return 0;
 }
@@ -49,6 +51,8 @@ extern "C" int mga_wfa_batch(int n, const char *tseq, const int64_t *t_off, cons
 {
 	*score = 0, *cigar = 0, *cig_off = 0;
 	if (mga_dev_init() < 0) return -1;
+	mga_sctx_t *SC = mga_sctx_default();
+	if (SC == 0) return -1;
 	if (n <= 0) { *cig_off = (int64_t*)calloc(1, 8); return 0; }
 	const int64_t tt = t_off[n], tq = q_off[n];
 	std::vector<mga_wfa_prob_t> prob(n);
@@ -62,13 +66,13 @@ extern "C" int mga_wfa_batch(int n, const char *tseq, const int64_t *t_off, cons
 	if (!d_t.alloc(tt + 64) || !d_q.alloc(tq + 64) || !d_prob.alloc((size_t)n * sizeof(mga_wfa_prob_t)) ||
 		!d_res.alloc((size_t)n * sizeof(mga_wfa_res_t)) || !d_used.alloc(8)) return -1;
 	if (mga_h2d(d_t.p, tseq, tt) < 0 || mga_h2d(d_q.p, qseq, tq) < 0 || mga_h2d(d_prob.p, prob.data(), (size_t)n * sizeof(mga_wfa_prob_t)) < 0) return -1;
-	if (mga_dmemset((char*)d_t.p + tt, 0, 64) < 0 || mga_dmemset((char*)d_q.p + tq, 0, 64) < 0) return -1;
+	if (mga_dmemset_s(SC, (char*)d_t.p + tt, 0, 64) < 0 || mga_dmemset_s(SC, (char*)d_q.p + tq, 0, 64) < 0) return -1;
 
 	std::vector<mga_wfa_res_t> res(n);
 	std::vector<int8_t> tier_of(n);
 	std::vector<int32_t> todo;
 	for (int i = 0; i < n; ++i) tier_of[i] = (int8_t)mga_wfa_first_tier(prob[i].tl, prob[i].ql);
-	if (!d_pool.alloc((size_t)pool_cap * 4) || !d_list.alloc((size_t)n * 4) || mga_dmemset(d_used.p, 0, 8) < 0) return -1;
+	if (!d_pool.alloc((size_t)pool_cap * 4) || !d_list.alloc((size_t)n * 4) || mga_dmemset_s(SC, d_used.p, 0, 8) < 0) return -1;
 	for (int pass = 0;; ++pass) { // first pass: every problem in the tier its length suggests; then only the ones that outgrew it, one tier up
 		int64_t n_left = 0;
 		for (int t = 0; t < MGA_WFA_N_TIER; ++t) {
@@ -76,12 +80,12 @@ extern "C" int mga_wfa_batch(int n, const char *tseq, const int64_t *t_off, cons
 			for (int i = 0; i < n; ++i) if (tier_of[i] == t) todo.push_back(i);
 			if (todo.empty()) continue;
 			if (mga_h2d((int32_t*)d_list.p + n_left, todo.data(), todo.size() * 4) < 0) return -1;
-			if (mga_dev_wfa_tier((int)todo.size(), (const int32_t*)d_list.p + n_left, d_prob.as<mga_wfa_prob_t>(), d_t.as<char>(), d_q.as<char>(), d_res.as<mga_wfa_res_t>(),
+			if (mga_dev_wfa_tier(SC, (int)todo.size(), (const int32_t*)d_list.p + n_left, d_prob.as<mga_wfa_prob_t>(), d_t.as<char>(), d_q.as<char>(), d_res.as<mga_wfa_res_t>(),
 								 d_pool.as<uint32_t>(), pool_cap, (unsigned long long*)d_used.p, t) < 0) return -1;
 			n_left += (int64_t)todo.size();
 		}
 		if (n_left == 0) break;
-		if (mga_dsync() < 0 || mga_d2h(res.data(), d_res.p, (size_t)n * sizeof(mga_wfa_res_t)) < 0) return -1;
+		if (mga_ssync(SC) < 0 || mga_d2h(res.data(), d_res.p, (size_t)n * sizeof(mga_wfa_res_t)) < 0) return -1;
 		bool again = false;
 		for (int i = 0; i < n; ++i) {
 			if (tier_of[i] < 0) continue;
@@ -94,7 +98,7 @@ extern "C" int mga_wfa_batch(int n, const char *tseq, const int64_t *t_off, cons
 		if (!again) break;
 	}
 	unsigned long long used = 0;
-	if (mga_d2h(&used, d_used.p, 8) < 0) return -1;
+	if (mga_ssync(SC) < 0 || mga_d2h(&used, d_used.p, 8) < 0) return -1;
 	std::vector<uint32_t> hpool((size_t)used + 1);
 	if (used && mga_d2h(hpool.data(), d_pool.p, (size_t)used * 4) < 0) return -1;
 	int32_t *h_score = (int32_t*)malloc((size_t)n * 4);
@@ -117,6 +121,8 @@ extern "C" int mga_seed_batch(const mg_idx_t *gi, int n, const mg128_t *mz, cons
 {
 	*a = 0, *a_off = 0, *rep_len = 0, *mini_pos = 0, *mini_off = 0;
 	if (mga_dev_init() < 0) return -1;
+	mga_sctx_t *SC = mga_sctx_default();
+	if (SC == 0) return -1;
 	if (n <= 0) { *a_off = (int64_t*)calloc(1, 8); *mini_off = (int64_t*)calloc(1, 8); return 0; }
 	const mga_didx_t *ix = &((const mg_idx_bucket_s_view*)gi->B)->dev;
 	const int64_t n_mz = mz_off[n];
@@ -124,20 +130,20 @@ extern "C" int mga_seed_batch(const mg_idx_t *gi, int n, const mg128_t *mz, cons
 	if (!d_mz.alloc((size_t)n_mz * 16 + 16) || !d_mzoff.alloc((n + 1) * 8) || !d_occ.alloc((size_t)n_mz * 4 + 4) || !d_val.alloc((size_t)n_mz * 8 + 8) ||
 		!d_na.alloc(n * 4) || !d_nmini.alloc(n * 4) || !d_rep.alloc(n * 4) || !d_aoff.alloc((n + 1) * 8) || !d_minioff.alloc((n + 1) * 8)) return -1;
 	if (mga_h2d(d_mz.p, mz, (size_t)n_mz * 16) < 0 || mga_h2d(d_mzoff.p, mz_off, (n + 1) * 8) < 0) return -1;
-	if (mga_dev_seed_count(ix, n, d_mz.as<mg128_t>(), d_mzoff.as<int64_t>(), max_occ, d_occ.as<int32_t>(), d_val.as<uint64_t>(),
+	if (mga_dev_seed_count(SC, ix, n, d_mz.as<mg128_t>(), d_mzoff.as<int64_t>(), max_occ, d_occ.as<int32_t>(), d_val.as<uint64_t>(),
 						   d_na.as<int32_t>(), d_nmini.as<int32_t>(), d_rep.as<int32_t>()) < 0) return -1;
-	if (mga_dev_scan_i32_to_i64(d_na.as<int32_t>(), n, d_aoff.as<int64_t>()) < 0) return -1;
-	if (mga_dev_scan_i32_to_i64(d_nmini.as<int32_t>(), n, d_minioff.as<int64_t>()) < 0) return -1;
+	if (mga_dev_scan_i32_to_i64(SC, d_na.as<int32_t>(), n, d_aoff.as<int64_t>()) < 0) return -1;
+	if (mga_dev_scan_i32_to_i64(SC, d_nmini.as<int32_t>(), n, d_minioff.as<int64_t>()) < 0) return -1;
 	int64_t *h_aoff = (int64_t*)malloc((n + 1) * 8), *h_moff = (int64_t*)malloc((n + 1) * 8);
 	int32_t *h_rep = (int32_t*)malloc(n * 4);
-	if (mga_d2h(h_aoff, d_aoff.p, (n + 1) * 8) < 0 || mga_d2h(h_moff, d_minioff.p, (n + 1) * 8) < 0 || mga_d2h(h_rep, d_rep.p, n * 4) < 0) return -1;
+	if (mga_ssync(SC) < 0 || mga_d2h(h_aoff, d_aoff.p, (n + 1) * 8) < 0 || mga_d2h(h_moff, d_minioff.p, (n + 1) * 8) < 0 || mga_d2h(h_rep, d_rep.p, n * 4) < 0) return -1;
 	const int64_t n_a = h_aoff[n], n_m = h_moff[n];
 	if (!d_a.alloc((size_t)n_a * 16 + 64) || !d_tmp.alloc((size_t)n_a * 16 + 64) || !d_mini.alloc((size_t)n_m * 4 + 16)) return -1;
-	if (mga_dev_seed_fill(ix, n, d_mz.as<mg128_t>(), d_mzoff.as<int64_t>(), max_occ, d_occ.as<int32_t>(), d_val.as<uint64_t>(),
+	if (mga_dev_seed_fill(SC, ix, n, d_mz.as<mg128_t>(), d_mzoff.as<int64_t>(), max_occ, d_occ.as<int32_t>(), d_val.as<uint64_t>(),
 						  d_aoff.as<int64_t>(), d_a.as<mg128_t>(), d_minioff.as<int64_t>(), d_mini.as<int32_t>(), d_tmp.as<mg128_t>()) < 0) return -1;
 	mg128_t *h_a = (mg128_t*)malloc((size_t)n_a * 16 + 16);
 	int32_t *h_mini = (int32_t*)malloc((size_t)n_m * 4 + 4);
-	if (mga_d2h(h_a, d_a.p, (size_t)n_a * 16) < 0 || mga_d2h(h_mini, d_mini.p, (size_t)n_m * 4) < 0 || mga_dsync() < 0) return -1;
+	if (mga_ssync(SC) < 0 || mga_d2h(h_a, d_a.p, (size_t)n_a * 16) < 0 || mga_d2h(h_mini, d_mini.p, (size_t)n_m * 4) < 0) return -1;
 	*a = h_a, *a_off = h_aoff, *rep_len = h_rep, *mini_pos = h_mini, *mini_off = h_moff;
 	return 0;
 }
@@ -147,6 +153,8 @@ extern "C" int mga_lchain_batch(int n, const mg128_t *a, const int64_t *a_off, c
 {
 	*u = 0, *u_off = 0, *b = 0, *b_off = 0;
 	if (mga_dev_init() < 0) return -1;
+	mga_sctx_t *SC = mga_sctx_default();
+	if (SC == 0) return -1;
 	if (n <= 0) { *u_off = (int64_t*)calloc(1, 8); *b_off = (int64_t*)calloc(1, 8); return 0; }
 	const int64_t tot = a_off[n];
 	dptr d_a, d_aoff, d_u, d_b, d_nu, d_nb, d_ws;
@@ -154,12 +162,12 @@ extern "C" int mga_lchain_batch(int n, const mg128_t *a, const int64_t *a_off, c
 	if (!d_a.alloc((size_t)tot * 16 + 16) || !d_aoff.alloc((n + 1) * 8) || !d_u.alloc((size_t)tot * 8 + 8) || !d_b.alloc((size_t)tot * 16 + 16) ||
 		!d_nu.alloc(n * 4) || !d_nb.alloc(n * 4) || !d_ws.alloc(wsb)) return -1;
 	if (mga_h2d(d_a.p, a, (size_t)tot * 16) < 0 || mga_h2d(d_aoff.p, a_off, (n + 1) * 8) < 0) return -1;
-	if (mga_dev_lchain(n, d_a.as<mg128_t>(), d_aoff.as<int64_t>(), par, d_u.as<uint64_t>(), d_b.as<mg128_t>(), d_nu.as<int32_t>(), d_nb.as<int32_t>(),
+	if (mga_dev_lchain(SC, n, d_a.as<mg128_t>(), d_aoff.as<int64_t>(), par, d_u.as<uint64_t>(), d_b.as<mg128_t>(), d_nu.as<int32_t>(), d_nb.as<int32_t>(),
 					   d_ws.p, wsb, tot) < 0) return -1;
 	std::vector<int32_t> nu(n), nb(n);
 	std::vector<uint64_t> hu((size_t)tot + 1);
 	std::vector<mg128_t> hb((size_t)tot + 1);
-	if (mga_dsync() < 0 || mga_d2h(nu.data(), d_nu.p, n * 4) < 0 || mga_d2h(nb.data(), d_nb.p, n * 4) < 0 ||
+	if (mga_ssync(SC) < 0 || mga_d2h(nu.data(), d_nu.p, n * 4) < 0 || mga_d2h(nb.data(), d_nb.p, n * 4) < 0 ||
 		mga_d2h(hu.data(), d_u.p, (size_t)tot * 8) < 0 || mga_d2h(hb.data(), d_b.p, (size_t)tot * 16) < 0) return -1;
 	int64_t *uo = (int64_t*)malloc((n + 1) * 8), *bo = (int64_t*)malloc((n + 1) * 8);
 	int64_t tu = 0, tb = 0;
