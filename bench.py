@@ -111,9 +111,9 @@ def main():
     log("[bench] rank %d: gen %.1fs, load+index %.1fs, %d reads / %d bp resident, %d host threads" % (rank, t_gen, t_index, R.n, R.bases, threads))
 
     def step():
-        gaf = mga.map_reads(G, R, n_threads=threads)
+        gaf = mga.map_reads(G, R, n_threads=threads, copy=False)   # GAF text stays in the C library's buffer
         if dist is not None:  # RCCL over xGMI: gather the GAF bytes of every rank to rank 0
-            gather_bytes(gaf, dst=0, device="cuda")
+            gather_bytes(gaf.bytes(), dst=0, device="cuda")
         return gaf
 
     def sync():
@@ -182,6 +182,7 @@ def main():
                 cb, cpu_gaf, n_cpu = cpu_baseline(ref_bin, graph_path, reads_path, args.cpu_reads, d, ncpu)
                 res["cpu_baseline"] = cb
                 want = open(cpu_gaf, "rb").read()
+                gaf = gaf.bytes()
                 res["parity"] = "GAF byte-identical to the reference on the %d-read sample" % n_cpu if gaf[:len(want)] == want and (len(gaf) == len(want) or gaf[len(want) - 1:len(want)] == b"\n") else "MISMATCH vs reference GAF"
             except Exception as e:  # the baseline is a reported number, never a reason to lose the bench line
                 res["cpu_baseline"] = dict(value=None, unit="Gbp/s", cores=ncpu, kind="reference", sample="failed: %r" % (e,))

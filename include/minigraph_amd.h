@@ -278,7 +278,7 @@ int mga_map_batch_resident(const mg_idx_t *gi, int n, const int *qlens, const ch
 typedef struct {
 	int64_t n_reads, n_bases, n_mz, n_probe, n_hit, n_anchor_chained;
 	int64_t n_wfa, wfa_t_bases, wfa_q_bases, wfa_cells, gaf_bytes;
-	double t_sketch, t_seed, t_lchain, t_host_chain, t_wfa, t_host_post; /* seconds, summed */
+	double t_sketch, t_seed, t_lchain, t_host_chain, t_wfa, t_host_post, t_gaf; /* seconds, summed over pipeline threads */
 } mga_stats_t;
 void mga_get_stats(const mg_idx_t *gi, mga_stats_t *st, int reset);
 

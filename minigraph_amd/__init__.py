@@ -67,7 +67,7 @@ KERNELS = ["k_sketch", "k_seed_count", "k_seed_fill", "k_lchain", "k_wfa_reg[64]
 class stats_t(C.Structure):  # mga_stats_t
     _fields_ = [(n, C.c_int64) for n in ("n_reads", "n_bases", "n_mz", "n_probe", "n_hit", "n_anchor_chained", "n_wfa",
                                          "wfa_t_bases", "wfa_q_bases", "wfa_cells", "gaf_bytes")] + \
-               [(n, C.c_double) for n in ("t_sketch", "t_seed", "t_lchain", "t_host_chain", "t_wfa", "t_host_post")]
+               [(n, C.c_double) for n in ("t_sketch", "t_seed", "t_lchain", "t_host_chain", "t_wfa", "t_host_post", "t_gaf")]
 
 
 def load():
@@ -261,13 +261,43 @@ class Reads:
         self.h = None
 
 
-def map_reads(graph, reads, n_threads=8):
-    """one pass of the hot path over a resident read set -> GAF bytes"""
+class GafBuffer:
+    """the GAF text of one pass, owned by the C library (no copy until bytes() is asked for)"""
+
+    def __init__(self, ptr, n):
+        self.ptr, self.n = ptr, n
+
+    def __len__(self):
+        return self.n
+
+    def view(self):
+        return np.ctypeslib.as_array(C.cast(self.ptr, C.POINTER(C.c_uint8)), shape=(self.n,)) if self.n else np.zeros(0, dtype=np.uint8)
+
+    def bytes(self):
+        return C.string_at(self.ptr, self.n)
+
+    def free(self):
+        if self.ptr:
+            load().mga_free(self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def map_reads(graph, reads, n_threads=8, copy=True):
+    """one pass of the hot path over a resident read set -> GAF bytes (or a GafBuffer when copy=False)"""
     L = load()
     buf, n = C.c_void_p(), C.c_int64(0)
     _check(L.mga_map_reads(graph.gi, reads.h, C.byref(graph.mo), n_threads, C.byref(buf), C.byref(n)), "mga_map_reads")
-    out = C.string_at(buf, n.value)
-    L.mga_free(buf)
+    gb = GafBuffer(buf, n.value)
+    if not copy:
+        return gb
+    out = gb.bytes()
+    gb.free()
     return out
 
 

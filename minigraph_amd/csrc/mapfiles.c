@@ -114,48 +114,15 @@ void mga_reads_free(mga_reads_t *rd)
 int mga_reads_count(const mga_reads_t *rd) { return rd->n; }
 int64_t mga_reads_bases(const mga_reads_t *rd) { return rd->n_bases; }
 
-typedef struct { const mg_idx_t *gi; const mga_reads_t *rd; mg_gchains_t **gcs; uint64_t flag; int n_threads; kstring_t *part; } gafw_t;
+int mga_map_gaf(const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, const mg_mapopt_t *opt, int n_threads,
+				const char *d_seq, const int64_t *q_off, char **gaf, int64_t *gaf_len);
 
-static void gaf_worker(void *data, int64_t t, int tid)
-{
-	gafw_t *w = (gafw_t*)data;
-	const int n = w->rd->n;
-	int64_t b = (int64_t)n * t / w->n_threads, e = (int64_t)n * (t + 1) / w->n_threads, i;
-	kstring_t one = {0, 0, 0}, *out = &w->part[t];
-	(void)tid;
-	for (i = b; i < e; ++i) {
-		int32_t ql = w->rd->qlens[i];
-		mg_write_gaf(&one, w->gi->g, w->gcs[i], 1, &ql, w->rd->names[i], w->flag, 0);
-		if (one.l) {
-			if (out->l + one.l + 1 > out->m) { size_t m = ((size_t)out->l + one.l + 1) * 3 / 2; out->m = (unsigned)m; out->s = (char*)realloc(out->s, out->m); }
-			memcpy(out->s + out->l, one.s, one.l); out->l += one.l;
-		}
-	}
-	free(one.s);
-}
-
-/* map a resident read set and format its GAF (input order) into one malloc'ed buffer */
+/* map a resident read set and format its GAF (input order) into one malloc'ed buffer; formatting runs inside the
+ * mapping pipeline, chunk by chunk */
 int mga_map_reads(const mg_idx_t *gi, const mga_reads_t *rd, const mg_mapopt_t *opt, int n_threads, char **gaf, int64_t *gaf_len)
 {
-	mg_gchains_t **gcs = MGA_CALLOC(mg_gchains_t*, rd->n > 0 ? rd->n : 1);
-	gafw_t w;
-	int t, i, rc;
-	int64_t tot = 0;
-	*gaf = 0, *gaf_len = 0;
 	if (n_threads < 1) n_threads = 1;
-	rc = mga_map_batch_resident(gi, rd->n, rd->qlens, (const char**)rd->seqs, (const char**)rd->names, gcs, opt, n_threads, rd->d_seq, rd->q_off);
-	if (rc < 0) { free(gcs); return rc; }
-	w.gi = gi, w.rd = rd, w.gcs = gcs, w.flag = opt->flag, w.n_threads = n_threads;
-	w.part = MGA_CALLOC(kstring_t, n_threads);
-	mga_parallel_for(n_threads, n_threads, gaf_worker, &w);
-	for (t = 0; t < n_threads; ++t) tot += w.part[t].l;
-	*gaf = (char*)malloc((size_t)tot + 1);
-	for (t = 0, tot = 0; t < n_threads; ++t) { memcpy(*gaf + tot, w.part[t].s, w.part[t].l); tot += w.part[t].l; free(w.part[t].s); }
-	(*gaf)[tot] = 0, *gaf_len = tot;
-	gi->B->st.gaf_bytes += tot;
-	for (i = 0; i < rd->n; ++i) mg_gchain_free(gcs[i]);
-	free(gcs); free(w.part);
-	return 0;
+	return mga_map_gaf(gi, rd->n, rd->qlens, (const char**)rd->seqs, (const char**)rd->names, opt, n_threads, rd->d_seq, rd->q_off, gaf, gaf_len);
 }
 
 int mg_map_files_fp(gfa_t *g, int n_fn, const char **fn, const mg_idxopt_t *ipt, const mg_mapopt_t *opt0, int n_threads, FILE *out)

@@ -183,18 +183,26 @@ int mga_batch_chain(mga_batch_t *b, const int32_t *n_mz, const int32_t *rep_len,
 int64_t mga_batch_n_wfa(const mga_batch_t *b) { return b->tp_prob_base[b->n_threads]; }
 int64_t mga_batch_wfa_target_bytes(const mga_batch_t *b) { return b->tp_t_base[b->n_threads]; }
 
+typedef struct { const mga_batch_t *b; mga_wfa_prob_t *prob; char *tseq; } export_t;
+static void export_worker(void *data, int64_t t, int tid)
+{
+	export_t *e = (export_t*)data;
+	const mga_batch_t *b = e->b;
+	const mga_tpool_t *tp = &b->tp[t];
+	int64_t j;
+	(void)tid;
+	memcpy(e->tseq + b->tp_t_base[t], tp->tseq, (size_t)tp->n_t);
+	for (j = 0; j < tp->n_prob; ++j) {
+		e->prob[b->tp_prob_base[t] + j] = tp->prob[j];
+		e->prob[b->tp_prob_base[t] + j].t_off += b->tp_t_base[t];
+	}
+}
+
 void mga_batch_wfa_export(const mga_batch_t *b, mga_wfa_prob_t *prob, char *tseq)
 {
-	int t;
-	int64_t j;
-	for (t = 0; t < b->n_threads; ++t) {
-		const mga_tpool_t *tp = &b->tp[t];
-		memcpy(tseq + b->tp_t_base[t], tp->tseq, (size_t)tp->n_t);
-		for (j = 0; j < tp->n_prob; ++j) {
-			prob[b->tp_prob_base[t] + j] = tp->prob[j];
-			prob[b->tp_prob_base[t] + j].t_off += b->tp_t_base[t];
-		}
-	}
+	export_t e;
+	e.b = b, e.prob = prob, e.tseq = tseq;
+	mga_parallel_for(b->n_threads, b->n_threads, export_worker, &e);
 }
 
 static void finish_worker(void *data, int64_t i, int tid)
@@ -438,9 +446,32 @@ typedef struct {
 	volatile int next, err;
 	pthread_mutex_t mtx;
 	char errmsg[512];
+	kstring_t *gaf_part; /* when non-NULL: n_chunks * n_threads GAF pieces, in read order; chains are freed after formatting */
 } pipe_job_t;
 
 typedef struct { pipe_job_t *job; pipe_ctx_t *P; mga_stats_t st; } pipe_thr_t;
+
+typedef struct { pipe_job_t *J; int st, en, T; kstring_t *part; } gafw_t;
+
+static void gaf_worker(void *data, int64_t t, int tid)
+{
+	gafw_t *w = (gafw_t*)data;
+	pipe_job_t *J = w->J;
+	const int n = w->en - w->st;
+	int64_t b = w->st + (int64_t)n * t / w->T, e = w->st + (int64_t)n * (t + 1) / w->T, i;
+	kstring_t one = {0, 0, 0}, *out = &w->part[t];
+	(void)tid;
+	for (i = b; i < e; ++i) {
+		int32_t ql = J->qlens[i];
+		mg_write_gaf(&one, J->gi->g, J->gcs[i], 1, &ql, J->qnames ? J->qnames[i] : "*", J->opt->flag, 0);
+		if (one.l) {
+			if ((size_t)out->l + one.l + 1 > out->m) { size_t m = ((size_t)out->l + one.l + 1) * 3 / 2 + 65536; out->m = (unsigned)m; out->s = (char*)realloc(out->s, out->m); }
+			memcpy(out->s + out->l, one.s, one.l); out->l += one.l;
+		}
+		mg_gchain_free(J->gcs[i]); J->gcs[i] = 0;
+	}
+	free(one.s);
+}
 
 static void *pipe_worker(void *a)
 {
@@ -458,14 +489,24 @@ static void *pipe_worker(void *a)
 			pthread_mutex_unlock(&J->mtx);
 			break;
 		}
+		if (J->gaf_part) { /* GAF text of this chunk, formatted while the other pipeline thread owns the GPU */
+			gafw_t w;
+			double t0 = mga_wtime();
+			w.J = J, w.st = st, w.en = en, w.T = J->n_threads, w.part = J->gaf_part + (size_t)c * J->n_threads;
+			mga_parallel_for(J->n_threads, J->n_threads, gaf_worker, &w);
+			t->st.t_gaf += mga_wtime() - t0;
+		}
 	}
 	return 0;
 }
 
 static int env_int(const char *name, int dflt) { const char *s = getenv(name); return s && *s ? atoi(s) : dflt; }
 
+typedef struct { kstring_t *part; int64_t *off; char *dst; } gcopy_t;
+static void gaf_copy_worker(void *data, int64_t i, int tid) { gcopy_t *g = (gcopy_t*)data; (void)tid; if (g->part[i].l) memcpy(g->dst + g->off[i], g->part[i].s, g->part[i].l); free(g->part[i].s); }
+
 static int map_all(const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs,
-				   const mg_mapopt_t *opt, int n_threads, const char *d_seq, const int64_t *q_off)
+				   const mg_mapopt_t *opt, int n_threads, const char *d_seq, const int64_t *q_off, char **gaf, int64_t *gaf_len)
 {
 	pipe_job_t J;
 	pipe_thr_t thr[MGA_MAX_PIPE];
@@ -483,6 +524,7 @@ static int map_all(const mg_idx_t *gi, int n, const int *qlens, const char **seq
 	if (n_pipe > n_chunks) n_pipe = n_chunks;
 	if (n_pipe < 1) n_pipe = 1;
 	J.n_threads = n_threads / n_pipe > 0 ? n_threads / n_pipe : 1;
+	if (gaf) J.gaf_part = MGA_CALLOC(kstring_t, (size_t)n_chunks * J.n_threads);
 	pthread_mutex_init(&J.mtx, 0);
 	for (i = 0; i < n_pipe; ++i) {
 		if (g_pipe[i].sc == 0 && (g_pipe[i].sc = mga_sctx_create()) == 0) return -1;
@@ -501,19 +543,47 @@ static int map_all(const mg_idx_t *gi, int n, const int *qlens, const char **seq
 		d->n_anchor_chained += s->n_anchor_chained, d->n_wfa += s->n_wfa, d->wfa_t_bases += s->wfa_t_bases, d->wfa_q_bases += s->wfa_q_bases;
 		d->wfa_cells += s->wfa_cells;
 		d->t_sketch += s->t_sketch, d->t_seed += s->t_seed, d->t_lchain += s->t_lchain, d->t_host_chain += s->t_host_chain, d->t_wfa += s->t_wfa, d->t_host_post += s->t_host_post;
+		d->t_gaf += s->t_gaf;
 	}
 	if (J.err) {
 		for (i = 0; i < n; ++i) { mg_gchain_free(gcs[i]); gcs[i] = 0; }
+		if (J.gaf_part) { for (i = 0; i < n_chunks * J.n_threads; ++i) free(J.gaf_part[i].s); free(J.gaf_part); }
 		mga_set_error("%s", J.errmsg[0] ? J.errmsg : "mapping pipeline failed");
 		return -1;
 	}
+	if (gaf) { /* stitch the pieces (already in read order) into one buffer, copies in parallel */
+		const int64_t np = (int64_t)n_chunks * J.n_threads;
+		gcopy_t g;
+		int64_t tot = 0, k;
+		double t0 = mga_wtime();
+		g.part = J.gaf_part, g.off = MGA_MALLOC(int64_t, np + 1);
+		for (k = 0; k < np; ++k) g.off[k] = tot, tot += J.gaf_part[k].l;
+		g.dst = (char*)malloc((size_t)tot + 1);
+		mga_parallel_for(n_threads, np, gaf_copy_worker, &g);
+		g.dst[tot] = 0;
+		*gaf = g.dst, *gaf_len = tot;
+		gi->B->st.gaf_bytes += tot, gi->B->st.t_gaf += mga_wtime() - t0;
+		free(g.off); free(J.gaf_part);
+	}
 	return 0;
+}
+
+/* map + format: the GAF text (input order) of n reads in one malloc'ed buffer; chains are not returned */
+int mga_map_gaf(const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, const mg_mapopt_t *opt, int n_threads,
+				const char *d_seq, const int64_t *q_off, char **gaf, int64_t *gaf_len)
+{
+	mg_gchains_t **gcs = MGA_CALLOC(mg_gchains_t*, n > 0 ? n : 1);
+	int rc;
+	*gaf = 0, *gaf_len = 0;
+	rc = map_all(gi, n, qlens, seqs, qnames, gcs, opt, n_threads, d_seq, q_off, gaf, gaf_len);
+	free(gcs);
+	return rc;
 }
 
 int mg_map_batch(const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs,
 				 const mg_mapopt_t *opt, int n_threads)
 {
-	return map_all(gi, n, qlens, seqs, qnames, gcs, opt, n_threads, 0, 0);
+	return map_all(gi, n, qlens, seqs, qnames, gcs, opt, n_threads, 0, 0, 0, 0);
 }
 
 /* same as mg_map_batch() for reads that already sit in HBM: d_seq holds the reads back to back (+64 readable bytes),
@@ -521,7 +591,7 @@ int mg_map_batch(const mg_idx_t *gi, int n, const int *qlens, const char **seqs,
 int mga_map_batch_resident(const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs,
 						   const mg_mapopt_t *opt, int n_threads, const char *d_seq, const int64_t *q_off)
 {
-	return map_all(gi, n, qlens, seqs, qnames, gcs, opt, n_threads, d_seq, q_off);
+	return map_all(gi, n, qlens, seqs, qnames, gcs, opt, n_threads, d_seq, q_off, 0, 0);
 }
 
 void mg_map_frag(const mg_idx_t *gi, int n_segs, const int *qlens, const char **seqs, mg_gchains_t **gcs, mg_tbuf_t *b, const mg_mapopt_t *opt, const char *qname)
