@@ -65,12 +65,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=20000, help="reads per GPU per step")
+    ap.add_argument("--reads", type=int, default=40000, help="reads per GPU per step")
     ap.add_argument("--genome", type=int, default=50000000)
     ap.add_argument("--hap", type=int, default=3)
-    ap.add_argument("--cpu-reads", type=int, default=4000)
+    ap.add_argument("--cpu-reads", type=int, default=20000)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--threads", type=int, default=0, help="host threads per rank (0: all cores / ranks)")
+    ap.add_argument("--threads", type=int, default=0, help="host threads per rank (0: min(64, cores / ranks); more oversubscribes the host stages)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,7 +94,7 @@ def main():
     if L.mga_device_count() <= 0:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     ncpu = os.cpu_count() or 1
-    threads = args.threads or max(1, ncpu // world)
+    threads = args.threads or max(1, min(64, ncpu // world))
 
     # ---- synthetic workload (untimed) ----
     d = tempfile.mkdtemp(prefix="mga_bench_r%d_" % rank)

@@ -60,8 +60,8 @@ class ggopt_t(C.Structure):
 
 MG_M_CIGAR = 0x4000000
 
-KERNELS = ["k_sketch", "k_seed_count", "k_seed_fill", "k_lchain", "k_wfa_reg[64]", "k_wfa_reg[128]", "k_wfa_reg[256]", "k_wfa_reg[512]",
-           "k_wfa_lds[1024]", "k_wfa[hbm0]", "k_wfa[hbm1]", "k_wfa[hbm2]", "k_scan"]
+KERNELS = ["k_sketch", "k_seed_count", "k_seed_fill", "k_lchain", "k_wfa_reg[64]", "k_wfa_reg[128]", "k_wfa_regw[256]", "k_wfa_regw[512]",
+           "k_wfa_regw[1024]", "k_wfa[hbm4096]", "k_wfa[hbm32768]", "unused", "k_scan"]
 
 
 class stats_t(C.Structure):  # mga_stats_t

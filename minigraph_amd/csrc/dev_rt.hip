@@ -68,6 +68,12 @@ extern "C" mga_sctx_t *mga_sctx_create(void)
 	hipStream_t st;
 	if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { free(sc); mga_set_error("hipStreamCreate failed"); return 0; }
 	sc->stream = (void*)st;
+	for (int i = 0; i < 8; ++i) {
+		hipStream_t t; hipEvent_t e;
+		if (hipStreamCreateWithFlags(&t, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { mga_set_error("hipStreamCreate failed"); return 0; }
+		sc->tier_stream[i] = (void*)t, sc->ev_done[i] = (void*)e;
+	}
+	{ hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return 0; sc->ev_ready = (void*)e; }
 	return sc;
 }
 
@@ -77,8 +83,28 @@ extern "C" void mga_sctx_destroy(mga_sctx_t *sc)
 	(void)hipStreamSynchronize((hipStream_t)sc->stream);
 	for (int i = 0; i < 8; ++i) mga_dbuf_free(&sc->wfa_ws[i]);
 	mga_dbuf_free(&sc->wfa_cnt);
+	for (int i = 0; i < 8; ++i) { (void)hipStreamDestroy((hipStream_t)sc->tier_stream[i]); (void)hipEventDestroy((hipEvent_t)sc->ev_done[i]); }
+	(void)hipEventDestroy((hipEvent_t)sc->ev_ready);
 	(void)hipStreamDestroy((hipStream_t)sc->stream);
 	free(sc);
+}
+
+extern "C" void *mga_wfa_stream(mga_sctx_t *sc, int slot) { return sc->tier_stream[slot & 7]; }
+
+extern "C" int mga_wfa_fork(mga_sctx_t *sc)
+{
+	MGA_HIP_CHECK(hipEventRecord((hipEvent_t)sc->ev_ready, (hipStream_t)sc->stream));
+	for (int i = 0; i < 8; ++i) MGA_HIP_CHECK(hipStreamWaitEvent((hipStream_t)sc->tier_stream[i], (hipEvent_t)sc->ev_ready, 0));
+	return 0;
+}
+
+extern "C" int mga_wfa_join(mga_sctx_t *sc)
+{
+	for (int i = 0; i < 8; ++i) {
+		MGA_HIP_CHECK(hipEventRecord((hipEvent_t)sc->ev_done[i], (hipStream_t)sc->tier_stream[i]));
+		MGA_HIP_CHECK(hipStreamWaitEvent((hipStream_t)sc->stream, (hipEvent_t)sc->ev_done[i], 0));
+	}
+	return 0;
 }
 
 extern "C" mga_sctx_t *mga_sctx_default(void)
@@ -235,9 +261,9 @@ __global__ void __launch_bounds__(1024) k_scan_i32_i64(const int32_t *__restrict
 
 extern "C" int mga_dev_scan_i32_to_i64(mga_sctx_t *sc, const int32_t *d_cnt, int64_t n, int64_t *d_off)
 {
-	mga_prof_begin(sc, MGA_K_SCAN);
+	mga_prof_begin(sc->stream, MGA_K_SCAN);
 	hipLaunchKernelGGL(k_scan_i32_i64, dim3(1), dim3(1024), 0, (hipStream_t)sc->stream, d_cnt, n, d_off);
-	mga_prof_end(sc, MGA_K_SCAN);
+	mga_prof_end(sc->stream, MGA_K_SCAN);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;
 }
@@ -269,7 +295,7 @@ static void prof_collect_locked(void)
 
 extern "C" void mga_prof_collect(void) { std::lock_guard<std::mutex> lk(g_prof.mtx); prof_collect_locked(); }
 
-extern "C" void mga_prof_begin(mga_sctx_t *sc, int kid)
+extern "C" void mga_prof_begin(void *stream, int kid)
 {
 	t_prof_slot = -1;
 	if (!g_prof.enabled) return;
@@ -281,17 +307,17 @@ extern "C" void mga_prof_begin(mga_sctx_t *sc, int kid)
 		g_prof.n_created = i + 1;
 	}
 	g_prof.kid[i] = kid;
-	(void)hipEventRecord(g_prof.ev[i][0], (hipStream_t)sc->stream);
+	(void)hipEventRecord(g_prof.ev[i][0], (hipStream_t)stream);
 	t_prof_slot = i;
 	++g_prof.n_pending;
 }
 
-extern "C" void mga_prof_end(mga_sctx_t *sc, int kid)
+extern "C" void mga_prof_end(void *stream, int kid)
 {
 	(void)kid;
 	if (t_prof_slot < 0) return;
 	std::lock_guard<std::mutex> lk(g_prof.mtx);
-	(void)hipEventRecord(g_prof.ev[t_prof_slot][1], (hipStream_t)sc->stream);
+	(void)hipEventRecord(g_prof.ev[t_prof_slot][1], (hipStream_t)stream);
 	t_prof_slot = -1;
 }
 

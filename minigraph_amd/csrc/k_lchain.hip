@@ -233,9 +233,9 @@ extern "C" int mga_dev_lchain(mga_sctx_t *sc, int n, const mg128_t *d_a, const i
 	if (ws_bytes < mga_dev_lchain_ws_bytes(total_anchors)) { mga_set_error("lchain: workspace too small"); return -1; }
 	int32_t *ws_i32 = (int32_t*)d_ws;
 	mg128_t *ws_z = (mg128_t*)((char*)d_ws + (size_t)(total_anchors + 8) * 16);
-	mga_prof_begin(sc, MGA_K_LCHAIN);
+	mga_prof_begin(sc->stream, MGA_K_LCHAIN);
 	hipLaunchKernelGGL(k_lchain, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, d_u, d_b, d_nu, d_nb, ws_i32, ws_z);
-	mga_prof_end(sc, MGA_K_LCHAIN);
+	mga_prof_end(sc->stream, MGA_K_LCHAIN);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;
 }

@@ -130,9 +130,9 @@ extern "C" int mga_dev_seed_count(mga_sctx_t *sc, const mga_didx_t *ix, int n, c
 								  int32_t *d_occ, uint64_t *d_val, int32_t *d_na, int32_t *d_nmini, int32_t *d_rep_len)
 {
 	if (n <= 0) return 0;
-	mga_prof_begin(sc, MGA_K_SEED_COUNT);
+	mga_prof_begin(sc->stream, MGA_K_SEED_COUNT);
 	hipLaunchKernelGGL(k_seed_count, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, *ix, n, d_mz, d_mz_off, max_occ, d_occ, d_val, d_na, d_nmini, d_rep_len);
-	mga_prof_end(sc, MGA_K_SEED_COUNT);
+	mga_prof_end(sc->stream, MGA_K_SEED_COUNT);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;
 }
@@ -142,9 +142,9 @@ extern "C" int mga_dev_seed_fill(mga_sctx_t *sc, const mga_didx_t *ix, int n, co
 								 const int64_t *d_mini_off, int32_t *d_mini, mg128_t *d_tmp)
 {
 	if (n <= 0) return 0;
-	mga_prof_begin(sc, MGA_K_SEED_FILL);
+	mga_prof_begin(sc->stream, MGA_K_SEED_FILL);
 	hipLaunchKernelGGL(k_seed_fill, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, *ix, n, d_mz, d_mz_off, max_occ, d_occ, d_val, d_a_off, d_a, d_mini_off, d_mini, d_tmp);
-	mga_prof_end(sc, MGA_K_SEED_FILL);
+	mga_prof_end(sc->stream, MGA_K_SEED_FILL);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;
 }

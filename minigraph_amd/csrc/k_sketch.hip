@@ -173,9 +173,9 @@ extern "C" int mga_dev_sketch(mga_sctx_t *sc, int n, const char *d_seq, const in
 {
 	if (n <= 0) return 0;
 	if (w < 1 || w > 255 || k < 1 || k > 28) { mga_set_error("sketch: need 0<w<256 and 0<k<=28 (sketch.c:62), got w=%d k=%d", w, k); return -1; }
-	mga_prof_begin(sc, MGA_K_SKETCH);
+	mga_prof_begin(sc->stream, MGA_K_SKETCH);
 	hipLaunchKernelGGL(k_sketch, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_seq, d_off, d_rid, w, k, d_cnt, d_mz_off, d_mz);
-	mga_prof_end(sc, MGA_K_SKETCH);
+	mga_prof_end(sc->stream, MGA_K_SKETCH);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;
 }

@@ -314,13 +314,15 @@ extern "C" int mga_dev_wfa(mga_sctx_t *sc, int n, const int32_t *d_list, const m
 	cfg.ws_stride = (int64_t)wfa_ws_bytes(cfg);
 	int waves = g_tier_waves[tier];
 	if (waves > n) waves = n;
-	if (mga_dbuf_reserve(&sc->wfa_ws[5 + tier], (size_t)cfg.ws_stride * g_tier_waves[tier]) < 0) return -1;
-	if (mga_dbuf_reserve(&sc->wfa_cnt, 256) < 0) return -1;
-	MGA_HIP_CHECK(hipMemsetAsync(sc->wfa_cnt.p, 0, 4, (hipStream_t)sc->stream));
-	mga_prof_begin(sc, MGA_K_WFA0 + 5 + tier);
-	hipLaunchKernelGGL(k_wfa, dim3(waves), dim3(64), 0, (hipStream_t)sc->stream, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap,
-					   d_pool_used, (char*)sc->wfa_ws[5 + tier].p, (int*)sc->wfa_cnt.p, cfg);
-	mga_prof_end(sc, MGA_K_WFA0 + 5 + tier);
+	if (mga_dbuf_reserve(&sc->wfa_ws[4 + tier], (size_t)cfg.ws_stride * g_tier_waves[tier]) < 0) return -1;
+	if (mga_dbuf_reserve(&sc->wfa_cnt, 1024) < 0) return -1;
+	hipStream_t st = (hipStream_t)mga_wfa_stream(sc, 4 + tier);
+	int *d_counter = (int*)((char*)sc->wfa_cnt.p + 64 * (4 + tier));
+	MGA_HIP_CHECK(hipMemsetAsync(d_counter, 0, 4, st));
+	mga_prof_begin(st, MGA_K_WFA0 + 4 + tier);
+	hipLaunchKernelGGL(k_wfa, dim3(waves), dim3(64), 0, st, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap,
+					   d_pool_used, (char*)sc->wfa_ws[4 + tier].p, d_counter, cfg);
+	mga_prof_end(st, MGA_K_WFA0 + 4 + tier);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;
 }
@@ -328,9 +330,9 @@ extern "C" int mga_dev_wfa(mga_sctx_t *sc, int n, const int32_t *d_list, const m
 extern "C" int mga_dev_wfa_tier(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 								mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier)
 {
-	if (tier < 4) return mga_dev_wfa_reg(sc, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier);
-	if (tier == 4) return mga_dev_wfa_lds(sc, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, 2);
-	return mga_dev_wfa(sc, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier - 5);
+	if (tier < 2) return mga_dev_wfa_reg(sc, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier);
+	if (tier < 5) return mga_dev_wfa_regw(sc, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier - 2, tier);
+	return mga_dev_wfa(sc, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier - 5 + 1); /* HBM tiers with 4096 / 32768 diagonals */
 }
 
 // the band of a 10%-error gap is about as wide as the gap is long ([measured] on the benchmark workload:
@@ -342,6 +344,6 @@ extern "C" int mga_wfa_first_tier(int32_t tl, int32_t ql)
 	if (m <= 112) return 1;
 	if (m <= 224) return 2;
 	if (m <= 450) return 3;
-	if (m <= 1024) return 4;
+	if (m <= 2048) return 4;
 	return 5;
 }

@@ -138,6 +138,7 @@ __global__ void __launch_bounds__(64) k_wfa_reg(int n_items, const int32_t *__re
 				const int32_t width = nhi - nlo + 1;
 				if (nlo < D0 || nhi > D0 + NV - 1 || s + 1 > SMAX || tb_used + width > tbcap) { status = MGA_WFA_RETRY_TIER; break; }
 				++s;
+				const bool track_alive = (s & 0xff) >= 239 || (s & 0xff) == 0; // the trimming at score 256k looks back 17 scores only
 				if (lane == 0) { row[s] = (int32_t)tb_used; rlo[s] = (int16_t)nlo; }
 				int32_t nH[J], nE1[J], nF1[J], nE2[J], nF2[J];
 				bool reach_lo = false, reach_hi = false;
@@ -182,7 +183,7 @@ __global__ void __launch_bounds__(64) k_wfa_reg(int n_items, const int32_t *__re
 						if (d == nlo) reach_lo = reach;
 						if (d == nhi) reach_hi = reach;
 #define WFR_IN(k_) ((k_) >= -1 && (k_) < tl && d + (k_) >= -1 && d + (k_) < ql)
-						if (WFR_IN(vH) || WFR_IN(vE1) || WFR_IN(vF1) || WFR_IN(vE2) || WFR_IN(vF2)) GL[j] = s;
+						if (track_alive && (WFR_IN(vH) || WFR_IN(vE1) || WFR_IN(vF1) || WFR_IN(vE2) || WFR_IN(vF2))) GL[j] = s;
 #undef WFR_IN
 					} else vH = vE1 = vF1 = vE2 = vF2 = WF_NEG_INF; // outside the slice: what the padded reference slices hold
 					nH[j] = vH, nE1[j] = vE1, nF1[j] = vF1, nE2[j] = vE2, nF2[j] = vF2;
@@ -321,16 +322,17 @@ extern "C" int mga_dev_wfa_reg(mga_sctx_t *sc, int n, const int32_t *d_list, con
 	int waves = T.n_wave < (n + 7) / 8 ? T.n_wave : (n + 7) / 8;
 	if (waves < 1) waves = 1;
 	if (mga_dbuf_reserve(&sc->wfa_ws[tier], (size_t)cfg.ws_stride * T.n_wave) < 0) return -1;
-	if (mga_dbuf_reserve(&sc->wfa_cnt, 256) < 0) return -1;
-	MGA_HIP_CHECK(hipMemsetAsync(sc->wfa_cnt.p, 0, 4, (hipStream_t)sc->stream));
-	mga_prof_begin(sc, MGA_K_WFA0 + tier);
-#define LAUNCH(JJ, SEQ, SM, TBL) hipLaunchKernelGGL((k_wfa_reg<JJ, SEQ, SM, TBL>), dim3(waves), dim3(64), 0, (hipStream_t)sc->stream, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap, d_pool_used, (char*)sc->wfa_ws[tier].p, (int*)sc->wfa_cnt.p, cfg)
+	if (mga_dbuf_reserve(&sc->wfa_cnt, 1024) < 0) return -1;
+	hipStream_t st = (hipStream_t)mga_wfa_stream(sc, tier);
+	int *d_counter = (int*)((char*)sc->wfa_cnt.p + 64 * (tier));
+	MGA_HIP_CHECK(hipMemsetAsync(d_counter, 0, 4, st));
+	mga_prof_begin(st, MGA_K_WFA0 + tier);
+#define LAUNCH(JJ, SEQ, SM, TBL) hipLaunchKernelGGL((k_wfa_reg<JJ, SEQ, SM, TBL>), dim3(waves), dim3(64), 0, st, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap, d_pool_used, (char*)sc->wfa_ws[tier].p, d_counter, cfg)
 	if (tier == 0) LAUNCH(1, 128, 64, 2048);
 	else if (tier == 1) LAUNCH(2, 256, 128, 6144);
-	else if (tier == 2) LAUNCH(4, 512, 512, 0);
-	else LAUNCH(8, 1024, 1024, 0);
+	else { mga_set_error("wfa_reg: bands above 128 diagonals run on the multi-wave kernel (k_wfa_regw.hip)"); return -1; }
 #undef LAUNCH
-	mga_prof_end(sc, MGA_K_WFA0 + tier);
+	mga_prof_end(st, MGA_K_WFA0 + tier);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;
 }

@@ -261,6 +261,19 @@ void mga_batch_destroy(mga_batch_t *b)
  * ---------------------------------------------------------------------------------------------- */
 #include <pthread.h>
 
+/* order problem ids by decreasing tl+ql (bucket sort on min(len/8, 1023)) */
+static void lpt_order(int32_t *ids, int64_t n, const mga_wfa_prob_t *prob)
+{
+	int64_t cnt[1025], i;
+	int32_t *tmp = MGA_MALLOC(int32_t, n);
+	memset(cnt, 0, sizeof cnt);
+	for (i = 0; i < n; ++i) { int b = (prob[ids[i]].tl + prob[ids[i]].ql) >> 3; if (b > 1023) b = 1023; ++cnt[1023 - b + 1]; }
+	for (i = 0; i < 1024; ++i) cnt[i + 1] += cnt[i];
+	for (i = 0; i < n; ++i) { int b = (prob[ids[i]].tl + prob[ids[i]].ql) >> 3; if (b > 1023) b = 1023; tmp[cnt[1023 - b]++] = ids[i]; }
+	memcpy(ids, tmp, (size_t)n * 4);
+	free(tmp);
+}
+
 typedef struct {
 	mga_sctx_t *sc;
 	mga_dbuf_t seq, qoff, cnt, mzoff, mz, occ, val, na, nmini, rep, aoff, minioff, a, tmp, mini, u, b, nu, nb, ws;
@@ -393,13 +406,20 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 			for (k = 0; k < MGA_WFA_N_TIER; ++k) cnt[k + 1] += cnt[k];
 			for (k = 0; k < MGA_WFA_N_TIER; ++k) pos[k] = cnt[k];
 			for (j = 0; j < n_prob; ++j) if (tier_of[j] >= 0) todo[pos[tier_of[j]]++] = (int32_t)j;
-			if (mga_h2d_s(sc, P->list.p, todo, (size_t)n_left * 4) < 0) { free(tier_of); rc = -1; goto done; }
+			for (k = 0; k < MGA_WFA_N_TIER; ++k) /* longest first inside a tier: the slow problems start early instead of forming the tail */
+				if (cnt[k + 1] - cnt[k] > 1) lpt_order(todo + cnt[k], cnt[k + 1] - cnt[k], h_prob);
+			if (mga_h2d_s(sc, P->list.p, todo, (size_t)n_left * 4) < 0 || mga_wfa_fork(sc) < 0) { free(tier_of); rc = -1; goto done; }
 			for (k = 0; k < MGA_WFA_N_TIER; ++k) {
 				int64_t c = cnt[k + 1] - cnt[k];
 				if (c > 0 && mga_dev_wfa_tier(sc, (int)c, (const int32_t*)P->list.p + cnt[k], (const mga_wfa_prob_t*)P->prob.p, (const char*)P->tseq.p, d_seq,
 											  (mga_wfa_res_t*)P->res.p, (uint32_t*)P->pool.p, pool_cap, (unsigned long long*)P->used.p, (int)k) < 0) { free(tier_of); rc = -1; goto done; }
 			}
-			if (mga_d2h_s(sc, h_res, P->res.p, (size_t)n_prob * sizeof(mga_wfa_res_t)) < 0 || mga_ssync(sc) < 0) { free(tier_of); rc = -1; goto done; }
+			if (mga_wfa_join(sc) < 0 || mga_d2h_s(sc, h_res, P->res.p, (size_t)n_prob * sizeof(mga_wfa_res_t)) < 0 || mga_ssync(sc) < 0) { free(tier_of); rc = -1; goto done; }
+			if (getenv("MGA_DEBUG_WFA")) {
+				int64_t nt[MGA_WFA_N_TIER] = {0}, nr[MGA_WFA_N_TIER] = {0}, mx[MGA_WFA_N_TIER] = {0}, sm[MGA_WFA_N_TIER] = {0}; int mxs[MGA_WFA_N_TIER] = {0};
+				for (j = 0; j < n_prob; ++j) if (tier_of[j] >= 0) { int t = tier_of[j]; ++nt[t]; if (h_res[j].status == MGA_WFA_RETRY_TIER) ++nr[t]; sm[t] += h_res[j].n_iter; if (h_res[j].n_iter > mx[t]) mx[t] = h_res[j].n_iter, mxs[t] = h_res[j].score; }
+				for (k = 0; k < MGA_WFA_N_TIER; ++k) if (nt[k]) fprintf(stderr, "[wfa] pass %d tier %ld: %ld problems, %ld retry, cells sum %ld max %ld (score %d)\n", pass, (long)k, (long)nt[k], (long)nr[k], (long)sm[k], (long)mx[k], mxs[k]);
+			}
 			for (j = 0, n_left = 0; j < n_prob; ++j) {
 				if (tier_of[j] < 0) continue;
 				if (h_res[j].status == MGA_WFA_RETRY_TIER) {

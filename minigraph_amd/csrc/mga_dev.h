@@ -36,8 +36,13 @@ void mga_dbuf_free(mga_dbuf_t *b);
 typedef struct mga_sctx_s {
 	void *stream;              /* hipStream_t */
 	mga_dbuf_t wfa_ws[8];      /* per-tier WFA workspaces */
-	mga_dbuf_t wfa_cnt;        /* work-queue counters */
+	mga_dbuf_t wfa_cnt;        /* work-queue counters, one 64-byte line per tier */
+	void *tier_stream[8];      /* WFA tiers run concurrently on their own streams (long-tailed wide problems next to the small ones) */
+	void *ev_ready, *ev_done[8];
 } mga_sctx_t;
+void *mga_wfa_stream(mga_sctx_t *sc, int slot);       /* stream of WFA tier `slot` */
+int mga_wfa_fork(mga_sctx_t *sc);                     /* tier streams wait for everything queued on sc->stream so far */
+int mga_wfa_join(mga_sctx_t *sc);                     /* sc->stream waits for every tier stream */
 mga_sctx_t *mga_sctx_create(void);
 void mga_sctx_destroy(mga_sctx_t *sc);
 mga_sctx_t *mga_sctx_default(void);            /* lazily created, used by the stage-level API */
@@ -51,11 +56,11 @@ int  mga_hbuf_reserve(mga_hbuf_t *b, size_t bytes);
 void mga_hbuf_free(mga_hbuf_t *b);
 
 /* per-kernel HIP-event timing on the launch stream (bench.py reads it through mga_prof_get) */
-enum { MGA_K_SKETCH = 0, MGA_K_SEED_COUNT, MGA_K_SEED_FILL, MGA_K_LCHAIN, MGA_K_WFA0 /* +tier: 0-3 register tiers (band 64..512), 4 LDS tier (band 1024), 5-7 HBM tiers */, MGA_K_SCAN = MGA_K_WFA0 + 8, MGA_K_N };
-#define MGA_WFA_N_TIER 8
+enum { MGA_K_SKETCH = 0, MGA_K_SEED_COUNT, MGA_K_SEED_FILL, MGA_K_LCHAIN, MGA_K_WFA0 /* +tier: 0-1 single-wave register tiers (band 64,128), 2-4 multi-wave register tiers (256,512,1024), 5-6 HBM tiers */, MGA_K_SCAN = MGA_K_WFA0 + 8, MGA_K_N };
+#define MGA_WFA_N_TIER 7
 void mga_prof_enable(int on);
-void mga_prof_begin(mga_sctx_t *sc, int kid);
-void mga_prof_end(mga_sctx_t *sc, int kid);
+void mga_prof_begin(void *stream, int kid);
+void mga_prof_end(void *stream, int kid);
 void mga_prof_collect(void);
 void mga_prof_get(double *ms, int64_t *launches, int reset); /* arrays of MGA_K_N */
 
@@ -107,13 +112,13 @@ enum { MGA_WFA_OK = 0, MGA_WFA_PENDING = 1, MGA_WFA_RETRY_TIER = 2, MGA_WFA_POOL
  * (capacity pool_cap ops, *d_pool_used bumped atomically); sequences must be padded by >= 8 readable bytes */
 int mga_dev_wfa(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 				mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier);
-/* the LDS-resident tiers (k_wfa_lds.hip): 0: band<=128, 1: band<=512, 2: band<=1024 */
-int mga_dev_wfa_lds(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
-					mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier);
 /* register-resident tiers (k_wfa_reg.hip): tier t covers a window of 64<<t diagonals */
 int mga_dev_wfa_reg(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 					mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier);
-/* tier 0..7: register tiers, the LDS tier, then the HBM-resident tiers; a problem failing with MGA_WFA_RETRY_TIER moves up one */
+/* multi-wave register tiers (k_wfa_regw.hip): 0 = 4 waves x 64 (256 diagonals), 1 = 4 waves x 128 (512 diagonals) */
+int mga_dev_wfa_regw(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+					 mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier, int ws_slot);
+/* tier 0..6: register tiers (one wave, then 4-8 waves per problem), then the HBM-resident tiers; a problem failing with MGA_WFA_RETRY_TIER moves up one */
 int mga_wfa_first_tier(int32_t tl, int32_t ql); /* cheapest tier likely to fit, from the sequence lengths */
 int mga_dev_wfa_tier(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 					 mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier);

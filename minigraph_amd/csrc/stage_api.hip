@@ -75,6 +75,7 @@ extern "C" int mga_wfa_batch(int n, const char *tseq, const int64_t *t_off, cons
 	if (!d_pool.alloc((size_t)pool_cap * 4) || !d_list.alloc((size_t)n * 4) || mga_dmemset_s(SC, d_used.p, 0, 8) < 0) return -1;
 	for (int pass = 0;; ++pass) { // first pass: every problem in the tier its length suggests; then only the ones that outgrew it, one tier up
 		int64_t n_left = 0;
+		if (mga_wfa_fork(SC) < 0) return -1;
 		for (int t = 0; t < MGA_WFA_N_TIER; ++t) {
 			todo.clear();
 			for (int i = 0; i < n; ++i) if (tier_of[i] == t) todo.push_back(i);
@@ -85,7 +86,7 @@ extern "C" int mga_wfa_batch(int n, const char *tseq, const int64_t *t_off, cons
 			n_left += (int64_t)todo.size();
 		}
 		if (n_left == 0) break;
-		if (mga_ssync(SC) < 0 || mga_d2h(res.data(), d_res.p, (size_t)n * sizeof(mga_wfa_res_t)) < 0) return -1;
+		if (mga_dsync() < 0 || mga_d2h(res.data(), d_res.p, (size_t)n * sizeof(mga_wfa_res_t)) < 0) return -1;
 		bool again = false;
 		for (int i = 0; i < n; ++i) {
 			if (tier_of[i] < 0) continue;
@@ -98,7 +99,7 @@ extern "C" int mga_wfa_batch(int n, const char *tseq, const int64_t *t_off, cons
 		if (!again) break;
 	}
 	unsigned long long used = 0;
-	if (mga_ssync(SC) < 0 || mga_d2h(&used, d_used.p, 8) < 0) return -1;
+	if (mga_dsync() < 0 || mga_d2h(&used, d_used.p, 8) < 0) return -1;
 	std::vector<uint32_t> hpool((size_t)used + 1);
 	if (used && mga_d2h(hpool.data(), d_pool.p, (size_t)used * 4) < 0) return -1;
 	int32_t *h_score = (int32_t*)malloc((size_t)n * 4);
