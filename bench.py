@@ -31,7 +31,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(ref_bin, graph, reads_fa, n_reads, out_dir, threads):
+def cpu_baseline(ref_bin, graph, reads_fa, n_reads, out_dir, threads, cores):
     """the UNMODIFIED reference (oracle/_ref/minigraph) on a bounded sample of the same workload"""
     sample = os.path.join(out_dir, "cpu_sample.fa")
     with open(reads_fa) as fi, open(sample, "w") as fo:
@@ -56,8 +56,28 @@ def cpu_baseline(ref_bin, graph, reads_fa, n_reads, out_dir, threads):
                 t_map = float(m.group(2))
     bases = sum(len(l.strip()) for l in open(sample) if not l.startswith(">"))
     dt = (t_map - t_upd) if (t_upd is not None and t_map is not None) else float("nan")
-    return dict(value=bases / dt / 1e9, unit="Gbp/s", cores=threads, kind="reference",
-                sample="%d reads (%d bp) of the same workload, minigraph -cx lr -t %d, map phase only (worker_pipeline - mg_opt_update)" % (n, bases, threads)), gaf, n
+    return dict(value=bases / dt / 1e9, unit="Gbp/s", cores=cores, kind="reference",
+                sample="%d reads (%d bp) of the same workload, minigraph -cx lr -t %d on %d usable cores (affinity capped by the cgroup CPU quota), map phase only (worker_pipeline - mg_opt_update)" % (n, bases, threads, cores)), gaf, n
+
+
+def usable_cores():
+    """cores this process may actually burn: the affinity mask capped by the cgroup CPU quota (cpu.max)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return n
+
+
+def cgroup_throttled():
+    try:
+        kv = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+        return int(kv.get("nr_throttled", 0)), int(kv.get("throttled_usec", 0))
+    except Exception:
+        return 0, 0
 
 
 def main():
@@ -70,7 +90,7 @@ def main():
     ap.add_argument("--hap", type=int, default=3)
     ap.add_argument("--cpu-reads", type=int, default=20000)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--threads", type=int, default=0, help="host threads per rank (0: min(64, cores / ranks); more oversubscribes the host stages)")
+    ap.add_argument("--threads", type=int, default=0, help="host threads per rank (0: min(64, usable cores / ranks))")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,7 +114,8 @@ def main():
     if L.mga_device_count() <= 0:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     ncpu = os.cpu_count() or 1
-    threads = args.threads or max(1, min(64, ncpu // world))
+    quota = usable_cores()
+    threads = args.threads or max(2, min(64, quota // world))  # [measured] more threads than usable cores only adds contention + CFS throttling
 
     # ---- synthetic workload (untimed) ----
     d = tempfile.mkdtemp(prefix="mga_bench_r%d_" % rank)
@@ -128,12 +149,14 @@ def main():
     mga.prof_enable(True)
     mga.prof_get(reset=True)
     sync()
+    cpu0, thr0 = time.process_time(), cgroup_throttled()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         gaf = step()
     torch.cuda.synchronize()
     sync()
     dt = time.perf_counter() - t0
+    cpu1, thr1 = time.process_time(), cgroup_throttled()
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -175,19 +198,21 @@ def main():
                    per_read=dict(n_mz=st["n_mz"] / max(1, st["n_reads"]), n_hit=st["n_hit"] / max(1, st["n_reads"]),
                                  n_wfa=st["n_wfa"] / max(1, st["n_reads"]), wfa_cells=st["wfa_cells"] / max(1, st["n_reads"]),
                                  gaf_bytes=st["gaf_bytes"] / max(1, st["n_reads"])),
-                   index_s=round(t_index, 2))
+                   index_s=round(t_index, 2),
+                   host=dict(logical_cpus=ncpu, usable_cores=quota, cpu_s_per_step=round((cpu1 - cpu0) / args.steps, 3),
+                             cfs_throttled_periods=thr1[0] - thr0[0], cfs_throttled_s=round((thr1[1] - thr0[1]) * 1e-6, 3)))
         ref_bin = os.path.join(ROOT, "oracle", "_ref", "minigraph")
         if not args.no_cpu and os.path.exists(ref_bin) and n_gpus == 1:
             try:
-                cb, cpu_gaf, n_cpu = cpu_baseline(ref_bin, graph_path, reads_path, args.cpu_reads, d, ncpu)
+                cb, cpu_gaf, n_cpu = cpu_baseline(ref_bin, graph_path, reads_path, args.cpu_reads, d, min(ncpu, 2 * quota), quota)
                 res["cpu_baseline"] = cb
                 want = open(cpu_gaf, "rb").read()
                 gaf = gaf.bytes()
                 res["parity"] = "GAF byte-identical to the reference on the %d-read sample" % n_cpu if gaf[:len(want)] == want and (len(gaf) == len(want) or gaf[len(want) - 1:len(want)] == b"\n") else "MISMATCH vs reference GAF"
             except Exception as e:  # the baseline is a reported number, never a reason to lose the bench line
-                res["cpu_baseline"] = dict(value=None, unit="Gbp/s", cores=ncpu, kind="reference", sample="failed: %r" % (e,))
+                res["cpu_baseline"] = dict(value=None, unit="Gbp/s", cores=quota, kind="reference", sample="failed: %r" % (e,))
         else:
-            res["cpu_baseline"] = dict(value=None, unit="Gbp/s", cores=ncpu, kind="reference",
+            res["cpu_baseline"] = dict(value=None, unit="Gbp/s", cores=quota, kind="reference",
                                        sample="not run (N>1, --no-cpu, or oracle/_ref/minigraph absent)")
         print(json.dumps(res), flush=True)
     R.close()

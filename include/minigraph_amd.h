@@ -269,7 +269,8 @@ mga_reads_t *mga_reads_load(const char *fn, int64_t max_reads);   /* FASTA/FASTQ
 void mga_reads_free(mga_reads_t *rd);
 int mga_reads_count(const mga_reads_t *rd);
 int64_t mga_reads_bases(const mga_reads_t *rd);
-/* mg_map_batch() + mg_write_gaf() for a resident read set; *gaf is malloc()'ed (release with mga_free) */
+/* mg_map_batch() + mg_write_gaf() for a resident read set; *gaf (NUL-terminated, input order) points into a buffer owned by the
+ * index: valid until the next mga_map_reads() on this index or mg_idx_destroy(); do NOT free it */
 int mga_map_reads(const mg_idx_t *gi, const mga_reads_t *rd, const mg_mapopt_t *opt, int n_threads, char **gaf, int64_t *gaf_len);
 int mga_map_batch_resident(const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs,
 						   const mg_mapopt_t *opt, int n_threads, const char *d_seq, const int64_t *q_off);

@@ -60,8 +60,8 @@ class ggopt_t(C.Structure):
 
 MG_M_CIGAR = 0x4000000
 
-KERNELS = ["k_sketch", "k_seed_count", "k_seed_fill", "k_lchain", "k_wfa_reg[64]", "k_wfa_reg[128]", "k_wfa_regw[256]", "k_wfa_regw[512]",
-           "k_wfa_regw[1024]", "k_wfa[hbm4096]", "k_wfa[hbm32768]", "unused", "k_scan"]
+KERNELS = ["k_sketch", "k_seed_count", "k_seed_fill", "k_lchain", "k_wfa_r[64]", "k_wfa_r[128]", "k_wfa_r[256]", "k_wfa_r[512]",
+           "k_wfa_r[1024]", "k_wfa_r[2048]", "k_wfa[hbm4096]", "k_wfa[hbm32768]", "k_scan"]
 
 
 class stats_t(C.Structure):  # mga_stats_t
@@ -262,7 +262,8 @@ class Reads:
 
 
 class GafBuffer:
-    """the GAF text of one pass, owned by the C library (no copy until bytes() is asked for)"""
+    """the GAF text of one pass, owned by the index inside the C library: valid until the next map_reads() on the same
+    Graph (no copy until bytes() is asked for)"""
 
     def __init__(self, ptr, n):
         self.ptr, self.n = ptr, n
@@ -277,15 +278,7 @@ class GafBuffer:
         return C.string_at(self.ptr, self.n)
 
     def free(self):
-        if self.ptr:
-            load().mga_free(self.ptr)
         self.ptr = None
-
-    def __del__(self):
-        try:
-            self.free()
-        except Exception:
-            pass
 
 
 def map_reads(graph, reads, n_threads=8, copy=True):

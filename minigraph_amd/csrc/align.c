@@ -83,52 +83,53 @@ void mga_plan_cigar(const gfa_t *g, const gfa_edseq_t *es, const mg_gchains_t *g
 	}
 }
 
-typedef struct { uint64_t *a; int32_t n, m; } cig64_v;
-
-static inline void cig_push1(cig64_v *c, int32_t op, int32_t len) /* append_cigar1, galign.c:11-23 */
-{
-	if (c->n > 0 && (int32_t)(c->a[c->n - 1] & 0xf) == op) c->a[c->n - 1] += (uint64_t)len << 4;
-	else {
-		if (c->n == c->m) { c->m += (c->m >> 1) + 16; c->a = MGA_REALLOC(uint64_t, c->a, c->m); }
-		c->a[c->n++] = (uint64_t)len << 4 | (uint64_t)op;
-	}
-}
-
-int mga_apply_cigar(mg_gchains_t *gt, int32_t gc_idx, const mga_cigitem_t *item, int64_t n_item, int64_t prob_base,
-					const mga_wfa_res_t *res, const uint32_t *pool)
+int mga_apply_cigar(mg_gchains_t *gt, int32_t gc_idx, const mga_cigitem_t *item, int64_t n_item, int64_t prob_base, const mga_cigsrc_t *src)
 {
 	mg_gchain_t *gc = &gt->gc[gc_idx];
-	cig64_v c = {0, 0, 0};
-	int64_t t;
-	int32_t j, l, off_a0 = gt->lc[gc->off].off;
+	int64_t t, cap = 0;
+	int32_t j, l, n = 0, off_a0 = gt->lc[gc->off].off;
+	uint64_t *c;
+	/* upper bound on the operator count, then the CIGAR is built in place inside the mg_cigar_t */
 	for (t = 0; t < n_item; ++t) {
-		if (item[t].op >= 0) cig_push1(&c, item[t].op, item[t].val);
+		if (item[t].op >= 0) ++cap;
+		else if (src->ord) cap += src->ncig[prob_base + item[t].val];
 		else {
-			const mga_wfa_res_t *r = &res[prob_base + item[t].val];
-			const uint32_t *cg = pool + r->cig_off;
-			int32_t k;
-			if (r->status != MGA_WFA_OK) { free(c.a); return -1; }
-			if (r->n_cigar == 0) continue;
-			cig_push1(&c, (int32_t)(cg[0] & 0xf), (int32_t)(cg[0] >> 4)); /* append_cigar, galign.c:25-37 */
-			if (c.n + r->n_cigar - 1 > c.m) { c.m = c.n + r->n_cigar - 1 + 16; c.a = MGA_REALLOC(uint64_t, c.a, c.m); }
-			for (k = 0; k < r->n_cigar - 1; ++k) c.a[c.n + k] = cg[1 + k];
-			c.n += r->n_cigar - 1;
+			const mga_wfa_res_t *r = &src->res[prob_base + item[t].val];
+			if (r->status != MGA_WFA_OK) return -1;
+			cap += r->n_cigar;
 		}
 	}
-	gc->p = (mg_cigar_t*)calloc(1, (size_t)c.n * 8 + sizeof(mg_cigar_t));
+	gc->p = (mg_cigar_t*)calloc(1, (size_t)cap * 8 + sizeof(mg_cigar_t));
+	c = gc->p->cigar;
+#define PUSH1(op_, len_) do { /* append_cigar1, galign.c:11-23 */ \
+		if (n > 0 && (int32_t)(c[n - 1] & 0xf) == (op_)) c[n - 1] += (uint64_t)(len_) << 4; \
+		else c[n++] = (uint64_t)(len_) << 4 | (uint64_t)(op_); \
+	} while (0)
+	for (t = 0; t < n_item; ++t) {
+		if (item[t].op >= 0) PUSH1(item[t].op, item[t].val);
+		else {
+			const int64_t pj = prob_base + item[t].val;
+			const uint32_t *cg;
+			int32_t k, nc;
+			if (src->ord) nc = src->ncig[pj], cg = src->ord + src->off[pj];
+			else nc = src->res[pj].n_cigar, cg = src->pool + src->res[pj].cig_off;
+			if (nc == 0) continue;
+			PUSH1((int32_t)(cg[0] & 0xf), (int32_t)(cg[0] >> 4)); /* append_cigar, galign.c:25-37: only the first operator can merge */
+			for (k = 1; k < nc; ++k) c[n++] = cg[k];
+		}
+	}
+#undef PUSH1
 	gc->p->ss = (int32_t)gt->a[off_a0].x + 1 - (int32_t)(gt->a[off_a0].y >> 32 & 0xff);
 	gc->p->ee = (int32_t)gt->a[off_a0 + gc->n_anchor - 1].x + 1;
-	gc->p->n_cigar = c.n;
-	memcpy(gc->p->cigar, c.a, (size_t)c.n * 8);
-	for (j = 0, l = 0; j < gc->p->n_cigar; ++j) {
-		int32_t op = (int32_t)(gc->p->cigar[j] & 0xf), len = (int32_t)(gc->p->cigar[j] >> 4);
+	gc->p->n_cigar = n;
+	for (j = 0, l = 0; j < n; ++j) {
+		int32_t op = (int32_t)(c[j] & 0xf), len = (int32_t)(c[j] >> 4);
 		if (op == 7) gc->p->mlen += len, gc->p->blen += len;
 		else gc->p->blen += len;
 		if (op != 1) gc->p->aplen += len;
 		if (op != 2) l += len;
 	}
 	memset(&gc->ds, 0, sizeof gc->ds);
-	free(c.a);
 	if (!(l == gc->qe - gc->qs && gc->p->aplen == gc->pe - gc->ps)) {
 		fprintf(stderr, "[E::%s] CIGAR inconsistent with chain coordinates (galign.c:140): q %d vs %d, path %d vs %d\n", __func__, l, gc->qe - gc->qs, gc->p->aplen, gc->pe - gc->ps);
 		return -2;
@@ -201,7 +202,8 @@ void mga_gen_ds(const gfa_edseq_t *es, const char *qseq, mg_gchains_t *gt) /* mg
 		assert(l_seq == gc->p->aplen);
 		for (j = 0, x = 0, y = gc->qs; j < gc->p->n_cigar; ++j) { /* upper bound on the number of entries */
 			int64_t op = gc->p->cigar[j] & 0xf, len = gc->p->cigar[j] >> 4, zz;
-			if (op == 0 || op == 7 || op == 8) {
+			if (op == 7) ++n_off, x += len, y += len; /* '=': byte-identical bases, nothing to compare */
+			else if (op == 0 || op == 8) {
 				++n_off;
 				for (zz = 0; zz < len; ++zz)
 					if (mga_nt4_table[(uint8_t)seq[x + zz]] != mga_nt4_table[(uint8_t)qseq[y + zz]]) n_off += 2;
@@ -212,7 +214,10 @@ void mga_gen_ds(const gfa_edseq_t *es, const char *qseq, mg_gchains_t *gt) /* mg
 		if (n_off > m_off) { m_off = n_off + (n_off >> 1) + 16; off = MGA_REALLOC(int32_t, off, m_off); }
 		for (j = 0, x = 0, y = gc->qs, n_off = 0; j < gc->p->n_cigar; ++j) {
 			int64_t op = gc->p->cigar[j] & 0xf, len = gc->p->cigar[j] >> 4;
-			if (op == 0 || op == 7 || op == 8) {
+			if (op == 7) { /* the reference's base-by-base loop (galign.c:228-243) sees len equal codes: one ":len" entry */
+				if (len > 0) { off[n_off++] = (int32_t)str.l; ds_c(&str, ':'); ds_int(&str, (int32_t)len); }
+				x += len, y += len;
+			} else if (op == 0 || op == 8) {
 				int64_t zz;
 				int32_t l = 0;
 				for (zz = 0; zz < len; ++zz) {

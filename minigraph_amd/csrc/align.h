@@ -13,7 +13,9 @@ typedef struct { /* per host thread accumulators of one batch */
 } mga_tpool_t;
 
 void mga_plan_cigar(const gfa_t *g, const gfa_edseq_t *es, const mg_gchains_t *gt, int32_t gc_idx, int64_t q_base, mga_tpool_t *tp);
-int mga_apply_cigar(mg_gchains_t *gt, int32_t gc_idx, const mga_cigitem_t *item, int64_t n_item, int64_t prob_base,
-					const mga_wfa_res_t *res, const uint32_t *pool);
+/* where the CIGAR of WFA problem j lives: either the kernels' raw output (res[j].cig_off into the pool, completion order)
+ * or, when ord != NULL, the device-gathered copy in problem order (ncig[j] ops at ord + off[j]) */
+typedef struct { const mga_wfa_res_t *res; const uint32_t *pool; const int32_t *ncig; const int64_t *off; const uint32_t *ord; } mga_cigsrc_t;
+int mga_apply_cigar(mg_gchains_t *gt, int32_t gc_idx, const mga_cigitem_t *item, int64_t n_item, int64_t prob_base, const mga_cigsrc_t *src);
 void mga_gen_ds(const gfa_edseq_t *es, const char *qseq, mg_gchains_t *gt);
 #endif

@@ -74,6 +74,7 @@ extern "C" mga_sctx_t *mga_sctx_create(void)
 		sc->tier_stream[i] = (void*)t, sc->ev_done[i] = (void*)e;
 	}
 	{ hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return 0; sc->ev_ready = (void*)e; }
+	{ hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) return 0; sc->ev_sync = (void*)e; }
 	return sc;
 }
 
@@ -83,13 +84,17 @@ extern "C" void mga_sctx_destroy(mga_sctx_t *sc)
 	(void)hipStreamSynchronize((hipStream_t)sc->stream);
 	for (int i = 0; i < 8; ++i) mga_dbuf_free(&sc->wfa_ws[i]);
 	mga_dbuf_free(&sc->wfa_cnt);
+	mga_dbuf_free(&sc->wfa_list[0]); mga_dbuf_free(&sc->wfa_list[1]); mga_dbuf_free(&sc->wfa_key); mga_dbuf_free(&sc->wfa_ctl);
 	for (int i = 0; i < 8; ++i) { (void)hipStreamDestroy((hipStream_t)sc->tier_stream[i]); (void)hipEventDestroy((hipEvent_t)sc->ev_done[i]); }
-	(void)hipEventDestroy((hipEvent_t)sc->ev_ready);
+	(void)hipEventDestroy((hipEvent_t)sc->ev_ready); (void)hipEventDestroy((hipEvent_t)sc->ev_sync);
 	(void)hipStreamDestroy((hipStream_t)sc->stream);
 	free(sc);
 }
 
-extern "C" void *mga_wfa_stream(mga_sctx_t *sc, int slot) { return sc->tier_stream[slot & 7]; }
+// MGA_WFA_SERIAL=1 (profiling aid) runs the tiers one after another on the context's stream, so that per-kernel
+// durations are not inflated by the tiers sharing the GPU
+static int wfa_serial(void) { static int v = -1; if (v < 0) { const char *e = getenv("MGA_WFA_SERIAL"); v = e && atoi(e) > 0; } return v; }
+extern "C" void *mga_wfa_stream(mga_sctx_t *sc, int slot) { return wfa_serial() ? sc->stream : sc->tier_stream[slot & 7]; }
 
 extern "C" int mga_wfa_fork(mga_sctx_t *sc)
 {
@@ -135,9 +140,12 @@ extern "C" int mga_dmemset_s(mga_sctx_t *sc, void *d, int v, size_t bytes)
 	return 0;
 }
 
+// Waiting on a blocking-sync event lets the pipeline thread sleep; hipStreamSynchronize() would spin on a core, and the
+// host stages of the other chunks need every core the (often CPU-quota-limited) box gives us.
 extern "C" int mga_ssync(mga_sctx_t *sc)
 {
-	MGA_HIP_CHECK(hipStreamSynchronize((hipStream_t)sc->stream));
+	MGA_HIP_CHECK(hipEventRecord((hipEvent_t)sc->ev_sync, (hipStream_t)sc->stream));
+	MGA_HIP_CHECK(hipEventSynchronize((hipEvent_t)sc->ev_sync));
 	return 0;
 }
 

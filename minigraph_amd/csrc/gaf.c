@@ -38,13 +38,20 @@ static void ks_path_piece(kstring_t *s, int rev, const char *name, int32_t st, i
 
 void mg_write_gaf(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, int32_t n_seg, const int32_t *qlens, const char *qname, uint64_t flag, void *km)
 {
-	int32_t i, j, qlen, rev_sign = 0; /* rev_sign is deliberately NOT reset per chain (format.c:123) */
 	(void)km;
 	s->l = 0;
+	mga_write_gaf_append(s, g, gs, n_seg, qlens, qname, flag);
+}
+
+/* the body of mg_write_gaf, appending to s (the batch formatter writes the lines of many reads into one buffer) */
+void mga_write_gaf_append(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, int32_t n_seg, const int32_t *qlens, const char *qname, uint64_t flag)
+{
+	int32_t i, j, qlen, rev_sign = 0; /* rev_sign is deliberately NOT reset per chain (format.c:123) */
+	const size_t l0 = s->l;
 	for (i = 0, qlen = 0; i < n_seg; ++i) qlen += qlens[i];
 	if ((gs == 0 || gs->n_gc == 0) && (flag & MG_M_SHOW_UNMAP)) {
 		ks_s(s, qname);
-		if ((flag & MG_M_FRAG_MERGE) && n_seg == 2 && s->l > 2 && s->s[s->l-1] == '1' && s->s[s->l-2] == '/') s->l -= 2;
+		if ((flag & MG_M_FRAG_MERGE) && n_seg == 2 && s->l > l0 + 2 && s->s[s->l-1] == '1' && s->s[s->l-2] == '/') s->l -= 2;
 		ks_c(s, '\t'); ks_d(s, qlen); ks_s(s, "\t0\t0\t*\t*\t0\t0\t0\t0\t0\t0\n");
 		return;
 	}
@@ -55,7 +62,7 @@ void mg_write_gaf(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, int32_t 
 		if (p->id != p->parent && !(flag & MG_M_PRINT_2ND)) continue;
 		if (p->cnt == 0) continue;
 		ks_s(s, qname);
-		if ((flag & MG_M_FRAG_MERGE) && n_seg == 2 && s->l > 2 && s->s[s->l-1] == '1' && s->s[s->l-2] == '/') s->l -= 2;
+		if ((flag & MG_M_FRAG_MERGE) && n_seg == 2 && s->l > l0 + 2 && s->s[s->l-1] == '1' && s->s[s->l-2] == '/') s->l -= 2;
 		ks_c(s, '\t'); ks_d(s, qlen); ks_c(s, '\t'); ks_d(s, p->qs); ks_c(s, '\t'); ks_d(s, p->qe); ks_s(s, "\t+\t");
 		sign_pos = (int32_t)s->l - 2;
 		if (flag & MG_M_VERTEX_COOR) {
@@ -119,29 +126,51 @@ void mg_write_gaf(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, int32_t 
 			for (j = 0; j < n_seg; ++j) { ks_c(s, ','); ks_d(s, qlens[j]); }
 		}
 		if (p->p) {
+			const int32_t nc = p->p->n_cigar;
+			char *w;
 			ks_s(s, "\tcg:Z:");
-			if (rev_sign) for (j = p->p->n_cigar - 1; j >= 0; --j) { ks_d(s, (int32_t)(p->p->cigar[j] >> 4)); ks_c(s, "MIDNSHP=XB"[p->p->cigar[j] & 0xf]); }
-			else for (j = 0; j < p->p->n_cigar; ++j) { ks_d(s, (int32_t)(p->p->cigar[j] >> 4)); ks_c(s, "MIDNSHP=XB"[p->p->cigar[j] & 0xf]); }
+			ks_room(s, (size_t)nc * 12); /* <= 10 digits + operator per entry: one reservation, raw writes */
+			w = s->s + s->l;
+			for (j = 0; j < nc; ++j) {
+				const uint64_t c = p->p->cigar[rev_sign ? nc - 1 - j : j];
+				uint32_t x = (uint32_t)(c >> 4);
+				if (x < 10) *w++ = (char)('0' + x);
+				else if (x < 100) { *w++ = (char)('0' + x / 10); *w++ = (char)('0' + x % 10); }
+				else {
+					char buf[12];
+					int l = 0;
+					do { buf[l++] = (char)('0' + x % 10); x /= 10; } while (x > 0);
+					while (l > 0) *w++ = buf[--l];
+				}
+				*w++ = "MIDNSHP=XB"[c & 0xf];
+			}
+			s->l = (unsigned)(w - s->s);
+			s->s[s->l] = 0;
 		}
 		if (p->ds.ds) {
 			ks_s(s, "\tds:Z:");
 			if (rev_sign) { /* reverse-complement the difference string entry by entry (format.c:217-241) */
 				const char *ds = p->ds.ds;
 				int32_t ii, jj;
+				char *w;
+				ks_room(s, (size_t)p->ds.len + 1); /* the reversed string has the same length */
+				w = s->s + s->l;
 				for (ii = p->ds.n_off - 1; ii >= 0; --ii) {
 					int32_t off = p->ds.off[ii], en = ii < p->ds.n_off - 1 ? p->ds.off[ii+1] : p->ds.len;
-					ks_c(s, ds[off]);
-					if (ds[off] == ':') ks_sn(s, ds + off + 1, (size_t)(en - off - 1));
-					else if (ds[off] == '*') { for (jj = off + 1; jj < en; ++jj) ks_c(s, (char)mga_comp_table[(uint8_t)ds[jj]]); }
+					*w++ = ds[off];
+					if (ds[off] == ':') { memcpy(w, ds + off + 1, (size_t)(en - off - 1)); w += en - off - 1; }
+					else if (ds[off] == '*') { for (jj = off + 1; jj < en; ++jj) *w++ = (char)mga_comp_table[(uint8_t)ds[jj]]; }
 					else {
 						for (jj = en - 1; jj >= off + 1; --jj) {
-							if (ds[jj] == '[') ks_c(s, ']');
-							else if (ds[jj] == ']') ks_c(s, '[');
-							else ks_c(s, (char)mga_comp_table[(uint8_t)ds[jj]]);
+							if (ds[jj] == '[') *w++ = ']';
+							else if (ds[jj] == ']') *w++ = '[';
+							else *w++ = (char)mga_comp_table[(uint8_t)ds[jj]];
 						}
 					}
 				}
-			} else ks_s(s, p->ds.ds);
+				s->l = (unsigned)(w - s->s);
+				s->s[s->l] = 0;
+			} else ks_sn(s, p->ds.ds, (size_t)p->ds.len);
 		}
 		ks_c(s, '\n');
 		if ((mg_dbg_flag & 0x8) || (flag & MG_M_WRITE_LCHAIN)) { /* per-vertex lines, -S / --write-mz (format.c:252-289) */

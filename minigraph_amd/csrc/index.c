@@ -181,7 +181,7 @@ void mg_idx_destroy(mg_idx_t *gi)
 	if (gi == 0) return;
 	if (gi->B) {
 		mga_dfree(gi->B->dev.d_tab); mga_dfree(gi->B->dev.d_pos); mga_dfree(gi->B->dev.d_seg_len);
-		free(gi->B->occ_hist);
+		free(gi->B->occ_hist); free(gi->B->gaf_out);
 		free(gi->B);
 	}
 	if (gi->es) {

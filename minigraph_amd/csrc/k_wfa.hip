@@ -78,7 +78,7 @@ __device__ __forceinline__ int32_t wfa_lcp(const char *a, const char *b, int32_t
 __global__ void __launch_bounds__(64) k_wfa(int n_items, const int32_t *__restrict__ list,
 											const mga_wfa_prob_t *__restrict__ prob, const char *__restrict__ tseq, const char *__restrict__ qseq,
 											mga_wfa_res_t *__restrict__ res, uint32_t *__restrict__ pool, long long pool_cap, unsigned long long *pool_used,
-											char *__restrict__ ws_base, int *__restrict__ counter, wfa_cfg_t cfg)
+											char *__restrict__ ws_base, int *__restrict__ counter, mga_wfa_retry_t rt, wfa_cfg_t cfg)
 {
 	__shared__ int32_t lo_s[WF_NSLOT], hi_s[WF_NSLOT];
 	__shared__ int32_t item_s;
@@ -288,6 +288,8 @@ __global__ void __launch_bounds__(64) k_wfa(int n_items, const int32_t *__restri
 			r.n_cigar = status == MGA_WFA_OK ? n_cig : 0;
 			r.cig_off = cig_off, r.status = status, r.pad = 0, r.n_iter = n_iter;
 			res[pi] = r;
+			if (status == MGA_WFA_RETRY_TIER) rt.list[atomicAdd(rt.cnt, 1)] = pi; // next tier's work list
+			else if (status != MGA_WFA_OK) atomicAdd(rt.err, 1);
 		}
 		__syncthreads();
 	}
@@ -296,54 +298,32 @@ __global__ void __launch_bounds__(64) k_wfa(int n_items, const int32_t *__restri
 
 // ---- host driver -------------------------------------------------------------------------------
 
-static const wfa_cfg_t g_tier[3] = {
+static const wfa_cfg_t g_tier[2] = {
 	// x o1 e1 o2 e2   wmax   smax   cigcap   tbcap        max_iter   stride
-	{ 4, 4, 2, 15, 1,   256,   1024,    4096,  1 << 16,    100000000, 0 },
 	{ 4, 4, 2, 15, 1,  4096,   8192,   65536,  1 << 24,    100000000, 0 },
 	{ 4, 4, 2, 15, 1, 32768,  32768, 1 << 20,  104000000,  100000000, 0 },
 };
-static const int g_tier_waves[3] = { 8192, 256, 16 };
+static const int g_tier_waves[2] = { 256, 16 };
 
 
 extern "C" int mga_dev_wfa(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
-						   mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier)
+						   mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier, mga_wfa_retry_t rt)
 {
 	if (n <= 0) return 0;
-	if (tier < 0 || tier > 2) { mga_set_error("wfa: bad tier %d", tier); return -1; }
+	if (tier < 0 || tier > 1) { mga_set_error("wfa: bad tier %d", tier); return -1; }
 	wfa_cfg_t cfg = g_tier[tier];
 	cfg.ws_stride = (int64_t)wfa_ws_bytes(cfg);
 	int waves = g_tier_waves[tier];
 	if (waves > n) waves = n;
-	if (mga_dbuf_reserve(&sc->wfa_ws[4 + tier], (size_t)cfg.ws_stride * g_tier_waves[tier]) < 0) return -1;
+	if (mga_dbuf_reserve(&sc->wfa_ws[6 + tier], (size_t)cfg.ws_stride * g_tier_waves[tier]) < 0) return -1;
 	if (mga_dbuf_reserve(&sc->wfa_cnt, 1024) < 0) return -1;
-	hipStream_t st = (hipStream_t)mga_wfa_stream(sc, 4 + tier);
-	int *d_counter = (int*)((char*)sc->wfa_cnt.p + 64 * (4 + tier));
+	hipStream_t st = (hipStream_t)mga_wfa_stream(sc, 6 + tier);
+	int *d_counter = (int*)((char*)sc->wfa_cnt.p + 64 * (6 + tier));
 	MGA_HIP_CHECK(hipMemsetAsync(d_counter, 0, 4, st));
-	mga_prof_begin(st, MGA_K_WFA0 + 4 + tier);
+	mga_prof_begin(st, MGA_K_WFA0 + 6 + tier);
 	hipLaunchKernelGGL(k_wfa, dim3(waves), dim3(64), 0, st, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap,
-					   d_pool_used, (char*)sc->wfa_ws[4 + tier].p, d_counter, cfg);
-	mga_prof_end(st, MGA_K_WFA0 + 4 + tier);
+					   d_pool_used, (char*)sc->wfa_ws[6 + tier].p, d_counter, rt, cfg);
+	mga_prof_end(st, MGA_K_WFA0 + 6 + tier);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;
-}
-
-extern "C" int mga_dev_wfa_tier(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
-								mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier)
-{
-	if (tier < 2) return mga_dev_wfa_reg(sc, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier);
-	if (tier < 5) return mga_dev_wfa_regw(sc, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier - 2, tier);
-	return mga_dev_wfa(sc, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier - 5 + 1); /* HBM tiers with 4096 / 32768 diagonals */
-}
-
-// the band of a 10%-error gap is about as wide as the gap is long ([measured] on the benchmark workload:
-// mean length 76 -> mean score 40 -> band 81), so start where a band of ~1.3x the length fits
-extern "C" int mga_wfa_first_tier(int32_t tl, int32_t ql)
-{
-	const int32_t m = tl > ql ? tl : ql;
-	if (m <= 56) return 0;
-	if (m <= 112) return 1;
-	if (m <= 224) return 2;
-	if (m <= 450) return 3;
-	if (m <= 2048) return 4;
-	return 5;
 }

@@ -1,0 +1,219 @@
+// k_wfa_sched.hip -- device-side scheduling of the gap-filling problems over the WFA capacity tiers.
+//
+// Every problem starts in the cheapest tier its length suggests; a problem that outgrows its tier is appended by
+// the kernel itself to the next tier's work list (mga_wfa_retry_t).  The host only reads a handful of counters
+// per pass -- it never walks the (millions of) problems.
+//   pass 0:  counting sort of the problem ids by (tier, decreasing length): k_wfa_bin_count -> k_wfa_bin_scan ->
+//            k_wfa_bin_scatter.  Longest-first inside a tier starts the slow problems early instead of leaving
+//            them as the tail of the launch.
+//   pass p:  the retry lists written during pass p-1, one tier up (double-buffered work lists).
+// All tiers of a pass run concurrently on their own streams (mga_wfa_fork / mga_wfa_join).
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <stdio.h>
+#include "mga_dev.h"
+#include "dev_common.h"
+
+#define WFS_NBIN (MGA_WFA_N_TIER * 1024)
+
+// the band of a 10%-error gap is about as wide as the gap is long ([measured] on the benchmark workload:
+// mean length 76 -> mean score 40 -> band 81), so start where a band of ~1.1x the length fits
+__host__ __device__ __forceinline__ int wfs_first_tier(int32_t tl, int32_t ql)
+{
+	const int32_t m = tl > ql ? tl : ql;
+	if (m <= 56) return 0;
+	if (m <= 112) return 1;
+	if (m <= 224) return 2;
+	if (m <= 450) return 3;
+	if (m <= 2048) return 4;
+	if (m <= 4096) return 5;
+	return 6;
+}
+
+extern "C" int mga_wfa_first_tier(int32_t tl, int32_t ql) { return wfs_first_tier(tl, ql); }
+
+__global__ void __launch_bounds__(1024) k_wfa_bin_count(int n, const mga_wfa_prob_t *__restrict__ prob, int32_t *__restrict__ key, int *__restrict__ hist)
+{
+	__shared__ int h[WFS_NBIN];
+	for (int i = threadIdx.x; i < WFS_NBIN; i += blockDim.x) h[i] = 0;
+	__syncthreads();
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const int32_t tl = prob[i].tl, ql = prob[i].ql;
+		int lb = (tl + ql) >> 3;
+		if (lb > 1023) lb = 1023;
+		const int k = wfs_first_tier(tl, ql) << 10 | (1023 - lb);
+		key[i] = k;
+		atomicAdd(&h[k], 1);
+	}
+	__syncthreads();
+	for (int i = threadIdx.x; i < WFS_NBIN; i += blockDim.x) if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+// counts -> exclusive offsets in place (the scatter's cursors); tier_off[t] = first list slot of tier t, tier_off[N_TIER] = n
+__global__ void __launch_bounds__(1024) k_wfa_bin_scan(int *__restrict__ hist, int *__restrict__ tier_off)
+{
+	constexpr int PER = WFS_NBIN / 1024;
+	__shared__ int wsum[16];
+	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	int v[PER], sum = 0;
+#pragma unroll
+	for (int i = 0; i < PER; ++i) { v[i] = hist[tid * PER + i]; sum += v[i]; }
+	int inc = sum;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(inc, d); if (lane >= d) inc += u; }
+	if (lane == 63) wsum[wid] = inc;
+	__syncthreads();
+	int base = 0;
+	for (int w = 0; w < wid; ++w) base += wsum[w];
+	int run = base + inc - sum;
+#pragma unroll
+	for (int i = 0; i < PER; ++i) {
+		const int b = tid * PER + i;
+		hist[b] = run;
+		if ((b & 1023) == 0) tier_off[b >> 10] = run;
+		run += v[i];
+	}
+	if (tid == 1023) tier_off[MGA_WFA_N_TIER] = run;
+}
+
+__global__ void __launch_bounds__(256) k_wfa_bin_scatter(int n, const int32_t *__restrict__ key, int *__restrict__ cursor, int32_t *__restrict__ list)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) list[atomicAdd(&cursor[key[i]], 1)] = i;
+}
+
+__global__ void __launch_bounds__(256) k_wfa_sum_cells(int n, const mga_wfa_res_t *__restrict__ res, unsigned long long *__restrict__ out)
+{
+	__shared__ unsigned long long ws[4];
+	unsigned long long s = 0;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) s += (unsigned long long)res[i].n_iter;
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
+	if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) atomicAdd(out, ws[0] + ws[1] + ws[2] + ws[3]);
+}
+
+// ---- CIGARs back in PROBLEM order ----------------------------------------------------------------------------
+// The kernels append CIGARs to the pool in completion order; the host stitches them per read, i.e. in problem
+// order.  Gathering them on the device turns ~120 cache misses per read on the host into one sequential stream.
+__global__ void __launch_bounds__(256) k_wfa_ncig(int n, const mga_wfa_res_t *__restrict__ res, int32_t *__restrict__ ncig)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) ncig[i] = res[i].status == MGA_WFA_OK ? res[i].n_cigar : 0;
+}
+
+// one wavefront per 64 consecutive problems: lanes stride over the group's output range; the owner of an output
+// slot is found by a 6-step binary search over the 64 offsets held one per lane
+__global__ void __launch_bounds__(256) k_wfa_gather(int n, const mga_wfa_res_t *__restrict__ res, const int64_t *__restrict__ off,
+													const uint32_t *__restrict__ pool, uint32_t *__restrict__ ord)
+{
+	const int lane = threadIdx.x & 63;
+	const int g = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64;
+	if (g >= n) return;
+	const int me = g + lane < n ? g + lane : n - 1;
+	const long long o_l = g + lane < n ? off[g + lane] : off[n];
+	const long long c_l = res[me].cig_off;
+	const long long o_end = off[g + 64 < n ? g + 64 : n];
+	for (long long o0 = __shfl(o_l, 0); o0 < o_end; o0 += 64) { // uniform trip count: the shuffles below need every lane
+		const long long o = o0 + lane;
+		int lo = 0;
+#pragma unroll
+		for (int step = 32; step > 0; step >>= 1) {
+			const long long v = __shfl(o_l, lo + step);
+			if (v <= o) lo += step; // offsets beyond the last problem equal off[n] > o
+		}
+		const long long src = __shfl(c_l, lo) + (o - __shfl(o_l, lo));
+		if (o < o_end) ord[o] = pool[src];
+	}
+}
+
+extern "C" int mga_dev_wfa_gather(mga_sctx_t *sc, int n, const mga_wfa_res_t *d_res, const uint32_t *d_pool, int32_t *d_ncig, int64_t *d_off, uint32_t *d_ord,
+								  int64_t ord_cap, int64_t *h_total)
+{
+	*h_total = 0;
+	if (n <= 0) return 0;
+	hipStream_t st = (hipStream_t)sc->stream;
+	long long tot = 0;
+	hipLaunchKernelGGL(k_wfa_ncig, dim3((n + 255) / 256), dim3(256), 0, st, n, d_res, d_ncig);
+	MGA_HIP_CHECK(hipGetLastError());
+	if (mga_dev_scan_i32_to_i64(sc, d_ncig, n, d_off) < 0) return -1;
+	if (mga_d2h_s(sc, &tot, d_off + n, 8) < 0 || mga_ssync(sc) < 0) return -1;
+	if (tot > ord_cap) { mga_set_error("WFA gather: %lld operators exceed the buffer of %lld", tot, (long long)ord_cap); return -1; }
+	hipLaunchKernelGGL(k_wfa_gather, dim3((n + 255) / 256), dim3(256), 0, st, n, d_res, (const int64_t*)d_off, d_pool, d_ord);
+	MGA_HIP_CHECK(hipGetLastError());
+	*h_total = (int64_t)tot;
+	return 0;
+}
+
+extern "C" int mga_dev_wfa_tier(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+								mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier, mga_wfa_retry_t rt)
+{
+	if (tier < 6) return mga_dev_wfa_reg(sc, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier, rt);
+	return mga_dev_wfa(sc, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier - 6, rt); /* HBM tiers with 4096 / 32768 diagonals */
+}
+
+extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+								 mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int64_t *cells)
+{
+	if (cells) *cells = 0;
+	if (n <= 0) return 0;
+	static int dbg = -1;
+	if (dbg < 0) { const char *e = getenv("MGA_DEBUG_WFA"); dbg = e && atoi(e) > 0; }
+	hipStream_t st = (hipStream_t)sc->stream;
+	// ctl: hist[NBIN] | tier_off[16] | rc[2][16] | err[2] | cells (8 bytes)
+	constexpr int O_TOFF = WFS_NBIN, O_RC = O_TOFF + 16, O_ERR = O_RC + 32, O_CELLS = O_ERR + 2, N_CTL = O_CELLS + 2;
+	if (mga_dbuf_reserve(&sc->wfa_list[0], (size_t)n * 4 + 64) < 0 || mga_dbuf_reserve(&sc->wfa_list[1], (size_t)n * 4 + 64) < 0 ||
+		mga_dbuf_reserve(&sc->wfa_key, (size_t)n * 4 + 64) < 0 || mga_dbuf_reserve(&sc->wfa_ctl, (size_t)N_CTL * 4) < 0) return -1;
+	int *ctl = (int*)sc->wfa_ctl.p;
+	int32_t *L[2] = { (int32_t*)sc->wfa_list[0].p, (int32_t*)sc->wfa_list[1].p };
+	MGA_HIP_CHECK(hipMemsetAsync(ctl, 0, (size_t)N_CTL * 4, st));
+	{
+		int nb = (n + 1023) / 1024;
+		if (nb > 1024) nb = 1024;
+		mga_prof_begin(st, MGA_K_SCAN);
+		hipLaunchKernelGGL(k_wfa_bin_count, dim3(nb), dim3(1024), 0, st, n, d_prob, (int32_t*)sc->wfa_key.p, ctl);
+		hipLaunchKernelGGL(k_wfa_bin_scan, dim3(1), dim3(1024), 0, st, ctl, ctl + O_TOFF);
+		hipLaunchKernelGGL(k_wfa_bin_scatter, dim3((n + 255) / 256), dim3(256), 0, st, n, (const int32_t*)sc->wfa_key.p, ctl, L[0]);
+		mga_prof_end(st, MGA_K_SCAN);
+		MGA_HIP_CHECK(hipGetLastError());
+	}
+	int h[MGA_WFA_N_TIER + 2], off[MGA_WFA_N_TIER + 1], cnt[MGA_WFA_N_TIER + 1];
+	if (mga_d2h_s(sc, h, ctl + O_TOFF, (MGA_WFA_N_TIER + 1) * 4) < 0 || mga_ssync(sc) < 0) return -1;
+	for (int t = 0; t < MGA_WFA_N_TIER; ++t) off[t] = h[t], cnt[t] = h[t + 1] - h[t];
+	for (int pass = 0, cur = 0;; ++pass, cur ^= 1) {
+		int *rc = ctl + O_RC + 16 * (pass & 1), nstart[MGA_WFA_N_TIER + 2];
+		MGA_HIP_CHECK(hipMemsetAsync(rc, 0, 16 * 4, st));
+		nstart[0] = nstart[1] = 0; // region of tier u in the next pass's list: as many slots as tier u-1 runs problems now
+		for (int u = 1; u <= MGA_WFA_N_TIER; ++u) nstart[u + 1] = nstart[u] + cnt[u - 1];
+		if (mga_wfa_fork(sc) < 0) return -1;
+		for (int t = 0; t < MGA_WFA_N_TIER; ++t) {
+			if (cnt[t] <= 0) continue;
+			mga_wfa_retry_t rt = { L[cur ^ 1] + nstart[t + 1], rc + t + 1, ctl + O_ERR };
+			if (mga_dev_wfa_tier(sc, cnt[t], L[cur] + off[t], d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, t, rt) < 0) return -1;
+		}
+		if (mga_wfa_join(sc) < 0) return -1;
+		int hr[MGA_WFA_N_TIER + 1], herr = 0, left = 0;
+		if (mga_d2h_s(sc, hr, rc, (MGA_WFA_N_TIER + 1) * 4) < 0 || mga_d2h_s(sc, &herr, ctl + O_ERR, 4) < 0 || mga_ssync(sc) < 0) return -1;
+		if (dbg) {
+			fprintf(stderr, "[wfa] pass %d:", pass);
+			for (int t = 0; t < MGA_WFA_N_TIER; ++t) if (cnt[t]) fprintf(stderr, " tier %d: %d (%d retry)", t, cnt[t], hr[t + 1]);
+			fprintf(stderr, "\n");
+		}
+		if (herr) { mga_set_error("WFA: %d problems failed (CIGAR pool of %ld ops exhausted, or iteration cap)", herr, (long)pool_cap); return -1; }
+		if (hr[MGA_WFA_N_TIER] > 0) { mga_set_error("%d WFA problems exceed the largest capacity tier", hr[MGA_WFA_N_TIER]); return -1; }
+		cnt[0] = 0;
+		for (int u = 1; u < MGA_WFA_N_TIER; ++u) cnt[u] = hr[u], off[u] = nstart[u], left += hr[u];
+		if (left == 0) break;
+	}
+	if (cells) {
+		unsigned long long c = 0;
+		int nb = (n + 255) / 256;
+		if (nb > 2048) nb = 2048;
+		hipLaunchKernelGGL(k_wfa_sum_cells, dim3(nb), dim3(256), 0, st, n, (const mga_wfa_res_t*)d_res, (unsigned long long*)(ctl + O_CELLS));
+		MGA_HIP_CHECK(hipGetLastError());
+		if (mga_d2h_s(sc, &c, ctl + O_CELLS, 8) < 0 || mga_ssync(sc) < 0) return -1;
+		*cells = (int64_t)c;
+	}
+	return 0;
+}

@@ -117,7 +117,7 @@ int64_t mga_reads_bases(const mga_reads_t *rd) { return rd->n_bases; }
 int mga_map_gaf(const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, const mg_mapopt_t *opt, int n_threads,
 				const char *d_seq, const int64_t *q_off, char **gaf, int64_t *gaf_len);
 
-/* map a resident read set and format its GAF (input order) into one malloc'ed buffer; formatting runs inside the
+/* map a resident read set and format its GAF (input order) into the index-owned output buffer; formatting runs inside the
  * mapping pipeline, chunk by chunk */
 int mga_map_reads(const mg_idx_t *gi, const mga_reads_t *rd, const mg_mapopt_t *opt, int n_threads, char **gaf, int64_t *gaf_len)
 {

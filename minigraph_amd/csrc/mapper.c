@@ -22,6 +22,15 @@
 #include "align.h"
 #include "mapper.h"
 
+/* MGA_DEBUG_PIPE: per-stage host CPU time (thread clocks), summed over worker threads */
+#include <time.h>
+enum { C_LCCOPY, C_LCRESCUE, C_LCPREP, C_GCDP, C_GCGEN, C_GCPOST, C_PLAN, C_APPLY, C_DS, C_GAF, C_EXPORT, C_N };
+static const char *g_cname[C_N] = { "lchain_copy", "lchain_rescue", "lchain_gen", "gchain_dp", "gchain_gen", "gchain_post", "plan_cigar", "apply_cigar", "gen_ds", "gaf", "export" };
+static volatile int64_t g_cpu_ns[C_N];
+static int g_cpu_on = 0;
+static inline int64_t cpu_now(void) { struct timespec ts; if (!g_cpu_on) return 0; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (int64_t)ts.tv_sec * 1000000000LL + ts.tv_nsec; }
+#define CPU_ADD(which, t0) do { if (g_cpu_on) { int64_t t1_ = cpu_now(); __sync_fetch_and_add(&g_cpu_ns[which], t1_ - (t0)); (t0) = t1_; } } while (0)
+
 struct mg_tbuf_s { int dummy; };
 mg_tbuf_t *mg_tbuf_init(void) { return (mg_tbuf_t*)calloc(1, sizeof(mg_tbuf_t)); } /* map-algo.c:14-20: scratch is per batch here */
 void mg_tbuf_destroy(mg_tbuf_t *b) { free(b); }
@@ -53,8 +62,7 @@ struct mga_batch_s {
 	const mg128_t *a;
 	int a_is_raw;
 	/* stage-2 inputs */
-	const mga_wfa_res_t *res;
-	const uint32_t *pool;
+	mga_cigsrc_t src;
 	int err;
 };
 
@@ -104,6 +112,7 @@ static void chain_worker(void *data, int64_t i, int tid)
 	mg_lchain_t *lc = 0;
 	mg_gchains_t *gcs;
 
+	int64_t tc = cpu_now();
 	b->gcs[i] = 0;
 	if (qlen == 0) return; /* map-algo.c:359-360 */
 	if (opt->max_qlen > 0 && qlen > opt->max_qlen) return;
@@ -122,6 +131,7 @@ static void chain_worker(void *data, int64_t i, int tid)
 			a = MGA_MALLOC(mg128_t, n_a); memcpy(a, b->a + b->a_off[i], (size_t)n_a * 16);
 		}
 	}
+	CPU_ADD(C_LCCOPY, tc);
 	/* long-join rescue (map-algo.c:407-417) */
 	if (opt->bw_long > opt->bw && (opt->flag & (MG_M_SPLICE | MG_M_SR)) == 0 && n_lc > 1) {
 		int32_t st = (int32_t)a[0].y, en = (int32_t)a[(int32_t)u[0] - 1].y;
@@ -135,6 +145,7 @@ static void chain_worker(void *data, int64_t i, int tid)
 			free(a); a = a2;
 		}
 	}
+	CPU_ADD(C_LCRESCUE, tc);
 	if (n_lc) { /* map-algo.c:423-448 */
 		const int32_t *mini = b->mini_pos + b->mini_off[i];
 		const int32_t n_mini = (int32_t)(b->mini_off[i + 1] - b->mini_off[i]);
@@ -143,16 +154,20 @@ static void chain_worker(void *data, int64_t i, int tid)
 		for (k = 0; k < n_lc; ++k) mga_update_anchors(lc[k].cnt, &a[lc[k].off], n_mini, mini);
 	}
 	free(u); u = 0;
+	CPU_ADD(C_LCPREP, tc);
 	n_gc = mga_gchain1_dp(gi->g, &n_lc, lc, qlen, opt->bw_long, opt->bw_long, opt->bw_long, opt->max_gc_skip, opt->ref_bonus,
 						  b->pen_gap, b->pen_skip, opt->mask_level, a, &u2);
+	CPU_ADD(C_GCDP, tc);
 	gcs = mga_gchain_gen(gi->g, gi->es, n_gc, u2, lc, a, hash, opt->min_gc_cnt, opt->min_gc_score, opt->gdp_max_ed, 1, seq);
 	gcs->rep_len = b->rep_len[i];
 	free(a); free(lc); free(u2);
+	CPU_ADD(C_GCGEN, tc);
 	mga_gchain_set_parent(opt->mask_level, gcs->n_gc, gcs->gc, opt->sub_diff, 0);
 	mga_gchain_flt_sub(opt->pri_ratio, gi->k * 2, opt->best_n, gcs->n_gc, gcs->gc);
 	mga_gchain_drop_flt(gcs);
 	mga_gchain_set_mapq(gcs, qlen, b->n_mz[i], opt->min_gc_score);
 	b->gcs[i] = gcs;
+	CPU_ADD(C_GCPOST, tc);
 	if (opt->flag & MG_M_CIGAR) { /* list the gaps of every chain for the WFA kernel */
 		read_plan_t *pl = &b->plan[i];
 		mga_tpool_t *tp = &b->tp[tid];
@@ -163,6 +178,7 @@ static void chain_worker(void *data, int64_t i, int tid)
 			mga_plan_cigar(gi->g, gi->es, gcs, k, b->q_off ? b->q_off[i] : 0, tp);
 		}
 		pl->item_off[gcs->n_gc] = tp->n_item;
+		CPU_ADD(C_PLAN, tc);
 	}
 }
 
@@ -190,12 +206,14 @@ static void export_worker(void *data, int64_t t, int tid)
 	const mga_batch_t *b = e->b;
 	const mga_tpool_t *tp = &b->tp[t];
 	int64_t j;
+	int64_t tc = cpu_now();
 	(void)tid;
 	memcpy(e->tseq + b->tp_t_base[t], tp->tseq, (size_t)tp->n_t);
 	for (j = 0; j < tp->n_prob; ++j) {
 		e->prob[b->tp_prob_base[t] + j] = tp->prob[j];
 		e->prob[b->tp_prob_base[t] + j].t_off += b->tp_t_base[t];
 	}
+	CPU_ADD(C_EXPORT, tc);
 }
 
 void mga_batch_wfa_export(const mga_batch_t *b, mga_wfa_prob_t *prob, char *tseq)
@@ -211,20 +229,40 @@ static void finish_worker(void *data, int64_t i, int tid)
 	mg_gchains_t *gcs = b->gcs[i];
 	read_plan_t *pl = &b->plan[i];
 	int32_t k;
+	int64_t tc = cpu_now();
 	(void)tid;
 	if (gcs == 0 || pl->item_off == 0) return;
 	for (k = 0; k < gcs->n_gc; ++k) {
 		const mga_tpool_t *tp = &b->tp[pl->tid];
-		int r = mga_apply_cigar(gcs, k, tp->item + pl->item_off[k], pl->item_off[k + 1] - pl->item_off[k], b->tp_prob_base[pl->tid], b->res, b->pool);
+		int r = mga_apply_cigar(gcs, k, tp->item + pl->item_off[k], pl->item_off[k + 1] - pl->item_off[k], b->tp_prob_base[pl->tid], &b->src);
 		if (r < 0) { b->err = r; return; }
 	}
+	CPU_ADD(C_APPLY, tc);
 	mga_gen_ds(b->gi->es, b->seqs[i], gcs);
+	CPU_ADD(C_DS, tc);
 }
+
+static int batch_finish(mga_batch_t *b);
 
 int mga_batch_finish(mga_batch_t *b, const mga_wfa_res_t *res, const uint32_t *pool)
 {
+	memset(&b->src, 0, sizeof b->src);
+	b->src.res = res, b->src.pool = pool;
+	return batch_finish(b);
+}
+
+/* same with the CIGARs gathered in problem order by the device (k_wfa_sched.hip): ncig[j] operators at ord + off[j] */
+int mga_batch_finish_ordered(mga_batch_t *b, const int32_t *ncig, const int64_t *off, const uint32_t *ord)
+{
+	memset(&b->src, 0, sizeof b->src);
+	b->src.ncig = ncig, b->src.off = off, b->src.ord = ord;
+	return batch_finish(b);
+}
+
+static int batch_finish(mga_batch_t *b)
+{
 	if (!(b->opt.flag & MG_M_CIGAR)) return 0;
-	b->res = res, b->pool = pool, b->err = 0;
+	b->err = 0;
 	mga_parallel_for(b->n_threads, b->n, finish_worker, b);
 	if (b->err == -1) mga_set_error("a gap exceeded miniwfa's max_iter (1e8 cells): the k-mer chaining heuristic of mwf_wfa_chain (miniwfa.c:776-822) is not implemented on this path yet");
 	else if (b->err < 0) mga_set_error("stitched CIGAR is inconsistent with the chain coordinates");
@@ -261,28 +299,24 @@ void mga_batch_destroy(mga_batch_t *b)
  * ---------------------------------------------------------------------------------------------- */
 #include <pthread.h>
 
-/* order problem ids by decreasing tl+ql (bucket sort on min(len/8, 1023)) */
-static void lpt_order(int32_t *ids, int64_t n, const mga_wfa_prob_t *prob)
-{
-	int64_t cnt[1025], i;
-	int32_t *tmp = MGA_MALLOC(int32_t, n);
-	memset(cnt, 0, sizeof cnt);
-	for (i = 0; i < n; ++i) { int b = (prob[ids[i]].tl + prob[ids[i]].ql) >> 3; if (b > 1023) b = 1023; ++cnt[1023 - b + 1]; }
-	for (i = 0; i < 1024; ++i) cnt[i + 1] += cnt[i];
-	for (i = 0; i < n; ++i) { int b = (prob[ids[i]].tl + prob[ids[i]].ql) >> 3; if (b > 1023) b = 1023; tmp[cnt[1023 - b]++] = ids[i]; }
-	memcpy(ids, tmp, (size_t)n * 4);
-	free(tmp);
-}
-
 typedef struct {
 	mga_sctx_t *sc;
 	mga_dbuf_t seq, qoff, cnt, mzoff, mz, occ, val, na, nmini, rep, aoff, minioff, a, tmp, mini, u, b, nu, nb, ws;
-	mga_dbuf_t tseq, prob, res, pool, used, list;
-	mga_hbuf_t h_b, h_u, h_mini, h_tseq, h_prob, h_res, h_pool, h_seq, h_list; /* pinned staging */
+	mga_dbuf_t tseq, prob, res, pool, used, ncig, cigoff, ord;
+	mga_hbuf_t h_b, h_u, h_mini, h_tseq, h_prob, h_pool, h_seq, h_ncig, h_cigoff; /* pinned staging */
 } pipe_ctx_t;
 
 #define MGA_MAX_PIPE 4
 static pipe_ctx_t g_pipe[MGA_MAX_PIPE]; /* grow-only, reused across batches (one GPU per process) */
+
+static double g_job_t0;
+static int g_dbg_pipe = -1;
+#define PIPE_LOG(what, c, tb) do { if (g_dbg_pipe > 0) fprintf(stderr, "[pipe] chunk %d %-10s %8.1f .. %8.1f ms\n", (c), (what), ((tb) - g_job_t0) * 1e3, (mga_wtime() - g_job_t0) * 1e3); } while (0)
+
+/* Two pipeline threads that start together would run every stage in lockstep (both on the GPU, then both on the host).
+ * One token per GPU phase staggers them: while one chunk fills gaps on the GPU, the other one's host stages run, and the
+ * cheap front phase (sketch/seed/chain) of one chunk fills the tail of another chunk's WFA launches. */
+static pthread_mutex_t g_gpu_front = PTHREAD_MUTEX_INITIALIZER, g_gpu_wfa = PTHREAD_MUTEX_INITIALIZER;
 
 #define CK(x) do { if ((x) < 0) { rc = -1; goto done; } } while (0)
 
@@ -300,12 +334,16 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	const int is_rmq = !!(opt->flag & MG_M_RMQ);
 	const char *d_seq;
 	double t0, t1;
+	pthread_mutex_t *held = 0; /* GPU phase token currently owned */
+#define GPU_ACQUIRE(m) do { pthread_mutex_lock(m); held = (m); } while (0)
+#define GPU_RELEASE() do { if (held) { pthread_mutex_unlock(held); held = 0; } } while (0)
 
 	if (opt->flag & (MG_M_SR | MG_M_HEAP_SORT | MG_M_SPLICE | MG_M_NO_DIAG)) {
 		mga_set_error("mg_map_batch: short-read / splice / -D modes are outside the accelerated long-read path"); rc = -1; goto done;
 	}
 	/* ---- reads -> HBM, back to back, 64 readable bytes of padding at the end (8-byte compares in k_wfa);
 	 *      skipped when the caller keeps the batch resident (d_seq_res + absolute offsets q_off_res) ---- */
+	GPU_ACQUIRE(&g_gpu_front);
 	t0 = mga_wtime();
 	CK(mga_dbuf_reserve(&P->qoff, (size_t)(n + 1) * 8));
 	if (d_seq_res) {
@@ -345,6 +383,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	h_aoff = MGA_MALLOC(int64_t, n + 1); h_minioff = MGA_MALLOC(int64_t, n + 1); h_rep = MGA_MALLOC(int32_t, n);
 	CK(mga_d2h_s(sc, h_aoff, P->aoff.p, (size_t)(n + 1) * 8)); CK(mga_d2h_s(sc, h_minioff, P->minioff.p, (size_t)(n + 1) * 8)); CK(mga_d2h_s(sc, h_rep, P->rep.p, (size_t)n * 4));
 	CK(mga_ssync(sc));
+	if (g_dbg_pipe > 1) PIPE_LOG(" sketch", n, t0);
 	t1 = mga_wtime(); st->t_sketch += t1 - t0; t0 = t1;
 	n_a = h_aoff[n], n_mini = h_minioff[n];
 	CK(mga_dbuf_reserve(&P->a, (size_t)n_a * 16 + 64)); CK(mga_dbuf_reserve(&P->tmp, (size_t)n_a * 16 + 64)); CK(mga_dbuf_reserve(&P->mini, (size_t)n_mini * 4 + 16));
@@ -368,77 +407,52 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 		CK(mga_d2h_s(sc, P->h_u.p, P->u.p, (size_t)n_a * 8)); CK(mga_d2h_s(sc, P->h_b.p, P->b.p, (size_t)n_a * 16));
 	} else CK(mga_d2h_s(sc, P->h_b.p, P->a.p, (size_t)n_a * 16));
 	CK(mga_ssync(sc));
+	GPU_RELEASE();
+	if (g_dbg_pipe > 1) PIPE_LOG(" lchain", n, t0);
 	t1 = mga_wtime(); st->t_lchain += t1 - t0; t0 = t1;
 	/* ---- host: graph chaining + gap list ---- */
 	b = mga_batch_init(gi, opt, n, qlens, seqs, qnames, q_off, n_threads);
 	CK(mga_batch_chain(b, h_nmz, h_rep, (const int32_t*)P->h_mini.p, h_minioff, h_nu, h_nb, (const uint64_t*)P->h_u.p, (const mg128_t*)P->h_b.p, h_aoff, is_rmq));
+	if (g_dbg_pipe > 1) PIPE_LOG(" hostchain", n, t0);
 	t1 = mga_wtime(); st->t_host_chain += t1 - t0; t0 = t1;
 	/* ---- WFA over all gaps ---- */
 	n_prob = mga_batch_n_wfa(b), n_tb = mga_batch_wfa_target_bytes(b);
 	if ((opt->flag & MG_M_CIGAR) && n_prob > 0) {
-		unsigned long long used = 0;
 		mga_wfa_prob_t *h_prob;
-		mga_wfa_res_t *h_res;
-		int32_t *todo;
-		int8_t *tier_of;
-		int64_t cnt[MGA_WFA_N_TIER + 1], j, n_left;
-		int pass = 0;
+		int64_t cells = 0;
+		if (n_prob > 0x7fffffff) { mga_set_error("too many WFA problems in one chunk (%ld); lower MGA_CHUNK", (long)n_prob); rc = -1; goto done; }
 		CK(mga_hbuf_reserve(&P->h_prob, (size_t)n_prob * sizeof(mga_wfa_prob_t))); CK(mga_hbuf_reserve(&P->h_tseq, (size_t)n_tb + 64));
-		CK(mga_hbuf_reserve(&P->h_res, (size_t)n_prob * sizeof(mga_wfa_res_t))); CK(mga_hbuf_reserve(&P->h_list, (size_t)n_prob * 4));
-		h_prob = (mga_wfa_prob_t*)P->h_prob.p, h_res = (mga_wfa_res_t*)P->h_res.p, todo = (int32_t*)P->h_list.p;
+		h_prob = (mga_wfa_prob_t*)P->h_prob.p;
 		mga_batch_wfa_export(b, h_prob, (char*)P->h_tseq.p);
 		memset((char*)P->h_tseq.p + n_tb, 0, 64);
 		CK(mga_dbuf_reserve(&P->tseq, (size_t)n_tb + 64)); CK(mga_dbuf_reserve(&P->prob, (size_t)n_prob * sizeof(mga_wfa_prob_t))); CK(mga_dbuf_reserve(&P->res, (size_t)n_prob * sizeof(mga_wfa_res_t)));
-		CK(mga_dbuf_reserve(&P->used, 64)); CK(mga_dbuf_reserve(&P->list, (size_t)n_prob * 4));
+		CK(mga_dbuf_reserve(&P->used, 64));
+		GPU_ACQUIRE(&g_gpu_wfa);
 		CK(mga_h2d_s(sc, P->tseq.p, P->h_tseq.p, (size_t)n_tb + 64)); CK(mga_h2d_s(sc, P->prob.p, h_prob, (size_t)n_prob * sizeof(mga_wfa_prob_t)));
 		pool_cap = (n_tb + n_prob * 8) / 2 + 4096 + 40000LL * 512; /* + abandoned block tails (<= 512 ops) of every resident wave */
 		for (i = 0; i < b->n_threads; ++i) pool_cap += b->tp[i].wfa_q_bases / 2;
 		CK(mga_dbuf_reserve(&P->pool, (size_t)pool_cap * 4)); CK(mga_dmemset_s(sc, P->used.p, 0, 8));
-		/* every problem starts in the cheapest tier its length suggests; all first-pass launches are queued back to back,
-		 * then only the (few) problems that outgrew their tier are re-run one tier up */
-		tier_of = (int8_t*)malloc((size_t)n_prob);
-		for (j = 0; j < n_prob; ++j) tier_of[j] = (int8_t)mga_wfa_first_tier(h_prob[j].tl, h_prob[j].ql);
-		n_left = n_prob;
-		while (n_left > 0) {
-			int64_t k, pos[MGA_WFA_N_TIER];
-			memset(cnt, 0, sizeof cnt);
-			for (j = 0; j < n_prob; ++j) if (tier_of[j] >= 0) ++cnt[tier_of[j] + 1];
-			for (k = 0; k < MGA_WFA_N_TIER; ++k) cnt[k + 1] += cnt[k];
-			for (k = 0; k < MGA_WFA_N_TIER; ++k) pos[k] = cnt[k];
-			for (j = 0; j < n_prob; ++j) if (tier_of[j] >= 0) todo[pos[tier_of[j]]++] = (int32_t)j;
-			for (k = 0; k < MGA_WFA_N_TIER; ++k) /* longest first inside a tier: the slow problems start early instead of forming the tail */
-				if (cnt[k + 1] - cnt[k] > 1) lpt_order(todo + cnt[k], cnt[k + 1] - cnt[k], h_prob);
-			if (mga_h2d_s(sc, P->list.p, todo, (size_t)n_left * 4) < 0 || mga_wfa_fork(sc) < 0) { free(tier_of); rc = -1; goto done; }
-			for (k = 0; k < MGA_WFA_N_TIER; ++k) {
-				int64_t c = cnt[k + 1] - cnt[k];
-				if (c > 0 && mga_dev_wfa_tier(sc, (int)c, (const int32_t*)P->list.p + cnt[k], (const mga_wfa_prob_t*)P->prob.p, (const char*)P->tseq.p, d_seq,
-											  (mga_wfa_res_t*)P->res.p, (uint32_t*)P->pool.p, pool_cap, (unsigned long long*)P->used.p, (int)k) < 0) { free(tier_of); rc = -1; goto done; }
-			}
-			if (mga_wfa_join(sc) < 0 || mga_d2h_s(sc, h_res, P->res.p, (size_t)n_prob * sizeof(mga_wfa_res_t)) < 0 || mga_ssync(sc) < 0) { free(tier_of); rc = -1; goto done; }
-			if (getenv("MGA_DEBUG_WFA")) {
-				int64_t nt[MGA_WFA_N_TIER] = {0}, nr[MGA_WFA_N_TIER] = {0}, mx[MGA_WFA_N_TIER] = {0}, sm[MGA_WFA_N_TIER] = {0}; int mxs[MGA_WFA_N_TIER] = {0};
-				for (j = 0; j < n_prob; ++j) if (tier_of[j] >= 0) { int t = tier_of[j]; ++nt[t]; if (h_res[j].status == MGA_WFA_RETRY_TIER) ++nr[t]; sm[t] += h_res[j].n_iter; if (h_res[j].n_iter > mx[t]) mx[t] = h_res[j].n_iter, mxs[t] = h_res[j].score; }
-				for (k = 0; k < MGA_WFA_N_TIER; ++k) if (nt[k]) fprintf(stderr, "[wfa] pass %d tier %ld: %ld problems, %ld retry, cells sum %ld max %ld (score %d)\n", pass, (long)k, (long)nt[k], (long)nr[k], (long)sm[k], (long)mx[k], mxs[k]);
-			}
-			for (j = 0, n_left = 0; j < n_prob; ++j) {
-				if (tier_of[j] < 0) continue;
-				if (h_res[j].status == MGA_WFA_RETRY_TIER) {
-					if (++tier_of[j] >= MGA_WFA_N_TIER) { free(tier_of); mga_set_error("a WFA problem exceeds the largest capacity tier"); rc = -1; goto done; }
-					++n_left;
-				} else if (h_res[j].status == MGA_WFA_POOL_FULL) { free(tier_of); mga_set_error("WFA CIGAR pool exhausted (capacity %ld ops)", (long)pool_cap); rc = -1; goto done; }
-				else tier_of[j] = -1;
-			}
-			if (++pass > 2 * MGA_WFA_N_TIER) break;
+		/* the tier ladder runs on the device (k_wfa_sched.hip); the host never walks the problems */
+		CK(mga_dev_wfa_solve(sc, (int)n_prob, (const mga_wfa_prob_t*)P->prob.p, (const char*)P->tseq.p, d_seq, (mga_wfa_res_t*)P->res.p,
+							 (uint32_t*)P->pool.p, pool_cap, (unsigned long long*)P->used.p, &cells));
+		{ /* CIGARs back in problem order (one sequential stream for the stitching threads), then to the host */
+			int64_t n_ops = 0;
+			CK(mga_dbuf_reserve(&P->ncig, (size_t)n_prob * 4 + 16)); CK(mga_dbuf_reserve(&P->cigoff, (size_t)(n_prob + 1) * 8)); CK(mga_dbuf_reserve(&P->ord, (size_t)pool_cap * 4));
+			CK(mga_dev_wfa_gather(sc, (int)n_prob, (const mga_wfa_res_t*)P->res.p, (const uint32_t*)P->pool.p, (int32_t*)P->ncig.p, (int64_t*)P->cigoff.p,
+								  (uint32_t*)P->ord.p, pool_cap, &n_ops));
+			CK(mga_hbuf_reserve(&P->h_ncig, (size_t)n_prob * 4 + 16)); CK(mga_hbuf_reserve(&P->h_cigoff, (size_t)(n_prob + 1) * 8)); CK(mga_hbuf_reserve(&P->h_pool, (size_t)n_ops * 4 + 16));
+			CK(mga_d2h_s(sc, P->h_ncig.p, P->ncig.p, (size_t)n_prob * 4)); CK(mga_d2h_s(sc, P->h_cigoff.p, P->cigoff.p, (size_t)(n_prob + 1) * 8));
+			CK(mga_d2h_s(sc, P->h_pool.p, P->ord.p, (size_t)n_ops * 4)); CK(mga_ssync(sc));
 		}
-		free(tier_of);
-		CK(mga_d2h_s(sc, &used, P->used.p, 8)); CK(mga_ssync(sc));
-		CK(mga_hbuf_reserve(&P->h_pool, (size_t)used * 4 + 16));
-		CK(mga_d2h_s(sc, P->h_pool.p, P->pool.p, (size_t)used * 4)); CK(mga_ssync(sc));
-		for (i = 0; i < n_prob; ++i) st->wfa_cells += h_res[i].n_iter;
+		GPU_RELEASE();
+		st->wfa_cells += cells;
 	}
+	if (g_dbg_pipe > 1) PIPE_LOG(" wfa", n, t0);
 	t1 = mga_wtime(); st->t_wfa += t1 - t0; t0 = t1;
 	/* ---- host: CIGAR stitching + ds ---- */
-	CK(mga_batch_finish(b, (const mga_wfa_res_t*)P->h_res.p, (const uint32_t*)P->h_pool.p));
+	if ((opt->flag & MG_M_CIGAR) && n_prob > 0) CK(mga_batch_finish_ordered(b, (const int32_t*)P->h_ncig.p, (const int64_t*)P->h_cigoff.p, (const uint32_t*)P->h_pool.p));
+	else CK(mga_batch_finish(b, 0, 0));
+	if (g_dbg_pipe > 1) PIPE_LOG(" hostpost", n, t0);
 	t1 = mga_wtime(); st->t_host_post += t1 - t0;
 	{
 		mg_gchains_t **r = mga_batch_take_results(b);
@@ -449,6 +463,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	for (i = 0; i < n && h_nb; ++i) st->n_anchor_chained += h_nb[i];
 	mga_batch_stats(b, st);
 done:
+	GPU_RELEASE();
 	if (b) mga_batch_destroy(b);
 	free(q_off); free(h_mzoff); free(h_aoff); free(h_minioff); free(h_nmz); free(h_rep); free(h_nu); free(h_nb);
 	return rc;
@@ -467,6 +482,11 @@ typedef struct {
 	pthread_mutex_t mtx;
 	char errmsg[512];
 	kstring_t *gaf_part; /* when non-NULL: n_chunks * n_threads GAF pieces, in read order; chains are freed after formatting */
+	/* ordered commit of finished chunks into the index-owned output buffer, overlapped with the pipeline */
+	pthread_mutex_t cmtx;
+	char *done;
+	int n_chunks, next_commit;
+	int64_t out_len;
 } pipe_job_t;
 
 typedef struct { pipe_job_t *job; pipe_ctx_t *P; mga_stats_t st; } pipe_thr_t;
@@ -479,18 +499,43 @@ static void gaf_worker(void *data, int64_t t, int tid)
 	pipe_job_t *J = w->J;
 	const int n = w->en - w->st;
 	int64_t b = w->st + (int64_t)n * t / w->T, e = w->st + (int64_t)n * (t + 1) / w->T, i;
-	kstring_t one = {0, 0, 0}, *out = &w->part[t];
+	kstring_t *out = &w->part[t];
+	int64_t tc = cpu_now();
 	(void)tid;
 	for (i = b; i < e; ++i) {
 		int32_t ql = J->qlens[i];
-		mg_write_gaf(&one, J->gi->g, J->gcs[i], 1, &ql, J->qnames ? J->qnames[i] : "*", J->opt->flag, 0);
-		if (one.l) {
-			if ((size_t)out->l + one.l + 1 > out->m) { size_t m = ((size_t)out->l + one.l + 1) * 3 / 2 + 65536; out->m = (unsigned)m; out->s = (char*)realloc(out->s, out->m); }
-			memcpy(out->s + out->l, one.s, one.l); out->l += one.l;
-		}
+		mga_write_gaf_append(out, J->gi->g, J->gcs[i], 1, &ql, J->qnames ? J->qnames[i] : "*", J->opt->flag);
 		mg_gchain_free(J->gcs[i]); J->gcs[i] = 0;
 	}
-	free(one.s);
+	CPU_ADD(C_GAF, tc);
+}
+
+typedef struct { kstring_t *part; int64_t *off; char *dst; } gcopy_t;
+static void gaf_copy_worker(void *data, int64_t i, int tid) { gcopy_t *g = (gcopy_t*)data; (void)tid; if (g->part[i].l) memcpy(g->dst + g->off[i], g->part[i].s, g->part[i].l); free(g->part[i].s); g->part[i].s = 0; }
+
+/* chunk c is formatted: append every chunk that is now complete AND next in read order to the index-owned output buffer */
+static void commit_chunks(pipe_job_t *J, int c)
+{
+	struct mg_idx_bucket_s *B = J->gi->B;
+	pthread_mutex_lock(&J->cmtx);
+	J->done[c] = 1;
+	while (J->next_commit < J->n_chunks && J->done[J->next_commit]) {
+		const int T = J->n_threads;
+		gcopy_t g;
+		int64_t off[T + 1], tot = 0;
+		int k;
+		g.part = J->gaf_part + (size_t)J->next_commit * T, g.off = off;
+		for (k = 0; k < T; ++k) off[k] = tot, tot += g.part[k].l;
+		if (J->out_len + tot + 1 > B->gaf_cap) {
+			B->gaf_cap = (J->out_len + tot + 1) * 3 / 2 + (1 << 20);
+			B->gaf_out = (char*)realloc(B->gaf_out, (size_t)B->gaf_cap);
+		}
+		g.dst = B->gaf_out + J->out_len;
+		mga_parallel_for(T < 16 ? T : 16, T, gaf_copy_worker, &g);
+		J->out_len += tot;
+		++J->next_commit;
+	}
+	pthread_mutex_unlock(&J->cmtx);
 }
 
 static void *pipe_worker(void *a)
@@ -502,6 +547,7 @@ static void *pipe_worker(void *a)
 		int c = __sync_fetch_and_add(&J->next, 1), st = c * J->chunk, en;
 		if (st >= J->n || J->err) break;
 		en = st + J->chunk < J->n ? st + J->chunk : J->n;
+		double tc = mga_wtime();
 		if (map_chunk(t->P, J->gi, en - st, J->qlens + st, J->seqs + st, J->qnames ? J->qnames + st : 0, J->gcs + st, J->opt, J->n_threads,
 					  J->d_seq, J->q_off ? J->q_off + st : 0, &t->st) < 0) {
 			pthread_mutex_lock(&J->mtx);
@@ -509,12 +555,15 @@ static void *pipe_worker(void *a)
 			pthread_mutex_unlock(&J->mtx);
 			break;
 		}
+		PIPE_LOG("map_chunk", c, tc);
 		if (J->gaf_part) { /* GAF text of this chunk, formatted while the other pipeline thread owns the GPU */
 			gafw_t w;
 			double t0 = mga_wtime();
 			w.J = J, w.st = st, w.en = en, w.T = J->n_threads, w.part = J->gaf_part + (size_t)c * J->n_threads;
 			mga_parallel_for(J->n_threads, J->n_threads, gaf_worker, &w);
+			commit_chunks(J, c);
 			t->st.t_gaf += mga_wtime() - t0;
+			PIPE_LOG("gaf", c, t0);
 		}
 	}
 	return 0;
@@ -522,18 +571,19 @@ static void *pipe_worker(void *a)
 
 static int env_int(const char *name, int dflt) { const char *s = getenv(name); return s && *s ? atoi(s) : dflt; }
 
-typedef struct { kstring_t *part; int64_t *off; char *dst; } gcopy_t;
-static void gaf_copy_worker(void *data, int64_t i, int tid) { gcopy_t *g = (gcopy_t*)data; (void)tid; if (g->part[i].l) memcpy(g->dst + g->off[i], g->part[i].s, g->part[i].l); free(g->part[i].s); }
-
 static int map_all(const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs,
 				   const mg_mapopt_t *opt, int n_threads, const char *d_seq, const int64_t *q_off, char **gaf, int64_t *gaf_len)
 {
 	pipe_job_t J;
 	pipe_thr_t thr[MGA_MAX_PIPE];
 	pthread_t tid[MGA_MAX_PIPE];
-	int i, n_pipe = env_int("MGA_PIPE", 2), n_chunks;
+	int i, n_pipe = env_int("MGA_PIPE", 3), n_chunks;
 	if (n <= 0) return 0;
 	if (mga_dev_init() < 0) return -1;
+	if (g_dbg_pipe < 0) g_dbg_pipe = env_int("MGA_DEBUG_PIPE", 0);
+	g_cpu_on = g_dbg_pipe > 0;
+	if (g_cpu_on) memset((void*)g_cpu_ns, 0, sizeof g_cpu_ns);
+	g_job_t0 = mga_wtime();
 	for (i = 0; i < n; ++i) gcs[i] = 0;
 	memset(&J, 0, sizeof J);
 	J.gi = gi, J.opt = opt, J.n = n, J.qlens = qlens, J.seqs = seqs, J.qnames = qnames, J.gcs = gcs, J.d_seq = d_seq, J.q_off = q_off;
@@ -543,9 +593,10 @@ static int map_all(const mg_idx_t *gi, int n, const int *qlens, const char **seq
 	if (n_pipe > MGA_MAX_PIPE) n_pipe = MGA_MAX_PIPE;
 	if (n_pipe > n_chunks) n_pipe = n_chunks;
 	if (n_pipe < 1) n_pipe = 1;
-	J.n_threads = n_threads / n_pipe > 0 ? n_threads / n_pipe : 1;
-	if (gaf) J.gaf_part = MGA_CALLOC(kstring_t, (size_t)n_chunks * J.n_threads);
-	pthread_mutex_init(&J.mtx, 0);
+	J.n_threads = env_int("MGA_SPLIT_THREADS", 0) ? (n_threads / n_pipe > 0 ? n_threads / n_pipe : 1) : n_threads; /* host stages of different chunks rarely coincide */
+	J.n_chunks = n_chunks;
+	if (gaf) { J.gaf_part = MGA_CALLOC(kstring_t, (size_t)n_chunks * J.n_threads); J.done = MGA_CALLOC(char, n_chunks); }
+	pthread_mutex_init(&J.mtx, 0); pthread_mutex_init(&J.cmtx, 0);
 	for (i = 0; i < n_pipe; ++i) {
 		if (g_pipe[i].sc == 0 && (g_pipe[i].sc = mga_sctx_create()) == 0) return -1;
 		thr[i].job = &J, thr[i].P = &g_pipe[i];
@@ -556,7 +607,7 @@ static int map_all(const mg_idx_t *gi, int n, const int *qlens, const char **seq
 		for (i = 0; i < n_pipe; ++i) pthread_create(&tid[i], 0, pipe_worker, &thr[i]);
 		for (i = 0; i < n_pipe; ++i) pthread_join(tid[i], 0);
 	}
-	pthread_mutex_destroy(&J.mtx);
+	pthread_mutex_destroy(&J.mtx); pthread_mutex_destroy(&J.cmtx);
 	for (i = 0; i < n_pipe; ++i) { /* merge the per-thread counters */
 		mga_stats_t *d = &gi->B->st, *s = &thr[i].st;
 		d->n_reads += s->n_reads, d->n_bases += s->n_bases, d->n_mz += s->n_mz, d->n_probe += s->n_probe, d->n_hit += s->n_hit;
@@ -567,28 +618,30 @@ static int map_all(const mg_idx_t *gi, int n, const int *qlens, const char **seq
 	}
 	if (J.err) {
 		for (i = 0; i < n; ++i) { mg_gchain_free(gcs[i]); gcs[i] = 0; }
-		if (J.gaf_part) { for (i = 0; i < n_chunks * J.n_threads; ++i) free(J.gaf_part[i].s); free(J.gaf_part); }
+		if (J.gaf_part) { for (i = 0; i < n_chunks * J.n_threads; ++i) free(J.gaf_part[i].s); free(J.gaf_part); free(J.done); }
 		mga_set_error("%s", J.errmsg[0] ? J.errmsg : "mapping pipeline failed");
 		return -1;
 	}
-	if (gaf) { /* stitch the pieces (already in read order) into one buffer, copies in parallel */
-		const int64_t np = (int64_t)n_chunks * J.n_threads;
-		gcopy_t g;
-		int64_t tot = 0, k;
-		double t0 = mga_wtime();
-		g.part = J.gaf_part, g.off = MGA_MALLOC(int64_t, np + 1);
-		for (k = 0; k < np; ++k) g.off[k] = tot, tot += J.gaf_part[k].l;
-		g.dst = (char*)malloc((size_t)tot + 1);
-		mga_parallel_for(n_threads, np, gaf_copy_worker, &g);
-		g.dst[tot] = 0;
-		*gaf = g.dst, *gaf_len = tot;
-		gi->B->st.gaf_bytes += tot, gi->B->st.t_gaf += mga_wtime() - t0;
-		free(g.off); free(J.gaf_part);
+	if (g_cpu_on) {
+		struct timespec ts;
+		fprintf(stderr, "[pipe] host CPU seconds by stage (%d reads):", n);
+		for (i = 0; i < C_N; ++i) fprintf(stderr, " %s %.3f", g_cname[i], g_cpu_ns[i] * 1e-9);
+		clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts);
+		fprintf(stderr, "; process total so far %.3f\n", ts.tv_sec + ts.tv_nsec * 1e-9);
+	}
+	if (gaf) { /* every chunk was committed in read order while the pipeline ran */
+		struct mg_idx_bucket_s *B = gi->B;
+		if (B->gaf_out == 0) B->gaf_out = (char*)malloc(1), B->gaf_cap = 1;
+		B->gaf_out[J.out_len] = 0;
+		*gaf = B->gaf_out, *gaf_len = J.out_len;
+		B->st.gaf_bytes += J.out_len;
+		free(J.gaf_part); free(J.done);
 	}
 	return 0;
 }
 
-/* map + format: the GAF text (input order) of n reads in one malloc'ed buffer; chains are not returned */
+/* map + format: the GAF text (input order) of n reads; *gaf points into a grow-only buffer OWNED BY THE INDEX, valid until the
+ * next call on this index or mg_idx_destroy(); chains are not returned */
 int mga_map_gaf(const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, const mg_mapopt_t *opt, int n_threads,
 				const char *d_seq, const int64_t *q_off, char **gaf, int64_t *gaf_len)
 {

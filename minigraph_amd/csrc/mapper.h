@@ -18,6 +18,7 @@ int64_t mga_batch_wfa_target_bytes(const mga_batch_t *b);
 void mga_batch_wfa_export(const mga_batch_t *b, mga_wfa_prob_t *prob, char *tseq);
 /* host half 2: CIGAR stitching + ds from the WFA results */
 int mga_batch_finish(mga_batch_t *b, const mga_wfa_res_t *res, const uint32_t *pool);
+int mga_batch_finish_ordered(mga_batch_t *b, const int32_t *ncig, const int64_t *off, const uint32_t *ord);
 mg_gchains_t **mga_batch_take_results(mga_batch_t *b);
 void mga_batch_stats(const mga_batch_t *b, mga_stats_t *st);
 void mga_batch_destroy(mga_batch_t *b);

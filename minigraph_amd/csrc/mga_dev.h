@@ -37,8 +37,10 @@ typedef struct mga_sctx_s {
 	void *stream;              /* hipStream_t */
 	mga_dbuf_t wfa_ws[8];      /* per-tier WFA workspaces */
 	mga_dbuf_t wfa_cnt;        /* work-queue counters, one 64-byte line per tier */
+	mga_dbuf_t wfa_list[2], wfa_key, wfa_ctl; /* tier scheduler (k_wfa_sched.hip): double-buffered work lists, sort keys, counters */
 	void *tier_stream[8];      /* WFA tiers run concurrently on their own streams (long-tailed wide problems next to the small ones) */
 	void *ev_ready, *ev_done[8];
+	void *ev_sync;             /* blocking-sync event behind mga_ssync() */
 } mga_sctx_t;
 void *mga_wfa_stream(mga_sctx_t *sc, int slot);       /* stream of WFA tier `slot` */
 int mga_wfa_fork(mga_sctx_t *sc);                     /* tier streams wait for everything queued on sc->stream so far */
@@ -56,8 +58,8 @@ int  mga_hbuf_reserve(mga_hbuf_t *b, size_t bytes);
 void mga_hbuf_free(mga_hbuf_t *b);
 
 /* per-kernel HIP-event timing on the launch stream (bench.py reads it through mga_prof_get) */
-enum { MGA_K_SKETCH = 0, MGA_K_SEED_COUNT, MGA_K_SEED_FILL, MGA_K_LCHAIN, MGA_K_WFA0 /* +tier: 0-1 single-wave register tiers (band 64,128), 2-4 multi-wave register tiers (256,512,1024), 5-6 HBM tiers */, MGA_K_SCAN = MGA_K_WFA0 + 8, MGA_K_N };
-#define MGA_WFA_N_TIER 7
+enum { MGA_K_SKETCH = 0, MGA_K_SEED_COUNT, MGA_K_SEED_FILL, MGA_K_LCHAIN, MGA_K_WFA0 /* +tier: 0-1 single-wave register tiers (band 64,128), 2-5 multi-wave register tiers (256..2048), 6-7 HBM tiers */, MGA_K_SCAN = MGA_K_WFA0 + 8, MGA_K_N };
+#define MGA_WFA_N_TIER 8
 void mga_prof_enable(int on);
 void mga_prof_begin(void *stream, int kid);
 void mga_prof_end(void *stream, int kid);
@@ -108,20 +110,27 @@ size_t mga_dev_lchain_ws_bytes(int64_t total_anchors);
 typedef struct { int64_t t_off, q_off; int32_t tl, ql; } mga_wfa_prob_t;
 typedef struct { int32_t score, n_cigar; int64_t cig_off; int32_t status, pad; int64_t n_iter; } mga_wfa_res_t;
 enum { MGA_WFA_OK = 0, MGA_WFA_PENDING = 1, MGA_WFA_RETRY_TIER = 2, MGA_WFA_POOL_FULL = 3, MGA_WFA_MAX_ITER = 4 };
-/* solves problems d_list[0..n) (identity when d_list == NULL) in capacity tier 0..2; cigars are appended to d_pool
- * (capacity pool_cap ops, *d_pool_used bumped atomically); sequences must be padded by >= 8 readable bytes */
+/* where a WFA kernel appends the problems that outgrew its tier (device pointers); err counts the other failures */
+typedef struct { int32_t *list; int *cnt; int *err; } mga_wfa_retry_t;
+/* solves problems d_list[0..n) (identity when d_list == NULL) in HBM-resident capacity tier 0..1 (4096 / 32768 diagonals); cigars are
+ * appended to d_pool (capacity pool_cap ops, *d_pool_used bumped atomically); sequences must be padded by >= 8 readable bytes */
 int mga_dev_wfa(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
-				mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier);
-/* register-resident tiers (k_wfa_reg.hip): tier t covers a window of 64<<t diagonals */
+				mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier, mga_wfa_retry_t rt);
+/* register-resident tiers (k_wfa_r.hip): tier 0-1 one wave per problem (64, 128 diagonals), 2-5 four to sixteen waves (256, 512, 1024, 2048) */
 int mga_dev_wfa_reg(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
-					mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier);
-/* multi-wave register tiers (k_wfa_regw.hip): 0 = 4 waves x 64 (256 diagonals), 1 = 4 waves x 128 (512 diagonals) */
-int mga_dev_wfa_regw(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
-					 mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier, int ws_slot);
-/* tier 0..6: register tiers (one wave, then 4-8 waves per problem), then the HBM-resident tiers; a problem failing with MGA_WFA_RETRY_TIER moves up one */
+					mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier, mga_wfa_retry_t rt);
+/* tier 0..7: register tiers (one wave, then 4-16 waves per problem), then the HBM-resident tiers */
 int mga_wfa_first_tier(int32_t tl, int32_t ql); /* cheapest tier likely to fit, from the sequence lengths */
 int mga_dev_wfa_tier(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
-					 mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier);
+					 mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier, mga_wfa_retry_t rt);
+/* the whole ladder (k_wfa_sched.hip): every problem in its first tier, the ones that outgrow it one tier up, until none is left;
+ * d_res[i] / d_pool hold the results; *cells (optional) = total wavefront cells */
+int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+					  mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int64_t *cells);
+
+/* CIGARs of all problems copied into problem order: d_ncig[i] operators at d_ord + d_off[i] (d_off has n+1 entries); *h_total = d_off[n] */
+int mga_dev_wfa_gather(mga_sctx_t *sc, int n, const mga_wfa_res_t *d_res, const uint32_t *d_pool, int32_t *d_ncig, int64_t *d_off, uint32_t *d_ord,
+					   int64_t ord_cap, int64_t *h_total);
 
 #ifdef __cplusplus
 }

@@ -62,8 +62,11 @@ struct mg_idx_bucket_s {
 	int64_t *occ_hist;       /* occ_hist[c] = number of distinct minimizers occurring c times, c <= max_occ_seen */
 	int64_t max_occ_seen;
 	mga_stats_t st;
+	char *gaf_out;           /* GAF text of the last mga_map_reads() pass; grow-only, owned by the index */
+	int64_t gaf_cap;
 };
 
+void mga_write_gaf_append(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, int32_t n_seg, const int32_t *qlens, const char *qname, uint64_t flag);
 mg_idx_t *mga_idx_hostpart(gfa_t *g, const mg_idxopt_t *io);
 
 /* ---- simple parallel-for over [0,n) on n_threads pthreads, dynamic chunks (par.c) ---- */

@@ -61,7 +61,7 @@ extern "C" int mga_wfa_batch(int n, const char *tseq, const int64_t *t_off, cons
 		prob[i].tl = (int32_t)(t_off[i + 1] - t_off[i]), prob[i].ql = (int32_t)(q_off[i + 1] - q_off[i]);
 		if (prob[i].tl <= 0 || prob[i].ql <= 0) { mga_set_error("wfa: problem %d has an empty sequence (the caller handles those, galign.c:98-100)", i); return -1; }
 	}
-	dptr d_t, d_q, d_prob, d_res, d_pool, d_used, d_list;
+	dptr d_t, d_q, d_prob, d_res, d_pool, d_used;
 	int64_t pool_cap = (tt + tq) / 4 + n * 4 + 1024 + 40000LL * 512;
 	if (!d_t.alloc(tt + 64) || !d_q.alloc(tq + 64) || !d_prob.alloc((size_t)n * sizeof(mga_wfa_prob_t)) ||
 		!d_res.alloc((size_t)n * sizeof(mga_wfa_res_t)) || !d_used.alloc(8)) return -1;
@@ -69,35 +69,10 @@ extern "C" int mga_wfa_batch(int n, const char *tseq, const int64_t *t_off, cons
 	if (mga_dmemset_s(SC, (char*)d_t.p + tt, 0, 64) < 0 || mga_dmemset_s(SC, (char*)d_q.p + tq, 0, 64) < 0) return -1;
 
 	std::vector<mga_wfa_res_t> res(n);
-	std::vector<int8_t> tier_of(n);
-	std::vector<int32_t> todo;
-	for (int i = 0; i < n; ++i) tier_of[i] = (int8_t)mga_wfa_first_tier(prob[i].tl, prob[i].ql);
-	if (!d_pool.alloc((size_t)pool_cap * 4) || !d_list.alloc((size_t)n * 4) || mga_dmemset_s(SC, d_used.p, 0, 8) < 0) return -1;
-	for (int pass = 0;; ++pass) { // first pass: every problem in the tier its length suggests; then only the ones that outgrew it, one tier up
-		int64_t n_left = 0;
-		if (mga_wfa_fork(SC) < 0) return -1;
-		for (int t = 0; t < MGA_WFA_N_TIER; ++t) {
-			todo.clear();
-			for (int i = 0; i < n; ++i) if (tier_of[i] == t) todo.push_back(i);
-			if (todo.empty()) continue;
-			if (mga_h2d((int32_t*)d_list.p + n_left, todo.data(), todo.size() * 4) < 0) return -1;
-			if (mga_dev_wfa_tier(SC, (int)todo.size(), (const int32_t*)d_list.p + n_left, d_prob.as<mga_wfa_prob_t>(), d_t.as<char>(), d_q.as<char>(), d_res.as<mga_wfa_res_t>(),
-								 d_pool.as<uint32_t>(), pool_cap, (unsigned long long*)d_used.p, t) < 0) return -1;
-			n_left += (int64_t)todo.size();
-		}
-		if (n_left == 0) break;
-		if (mga_dsync() < 0 || mga_d2h(res.data(), d_res.p, (size_t)n * sizeof(mga_wfa_res_t)) < 0) return -1;
-		bool again = false;
-		for (int i = 0; i < n; ++i) {
-			if (tier_of[i] < 0) continue;
-			if (res[i].status == MGA_WFA_RETRY_TIER) {
-				if (++tier_of[i] >= MGA_WFA_N_TIER) { mga_set_error("wfa: problem exceeds the largest capacity tier"); return -1; }
-				again = true;
-			} else if (res[i].status == MGA_WFA_POOL_FULL) { mga_set_error("wfa: CIGAR pool exhausted"); return -1; }
-			else tier_of[i] = -1;
-		}
-		if (!again) break;
-	}
+	if (!d_pool.alloc((size_t)pool_cap * 4) || mga_dmemset_s(SC, d_used.p, 0, 8) < 0) return -1;
+	if (mga_dev_wfa_solve(SC, n, d_prob.as<mga_wfa_prob_t>(), d_t.as<char>(), d_q.as<char>(), d_res.as<mga_wfa_res_t>(),
+						  d_pool.as<uint32_t>(), pool_cap, (unsigned long long*)d_used.p, 0) < 0) return -1;
+	if (mga_dsync() < 0 || mga_d2h(res.data(), d_res.p, (size_t)n * sizeof(mga_wfa_res_t)) < 0) return -1;
 	unsigned long long used = 0;
 	if (mga_dsync() < 0 || mga_d2h(&used, d_used.p, 8) < 0) return -1;
 	std::vector<uint32_t> hpool((size_t)used + 1);
