@@ -182,8 +182,22 @@ def main():
             "k_lchain": 32 * st["n_hit"],
         }
         dom = max(fam, key=lambda k: fam[k])
+        # HBM traffic of the dominant family per launch, from the committed PMC passes of this same command (profiles/*_pmc.json;
+        # bench.py cannot run rocprofv3 around itself).  KB of FETCH_SIZE + WRITE_SIZE, uncorrected (see the file's "source").
+        traffic, traffic_src = None, None
+        try:
+            import glob
+            pf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))[-1]
+            pk = json.load(open(pf))["kernels"]
+            sel = [v for k, v in pk.items() if k.startswith(dom)]
+            nl = sum(v.get("launches_fetch", 0) for v in sel)
+            if nl:
+                traffic = sum(v.get("fetch_kb", 0) + v.get("write_kb", 0) for v in sel) * 1024.0 / nl
+                traffic_src = os.path.relpath(pf, ROOT)
+        except Exception:
+            pass
         ach = alg[dom] / (fam[dom] * 1e-3) / 1e9 if fam[dom] > 0 else 0.0
-        roof = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
+        roof = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
                     launches=launches[dom], avg_launch_ms=fam[dom] / max(1, launches[dom]),
                     alg_bytes_per_launch=alg[dom] / max(1, launches[dom]))
         res = dict(metric="mapped Gbp/sec (whole node), -cx lr 10kb reads, graph base alignment (-c)", value=value, unit="Gbp/s",

@@ -84,6 +84,7 @@ extern "C" void mga_sctx_destroy(mga_sctx_t *sc)
 	(void)hipStreamSynchronize((hipStream_t)sc->stream);
 	for (int i = 0; i < 8; ++i) mga_dbuf_free(&sc->wfa_ws[i]);
 	mga_dbuf_free(&sc->wfa_cnt);
+	mga_dbuf_free(&sc->scan_tmp);
 	mga_dbuf_free(&sc->wfa_list[0]); mga_dbuf_free(&sc->wfa_list[1]); mga_dbuf_free(&sc->wfa_key); mga_dbuf_free(&sc->wfa_ctl);
 	for (int i = 0; i < 8; ++i) { (void)hipStreamDestroy((hipStream_t)sc->tier_stream[i]); (void)hipEventDestroy((hipEvent_t)sc->ev_done[i]); }
 	(void)hipEventDestroy((hipEvent_t)sc->ev_ready); (void)hipEventDestroy((hipEvent_t)sc->ev_sync);
@@ -267,10 +268,83 @@ __global__ void __launch_bounds__(1024) k_scan_i32_i64(const int32_t *__restrict
 	if (threadIdx.x == 0) off[n] = carry;
 }
 
+// large inputs: tiles of 8192 counts per workgroup -- tile sums, scan of the tile sums (one small workgroup), tile-local
+// scans with the tile's base.  (The single-workgroup kernel above took 1.6 ms for the 5*10^5 gap-filling problems of a chunk.)
+#define SCAN_TILE 8192
+__global__ void __launch_bounds__(1024) k_scan_tile_sum(const int32_t *__restrict__ cnt, int64_t n, int64_t *__restrict__ bsum)
+{
+	__shared__ int64_t ws[16];
+	const int64_t t0 = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * 8;
+	int64_t s = 0;
+#pragma unroll
+	for (int r = 0; r < 8; ++r) if (t0 + r < n) s += cnt[t0 + r];
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
+	if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) { int64_t t = 0; for (int w = 0; w < 16; ++w) t += ws[w]; bsum[blockIdx.x] = t; }
+}
+
+__global__ void __launch_bounds__(1024) k_scan_bsum(int64_t *__restrict__ bsum, int nb) // in place, exclusive; total at bsum[nb]
+{
+	__shared__ int64_t wsum[16];
+	__shared__ int64_t carry;
+	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+	if (threadIdx.x == 0) carry = 0;
+	__syncthreads();
+	for (int base = 0; base < nb; base += 1024) {
+		const int i = base + threadIdx.x;
+		int64_t v = i < nb ? bsum[i] : 0, x = v;
+		for (int d = 1; d < 64; d <<= 1) { int64_t y = __shfl_up(x, d); if (lane >= d) x += y; }
+		if (lane == 63) wsum[wid] = x;
+		__syncthreads();
+		if (wid == 0) {
+			int64_t s = lane < 16 ? wsum[lane] : 0, t = s;
+			for (int d = 1; d < 16; d <<= 1) { int64_t y = __shfl_up(t, d); if (lane >= d) t += y; }
+			if (lane < 16) wsum[lane] = t - s;
+		}
+		__syncthreads();
+		const int64_t c = carry;
+		if (i < nb) bsum[i] = c + wsum[wid] + x - v;
+		__syncthreads();
+		if (threadIdx.x == 1023) carry = c + wsum[wid] + x;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) bsum[nb] = carry;
+}
+
+__global__ void __launch_bounds__(1024) k_scan_tile_write(const int32_t *__restrict__ cnt, int64_t n, const int64_t *__restrict__ bsum, int nb, int64_t *__restrict__ off)
+{
+	__shared__ int64_t wsum[16];
+	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+	const int64_t t0 = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * 8;
+	int32_t v[8];
+	int64_t s = 0;
+#pragma unroll
+	for (int r = 0; r < 8; ++r) { v[r] = t0 + r < n ? cnt[t0 + r] : 0; s += v[r]; }
+	int64_t x = s;
+	for (int d = 1; d < 64; d <<= 1) { int64_t y = __shfl_up(x, d); if (lane >= d) x += y; }
+	if (lane == 63) wsum[wid] = x;
+	__syncthreads();
+	int64_t run = bsum[blockIdx.x] + x - s;
+	for (int w = 0; w < wid; ++w) run += wsum[w];
+#pragma unroll
+	for (int r = 0; r < 8; ++r) { if (t0 + r < n) off[t0 + r] = run; run += v[r]; }
+	if (blockIdx.x == 0 && threadIdx.x == 0) off[n] = bsum[nb];
+}
+
 extern "C" int mga_dev_scan_i32_to_i64(mga_sctx_t *sc, const int32_t *d_cnt, int64_t n, int64_t *d_off)
 {
+	hipStream_t st = (hipStream_t)sc->stream;
 	mga_prof_begin(sc->stream, MGA_K_SCAN);
-	hipLaunchKernelGGL(k_scan_i32_i64, dim3(1), dim3(1024), 0, (hipStream_t)sc->stream, d_cnt, n, d_off);
+	if (n <= 4 * SCAN_TILE) hipLaunchKernelGGL(k_scan_i32_i64, dim3(1), dim3(1024), 0, st, d_cnt, n, d_off);
+	else {
+		const int nb = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
+		if (mga_dbuf_reserve(&sc->scan_tmp, (size_t)(nb + 1) * 8) < 0) return -1;
+		hipLaunchKernelGGL(k_scan_tile_sum, dim3(nb), dim3(1024), 0, st, d_cnt, n, (int64_t*)sc->scan_tmp.p);
+		hipLaunchKernelGGL(k_scan_bsum, dim3(1), dim3(1024), 0, st, (int64_t*)sc->scan_tmp.p, nb);
+		hipLaunchKernelGGL(k_scan_tile_write, dim3(nb), dim3(1024), 0, st, d_cnt, n, (const int64_t*)sc->scan_tmp.p, nb, d_off);
+	}
 	mga_prof_end(sc->stream, MGA_K_SCAN);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;

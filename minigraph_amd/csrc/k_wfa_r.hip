@@ -13,7 +13,7 @@
 // The periodic trimming (every 256 scores the reference looks back over its 17-slice ring) uses one more
 // register per diagonal: the last score at which the diagonal received an in-matrix value, maintained only
 // during the 17 scores before a trimming point.
-// Sequences sit in LDS and are compared 8 bytes at a time (unaligned ds_read_b64).  Traceback bytes (1 per
+// Sequences sit in LDS (four byte-shifted copies, so that 8 bases at any offset are one aligned ds_read2_b32).  Traceback bytes (1 per
 // cell) go to LDS for the first TBLDS cells of a problem and to an HBM scratch beyond that.
 // A problem whose band leaves the 64*J*NW window, or outgrows the score / traceback tables, returns
 // MGA_WFA_RETRY_TIER and is re-run by the next tier.
@@ -29,12 +29,12 @@ struct wfr_cfg_t {
 	int64_t ws_stride;
 };
 
-struct __attribute__((packed)) wfr_u64p { uint64_t v; };
-
 // lane l <- src[l-1]; lane 0 keeps edge        (DPP wave_shr:1, bound_ctrl off)
 __device__ __forceinline__ int32_t wfr_from_left(int32_t edge, int32_t src) { return __builtin_amdgcn_update_dpp(edge, src, 0x138, 0xf, 0xf, false); }
 // lane l <- src[l+1]; lane 63 keeps edge       (DPP wave_shl:1)
 __device__ __forceinline__ int32_t wfr_from_right(int32_t edge, int32_t src) { return __builtin_amdgcn_update_dpp(edge, src, 0x130, 0xf, 0xf, false); }
+
+struct wfr_u2 { uint32_t x, y; }; // 8 bytes with 4-byte alignment: loads become ds_read2_b32
 
 __device__ __forceinline__ int32_t wfr_max(int32_t a, int32_t b) { return a > b ? a : b; }
 
@@ -46,7 +46,10 @@ __global__ void __launch_bounds__(64 * NW) k_wfa_r(int n_items, const int32_t *_
 {
 	constexpr int NV = 64 * J * NW; // diagonals covered by the workgroup
 	constexpr int NT = 64 * NW;
-	__shared__ __attribute__((aligned(16))) uint8_t Tb[SEQCAP + 16], Qb[SEQCAP + 16];
+	// each sequence is staged four times, copy k shifted left by k bytes: any byte position is then dword-aligned in copy
+	// (pos & 3), and 8 bytes come from one ds_read2_b32 (an off-alignment ds_read_b64 is replayed at ~64 cycles)
+	constexpr int SEQS = SEQCAP + 16; // bytes per copy (multiple of 16)
+	__shared__ __attribute__((aligned(16))) uint8_t Tb[4 * SEQS], Qb[4 * SEQS];
 	__shared__ int32_t row[SMAX + 1];   // first traceback cell of score s
 	__shared__ int16_t rlo[SMAX + 1];   // lowest diagonal of score s
 	__shared__ uint8_t tb_lds[TBLDS];
@@ -101,8 +104,20 @@ __global__ void __launch_bounds__(64 * NW) k_wfa_r(int n_items, const int32_t *_
 			{ // stage the sequences; 16 bytes of padding so that the 8-byte compares may overrun
 				const char *ts = tseq + pb.t_off, *qs = qseq + pb.q_off;
 				if (NW == 1) WFR_LDS_FENCE(); // the previous problem's traceback has finished reading LDS (same wave, in order)
-				for (int32_t i = tid; i < tl + 16; i += NT) Tb[i] = i < tl ? (uint8_t)ts[i] : (uint8_t)0;
-				for (int32_t i = tid; i < ql + 16; i += NT) Qb[i] = i < ql ? (uint8_t)qs[i] : (uint8_t)1;
+				for (int32_t i = tid; i < tl + 16; i += NT) {
+					const uint8_t c = i < tl ? (uint8_t)ts[i] : (uint8_t)0;
+					Tb[i] = c;
+					if (i >= 1) Tb[SEQS + i - 1] = c;
+					if (i >= 2) Tb[2 * SEQS + i - 2] = c;
+					if (i >= 3) Tb[3 * SEQS + i - 3] = c;
+				}
+				for (int32_t i = tid; i < ql + 16; i += NT) {
+					const uint8_t c = i < ql ? (uint8_t)qs[i] : (uint8_t)1;
+					Qb[i] = c;
+					if (i >= 1) Qb[SEQS + i - 1] = c;
+					if (i >= 2) Qb[2 * SEQS + i - 2] = c;
+					if (i >= 3) Qb[3 * SEQS + i - 3] = c;
+				}
 				if (tid == 0) { row[0] = 0; rlo[0] = 0; tb_lds[0] = 0; flags[0] = 0; flags[2] = flags[3] = flags[4] = flags[5] = -1; }
 				if (NW > 1) {
 					if (tid < 2 * (NW + 2) * 8) ((int32_t*)xch)[tid] = WF_NEG_INF;
@@ -134,13 +149,16 @@ __global__ void __launch_bounds__(64 * NW) k_wfa_r(int n_items, const int32_t *_
 					const bool val = (uint32_t)(k0 + 1) <= (uint32_t)tl && (uint32_t)(i0 + 1) <= (uint32_t)ql; // -1 <= k0 < tl, -1 <= i0 < ql
 					const int32_t tp = val ? k0 + 1 : 0, qp = val ? i0 + 1 : 0;
 					const int32_t room = min(tl - tp, ql - qp);
-					int32_t n = 0;
+					const wfr_u2 *tw = (const wfr_u2*)(Tb + (tp & 3) * SEQS + (tp & ~3)), *qw = (const wfr_u2*)(Qb + (qp & 3) * SEQS + (qp & ~3)); // 4-byte aligned
+					int32_t n = 0, m8 = 0; // m8: matched blocks of 8 bases
 					bool act = val && room > 0;
-					while (__ballot(act)) { // uniform loop; finished lanes reload their last words
-						const uint64_t c = ((const wfr_u64p*)(Tb + tp + n))->v ^ ((const wfr_u64p*)(Qb + qp + n))->v;
-						const int32_t adv = c ? (int32_t)(__builtin_ctzll(c) >> 3) : 8;
-						n = act ? n + adv : n;
-						act = act && c == 0 && n < room;
+					while (__ballot(act)) { // uniform loop; finished lanes reload their last block
+						const wfr_u2 a = tw[m8], b = qw[m8];
+						const uint32_t c0 = a.x ^ b.x, c1 = a.y ^ b.y;
+						if (act) {
+							if ((c0 | c1) == 0) { ++m8; n += 8; act = n < room; }
+							else { n += c0 ? (int32_t)(__builtin_ctz(c0) >> 3) : 4 + (int32_t)(__builtin_ctz(c1) >> 3); act = false; }
+						}
 					}
 					n = min(n, room);
 					const int32_t k = k0 + n;
@@ -358,8 +376,8 @@ struct wfr_tier_t { int n_wg; int32_t cigcap, tbcap; };
 static const wfr_tier_t g_rtier[6] = {
 	//  workgroups  cigcap  HBM traceback scratch per workgroup
 	{ 8192,    512,        0 },   // 1 wave  x 1 slot :   64 diagonals, traceback in LDS only
-	{ 6144,   1024,        0 },   // 1 wave  x 2 slots:  128
-	{ 2048,   2048, 192 << 10 },  // 4 waves x 1 slot :  256
+	{ 6144,   1024,     8192 },   // 1 wave  x 2 slots:  128
+	{ 4096,   2048, 192 << 10 },  // 2 waves x 2 slots:  256
 	{ 1280,   4096, 768 << 10 },  // 4 waves x 2 slots:  512
 	{  512,   8192,   3 << 20 },  // 8 waves x 2 slots: 1024
 	{   64,  16384,  12 << 20 },  // 16 waves x 2 slots: 2048 (a handful of problems per 10^5 reads; keeps them off the slow HBM kernel)
@@ -376,15 +394,13 @@ extern "C" int mga_dev_wfa_reg(mga_sctx_t *sc, int n, const int32_t *d_list, con
 	int wgs = T.n_wg < (n + 3) / 4 ? T.n_wg : (n + 3) / 4;
 	if (wgs < 1) wgs = 1;
 	if (mga_dbuf_reserve(&sc->wfa_ws[tier], (size_t)cfg.ws_stride * T.n_wg) < 0) return -1;
-	if (mga_dbuf_reserve(&sc->wfa_cnt, 1024) < 0) return -1;
 	hipStream_t st = (hipStream_t)mga_wfa_stream(sc, tier);
 	int *d_counter = (int*)((char*)sc->wfa_cnt.p + 64 * tier);
-	MGA_HIP_CHECK(hipMemsetAsync(d_counter, 0, 4, st));
 	mga_prof_begin(st, MGA_K_WFA0 + tier);
 #define LAUNCH(NW, JJ, SEQ, SM, TBL) hipLaunchKernelGGL((k_wfa_r<NW, JJ, SEQ, SM, TBL>), dim3(wgs), dim3(64 * NW), 0, st, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap, d_pool_used, (char*)sc->wfa_ws[tier].p, d_counter, rt, cfg)
 	if (tier == 0) LAUNCH(1, 1, 128, 64, 2048);
-	else if (tier == 1) LAUNCH(1, 2, 256, 128, 6144);
-	else if (tier == 2) LAUNCH(4, 1, 512, 512, 8192);
+	else if (tier == 1) LAUNCH(1, 2, 256, 128, 4096);
+	else if (tier == 2) LAUNCH(2, 2, 512, 512, 8192);  // [measured] 2x2 beats 4x1 (fewer waves to synchronise) and 1x4 (register pressure)
 	else if (tier == 3) LAUNCH(4, 2, 1024, 1024, 8192);
 	else if (tier == 4) LAUNCH(8, 2, 2048, 2048, 8192);
 	else LAUNCH(16, 2, 4096, 4096, 8192);

@@ -76,10 +76,27 @@ __global__ void __launch_bounds__(1024) k_wfa_bin_scan(int *__restrict__ hist, i
 	if (tid == 1023) tier_off[MGA_WFA_N_TIER] = run;
 }
 
-__global__ void __launch_bounds__(256) k_wfa_bin_scatter(int n, const int32_t *__restrict__ key, int *__restrict__ cursor, int32_t *__restrict__ list)
+// tile of 8192 ids per workgroup: LDS histogram of the tile, ONE global atomic per non-empty bin to reserve its slots,
+// then LDS atomics hand out the slots (4.8 M global atomics on ~20 hot bins took 14 ms; this takes <1 ms)
+__global__ void __launch_bounds__(1024) k_wfa_bin_scatter(int n, const int32_t *__restrict__ key, int *__restrict__ cursor, int32_t *__restrict__ list)
 {
-	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) list[atomicAdd(&cursor[key[i]], 1)] = i;
+	__shared__ int cnt[WFS_NBIN], base[WFS_NBIN];
+	const int t0 = blockIdx.x * 8192;
+	for (int i = threadIdx.x; i < WFS_NBIN; i += 1024) cnt[i] = 0;
+	__syncthreads();
+	int k[8];
+#pragma unroll
+	for (int r = 0; r < 8; ++r) {
+		const int i = t0 + r * 1024 + threadIdx.x;
+		k[r] = i < n ? key[i] : -1;
+		if (k[r] >= 0) atomicAdd(&cnt[k[r]], 1);
+	}
+	__syncthreads();
+	for (int i = threadIdx.x; i < WFS_NBIN; i += 1024) if (cnt[i]) base[i] = atomicAdd(&cursor[i], cnt[i]);
+	__syncthreads();
+#pragma unroll
+	for (int r = 0; r < 8; ++r)
+		if (k[r] >= 0) list[base[k[r]] + atomicSub(&cnt[k[r]], 1) - 1] = t0 + r * 1024 + threadIdx.x;
 }
 
 __global__ void __launch_bounds__(256) k_wfa_sum_cells(int n, const mga_wfa_res_t *__restrict__ res, unsigned long long *__restrict__ out)
@@ -164,7 +181,8 @@ extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_
 	// ctl: hist[NBIN] | tier_off[16] | rc[2][16] | err[2] | cells (8 bytes)
 	constexpr int O_TOFF = WFS_NBIN, O_RC = O_TOFF + 16, O_ERR = O_RC + 32, O_CELLS = O_ERR + 2, N_CTL = O_CELLS + 2;
 	if (mga_dbuf_reserve(&sc->wfa_list[0], (size_t)n * 4 + 64) < 0 || mga_dbuf_reserve(&sc->wfa_list[1], (size_t)n * 4 + 64) < 0 ||
-		mga_dbuf_reserve(&sc->wfa_key, (size_t)n * 4 + 64) < 0 || mga_dbuf_reserve(&sc->wfa_ctl, (size_t)N_CTL * 4) < 0) return -1;
+		mga_dbuf_reserve(&sc->wfa_key, (size_t)n * 4 + 64) < 0 || mga_dbuf_reserve(&sc->wfa_ctl, (size_t)N_CTL * 4) < 0 ||
+		mga_dbuf_reserve(&sc->wfa_cnt, 1024) < 0) return -1;
 	int *ctl = (int*)sc->wfa_ctl.p;
 	int32_t *L[2] = { (int32_t*)sc->wfa_list[0].p, (int32_t*)sc->wfa_list[1].p };
 	MGA_HIP_CHECK(hipMemsetAsync(ctl, 0, (size_t)N_CTL * 4, st));
@@ -174,7 +192,7 @@ extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_
 		mga_prof_begin(st, MGA_K_SCAN);
 		hipLaunchKernelGGL(k_wfa_bin_count, dim3(nb), dim3(1024), 0, st, n, d_prob, (int32_t*)sc->wfa_key.p, ctl);
 		hipLaunchKernelGGL(k_wfa_bin_scan, dim3(1), dim3(1024), 0, st, ctl, ctl + O_TOFF);
-		hipLaunchKernelGGL(k_wfa_bin_scatter, dim3((n + 255) / 256), dim3(256), 0, st, n, (const int32_t*)sc->wfa_key.p, ctl, L[0]);
+		hipLaunchKernelGGL(k_wfa_bin_scatter, dim3((n + 8191) / 8192), dim3(1024), 0, st, n, (const int32_t*)sc->wfa_key.p, ctl, L[0]);
 		mga_prof_end(st, MGA_K_SCAN);
 		MGA_HIP_CHECK(hipGetLastError());
 	}
@@ -184,6 +202,7 @@ extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_
 	for (int pass = 0, cur = 0;; ++pass, cur ^= 1) {
 		int *rc = ctl + O_RC + 16 * (pass & 1), nstart[MGA_WFA_N_TIER + 2];
 		MGA_HIP_CHECK(hipMemsetAsync(rc, 0, 16 * 4, st));
+		MGA_HIP_CHECK(hipMemsetAsync(sc->wfa_cnt.p, 0, 1024, st)); // the tiers' work-queue counters (one 64-byte line each)
 		nstart[0] = nstart[1] = 0; // region of tier u in the next pass's list: as many slots as tier u-1 runs problems now
 		for (int u = 1; u <= MGA_WFA_N_TIER; ++u) nstart[u + 1] = nstart[u] + cnt[u - 1];
 		if (mga_wfa_fork(sc) < 0) return -1;

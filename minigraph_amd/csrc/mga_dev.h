@@ -37,6 +37,7 @@ typedef struct mga_sctx_s {
 	void *stream;              /* hipStream_t */
 	mga_dbuf_t wfa_ws[8];      /* per-tier WFA workspaces */
 	mga_dbuf_t wfa_cnt;        /* work-queue counters, one 64-byte line per tier */
+	mga_dbuf_t scan_tmp;       /* tile sums of mga_dev_scan_i32_to_i64 */
 	mga_dbuf_t wfa_list[2], wfa_key, wfa_ctl; /* tier scheduler (k_wfa_sched.hip): double-buffered work lists, sort keys, counters */
 	void *tier_stream[8];      /* WFA tiers run concurrently on their own streams (long-tailed wide problems next to the small ones) */
 	void *ev_ready, *ev_done[8];

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Turn a rocprofv3 `--kernel-trace --stats` result (sqlite .db or *_kernel_stats.csv) into the short
-text summary committed under profiles/.  usage: prof_summary.py <results.db|kernel_stats.csv> [title]"""
+text summary committed under profiles/.\nusage: prof_summary.py <results.db|kernel_stats.csv> [title]   |   prof_summary.py --pmc <results.db> [title]"""
 import csv
 import sqlite3
 import sys
@@ -16,7 +16,24 @@ def rows(path):
             yield r["Name"], int(r["Calls"]), float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3, float(r["Percentage"])
 
 
+def pmc_rows(path):
+    """per kernel: launches, total and per-launch KB of one --pmc pass (FETCH_SIZE / WRITE_SIZE are reported in KB)"""
+    cur = sqlite3.connect(path).cursor()
+    q = "select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name order by sum(value) desc"
+    for name, counter, calls, tot in cur.execute(q):
+        yield name, counter, int(calls), float(tot)
+
+
+def main_pmc(path, title):
+    print("# rocprofv3 --pmc (separate pass, no tracing)  %s" % title)
+    print("# %-40s %-12s %8s %14s %14s" % ("kernel", "counter", "launches", "total_KB", "KB_per_launch"))
+    for name, counter, calls, tot in pmc_rows(path):
+        print("%-42s %-12s %8d %14.1f %14.1f" % (name.split("(")[0][:42], counter, calls, tot, tot / max(1, calls)))
+
+
 def main():
+    if sys.argv[1] == "--pmc":
+        return main_pmc(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "")
     path, title = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "")
     print("# rocprofv3 --kernel-trace --stats  %s" % title)
     print("# %-40s %8s %14s %14s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
