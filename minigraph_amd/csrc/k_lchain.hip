@@ -19,8 +19,29 @@
 #include "mga_dev.h"
 #include "dev_common.h"
 #include "dev_klibsort.h"
+#include <string.h>
 
 #define LC_NONE INT32_MIN
+
+// ---- long-join rescue (map-algo.c:407-417 -> mg_lchain_rmq, lchain.c:252-372) -------------------------------
+// When the first pass leaves a read in several chains that cover too little of it, the reference re-chains ALL
+// chained anchors (x-sorted) with the RMQ chainer and a wide band.  Per anchor i that chainer takes (1) the
+// minimum-priority node of an AVL tree over the active anchors with y in (y_i - max_dist, y_i - 1), then (2)
+// walks a second tree in DESCENDING (y, index) order over the anchors within max_dist_inner, with the same
+// order-dependent skip heuristic as the first pass.  Here:
+//   (1) is a wave-wide arg-min over the active window.  The tree's answer equals the arg-min whenever the minimum
+//       is unique; when two candidates tie on the (double) priority the result would depend on the AVL shape, so
+//       the kernel gives up on that read (flag 2) and the host runs the sequential tree (rmq.c) for it;
+//   (2) gathers the <= 64 candidates, rank-sorts them by (y, index) and replays the heuristic from ballot masks
+//       exactly like the first pass; more than 64 candidates also defers the read to the host.
+// [measured] the rescue fires on ~48 % of 10 kb reads and cost 46 us/read of host CPU, a third of the host budget.
+struct lc_rescue_t {
+	int32_t enabled;          // bw_long > bw, long-read mode
+	int32_t max_dist, max_dist_inner, bw, max_skip, cap, min_cnt, min_sc;
+	float pen_gap, pen_skip;
+	int32_t rescue_size;
+	float rescue_ratio;
+};
 
 __device__ __forceinline__ float lc_log2(float x) // mgpriv.h:63-71
 {
@@ -52,29 +73,14 @@ __device__ __forceinline__ int32_t lc_score(uint64_t xi, uint64_t yi, uint64_t x
 	return sc;
 }
 
-__global__ void __launch_bounds__(64) k_lchain(int n_reads, const mg128_t *__restrict__ a_all, const int64_t *__restrict__ a_off, mga_lchain_par_t P,
-											   uint64_t *__restrict__ u_all, mg128_t *__restrict__ b_all, int32_t *__restrict__ d_nu, int32_t *__restrict__ d_nb,
-											   int32_t *__restrict__ ws_i32, mg128_t *__restrict__ ws_z)
-{
-	__shared__ klib_lds_t L;
-	const int r = blockIdx.x, lane = threadIdx.x;
-	if (r >= n_reads) return;
-	const int64_t off = a_off[r];
-	const int32_t n = (int32_t)(a_off[r + 1] - off);
-	if (n == 0) { if (lane == 0) d_nu[r] = 0, d_nb[r] = 0; return; }
-	const mg128_t *a = a_all + off;
-	int32_t *f = ws_i32 + off * 4, *p = f + n, *v = p + n, *t = v + n; // 4 int32 per anchor
-	mg128_t *z = ws_z + off;                                             // 1 mg128 per anchor
-	uint64_t *u = u_all + off;
-	mg128_t *b = b_all + off;
-	if (P.max_dist_x < P.bw) P.max_dist_x = P.bw;
-	if (P.max_dist_y < P.bw) P.max_dist_y = P.bw;
-	const int32_t max_drop = P.bw;
+struct lc_ws_t { int32_t *f, *p, *v, *t; mg128_t *z; };
 
+// ---------------- first-pass DP (lchain.c:168-207) ----------------
+__device__ void lc_dp(const mg128_t *__restrict__ a, int32_t n, mga_lchain_par_t P, lc_ws_t W, int lane)
+{
+	int32_t *f = W.f, *p = W.p, *v = W.v, *t = W.t;
 	for (int32_t i = lane; i < n; i += 64) t[i] = 0;
 	__syncthreads();
-
-	// ---------------- DP ----------------
 	int32_t st = 0, max_ii = -1;
 	for (int32_t i = 0; i < n; ++i) {
 		const uint64_t xi = a[i].x, yi = a[i].y;
@@ -145,20 +151,174 @@ __global__ void __launch_bounds__(64) k_lchain(int n_reads, const mg128_t *__res
 		if (max_ii < 0 || (xi - a[max_ii].x <= (uint64_t)(int64_t)P.max_dist_x && f[max_ii] < max_f)) max_ii = i;
 		__syncthreads();
 	}
+}
 
-	// ---------------- backtrack (lchain.c:27-77) ----------------
+// comput_sc_simple (lchain.c:234-250)
+__device__ __forceinline__ int32_t lc_score_simple(uint64_t xi, uint64_t yi, uint64_t xj, uint64_t yj, float pen_gap, float pen_skip, bool *exact, int32_t *width)
+{
+	const int32_t dq = (int32_t)yi - (int32_t)yj, dr = (int32_t)(xi - xj);
+	const int32_t dd = dr > dq ? dr - dq : dq - dr, dg = dr < dq ? dr : dq;
+	const int32_t q_span = (int32_t)(yj >> 32 & 0xff);
+	int32_t sc = q_span < dg ? q_span : dg;
+	*width = dd, *exact = (dd == 0 && dg <= q_span);
+	if (dd || dq > q_span) {
+		const float lin = pen_gap * (float)dd + pen_skip * (float)dg;
+		const float lg = dd >= 1 ? lc_log2((float)(dd + 1)) : 0.0f;
+		sc -= (int32_t)(lin + .5f * lg);
+	}
+	return sc;
+}
+
+// ---------------- RMQ DP of the rescue (lchain.c:275-357); false = this read must be re-chained by the host ----------------
+__device__ bool lc_dp_rmq(const mg128_t *__restrict__ a, int32_t n, const lc_rescue_t &R, lc_ws_t W, int lane)
+{
+	__shared__ int32_t cand_j[64], cand_y[64], sorted_j[64];
+	int32_t *f = W.f, *p = W.p, *v = W.v, *t = W.t;
+	double *pri = (double*)W.z; // z is free until the backtrack
+	int32_t max_dist = R.max_dist, max_dist_inner = R.max_dist_inner;
+	if (max_dist < R.bw) max_dist = R.bw;
+	if (max_dist_inner <= 0 || max_dist_inner >= max_dist) max_dist_inner = 0;
+	if (n > R.cap) return false; // the reference then evicts by tree size
+	for (int32_t i = lane; i < n; i += 64) t[i] = 0;
+	__syncthreads();
+	int32_t i0 = 0, st = 0, st_in = 0;
+	for (int32_t i = 0; i < n; ++i) {
+		const uint64_t xi = a[i].x, yi = a[i].y;
+		const int32_t yi32 = (int32_t)yi;
+		// anchors with a smaller x become available (lchain.c:279-293): their priorities are final now
+		if (i0 < i && a[i0].x != xi) {
+			for (int32_t j = i0 + lane; j < i; j += 64)
+				pri[j] = -((double)f[j] + 0.5 * (double)R.pen_gap * (double)((int32_t)a[j].x + (int32_t)a[j].y));
+			i0 = i;
+			__syncthreads();
+		}
+		// windows (lchain.c:294-312); the trees hold [st, i0) and [st_in, i0)
+		while (st < i) { const uint64_t xs = a[st].x; if (xi >> 32 != xs >> 32 || xi > xs + (uint64_t)(int64_t)max_dist) ++st; else break; }
+		if (max_dist_inner > 0)
+			while (st_in < i) { const uint64_t xs = a[st_in].x; if (xi >> 32 != xs >> 32 || xi > xs + (uint64_t)(int64_t)max_dist_inner) ++st_in; else break; }
+		int32_t max_f = (int32_t)(yi >> 32 & 0xff), max_j = -1;
+		// (1) range-minimum query: keys in [(y_i - max_dist, INT32_MAX), (y_i - 1, 0)] (lchain.c:313-316)
+		const int32_t ylo = yi32 - max_dist, yhi = yi32 - 1;
+		double bp = 0.0;
+		int32_t bj = -1;
+		bool tie = false;
+		for (int32_t j = st + lane; j < i0; j += 64) {
+			const int32_t yj = (int32_t)a[j].y;
+			if ((yj > ylo && yj < yhi) || (j == 0 && yj == yhi)) {
+				const double pj = pri[j];
+				if (bj < 0 || pj < bp) bp = pj, bj = j, tie = false;
+				else if (pj == bp) tie = true;
+			}
+		}
+		const uint64_t has = __ballot(bj >= 0);
+		if (has) {
+			double m = bp;
+			bool hm = bj >= 0;
+			for (int d = 32; d > 0; d >>= 1) {
+				const double om = __shfl_xor(m, d);
+				const bool oh = __shfl_xor((int)hm, d) != 0;
+				if (oh && (!hm || om < m)) m = om, hm = true;
+			}
+			const uint64_t at_min = __ballot(bj >= 0 && bp == m);
+			if (__popcll(at_min) > 1 || __ballot(bj >= 0 && bp == m && tie)) return false; // equal priorities: the AVL shape would decide
+			const int32_t jq = __shfl(bj, (int)__builtin_ctzll(at_min));
+			bool exact;
+			int32_t width;
+			const mg128_t aq = a[jq];
+			const int32_t sc = f[jq] + lc_score_simple(xi, yi, aq.x, aq.y, R.pen_gap, R.pen_skip, &exact, &width);
+			if (width <= R.bw && sc > max_f) max_f = sc, max_j = jq;
+			// (2) inner window in descending (y, index) order (lchain.c:321-350)
+			if (!exact && max_dist_inner > 0 && st_in < i0 && yi32 > 0) {
+				const int32_t ymin = yi32 - max_dist_inner;
+				int32_t m_c = 0;
+				for (int32_t j0 = st_in; j0 < i0; j0 += 64) {
+					const int32_t j = j0 + lane;
+					int32_t yj = 0;
+					bool c = false;
+					if (j < i0) { yj = (int32_t)a[j].y; c = yj <= yhi && yj >= ymin; }
+					const uint64_t mc = __ballot(c);
+					const int32_t pos = m_c + __popcll(mc & mga_lanemask_lt());
+					if (c && pos < 64) cand_j[pos] = j, cand_y[pos] = yj;
+					m_c += __popcll(mc);
+				}
+				if (m_c > 64) return false; // rank sort below handles one wave of candidates
+				__syncthreads();
+				if (m_c > 0) {
+					// rank by descending (y, j): keys are unique
+					const int32_t myj = lane < m_c ? cand_j[lane] : -1, myy = lane < m_c ? cand_y[lane] : 0;
+					int32_t rank = 0;
+					for (int32_t k = 0; k < m_c; ++k) {
+						const int32_t ky = cand_y[k], kj = cand_j[k];
+						rank += (ky > myy || (ky == myy && kj > myj)) ? 1 : 0;
+					}
+					if (lane < m_c) sorted_j[rank] = myj;
+					__syncthreads();
+					const int32_t j = lane < m_c ? sorted_j[lane] : -1;
+					int32_t sc2 = LC_NONE, pj = -1;
+					bool valid = false;
+					if (j >= 0) {
+						bool ex2;
+						int32_t w2;
+						const mg128_t aj = a[j];
+						sc2 = f[j] + lc_score_simple(xi, yi, aj.x, aj.y, R.pen_gap, R.pen_skip, &ex2, &w2);
+						valid = w2 <= R.bw;
+						pj = p[j];
+					}
+					if (valid && pj >= 0) t[pj] = i; // marks only reach candidates with a smaller y, i.e. visited later
+					__syncthreads();
+					const bool hit_t = valid && t[j] == i;
+					int32_t pm = valid ? sc2 : INT32_MIN;
+					for (int d = 1; d < 64; d <<= 1) { const int32_t y = __shfl_up(pm, d); if (lane >= d && y > pm) pm = y; }
+					int32_t exm = __shfl_up(pm, 1);
+					if (lane == 0) exm = INT32_MIN;
+					if (exm < max_f) exm = max_f;
+					const bool improve = valid && sc2 > exm;
+					const uint64_t m_imp = __ballot(improve), m_hit = __ballot(hit_t && !improve);
+					uint64_t ev = m_imp | m_hit;
+					int cut_lane = 64, n_skip = 0;
+					while (ev) {
+						const int l = __builtin_ctzll(ev);
+						ev &= ev - 1;
+						if (m_imp >> l & 1) { if (n_skip > 0) --n_skip; }
+						else if (++n_skip > R.max_skip) { cut_lane = l; break; }
+					}
+					const uint64_t before = cut_lane == 64 ? ~0ULL : (1ULL << cut_lane) - 1ULL;
+					const uint64_t imp_b = m_imp & before;
+					if (imp_b) {
+						const int bl = 63 - __clzll(imp_b);
+						max_f = __shfl(sc2, bl), max_j = __shfl(j, bl);
+					}
+				}
+				__syncthreads();
+			}
+		}
+		int32_t vi = max_f;
+		if (max_j >= 0) { const int32_t vj = v[max_j]; if (vj > max_f) vi = vj; }
+		if (lane == 0) { f[i] = max_f; p[i] = max_j; v[i] = vi; }
+		__syncthreads();
+	}
+	return true;
+}
+
+// ---------------- backtrack (lchain.c:27-77) + compact_a (lchain.c:79-112): chains of a[] -> (u, b) ----------------
+__device__ void lc_backtrack_compact(const mg128_t *a, int32_t n, int32_t min_sc, int32_t min_cnt, int32_t max_drop, lc_ws_t W,
+									 uint64_t *u, mg128_t *b, /* a may alias b: a is fully read into z before b is written */ int32_t *n_u_, int32_t *n_v_, klib_lds_t *L, int lane)
+{
+	int32_t *f = W.f, *p = W.p, *v = W.v, *t = W.t;
+	mg128_t *z = W.z;
+	*n_u_ = 0, *n_v_ = 0;
 	// z = chain ends with f >= min_sc, in index order, then the klib sort by score
 	int32_t n_z = 0;
 	for (int32_t c0 = 0; c0 < n; c0 += 64) {
 		const int32_t i = c0 + lane;
-		const bool ok = i < n && f[i] >= P.min_sc;
+		const bool ok = i < n && f[i] >= min_sc;
 		const uint64_t m = __ballot(ok);
 		if (ok) { mg128_t e; e.x = (uint64_t)(int64_t)f[i]; e.y = (uint64_t)i; z[n_z + __popcll(m & mga_lanemask_lt())] = e; }
 		n_z += __popcll(m);
 	}
 	__syncthreads();
-	if (n_z == 0) { if (lane == 0) d_nu[r] = 0, d_nb[r] = 0; return; }
-	klib_sort128x(z, n_z, t, &L); // t[] is free here (re-zeroed below) and large enough for the range stack
+	if (n_z == 0) return;
+	klib_sort128x(z, n_z, t, L); // t[] is free here (re-zeroed below) and large enough for the range stack
 	for (int32_t i = lane; i < n; i += 64) t[i] = 0;
 	__syncthreads();
 	int32_t n_u = 0, n_v = 0;
@@ -179,17 +339,14 @@ __global__ void __launch_bounds__(64) k_lchain(int n_reads, const mg128_t *__res
 			const int32_t cutp = best_i, n_v0 = n_v;
 			for (i = e; i != cutp; i = p[i]) v[n_v++] = i, t[i] = 1;
 			const int32_t sc = i < 0 ? zs : zs - f[i];
-			if (sc >= P.min_sc && n_v > n_v0 && n_v - n_v0 >= P.min_cnt) u[n_u++] = (uint64_t)sc << 32 | (uint64_t)(n_v - n_v0);
+			if (sc >= min_sc && n_v > n_v0 && n_v - n_v0 >= min_cnt) u[n_u++] = (uint64_t)sc << 32 | (uint64_t)(n_v - n_v0);
 			else n_v = n_v0;
 		}
 	}
 	n_u = __shfl(n_u, 0), n_v = __shfl(n_v, 0);
 	__syncthreads();
-	if (n_u == 0) { if (lane == 0) d_nu[r] = 0, d_nb[r] = 0; return; }
-
-	// ---------------- compact_a (lchain.c:79-112) ----------------
+	if (n_u == 0) return;
 	// NB: v[] was overwritten from index 0 by the walk (n_v <= anchors visited), as in the reference
-	// tmp anchors in chain order into z-space? z is still needed? no: reuse ws: write to b first (chain order), then reorder via z.
 	{
 		int32_t k0 = 0;
 		for (int32_t c = 0; c < n_u; ++c) {
@@ -206,7 +363,7 @@ __global__ void __launch_bounds__(64) k_lchain(int n_reads, const mg128_t *__res
 		for (int32_t c = 0; c < n_u; ++c) { w[c].x = z[k0].x; w[c].y = (uint64_t)k0 << 32 | (uint64_t)c; k0 += (int32_t)u[c]; }
 	}
 	__syncthreads();
-	klib_sort128x(w, n_u, t, &L);
+	klib_sort128x(w, n_u, t, L);
 	uint64_t *u2 = (uint64_t*)v; // n_u * 8 bytes <= n * 4 bytes when min_cnt >= 2; guarded by the host wrapper
 	if (lane == 0) for (int32_t c = 0; c < n_u; ++c) u2[c] = u[(int32_t)w[c].y];
 	__syncthreads();
@@ -220,21 +377,88 @@ __global__ void __launch_bounds__(64) k_lchain(int n_reads, const mg128_t *__res
 	}
 	__syncthreads();
 	for (int32_t c = lane; c < n_u; c += 64) u[c] = u2[c];
+	__syncthreads();
+	*n_u_ = n_u, *n_v_ = n_v;
+}
+
+// d_flag[r]: 0 = chains of the first pass; 1 = long-join rescue applied on the device; 2 = rescue due, left to the host
+__global__ void __launch_bounds__(64) k_lchain(int n_reads, const mg128_t *__restrict__ a_all, const int64_t *__restrict__ a_off, mga_lchain_par_t P,
+											   lc_rescue_t R, const int64_t *__restrict__ q_off,
+											   uint64_t *__restrict__ u_all, mg128_t *__restrict__ b_all, int32_t *__restrict__ d_nu, int32_t *__restrict__ d_nb,
+											   int32_t *__restrict__ d_flag, int32_t *__restrict__ ws_i32, mg128_t *__restrict__ ws_z, mg128_t *__restrict__ ws_keep)
+{
+	__shared__ klib_lds_t L;
+	const int r = blockIdx.x, lane = threadIdx.x;
+	if (r >= n_reads) return;
+	const int64_t off = a_off[r];
+	const int32_t n = (int32_t)(a_off[r + 1] - off);
+	if (lane == 0 && d_flag) d_flag[r] = 0;
+	if (n == 0) { if (lane == 0) d_nu[r] = 0, d_nb[r] = 0; return; }
+	const mg128_t *a = a_all + off;
+	lc_ws_t W;
+	W.f = ws_i32 + off * 4, W.p = W.f + n, W.v = W.p + n, W.t = W.v + n; // 4 int32 per anchor
+	W.z = ws_z + off;                                                     // 1 mg128 per anchor
+	uint64_t *u = u_all + off;
+	mg128_t *b = b_all + off;
+	if (P.max_dist_x < P.bw) P.max_dist_x = P.bw;
+	if (P.max_dist_y < P.bw) P.max_dist_y = P.bw;
+
+	int32_t n_u = 0, n_v = 0;
+	lc_dp(a, n, P, W, lane);
+	lc_backtrack_compact(a, n, P.min_sc, P.min_cnt, P.bw, W, u, b, &n_u, &n_v, &L, lane);
+
+	// ---- long-join rescue (map-algo.c:407-417) ----
+	if (R.enabled && n_u > 1 && q_off) {
+		const int32_t qlen = (int32_t)(q_off[r + 1] - q_off[r]);
+		const int32_t st = (int32_t)b[0].y, en = (int32_t)b[(int32_t)u[0] - 1].y;
+		const int32_t unc = qlen - (en - st);
+		if (unc > R.rescue_size || (float)unc > (float)qlen * R.rescue_ratio) {
+			mg128_t *keep = (mg128_t*)((char*)ws_keep + off * 24); // the first-pass result (16 B/anchor + 8 B/chain), should the host have to take over
+			uint64_t *keep_u = (uint64_t*)(keep + n_v);
+			for (int32_t i = lane; i < n_v; i += 64) keep[i] = b[i];
+			for (int32_t i = lane; i < n_u; i += 64) keep_u[i] = u[i];
+			__syncthreads();
+			klib_sort128x(b, n_v, W.t, &L); // all chained anchors, by x (n_v = sum of the chain sizes)
+			__syncthreads();
+			int32_t n_u2 = 0, n_v2 = 0;
+			const int32_t n_a = n_v;
+			if (lc_dp_rmq(b, n_a, R, W, lane)) {
+				// mg_lchain_rmq backtracks with max_drop = its bw (lchain.c:267,359); the anchors are read from b, the result overwrites b
+				lc_backtrack_compact(b, n_a, R.min_sc, R.min_cnt, R.bw, W, u, b, &n_u2, &n_v2, &L, lane);
+				n_u = n_u2, n_v = n_v2;
+				if (lane == 0 && d_flag) d_flag[r] = 1;
+			} else {
+				__syncthreads();
+				for (int32_t i = lane; i < n_v; i += 64) b[i] = keep[i];
+				for (int32_t i = lane; i < n_u; i += 64) u[i] = keep_u[i];
+				if (lane == 0 && d_flag) d_flag[r] = 2;
+			}
+		}
+	}
 	if (lane == 0) { d_nu[r] = n_u; d_nb[r] = n_v; }
 }
 
-extern "C" size_t mga_dev_lchain_ws_bytes(int64_t total_anchors) { return (size_t)(total_anchors + 16) * 32; }
+extern "C" size_t mga_dev_lchain_ws_bytes(int64_t total_anchors) { return (size_t)(total_anchors + 16) * 56; }
 
-extern "C" int mga_dev_lchain(mga_sctx_t *sc, int n, const mg128_t *d_a, const int64_t *d_a_off, const mga_lchain_par_t *par,
-							  uint64_t *d_u, mg128_t *d_b, int32_t *d_nu, int32_t *d_nb, void *d_ws, size_t ws_bytes, int64_t total_anchors)
+extern "C" int mga_dev_lchain(mga_sctx_t *sc, int n, const mg128_t *d_a, const int64_t *d_a_off, const mga_lchain_par_t *par, const mga_rescue_par_t *resc,
+							  const int64_t *d_q_off, uint64_t *d_u, mg128_t *d_b, int32_t *d_nu, int32_t *d_nb, int32_t *d_flag, void *d_ws, size_t ws_bytes, int64_t total_anchors)
 {
 	if (n <= 0) return 0;
 	if (par->min_cnt < 2) { mga_set_error("lchain: min_cnt >= 2 required by the workspace layout (got %d)", par->min_cnt); return -1; }
 	if (ws_bytes < mga_dev_lchain_ws_bytes(total_anchors)) { mga_set_error("lchain: workspace too small"); return -1; }
 	int32_t *ws_i32 = (int32_t*)d_ws;
 	mg128_t *ws_z = (mg128_t*)((char*)d_ws + (size_t)(total_anchors + 8) * 16);
+	mg128_t *ws_keep = (mg128_t*)((char*)d_ws + (size_t)(total_anchors + 8) * 32); // b copy (16 B/anchor) + u copy (<= 8 B/anchor / min_cnt)
+	lc_rescue_t R;
+	memset(&R, 0, sizeof R);
+	if (resc && resc->enabled && d_q_off && d_flag) {
+		if (resc->min_cnt < 2) { mga_set_error("lchain rescue: min_cnt >= 2 required"); return -1; }
+		R.enabled = 1, R.max_dist = resc->max_dist, R.max_dist_inner = resc->max_dist_inner, R.bw = resc->bw, R.max_skip = resc->max_skip, R.cap = resc->cap;
+		R.min_cnt = resc->min_cnt, R.min_sc = resc->min_sc, R.pen_gap = resc->chn_pen_gap, R.pen_skip = resc->chn_pen_skip;
+		R.rescue_size = resc->rescue_size, R.rescue_ratio = resc->rescue_ratio;
+	}
 	mga_prof_begin(sc->stream, MGA_K_LCHAIN);
-	hipLaunchKernelGGL(k_lchain, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, d_u, d_b, d_nu, d_nb, ws_i32, ws_z);
+	hipLaunchKernelGGL(k_lchain, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, R, d_q_off, d_u, d_b, d_nu, d_nb, d_flag, ws_i32, ws_z, ws_keep);
 	mga_prof_end(sc->stream, MGA_K_LCHAIN);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;

@@ -61,6 +61,7 @@ struct mga_batch_s {
 	const uint64_t *u;
 	const mg128_t *a;
 	int a_is_raw;
+	const int32_t *rescue_flag; /* per read: what the chaining kernel did about the long-join rescue (NULL: decide here) */
 	/* stage-2 inputs */
 	mga_cigsrc_t src;
 	int err;
@@ -133,9 +134,12 @@ static void chain_worker(void *data, int64_t i, int tid)
 	}
 	CPU_ADD(C_LCCOPY, tc);
 	/* long-join rescue (map-algo.c:407-417) */
-	if (opt->bw_long > opt->bw && (opt->flag & (MG_M_SPLICE | MG_M_SR)) == 0 && n_lc > 1) {
+	if (b->rescue_flag && !b->a_is_raw) { /* the kernel evaluated the condition: 1 = done there, 2 = due but deferred to the host (priority tie) */
+		if (b->rescue_flag[i] == 2) goto do_rescue;
+	} else if (opt->bw_long > opt->bw && (opt->flag & (MG_M_SPLICE | MG_M_SR)) == 0 && n_lc > 1) {
 		int32_t st = (int32_t)a[0].y, en = (int32_t)a[(int32_t)u[0] - 1].y;
 		if (qlen - (en - st) > opt->rmq_rescue_size || qlen - (en - st) > qlen * opt->rmq_rescue_ratio) {
+do_rescue:;
 			mg128_t *a2;
 			for (k = 0, n_a = 0; k < n_lc; ++k) n_a += (int32_t)u[k];
 			free(u); u = 0;
@@ -183,9 +187,10 @@ static void chain_worker(void *data, int64_t i, int tid)
 }
 
 int mga_batch_chain(mga_batch_t *b, const int32_t *n_mz, const int32_t *rep_len, const int32_t *mini_pos, const int64_t *mini_off,
-					const int32_t *nu, const int32_t *nb, const uint64_t *u, const mg128_t *a, const int64_t *a_off, int a_is_raw)
+					const int32_t *nu, const int32_t *nb, const uint64_t *u, const mg128_t *a, const int64_t *a_off, int a_is_raw, const int32_t *rescue_flag)
 {
 	int t;
+	b->rescue_flag = rescue_flag;
 	b->n_mz = n_mz, b->rep_len = rep_len, b->mini_pos = mini_pos, b->mini_off = mini_off;
 	b->nu = nu, b->nb = nb, b->u = u, b->a = a, b->a_off = a_off, b->a_is_raw = a_is_raw;
 	mga_parallel_for(b->n_threads, b->n, chain_worker, b);
@@ -302,7 +307,7 @@ void mga_batch_destroy(mga_batch_t *b)
 typedef struct {
 	mga_sctx_t *sc;
 	mga_dbuf_t seq, qoff, cnt, mzoff, mz, occ, val, na, nmini, rep, aoff, minioff, a, tmp, mini, u, b, nu, nb, ws;
-	mga_dbuf_t tseq, prob, res, pool, used, ncig, cigoff, ord;
+	mga_dbuf_t tseq, prob, res, pool, used, ncig, cigoff, ord, rflag;
 	mga_hbuf_t h_b, h_u, h_mini, h_tseq, h_prob, h_pool, h_seq, h_ncig, h_cigoff; /* pinned staging */
 } pipe_ctx_t;
 
@@ -318,6 +323,8 @@ static int g_dbg_pipe = -1;
  * cheap front phase (sketch/seed/chain) of one chunk fills the tail of another chunk's WFA launches. */
 static pthread_mutex_t g_gpu_front = PTHREAD_MUTEX_INITIALIZER, g_gpu_wfa = PTHREAD_MUTEX_INITIALIZER;
 
+static int env_int(const char *name, int dflt) { const char *s = getenv(name); return s && *s ? atoi(s) : dflt; }
+
 #define CK(x) do { if ((x) < 0) { rc = -1; goto done; } } while (0)
 
 static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs_out,
@@ -328,7 +335,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	int rc = 0, i;
 	int64_t tot = 0, n_mz, n_a, n_mini, n_prob = 0, n_tb = 0, pool_cap;
 	int64_t *q_off = MGA_MALLOC(int64_t, n + 2), *h_mzoff = 0, *h_aoff = 0, *h_minioff = 0;
-	int32_t *h_nmz = 0, *h_rep = 0, *h_nu = 0, *h_nb = 0;
+	int32_t *h_nmz = 0, *h_rep = 0, *h_nu = 0, *h_nb = 0, *h_rflag = 0;
 	mga_batch_t *b = 0;
 	mga_lchain_par_t par;
 	const int is_rmq = !!(opt->flag & MG_M_RMQ);
@@ -400,7 +407,19 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 		mga_batch_lchain_par(gi, opt, 0, &par);
 		CK(mga_dbuf_reserve(&P->u, (size_t)n_a * 8 + 8)); CK(mga_dbuf_reserve(&P->b, (size_t)n_a * 16 + 16));
 		CK(mga_dbuf_reserve(&P->nu, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&P->nb, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&P->ws, wsb));
-		CK(mga_dev_lchain(sc, n, (const mg128_t*)P->a.p, (const int64_t*)P->aoff.p, &par, (uint64_t*)P->u.p, (mg128_t*)P->b.p, (int32_t*)P->nu.p, (int32_t*)P->nb.p, P->ws.p, wsb, n_a));
+		{ /* the long-join rescue (map-algo.c:407-417) runs inside the same kernel; MGA_HOST_RESCUE=1 keeps it on the host (A/B testing) */
+			mga_rescue_par_t rs;
+			memset(&rs, 0, sizeof rs);
+			rs.enabled = opt->bw_long > opt->bw && (opt->flag & (MG_M_SPLICE | MG_M_SR)) == 0 && !env_int("MGA_HOST_RESCUE", 0);
+			rs.max_dist = opt->max_gap, rs.max_dist_inner = opt->max_gap_pre, rs.bw = opt->bw_long, rs.max_skip = opt->max_lc_skip, rs.cap = opt->rmq_size_cap;
+			rs.min_cnt = opt->min_lc_cnt, rs.min_sc = opt->min_lc_score, rs.chn_pen_gap = par.chn_pen_gap, rs.chn_pen_skip = par.chn_pen_skip;
+			rs.rescue_size = opt->rmq_rescue_size, rs.rescue_ratio = opt->rmq_rescue_ratio;
+			CK(mga_dbuf_reserve(&P->rflag, (size_t)n * 4 + 4));
+			CK(mga_dev_lchain(sc, n, (const mg128_t*)P->a.p, (const int64_t*)P->aoff.p, &par, &rs, (const int64_t*)P->qoff.p, (uint64_t*)P->u.p, (mg128_t*)P->b.p,
+							  (int32_t*)P->nu.p, (int32_t*)P->nb.p, (int32_t*)P->rflag.p, P->ws.p, wsb, n_a));
+			h_rflag = MGA_MALLOC(int32_t, n);
+			CK(mga_d2h_s(sc, h_rflag, P->rflag.p, (size_t)n * 4));
+		}
 		h_nu = MGA_MALLOC(int32_t, n); h_nb = MGA_MALLOC(int32_t, n);
 		CK(mga_hbuf_reserve(&P->h_u, (size_t)n_a * 8 + 8));
 		CK(mga_d2h_s(sc, h_nu, P->nu.p, (size_t)n * 4)); CK(mga_d2h_s(sc, h_nb, P->nb.p, (size_t)n * 4));
@@ -412,7 +431,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	t1 = mga_wtime(); st->t_lchain += t1 - t0; t0 = t1;
 	/* ---- host: graph chaining + gap list ---- */
 	b = mga_batch_init(gi, opt, n, qlens, seqs, qnames, q_off, n_threads);
-	CK(mga_batch_chain(b, h_nmz, h_rep, (const int32_t*)P->h_mini.p, h_minioff, h_nu, h_nb, (const uint64_t*)P->h_u.p, (const mg128_t*)P->h_b.p, h_aoff, is_rmq));
+	CK(mga_batch_chain(b, h_nmz, h_rep, (const int32_t*)P->h_mini.p, h_minioff, h_nu, h_nb, (const uint64_t*)P->h_u.p, (const mg128_t*)P->h_b.p, h_aoff, is_rmq, h_rflag));
 	if (g_dbg_pipe > 1) PIPE_LOG(" hostchain", n, t0);
 	t1 = mga_wtime(); st->t_host_chain += t1 - t0; t0 = t1;
 	/* ---- WFA over all gaps ---- */
@@ -465,7 +484,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 done:
 	GPU_RELEASE();
 	if (b) mga_batch_destroy(b);
-	free(q_off); free(h_mzoff); free(h_aoff); free(h_minioff); free(h_nmz); free(h_rep); free(h_nu); free(h_nb);
+	free(q_off); free(h_mzoff); free(h_aoff); free(h_minioff); free(h_nmz); free(h_rep); free(h_nu); free(h_nb); free(h_rflag);
 	return rc;
 }
 
@@ -569,7 +588,6 @@ static void *pipe_worker(void *a)
 	return 0;
 }
 
-static int env_int(const char *name, int dflt) { const char *s = getenv(name); return s && *s ? atoi(s) : dflt; }
 
 static int map_all(const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs,
 				   const mg_mapopt_t *opt, int n_threads, const char *d_seq, const int64_t *q_off, char **gaf, int64_t *gaf_len)

@@ -12,7 +12,7 @@ void mga_batch_lchain_par(const mg_idx_t *gi, const mg_mapopt_t *opt, int qlen_m
 /* host half 1 (map-algo.c:407-474 + the gap list of galign.c:53-125).  Inputs are what the GPU stages produce:
  * per read n_mz, rep_len, mini_pos; and either the DP chains (nu, nb, u, a laid out at a_off) or, with a_is_raw, the sorted anchors */
 int mga_batch_chain(mga_batch_t *b, const int32_t *n_mz, const int32_t *rep_len, const int32_t *mini_pos, const int64_t *mini_off,
-					const int32_t *nu, const int32_t *nb, const uint64_t *u, const mg128_t *a, const int64_t *a_off, int a_is_raw);
+					const int32_t *nu, const int32_t *nb, const uint64_t *u, const mg128_t *a, const int64_t *a_off, int a_is_raw, const int32_t *rescue_flag);
 int64_t mga_batch_n_wfa(const mga_batch_t *b);
 int64_t mga_batch_wfa_target_bytes(const mga_batch_t *b);
 void mga_batch_wfa_export(const mga_batch_t *b, mga_wfa_prob_t *prob, char *tseq);

@@ -103,8 +103,16 @@ int mga_dev_seed_fill(mga_sctx_t *sc, const mga_didx_t *ix, int n, const mg128_t
 /* ---- linear chaining (k_lchain.hip) ---- */
 /* per read i with anchors d_a[a_off[i]..a_off[i+1]) (x-sorted): chains u[] (score<<32|cnt) at d_u + a_off[i],
  * compacted anchors at d_b + a_off[i]; d_nu[i], d_nb[i] = their counts.  d_ws: mga_dev_lchain_ws_bytes(total) bytes. */
-int mga_dev_lchain(mga_sctx_t *sc, int n, const mg128_t *d_a, const int64_t *d_a_off, const mga_lchain_par_t *par,
-				   uint64_t *d_u, mg128_t *d_b, int32_t *d_nu, int32_t *d_nb, void *d_ws, size_t ws_bytes, int64_t total_anchors);
+/* long-join rescue on the device (k_lchain.hip): parameters of the mg_lchain_rmq call at map-algo.c:407-417 */
+typedef struct {
+	int32_t enabled, max_dist, max_dist_inner, bw, max_skip, cap, min_cnt, min_sc;
+	float chn_pen_gap, chn_pen_skip;
+	int32_t rescue_size;
+	float rescue_ratio;
+} mga_rescue_par_t;
+/* resc/d_q_off/d_flag may be NULL (no rescue).  d_flag[i]: 0 first-pass chains, 1 rescued on the device, 2 rescue due but left to the host */
+int mga_dev_lchain(mga_sctx_t *sc, int n, const mg128_t *d_a, const int64_t *d_a_off, const mga_lchain_par_t *par, const mga_rescue_par_t *resc,
+				   const int64_t *d_q_off, uint64_t *d_u, mg128_t *d_b, int32_t *d_nu, int32_t *d_nb, int32_t *d_flag, void *d_ws, size_t ws_bytes, int64_t total_anchors);
 size_t mga_dev_lchain_ws_bytes(int64_t total_anchors);
 
 /* ---- WFA (k_wfa.hip) ---- */

@@ -138,7 +138,7 @@ extern "C" int mga_lchain_batch(int n, const mg128_t *a, const int64_t *a_off, c
 	if (!d_a.alloc((size_t)tot * 16 + 16) || !d_aoff.alloc((n + 1) * 8) || !d_u.alloc((size_t)tot * 8 + 8) || !d_b.alloc((size_t)tot * 16 + 16) ||
 		!d_nu.alloc(n * 4) || !d_nb.alloc(n * 4) || !d_ws.alloc(wsb)) return -1;
 	if (mga_h2d(d_a.p, a, (size_t)tot * 16) < 0 || mga_h2d(d_aoff.p, a_off, (n + 1) * 8) < 0) return -1;
-	if (mga_dev_lchain(SC, n, d_a.as<mg128_t>(), d_aoff.as<int64_t>(), par, d_u.as<uint64_t>(), d_b.as<mg128_t>(), d_nu.as<int32_t>(), d_nb.as<int32_t>(),
+	if (mga_dev_lchain(SC, n, d_a.as<mg128_t>(), d_aoff.as<int64_t>(), par, 0, 0, d_u.as<uint64_t>(), d_b.as<mg128_t>(), d_nu.as<int32_t>(), d_nb.as<int32_t>(), 0,
 					   d_ws.p, wsb, tot) < 0) return -1;
 	std::vector<int32_t> nu(n), nb(n);
 	std::vector<uint64_t> hu((size_t)tot + 1);

@@ -62,7 +62,7 @@ def map_with_oracle_stages(graph, reads, occ_max1, lc_max_occ, cigar=True, n_thr
     L.mga_idx_hostpart.restype = C.c_void_p
     L.mga_batch_init.argtypes = [C.c_void_p, C.POINTER(mga.mapopt_t), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.mga_batch_init.restype = C.c_void_p
-    L.mga_batch_chain.argtypes = [C.c_void_p] + [C.c_void_p] * 9 + [C.c_int]
+    L.mga_batch_chain.argtypes = [C.c_void_p] + [C.c_void_p] * 9 + [C.c_int, C.c_void_p]
     L.mga_batch_n_wfa.argtypes = [C.c_void_p]
     L.mga_batch_n_wfa.restype = C.c_int64
     L.mga_batch_wfa_target_bytes.argtypes = [C.c_void_p]
@@ -119,7 +119,7 @@ def map_with_oracle_stages(graph, reads, occ_max1, lc_max_occ, cigar=True, n_thr
     N_MZ, REP, NU, NB = i32(n_mz), i32(rep), i32(nus), i32(nbs)
     b = L.mga_batch_init(gi, C.byref(mo), n, qlens, seqp, namep, q_off.ctypes.data, n_threads)
     assert L.mga_batch_chain(b, N_MZ.ctypes.data, REP.ctypes.data, MINI.ctypes.data, mini_off.ctypes.data, NU.ctypes.data, NB.ctypes.data,
-                             U.ctypes.data, A.ctypes.data, a_off.ctypes.data, 0) == 0
+                             U.ctypes.data, A.ctypes.data, a_off.ctypes.data, 0, None) == 0
     n_prob, n_tb = L.mga_batch_n_wfa(b), L.mga_batch_wfa_target_bytes(b)
     probs = (wfa_prob_t * max(n_prob, 1))()
     tbuf = C.create_string_buffer(int(n_tb) + 64)
