@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=40000, help="reads per GPU per step")
+    ap.add_argument("--reads", type=int, default=100000, help="reads per GPU per step (BASELINE configs[2]: 100k reads)")
     ap.add_argument("--genome", type=int, default=50000000)
     ap.add_argument("--hap", type=int, default=3)
     ap.add_argument("--cpu-reads", type=int, default=20000)

@@ -67,7 +67,8 @@ KERNELS = ["k_sketch", "k_seed_count", "k_seed_fill", "k_lchain", "k_wfa_r[64]",
 class stats_t(C.Structure):  # mga_stats_t
     _fields_ = [(n, C.c_int64) for n in ("n_reads", "n_bases", "n_mz", "n_probe", "n_hit", "n_anchor_chained", "n_wfa",
                                          "wfa_t_bases", "wfa_q_bases", "wfa_cells", "gaf_bytes")] + \
-               [(n, C.c_double) for n in ("t_sketch", "t_seed", "t_lchain", "t_host_chain", "t_wfa", "t_host_post", "t_gaf")]
+               [(n, C.c_double) for n in ("t_sketch", "t_seed", "t_lchain", "t_host_chain", "t_wfa", "t_host_post", "t_gaf")] + \
+               [(n, C.c_int64) for n in ("n_rescue_dev", "n_rescue_host")]
 
 
 def load():

@@ -52,3 +52,29 @@ def test_synthetic_vs_reference_binary(cigar, target):
     mga.map_files(graph, [reads], got, cigar=cigar)
     if open(ref_out, "rb").read() != open(got, "rb").read():
         raise AssertionError(first_diff(ref_out, got))
+
+
+def test_long_join_rescue_on_device_matches_host_tree_and_reference(monkeypatch):
+    """the RMQ rescue (map-algo.c:407-417) runs inside k_lchain; the sequential AVL tree on the host (MGA_HOST_RESCUE=1)
+    and the reference binary must give the same bytes, and the device path must actually have been taken"""
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "5000000", "-H", "3", "-n", "1500", "-s", "9", "-S", "77"], stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    G = mga.Graph(graph, preset="lr", cigar=True, n_threads=8)
+    R = mga.Reads(reads)
+    mga.get_stats(G, reset=True)
+    dev = mga.map_reads(G, R, n_threads=8)
+    st = mga.get_stats(G, reset=True)
+    assert st["n_rescue_dev"] > 100, st          # bubbles split ~half of the reads into several chains
+    assert st["n_rescue_host"] <= st["n_rescue_dev"] // 10, st
+    monkeypatch.setenv("MGA_HOST_RESCUE", "1")
+    host = mga.map_reads(G, R, n_threads=8)
+    st2 = mga.get_stats(G, reset=True)
+    assert st2["n_rescue_dev"] == 0
+    assert dev == host
+    R.close()
+    G.close()
+    if os.path.exists(rb.REF_BIN):
+        ref_out = os.path.join(d, "ref.gaf")
+        run_ref(["-c", "-x", "lr", "-t", "4", graph, reads], ref_out)
+        assert open(ref_out, "rb").read() == dev
