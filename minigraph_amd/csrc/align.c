@@ -99,7 +99,8 @@ int mga_apply_cigar(mg_gchains_t *gt, int32_t gc_idx, const mga_cigitem_t *item,
 			cap += r->n_cigar;
 		}
 	}
-	gc->p = (mg_cigar_t*)calloc(1, (size_t)cap * 8 + sizeof(mg_cigar_t));
+	gc->p = (mg_cigar_t*)malloc((size_t)cap * 8 + sizeof(mg_cigar_t));
+	memset(gc->p, 0, sizeof(mg_cigar_t)); /* the operators are written below, no need to zero them */
 	c = gc->p->cigar;
 #define PUSH1(op_, len_) do { /* append_cigar1, galign.c:11-23 */ \
 		if (n > 0 && (int32_t)(c[n - 1] & 0xf) == (op_)) c[n - 1] += (uint64_t)(len_) << 4; \
@@ -138,98 +139,94 @@ int mga_apply_cigar(mg_gchains_t *gt, int32_t gc_idx, const mga_cigitem_t *item,
 }
 
 /* ---- ds:Z ---- */
-typedef struct { char *s; int64_t l, m; } dstr_t;
-
-static inline void ds_room(dstr_t *s, int64_t extra)
-{
-	if (s->l + extra + 1 > s->m) { s->m = (s->l + extra + 1) * 2; s->s = (char*)realloc(s->s, (size_t)s->m); }
-}
-static inline void ds_c(dstr_t *s, char ch) { ds_room(s, 1); s->s[s->l++] = ch; }
-static inline void ds_int(dstr_t *s, int32_t x)
-{
-	char buf[16];
-	int l = 0;
-	do { buf[l++] = (char)('0' + x % 10); x /= 10; } while (x > 0);
-	ds_room(s, l);
-	while (l > 0) s->s[s->l++] = buf[--l];
-}
+/* lower-case base of a (possibly ambiguous) sequence character, as the reference prints it */
 #define NT_LC(ch) ("acgtn"[mga_nt4_table[(uint8_t)(ch)]])
 
-static void ds_indel(dstr_t *s, int64_t len, const char *seq, int64_t ll, int64_t lr) /* write_indel, galign.c:153-180 */
+static inline char *ds_put_int(char *w, int32_t x)
+{
+	char buf[12];
+	int l = 0;
+	if (x < 10) { *w++ = (char)('0' + x); return w; }
+	do { buf[l++] = (char)('0' + x % 10); x /= 10; } while (x > 0);
+	while (l > 0) *w++ = buf[--l];
+	return w;
+}
+
+static inline char *ds_put_indel(char *w, int64_t len, const char *seq, int64_t ll, int64_t lr) /* write_indel, galign.c:153-180 */
 {
 	int64_t i;
 	if (ll + lr >= len) {
-		ds_c(s, '[');
-		for (i = 0; i < len; ++i) ds_c(s, NT_LC(seq[i]));
-		ds_c(s, ']');
+		*w++ = '[';
+		for (i = 0; i < len; ++i) *w++ = NT_LC(seq[i]);
+		*w++ = ']';
 	} else {
 		int64_t k = 0;
 		if (ll > 0) {
-			ds_c(s, '[');
-			for (i = 0; i < ll; ++i) ds_c(s, NT_LC(seq[k + i]));
-			ds_c(s, ']');
+			*w++ = '[';
+			for (i = 0; i < ll; ++i) *w++ = NT_LC(seq[k + i]);
+			*w++ = ']';
 			k += ll;
 		}
-		for (i = 0; i < len - lr - ll; ++i) ds_c(s, NT_LC(seq[k + i]));
+		for (i = 0; i < len - lr - ll; ++i) *w++ = NT_LC(seq[k + i]);
 		k += len - lr - ll;
 		if (lr > 0) {
-			ds_c(s, '[');
-			for (i = 0; i < lr; ++i) ds_c(s, NT_LC(seq[k + i]));
-			ds_c(s, ']');
+			*w++ = '[';
+			for (i = 0; i < lr; ++i) *w++ = NT_LC(seq[k + i]);
+			*w++ = ']';
 		}
 	}
+	return w;
 }
 
-void mga_gen_ds(const gfa_edseq_t *es, const char *qseq, mg_gchains_t *gt) /* mg_gchain_gen_ds, galign.c:182-293 */
+/* mg_gchain_gen_ds (galign.c:182-293).  One sizing pass over the CIGAR (no base compares: an '=' run is one entry, an
+ * X/M run of length l at most 1 + 2l entries and 3l + 11 characters, an indel one entry and l + 5 characters), then the
+ * string is written with raw stores into a buffer that is handed to the chain as is. */
+void mga_gen_ds(const gfa_edseq_t *es, const char *qseq, mg_gchains_t *gt)
 {
-	int32_t i, m_off = 0, *off = 0;
-	dstr_t str = {0, 0, 0};
+	int32_t i;
 	char *seq = 0;
 	int64_t m_seq = 0;
 	for (i = 0; i < gt->n_gc; ++i) {
 		mg_gchain_t *gc = &gt->gc[i];
-		int32_t j, n_off = 0;
-		int64_t x, y, l_seq = 0;
-		if (gc->p == 0) continue;
-		str.l = 0;
-		if (gc->p->aplen + 1 > m_seq) { m_seq = gc->p->aplen + 1; seq = (char*)realloc(seq, (size_t)m_seq); }
+		int32_t j, n_off = 0, *off;
+		int64_t x, y, l_seq = 0, cap_off = 0, cap_len = 1;
+		char *ds, *w;
+		const mg_cigar_t *p = gc->p;
+		if (p == 0) continue;
+		if (p->aplen + 1 > m_seq) { m_seq = p->aplen + 1 + (p->aplen >> 2); free(seq); seq = (char*)malloc((size_t)m_seq); }
 		for (j = 0; j < gc->cnt; ++j) { /* the aligned stretch of the walk */
 			uint32_t v = gt->lc[gc->off + j].v;
-			int32_t st = j > 0 ? 0 : gc->p->ss, en = j < gc->cnt - 1 ? es[v].len : gc->p->ee;
+			int32_t st = j > 0 ? 0 : p->ss, en = j < gc->cnt - 1 ? es[v].len : p->ee;
 			memcpy(&seq[l_seq], &es[v].seq[st], (size_t)(en - st));
 			l_seq += en - st;
 		}
-		assert(l_seq == gc->p->aplen);
-		for (j = 0, x = 0, y = gc->qs; j < gc->p->n_cigar; ++j) { /* upper bound on the number of entries */
-			int64_t op = gc->p->cigar[j] & 0xf, len = gc->p->cigar[j] >> 4, zz;
-			if (op == 7) ++n_off, x += len, y += len; /* '=': byte-identical bases, nothing to compare */
-			else if (op == 0 || op == 8) {
-				++n_off;
-				for (zz = 0; zz < len; ++zz)
-					if (mga_nt4_table[(uint8_t)seq[x + zz]] != mga_nt4_table[(uint8_t)qseq[y + zz]]) n_off += 2;
-				x += len, y += len;
-			} else if (op == 1) ++n_off, y += len;
-			else if (op == 2) ++n_off, x += len;
+		assert(l_seq == p->aplen);
+		for (j = 0; j < p->n_cigar; ++j) {
+			const int64_t op = p->cigar[j] & 0xf, len = (int64_t)(p->cigar[j] >> 4);
+			if (op == 7) cap_off += 1, cap_len += 11;
+			else if (op == 0 || op == 8) cap_off += 1 + 2 * len, cap_len += 3 * len + 11 * (len + 1);
+			else cap_off += 1, cap_len += len + 5;
 		}
-		if (n_off > m_off) { m_off = n_off + (n_off >> 1) + 16; off = MGA_REALLOC(int32_t, off, m_off); }
-		for (j = 0, x = 0, y = gc->qs, n_off = 0; j < gc->p->n_cigar; ++j) {
-			int64_t op = gc->p->cigar[j] & 0xf, len = gc->p->cigar[j] >> 4;
+		off = MGA_MALLOC(int32_t, cap_off > 0 ? cap_off : 1);
+		ds = w = (char*)malloc((size_t)cap_len);
+		for (j = 0, x = 0, y = gc->qs; j < p->n_cigar; ++j) {
+			const int64_t op = p->cigar[j] & 0xf, len = (int64_t)(p->cigar[j] >> 4);
 			if (op == 7) { /* the reference's base-by-base loop (galign.c:228-243) sees len equal codes: one ":len" entry */
-				if (len > 0) { off[n_off++] = (int32_t)str.l; ds_c(&str, ':'); ds_int(&str, (int32_t)len); }
+				if (len > 0) { off[n_off++] = (int32_t)(w - ds); *w++ = ':'; w = ds_put_int(w, (int32_t)len); }
 				x += len, y += len;
 			} else if (op == 0 || op == 8) {
 				int64_t zz;
 				int32_t l = 0;
 				for (zz = 0; zz < len; ++zz) {
-					uint8_t cx = mga_nt4_table[(uint8_t)seq[x + zz]], cy = mga_nt4_table[(uint8_t)qseq[y + zz]];
+					const uint8_t cx = mga_nt4_table[(uint8_t)seq[x + zz]], cy = mga_nt4_table[(uint8_t)qseq[y + zz]];
 					if (cx != cy) {
-						if (l > 0) { off[n_off++] = (int32_t)str.l; ds_c(&str, ':'); ds_int(&str, l); }
-						off[n_off++] = (int32_t)str.l;
-						ds_c(&str, '*'); ds_c(&str, "acgtn"[cx]); ds_c(&str, "acgtn"[cy]);
+						if (l > 0) { off[n_off++] = (int32_t)(w - ds); *w++ = ':'; w = ds_put_int(w, l); }
+						off[n_off++] = (int32_t)(w - ds);
+						*w++ = '*'; *w++ = "acgtn"[cx]; *w++ = "acgtn"[cy];
 						l = 0;
 					} else ++l;
 				}
-				if (l > 0) { off[n_off++] = (int32_t)str.l; ds_c(&str, ':'); ds_int(&str, l); }
+				if (l > 0) { off[n_off++] = (int32_t)(w - ds); *w++ = ':'; w = ds_put_int(w, l); }
 				x += len, y += len;
 			} else if (op == 1) { /* insertion: micro-homology on either side */
 				int64_t zz, ll, lr;
@@ -237,28 +234,28 @@ void mga_gen_ds(const gfa_edseq_t *es, const char *qseq, mg_gchains_t *gt) /* mg
 				lr = zz - 1;
 				for (zz = 0; zz < len; ++zz) if (y + len + zz >= gc->qe || qseq[y + len + zz] != qseq[y + zz]) break;
 				ll = zz;
-				off[n_off++] = (int32_t)str.l;
-				ds_c(&str, '+');
-				ds_indel(&str, len, &qseq[y], ll, lr);
+				off[n_off++] = (int32_t)(w - ds);
+				*w++ = '+';
+				w = ds_put_indel(w, len, &qseq[y], ll, lr);
 				y += len;
 			} else if (op == 2) {
 				int64_t zz, ll, lr;
 				for (zz = 1; zz <= len; ++zz) if (x - zz < 0 || seq[x + len - zz] != seq[x - zz]) break;
 				lr = zz - 1;
-				for (zz = 0; zz < len; ++zz) if (x + len + zz >= gc->p->aplen || seq[x + zz] != seq[x + len + zz]) break;
+				for (zz = 0; zz < len; ++zz) if (x + len + zz >= p->aplen || seq[x + zz] != seq[x + len + zz]) break;
 				ll = zz;
-				off[n_off++] = (int32_t)str.l;
-				ds_c(&str, '-');
-				ds_indel(&str, len, &seq[x], ll, lr);
+				off[n_off++] = (int32_t)(w - ds);
+				*w++ = '-';
+				w = ds_put_indel(w, len, &seq[x], ll, lr);
 				x += len;
 			}
 		}
-		gc->ds.len = (int32_t)str.l;
-		gc->ds.ds = (char*)calloc((size_t)str.l + 1, 1);
-		memcpy(gc->ds.ds, str.s, (size_t)str.l);
+		*w = 0;
+		assert(w - ds < cap_len && n_off <= cap_off);
+		gc->ds.len = (int32_t)(w - ds);
+		gc->ds.ds = ds;       /* (the reference callocs len+1 bytes; the spare capacity here is never read) */
 		gc->ds.n_off = n_off;
-		gc->ds.off = MGA_CALLOC(int32_t, n_off > 0 ? n_off : 1);
-		memcpy(gc->ds.off, off, (size_t)n_off * sizeof(int32_t));
+		gc->ds.off = off;
 	}
-	free(off); free(str.s); free(seq);
+	free(seq);
 }

@@ -3,13 +3,16 @@
 #define MGA_ALIGN_H
 #include "mga_host.h"
 
-typedef struct { int32_t op, val; } mga_cigitem_t; /* op >= 0: ready operator (op, len = val); op == -1: WFA problem #val of this pool */
+/* mga_cigitem_t (mga_dev.h): op >= 0: ready operator (op, len = val); op == -1: WFA problem #val of this pool */
 
 typedef struct { /* per host thread accumulators of one batch */
 	char *tseq; int64_t n_t, m_t;                  /* spliced target sequences */
 	mga_wfa_prob_t *prob; int64_t n_prob, m_prob;  /* t_off relative to this pool; q_off absolute in the device read buffer */
 	mga_cigitem_t *item; int64_t n_item, m_item;
 	int64_t wfa_t_bases, wfa_q_bases;
+	/* text mode (the device writes cg:Z / ds:Z): printed chains and the vertices of their walks; offsets local to this pool */
+	mga_txt_chain_t *chain; int64_t n_chain, m_chain;
+	uint32_t *vert; int64_t n_vert, m_vert;
 } mga_tpool_t;
 
 void mga_plan_cigar(const gfa_t *g, const gfa_edseq_t *es, const mg_gchains_t *gt, int32_t gc_idx, int64_t q_base, mga_tpool_t *tp);

@@ -84,7 +84,7 @@ extern "C" void mga_sctx_destroy(mga_sctx_t *sc)
 	(void)hipStreamSynchronize((hipStream_t)sc->stream);
 	for (int i = 0; i < 8; ++i) mga_dbuf_free(&sc->wfa_ws[i]);
 	mga_dbuf_free(&sc->wfa_cnt);
-	mga_dbuf_free(&sc->scan_tmp);
+	mga_dbuf_free(&sc->scan_tmp); mga_dbuf_free(&sc->txt_cnt); mga_dbuf_free(&sc->txt_off); mga_dbuf_free(&sc->txt_vwb); mga_dbuf_free(&sc->txt_el);
 	mga_dbuf_free(&sc->wfa_list[0]); mga_dbuf_free(&sc->wfa_list[1]); mga_dbuf_free(&sc->wfa_key); mga_dbuf_free(&sc->wfa_ctl);
 	for (int i = 0; i < 8; ++i) { (void)hipStreamDestroy((hipStream_t)sc->tier_stream[i]); (void)hipEventDestroy((hipEvent_t)sc->ev_done[i]); }
 	(void)hipEventDestroy((hipEvent_t)sc->ev_ready); (void)hipEventDestroy((hipEvent_t)sc->ev_sync);

@@ -40,11 +40,43 @@ void mg_write_gaf(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, int32_t 
 {
 	(void)km;
 	s->l = 0;
-	mga_write_gaf_append(s, g, gs, n_seg, qlens, qname, flag);
+	mga_write_gaf_append(s, g, gs, n_seg, qlens, qname, flag, 0);
+}
+
+/* does the path of chain p print as ONE piece of a rank-0 stable sequence, on its reverse strand?  (format.c:150-199: the
+ * "compact" form; that is what flips rev_sign).  Same decisions as the printing loop below, without printing. */
+int mga_gaf_chain_rev(const gfa_t *g, const mg_gchains_t *gs, const mg_gchain_t *p, uint64_t flag)
+{
+	int32_t j, last_pnid = -1, st = -1, en = -1, rev = -1, compact;
+	if (flag & MG_M_VERTEX_COOR) return 0;
+	compact = flag & MG_M_NO_COMP_PATH ? 0 : 1;
+	for (j = 0; j < p->cnt; ++j) {
+		const mg_llchain_t *q = &gs->lc[p->off + j];
+		const gfa_seg_t *t = &g->seg[q->v>>1];
+		if (t->snid < 0) {
+			compact = 0;
+			last_pnid = -1, st = -1, en = -1, rev = -1;
+		} else {
+			int cont = 0;
+			if (last_pnid >= 0 && t->snid == last_pnid && (int32_t)(q->v&1) == rev) {
+				if (!(q->v&1)) { if (t->soff == en) en = t->soff + t->len, cont = 1; }
+				else { if (t->soff + t->len == st) st = t->soff, cont = 1; }
+			}
+			if (cont == 0) {
+				if (last_pnid >= 0) compact = 0;
+				last_pnid = t->snid, rev = q->v&1, st = t->soff, en = st + t->len;
+			}
+		}
+	}
+	if (last_pnid >= 0) {
+		if (g->sseq[last_pnid].rank != 0 || g->sseq[last_pnid].min != 0) compact = 0;
+	} else compact = 0;
+	return compact && (gs->lc[p->off].v&1);
 }
 
 /* the body of mg_write_gaf, appending to s (the batch formatter writes the lines of many reads into one buffer) */
-void mga_write_gaf_append(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, int32_t n_seg, const int32_t *qlens, const char *qname, uint64_t flag)
+void mga_write_gaf_append(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, int32_t n_seg, const int32_t *qlens, const char *qname, uint64_t flag,
+						  const mga_chain_text_t *txt) /* txt: per chain, statistics + cg/ds text produced by the device (k_text.hip), or NULL */
 {
 	int32_t i, j, qlen, rev_sign = 0; /* rev_sign is deliberately NOT reset per chain (format.c:123) */
 	const size_t l0 = s->l;
@@ -111,9 +143,11 @@ void mga_write_gaf_append(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, 
 				ks_d(s, t->soff + (p->plen - p->pe)); ks_c(s, '\t'); ks_d(s, t->soff + (p->plen - p->ps));
 			} else { ks_d(s, t->soff + p->ps); ks_c(s, '\t'); ks_d(s, t->soff + p->pe); }
 		} else { ks_c(s, '\t'); ks_d(s, p->plen); ks_c(s, '\t'); ks_d(s, p->ps); ks_c(s, '\t'); ks_d(s, p->pe); }
-		ks_c(s, '\t'); ks_d(s, p->p ? p->p->mlen : p->mlen); ks_c(s, '\t'); ks_d(s, p->p ? p->p->blen : p->blen); ks_c(s, '\t'); ks_d(s, (int32_t)p->mapq);
+		const mga_chain_text_t *tx = txt && txt[i].cg ? &txt[i] : 0;
+		const int32_t a_mlen = tx ? tx->mlen : p->p ? p->p->mlen : p->mlen, a_blen = tx ? tx->blen : p->p ? p->p->blen : p->blen;
+		ks_c(s, '\t'); ks_d(s, a_mlen); ks_c(s, '\t'); ks_d(s, a_blen); ks_c(s, '\t'); ks_d(s, (int32_t)p->mapq);
 		ks_s(s, "\ttp:A:"); ks_c(s, p->id == p->parent ? 'P' : 'S');
-		if (p->p) { ks_s(s, "\tNM:i:"); ks_d(s, p->p->blen - p->p->mlen); }
+		if (p->p || tx) { ks_s(s, "\tNM:i:"); ks_d(s, a_blen - a_mlen); }
 		ks_s(s, "\tcm:i:"); ks_d(s, p->n_anchor); ks_s(s, "\ts1:i:"); ks_d(s, p->score); ks_s(s, "\ts2:i:"); ks_d(s, p->subsc);
 		if (p->div >= 0.0f && p->div <= 1.0f) {
 			char buf[16];
@@ -125,7 +159,11 @@ void mga_write_gaf_append(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, 
 			ks_s(s, "\tql:B:i");
 			for (j = 0; j < n_seg; ++j) { ks_c(s, ','); ks_d(s, qlens[j]); }
 		}
-		if (p->p) {
+		if (tx) { /* both strings arrive in print order (already reversed when rev_sign is set) */
+			ks_s(s, "\tcg:Z:"); ks_sn(s, tx->cg, (size_t)tx->cg_len);
+			ks_s(s, "\tds:Z:"); ks_sn(s, tx->ds, (size_t)tx->ds_len);
+		}
+		if (p->p && !tx) {
 			const int32_t nc = p->p->n_cigar;
 			char *w;
 			ks_s(s, "\tcg:Z:");
@@ -147,7 +185,7 @@ void mga_write_gaf_append(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, 
 			s->l = (unsigned)(w - s->s);
 			s->s[s->l] = 0;
 		}
-		if (p->ds.ds) {
+		if (p->ds.ds && !tx) {
 			ks_s(s, "\tds:Z:");
 			if (rev_sign) { /* reverse-complement the difference string entry by entry (format.c:217-241) */
 				const char *ds = p->ds.ds;

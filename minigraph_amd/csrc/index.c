@@ -110,9 +110,9 @@ mg_idx_t *mg_index(gfa_t *g, const mg_idxopt_t *io, int n_threads, mg_mapopt_t *
 	cat = (char*)malloc((size_t)tot + 1);
 	for (s = 0; s < g->n_seg; ++s) if (g->seg[s].seq) memcpy(cat + off[s], g->seg[s].seq, (size_t)g->seg[s].len);
 	if (mga_sketch_batch((int)g->n_seg, cat, off, rid, w, k, &mz, &mz_off) < 0) { free(off); free(rid); free(seg_len); free(cat); return 0; }
-	free(cat); free(rid);
+	free(rid);
 	n_mz = mz_off[g->n_seg];
-	free(mz_off); free(off);
+	free(mz_off);
 
 	/* group occurrences by hash; each group's positions ascending */
 	radix_by_key(n_mz, mz, 2 * k);
@@ -158,13 +158,16 @@ mg_idx_t *mg_index(gfa_t *g, const mg_idxopt_t *io, int n_threads, mg_mapopt_t *
 	B->dev.d_tab = (mg128_t*)mga_dmalloc((size_t)n_slots * 16);
 	B->dev.d_pos = (uint64_t*)mga_dmalloc((size_t)(n_pos + 1) * 8);
 	B->dev.d_seg_len = (int32_t*)mga_dmalloc((size_t)(g->n_seg + 1) * 4);
-	if (!B->dev.d_tab || !B->dev.d_pos || !B->dev.d_seg_len ||
+	B->dev.d_gseq = (char*)mga_dmalloc((size_t)tot + 64);       /* forward segment sequences: the text kernel reads target bases from here */
+	B->dev.d_gseq_off = (int64_t*)mga_dmalloc((size_t)(g->n_seg + 1) * 8);
+	if (!B->dev.d_tab || !B->dev.d_pos || !B->dev.d_seg_len || !B->dev.d_gseq || !B->dev.d_gseq_off ||
 		mga_h2d(B->dev.d_tab, tab, (size_t)n_slots * 16) < 0 || mga_h2d(B->dev.d_pos, pos, (size_t)n_pos * 8) < 0 ||
-		mga_h2d(B->dev.d_seg_len, seg_len, (size_t)g->n_seg * 4) < 0) {
-		free(tab); free(pos); free(seg_len); free(B->occ_hist); free(B);
+		mga_h2d(B->dev.d_seg_len, seg_len, (size_t)g->n_seg * 4) < 0 || mga_h2d(B->dev.d_gseq, cat, (size_t)tot) < 0 ||
+		mga_h2d(B->dev.d_gseq_off, off, (size_t)(g->n_seg + 1) * 8) < 0 || mga_dev_text_tables(mga_comp_table, mga_nt4_table) < 0) {
+		free(tab); free(pos); free(seg_len); free(cat); free(off); free(B->occ_hist); free(B);
 		return 0;
 	}
-	free(tab); free(pos); free(seg_len);
+	free(tab); free(pos); free(seg_len); free(cat); free(off);
 
 	gi = mga_idx_hostpart(g, io);
 	gi->B = B;
@@ -180,7 +183,7 @@ void mg_idx_destroy(mg_idx_t *gi)
 	int32_t i;
 	if (gi == 0) return;
 	if (gi->B) {
-		mga_dfree(gi->B->dev.d_tab); mga_dfree(gi->B->dev.d_pos); mga_dfree(gi->B->dev.d_seg_len);
+		mga_dfree(gi->B->dev.d_tab); mga_dfree(gi->B->dev.d_pos); mga_dfree(gi->B->dev.d_seg_len); mga_dfree(gi->B->dev.d_gseq); mga_dfree(gi->B->dev.d_gseq_off);
 		free(gi->B->occ_hist); free(gi->B->gaf_out);
 		free(gi->B);
 	}

@@ -1,0 +1,302 @@
+// k_text.hip -- alignment text on the device: CIGAR stitching (mg_gchain_cigar, galign.c:39-145), the ds:Z difference
+// string (mg_gchain_gen_ds, galign.c:182-293) and the cg:Z / ds:Z fields of the GAF line (format.c:205-246), for
+// the path that only wants GAF bytes (mga_map_reads).  These three loops cost the host 45 us per 10 kb read
+// ([measured]: ~1600 branchy operators per read), half of its budget.  One wavefront per printed chain:
+//
+//   S1  the plan items (ready operators / references to WFA problems, align.c:mga_plan_cigar) are expanded into
+//       the concatenated operator list (64 output slots per step, owner item found by binary search over the
+//       lanes' offsets);
+//   S2  runs: an element starts a new operator unless it is allowed to merge (append_cigar1: every ready operator
+//       and the FIRST operator of a WFA CIGAR) and equals the previous operator; run lengths by atomic adds;
+//   S3  per run (lane = run): target/query coordinates by wave scans, statistics (mlen/blen/aplen), the length of
+//       its cg:Z piece and of its ds:Z entries (mismatch runs compare nt4 codes base by base; indels look for
+//       micro-homology, write_indel galign.c:153-180);
+//   S4  space for the two strings is taken from the text pool with one atomic, then every run writes its pieces
+//       at its scanned offset -- from the END of the strings, entry by entry reversed/complemented, when the line
+//       is printed on the reverse strand (rev_sign, format.c:123,183,217-241).
+// k_text_count (lane per chain) sizes the element lists and tabulates where each vertex of the walk starts.
+#include "mga_dev.h"
+#include "dev_common.h"
+#include <string.h>
+
+struct txt_tables_t { unsigned char comp[256], nt4[256]; };
+__constant__ txt_tables_t c_txt;
+
+struct txt_walk_t {
+	const uint32_t *vert; const int32_t *vwb; int32_t cnt, ss; // vwb[k]: walk position where vertex k starts
+	const char *gseq; const int64_t *gseq_off; const int32_t *seg_len;
+};
+
+// base x of the aligned stretch of the walk (what mg_gchain_gen_ds copies into seq[], galign.c:195-200)
+__device__ __forceinline__ char walk_get(const txt_walk_t &W, int32_t x)
+{
+	int32_t lo = 0, hi = W.cnt - 1;
+	while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (W.vwb[mid] <= x) lo = mid; else hi = mid - 1; }
+	const uint32_t v = W.vert[lo];
+	const int32_t p = (lo > 0 ? 0 : W.ss) + (x - W.vwb[lo]);
+	const int64_t o = W.gseq_off[v >> 1];
+	if (!(v & 1)) return W.gseq[o + p];
+	return (char)c_txt.comp[(unsigned char)W.gseq[o + (W.seg_len[v >> 1] - 1 - p)]]; // gfa_edseq_init: reverse complement (gfa-ed.c:24-42)
+}
+
+__device__ __forceinline__ int txt_ndigits(uint32_t x) { int n = 1; while (x >= 10) x /= 10, ++n; return n; }
+__device__ __forceinline__ void txt_put_uint(char *w, uint32_t x, int nd) { for (int i = nd - 1; i >= 0; --i) { w[i] = (char)('0' + x % 10); x /= 10; } }
+
+// ---- sizes: elements per chain, walk offsets of its vertices (lane per chain) ----
+__global__ void __launch_bounds__(64) k_text_count(int n_chain, const mga_txt_chain_t *__restrict__ chain, const mga_cigitem_t *__restrict__ item, const uint32_t *__restrict__ vert,
+												   const int32_t *__restrict__ seg_len, const int32_t *__restrict__ ncig, int32_t *__restrict__ n_el, int32_t *__restrict__ vwb)
+{
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= n_chain) return;
+	const mga_txt_chain_t C = chain[c];
+	int32_t n = 0, w = 0;
+	for (int64_t t = C.item_beg; t < C.item_end; ++t) { const mga_cigitem_t it = item[t]; n += it.op >= 0 ? 1 : ncig[C.prob_base + it.val]; }
+	n_el[c] = n;
+	for (int32_t k = 0; k < C.vert_cnt; ++k) {
+		const int32_t len = seg_len[vert[C.vert_beg + k] >> 1];
+		vwb[C.vert_beg + k] = w;
+		w += (k < C.vert_cnt - 1 ? len : C.ee) - (k > 0 ? 0 : C.ss);
+	}
+}
+
+// ds:Z entries of one run: returns their total length; WRITE: stores them at w (REV: from w + n backwards, each entry transformed)
+template<bool WRITE, bool REV> __device__ int32_t txt_ds_run(const txt_walk_t &W, const char *q, int32_t op, int32_t len, int32_t x, int32_t y, int32_t qs, int32_t qe, int32_t apl,
+															char *w, int32_t n_total)
+{
+	int32_t n = 0; // bytes produced so far
+#define TXT_PLACE(len_) (REV ? w + (n_total - n - (len_)) : w + n)
+	if (op == 7) { // byte-identical bases: one ":len" entry (the reference's base loop sees len equal codes, galign.c:228-243)
+		if (len > 0) { const int nd = txt_ndigits((uint32_t)len); if (WRITE) { char *p = TXT_PLACE(1 + nd); p[0] = ':'; txt_put_uint(p + 1, (uint32_t)len, nd); } n += 1 + nd; }
+	} else if (op == 0 || op == 8) {
+		int32_t l = 0;
+		for (int32_t z = 0; z <= len; ++z) {
+			unsigned char cx = 0, cy = 0;
+			const bool last = z == len;
+			if (!last) cx = c_txt.nt4[(unsigned char)walk_get(W, x + z)], cy = c_txt.nt4[(unsigned char)q[y + z]];
+			if (last || cx != cy) {
+				if (l > 0) { const int nd = txt_ndigits((uint32_t)l); if (WRITE) { char *p = TXT_PLACE(1 + nd); p[0] = ':'; txt_put_uint(p + 1, (uint32_t)l, nd); } n += 1 + nd; }
+				if (!last) {
+					if (WRITE) {
+						char *p = TXT_PLACE(3);
+						char c1 = "acgtn"[cx], c2 = "acgtn"[cy];
+						if (REV) c1 = (char)c_txt.comp[(unsigned char)c1], c2 = (char)c_txt.comp[(unsigned char)c2]; // format.c:225-226: same order, complemented
+						p[0] = '*', p[1] = c1, p[2] = c2;
+					}
+					n += 3;
+				}
+				l = 0;
+			} else ++l;
+		}
+	} else if (op == 1 || op == 2) { // micro-homology on either side (galign.c:229-249), then write_indel (galign.c:153-180)
+		const bool ins = op == 1;
+		int32_t z, ll, lr;
+		if (ins) {
+			for (z = 1; z <= len; ++z) if (y - z < qs || q[y + len - z] != q[y - z]) break;
+			lr = z - 1;
+			for (z = 0; z < len; ++z) if (y + len + z >= qe || q[y + len + z] != q[y + z]) break;
+			ll = z;
+		} else {
+			for (z = 1; z <= len; ++z) if (x - z < 0 || walk_get(W, x + len - z) != walk_get(W, x - z)) break;
+			lr = z - 1;
+			for (z = 0; z < len; ++z) if (x + len + z >= apl || walk_get(W, x + z) != walk_get(W, x + len + z)) break;
+			ll = z;
+		}
+		int32_t m = 1 + len;
+		if (ll + lr >= len) m += 2; else m += (ll > 0 ? 2 : 0) + (lr > 0 ? 2 : 0);
+		if (WRITE) {
+			char *p0 = TXT_PLACE(m), *p = p0;
+			*p++ = ins ? '+' : '-';
+#define TXT_B(i_) ("acgtn"[c_txt.nt4[(unsigned char)(ins ? q[y + (i_)] : walk_get(W, x + (i_)))]])
+			if (ll + lr >= len) {
+				*p++ = '[';
+				for (int32_t i = 0; i < len; ++i) *p++ = TXT_B(i);
+				*p++ = ']';
+			} else {
+				int32_t k = 0;
+				if (ll > 0) { *p++ = '['; for (int32_t i = 0; i < ll; ++i) *p++ = TXT_B(k + i); *p++ = ']'; k += ll; }
+				for (int32_t i = 0; i < len - lr - ll; ++i) *p++ = TXT_B(k + i);
+				k += len - lr - ll;
+				if (lr > 0) { *p++ = '['; for (int32_t i = 0; i < lr; ++i) *p++ = TXT_B(k + i); *p++ = ']'; }
+			}
+#undef TXT_B
+			if (REV) { // everything after the sign: reversed, complemented, brackets swapped (format.c:229-237)
+#define TXT_T(ch_) ((ch_) == '[' ? ']' : (ch_) == ']' ? '[' : (char)c_txt.comp[(unsigned char)(ch_)])
+				char *a = p0 + 1, *b = p0 + m - 1;
+				while (a < b) { const char ca = TXT_T(*a), cb = TXT_T(*b); *a++ = cb; *b-- = ca; }
+				if (a == b) *a = TXT_T(*a);
+#undef TXT_T
+			}
+		}
+		n += m;
+	}
+#undef TXT_PLACE
+	return n;
+}
+
+__device__ __forceinline__ int32_t wave_excl_scan(int32_t v, int lane, int32_t *total)
+{
+	int32_t x = v;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { const int32_t y = __shfl_up(x, d); if (lane >= d) x += y; }
+	*total = __shfl(x, 63);
+	return x - v;
+}
+__device__ __forceinline__ int32_t wave_sum(int32_t v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d); return v; }
+
+__global__ void __launch_bounds__(64) k_text(int n_chain, const mga_txt_chain_t *__restrict__ chain, const mga_cigitem_t *__restrict__ item, const uint32_t *__restrict__ vert,
+											 const int32_t *__restrict__ vwb, const char *__restrict__ gseq, const int64_t *__restrict__ gseq_off, const int32_t *__restrict__ seg_len,
+											 const char *__restrict__ reads, const int32_t *__restrict__ ncig, const int64_t *__restrict__ cigoff, const uint32_t *__restrict__ ord,
+											 const int64_t *__restrict__ el_off, uint32_t *__restrict__ el, uint32_t *__restrict__ run, int32_t *__restrict__ run_txt,
+											 mga_txt_res_t *__restrict__ res, char *__restrict__ pool, long long pool_cap, unsigned long long *pool_used)
+{
+	const int c = blockIdx.x, lane = threadIdx.x;
+	if (c >= n_chain) return;
+	const mga_txt_chain_t C = chain[c];
+	const int64_t eo = el_off[c];
+	const int32_t n_el = (int32_t)(el_off[c + 1] - eo);
+	uint32_t *E = el + eo, *R = run + eo; // elements / runs: len << 5 | mergeable << 4 | op
+	int32_t *RT = run_txt + 2 * eo;      // per run: cg piece length, ds entries length
+	const char *q = reads + C.q_base;
+	txt_walk_t W;
+	W.vert = vert + C.vert_beg, W.vwb = vwb + C.vert_beg, W.cnt = C.vert_cnt, W.ss = C.ss, W.gseq = gseq, W.gseq_off = gseq_off, W.seg_len = seg_len;
+
+	// ---- S1: concatenated operator list
+	{
+		int32_t base = 0;
+		for (int64_t tb = C.item_beg; tb < C.item_end; tb += 64) {
+			const int64_t t = tb + lane;
+			mga_cigitem_t it; it.op = 0, it.val = 0;
+			int32_t cnt = 0;
+			int64_t src = 0;
+			if (t < C.item_end) {
+				it = item[t];
+				if (it.op >= 0) cnt = 1; else { const int64_t pj = C.prob_base + it.val; cnt = ncig[pj]; src = cigoff[pj]; }
+			}
+			int32_t tot;
+			const int32_t o_l = wave_excl_scan(cnt, lane, &tot);
+			for (int32_t o0 = 0; o0 < tot; o0 += 64) { // uniform trip count: the shuffles need every lane
+				const int32_t o = o0 + lane;
+				int lo = 0;
+#pragma unroll
+				for (int step = 32; step > 0; step >>= 1) { const int32_t v = __shfl(o_l, lo + step); if (v <= o) lo += step; } // last item whose first slot is <= o (empty items share offsets)
+				const int32_t k = o - __shfl(o_l, lo), op_l = __shfl(it.op, lo), val_l = __shfl(it.val, lo);
+				const int64_t src_l = __shfl(src, lo);
+				if (o < tot) {
+					uint32_t e;
+					if (op_l >= 0) e = (uint32_t)val_l << 5 | 1u << 4 | (uint32_t)op_l;
+					else { const uint32_t cg = ord[src_l + k]; e = (cg >> 4) << 5 | (k == 0 ? 1u << 4 : 0u) | (cg & 0xf); }
+					E[base + o] = e;
+				}
+			}
+			base += tot;
+		}
+	}
+	for (int32_t i = lane; i < n_el; i += 64) R[i] = 0;
+	__threadfence_block();
+	__syncthreads();
+	// ---- S2: runs (append_cigar1 / append_cigar, galign.c:11-37)
+	int32_t n_run = 0;
+	{
+		int32_t carry_op = -1;
+		for (int32_t b0 = 0; b0 < n_el; b0 += 64) {
+			const int32_t i = b0 + lane;
+			const uint32_t e = i < n_el ? E[i] : 0;
+			const int32_t op = (int32_t)(e & 0xf);
+			int32_t prev = __shfl_up(op, 1);
+			if (lane == 0) prev = carry_op;
+			const bool head = i < n_el && !((e >> 4 & 1) && op == prev);
+			const uint64_t hm = __ballot(head);
+			const int32_t ridx = n_run + __popcll(hm & (mga_lanemask_lt() | (1ULL << lane))) - 1;
+			if (i < n_el) atomicAdd(&R[ridx], (e >> 5) << 5 | (head ? (uint32_t)op : 0u)); // lengths add up; the head contributes the operator bits
+			n_run += __popcll(hm);
+			const int last = (n_el - b0 < 64 ? n_el - b0 : 64) - 1;
+			carry_op = __shfl(op, last);
+		}
+	}
+	__threadfence_block();
+	__syncthreads();
+	// ---- S3: coordinates, statistics, text lengths per run
+	const int32_t apl = C.pe - C.ps;
+	int32_t mlen = 0, blen = 0, aplen = 0, qlen = 0, cg_n = 0, ds_n = 0;
+	for (int pass = 0; pass < 2; ++pass) {
+		int32_t x0 = 0, y0 = C.qs, cg0 = 0, ds0 = 0;
+		char *cg_base = 0, *ds_base = 0;
+		if (pass == 1) {
+			unsigned long long o = 0;
+			const unsigned long long need = (unsigned long long)cg_n + (unsigned long long)ds_n;
+			if (lane == 0) o = atomicAdd(pool_used, need);
+			o = __shfl(o, 0);
+			mga_txt_res_t r;
+			r.txt_off = (int64_t)o, r.cg_len = cg_n, r.ds_len = ds_n, r.n_cigar = n_run, r.mlen = mlen, r.blen = blen, r.aplen = aplen, r.pad = 0;
+			r.status = (qlen == C.qe - C.qs && aplen == apl) ? 0 : 1; // galign.c:140
+			if (r.status == 0 && (long long)(o + need) > pool_cap) r.status = 2;
+			if (lane == 0) res[c] = r;
+			if (r.status != 0) return;
+			cg_base = pool + o, ds_base = pool + o + cg_n;
+		}
+		for (int32_t b0 = 0; b0 < n_run; b0 += 64) {
+			const int32_t r = b0 + lane;
+			const uint32_t e = r < n_run ? R[r] : 0;
+			const int32_t op = (int32_t)(e & 0xf), len = (int32_t)(e >> 5);
+			const int32_t dx = r < n_run && op != 1 ? len : 0, dy = r < n_run && op != 2 ? len : 0;
+			int32_t tx, ty;
+			const int32_t x = x0 + wave_excl_scan(dx, lane, &tx), y = y0 + wave_excl_scan(dy, lane, &ty);
+			if (pass == 0) {
+				int32_t lc = 0, ld = 0;
+				if (r < n_run) {
+					lc = txt_ndigits((uint32_t)len) + 1;
+					ld = txt_ds_run<false, false>(W, q, op, len, x, y, C.qs, C.qe, apl, 0, 0);
+					RT[2 * r] = lc, RT[2 * r + 1] = ld;
+				}
+				mlen += wave_sum(r < n_run && op == 7 ? len : 0), blen += wave_sum(r < n_run ? len : 0);
+				aplen += tx, qlen += ty, cg_n += wave_sum(lc), ds_n += wave_sum(ld);
+			} else {
+				const int32_t lc = r < n_run ? RT[2 * r] : 0, ld = r < n_run ? RT[2 * r + 1] : 0;
+				int32_t tc, td;
+				const int32_t oc = cg0 + wave_excl_scan(lc, lane, &tc), od = ds0 + wave_excl_scan(ld, lane, &td);
+				if (r < n_run) {
+					char *wc = C.rev_sign ? cg_base + (cg_n - oc - lc) : cg_base + oc; // cg:Z piece: "<len><op>" (format.c:205-215)
+					txt_put_uint(wc, (uint32_t)len, lc - 1);
+					wc[lc - 1] = "MIDNSHP=XB"[op];
+					if (C.rev_sign) txt_ds_run<true, true>(W, q, op, len, x, y, C.qs, C.qe, apl, ds_base + (ds_n - od - ld), ld);
+					else txt_ds_run<true, false>(W, q, op, len, x, y, C.qs, C.qe, apl, ds_base + od, ld);
+				}
+				cg0 += tc, ds0 += td;
+			}
+			x0 += tx, y0 += ty;
+		}
+	}
+}
+
+extern "C" int mga_dev_text_tables(const unsigned char *comp, const unsigned char *nt4)
+{
+	txt_tables_t h;
+	memcpy(h.comp, comp, 256); memcpy(h.nt4, nt4, 256);
+	MGA_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_txt), &h, sizeof h));
+	return 0;
+}
+
+// scratch (grow-only, in the stream context): per chain element counts/offsets, per vertex walk offsets, per element 16 bytes
+extern "C" int mga_dev_text(mga_sctx_t *sc, int n_chain, const mga_txt_chain_t *d_chain, const mga_cigitem_t *d_item, int64_t n_vert, const uint32_t *d_vert,
+							const mga_didx_t *ix, const char *d_reads, int64_t n_el_max, const int32_t *d_ncig, const int64_t *d_cigoff, const uint32_t *d_ord,
+							mga_txt_res_t *d_res, char *d_pool, int64_t pool_cap, unsigned long long *d_pool_used)
+{
+	if (n_chain <= 0) return 0;
+	if (ix->d_gseq == 0) { mga_set_error("text kernel: the index holds no device copy of the graph sequences"); return -1; }
+	hipStream_t st = (hipStream_t)sc->stream;
+	if (mga_dbuf_reserve(&sc->txt_cnt, (size_t)(n_chain + 1) * 4) < 0 || mga_dbuf_reserve(&sc->txt_off, (size_t)(n_chain + 2) * 8) < 0 ||
+		mga_dbuf_reserve(&sc->txt_vwb, (size_t)(n_vert + 1) * 4) < 0 || mga_dbuf_reserve(&sc->txt_el, (size_t)(n_el_max + 64) * 16) < 0) return -1;
+	uint32_t *el = (uint32_t*)sc->txt_el.p, *run = el + (n_el_max + 64);
+	int32_t *run_txt = (int32_t*)(run + (n_el_max + 64));
+	mga_prof_begin(sc->stream, MGA_K_TEXT);
+	hipLaunchKernelGGL(k_text_count, dim3((n_chain + 63) / 64), dim3(64), 0, st, n_chain, d_chain, d_item, d_vert, (const int32_t*)ix->d_seg_len, d_ncig,
+					   (int32_t*)sc->txt_cnt.p, (int32_t*)sc->txt_vwb.p);
+	MGA_HIP_CHECK(hipGetLastError());
+	if (mga_dev_scan_i32_to_i64(sc, (const int32_t*)sc->txt_cnt.p, n_chain, (int64_t*)sc->txt_off.p) < 0) return -1;
+	hipLaunchKernelGGL(k_text, dim3(n_chain), dim3(64), 0, st, n_chain, d_chain, d_item, d_vert, (const int32_t*)sc->txt_vwb.p, (const char*)ix->d_gseq,
+					   (const int64_t*)ix->d_gseq_off, (const int32_t*)ix->d_seg_len, d_reads, d_ncig, d_cigoff, d_ord, (const int64_t*)sc->txt_off.p,
+					   el, run, run_txt, d_res, d_pool, (long long)pool_cap, d_pool_used);
+	mga_prof_end(sc->stream, MGA_K_TEXT);
+	MGA_HIP_CHECK(hipGetLastError());
+	return 0;
+}

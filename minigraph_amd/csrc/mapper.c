@@ -41,6 +41,7 @@ typedef struct {
 	int32_t tid;          /* pool that holds this read's plan */
 	int32_t n_gc;
 	int64_t *item_off;    /* n_gc + 1 offsets into the pool's item[] */
+	int64_t *chain_id;    /* text mode: per chain, its index in the pool's chain[] (-1: not printed) */
 } read_plan_t;
 
 struct mga_batch_s {
@@ -54,7 +55,10 @@ struct mga_batch_s {
 	mg_gchains_t **gcs;
 	read_plan_t *plan;
 	mga_tpool_t *tp;
-	int64_t *tp_prob_base, *tp_t_base;
+	int64_t *tp_prob_base, *tp_t_base, *tp_item_base, *tp_chain_base, *tp_vert_base;
+	int want_text;          /* the caller only wants GAF bytes: cg:Z / ds:Z come from the device (k_text.hip) */
+	const mga_txt_res_t *txt_res; /* text-mode results, global chain order */
+	const char *txt_pool;
 	/* stage-1 inputs, valid during mga_batch_chain() only */
 	const int32_t *n_mz, *rep_len, *mini_pos, *nu, *nb;
 	const int64_t *mini_off, *a_off;
@@ -81,6 +85,9 @@ mga_batch_t *mga_batch_init(const mg_idx_t *gi, const mg_mapopt_t *opt, int n, c
 	b->tp = MGA_CALLOC(mga_tpool_t, b->n_threads);
 	b->tp_prob_base = MGA_CALLOC(int64_t, b->n_threads + 1);
 	b->tp_t_base = MGA_CALLOC(int64_t, b->n_threads + 1);
+	b->tp_item_base = MGA_CALLOC(int64_t, b->n_threads + 1);
+	b->tp_chain_base = MGA_CALLOC(int64_t, b->n_threads + 1);
+	b->tp_vert_base = MGA_CALLOC(int64_t, b->n_threads + 1);
 	return b;
 }
 
@@ -176,10 +183,36 @@ do_rescue:;
 		read_plan_t *pl = &b->plan[i];
 		mga_tpool_t *tp = &b->tp[tid];
 		pl->tid = tid, pl->n_gc = gcs->n_gc;
+		int rev_sign = 0; /* carried from chain to chain like mg_write_gaf does (format.c:123) */
 		pl->item_off = MGA_MALLOC(int64_t, gcs->n_gc + 1);
+		if (b->want_text) pl->chain_id = MGA_MALLOC(int64_t, gcs->n_gc > 0 ? gcs->n_gc : 1);
 		for (k = 0; k < gcs->n_gc; ++k) {
+			const mg_gchain_t *gc = &gcs->gc[k];
 			pl->item_off[k] = tp->n_item;
+			if (b->want_text) {
+				pl->chain_id[k] = -1;
+				if ((gc->id != gc->parent && !(opt->flag & MG_M_PRINT_2ND)) || gc->cnt == 0) continue; /* not printed (format.c:135-136): no alignment needed */
+			}
 			mga_plan_cigar(gi->g, gi->es, gcs, k, b->q_off ? b->q_off[i] : 0, tp);
+			if (b->want_text) { /* what the text kernel needs to know about this chain */
+				mga_txt_chain_t *c;
+				const int32_t off_a0 = gcs->lc[gc->off].off;
+				int32_t j;
+				if (mga_gaf_chain_rev(gi->g, gcs, gc, opt->flag)) rev_sign = 1;
+				MGA_GROW(mga_txt_chain_t, tp->chain, tp->n_chain, tp->m_chain);
+				c = &tp->chain[tp->n_chain];
+				c->item_beg = pl->item_off[k], c->item_end = tp->n_item, c->prob_base = 0, c->q_base = b->q_off ? b->q_off[i] : 0;
+				c->vert_beg = tp->n_vert, c->vert_cnt = gc->cnt;
+				c->qs = gc->qs, c->qe = gc->qe, c->ps = gc->ps, c->pe = gc->pe;
+				c->ss = (int32_t)gcs->a[off_a0].x + 1 - (int32_t)(gcs->a[off_a0].y >> 32 & 0xff); /* galign.c:128-129 */
+				c->ee = (int32_t)gcs->a[off_a0 + gc->n_anchor - 1].x + 1;
+				c->rev_sign = rev_sign;
+				for (j = 0; j < gc->cnt; ++j) {
+					MGA_GROW(uint32_t, tp->vert, tp->n_vert, tp->m_vert);
+					tp->vert[tp->n_vert++] = gcs->lc[gc->off + j].v;
+				}
+				pl->chain_id[k] = tp->n_chain++;
+			}
 		}
 		pl->item_off[gcs->n_gc] = tp->n_item;
 		CPU_ADD(C_PLAN, tc);
@@ -197,6 +230,9 @@ int mga_batch_chain(mga_batch_t *b, const int32_t *n_mz, const int32_t *rep_len,
 	for (t = 0; t < b->n_threads; ++t) {
 		b->tp_prob_base[t + 1] = b->tp_prob_base[t] + b->tp[t].n_prob;
 		b->tp_t_base[t + 1] = b->tp_t_base[t] + b->tp[t].n_t;
+		b->tp_item_base[t + 1] = b->tp_item_base[t] + b->tp[t].n_item;
+		b->tp_chain_base[t + 1] = b->tp_chain_base[t] + b->tp[t].n_chain;
+		b->tp_vert_base[t + 1] = b->tp_vert_base[t] + b->tp[t].n_vert;
 	}
 	return 0;
 }
@@ -226,6 +262,33 @@ void mga_batch_wfa_export(const mga_batch_t *b, mga_wfa_prob_t *prob, char *tseq
 	export_t e;
 	e.b = b, e.prob = prob, e.tseq = tseq;
 	mga_parallel_for(b->n_threads, b->n_threads, export_worker, &e);
+}
+
+/* text mode: plan items, printed chains and their vertices of all pools, flattened in pool order with global offsets */
+int64_t mga_batch_n_items(const mga_batch_t *b) { return b->tp_item_base[b->n_threads]; }
+int64_t mga_batch_n_chains(const mga_batch_t *b) { return b->tp_chain_base[b->n_threads]; }
+int64_t mga_batch_n_verts(const mga_batch_t *b) { return b->tp_vert_base[b->n_threads]; }
+typedef struct { const mga_batch_t *b; mga_cigitem_t *item; mga_txt_chain_t *chain; uint32_t *vert; } texport_t;
+static void text_export_worker(void *data, int64_t t, int tid)
+{
+	texport_t *e = (texport_t*)data;
+	const mga_batch_t *b = e->b;
+	const mga_tpool_t *tp = &b->tp[t];
+	int64_t j;
+	(void)tid;
+	memcpy(e->item + b->tp_item_base[t], tp->item, (size_t)tp->n_item * sizeof(mga_cigitem_t));
+	memcpy(e->vert + b->tp_vert_base[t], tp->vert, (size_t)tp->n_vert * 4);
+	for (j = 0; j < tp->n_chain; ++j) {
+		mga_txt_chain_t *c = &e->chain[b->tp_chain_base[t] + j];
+		*c = tp->chain[j];
+		c->item_beg += b->tp_item_base[t], c->item_end += b->tp_item_base[t], c->vert_beg += b->tp_vert_base[t], c->prob_base = b->tp_prob_base[t];
+	}
+}
+void mga_batch_text_export(const mga_batch_t *b, mga_cigitem_t *item, mga_txt_chain_t *chain, uint32_t *vert)
+{
+	texport_t e;
+	e.b = b, e.item = item, e.chain = chain, e.vert = vert;
+	mga_parallel_for(b->n_threads, b->n_threads, text_export_worker, &e);
 }
 
 static void finish_worker(void *data, int64_t i, int tid)
@@ -287,11 +350,54 @@ void mga_batch_destroy(mga_batch_t *b)
 {
 	int i;
 	if (b == 0) return;
-	for (i = 0; i < b->n; ++i) free(b->plan[i].item_off);
-	for (i = 0; i < b->n_threads; ++i) { free(b->tp[i].tseq); free(b->tp[i].prob); free(b->tp[i].item); }
+	for (i = 0; i < b->n; ++i) { free(b->plan[i].item_off); free(b->plan[i].chain_id); }
+	for (i = 0; i < b->n_threads; ++i) { free(b->tp[i].tseq); free(b->tp[i].prob); free(b->tp[i].item); free(b->tp[i].chain); free(b->tp[i].vert); }
 	if (b->gcs) { for (i = 0; i < b->n; ++i) mg_gchain_free(b->gcs[i]); free(b->gcs); }
-	free(b->plan); free(b->tp); free(b->tp_prob_base); free(b->tp_t_base);
+	free(b->plan); free(b->tp); free(b->tp_prob_base); free(b->tp_t_base); free(b->tp_item_base); free(b->tp_chain_base); free(b->tp_vert_base);
 	free(b);
+}
+
+/* GAF text of one chunk: T pieces in read order; in text mode cg:Z / ds:Z are copied from the device's output */
+typedef struct { mga_batch_t *b; int n, T; kstring_t *part; } gafw_t;
+
+static void gaf_worker(void *data, int64_t t, int tid)
+{
+	gafw_t *w = (gafw_t*)data;
+	mga_batch_t *bt = w->b;
+	const int n = w->n;
+	int64_t b = (int64_t)n * t / w->T, e = (int64_t)n * (t + 1) / w->T, i;
+	kstring_t *out = &w->part[t];
+	mga_chain_text_t *txt = 0;
+	int32_t m_txt = 0;
+	int64_t tc = cpu_now();
+	(void)tid;
+	{ /* one allocation per piece: a base-aligned read prints about one byte per base (cg + ds), an unaligned one ~120 bytes */
+		size_t est = 4096;
+		for (i = b; i < e; ++i) est += (bt->opt.flag & MG_M_CIGAR) ? (size_t)bt->qlens[i] + 512 : 512;
+		if (est < 0xfffffff0u && est > out->m) { out->m = (unsigned)est; out->s = (char*)realloc(out->s, out->m); }
+	}
+	for (i = b; i < e; ++i) {
+		int32_t ql = bt->qlens[i], k;
+		const mg_gchains_t *gcs = bt->gcs[i];
+		const read_plan_t *pl = &bt->plan[i];
+		const mga_chain_text_t *tx = 0;
+		if (bt->txt_res && gcs && pl->chain_id) {
+			if (gcs->n_gc > m_txt) { m_txt = gcs->n_gc + 8; txt = MGA_REALLOC(mga_chain_text_t, txt, m_txt); }
+			for (k = 0; k < gcs->n_gc; ++k) {
+				txt[k].cg = txt[k].ds = 0;
+				if (pl->chain_id[k] >= 0) {
+					const mga_txt_res_t *r = &bt->txt_res[bt->tp_chain_base[pl->tid] + pl->chain_id[k]];
+					txt[k].cg = bt->txt_pool + r->txt_off, txt[k].ds = txt[k].cg + r->cg_len;
+					txt[k].cg_len = r->cg_len, txt[k].ds_len = r->ds_len, txt[k].mlen = r->mlen, txt[k].blen = r->blen;
+				}
+			}
+			tx = txt;
+		}
+		mga_write_gaf_append(out, bt->gi->g, gcs, 1, &ql, bt->qnames ? bt->qnames[i] : "*", bt->opt.flag, tx);
+		mg_gchain_free(bt->gcs[i]); bt->gcs[i] = 0;
+	}
+	free(txt);
+	CPU_ADD(C_GAF, tc);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -307,8 +413,8 @@ void mga_batch_destroy(mga_batch_t *b)
 typedef struct {
 	mga_sctx_t *sc;
 	mga_dbuf_t seq, qoff, cnt, mzoff, mz, occ, val, na, nmini, rep, aoff, minioff, a, tmp, mini, u, b, nu, nb, ws;
-	mga_dbuf_t tseq, prob, res, pool, used, ncig, cigoff, ord, rflag;
-	mga_hbuf_t h_b, h_u, h_mini, h_tseq, h_prob, h_pool, h_seq, h_ncig, h_cigoff; /* pinned staging */
+	mga_dbuf_t tseq, prob, res, pool, used, ncig, cigoff, ord, rflag, item, chain, vert, txtres, txtpool;
+	mga_hbuf_t h_b, h_u, h_mini, h_tseq, h_prob, h_pool, h_seq, h_ncig, h_cigoff, h_item, h_chain, h_vert, h_txtres, h_txtpool; /* pinned staging */
 } pipe_ctx_t;
 
 #define MGA_MAX_PIPE 4
@@ -331,7 +437,7 @@ static int env_int(const char *name, int dflt) { const char *s = getenv(name); r
 #define CK(x) do { if ((x) < 0) { rc = -1; goto done; } } while (0)
 
 static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs_out,
-					 const mg_mapopt_t *opt, int n_threads, const char *d_seq_res, const int64_t *q_off_res, mga_stats_t *st)
+					 const mg_mapopt_t *opt, int n_threads, const char *d_seq_res, const int64_t *q_off_res, mga_stats_t *st, kstring_t *gaf_part)
 {
 	struct mg_idx_bucket_s *B = gi->B;
 	mga_sctx_t *sc = P->sc;
@@ -436,6 +542,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	t1 = mga_wtime(); st->t_lchain += t1 - t0; t0 = t1;
 	/* ---- host: graph chaining + gap list ---- */
 	b = mga_batch_init(gi, opt, n, qlens, seqs, qnames, q_off, n_threads);
+	b->want_text = gaf_part != 0 && (opt->flag & MG_M_CIGAR) && B->dev.d_gseq != 0 && !env_int("MGA_HOST_TEXT", 0); /* only GAF bytes are wanted: cg/ds come from the device */
 	CK(mga_batch_chain(b, h_nmz, h_rep, (const int32_t*)P->h_mini.p, h_minioff, h_nu, h_nb, (const uint64_t*)P->h_u.p, (const mg128_t*)P->h_b.p, h_aoff, is_rmq, h_rflag));
 	if (g_dbg_pipe > 1) PIPE_LOG(" hostchain", n, t0);
 	t1 = mga_wtime(); st->t_host_chain += t1 - t0; t0 = t1;
@@ -460,26 +567,61 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 		/* the tier ladder runs on the device (k_wfa_sched.hip); the host never walks the problems */
 		CK(mga_dev_wfa_solve(sc, (int)n_prob, (const mga_wfa_prob_t*)P->prob.p, (const char*)P->tseq.p, d_seq, (mga_wfa_res_t*)P->res.p,
 							 (uint32_t*)P->pool.p, pool_cap, (unsigned long long*)P->used.p, &cells));
-		{ /* CIGARs back in problem order (one sequential stream for the stitching threads), then to the host */
+		{ /* CIGARs back in problem order: one sequential stream for the host's stitching threads, or the input of the text kernel */
 			int64_t n_ops = 0;
 			CK(mga_dbuf_reserve(&P->ncig, (size_t)n_prob * 4 + 16)); CK(mga_dbuf_reserve(&P->cigoff, (size_t)(n_prob + 1) * 8)); CK(mga_dbuf_reserve(&P->ord, (size_t)pool_cap * 4));
 			CK(mga_dev_wfa_gather(sc, (int)n_prob, (const mga_wfa_res_t*)P->res.p, (const uint32_t*)P->pool.p, (int32_t*)P->ncig.p, (int64_t*)P->cigoff.p,
 								  (uint32_t*)P->ord.p, pool_cap, &n_ops));
-			GPU_RELEASE(); /* the gather kernel and the downloads trail on this chunk's stream while the next chunk's kernels start */
-			CK(mga_hbuf_reserve(&P->h_ncig, (size_t)n_prob * 4 + 16)); CK(mga_hbuf_reserve(&P->h_cigoff, (size_t)(n_prob + 1) * 8)); CK(mga_hbuf_reserve(&P->h_pool, (size_t)n_ops * 4 + 16));
-			CK(mga_d2h_s(sc, P->h_ncig.p, P->ncig.p, (size_t)n_prob * 4)); CK(mga_d2h_s(sc, P->h_cigoff.p, P->cigoff.p, (size_t)(n_prob + 1) * 8));
-			CK(mga_d2h_s(sc, P->h_pool.p, P->ord.p, (size_t)n_ops * 4)); CK(mga_ssync(sc));
+			GPU_RELEASE(); /* the gather kernel and what follows trail on this chunk's stream while the next chunk's kernels start */
+			if (b->want_text) { /* stitching, statistics, cg:Z and ds:Z on the device (k_text.hip): one lane per printed chain */
+				const int64_t n_item = mga_batch_n_items(b), n_chain = mga_batch_n_chains(b), n_vert = mga_batch_n_verts(b);
+				int64_t txt_cap = 4096, k;
+				unsigned long long txt_used = 0;
+				for (k = 0; k < n; ++k) txt_cap += 3 * (int64_t)qlens[k] + 1024;
+				CK(mga_hbuf_reserve(&P->h_item, (size_t)n_item * sizeof(mga_cigitem_t) + 16)); CK(mga_hbuf_reserve(&P->h_chain, (size_t)n_chain * sizeof(mga_txt_chain_t) + 16));
+				CK(mga_hbuf_reserve(&P->h_vert, (size_t)n_vert * 4 + 16));
+				mga_batch_text_export(b, (mga_cigitem_t*)P->h_item.p, (mga_txt_chain_t*)P->h_chain.p, (uint32_t*)P->h_vert.p);
+				CK(mga_dbuf_reserve(&P->item, (size_t)n_item * sizeof(mga_cigitem_t) + 16)); CK(mga_dbuf_reserve(&P->chain, (size_t)n_chain * sizeof(mga_txt_chain_t) + 16));
+				CK(mga_dbuf_reserve(&P->vert, (size_t)n_vert * 4 + 16)); CK(mga_dbuf_reserve(&P->txtres, (size_t)n_chain * sizeof(mga_txt_res_t) + 16));
+				CK(mga_dbuf_reserve(&P->txtpool, (size_t)txt_cap)); CK(mga_dmemset_s(sc, P->used.p, 0, 8));
+				CK(mga_h2d_s(sc, P->item.p, P->h_item.p, (size_t)n_item * sizeof(mga_cigitem_t))); CK(mga_h2d_s(sc, P->chain.p, P->h_chain.p, (size_t)n_chain * sizeof(mga_txt_chain_t)));
+				CK(mga_h2d_s(sc, P->vert.p, P->h_vert.p, (size_t)n_vert * 4));
+				CK(mga_dev_text(sc, (int)n_chain, (const mga_txt_chain_t*)P->chain.p, (const mga_cigitem_t*)P->item.p, n_vert, (const uint32_t*)P->vert.p, &B->dev, d_seq,
+								n_item + n_ops, (const int32_t*)P->ncig.p, (const int64_t*)P->cigoff.p, (const uint32_t*)P->ord.p, (mga_txt_res_t*)P->txtres.p,
+								(char*)P->txtpool.p, txt_cap, (unsigned long long*)P->used.p));
+				CK(mga_d2h_s(sc, &txt_used, P->used.p, 8)); CK(mga_ssync(sc));
+				if ((int64_t)txt_used > txt_cap) { mga_set_error("text kernel: output of %lld bytes exceeds the pool of %lld", (long long)txt_used, (long long)txt_cap); rc = -1; goto done; }
+				CK(mga_hbuf_reserve(&P->h_txtres, (size_t)n_chain * sizeof(mga_txt_res_t) + 16)); CK(mga_hbuf_reserve(&P->h_txtpool, (size_t)txt_used + 16));
+				CK(mga_d2h_s(sc, P->h_txtres.p, P->txtres.p, (size_t)n_chain * sizeof(mga_txt_res_t))); CK(mga_d2h_s(sc, P->h_txtpool.p, P->txtpool.p, (size_t)txt_used));
+				CK(mga_ssync(sc));
+				for (k = 0; k < n_chain; ++k)
+					if (((const mga_txt_res_t*)P->h_txtres.p)[k].status != 0) { mga_set_error("text kernel: stitched CIGAR inconsistent with the chain coordinates (galign.c:140), chain %ld", (long)k); rc = -1; goto done; }
+				b->txt_res = (const mga_txt_res_t*)P->h_txtres.p, b->txt_pool = (const char*)P->h_txtpool.p;
+			} else {
+				CK(mga_hbuf_reserve(&P->h_ncig, (size_t)n_prob * 4 + 16)); CK(mga_hbuf_reserve(&P->h_cigoff, (size_t)(n_prob + 1) * 8)); CK(mga_hbuf_reserve(&P->h_pool, (size_t)n_ops * 4 + 16));
+				CK(mga_d2h_s(sc, P->h_ncig.p, P->ncig.p, (size_t)n_prob * 4)); CK(mga_d2h_s(sc, P->h_cigoff.p, P->cigoff.p, (size_t)(n_prob + 1) * 8));
+				CK(mga_d2h_s(sc, P->h_pool.p, P->ord.p, (size_t)n_ops * 4)); CK(mga_ssync(sc));
+			}
 		}
 		st->wfa_cells += cells;
 	}
 	if (g_dbg_pipe > 1) PIPE_LOG(" wfa", n, t0);
 	t1 = mga_wtime(); st->t_wfa += t1 - t0; t0 = t1;
 	/* ---- host: CIGAR stitching + ds ---- */
-	if ((opt->flag & MG_M_CIGAR) && n_prob > 0) CK(mga_batch_finish_ordered(b, (const int32_t*)P->h_ncig.p, (const int64_t*)P->h_cigoff.p, (const uint32_t*)P->h_pool.p));
+	if (b->txt_res) {} /* nothing to stitch on the host: the GAF writer copies the device's text */
+	else if ((opt->flag & MG_M_CIGAR) && n_prob > 0) CK(mga_batch_finish_ordered(b, (const int32_t*)P->h_ncig.p, (const int64_t*)P->h_cigoff.p, (const uint32_t*)P->h_pool.p));
 	else CK(mga_batch_finish(b, 0, 0));
 	if (g_dbg_pipe > 1) PIPE_LOG(" hostpost", n, t0);
 	t1 = mga_wtime(); st->t_host_post += t1 - t0;
-	{
+	if (gaf_part) { /* GAF text of this chunk, formatted while other chunks own the GPU; the chains are freed on the way */
+		gafw_t w;
+		double tg = mga_wtime();
+		w.b = b, w.n = n, w.T = n_threads, w.part = gaf_part;
+		mga_parallel_for(n_threads, n_threads, gaf_worker, &w);
+		for (i = 0; i < n; ++i) gcs_out[i] = 0;
+		if (g_dbg_pipe > 1) PIPE_LOG(" gaf", n, tg);
+		st->t_gaf += mga_wtime() - tg;
+	} else {
 		mg_gchains_t **r = mga_batch_take_results(b);
 		for (i = 0; i < n; ++i) gcs_out[i] = r[i];
 		free(r);
@@ -516,25 +658,6 @@ typedef struct {
 } pipe_job_t;
 
 typedef struct { pipe_job_t *job; pipe_ctx_t *P; mga_stats_t st; } pipe_thr_t;
-
-typedef struct { pipe_job_t *J; int st, en, T; kstring_t *part; } gafw_t;
-
-static void gaf_worker(void *data, int64_t t, int tid)
-{
-	gafw_t *w = (gafw_t*)data;
-	pipe_job_t *J = w->J;
-	const int n = w->en - w->st;
-	int64_t b = w->st + (int64_t)n * t / w->T, e = w->st + (int64_t)n * (t + 1) / w->T, i;
-	kstring_t *out = &w->part[t];
-	int64_t tc = cpu_now();
-	(void)tid;
-	for (i = b; i < e; ++i) {
-		int32_t ql = J->qlens[i];
-		mga_write_gaf_append(out, J->gi->g, J->gcs[i], 1, &ql, J->qnames ? J->qnames[i] : "*", J->opt->flag);
-		mg_gchain_free(J->gcs[i]); J->gcs[i] = 0;
-	}
-	CPU_ADD(C_GAF, tc);
-}
 
 typedef struct { kstring_t *part; int64_t *off; char *dst; } gcopy_t;
 static void gaf_copy_worker(void *data, int64_t i, int tid) { gcopy_t *g = (gcopy_t*)data; (void)tid; if (g->part[i].l) memcpy(g->dst + g->off[i], g->part[i].s, g->part[i].l); free(g->part[i].s); g->part[i].s = 0; }
@@ -575,21 +698,17 @@ static void *pipe_worker(void *a)
 		en = st + J->chunk < J->n ? st + J->chunk : J->n;
 		double tc = mga_wtime();
 		if (map_chunk(t->P, J->gi, en - st, J->qlens + st, J->seqs + st, J->qnames ? J->qnames + st : 0, J->gcs + st, J->opt, J->n_threads,
-					  J->d_seq, J->q_off ? J->q_off + st : 0, &t->st) < 0) {
+					  J->d_seq, J->q_off ? J->q_off + st : 0, &t->st, J->gaf_part ? J->gaf_part + (size_t)c * J->n_threads : 0) < 0) {
 			pthread_mutex_lock(&J->mtx);
 			if (!J->err) { J->err = 1; snprintf(J->errmsg, sizeof J->errmsg, "%s", mga_last_error()); }
 			pthread_mutex_unlock(&J->mtx);
 			break;
 		}
 		PIPE_LOG("map_chunk", c, tc);
-		if (J->gaf_part) { /* GAF text of this chunk, formatted while the other pipeline thread owns the GPU */
-			gafw_t w;
+		if (J->gaf_part) { /* the chunk's GAF text was formatted inside map_chunk(); append it to the output in read order */
 			double t0 = mga_wtime();
-			w.J = J, w.st = st, w.en = en, w.T = J->n_threads, w.part = J->gaf_part + (size_t)c * J->n_threads;
-			mga_parallel_for(J->n_threads, J->n_threads, gaf_worker, &w);
 			commit_chunks(J, c);
 			t->st.t_gaf += mga_wtime() - t0;
-			PIPE_LOG("gaf", c, t0);
 		}
 	}
 	return 0;

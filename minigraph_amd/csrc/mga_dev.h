@@ -38,6 +38,7 @@ typedef struct mga_sctx_s {
 	mga_dbuf_t wfa_ws[8];      /* per-tier WFA workspaces */
 	mga_dbuf_t wfa_cnt;        /* work-queue counters, one 64-byte line per tier */
 	mga_dbuf_t scan_tmp;       /* tile sums of mga_dev_scan_i32_to_i64 */
+	mga_dbuf_t txt_cnt, txt_off, txt_vwb, txt_el; /* text kernel scratch (k_text.hip) */
 	mga_dbuf_t wfa_list[2], wfa_key, wfa_ctl; /* tier scheduler (k_wfa_sched.hip): double-buffered work lists, sort keys, counters */
 	void *tier_stream[8];      /* WFA tiers run concurrently on their own streams (long-tailed wide problems next to the small ones) */
 	void *ev_ready, *ev_done[8];
@@ -59,7 +60,7 @@ int  mga_hbuf_reserve(mga_hbuf_t *b, size_t bytes);
 void mga_hbuf_free(mga_hbuf_t *b);
 
 /* per-kernel HIP-event timing on the launch stream (bench.py reads it through mga_prof_get) */
-enum { MGA_K_SKETCH = 0, MGA_K_SEED_COUNT, MGA_K_SEED_FILL, MGA_K_LCHAIN, MGA_K_WFA0 /* +tier: 0-1 single-wave register tiers (band 64,128), 2-5 multi-wave register tiers (256..2048), 6-7 HBM tiers */, MGA_K_SCAN = MGA_K_WFA0 + 8, MGA_K_N };
+enum { MGA_K_SKETCH = 0, MGA_K_SEED_COUNT, MGA_K_SEED_FILL, MGA_K_LCHAIN, MGA_K_WFA0 /* +tier: 0-1 single-wave register tiers (band 64,128), 2-5 multi-wave register tiers (256..2048), 6-7 HBM tiers */, MGA_K_SCAN = MGA_K_WFA0 + 8, MGA_K_TEXT, MGA_K_N };
 #define MGA_WFA_N_TIER 8
 void mga_prof_enable(int on);
 void mga_prof_begin(void *stream, int kid);
@@ -86,6 +87,8 @@ typedef struct {
 	uint64_t *d_pos;         /* position lists, each ascending */
 	int64_t n_pos;
 	int32_t *d_seg_len;      /* n_seg segment lengths */
+	char *d_gseq;            /* forward segment sequences back to back (text kernel: target bases of ds:Z) */
+	int64_t *d_gseq_off;     /* n_seg + 1 offsets into d_gseq */
 } mga_didx_t;
 
 /* collect_matches (map-algo.c:58-91), pass 1: probe every minimizer.  Flat per-minimizer outputs
@@ -136,6 +139,24 @@ int mga_dev_wfa_tier(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa
  * d_res[i] / d_pool hold the results; *cells (optional) = total wavefront cells */
 int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 					  mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int64_t *cells);
+
+/* ---- alignment text on the device (k_text.hip): stitched CIGAR statistics + cg:Z / ds:Z strings of a chain ---- */
+typedef struct { int32_t op, val; } mga_cigitem_t; /* op >= 0: ready operator (op, len = val); op == -1: WFA problem #val of this read's pool */
+typedef struct {
+	int64_t item_beg, item_end;   /* plan items of the chain */
+	int64_t prob_base;            /* global index of problem 0 of the pool the items refer to */
+	int64_t q_base;               /* offset of the read in the resident read buffer */
+	int64_t vert_beg;             /* oriented vertices of the walk */
+	int32_t vert_cnt;
+	int32_t qs, qe, ss, ee, ps, pe;
+	int32_t rev_sign;             /* the line is printed on the reverse strand (format.c:123,183) */
+} mga_txt_chain_t;
+typedef struct { int64_t txt_off; int32_t cg_len, ds_len, n_cigar, mlen, blen, aplen, status, pad; } mga_txt_res_t; /* text = pool + txt_off: cg then ds */
+int mga_dev_text_tables(const unsigned char *comp, const unsigned char *nt4); /* once: IUPAC complement + nt4 code tables to constant memory */
+/* n_el_max: upper bound on the operators of all chains before merging (plan items + operators of all WFA CIGARs) */
+int mga_dev_text(mga_sctx_t *sc, int n_chain, const mga_txt_chain_t *d_chain, const mga_cigitem_t *d_item, int64_t n_vert, const uint32_t *d_vert,
+				 const mga_didx_t *ix, const char *d_reads, int64_t n_el_max, const int32_t *d_ncig, const int64_t *d_cigoff, const uint32_t *d_ord,
+				 mga_txt_res_t *d_res, char *d_pool, int64_t pool_cap, unsigned long long *d_pool_used);
 
 /* CIGARs of all problems copied into problem order: d_ncig[i] operators at d_ord + d_off[i] (d_off has n+1 entries); *h_total = d_off[n] */
 int mga_dev_wfa_gather(mga_sctx_t *sc, int n, const mga_wfa_res_t *d_res, const uint32_t *d_pool, int32_t *d_ncig, int64_t *d_off, uint32_t *d_ord,

@@ -66,7 +66,10 @@ struct mg_idx_bucket_s {
 	int64_t gaf_cap;
 };
 
-void mga_write_gaf_append(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, int32_t n_seg, const int32_t *qlens, const char *qname, uint64_t flag);
+typedef struct { const char *cg, *ds; int32_t cg_len, ds_len, mlen, blen; } mga_chain_text_t; /* cg == NULL: format from the chain itself */
+void mga_write_gaf_append(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, int32_t n_seg, const int32_t *qlens, const char *qname, uint64_t flag,
+						  const mga_chain_text_t *txt);
+int mga_gaf_chain_rev(const gfa_t *g, const mg_gchains_t *gs, const mg_gchain_t *p, uint64_t flag);
 mg_idx_t *mga_idx_hostpart(gfa_t *g, const mg_idxopt_t *io);
 
 /* ---- simple parallel-for over [0,n) on n_threads pthreads, dynamic chunks (par.c) ---- */
