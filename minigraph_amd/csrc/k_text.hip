@@ -291,8 +291,10 @@ extern "C" int mga_dev_text(mga_sctx_t *sc, int n_chain, const mga_txt_chain_t *
 	mga_prof_begin(sc->stream, MGA_K_TEXT);
 	hipLaunchKernelGGL(k_text_count, dim3((n_chain + 63) / 64), dim3(64), 0, st, n_chain, d_chain, d_item, d_vert, (const int32_t*)ix->d_seg_len, d_ncig,
 					   (int32_t*)sc->txt_cnt.p, (int32_t*)sc->txt_vwb.p);
+	mga_prof_end(sc->stream, MGA_K_TEXT);
 	MGA_HIP_CHECK(hipGetLastError());
 	if (mga_dev_scan_i32_to_i64(sc, (const int32_t*)sc->txt_cnt.p, n_chain, (int64_t*)sc->txt_off.p) < 0) return -1;
+	mga_prof_begin(sc->stream, MGA_K_TEXT);
 	hipLaunchKernelGGL(k_text, dim3(n_chain), dim3(64), 0, st, n_chain, d_chain, d_item, d_vert, (const int32_t*)sc->txt_vwb.p, (const char*)ix->d_gseq,
 					   (const int64_t*)ix->d_gseq_off, (const int32_t*)ix->d_seg_len, d_reads, d_ncig, d_cigoff, d_ord, (const int64_t*)sc->txt_off.p,
 					   el, run, run_txt, d_res, d_pool, (long long)pool_cap, d_pool_used);

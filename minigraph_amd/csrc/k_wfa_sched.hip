@@ -17,22 +17,31 @@
 #define WFS_NBIN (MGA_WFA_N_TIER * 1024)
 
 // the band of a 10%-error gap is about as wide as the gap is long ([measured] on the benchmark workload:
-// mean length 76 -> mean score 40 -> band 81), so start where a band of ~1.1x the length fits
-__host__ __device__ __forceinline__ int wfs_first_tier(int32_t tl, int32_t ql)
+// mean length 76 -> mean score 40 -> band 81), so start where a band equal to the length fits: [measured] 2-5 % of the
+// problems then outgrow their tier and are re-run one tier up, which is cheaper than starting everything wider
+struct wfs_thr_t { int32_t t[6]; };
+__host__ __device__ __forceinline__ int wfs_first_tier_thr(int32_t tl, int32_t ql, const wfs_thr_t &T)
 {
 	const int32_t m = tl > ql ? tl : ql;
-	if (m <= 56) return 0;
-	if (m <= 112) return 1;
-	if (m <= 224) return 2;
-	if (m <= 450) return 3;
-	if (m <= 2048) return 4;
-	if (m <= 4096) return 5;
+	for (int k = 0; k < 6; ++k) if (m <= T.t[k]) return k;
 	return 6;
 }
+static wfs_thr_t wfs_thresholds(void)
+{
+	static wfs_thr_t T = { { 64, 128, 256, 512, 2048, 4096 } };
+	static int init = 0;
+	if (!init) { // MGA_WFA_THR="a,b,c,d": first-tier length limits of the 64/128/256/512-diagonal tiers (tuning aid)
+		const char *e = getenv("MGA_WFA_THR");
+		if (e) sscanf(e, "%d,%d,%d,%d", &T.t[0], &T.t[1], &T.t[2], &T.t[3]);
+		init = 1;
+	}
+	return T;
+}
+__host__ __device__ __forceinline__ int wfs_first_tier(int32_t tl, int32_t ql) { const wfs_thr_t T = { { 64, 128, 256, 512, 2048, 4096 } }; return wfs_first_tier_thr(tl, ql, T); }
 
 extern "C" int mga_wfa_first_tier(int32_t tl, int32_t ql) { return wfs_first_tier(tl, ql); }
 
-__global__ void __launch_bounds__(1024) k_wfa_bin_count(int n, const mga_wfa_prob_t *__restrict__ prob, int32_t *__restrict__ key, int *__restrict__ hist)
+__global__ void __launch_bounds__(1024) k_wfa_bin_count(int n, const mga_wfa_prob_t *__restrict__ prob, int32_t *__restrict__ key, int *__restrict__ hist, wfs_thr_t T)
 {
 	__shared__ int h[WFS_NBIN];
 	for (int i = threadIdx.x; i < WFS_NBIN; i += blockDim.x) h[i] = 0;
@@ -41,7 +50,7 @@ __global__ void __launch_bounds__(1024) k_wfa_bin_count(int n, const mga_wfa_pro
 		const int32_t tl = prob[i].tl, ql = prob[i].ql;
 		int lb = (tl + ql) >> 3;
 		if (lb > 1023) lb = 1023;
-		const int k = wfs_first_tier(tl, ql) << 10 | (1023 - lb);
+		const int k = wfs_first_tier_thr(tl, ql, T) << 10 | (1023 - lb);
 		key[i] = k;
 		atomicAdd(&h[k], 1);
 	}
@@ -190,7 +199,7 @@ extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_
 		int nb = (n + 1023) / 1024;
 		if (nb > 1024) nb = 1024;
 		mga_prof_begin(st, MGA_K_SCAN);
-		hipLaunchKernelGGL(k_wfa_bin_count, dim3(nb), dim3(1024), 0, st, n, d_prob, (int32_t*)sc->wfa_key.p, ctl);
+		hipLaunchKernelGGL(k_wfa_bin_count, dim3(nb), dim3(1024), 0, st, n, d_prob, (int32_t*)sc->wfa_key.p, ctl, wfs_thresholds());
 		hipLaunchKernelGGL(k_wfa_bin_scan, dim3(1), dim3(1024), 0, st, ctl, ctl + O_TOFF);
 		hipLaunchKernelGGL(k_wfa_bin_scatter, dim3((n + 8191) / 8192), dim3(1024), 0, st, n, (const int32_t*)sc->wfa_key.p, ctl, L[0]);
 		mga_prof_end(st, MGA_K_SCAN);

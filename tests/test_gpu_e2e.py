@@ -78,3 +78,26 @@ def test_long_join_rescue_on_device_matches_host_tree_and_reference(monkeypatch)
         ref_out = os.path.join(d, "ref.gaf")
         run_ref(["-c", "-x", "lr", "-t", "4", graph, reads], ref_out)
         assert open(ref_out, "rb").read() == dev
+
+
+@pytest.mark.parametrize("target", ["gfa", "lin.fa"])
+def test_device_text_equals_host_text_and_reference(monkeypatch, target):
+    """mga_map_reads lets the device stitch the CIGARs and write cg:Z / ds:Z (k_text.hip, incl. the reverse-strand form);
+    MGA_HOST_TEXT=1 keeps mg_gchain_cigar / mg_gchain_gen_ds / mg_write_gaf on the host: same bytes, and the reference's"""
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "4000000", "-H", "3", "-n", "1200", "-s", "21", "-S", "5"], stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t." + target), os.path.join(d, "t.reads.fa")
+    G = mga.Graph(graph, preset="lr", cigar=True, n_threads=8)
+    R = mga.Reads(reads)
+    dev = mga.map_reads(G, R, n_threads=8)
+    monkeypatch.setenv("MGA_HOST_TEXT", "1")
+    host = mga.map_reads(G, R, n_threads=8)
+    R.close()
+    G.close()
+    assert dev.count(b"\n") > 1000 and b"\tds:Z:" in dev
+    assert sum(1 for l in dev.split(b"\n") if l and l.split(b"\t")[4] == b"-") > 100   # reverse-strand lines are exercised
+    assert dev == host
+    if os.path.exists(rb.REF_BIN):
+        ref_out = os.path.join(d, "ref.gaf")
+        run_ref(["-c", "-x", "lr", "-t", "4", graph, reads], ref_out)
+        assert open(ref_out, "rb").read() == dev
