@@ -548,15 +548,15 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	t1 = mga_wtime(); st->t_host_chain += t1 - t0; t0 = t1;
 	/* ---- WFA over all gaps ---- */
 	n_prob = mga_batch_n_wfa(b), n_tb = mga_batch_wfa_target_bytes(b);
-	if ((opt->flag & MG_M_CIGAR) && n_prob > 0) {
+	if ((opt->flag & MG_M_CIGAR) && (n_prob > 0 || (b->want_text && mga_batch_n_chains(b) > 0))) { /* (text mode: chains made of ready operators only still need their text) */
 		mga_wfa_prob_t *h_prob;
 		int64_t cells = 0;
 		if (n_prob > 0x7fffffff) { mga_set_error("too many WFA problems in one chunk (%ld); lower MGA_CHUNK", (long)n_prob); rc = -1; goto done; }
-		CK(mga_hbuf_reserve(&P->h_prob, (size_t)n_prob * sizeof(mga_wfa_prob_t))); CK(mga_hbuf_reserve(&P->h_tseq, (size_t)n_tb + 64));
+		CK(mga_hbuf_reserve(&P->h_prob, (size_t)n_prob * sizeof(mga_wfa_prob_t) + 16)); CK(mga_hbuf_reserve(&P->h_tseq, (size_t)n_tb + 64));
 		h_prob = (mga_wfa_prob_t*)P->h_prob.p;
 		mga_batch_wfa_export(b, h_prob, (char*)P->h_tseq.p);
 		memset((char*)P->h_tseq.p + n_tb, 0, 64);
-		CK(mga_dbuf_reserve(&P->tseq, (size_t)n_tb + 64)); CK(mga_dbuf_reserve(&P->prob, (size_t)n_prob * sizeof(mga_wfa_prob_t))); CK(mga_dbuf_reserve(&P->res, (size_t)n_prob * sizeof(mga_wfa_res_t)));
+		CK(mga_dbuf_reserve(&P->tseq, (size_t)n_tb + 64)); CK(mga_dbuf_reserve(&P->prob, (size_t)n_prob * sizeof(mga_wfa_prob_t) + 16)); CK(mga_dbuf_reserve(&P->res, (size_t)n_prob * sizeof(mga_wfa_res_t) + 16));
 		CK(mga_dbuf_reserve(&P->used, 64));
 		/* uploads ride the copy engine while another chunk owns the WFA phase */
 		CK(mga_h2d_s(sc, P->tseq.p, P->h_tseq.p, (size_t)n_tb + 64)); CK(mga_h2d_s(sc, P->prob.p, h_prob, (size_t)n_prob * sizeof(mga_wfa_prob_t)));

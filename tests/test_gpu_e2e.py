@@ -101,3 +101,22 @@ def test_device_text_equals_host_text_and_reference(monkeypatch, target):
         ref_out = os.path.join(d, "ref.gaf")
         run_ref(["-c", "-x", "lr", "-t", "4", graph, reads], ref_out)
         assert open(ref_out, "rb").read() == dev
+
+
+def test_error_free_reads_need_no_wfa_problem():
+    """reads without errors: every gap is a ready '=' operator (galign.c:98-100), the chunk has no WFA problem at all,
+    and the text kernel still has to print the chains"""
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "2000000", "-H", "2", "-n", "300", "-e", "0", "-s", "3"], stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    G = mga.Graph(graph, preset="lr", cigar=True, n_threads=4)
+    R = mga.Reads(reads)
+    dev = mga.map_reads(G, R, n_threads=4)
+    R.close()
+    G.close()
+    import re
+    assert len(re.findall(rb"\tcg:Z:\d+=\tds:Z::\d+\n", dev)) > 250   # whole reads in one '=' run (minus the ends before the first / after the last minimizer)
+    if os.path.exists(rb.REF_BIN):
+        ref_out = os.path.join(d, "ref.gaf")
+        run_ref(["-c", "-x", "lr", "-t", "4", graph, reads], ref_out)
+        assert open(ref_out, "rb").read() == dev
