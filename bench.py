@@ -16,6 +16,7 @@ import argparse
 import json
 import os
 import re
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -90,6 +91,8 @@ def main():
     ap.add_argument("--hap", type=int, default=3)
     ap.add_argument("--cpu-reads", type=int, default=20000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--gather", action="store_true", help="N>1: also gather every rank's GAF bytes to rank 0 over RCCL inside the timed region "
+                    "(off by default: the shards are independent, each rank keeps / writes its own GAF)")
     ap.add_argument("--threads", type=int, default=0, help="host threads per rank (0: min(64, usable cores / ranks))")
     args = ap.parse_args()
 
@@ -133,8 +136,8 @@ def main():
 
     def step():
         gaf = mga.map_reads(G, R, n_threads=threads, copy=False)   # GAF text stays in the C library's buffer
-        if dist is not None:  # RCCL over xGMI: gather the GAF bytes of every rank to rank 0
-            gather_bytes(gaf.bytes(), dst=0, device="cuda")
+        if dist is not None and args.gather:  # optional: one output stream on rank 0; zero-copy view -> GPU -> RCCL gather
+            gather_bytes(gaf.view(), dst=0, device="cuda", as_tensors=True)
         return gaf
 
     def sync():
@@ -204,7 +207,7 @@ def main():
                    n_gpus=n_gpus, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="u8/int32", data="synthetic",
                    config=dict(workload="configs[2]: %d x 10kb synthetic ONT reads per GPU vs %d bp %d-haplotype bubble graph, -cx lr -c"
-                               % (R.n, args.genome, args.hap), reads_per_gpu=R.n, read_len=10000, err=0.1, sharding="reads/%dgpu" % n_gpus,
+                               % (R.n, args.genome, args.hap), reads_per_gpu=R.n, read_len=10000, err=0.1, sharding="reads/%dgpu, no data-path collective%s" % (n_gpus, " + RCCL gather of GAF bytes" if (args.gather and n_gpus > 1) else ""),
                                host_threads_per_rank=threads),
                    roofline=roof,
                    kernels_ms={k: round(v[0], 3) for k, v in prof.items()},
@@ -231,6 +234,7 @@ def main():
         print(json.dumps(res), flush=True)
     R.close()
     G.close()
+    shutil.rmtree(d, ignore_errors=True)
     if dist is not None:
         dist.destroy_process_group()
 

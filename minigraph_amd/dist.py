@@ -12,20 +12,28 @@ def shard_range(n_items, rank, world):
     return st, st + base + (1 if rank < rem else 0)
 
 
-def gather_bytes(payload, dst=0, device="cpu"):
-    """gather one bytes object per rank to `dst`; returns the list in rank order on dst, None elsewhere.
-    size all_gather + gather of byte tensors padded to the largest payload"""
+def gather_bytes(payload, dst=0, device="cpu", as_tensors=False):
+    """gather one byte string per rank to `dst`; returns the list in rank order on dst, None elsewhere.
+    payload: bytes, or any C-contiguous uint8 buffer (e.g. the zero-copy numpy view of the library's GAF buffer).
+    One all_gather of the sizes + one gather of byte tensors padded to the largest payload; with as_tensors=True the
+    result stays on `device` (uint8 tensors, no host round trip)."""
+    import numpy as np
     world, rank = dist.get_world_size(), dist.get_rank()
-    n = torch.tensor([len(payload)], dtype=torch.int64, device=device)
+    src = np.frombuffer(payload, dtype=np.uint8) if not isinstance(payload, np.ndarray) else payload.reshape(-1)
+    n = torch.tensor([src.size], dtype=torch.int64, device=device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n)
     sizes = [int(s.item()) for s in sizes]
     mx = max(max(sizes), 1)
-    buf = torch.zeros(mx, dtype=torch.uint8, device=device)
-    if len(payload):
-        buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device)
-    out = [torch.zeros(mx, dtype=torch.uint8, device=device) for _ in range(world)] if rank == dst else None
+    buf = torch.empty(mx, dtype=torch.uint8, device=device)
+    if src.size:
+        if not src.flags.writeable:
+            src = src.copy()  # torch.from_numpy wants a writable array (bytes objects are not)
+        buf[:src.size].copy_(torch.from_numpy(src), non_blocking=False)
+    out = [torch.empty(mx, dtype=torch.uint8, device=device) for _ in range(world)] if rank == dst else None
     dist.gather(buf, out, dst=dst)
     if rank != dst:
         return None
-    return [bytes(out[r][:sizes[r]].cpu().numpy().tobytes()) for r in range(world)]
+    if as_tensors:
+        return [out[r][:sizes[r]] for r in range(world)]
+    return [out[r][:sizes[r]].cpu().numpy().tobytes() for r in range(world)]
