@@ -61,6 +61,13 @@ extern "C" int mga_dev_bind_thread(void)
 	return 0;
 }
 
+// pinned staging of small read-backs, see mga_d2h_s()
+#define MGA_STAGE_BYTES (1 << 20)
+#define MGA_STAGE_MAX   (256 << 10)
+#define MGA_STAGE_SLOTS 64
+struct stage_ent_t { void *dst; size_t off, bytes; };
+struct stage_t { char *buf; size_t used; int n; stage_ent_t e[MGA_STAGE_SLOTS]; };
+
 extern "C" mga_sctx_t *mga_sctx_create(void)
 {
 	if (mga_dev_init() < 0) return 0;
@@ -74,7 +81,13 @@ extern "C" mga_sctx_t *mga_sctx_create(void)
 		sc->tier_stream[i] = (void*)t, sc->ev_done[i] = (void*)e;
 	}
 	{ hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return 0; sc->ev_ready = (void*)e; }
-	{ hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) return 0; sc->ev_sync = (void*)e; }
+	{ hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return 0; sc->ev_sync = (void*)e; }
+	{
+		stage_t *S = (stage_t*)calloc(1, sizeof(stage_t));
+		S->buf = (char*)mga_hmalloc_pinned(MGA_STAGE_BYTES);
+		if (S->buf == 0) { free(S); return 0; }
+		sc->stage = S;
+	}
 	return sc;
 }
 
@@ -88,6 +101,7 @@ extern "C" void mga_sctx_destroy(mga_sctx_t *sc)
 	mga_dbuf_free(&sc->wfa_list[0]); mga_dbuf_free(&sc->wfa_list[1]); mga_dbuf_free(&sc->wfa_key); mga_dbuf_free(&sc->wfa_ctl);
 	for (int i = 0; i < 8; ++i) { (void)hipStreamDestroy((hipStream_t)sc->tier_stream[i]); (void)hipEventDestroy((hipEvent_t)sc->ev_done[i]); }
 	(void)hipEventDestroy((hipEvent_t)sc->ev_ready); (void)hipEventDestroy((hipEvent_t)sc->ev_sync);
+	if (sc->stage) { mga_hfree_pinned(((stage_t*)sc->stage)->buf); free(sc->stage); }
 	(void)hipStreamDestroy((hipStream_t)sc->stream);
 	free(sc);
 }
@@ -127,11 +141,32 @@ extern "C" int mga_h2d_s(mga_sctx_t *sc, void *d, const void *h, size_t bytes)
 	return 0;
 }
 
+// Small read-backs (counters, offsets) usually land in ordinary host variables.  An async copy to PAGEABLE memory is
+// staged and waited for inside the runtime -- a spinning wait for everything queued before it on the stream.  So copies
+// of up to MGA_STAGE_MAX bytes go to a pinned staging block of the context first and are handed to their destination
+// by the next mga_ssync(); larger destinations must be pinned (mga_hbuf_t).
+
 extern "C" int mga_d2h_s(mga_sctx_t *sc, void *h, const void *d, size_t bytes)
 {
 	if (bytes == 0) return 0;
+	stage_t *S = (stage_t*)sc->stage;
+	if (S && bytes <= MGA_STAGE_MAX && S->n < MGA_STAGE_SLOTS && S->used + bytes <= MGA_STAGE_BYTES) {
+		stage_ent_t *e = &S->e[S->n++];
+		e->dst = h, e->off = S->used, e->bytes = bytes;
+		S->used += (bytes + 63) & ~(size_t)63;
+		MGA_HIP_CHECK(hipMemcpyAsync(S->buf + e->off, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)sc->stream));
+		return 0;
+	}
 	MGA_HIP_CHECK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)sc->stream));
 	return 0;
+}
+
+static void stage_deliver(mga_sctx_t *sc)
+{
+	stage_t *S = (stage_t*)sc->stage;
+	if (S == 0) return;
+	for (int i = 0; i < S->n; ++i) memcpy(S->e[i].dst, S->buf + S->e[i].off, S->e[i].bytes);
+	S->n = 0, S->used = 0;
 }
 
 extern "C" int mga_dmemset_s(mga_sctx_t *sc, void *d, int v, size_t bytes)
@@ -141,12 +176,23 @@ extern "C" int mga_dmemset_s(mga_sctx_t *sc, void *d, int v, size_t bytes)
 	return 0;
 }
 
-// Waiting on a blocking-sync event lets the pipeline thread sleep; hipStreamSynchronize() would spin on a core, and the
-// host stages of the other chunks need every core the (often CPU-quota-limited) box gives us.
+// Waiting without burning a core: hipStreamSynchronize() spins, and [measured] so does hipEventSynchronize() on an event
+// created with hipEventBlockingSync under this runtime (4 pipeline threads waiting = 2 CPU-s per 0.55 s step).  The
+// host stages of the other chunks need every core the (often CPU-quota-limited) box gives us, so poll the event and
+// sleep in between; a sync happens ~12 times per chunk of ~45 ms, the added latency (<= 100 us each) is noise.
 extern "C" int mga_ssync(mga_sctx_t *sc)
 {
 	MGA_HIP_CHECK(hipEventRecord((hipEvent_t)sc->ev_sync, (hipStream_t)sc->stream));
-	MGA_HIP_CHECK(hipEventSynchronize((hipEvent_t)sc->ev_sync));
+	struct timespec ts = { 0, 20000 };
+	for (int spin = 0;; ++spin) {
+		const hipError_t e = hipEventQuery((hipEvent_t)sc->ev_sync);
+		if (e == hipSuccess) break;
+		if (e != hipErrorNotReady) { mga_set_error("HIP error while waiting for the stream: %s", hipGetErrorString(e)); return -1; }
+		if (spin < 3) continue; // the copy or kernel may be just about done
+		nanosleep(&ts, 0);
+		if (ts.tv_nsec < 100000) ts.tv_nsec += 20000;
+	}
+	stage_deliver(sc);
 	return 0;
 }
 

@@ -31,6 +31,53 @@ static int g_cpu_on = 0;
 static inline int64_t cpu_now(void) { struct timespec ts; if (!g_cpu_on) return 0; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (int64_t)ts.tv_sec * 1000000000LL + ts.tv_nsec; }
 #define CPU_ADD(which, t0) do { if (g_cpu_on) { int64_t t1_ = cpu_now(); __sync_fetch_and_add(&g_cpu_ns[which], t1_ - (t0)); (t0) = t1_; } } while (0)
 
+/* Grow-only scratch that is recycled across chunks instead of being freed: the per-thread planning pools and the GAF
+ * pieces are tens of MB per chunk, and handing them back to malloc means mmap/munmap and a page fault per 4 KB on
+ * every chunk ([measured] ~0.2 s of host CPU per 100k reads). */
+#include <pthread.h>
+static pthread_mutex_t g_cache_mtx = PTHREAD_MUTEX_INITIALIZER;
+#define TP_CACHE_MAX 512
+static mga_tpool_t g_tp_cache[TP_CACHE_MAX];
+static int g_n_tp_cache = 0;
+static void tpool_get(mga_tpool_t *tp)
+{
+	pthread_mutex_lock(&g_cache_mtx);
+	if (g_n_tp_cache > 0) *tp = g_tp_cache[--g_n_tp_cache]; else memset(tp, 0, sizeof *tp);
+	pthread_mutex_unlock(&g_cache_mtx);
+	tp->n_t = tp->n_prob = tp->n_item = tp->n_chain = tp->n_vert = 0, tp->wfa_t_bases = tp->wfa_q_bases = 0;
+}
+static void tpool_put(mga_tpool_t *tp)
+{
+	pthread_mutex_lock(&g_cache_mtx);
+	if (g_n_tp_cache < TP_CACHE_MAX) { g_tp_cache[g_n_tp_cache++] = *tp; pthread_mutex_unlock(&g_cache_mtx); return; }
+	pthread_mutex_unlock(&g_cache_mtx);
+	free(tp->tseq); free(tp->prob); free(tp->item); free(tp->chain); free(tp->vert);
+}
+#define STR_CACHE_MAX 512
+static struct { char *s; size_t m; } g_str_cache[STR_CACHE_MAX];
+static int g_n_str_cache = 0;
+static char *strbuf_get(size_t want, size_t *cap) /* a cached buffer (possibly grown) of at least `want` bytes */
+{
+	char *p = 0;
+	size_t m = 0;
+	int i, best = -1;
+	pthread_mutex_lock(&g_cache_mtx);
+	for (i = g_n_str_cache - 1; i >= 0; --i) { if (g_str_cache[i].m >= want) { best = i; break; } if (best < 0 || g_str_cache[i].m > g_str_cache[best].m) best = i; }
+	if (best >= 0) { p = g_str_cache[best].s, m = g_str_cache[best].m; g_str_cache[best] = g_str_cache[--g_n_str_cache]; }
+	pthread_mutex_unlock(&g_cache_mtx);
+	if (m < want) { p = (char*)realloc(p, want); m = want; }
+	*cap = m;
+	return p;
+}
+static void strbuf_put(char *p, size_t m)
+{
+	if (p == 0) return;
+	pthread_mutex_lock(&g_cache_mtx);
+	if (g_n_str_cache < STR_CACHE_MAX) { g_str_cache[g_n_str_cache].s = p, g_str_cache[g_n_str_cache++].m = m; p = 0; }
+	pthread_mutex_unlock(&g_cache_mtx);
+	free(p);
+}
+
 struct mg_tbuf_s { int dummy; };
 mg_tbuf_t *mg_tbuf_init(void) { return (mg_tbuf_t*)calloc(1, sizeof(mg_tbuf_t)); } /* map-algo.c:14-20: scratch is per batch here */
 void mg_tbuf_destroy(mg_tbuf_t *b) { free(b); }
@@ -83,6 +130,7 @@ mga_batch_t *mga_batch_init(const mg_idx_t *gi, const mg_mapopt_t *opt, int n, c
 	b->gcs = MGA_CALLOC(mg_gchains_t*, n > 0 ? n : 1);
 	b->plan = MGA_CALLOC(read_plan_t, n > 0 ? n : 1);
 	b->tp = MGA_CALLOC(mga_tpool_t, b->n_threads);
+	{ int t_; for (t_ = 0; t_ < b->n_threads; ++t_) tpool_get(&b->tp[t_]); }
 	b->tp_prob_base = MGA_CALLOC(int64_t, b->n_threads + 1);
 	b->tp_t_base = MGA_CALLOC(int64_t, b->n_threads + 1);
 	b->tp_item_base = MGA_CALLOC(int64_t, b->n_threads + 1);
@@ -351,7 +399,7 @@ void mga_batch_destroy(mga_batch_t *b)
 	int i;
 	if (b == 0) return;
 	for (i = 0; i < b->n; ++i) { free(b->plan[i].item_off); free(b->plan[i].chain_id); }
-	for (i = 0; i < b->n_threads; ++i) { free(b->tp[i].tseq); free(b->tp[i].prob); free(b->tp[i].item); free(b->tp[i].chain); free(b->tp[i].vert); }
+	for (i = 0; i < b->n_threads; ++i) tpool_put(&b->tp[i]);
 	if (b->gcs) { for (i = 0; i < b->n; ++i) mg_gchain_free(b->gcs[i]); free(b->gcs); }
 	free(b->plan); free(b->tp); free(b->tp_prob_base); free(b->tp_t_base); free(b->tp_item_base); free(b->tp_chain_base); free(b->tp_vert_base);
 	free(b);
@@ -374,7 +422,7 @@ static void gaf_worker(void *data, int64_t t, int tid)
 	{ /* one allocation per piece: a base-aligned read prints about one byte per base (cg + ds), an unaligned one ~120 bytes */
 		size_t est = 4096;
 		for (i = b; i < e; ++i) est += (bt->opt.flag & MG_M_CIGAR) ? (size_t)bt->qlens[i] + 512 : 512;
-		if (est < 0xfffffff0u && est > out->m) { out->m = (unsigned)est; out->s = (char*)realloc(out->s, out->m); }
+		if (est < 0xfffffff0u && est > out->m) { size_t cap; char *p = strbuf_get(est, &cap); if (cap > 0xfffffff0u) cap = 0xfffffff0u; free(out->s); out->s = p, out->m = (unsigned)cap, out->l = 0; }
 	}
 	for (i = b; i < e; ++i) {
 		int32_t ql = bt->qlens[i], k;
@@ -660,7 +708,7 @@ typedef struct {
 typedef struct { pipe_job_t *job; pipe_ctx_t *P; mga_stats_t st; } pipe_thr_t;
 
 typedef struct { kstring_t *part; int64_t *off; char *dst; } gcopy_t;
-static void gaf_copy_worker(void *data, int64_t i, int tid) { gcopy_t *g = (gcopy_t*)data; (void)tid; if (g->part[i].l) memcpy(g->dst + g->off[i], g->part[i].s, g->part[i].l); free(g->part[i].s); g->part[i].s = 0; }
+static void gaf_copy_worker(void *data, int64_t i, int tid) { gcopy_t *g = (gcopy_t*)data; (void)tid; if (g->part[i].l) memcpy(g->dst + g->off[i], g->part[i].s, g->part[i].l); strbuf_put(g->part[i].s, g->part[i].m); g->part[i].s = 0, g->part[i].m = g->part[i].l = 0; }
 
 /* chunk c is formatted: append every chunk that is now complete AND next in read order to the index-owned output buffer */
 static void commit_chunks(pipe_job_t *J, int c)

@@ -42,7 +42,8 @@ typedef struct mga_sctx_s {
 	mga_dbuf_t wfa_list[2], wfa_key, wfa_ctl; /* tier scheduler (k_wfa_sched.hip): double-buffered work lists, sort keys, counters */
 	void *tier_stream[8];      /* WFA tiers run concurrently on their own streams (long-tailed wide problems next to the small ones) */
 	void *ev_ready, *ev_done[8];
-	void *ev_sync;             /* blocking-sync event behind mga_ssync() */
+	void *ev_sync;             /* event behind mga_ssync() */
+	void *stage;               /* pinned staging for small device-to-host read-backs, delivered by mga_ssync() */
 } mga_sctx_t;
 void *mga_wfa_stream(mga_sctx_t *sc, int slot);       /* stream of WFA tier `slot` */
 int mga_wfa_fork(mga_sctx_t *sc);                     /* tier streams wait for everything queued on sc->stream so far */
@@ -52,7 +53,7 @@ void mga_sctx_destroy(mga_sctx_t *sc);
 mga_sctx_t *mga_sctx_default(void);            /* lazily created, used by the stage-level API */
 int  mga_dev_bind_thread(void);                /* hipSetDevice() for threads other than the one that called mga_dev_init */
 int  mga_h2d_s(mga_sctx_t *sc, void *d, const void *h, size_t bytes);   /* async on sc->stream */
-int  mga_d2h_s(mga_sctx_t *sc, void *h, const void *d, size_t bytes);
+int  mga_d2h_s(mga_sctx_t *sc, void *h, const void *d, size_t bytes); /* <= 256 KB: any host memory, valid after mga_ssync(); larger: h must be pinned */
 int  mga_dmemset_s(mga_sctx_t *sc, void *d, int v, size_t bytes);
 int  mga_ssync(mga_sctx_t *sc);
 typedef struct { void *p; size_t cap; } mga_hbuf_t;                     /* grow-only PINNED host buffer */
