@@ -10,6 +10,7 @@
 // All tiers of a pass run concurrently on their own streams (mga_wfa_fork / mga_wfa_join).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <time.h>
 #include <stdio.h>
 #include "mga_dev.h"
 #include "dev_common.h"
@@ -180,7 +181,8 @@ extern "C" int mga_dev_wfa_tier(mga_sctx_t *sc, int n, const int32_t *d_list, co
 }
 
 extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
-								 mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int64_t *cells)
+								 mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int64_t *cells,
+								 void (*bulk_done)(void*), void *bulk_arg)
 {
 	if (cells) *cells = 0;
 	if (n <= 0) return 0;
@@ -221,6 +223,13 @@ extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_
 			if (mga_dev_wfa_tier(sc, cnt[t], L[cur] + off[t], d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, t, rt) < 0) return -1;
 		}
 		if (mga_wfa_join(sc) < 0) return -1;
+		if (pass == 0 && bulk_done) { // the narrow tiers carry >95 % of the work: once they are done the caller may let the next chunk's
+			// WFA phase start; the long tails of the wide tiers and the retry passes then overlap with it instead of idling the GPU
+			struct timespec ts = { 0, 50000 };
+			for (int t = 0; t < 4; ++t)
+				while (cnt[t] > 0 && hipEventQuery((hipEvent_t)sc->ev_done[t]) == hipErrorNotReady) nanosleep(&ts, 0);
+			bulk_done(bulk_arg);
+		}
 		int hr[MGA_WFA_N_TIER + 1], herr = 0, left = 0;
 		if (mga_d2h_s(sc, hr, rc, (MGA_WFA_N_TIER + 1) * 4) < 0 || mga_d2h_s(sc, &herr, ctl + O_ERR, 4) < 0 || mga_ssync(sc) < 0) return -1;
 		if (dbg) {

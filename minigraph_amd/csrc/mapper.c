@@ -484,6 +484,8 @@ static int env_int(const char *name, int dflt) { const char *s = getenv(name); r
 
 #define CK(x) do { if ((x) < 0) { rc = -1; goto done; } } while (0)
 
+static void release_token_cb(void *a) { gpu_token_t **held = (gpu_token_t**)a; if (*held) { token_release(*held); *held = 0; } }
+
 static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs_out,
 					 const mg_mapopt_t *opt, int n_threads, const char *d_seq_res, const int64_t *q_off_res, mga_stats_t *st, kstring_t *gaf_part)
 {
@@ -614,7 +616,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 		CK(mga_dbuf_reserve(&P->pool, (size_t)pool_cap * 4)); CK(mga_dmemset_s(sc, P->used.p, 0, 8));
 		/* the tier ladder runs on the device (k_wfa_sched.hip); the host never walks the problems */
 		CK(mga_dev_wfa_solve(sc, (int)n_prob, (const mga_wfa_prob_t*)P->prob.p, (const char*)P->tseq.p, d_seq, (mga_wfa_res_t*)P->res.p,
-							 (uint32_t*)P->pool.p, pool_cap, (unsigned long long*)P->used.p, &cells));
+							 (uint32_t*)P->pool.p, pool_cap, (unsigned long long*)P->used.p, &cells, env_int("MGA_EARLY_RELEASE", 1) ? release_token_cb : 0, &held));
 		{ /* CIGARs back in problem order: one sequential stream for the host's stitching threads, or the input of the text kernel */
 			int64_t n_ops = 0;
 			CK(mga_dbuf_reserve(&P->ncig, (size_t)n_prob * 4 + 16)); CK(mga_dbuf_reserve(&P->cigoff, (size_t)(n_prob + 1) * 8)); CK(mga_dbuf_reserve(&P->ord, (size_t)pool_cap * 4));
@@ -702,6 +704,7 @@ typedef struct {
 	pthread_mutex_t cmtx;
 	char *done;
 	int n_chunks, next_commit;
+	int *cstart; /* n_chunks + 1 chunk boundaries: small chunks first and last shorten the pipeline's fill and drain */
 	int64_t out_len;
 } pipe_job_t;
 
@@ -741,9 +744,9 @@ static void *pipe_worker(void *a)
 	pipe_job_t *J = t->job;
 	if (mga_dev_bind_thread() < 0) { J->err = 1; return 0; }
 	for (;;) {
-		int c = __sync_fetch_and_add(&J->next, 1), st = c * J->chunk, en;
-		if (st >= J->n || J->err) break;
-		en = st + J->chunk < J->n ? st + J->chunk : J->n;
+		int c = __sync_fetch_and_add(&J->next, 1), st, en;
+		if (c >= J->n_chunks || J->err) break;
+		st = J->cstart[c], en = J->cstart[c + 1];
 		double tc = mga_wtime();
 		if (map_chunk(t->P, J->gi, en - st, J->qlens + st, J->seqs + st, J->qnames ? J->qnames + st : 0, J->gcs + st, J->opt, J->n_threads,
 					  J->d_seq, J->q_off ? J->q_off + st : 0, &t->st, J->gaf_part ? J->gaf_part + (size_t)c * J->n_threads : 0) < 0) {
@@ -781,7 +784,24 @@ static int map_all(const mg_idx_t *gi, int n, const int *qlens, const char **seq
 	J.gi = gi, J.opt = opt, J.n = n, J.qlens = qlens, J.seqs = seqs, J.qnames = qnames, J.gcs = gcs, J.d_seq = d_seq, J.q_off = q_off;
 	J.chunk = env_int("MGA_CHUNK", 8192); /* [measured] larger launches amortise the tails of the WFA tiers: 4096 -> 8192 reads +5 % */
 	if (J.chunk < 1) J.chunk = 1;
-	n_chunks = (n + J.chunk - 1) / J.chunk;
+	{ /* chunk boundaries: ramp up from chunk/4 at the start and down at the end (fill/drain of the pipeline cost one chunk
+	   * time each, ~8 % of a 100k-read batch); everything in between is MGA_CHUNK reads */
+		const int ramp = env_int("MGA_RAMP", 1) && n > 6 * J.chunk;
+		int pos = 0, m = 0, cap = n / (J.chunk / 4 > 0 ? J.chunk / 4 : 1) + 8;
+		J.cstart = MGA_MALLOC(int, cap + 1);
+		while (pos < n) {
+			int sz = J.chunk, left = n - pos;
+			if (ramp) {
+				if (m == 0) sz = J.chunk / 4; else if (m == 1) sz = J.chunk / 2;
+				if (left <= J.chunk + J.chunk / 2) sz = left > J.chunk / 2 + J.chunk / 8 ? left - J.chunk / 2 : left; /* tail: the last chunk is chunk/2 (or what is left) */
+			}
+			if (sz < 1) sz = 1;
+			if (sz > left) sz = left;
+			J.cstart[m++] = pos; pos += sz;
+		}
+		J.cstart[m] = n;
+		n_chunks = m;
+	}
 	if (n_pipe > MGA_MAX_PIPE) n_pipe = MGA_MAX_PIPE;
 	if (n_pipe > n_chunks) n_pipe = n_chunks;
 	if (n_pipe < 1) n_pipe = 1;
@@ -800,6 +820,7 @@ static int map_all(const mg_idx_t *gi, int n, const int *qlens, const char **seq
 		for (i = 0; i < n_pipe; ++i) pthread_join(tid[i], 0);
 	}
 	pthread_mutex_destroy(&J.mtx); pthread_mutex_destroy(&J.cmtx);
+	free(J.cstart);
 	for (i = 0; i < n_pipe; ++i) { /* merge the per-thread counters */
 		mga_stats_t *d = &gi->B->st, *s = &thr[i].st;
 		d->n_reads += s->n_reads, d->n_bases += s->n_bases, d->n_mz += s->n_mz, d->n_probe += s->n_probe, d->n_hit += s->n_hit;

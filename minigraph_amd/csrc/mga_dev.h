@@ -139,7 +139,8 @@ int mga_dev_wfa_tier(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa
 /* the whole ladder (k_wfa_sched.hip): every problem in its first tier, the ones that outgrow it one tier up, until none is left;
  * d_res[i] / d_pool hold the results; *cells (optional) = total wavefront cells */
 int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
-					  mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int64_t *cells);
+					  mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int64_t *cells,
+					  void (*bulk_done)(void*), void *bulk_arg); /* bulk_done (optional): called once the tiers of <= 512 diagonals finished their first pass */
 
 /* ---- alignment text on the device (k_text.hip): stitched CIGAR statistics + cg:Z / ds:Z strings of a chain ---- */
 typedef struct { int32_t op, val; } mga_cigitem_t; /* op >= 0: ready operator (op, len = val); op == -1: WFA problem #val of this read's pool */

@@ -71,7 +71,7 @@ extern "C" int mga_wfa_batch(int n, const char *tseq, const int64_t *t_off, cons
 	std::vector<mga_wfa_res_t> res(n);
 	if (!d_pool.alloc((size_t)pool_cap * 4) || mga_dmemset_s(SC, d_used.p, 0, 8) < 0) return -1;
 	if (mga_dev_wfa_solve(SC, n, d_prob.as<mga_wfa_prob_t>(), d_t.as<char>(), d_q.as<char>(), d_res.as<mga_wfa_res_t>(),
-						  d_pool.as<uint32_t>(), pool_cap, (unsigned long long*)d_used.p, 0) < 0) return -1;
+						  d_pool.as<uint32_t>(), pool_cap, (unsigned long long*)d_used.p, 0, 0, 0) < 0) return -1;
 	if (mga_dsync() < 0 || mga_d2h(res.data(), d_res.p, (size_t)n * sizeof(mga_wfa_res_t)) < 0) return -1;
 	unsigned long long used = 0;
 	if (mga_dsync() < 0 || mga_d2h(&used, d_used.p, 8) < 0) return -1;
