@@ -120,3 +120,31 @@ def test_error_free_reads_need_no_wfa_problem():
         ref_out = os.path.join(d, "ref.gaf")
         run_ref(["-c", "-x", "lr", "-t", "4", graph, reads], ref_out)
         assert open(ref_out, "rb").read() == dev
+
+
+@pytest.mark.parametrize("tag,simargs,cigar", [
+    ("50kb reads", ["-G", "5000000", "-H", "3", "-n", "200", "-l", "50000", "-s", "31"], True),
+    ("100kb reads, 15% errors", ["-G", "5000000", "-H", "3", "-n", "60", "-l", "100000", "-e", "0.15", "-s", "32"], True),
+    ("1kb reads", ["-G", "3000000", "-H", "3", "-n", "3000", "-l", "1000", "-s", "33"], True),
+    ("20% errors", ["-G", "3000000", "-H", "3", "-n", "800", "-e", "0.2", "-s", "34"], True),
+    ("5 haplotypes, 3 chromosomes", ["-G", "6000000", "-H", "5", "-c", "3", "-n", "1500", "-s", "35"], True),
+    ("chains only", ["-G", "3000000", "-H", "3", "-n", "1500", "-s", "36"], False),
+])
+def test_parity_sweep_vs_reference_binary(tag, simargs, cigar):
+    """shapes the benchmark workload does not reach: wide WFA tiers (long gaps of long / noisy reads), many short reads,
+    several stable sequences, the chains-only output"""
+    if not os.path.exists(rb.REF_BIN):
+        pytest.skip("oracle/_ref/minigraph not present")
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t")] + simargs, stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    ref_out = os.path.join(d, "ref.gaf")
+    run_ref((["-c"] if cigar else []) + ["-x", "lr", "-t", "8", graph, reads], ref_out)
+    G = mga.Graph(graph, preset="lr", cigar=cigar, n_threads=8)
+    R = mga.Reads(reads)
+    got = mga.map_reads(G, R, n_threads=8)
+    R.close()
+    G.close()
+    if open(ref_out, "rb").read() != got:
+        open(os.path.join(d, "got.gaf"), "wb").write(got)
+        raise AssertionError(tag + ": " + first_diff(ref_out, os.path.join(d, "got.gaf")))
