@@ -267,6 +267,8 @@ int mga_map_files_to_path(gfa_t *g, int n_fn, const char **fn, const mg_idxopt_t
 typedef struct mga_reads_s mga_reads_t;
 mga_reads_t *mga_reads_load(const char *fn, int64_t max_reads);   /* FASTA/FASTQ(.gz) -> host copy + HBM copy; NULL on error */
 void mga_reads_free(mga_reads_t *rd);
+/* the FASTA/FASTQ(.gz) reader alone (no device): record count, bases, FNV-1a hash over "name\nSEQ\n" after upper-casing and U->T */
+int mga_reads_parse(const char *fn, int64_t *n_reads, int64_t *n_bases, uint64_t *hash);
 int mga_reads_count(const mga_reads_t *rd);
 int64_t mga_reads_bases(const mga_reads_t *rd);
 /* mg_map_batch() + mg_write_gaf() for a resident read set; *gaf (NUL-terminated, input order) points into a buffer owned by the

@@ -9,49 +9,112 @@
 #include <ctype.h>
 #include "mga_host.h"
 
+#define RD_BUF (4 << 20)
 typedef struct { gzFile fp; char *buf; int beg, end, eof; } rd_t;
 
-static int rd_getc(rd_t *r)
+static int rd_fill(rd_t *r) /* 1 if the buffer holds data */
 {
-	if (r->beg >= r->end) {
-		if (r->eof) return -1;
-		r->end = gzread(r->fp, r->buf, 1 << 20), r->beg = 0;
-		if (r->end <= 0) { r->eof = 1, r->end = 0; return -1; }
-	}
-	return (unsigned char)r->buf[r->beg++];
+	if (r->beg < r->end) return 1;
+	if (r->eof) return 0;
+	r->end = gzread(r->fp, r->buf, RD_BUF), r->beg = 0;
+	if (r->end <= 0) { r->eof = 1, r->end = 0; return 0; }
+	return 1;
 }
+static inline int rd_getc(rd_t *r) { return rd_fill(r) ? (unsigned char)r->buf[r->beg++] : -1; }
 
 typedef struct { char *s; size_t l, m; } str_t;
-static inline void str_c(str_t *s, int c) { if (s->l + 2 > s->m) { s->m = s->m ? s->m << 1 : 256; s->s = (char*)realloc(s->s, s->m); } s->s[s->l++] = (char)c; s->s[s->l] = 0; }
+static inline void str_room(str_t *s, size_t extra) { if (s->l + extra + 2 > s->m) { s->m = (s->l + extra + 2) * 2; if (s->m < 256) s->m = 256; s->s = (char*)realloc(s->s, s->m); } }
+static inline void str_c(str_t *s, int c) { str_room(s, 1); s->s[s->l++] = (char)c; s->s[s->l] = 0; }
 
-/* one FASTA/FASTQ record; returns 0, or -1 at EOF.  `last` carries the record marker between calls (kseq semantics) */
+/* the rest of the current line: appended to s when s != NULL (a trailing '\r' is dropped, as kseq does), the '\n' is consumed */
+static void rd_line(rd_t *r, str_t *s)
+{
+	while (rd_fill(r)) {
+		char *p = r->buf + r->beg, *q = (char*)memchr(p, '\n', (size_t)(r->end - r->beg));
+		const size_t n = q ? (size_t)(q - p) : (size_t)(r->end - r->beg);
+		if (s) { str_room(s, n); memcpy(s->s + s->l, p, n); s->l += n; s->s[s->l] = 0; }
+		r->beg += (int)n + (q ? 1 : 0);
+		if (q) break;
+	}
+	if (s && s->l > 0 && s->s[s->l - 1] == '\r') s->s[--s->l] = 0;
+}
+
+/* one FASTA/FASTQ record (kseq semantics, bseq.c:61-98 via kseq.h); returns 0, or -1 at EOF.  `last` carries a record
+ * marker that was read as the first character of a line between calls.  Lines are moved with memchr/memcpy. */
 static int read_record(rd_t *r, int *last, str_t *name, str_t *seq)
 {
 	int c;
-	if (*last == 0) {
-		while ((c = rd_getc(r)) >= 0 && c != '>' && c != '@') {}
+	if (*last == 0) { /* find the next record: a marker at the start of a line */
+		while ((c = rd_getc(r)) >= 0 && c != '>' && c != '@') if (c != '\n') rd_line(r, 0);
 		if (c < 0) return -1;
 		*last = c;
 	}
 	name->l = seq->l = 0;
-	while ((c = rd_getc(r)) >= 0 && !isspace(c)) str_c(name, c);
-	if (name->s == 0) str_c(name, 0), name->l = 0;
-	while (c >= 0 && c != '\n') c = rd_getc(r); /* drop the comment */
+	str_room(name, 1); str_room(seq, 1);
+	name->s[0] = seq->s[0] = 0;
+	{ /* header line: the name ends at the first white space, the comment is dropped */
+		size_t k;
+		rd_line(r, name);
+		for (k = 0; k < name->l; ++k) if (isspace((unsigned char)name->s[k])) break;
+		name->l = k, name->s[k] = 0;
+	}
 	while ((c = rd_getc(r)) >= 0 && c != '>' && c != '+' && c != '@') {
 		if (c == '\n') continue;
 		str_c(seq, c);
-		while ((c = rd_getc(r)) >= 0 && c != '\n') str_c(seq, c);
+		rd_line(r, seq);
 	}
-	if (seq->s == 0) str_c(seq, 0), seq->l = 0;
-	if (seq->l > 0 && seq->s[seq->l - 1] == '\r') seq->s[--seq->l] = 0;
 	if (c == '>' || c == '@') *last = c;
 	else *last = 0;
 	if (c == '+') { /* FASTQ: skip the '+' line and as many quality characters as bases */
 		size_t ql = 0;
-		while ((c = rd_getc(r)) >= 0 && c != '\n') {}
-		while (ql < seq->l && (c = rd_getc(r)) >= 0) if (c != '\n' && c != '\r') ++ql;
+		rd_line(r, 0);
+		while (ql < seq->l && rd_fill(r)) {
+			char *p = r->buf + r->beg, *q = (char*)memchr(p, '\n', (size_t)(r->end - r->beg));
+			size_t n = q ? (size_t)(q - p) : (size_t)(r->end - r->beg);
+			r->beg += (int)n + (q ? 1 : 0);
+			if (n > 0 && p[n - 1] == '\r') --n;
+			ql += n;
+		}
 		*last = 0;
 	}
+	return 0;
+}
+
+/* upper case + U -> T, as the reference does per base (gmap.c:81, bseq.c:50-58); branch-free so that it vectorises */
+__attribute__((optimize("O3"))) static void seq_normalize(char *s, size_t l)
+{
+	size_t k;
+	for (k = 0; k < l; ++k) {
+		unsigned char c = (unsigned char)s[k];
+		c = (unsigned char)(c - ((c == 'u') | (c == 'U')));
+		c = (unsigned char)(c - (((c >= 'a') & (c <= 'z')) << 5));
+		s[k] = (char)c;
+	}
+}
+
+/* parser check without a device: number of records, bases, and an FNV-1a hash over "name\nSEQ\n" of every record */
+int mga_reads_parse(const char *fn, int64_t *n_reads, int64_t *n_bases, uint64_t *hash)
+{
+	rd_t r;
+	int last = 0;
+	str_t name = {0, 0, 0}, seq = {0, 0, 0};
+	uint64_t h = 0xcbf29ce484222325ULL;
+	size_t k;
+	*n_reads = *n_bases = 0, *hash = 0;
+	memset(&r, 0, sizeof r);
+	r.fp = gzopen(fn, "r");
+	if (r.fp == 0) { mga_set_error("cannot open '%s'", fn); return -1; }
+	r.buf = (char*)malloc(RD_BUF);
+	while (read_record(&r, &last, &name, &seq) == 0) {
+		seq_normalize(seq.s, seq.l);
+		for (k = 0; k < name.l; ++k) h = (h ^ (unsigned char)name.s[k]) * 0x100000001b3ULL;
+		h = (h ^ '\n') * 0x100000001b3ULL;
+		for (k = 0; k < seq.l; ++k) h = (h ^ (unsigned char)seq.s[k]) * 0x100000001b3ULL;
+		h = (h ^ '\n') * 0x100000001b3ULL;
+		++*n_reads, *n_bases += (int64_t)seq.l;
+	}
+	free(name.s); free(seq.s); free(r.buf); gzclose(r.fp);
+	*hash = h;
 	return 0;
 }
 
@@ -76,15 +139,11 @@ mga_reads_t *mga_reads_load(const char *fn, int64_t max_reads)
 	memset(&r, 0, sizeof r);
 	r.fp = gzopen(fn, "r");
 	if (r.fp == 0) { mga_set_error("cannot open '%s'", fn); return 0; }
-	r.buf = (char*)malloc(1 << 20);
+	r.buf = (char*)malloc(RD_BUF);
 	rd = MGA_CALLOC(mga_reads_t, 1);
 	while ((max_reads <= 0 || rd->n < max_reads) && read_record(&r, &last, &name, &seq) == 0) {
-		size_t k;
 		if (rd->n == m) { m = m ? m << 1 : 256; rd->qlens = MGA_REALLOC(int, rd->qlens, m); rd->seqs = MGA_REALLOC(char*, rd->seqs, m); rd->names = MGA_REALLOC(char*, rd->names, m); }
-		for (k = 0; k < seq.l; ++k) {
-			if (seq.s[k] == 'u' || seq.s[k] == 'U') --seq.s[k];
-			if (seq.s[k] >= 'a' && seq.s[k] <= 'z') seq.s[k] -= 32;
-		}
+		seq_normalize(seq.s, seq.l);
 		rd->seqs[rd->n] = (char*)malloc(seq.l + 1); memcpy(rd->seqs[rd->n], seq.s, seq.l + 1);
 		rd->names[rd->n] = (char*)malloc(name.l + 1); memcpy(rd->names[rd->n], name.s, name.l + 1);
 		rd->qlens[rd->n++] = (int)seq.l;
@@ -125,62 +184,141 @@ int mga_map_reads(const mg_idx_t *gi, const mga_reads_t *rd, const mg_mapopt_t *
 	return mga_map_gaf(gi, rd->n, rd->qlens, (const char**)rd->seqs, (const char**)rd->names, opt, n_threads, rd->d_seq, rd->q_off, gaf, gaf_len);
 }
 
-int mg_map_files_fp(gfa_t *g, int n_fn, const char **fn, const mg_idxopt_t *ipt, const mg_mapopt_t *opt0, int n_threads, FILE *out)
+/* ---- mg_map_files (gmap.c:163-211): read -> map -> write as three overlapped stages, like the reference's kt_pipeline
+ * (gmap.c:70-141).  A reader thread parses mini-batches of opt->mini_batch_size bases, the calling thread maps them and
+ * gets the GAF text of the batch in one buffer (cg:Z / ds:Z written by the device), a writer thread writes it out. ---- */
+#include <pthread.h>
+
+typedef struct {
+	int n, m;
+	int *qlens;
+	char **seqs, **names;
+	str_t slab;              /* "name\0SEQ\0" of every record, back to back */
+	size_t *name_off, *seq_off;
+} fbatch_t;
+
+#define CHAN_CAP 4
+typedef struct { pthread_mutex_t m; pthread_cond_t c; void *item[CHAN_CAP]; int n, cap, closed; } chan_t; /* small bounded queue */
+static void chan_init(chan_t *c, int cap) { pthread_mutex_init(&c->m, 0); pthread_cond_init(&c->c, 0); c->n = 0, c->cap = cap, c->closed = 0; }
+static void chan_put(chan_t *c, void *item) /* item == NULL closes the channel */
 {
-	mg_mapopt_t opt = *opt0;
-	mg_idx_t *gi;
-	int f, ret = 0;
-	kstring_t str = {0, 0, 0};
-	if ((gi = mg_index(g, ipt, n_threads, &opt)) == 0) return -1;
-	for (f = 0; f < n_fn && ret == 0; ++f) {
+	pthread_mutex_lock(&c->m);
+	if (item) { while (c->n == c->cap) pthread_cond_wait(&c->c, &c->m); c->item[c->n++] = item; }
+	else c->closed = 1;
+	pthread_cond_broadcast(&c->c);
+	pthread_mutex_unlock(&c->m);
+}
+static void *chan_get(chan_t *c) /* FIFO; NULL once closed and drained */
+{
+	void *item = 0;
+	int i;
+	pthread_mutex_lock(&c->m);
+	while (c->n == 0 && !c->closed) pthread_cond_wait(&c->c, &c->m);
+	if (c->n > 0) { item = c->item[0]; for (i = 1; i < c->n; ++i) c->item[i - 1] = c->item[i]; --c->n; pthread_cond_broadcast(&c->c); }
+	pthread_mutex_unlock(&c->m);
+	return item;
+}
+
+typedef struct { int n_fn; const char **fn; int64_t batch_bases; chan_t *out; volatile int err; } reader_t;
+
+static void fbatch_free(fbatch_t *b) { if (b) { free(b->qlens); free(b->seqs); free(b->names); free(b->slab.s); free(b->name_off); free(b->seq_off); free(b); } }
+
+static void *reader_main(void *a)
+{
+	reader_t *R = (reader_t*)a;
+	int f;
+	for (f = 0; f < R->n_fn && !R->err; ++f) {
 		rd_t r;
 		int last = 0, done = 0;
 		str_t name = {0, 0, 0}, seq = {0, 0, 0};
 		memset(&r, 0, sizeof r);
-		r.fp = fn[f] && strcmp(fn[f], "-") ? gzopen(fn[f], "r") : gzdopen(0, "r");
-		if (r.fp == 0) { if (mg_verbose >= 1) fprintf(stderr, "ERROR: failed to open file '%s'\n", fn[f]); ret = -1; break; }
-		r.buf = (char*)malloc(1 << 20);
-		while (!done && ret == 0) {
-			int n = 0, m = 0, i, *qlens = 0;
+		r.fp = R->fn[f] && strcmp(R->fn[f], "-") ? gzopen(R->fn[f], "r") : gzdopen(0, "r");
+		if (r.fp == 0) { if (mg_verbose >= 1) fprintf(stderr, "ERROR: failed to open file '%s'\n", R->fn[f]); R->err = 1; break; }
+		r.buf = (char*)malloc(RD_BUF);
+		while (!done) { /* bseq.c:61-98: records until the batch holds mini_batch_size bases */
+			fbatch_t *b = MGA_CALLOC(fbatch_t, 1);
 			int64_t size = 0;
-			char **seqs = 0, **names = 0;
-			mg_gchains_t **gcs;
-			while (size < opt.mini_batch_size) { /* bseq.c:61-98 */
-				size_t k;
+			int i;
+			while (size < R->batch_bases) {
 				if (read_record(&r, &last, &name, &seq) < 0) { done = 1; break; }
-				if (n == m) { m = m ? m << 1 : 256; qlens = MGA_REALLOC(int, qlens, m); seqs = MGA_REALLOC(char*, seqs, m); names = MGA_REALLOC(char*, names, m); }
-				for (k = 0; k < seq.l; ++k) {
-					if (seq.s[k] == 'u' || seq.s[k] == 'U') --seq.s[k];
-					if (seq.s[k] >= 'a' && seq.s[k] <= 'z') seq.s[k] -= 32;
+				if (b->n == b->m) {
+					b->m = b->m ? b->m << 1 : 1024;
+					b->qlens = MGA_REALLOC(int, b->qlens, b->m); b->name_off = MGA_REALLOC(size_t, b->name_off, b->m); b->seq_off = MGA_REALLOC(size_t, b->seq_off, b->m);
 				}
-				seqs[n] = (char*)malloc(seq.l + 1); memcpy(seqs[n], seq.s, seq.l + 1);
-				names[n] = (char*)malloc(name.l + 1); memcpy(names[n], name.s, name.l + 1);
-				qlens[n++] = (int)seq.l;
+				seq_normalize(seq.s, seq.l);
+				str_room(&b->slab, name.l + seq.l + 2);
+				b->name_off[b->n] = b->slab.l; memcpy(b->slab.s + b->slab.l, name.s, name.l + 1); b->slab.l += name.l + 1;
+				b->seq_off[b->n] = b->slab.l; memcpy(b->slab.s + b->slab.l, seq.s, seq.l + 1); b->slab.l += seq.l + 1;
+				b->qlens[b->n++] = (int)seq.l;
 				size += (int64_t)seq.l;
 			}
-			if (n == 0) break;
-			gcs = MGA_CALLOC(mg_gchains_t*, n);
-			if (mg_map_batch(gi, n, qlens, (const char**)seqs, (const char**)names, gcs, &opt, n_threads) < 0) {
-				fprintf(stderr, "[E::%s] %s\n", __func__, mga_last_error());
-				ret = -1;
-			} else {
-				for (i = 0; i < n; ++i) {
-					int32_t ql = qlens[i];
-					mg_write_gaf(&str, gi->g, gcs[i], 1, &ql, names[i], opt.flag, 0);
-					if (str.l) {
-						gi->B->st.gaf_bytes += str.l;
-						if (fwrite(str.s, 1, str.l, out) != str.l) { fprintf(stderr, "[E::%s] failed to write the results\n", __func__); ret = -1; break; }
-					}
-				}
-			}
-			for (i = 0; i < n; ++i) { mg_gchain_free(gcs[i]); free(seqs[i]); free(names[i]); }
-			free(gcs); free(seqs); free(names); free(qlens);
-			if (mg_verbose >= 3) fprintf(stderr, "[M::%s] mapped %d sequences\n", __func__, n);
+			if (b->n == 0) { fbatch_free(b); break; }
+			b->seqs = MGA_MALLOC(char*, b->n); b->names = MGA_MALLOC(char*, b->n);
+			for (i = 0; i < b->n; ++i) b->seqs[i] = b->slab.s + b->seq_off[i], b->names[i] = b->slab.s + b->name_off[i];
+			chan_put(R->out, b);
 		}
 		free(name.s); free(seq.s); free(r.buf);
 		gzclose(r.fp);
 	}
-	free(str.s);
+	chan_put(R->out, 0);
+	return 0;
+}
+
+typedef struct { char *buf; int64_t len, cap; } wbuf_t;
+typedef struct { FILE *out; chan_t *in, *back; volatile int err; } writer_t;
+
+static void *writer_main(void *a)
+{
+	writer_t *W = (writer_t*)a;
+	wbuf_t *w;
+	while ((w = (wbuf_t*)chan_get(W->in)) != 0) {
+		if (!W->err && w->len > 0 && fwrite(w->buf, 1, (size_t)w->len, W->out) != (size_t)w->len) { fprintf(stderr, "[E::%s] failed to write the results\n", __func__); W->err = 1; }
+		chan_put(W->back, w); /* the buffer goes back to the mapper, which swaps it into the index for the batch after next */
+	}
+	return 0;
+}
+
+int mga_map_gaf(const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, const mg_mapopt_t *opt, int n_threads,
+				const char *d_seq, const int64_t *q_off, char **gaf, int64_t *gaf_len);
+
+int mg_map_files_fp(gfa_t *g, int n_fn, const char **fn, const mg_idxopt_t *ipt, const mg_mapopt_t *opt0, int n_threads, FILE *out)
+{
+	mg_mapopt_t opt = *opt0;
+	mg_idx_t *gi;
+	int ret = 0, n_spare = 2, k;
+	chan_t c_in, c_out, c_back;
+	reader_t R;
+	writer_t W;
+	wbuf_t wb[2];
+	pthread_t t_rd, t_wr;
+	fbatch_t *b;
+	if ((gi = mg_index(g, ipt, n_threads, &opt)) == 0) return -1;
+	chan_init(&c_in, 1); chan_init(&c_out, 1); chan_init(&c_back, CHAN_CAP); /* one parsed batch ahead, one batch being written; returned buffers never block the writer */
+	memset(wb, 0, sizeof wb);
+	R.n_fn = n_fn, R.fn = fn, R.batch_bases = opt.mini_batch_size, R.out = &c_in, R.err = 0;
+	W.out = out, W.in = &c_out, W.back = &c_back, W.err = 0;
+	pthread_create(&t_rd, 0, reader_main, &R);
+	pthread_create(&t_wr, 0, writer_main, &W);
+	while ((b = (fbatch_t*)chan_get(&c_in)) != 0) {
+		char *gaf = 0;
+		int64_t gaf_len = 0;
+		wbuf_t *w;
+		if (ret == 0 && mga_map_gaf(gi, b->n, b->qlens, (const char**)b->seqs, (const char**)b->names, &opt, n_threads, 0, 0, &gaf, &gaf_len) < 0) {
+			fprintf(stderr, "[E::%s] %s\n", __func__, mga_last_error());
+			ret = -1;
+		}
+		if (ret == 0 && !W.err) { /* hand the index's output buffer to the writer and give the index a spare one in exchange */
+			w = n_spare > 0 ? &wb[--n_spare] : (wbuf_t*)chan_get(&c_back);
+			{ char *t = gi->B->gaf_out; int64_t tc = gi->B->gaf_cap; gi->B->gaf_out = w->buf, gi->B->gaf_cap = w->cap; w->buf = t, w->cap = tc, w->len = gaf_len; }
+			chan_put(&c_out, w);
+		}
+		if (mg_verbose >= 3) fprintf(stderr, "[M::%s] mapped %d sequences\n", __func__, b->n);
+		fbatch_free(b);
+	}
+	chan_put(&c_out, 0);
+	pthread_join(t_rd, 0); pthread_join(t_wr, 0);
+	if (R.err || W.err) ret = -1;
+	for (k = 0; k < 2; ++k) if (wb[k].buf != gi->B->gaf_out) free(wb[k].buf);
 	mg_idx_destroy(gi);
 	return ret;
 }
