@@ -223,7 +223,7 @@ extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_
 			if (mga_dev_wfa_tier(sc, cnt[t], L[cur] + off[t], d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, t, rt) < 0) return -1;
 		}
 		if (mga_wfa_join(sc) < 0) return -1;
-		if (pass == 0 && bulk_done) { // the narrow tiers carry >95 % of the work: once they are done the caller may let the next chunk's
+		if (pass == 0 && bulk_done && !mga_wfa_tiers_serial()) { // the narrow tiers carry >95 % of the work: once they are done the caller may let the next chunk's
 			// WFA phase start; the long tails of the wide tiers and the retry passes then overlap with it instead of idling the GPU
 			struct timespec ts = { 0, 50000 };
 			for (int t = 0; t < 4; ++t)

@@ -775,7 +775,7 @@ static int map_all(const mg_idx_t *gi, int n, const int *qlens, const char **seq
 	int i, n_pipe = env_int("MGA_PIPE", 4), n_chunks;
 	if (n <= 0) return 0;
 	if (mga_dev_init() < 0) return -1;
-	if (g_dbg_pipe < 0) { g_dbg_pipe = env_int("MGA_DEBUG_PIPE", 0); g_gpu_wfa.avail = env_int("MGA_WFA_SLOTS", 1); }
+	if (g_dbg_pipe < 0) { g_dbg_pipe = env_int("MGA_DEBUG_PIPE", 0); g_gpu_wfa.avail = env_int("MGA_WFA_SLOTS", 2); /* two chunks may be in their WFA phase: the second one fills the tails of the first */ }
 	g_cpu_on = g_dbg_pipe > 0;
 	if (g_cpu_on) memset((void*)g_cpu_ns, 0, sizeof g_cpu_ns);
 	g_job_t0 = mga_wtime();

@@ -45,7 +45,8 @@ typedef struct mga_sctx_s {
 	void *ev_sync;             /* event behind mga_ssync() */
 	void *stage;               /* pinned staging for small device-to-host read-backs, delivered by mga_ssync() */
 } mga_sctx_t;
-void *mga_wfa_stream(mga_sctx_t *sc, int slot);       /* stream of WFA tier `slot` */
+void *mga_wfa_stream(mga_sctx_t *sc, int slot);       /* stream of WFA tier `slot` (the context's own stream unless MGA_WFA_CONCURRENT=1) */
+int mga_wfa_tiers_serial(void);
 int mga_wfa_fork(mga_sctx_t *sc);                     /* tier streams wait for everything queued on sc->stream so far */
 int mga_wfa_join(mga_sctx_t *sc);                     /* sc->stream waits for every tier stream */
 mga_sctx_t *mga_sctx_create(void);
