@@ -148,3 +148,61 @@ def test_parity_sweep_vs_reference_binary(tag, simargs, cigar):
     if open(ref_out, "rb").read() != got:
         open(os.path.join(d, "got.gaf"), "wb").write(got)
         raise AssertionError(tag + ": " + first_diff(ref_out, os.path.join(d, "got.gaf")))
+
+
+def test_edge_case_reads_vs_reference_binary():
+    """the shapes the reference's own callers have to survive: empty and tiny reads, reads without a single
+    minimizer hit, runs of N, lower case, U, FASTQ input, duplicated names"""
+    if not os.path.exists(rb.REF_BIN):
+        pytest.skip("oracle/_ref/minigraph not present")
+    import random
+    rng = random.Random(17)
+    human = b"".join(l.strip() for l in open(os.path.join(GOLD, "MT-human.fa"), "rb") if not l.startswith(b">")).upper()
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+
+    def noisy(s, e):
+        out = bytearray()
+        for ch in s:
+            r = rng.random()
+            if r < e * 0.4:
+                out.append(rng.choice(b"ACGT"))
+            elif r < e * 0.7:
+                out.append(ch); out.append(rng.choice(b"ACGT"))
+            elif r < e:
+                pass
+            else:
+                out.append(ch)
+        return bytes(out)
+
+    recs = [
+        (b"empty", b""),
+        (b"tiny", human[100:110]),
+        (b"below_k", human[200:216]),
+        (b"allN", b"N" * 500),
+        (b"random", bytes(rng.choice(b"ACGT") for _ in range(5000))),
+        (b"clean", human[1000:6000]),
+        (b"noisy", noisy(human[2000:9000], 0.12)),
+        (b"revcomp", noisy(human[3000:8000], 0.1).translate(comp)[::-1]),
+        (b"withN", noisy(human[500:3000], 0.05) + b"N" * 40 + noisy(human[3040:7000], 0.05)),
+        (b"lower", noisy(human[4000:9000], 0.08).lower()),
+        (b"rna", noisy(human[6000:9000], 0.05).replace(b"T", b"U")),
+        (b"clean", human[7000:12000]),                       # duplicated name
+        (b"chimera", noisy(human[1000:4000], 0.05) + noisy(human[9000:12000], 0.05).translate(comp)[::-1]),
+        (b"long", noisy(human, 0.1)),
+    ]
+    d = tempfile.mkdtemp()
+    fa, fq = os.path.join(d, "e.fa"), os.path.join(d, "e.fq")
+    with open(fa, "wb") as f:
+        for n, s in recs:
+            f.write(b">" + n + b" comment\n" + b"\n".join(s[k:k + 70] for k in range(0, len(s), 70)) + b"\n")
+    with open(fq, "wb") as f:
+        for n, s in recs:
+            f.write(b"@" + n + b"\n" + s + b"\n+\n" + b"I" * len(s) + b"\n")
+    graph = os.path.join(GOLD, "MT.gfa")
+    for reads in (fa, fq):
+        for cigar in (True, False):
+            ref_out, got = os.path.join(d, "ref.gaf"), os.path.join(d, "got.gaf")
+            run_ref((["-c"] if cigar else []) + ["-x", "lr", "-t", "2", graph, reads], ref_out)
+            mga.map_files(graph, [reads], got, cigar=cigar)
+            if open(ref_out, "rb").read() != open(got, "rb").read():
+                raise AssertionError("%s cigar=%s: %s" % (os.path.basename(reads), cigar, first_diff(ref_out, got)))
