@@ -42,32 +42,45 @@ static int cmp_u64(const void *a, const void *b)
 
 /* the host-visible part of the index handle: parameters + both orientations of every segment
  * (gfa_edseq_init, gfa-ed.c:24-42).  No device work; mg_index() completes it with the minimizer table. */
-mg_idx_t *mga_idx_hostpart(gfa_t *g, const mg_idxopt_t *io)
+static void upper_worker(void *data, int64_t s, int tid) /* uppercase in place, index.c:215-220 */
+{
+	gfa_seg_t *p = &((gfa_t*)data)->seg[s];
+	int32_t q;
+	(void)tid;
+	if (p->seq) for (q = 0; q < p->len; ++q) { unsigned char c = (unsigned char)p->seq[q]; p->seq[q] = (char)(c - (((c >= 'a') & (c <= 'z')) << 5)); }
+}
+
+typedef struct { const gfa_t *g; gfa_edseq_t *es; } esw_t;
+static void edseq_worker(void *data, int64_t s, int tid) /* both orientations of a segment, gfa_edseq_init (gfa-ed.c:24-42) */
+{
+	esw_t *w = (esw_t*)data;
+	const gfa_seg_t *p = &w->g->seg[s];
+	char *t = (char*)malloc((size_t)p->len + 1);
+	int32_t q;
+	(void)tid;
+	for (q = 0; q < p->len; ++q) t[p->len - q - 1] = (char)mga_comp_table[(uint8_t)p->seq[q]];
+	t[p->len] = 0;
+	w->es[s<<1].seq = p->seq, w->es[s<<1|1].seq = t;
+	w->es[s<<1].len = w->es[s<<1|1].len = p->len;
+}
+
+mg_idx_t *mga_idx_hostpart_mt(gfa_t *g, const mg_idxopt_t *io, int n_threads)
 {
 	mg_idx_t *gi = MGA_CALLOC(mg_idx_t, 1);
 	gfa_edseq_t *es = MGA_MALLOC(gfa_edseq_t, (size_t)g->n_seg * 2 + 1);
-	uint32_t s;
-	int k = io->k, w = io->w, b = io->bucket_bits;
+	esw_t w;
+	int k = io->k, wd = io->w, b = io->bucket_bits;
 	mga_tables_init();
 	if (k * 2 < b) b = k * 2; /* mg_idx_init, index.c:19-29 */
-	if (w < 1) w = 1;
-	for (s = 0; s < g->n_seg; ++s) { /* uppercase in place, index.c:215-220 */
-		gfa_seg_t *p = &g->seg[s];
-		int32_t q;
-		if (p->seq) for (q = 0; q < p->len; ++q) if (p->seq[q] >= 'a' && p->seq[q] <= 'z') p->seq[q] -= 32;
-	}
-	for (s = 0; s < g->n_seg; ++s) {
-		const gfa_seg_t *p = &g->seg[s];
-		char *t = (char*)malloc((size_t)p->len + 1);
-		int32_t q;
-		for (q = 0; q < p->len; ++q) t[p->len - q - 1] = (char)mga_comp_table[(uint8_t)p->seq[q]];
-		t[p->len] = 0;
-		es[s<<1].seq = p->seq, es[s<<1|1].seq = t;
-		es[s<<1].len = es[s<<1|1].len = p->len;
-	}
-	gi->g = g, gi->w = w, gi->k = k, gi->b = b, gi->n_seg = (int32_t)g->n_seg, gi->es = es, gi->B = 0;
+	if (wd < 1) wd = 1;
+	mga_parallel_for(n_threads, g->n_seg, upper_worker, g);
+	w.g = g, w.es = es;
+	mga_parallel_for(n_threads, g->n_seg, edseq_worker, &w);
+	gi->g = g, gi->w = wd, gi->k = k, gi->b = b, gi->n_seg = (int32_t)g->n_seg, gi->es = es, gi->B = 0;
 	return gi;
 }
+
+mg_idx_t *mga_idx_hostpart(gfa_t *g, const mg_idxopt_t *io) { return mga_idx_hostpart_mt(g, io, 1); }
 
 mg_idx_t *mg_index(gfa_t *g, const mg_idxopt_t *io, int n_threads, mg_mapopt_t *mo)
 {
@@ -90,11 +103,7 @@ mg_idx_t *mg_index(gfa_t *g, const mg_idxopt_t *io, int n_threads, mg_mapopt_t *
 			if (mg_verbose >= 1) fprintf(stderr, "[E::%s] minigraph doesn't work with graphs containing overlapping segments\n", __func__);
 			return 0;
 		}
-	for (s = 0; s < g->n_seg; ++s) { /* uppercase in place, index.c:215-220 */
-		gfa_seg_t *p = &g->seg[s];
-		int32_t q;
-		if (p->seq) for (q = 0; q < p->len; ++q) if (p->seq[q] >= 'a' && p->seq[q] <= 'z') p->seq[q] -= 32;
-	}
+	mga_parallel_for(n_threads, g->n_seg, upper_worker, g);
 	if (k * 2 < b) b = k * 2; /* mg_idx_init, index.c:19-29 */
 	if (w < 1) w = 1;
 
@@ -109,6 +118,31 @@ mg_idx_t *mg_index(gfa_t *g, const mg_idxopt_t *io, int n_threads, mg_mapopt_t *
 	off[g->n_seg] = tot;
 	cat = (char*)malloc((size_t)tot + 1);
 	for (s = 0; s < g->n_seg; ++s) if (g->seg[s].seq) memcpy(cat + off[s], g->seg[s].seq, (size_t)g->seg[s].len);
+	if (!(getenv("MGA_HOST_INDEX") && atoi(getenv("MGA_HOST_INDEX")) > 0)) { /* the whole build on the device (k_index.hip); MGA_HOST_INDEX=1 keeps the host build below (A/B) */
+		mga_sctx_t *sc = mga_sctx_default();
+		free(rid);
+		B = MGA_CALLOC(struct mg_idx_bucket_s, 1);
+		B->dev.n_seg = (int32_t)g->n_seg;
+		B->dev.d_seg_len = (int32_t*)mga_dmalloc((size_t)(g->n_seg + 1) * 4);
+		B->dev.d_gseq = (char*)mga_dmalloc((size_t)tot + 64);
+		B->dev.d_gseq_off = (int64_t*)mga_dmalloc((size_t)(g->n_seg + 1) * 8);
+		if (sc == 0 || !B->dev.d_seg_len || !B->dev.d_gseq || !B->dev.d_gseq_off ||
+			mga_h2d(B->dev.d_seg_len, seg_len, (size_t)g->n_seg * 4) < 0 || mga_h2d(B->dev.d_gseq, cat, (size_t)tot) < 0 || mga_dmemset((char*)B->dev.d_gseq + tot, 0, 64) < 0 ||
+			mga_h2d(B->dev.d_gseq_off, off, (size_t)(g->n_seg + 1) * 8) < 0 || mga_dev_text_tables(mga_comp_table, mga_nt4_table) < 0 ||
+			mga_dev_index_build(sc, (int)g->n_seg, B->dev.d_gseq, B->dev.d_gseq_off, w, k, &B->dev, &B->n_keys, &B->n_mz, &B->occ_hist, &B->max_occ_seen) < 0) {
+			mga_dfree(B->dev.d_seg_len); mga_dfree(B->dev.d_gseq); mga_dfree(B->dev.d_gseq_off);
+			free(off); free(seg_len); free(cat); free(B);
+			return 0;
+		}
+		free(off); free(seg_len); free(cat);
+		gi = mga_idx_hostpart_mt(g, io, n_threads);
+		gi->B = B;
+		if (mg_verbose >= 3)
+			fprintf(stderr, "[M::%s::%.3f] indexed the graph on the device: %ld minimizers, %ld distinct, table 2^%d slots\n", __func__, mga_wtime() - t0, (long)B->n_mz, (long)B->n_keys, B->dev.bits);
+		(void)n_threads;
+		if (mo) mg_opt_update(gi, mo, 0);
+		return gi;
+	}
 	if (mga_sketch_batch((int)g->n_seg, cat, off, rid, w, k, &mz, &mz_off) < 0) { free(off); free(rid); free(seg_len); free(cat); return 0; }
 	free(rid);
 	n_mz = mz_off[g->n_seg];

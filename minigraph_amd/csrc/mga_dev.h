@@ -143,6 +143,11 @@ int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_prob, const
 					  mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int64_t *cells,
 					  void (*bulk_done)(void*), void *bulk_arg); /* bulk_done (optional): called once the tiers of <= 512 diagonals finished their first pass */
 
+/* the whole minimizer index of the graph on the device (k_index.hip): sketch of the n_seg segments in d_seq/d_off, sort, table, position lists;
+ * fills ix->d_tab/d_pos/n_slots/bits/n_pos; the host gets the counters and the occurrence histogram (malloc'ed) */
+int mga_dev_index_build(mga_sctx_t *sc, int n_seg, const char *d_seq, const int64_t *d_off, int w, int k, mga_didx_t *ix,
+						int64_t *h_n_keys, int64_t *h_n_mz, int64_t **h_occ_hist, int64_t *h_max_occ);
+
 /* ---- alignment text on the device (k_text.hip): stitched CIGAR statistics + cg:Z / ds:Z strings of a chain ---- */
 typedef struct { int32_t op, val; } mga_cigitem_t; /* op >= 0: ready operator (op, len = val); op == -1: WFA problem #val of this read's pool */
 typedef struct {

@@ -206,3 +206,21 @@ def test_edge_case_reads_vs_reference_binary():
             mga.map_files(graph, [reads], got, cigar=cigar)
             if open(ref_out, "rb").read() != open(got, "rb").read():
                 raise AssertionError("%s cigar=%s: %s" % (os.path.basename(reads), cigar, first_diff(ref_out, got)))
+
+
+def test_device_index_build_equals_host_build(monkeypatch):
+    """mg_index builds the minimizer table on the device (k_index.hip: sketch -> stable radix sort -> CAS insertion);
+    MGA_HOST_INDEX=1 keeps the sequential host build: same occurrence thresholds, same mapping bytes"""
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "8000000", "-H", "4", "-n", "600", "-s", "41"], stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    out = {}
+    for host in ("0", "1"):
+        monkeypatch.setenv("MGA_HOST_INDEX", host)
+        G = mga.Graph(graph, preset="lr", cigar=True, n_threads=8)
+        R = mga.Reads(reads)
+        out[host] = (G.mo.occ_max1, G.mo.max_lc_skip, mga.map_reads(G, R, n_threads=8))
+        R.close()
+        G.close()
+    assert out["0"][:2] == out["1"][:2]
+    assert out["0"][2] == out["1"][2] and out["0"][2].count(b"\n") >= 600
