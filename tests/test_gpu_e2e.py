@@ -224,3 +224,33 @@ def test_device_index_build_equals_host_build(monkeypatch):
         G.close()
     assert out["0"][:2] == out["1"][:2]
     assert out["0"][2] == out["1"][2] and out["0"][2].count(b"\n") >= 600
+
+
+@pytest.mark.parametrize("preset", ["lr", "asm"])
+@pytest.mark.parametrize("query", ["MT-human.fa", "MT-chimp.fa", "MT-orangA.fa"])
+def test_reference_fixtures_both_presets(preset, query):
+    """the reference's own fixtures (test/MT*.fa vs test/MT.gfa) under -x lr and -x asm (RMQ chainer as the primary chainer,
+    lchain.c:252-372), with and without base alignment"""
+    if not os.path.exists(rb.REF_BIN):
+        pytest.skip("oracle/_ref/minigraph not present")
+    d = tempfile.mkdtemp()
+    for cigar in (True, False):
+        ref_out, got = os.path.join(d, "ref.gaf"), os.path.join(d, "got.gaf")
+        run_ref((["-c"] if cigar else []) + ["-x", preset, "-t", "2", os.path.join(GOLD, "MT.gfa"), os.path.join(GOLD, query)], ref_out)
+        mga.map_files(os.path.join(GOLD, "MT.gfa"), [os.path.join(GOLD, query)], got, preset=preset, cigar=cigar)
+        if open(ref_out, "rb").read() != open(got, "rb").read():
+            raise AssertionError("%s %s cigar=%s: %s" % (preset, query, cigar, first_diff(ref_out, got)))
+
+
+def test_asm_preset_long_contigs_vs_reference_binary():
+    """-cx asm on assembly-like queries: 300 kb contigs with 0.5 % divergence against the bubble graph"""
+    if not os.path.exists(rb.REF_BIN):
+        pytest.skip("oracle/_ref/minigraph not present")
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "6000000", "-H", "3", "-n", "30", "-l", "300000", "-e", "0.005", "-s", "51"], stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    ref_out, got = os.path.join(d, "ref.gaf"), os.path.join(d, "got.gaf")
+    run_ref(["-c", "-x", "asm", "-t", "8", graph, reads], ref_out)
+    mga.map_files(graph, [reads], got, preset="asm", cigar=True)
+    if open(ref_out, "rb").read() != open(got, "rb").read():
+        raise AssertionError(first_diff(ref_out, got))
