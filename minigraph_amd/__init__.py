@@ -246,6 +246,46 @@ def map_files(graph_path, read_paths, out_path, preset="lr", cigar=True, n_threa
         raise RuntimeError("mapping failed: %s" % L.mga_last_error().decode())
 
 
+class kstring_t(C.Structure):
+    _fields_ = [("l", C.c_uint), ("m", C.c_uint), ("s", C.c_void_p)]
+
+
+def map_batch_api(graph, names, seqs, n_threads=4, per_read=False):
+    """The reference-shaped C API, as a caller of minigraph.h would use it: mg_map_batch() (or mg_map() read by read when
+    per_read=True) -> mg_gchains_t objects -> mg_write_gaf() per read -> mg_gchain_free().  Returns the GAF bytes."""
+    L = load()
+    n = len(seqs)
+    L.mg_map.restype = C.c_void_p
+    L.mg_tbuf_init.restype = C.c_void_p
+    L.mg_map.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.POINTER(mapopt_t), C.c_char_p]
+    L.mg_map_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_void_p),
+                               C.POINTER(mapopt_t), C.c_int]
+    L.mg_write_gaf.argtypes = [C.POINTER(kstring_t), C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_char_p, C.c_uint64, C.c_void_p]
+    L.mg_write_gaf.restype = None
+    L.mg_gchain_free.argtypes = [C.c_void_p]
+    L.mg_gchain_free.restype = None
+    L.mg_tbuf_destroy.argtypes = [C.c_void_p]
+    gcs = (C.c_void_p * n)()
+    if per_read:
+        tb = L.mg_tbuf_init()
+        for i in range(n):
+            gcs[i] = L.mg_map(graph.gi, len(seqs[i]), seqs[i], tb, C.byref(graph.mo), names[i])
+        L.mg_tbuf_destroy(tb)
+    else:
+        qlens = (C.c_int * n)(*[len(s) for s in seqs])
+        sp, npp = (C.c_char_p * n)(*seqs), (C.c_char_p * n)(*names)
+        _check(L.mg_map_batch(graph.gi, n, qlens, sp, npp, gcs, C.byref(graph.mo), n_threads), "mg_map_batch")
+    out, ks = [], kstring_t(0, 0, None)
+    for i in range(n):
+        ql = C.c_int32(len(seqs[i]))
+        L.mg_write_gaf(C.byref(ks), graph.g, gcs[i], 1, C.byref(ql), names[i], graph.mo.flag, None)
+        if ks.l:
+            out.append(C.string_at(ks.s, ks.l))
+        L.mg_gchain_free(gcs[i])
+    L.mga_free(ks.s)
+    return b"".join(out)
+
+
 class Reads:
     """mga_reads_load(): a read set resident in host memory and HBM"""
 

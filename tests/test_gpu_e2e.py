@@ -254,3 +254,30 @@ def test_asm_preset_long_contigs_vs_reference_binary():
     mga.map_files(graph, [reads], got, preset="asm", cigar=True)
     if open(ref_out, "rb").read() != open(got, "rb").read():
         raise AssertionError(first_diff(ref_out, got))
+
+
+def test_reference_shaped_c_api_mg_map_and_mg_map_batch():
+    """what a caller of minigraph.h does: mg_map_batch() / mg_map() -> mg_gchains_t -> mg_write_gaf() ->
+    mg_gchain_free(); CIGAR stitching and ds run on the host on this path.  Same bytes as the GAF-only path and the reference"""
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "3000000", "-H", "3", "-n", "300", "-s", "61"], stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    names, seqs = [], []
+    for line in open(reads, "rb"):
+        if line.startswith(b">"):
+            names.append(line[1:].split()[0])
+        else:
+            seqs.append(line.strip())
+    G = mga.Graph(graph, preset="lr", cigar=True, n_threads=8)
+    R = mga.Reads(reads)
+    want = mga.map_reads(G, R, n_threads=8)
+    R.close()
+    batch = mga.map_batch_api(G, names, seqs, n_threads=8)
+    single = mga.map_batch_api(G, names[:40], seqs[:40], per_read=True)
+    G.close()
+    assert batch == want
+    assert single == b"".join(want.split(b"\n")[k] + b"\n" for k in range(40))
+    if os.path.exists(rb.REF_BIN):
+        ref_out = os.path.join(d, "ref.gaf")
+        run_ref(["-c", "-x", "lr", "-t", "4", graph, reads], ref_out)
+        assert open(ref_out, "rb").read() == batch
