@@ -181,6 +181,8 @@ int mga_map_gaf(const mg_idx_t *gi, int n, const int *qlens, const char **seqs, 
 int mga_map_reads(const mg_idx_t *gi, const mga_reads_t *rd, const mg_mapopt_t *opt, int n_threads, char **gaf, int64_t *gaf_len)
 {
 	if (n_threads < 1) n_threads = 1;
+	if (getenv("MGA_UPLOAD_READS") && atoi(getenv("MGA_UPLOAD_READS")) > 0) /* measurement aid: ignore the resident copy, upload the reads chunk by chunk (the PCIe-inclusive rate) */
+		return mga_map_gaf(gi, rd->n, rd->qlens, (const char**)rd->seqs, (const char**)rd->names, opt, n_threads, 0, 0, gaf, gaf_len);
 	return mga_map_gaf(gi, rd->n, rd->qlens, (const char**)rd->seqs, (const char**)rd->names, opt, n_threads, rd->d_seq, rd->q_off, gaf, gaf_len);
 }
 
