@@ -89,6 +89,7 @@ extern "C" int mga_dev_index_build(mga_sctx_t *sc, int n_seg, const char *d_seq,
 	IDX_CK(mga_dev_sketch(sc, n_seg, d_seq, d_off, (const uint32_t*)d_rid, w, k, (int32_t*)d_cnt, 0, 0));
 	IDX_CK(mga_dev_scan_i32_to_i64(sc, (const int32_t*)d_cnt, n_seg, (int64_t*)d_mzoff));
 	IDX_CK(mga_d2h_s(sc, &n_mz, (int64_t*)d_mzoff + n_seg, 8)); IDX_CK(mga_ssync(sc));
+	if (n_mz >= 0xffffffffLL) { mga_set_error("index build: %lld minimizers do not fit the 32-bit list offsets of the table", (long long)n_mz); goto done; }
 	IDX_ALLOC(d_mz, (size_t)n_mz * 16 + 16);
 	IDX_CK(mga_dev_sketch(sc, n_seg, d_seq, d_off, (const uint32_t*)d_rid, w, k, 0, (const int64_t*)d_mzoff, (mg128_t*)d_mz));
 	IDX_ALLOC(d_key, (size_t)n_mz * 8 + 8); IDX_ALLOC(d_val, (size_t)n_mz * 8 + 8); IDX_ALLOC(d_key2, (size_t)n_mz * 8 + 8); IDX_ALLOC(d_val2, (size_t)n_mz * 8 + 8);
