@@ -38,13 +38,14 @@ struct wfr_u2 { uint32_t x, y; }; // 8 bytes with 4-byte alignment: loads become
 
 __device__ __forceinline__ int32_t wfr_max(int32_t a, int32_t b) { return a > b ? a : b; }
 
-template<int NW, int J, int SEQCAP, int SMAX, int TBLDS>
+template<int NW, int J, int SEQCAP, int SMAX, int TBLDS, bool TBHBM>
 __global__ void __launch_bounds__(64 * NW) k_wfa_r(int n_items, const int32_t *__restrict__ list,
 												  const mga_wfa_prob_t *__restrict__ prob, const char *__restrict__ tseq, const char *__restrict__ qseq,
 												  mga_wfa_res_t *__restrict__ res, uint32_t *__restrict__ pool, long long pool_cap, unsigned long long *pool_used,
 												  char *__restrict__ ws_base, int *__restrict__ counter, mga_wfa_retry_t rt, wfr_cfg_t cfg)
 {
 	constexpr int NV = 64 * J * NW; // diagonals covered by the workgroup
+	constexpr bool TRIM = SMAX >= 256; // the reference trims the band every 256 scores (miniwfa.c:139-169): tiers that stop earlier need none of it
 	constexpr int NT = 64 * NW;
 	// each sequence is staged four times, copy k shifted left by k bytes: any byte position is then dword-aligned in copy
 	// (pos & 3), and 8 bytes come from one ds_read2_b32 (an off-alignment ds_read_b64 is replayed at ~64 cycles)
@@ -65,7 +66,7 @@ __global__ void __launch_bounds__(64 * NW) k_wfa_r(int n_items, const int32_t *_
 	char *wsb = ws_base + (size_t)blockIdx.x * cfg.ws_stride;
 	uint32_t *cig = (uint32_t*)wsb;
 	uint8_t *tbg = (uint8_t*)(cig + cfg.cigcap);
-	const int32_t tbcap = TBLDS + cfg.tbcap;
+	const int32_t tbcap = TBLDS + (TBHBM ? cfg.tbcap : 0); // TBHBM false: the whole traceback fits LDS, no spill path is compiled
 #define WFR_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory") /* LDS-only barrier: HBM traceback stores keep flying */
 #define WFR_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
@@ -180,7 +181,7 @@ __global__ void __launch_bounds__(64 * NW) k_wfa_r(int n_items, const int32_t *_
 				if (NW == 1 && !fits) { status = MGA_WFA_RETRY_TIER; break; }
 				bool reach_lo = false, reach_hi = false; // uniform
 				if (fits) {
-					const bool track_alive = ((s + 1) & 0xff) >= 239 || ((s + 1) & 0xff) == 0; // the trimming at score 256k looks back 17 scores only
+					const bool track_alive = TRIM && (((s + 1) & 0xff) >= 239 || ((s + 1) & 0xff) == 0); // the trimming at score 256k looks back 17 scores only
 					if (tid == 0) { row[s + 1] = tb_used; rlo[s + 1] = (int16_t)nlo; }
 					int32_t eL[4], eR[4]; // what the neighbouring waves published after the previous step
 					if (NW > 1) {
@@ -219,7 +220,7 @@ __global__ void __launch_bounds__(64 * NW) k_wfa_r(int n_items, const int32_t *_
 						TBC[j] = (int32_t)tbv;
 						if (inb) {
 							const int32_t off = tb_used + (int32_t)rel;
-							if (off < TBLDS) tb_lds[off] = (uint8_t)tbv;
+							if (!TBHBM || off < TBLDS) tb_lds[off] = (uint8_t)tbv;
 							else tbg[off - TBLDS] = (uint8_t)tbv;
 						}
 						const int32_t top = wfr_max(wfr_max(wfr_max(vH, vE1), wfr_max(vF1, vE2)), vF2);
@@ -266,7 +267,7 @@ __global__ void __launch_bounds__(64 * NW) k_wfa_r(int n_items, const int32_t *_
 				clo = nlo, chi = nhi;
 				if (reach_lo) wlo = nlo;
 				if (reach_hi) whi = nhi;
-				if ((s & 0xff) == 0) { // trimming (miniwfa.c:139-169): keep [first, last] diagonal that was in the matrix during the last 17 scores
+				if (TRIM && (s & 0xff) == 0) { // trimming (miniwfa.c:139-169): keep [first, last] diagonal that was in the matrix during the last 17 scores
 					int32_t mn = 0x7fffffff, mx = -0x7fffffff;
 #pragma unroll
 					for (int j = 0; j < J; ++j) {
@@ -322,7 +323,7 @@ __global__ void __launch_bounds__(64 * NW) k_wfa_r(int n_items, const int32_t *_
 						if (i < 0 || k < 0) break;
 					}
 					const int32_t off = row[sc] + ((i - k) - (int32_t)rlo[sc]);
-					const uint32_t x = off < TBLDS ? tb_lds[off] : tbg[off - TBLDS];
+					const uint32_t x = (!TBHBM || off < TBLDS) ? tb_lds[off] : tbg[off - TBLDS];
 					const int32_t state = last == 0 ? (int32_t)(x & 7) : last;
 					const int32_t ext = state > 0 ? (int32_t)(x >> (state + 2) & 1) : 0;
 					if (state == 0) { PUSH(8, 1); --i, --k, sc -= cfg.x; }
@@ -397,13 +398,13 @@ extern "C" int mga_dev_wfa_reg(mga_sctx_t *sc, int n, const int32_t *d_list, con
 	hipStream_t st = (hipStream_t)mga_wfa_stream(sc, tier);
 	int *d_counter = (int*)((char*)sc->wfa_cnt.p + 64 * tier);
 	mga_prof_begin(st, MGA_K_WFA0 + tier);
-#define LAUNCH(NW, JJ, SEQ, SM, TBL) hipLaunchKernelGGL((k_wfa_r<NW, JJ, SEQ, SM, TBL>), dim3(wgs), dim3(64 * NW), 0, st, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap, d_pool_used, (char*)sc->wfa_ws[tier].p, d_counter, rt, cfg)
-	if (tier == 0) LAUNCH(1, 1, 128, 64, 2048);
-	else if (tier == 1) LAUNCH(1, 2, 256, 128, 4096);
-	else if (tier == 2) LAUNCH(2, 2, 512, 512, 8192);  // [measured] 2x2 beats 4x1 (fewer waves to synchronise) and 1x4 (register pressure)
-	else if (tier == 3) LAUNCH(4, 2, 1024, 1024, 8192);
-	else if (tier == 4) LAUNCH(8, 2, 2048, 2048, 8192);
-	else LAUNCH(16, 2, 4096, 4096, 8192);
+#define LAUNCH(NW, JJ, SEQ, SM, TBL, HBM) hipLaunchKernelGGL((k_wfa_r<NW, JJ, SEQ, SM, TBL, HBM>), dim3(wgs), dim3(64 * NW), 0, st, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap, d_pool_used, (char*)sc->wfa_ws[tier].p, d_counter, rt, cfg)
+	if (tier == 0) LAUNCH(1, 1, 128, 64, 2048, false); // (g_rtier[0].tbcap == 0: traceback in LDS only)
+	else if (tier == 1) LAUNCH(1, 2, 256, 128, 4096, true);
+	else if (tier == 2) LAUNCH(2, 2, 512, 512, 8192, true);  // [measured] 2x2 beats 4x1 (fewer waves to synchronise) and 1x4 (register pressure)
+	else if (tier == 3) LAUNCH(4, 2, 1024, 1024, 8192, true);
+	else if (tier == 4) LAUNCH(8, 2, 2048, 2048, 8192, true);
+	else LAUNCH(16, 2, 4096, 4096, 8192, true);
 #undef LAUNCH
 	mga_prof_end(st, MGA_K_WFA0 + tier);
 	MGA_HIP_CHECK(hipGetLastError());
