@@ -32,14 +32,14 @@ __device__ __forceinline__ int32_t seed_probe(const mga_didx_t &ix, uint64_t key
 	}
 }
 
-__global__ void __launch_bounds__(64) k_seed_count(mga_didx_t ix, int n, const mg128_t *__restrict__ mz, const int64_t *__restrict__ mz_off, int max_occ,
+__global__ void __launch_bounds__(64) k_seed_count(mga_didx_t ix, int n, const mg128_t *__restrict__ mz, const int64_t *__restrict__ mz_off, const int32_t *__restrict__ mz_cnt, int max_occ,
 												   int32_t *__restrict__ occ, uint64_t *__restrict__ val,
 												   int32_t *__restrict__ d_na, int32_t *__restrict__ d_nmini, int32_t *__restrict__ d_rep)
 {
 	const int r = blockIdx.x, lane = threadIdx.x;
 	if (r >= n) return;
 	const int64_t base = mz_off[r];
-	const int32_t n_mz = (int32_t)(mz_off[r + 1] - base);
+	const int32_t n_mz = mz_cnt ? mz_cnt[r] : (int32_t)(mz_off[r + 1] - base); // (mz_cnt: the slots of a read are only partly filled)
 	int32_t na = 0, nmini = 0, rep_len = 0, en_prev = 0;
 	for (int32_t c0 = 0; c0 < n_mz; c0 += 64) {
 		const int32_t i = c0 + lane;
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(64) k_seed_count(mga_didx_t ix, int n, const m
 	if (lane == 0) { d_na[r] = na; d_nmini[r] = nmini; d_rep[r] = rep_len; }
 }
 
-__global__ void __launch_bounds__(64) k_seed_fill(mga_didx_t ix, int n, const mg128_t *__restrict__ mz, const int64_t *__restrict__ mz_off, int max_occ,
+__global__ void __launch_bounds__(64) k_seed_fill(mga_didx_t ix, int n, const mg128_t *__restrict__ mz, const int64_t *__restrict__ mz_off, const int32_t *__restrict__ mz_cnt, int max_occ,
 												  const int32_t *__restrict__ occ, const uint64_t *__restrict__ val,
 												  const int64_t *__restrict__ a_off, mg128_t *__restrict__ a_all,
 												  const int64_t *__restrict__ mini_off, int32_t *__restrict__ mini_all, mg128_t *__restrict__ tmp_all)
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(64) k_seed_fill(mga_didx_t ix, int n, const mg
 	const int r = blockIdx.x, lane = threadIdx.x;
 	if (r >= n) return;
 	const int64_t base = mz_off[r];
-	const int32_t n_mz = (int32_t)(mz_off[r + 1] - base);
+	const int32_t n_mz = mz_cnt ? mz_cnt[r] : (int32_t)(mz_off[r + 1] - base); // (mz_cnt: the slots of a read are only partly filled)
 	mg128_t *a = a_all + a_off[r];
 	int32_t *mini = mini_all + mini_off[r];
 	const int64_t n_a = a_off[r + 1] - a_off[r];
@@ -126,24 +126,24 @@ __global__ void __launch_bounds__(64) k_seed_fill(mga_didx_t ix, int n, const mg
 	klib_sort128x(a, n_a, (int32_t*)(tmp_all + a_off[r]), &L);
 }
 
-extern "C" int mga_dev_seed_count(mga_sctx_t *sc, const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, int max_occ,
+extern "C" int mga_dev_seed_count(mga_sctx_t *sc, const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, const int32_t *d_mz_cnt, int max_occ,
 								  int32_t *d_occ, uint64_t *d_val, int32_t *d_na, int32_t *d_nmini, int32_t *d_rep_len)
 {
 	if (n <= 0) return 0;
 	mga_prof_begin(sc->stream, MGA_K_SEED_COUNT);
-	hipLaunchKernelGGL(k_seed_count, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, *ix, n, d_mz, d_mz_off, max_occ, d_occ, d_val, d_na, d_nmini, d_rep_len);
+	hipLaunchKernelGGL(k_seed_count, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, *ix, n, d_mz, d_mz_off, d_mz_cnt, max_occ, d_occ, d_val, d_na, d_nmini, d_rep_len);
 	mga_prof_end(sc->stream, MGA_K_SEED_COUNT);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;
 }
 
-extern "C" int mga_dev_seed_fill(mga_sctx_t *sc, const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, int max_occ,
+extern "C" int mga_dev_seed_fill(mga_sctx_t *sc, const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, const int32_t *d_mz_cnt, int max_occ,
 								 const int32_t *d_occ, const uint64_t *d_val, const int64_t *d_a_off, mg128_t *d_a,
 								 const int64_t *d_mini_off, int32_t *d_mini, mg128_t *d_tmp)
 {
 	if (n <= 0) return 0;
 	mga_prof_begin(sc->stream, MGA_K_SEED_FILL);
-	hipLaunchKernelGGL(k_seed_fill, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, *ix, n, d_mz, d_mz_off, max_occ, d_occ, d_val, d_a_off, d_a, d_mini_off, d_mini, d_tmp);
+	hipLaunchKernelGGL(k_seed_fill, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, *ix, n, d_mz, d_mz_off, d_mz_cnt, max_occ, d_occ, d_val, d_a_off, d_a, d_mini_off, d_mini, d_tmp);
 	mga_prof_end(sc->stream, MGA_K_SEED_FILL);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;

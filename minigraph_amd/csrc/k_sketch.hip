@@ -14,7 +14,8 @@
 //     minimum before/after its event and derives what the reference would push at that step.
 //   * emission counts are prefix-summed across the wave so output order equals the reference's.
 //
-// Two passes over the same kernel: count (d_mz == NULL) and write.
+// Two passes over the same kernel: count (d_mz == NULL) and write -- or ONE pass when the caller provides per-read
+// capacities instead of exact offsets (the mapping pipeline: qlen/2 + 64 slots per read, ~3x the minimizer density).
 #include "mga_dev.h"
 #include "dev_common.h"
 
@@ -56,6 +57,10 @@ __global__ void __launch_bounds__(64) k_sketch(int n, const char *__restrict__ s
 	const uint64_t mask = (1ULL << 2 * k) - 1;
 	const uint64_t MAXV = ~0ULL;
 	mg128_t *out = mz ? mz + mz_off[r] : 0;
+	// single pass (cnt AND mz given): mz_off holds CAPACITIES, writes beyond the read's slots are dropped and the caller, who sees
+	// cnt[r] > capacity, falls back to count + write
+	const int cap = (mz && cnt) ? (int)(mz_off[r + 1] - mz_off[r]) : 0x7fffffff;
+#define SK_PUT(o_, x_, y_) do { if ((o_) < cap) { out[(o_)].x = (x_); out[(o_)].y = (y_); } } while (0)
 
 	// k-1 virtual "nothing yet" codes so that the first real base sits at compact index k-1
 	if (lane < k - 1) codes[lane] = 0;
@@ -137,12 +142,12 @@ __global__ void __launch_bounds__(64) k_sketch(int n, const char *__restrict__ s
 			int o = n_out + incl - tot;
 			if (c0) {
 				for (int q = (t - w + 1 < 0 ? 0 : t - w + 1); q <= t - 1; ++q)
-					if (ex[q & (SK_RING - 1)] == px && q != P) { out[o].x = px; out[o].y = ey[q & (SK_RING - 1)]; ++o; }
+					if (ex[q & (SK_RING - 1)] == px && q != P) { SK_PUT(o, px, ey[q & (SK_RING - 1)]); ++o; }
 			}
-			if (c1) { out[o].x = px; out[o].y = ey[P & (SK_RING - 1)]; ++o; }
+			if (c1) { SK_PUT(o, px, ey[P & (SK_RING - 1)]); ++o; }
 			if (c2 && moved_out) {
 				for (int q = (t - w + 1 < 0 ? 0 : t - w + 1); q <= t; ++q)
-					if (ex[q & (SK_RING - 1)] == nx && q != N) { out[o].x = nx; out[o].y = ey[q & (SK_RING - 1)]; ++o; }
+					if (ex[q & (SK_RING - 1)] == nx && q != N) { SK_PUT(o, nx, ey[q & (SK_RING - 1)]); ++o; }
 			}
 		}
 		n_out += wave_tot;
@@ -160,7 +165,7 @@ __global__ void __launch_bounds__(64) k_sketch(int n, const char *__restrict__ s
 				if (v <= nx) nx = v, N = q;
 			}
 			if (nx != MAXV) {
-				if (out) { out[n_out].x = nx; out[n_out].y = ey[N & (SK_RING - 1)]; }
+				if (out) SK_PUT(n_out, nx, ey[N & (SK_RING - 1)]);
 				++n_out;
 			}
 		}

@@ -529,20 +529,33 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 		d_seq = (const char*)P->seq.p;
 	}
 	CK(mga_h2d_s(sc, P->qoff.p, q_off, (size_t)(n + 1) * 8));
-	/* ---- sketch ---- */
+	/* ---- sketch: ONE pass into per-read slots of qlen/2 + 64 minimizers (the density is 2/(w+1), ~3x less); a read that would
+	 *      overflow its slots (never seen) sends the chunk through count + scan + write ---- */
 	CK(mga_dbuf_reserve(&P->cnt, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&P->mzoff, (size_t)(n + 1) * 8));
-	CK(mga_dev_sketch(sc, n, d_seq, (const int64_t*)P->qoff.p, 0, gi->w, gi->k, (int32_t*)P->cnt.p, 0, 0));
-	CK(mga_dev_scan_i32_to_i64(sc, (const int32_t*)P->cnt.p, n, (int64_t*)P->mzoff.p));
 	h_mzoff = MGA_MALLOC(int64_t, n + 1);
-	CK(mga_d2h_s(sc, h_mzoff, P->mzoff.p, (size_t)(n + 1) * 8)); CK(mga_ssync(sc));
-	n_mz = h_mzoff[n];
-	CK(mga_dbuf_reserve(&P->mz, (size_t)n_mz * 16 + 16));
-	CK(mga_dev_sketch(sc, n, d_seq, (const int64_t*)P->qoff.p, 0, gi->w, gi->k, 0, (const int64_t*)P->mzoff.p, (mg128_t*)P->mz.p));
+	h_nmz = MGA_MALLOC(int32_t, n);
+	{
+		int overflow = 0;
+		for (i = 0, n_mz = 0; i < n; ++i) { h_mzoff[i] = n_mz; n_mz += qlens[i] / 2 + 64; }
+		h_mzoff[n] = n_mz; /* capacity of the chunk */
+		CK(mga_h2d_s(sc, P->mzoff.p, h_mzoff, (size_t)(n + 1) * 8));
+		CK(mga_dbuf_reserve(&P->mz, (size_t)n_mz * 16 + 16));
+		CK(mga_dev_sketch(sc, n, d_seq, (const int64_t*)P->qoff.p, 0, gi->w, gi->k, (int32_t*)P->cnt.p, (const int64_t*)P->mzoff.p, (mg128_t*)P->mz.p));
+		CK(mga_d2h_s(sc, h_nmz, P->cnt.p, (size_t)n * 4)); CK(mga_ssync(sc));
+		for (i = 0; i < n; ++i) if (h_nmz[i] > qlens[i] / 2 + 64) overflow = 1;
+		if (overflow) {
+			CK(mga_dev_scan_i32_to_i64(sc, (const int32_t*)P->cnt.p, n, (int64_t*)P->mzoff.p));
+			CK(mga_d2h_s(sc, h_mzoff, P->mzoff.p, (size_t)(n + 1) * 8)); CK(mga_ssync(sc));
+			n_mz = h_mzoff[n];
+			CK(mga_dbuf_reserve(&P->mz, (size_t)n_mz * 16 + 16));
+			CK(mga_dev_sketch(sc, n, d_seq, (const int64_t*)P->qoff.p, 0, gi->w, gi->k, 0, (const int64_t*)P->mzoff.p, (mg128_t*)P->mz.p));
+		}
+	}
 	/* ---- seeds ---- */
 	CK(mga_dbuf_reserve(&P->occ, (size_t)n_mz * 4 + 4)); CK(mga_dbuf_reserve(&P->val, (size_t)n_mz * 8 + 8));
 	CK(mga_dbuf_reserve(&P->na, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&P->nmini, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&P->rep, (size_t)n * 4 + 4));
 	CK(mga_dbuf_reserve(&P->aoff, (size_t)(n + 1) * 8)); CK(mga_dbuf_reserve(&P->minioff, (size_t)(n + 1) * 8));
-	CK(mga_dev_seed_count(sc, &B->dev, n, (const mg128_t*)P->mz.p, (const int64_t*)P->mzoff.p, opt->occ_max1, (int32_t*)P->occ.p, (uint64_t*)P->val.p,
+	CK(mga_dev_seed_count(sc, &B->dev, n, (const mg128_t*)P->mz.p, (const int64_t*)P->mzoff.p, (const int32_t*)P->cnt.p, opt->occ_max1, (int32_t*)P->occ.p, (uint64_t*)P->val.p,
 						  (int32_t*)P->na.p, (int32_t*)P->nmini.p, (int32_t*)P->rep.p));
 	CK(mga_dev_scan_i32_to_i64(sc, (const int32_t*)P->na.p, n, (int64_t*)P->aoff.p));
 	CK(mga_dev_scan_i32_to_i64(sc, (const int32_t*)P->nmini.p, n, (int64_t*)P->minioff.p));
@@ -553,10 +566,8 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	t1 = mga_wtime(); st->t_sketch += t1 - t0; t0 = t1;
 	n_a = h_aoff[n], n_mini = h_minioff[n];
 	CK(mga_dbuf_reserve(&P->a, (size_t)n_a * 16 + 64)); CK(mga_dbuf_reserve(&P->tmp, (size_t)n_a * 16 + 64)); CK(mga_dbuf_reserve(&P->mini, (size_t)n_mini * 4 + 16));
-	CK(mga_dev_seed_fill(sc, &B->dev, n, (const mg128_t*)P->mz.p, (const int64_t*)P->mzoff.p, opt->occ_max1, (const int32_t*)P->occ.p, (const uint64_t*)P->val.p,
+	CK(mga_dev_seed_fill(sc, &B->dev, n, (const mg128_t*)P->mz.p, (const int64_t*)P->mzoff.p, (const int32_t*)P->cnt.p, opt->occ_max1, (const int32_t*)P->occ.p, (const uint64_t*)P->val.p,
 						 (const int64_t*)P->aoff.p, (mg128_t*)P->a.p, (const int64_t*)P->minioff.p, (int32_t*)P->mini.p, (mg128_t*)P->tmp.p));
-	h_nmz = MGA_MALLOC(int32_t, n);
-	for (i = 0; i < n; ++i) h_nmz[i] = (int32_t)(h_mzoff[i + 1] - h_mzoff[i]);
 	CK(mga_hbuf_reserve(&P->h_mini, (size_t)n_mini * 4 + 16));
 	CK(mga_d2h_s(sc, P->h_mini.p, P->mini.p, (size_t)n_mini * 4));
 	/* ---- linear chaining ---- */
@@ -676,6 +687,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 		for (i = 0; i < n; ++i) gcs_out[i] = r[i];
 		free(r);
 	}
+	for (i = 0, n_mz = 0; i < n; ++i) n_mz += h_nmz[i]; /* (above, n_mz was the capacity of the minimizer slots) */
 	st->n_reads += n, st->n_bases += tot, st->n_mz += n_mz, st->n_probe += n_mz, st->n_hit += n_a;
 	for (i = 0; i < n && h_nb; ++i) st->n_anchor_chained += h_nb[i];
 	for (i = 0; i < n && h_rflag; ++i) st->n_rescue_dev += h_rflag[i] == 1, st->n_rescue_host += h_rflag[i] == 2;

@@ -96,12 +96,12 @@ typedef struct {
 /* collect_matches (map-algo.c:58-91), pass 1: probe every minimizer.  Flat per-minimizer outputs
  * d_occ[m] (occurrence count) and d_val[m] (slot value); per read d_na[i] (anchors), d_nmini[i]
  * (kept minimizers) and d_rep_len[i]. */
-int mga_dev_seed_count(mga_sctx_t *sc, const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, int max_occ,
+int mga_dev_seed_count(mga_sctx_t *sc, const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, const int32_t *d_mz_cnt /* NULL: mz_off is exact */, int max_occ,
 					   int32_t *d_occ, uint64_t *d_val, int32_t *d_na, int32_t *d_nmini, int32_t *d_rep_len);
 /* collect_seed_hits (map-algo.c:152-192), pass 2: expand hits into anchors at d_a + d_a_off[i], write mini_pos at
  * d_mini + d_mini_off[i], then sort each read's anchors by x with the reference's exact permutation.
  * d_tmp: scratch of the same size as d_a. */
-int mga_dev_seed_fill(mga_sctx_t *sc, const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, int max_occ,
+int mga_dev_seed_fill(mga_sctx_t *sc, const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, const int32_t *d_mz_cnt, int max_occ,
 					  const int32_t *d_occ, const uint64_t *d_val, const int64_t *d_a_off, mg128_t *d_a,
 					  const int64_t *d_mini_off, int32_t *d_mini, mg128_t *d_tmp);
 

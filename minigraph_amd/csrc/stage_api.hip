@@ -106,7 +106,7 @@ extern "C" int mga_seed_batch(const mg_idx_t *gi, int n, const mg128_t *mz, cons
 	if (!d_mz.alloc((size_t)n_mz * 16 + 16) || !d_mzoff.alloc((n + 1) * 8) || !d_occ.alloc((size_t)n_mz * 4 + 4) || !d_val.alloc((size_t)n_mz * 8 + 8) ||
 		!d_na.alloc(n * 4) || !d_nmini.alloc(n * 4) || !d_rep.alloc(n * 4) || !d_aoff.alloc((n + 1) * 8) || !d_minioff.alloc((n + 1) * 8)) return -1;
 	if (mga_h2d(d_mz.p, mz, (size_t)n_mz * 16) < 0 || mga_h2d(d_mzoff.p, mz_off, (n + 1) * 8) < 0) return -1;
-	if (mga_dev_seed_count(SC, ix, n, d_mz.as<mg128_t>(), d_mzoff.as<int64_t>(), max_occ, d_occ.as<int32_t>(), d_val.as<uint64_t>(),
+	if (mga_dev_seed_count(SC, ix, n, d_mz.as<mg128_t>(), d_mzoff.as<int64_t>(), 0, max_occ, d_occ.as<int32_t>(), d_val.as<uint64_t>(),
 						   d_na.as<int32_t>(), d_nmini.as<int32_t>(), d_rep.as<int32_t>()) < 0) return -1;
 	if (mga_dev_scan_i32_to_i64(SC, d_na.as<int32_t>(), n, d_aoff.as<int64_t>()) < 0) return -1;
 	if (mga_dev_scan_i32_to_i64(SC, d_nmini.as<int32_t>(), n, d_minioff.as<int64_t>()) < 0) return -1;
@@ -115,7 +115,7 @@ extern "C" int mga_seed_batch(const mg_idx_t *gi, int n, const mg128_t *mz, cons
 	if (mga_ssync(SC) < 0 || mga_d2h(h_aoff, d_aoff.p, (n + 1) * 8) < 0 || mga_d2h(h_moff, d_minioff.p, (n + 1) * 8) < 0 || mga_d2h(h_rep, d_rep.p, n * 4) < 0) return -1;
 	const int64_t n_a = h_aoff[n], n_m = h_moff[n];
 	if (!d_a.alloc((size_t)n_a * 16 + 64) || !d_tmp.alloc((size_t)n_a * 16 + 64) || !d_mini.alloc((size_t)n_m * 4 + 16)) return -1;
-	if (mga_dev_seed_fill(SC, ix, n, d_mz.as<mg128_t>(), d_mzoff.as<int64_t>(), max_occ, d_occ.as<int32_t>(), d_val.as<uint64_t>(),
+	if (mga_dev_seed_fill(SC, ix, n, d_mz.as<mg128_t>(), d_mzoff.as<int64_t>(), 0, max_occ, d_occ.as<int32_t>(), d_val.as<uint64_t>(),
 						  d_aoff.as<int64_t>(), d_a.as<mg128_t>(), d_minioff.as<int64_t>(), d_mini.as<int32_t>(), d_tmp.as<mg128_t>()) < 0) return -1;
 	mg128_t *h_a = (mg128_t*)malloc((size_t)n_a * 16 + 16);
 	int32_t *h_mini = (int32_t*)malloc((size_t)n_m * 4 + 4);
