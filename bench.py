@@ -64,12 +64,18 @@ def cpu_baseline(ref_bin, graph, reads_fa, n_reads, out_dir, threads, cores):
 def usable_cores():
     """cores this process may actually burn: the affinity mask capped by the cgroup CPU quota (cpu.max)"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
+    try:  # cgroup v2
         q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
         if q != "max":
             n = min(n, max(1, int(int(q) / int(p))))
     except Exception:
-        pass
+        try:  # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
     return n
 
 
