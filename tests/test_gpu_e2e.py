@@ -281,3 +281,24 @@ def test_reference_shaped_c_api_mg_map_and_mg_map_batch():
         ref_out = os.path.join(d, "ref.gaf")
         run_ref(["-c", "-x", "lr", "-t", "4", graph, reads], ref_out)
         assert open(ref_out, "rb").read() == batch
+
+
+def test_pipeline_knobs_do_not_change_the_output(monkeypatch):
+    """chunking, pipeline depth, host threads and the tier scheduling mode are performance knobs only"""
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "3000000", "-H", "3", "-n", "257", "-s", "71"], stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    G = mga.Graph(graph, preset="lr", cigar=True, n_threads=8)
+    R = mga.Reads(reads)
+    want = mga.map_reads(G, R, n_threads=8)
+    for chunk, pipe, threads, extra in ((1, 4, 2, {}), (3, 2, 1, {}), (64, 1, 8, {}), (100, 3, 16, {"MGA_WFA_CONCURRENT": "1"}), (7, 4, 3, {"MGA_UPLOAD_READS": "1"})):
+        monkeypatch.setenv("MGA_CHUNK", str(chunk))
+        monkeypatch.setenv("MGA_PIPE", str(pipe))
+        for k, v in extra.items():
+            monkeypatch.setenv(k, v)
+        got = mga.map_reads(G, R, n_threads=threads)
+        for k in extra:
+            monkeypatch.delenv(k)
+        assert got == want, (chunk, pipe, threads, extra)
+    R.close()
+    G.close()
