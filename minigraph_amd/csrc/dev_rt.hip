@@ -75,7 +75,7 @@ extern "C" mga_sctx_t *mga_sctx_create(void)
 	hipStream_t st;
 	if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { free(sc); mga_set_error("hipStreamCreate failed"); return 0; }
 	sc->stream = (void*)st;
-	for (int i = 0; i < 8; ++i) {
+	for (int i = 0; i < MGA_WFA_MAX_TIER; ++i) {
 		hipStream_t t; hipEvent_t e;
 		if (hipStreamCreateWithFlags(&t, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { mga_set_error("hipStreamCreate failed"); return 0; }
 		sc->tier_stream[i] = (void*)t, sc->ev_done[i] = (void*)e;
@@ -95,11 +95,11 @@ extern "C" void mga_sctx_destroy(mga_sctx_t *sc)
 {
 	if (sc == 0) return;
 	(void)hipStreamSynchronize((hipStream_t)sc->stream);
-	for (int i = 0; i < 8; ++i) mga_dbuf_free(&sc->wfa_ws[i]);
+	for (int i = 0; i < MGA_WFA_MAX_TIER; ++i) mga_dbuf_free(&sc->wfa_ws[i]);
 	mga_dbuf_free(&sc->wfa_cnt);
 	mga_dbuf_free(&sc->scan_tmp); mga_dbuf_free(&sc->txt_cnt); mga_dbuf_free(&sc->txt_off); mga_dbuf_free(&sc->txt_vwb); mga_dbuf_free(&sc->txt_el);
 	mga_dbuf_free(&sc->wfa_list[0]); mga_dbuf_free(&sc->wfa_list[1]); mga_dbuf_free(&sc->wfa_key); mga_dbuf_free(&sc->wfa_ctl);
-	for (int i = 0; i < 8; ++i) { (void)hipStreamDestroy((hipStream_t)sc->tier_stream[i]); (void)hipEventDestroy((hipEvent_t)sc->ev_done[i]); }
+	for (int i = 0; i < MGA_WFA_MAX_TIER; ++i) { (void)hipStreamDestroy((hipStream_t)sc->tier_stream[i]); (void)hipEventDestroy((hipEvent_t)sc->ev_done[i]); }
 	(void)hipEventDestroy((hipEvent_t)sc->ev_ready); (void)hipEventDestroy((hipEvent_t)sc->ev_sync);
 	if (sc->stage) { mga_hfree_pinned(((stage_t*)sc->stage)->buf); free(sc->stage); }
 	(void)hipStreamDestroy((hipStream_t)sc->stream);
@@ -111,18 +111,18 @@ extern "C" void mga_sctx_destroy(mga_sctx_t *sc)
 // filled by the kernels of the OTHER chunks in the pipeline anyway.  MGA_WFA_CONCURRENT=1 brings the per-tier streams back.
 static int wfa_serial(void) { static int v = -1; if (v < 0) { const char *e = getenv("MGA_WFA_CONCURRENT"); v = !(e && atoi(e) > 0); } return v; }
 extern "C" int mga_wfa_tiers_serial(void) { return wfa_serial(); }
-extern "C" void *mga_wfa_stream(mga_sctx_t *sc, int slot) { return wfa_serial() ? sc->stream : sc->tier_stream[slot & 7]; }
+extern "C" void *mga_wfa_stream(mga_sctx_t *sc, int slot) { return wfa_serial() ? sc->stream : sc->tier_stream[slot % MGA_WFA_MAX_TIER]; }
 
 extern "C" int mga_wfa_fork(mga_sctx_t *sc)
 {
 	MGA_HIP_CHECK(hipEventRecord((hipEvent_t)sc->ev_ready, (hipStream_t)sc->stream));
-	for (int i = 0; i < 8; ++i) MGA_HIP_CHECK(hipStreamWaitEvent((hipStream_t)sc->tier_stream[i], (hipEvent_t)sc->ev_ready, 0));
+	for (int i = 0; i < MGA_WFA_MAX_TIER; ++i) MGA_HIP_CHECK(hipStreamWaitEvent((hipStream_t)sc->tier_stream[i], (hipEvent_t)sc->ev_ready, 0));
 	return 0;
 }
 
 extern "C" int mga_wfa_join(mga_sctx_t *sc)
 {
-	for (int i = 0; i < 8; ++i) {
+	for (int i = 0; i < MGA_WFA_MAX_TIER; ++i) {
 		MGA_HIP_CHECK(hipEventRecord((hipEvent_t)sc->ev_done[i], (hipStream_t)sc->tier_stream[i]));
 		MGA_HIP_CHECK(hipStreamWaitEvent((hipStream_t)sc->stream, (hipEvent_t)sc->ev_done[i], 0));
 	}

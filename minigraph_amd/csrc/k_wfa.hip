@@ -315,13 +315,13 @@ extern "C" int mga_dev_wfa(mga_sctx_t *sc, int n, const int32_t *d_list, const m
 	cfg.ws_stride = (int64_t)wfa_ws_bytes(cfg);
 	int waves = g_tier_waves[tier];
 	if (waves > n) waves = n;
-	if (mga_dbuf_reserve(&sc->wfa_ws[6 + tier], (size_t)cfg.ws_stride * g_tier_waves[tier]) < 0) return -1;
-	hipStream_t st = (hipStream_t)mga_wfa_stream(sc, 6 + tier);
-	int *d_counter = (int*)((char*)sc->wfa_cnt.p + 64 * (6 + tier));
-	mga_prof_begin(st, MGA_K_WFA0 + 6 + tier);
+	if (mga_dbuf_reserve(&sc->wfa_ws[7 + tier], (size_t)cfg.ws_stride * g_tier_waves[tier]) < 0) return -1;
+	hipStream_t st = (hipStream_t)mga_wfa_stream(sc, 7 + tier);
+	int *d_counter = (int*)((char*)sc->wfa_cnt.p + 64 * (7 + tier));
+	mga_prof_begin(st, MGA_K_WFA0 + 7 + tier);
 	hipLaunchKernelGGL(k_wfa, dim3(waves), dim3(64), 0, st, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap,
-					   d_pool_used, (char*)sc->wfa_ws[6 + tier].p, d_counter, rt, cfg);
-	mga_prof_end(st, MGA_K_WFA0 + 6 + tier);
+					   d_pool_used, (char*)sc->wfa_ws[7 + tier].p, d_counter, rt, cfg);
+	mga_prof_end(st, MGA_K_WFA0 + 7 + tier);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;
 }

@@ -374,10 +374,11 @@ __global__ void __launch_bounds__(64 * NW) k_wfa_r(int n_items, const int32_t *_
 // ---- host driver ---------------------------------------------------------------------------------
 
 struct wfr_tier_t { int n_wg; int32_t cigcap, tbcap; };
-static const wfr_tier_t g_rtier[6] = {
+static const wfr_tier_t g_rtier[7] = {
 	//  workgroups  cigcap  HBM traceback scratch per workgroup
 	{ 8192,    512,        0 },   // 1 wave  x 1 slot :   64 diagonals, traceback in LDS only
 	{ 6144,   1024,     8192 },   // 1 wave  x 2 slots:  128
+	{ 6144,   2048,    32768 },   // 1 wave  x 3 slots:  192
 	{ 4096,   2048, 192 << 10 },  // 2 waves x 2 slots:  256
 	{ 1280,   4096, 768 << 10 },  // 4 waves x 2 slots:  512
 	{  512,   8192,   3 << 20 },  // 8 waves x 2 slots: 1024
@@ -388,7 +389,7 @@ extern "C" int mga_dev_wfa_reg(mga_sctx_t *sc, int n, const int32_t *d_list, con
 							   mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier, mga_wfa_retry_t rt)
 {
 	if (n <= 0) return 0;
-	if (tier < 0 || tier > 5) { mga_set_error("wfa_reg: bad tier %d", tier); return -1; }
+	if (tier < 0 || tier > 6) { mga_set_error("wfa_reg: bad tier %d", tier); return -1; }
 	const wfr_tier_t &T = g_rtier[tier];
 	wfr_cfg_t cfg = { 4, 4, 2, 15, 1, T.cigcap, T.tbcap, 0 }; // register ages 17/3/2 are tied to these penalties (miniwfa.c:11-18)
 	cfg.ws_stride = (int64_t)(((size_t)T.cigcap * 4 + (size_t)T.tbcap + 255) & ~(size_t)255);
@@ -401,9 +402,10 @@ extern "C" int mga_dev_wfa_reg(mga_sctx_t *sc, int n, const int32_t *d_list, con
 #define LAUNCH(NW, JJ, SEQ, SM, TBL, HBM) hipLaunchKernelGGL((k_wfa_r<NW, JJ, SEQ, SM, TBL, HBM>), dim3(wgs), dim3(64 * NW), 0, st, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap, d_pool_used, (char*)sc->wfa_ws[tier].p, d_counter, rt, cfg)
 	if (tier == 0) LAUNCH(1, 1, 128, 64, 2048, false); // (g_rtier[0].tbcap == 0: traceback in LDS only)
 	else if (tier == 1) LAUNCH(1, 2, 256, 128, 4096, true);
-	else if (tier == 2) LAUNCH(2, 2, 512, 512, 8192, true);  // [measured] 2x2 beats 4x1 (fewer waves to synchronise) and 1x4 (register pressure)
-	else if (tier == 3) LAUNCH(4, 2, 1024, 1024, 8192, true);
-	else if (tier == 4) LAUNCH(8, 2, 2048, 2048, 8192, true);
+	else if (tier == 2) LAUNCH(1, 3, 256, 192, 6144, true); // [measured] 60 ns per problem against 87 ns in the two-wave 256-diagonal tier; the centre slot alone holds the first 32 scores
+	else if (tier == 3) LAUNCH(2, 2, 512, 512, 8192, true);
+	else if (tier == 4) LAUNCH(4, 2, 1024, 1024, 8192, true);
+	else if (tier == 5) LAUNCH(8, 2, 2048, 2048, 8192, true);
 	else LAUNCH(16, 2, 4096, 4096, 8192, true);
 #undef LAUNCH
 	mga_prof_end(st, MGA_K_WFA0 + tier);

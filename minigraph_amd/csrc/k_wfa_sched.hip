@@ -20,25 +20,25 @@
 // the band of a 10%-error gap is about as wide as the gap is long ([measured] on the benchmark workload:
 // mean length 76 -> mean score 40 -> band 81), so start where a band equal to the length fits: [measured] 2-5 % of the
 // problems then outgrow their tier and are re-run one tier up, which is cheaper than starting everything wider
-struct wfs_thr_t { int32_t t[6]; };
+struct wfs_thr_t { int32_t t[7]; };
 __host__ __device__ __forceinline__ int wfs_first_tier_thr(int32_t tl, int32_t ql, const wfs_thr_t &T)
 {
 	const int32_t m = tl > ql ? tl : ql;
-	for (int k = 0; k < 6; ++k) if (m <= T.t[k]) return k;
-	return 6;
+	for (int k = 0; k < 7; ++k) if (m <= T.t[k]) return k;
+	return 7;
 }
 static wfs_thr_t wfs_thresholds(void)
 {
-	static wfs_thr_t T = { { 64, 128, 256, 512, 2048, 4096 } };
+	static wfs_thr_t T = { { 64, 128, 192, 256, 512, 2048, 4096 } };
 	static int init = 0;
-	if (!init) { // MGA_WFA_THR="a,b,c,d": first-tier length limits of the 64/128/256/512-diagonal tiers (tuning aid)
+	if (!init) { // MGA_WFA_THR="a,b,c,d,e": first-tier length limits of the 64/128/192/256/512-diagonal tiers (tuning aid)
 		const char *e = getenv("MGA_WFA_THR");
-		if (e) sscanf(e, "%d,%d,%d,%d", &T.t[0], &T.t[1], &T.t[2], &T.t[3]);
+		if (e) sscanf(e, "%d,%d,%d,%d,%d", &T.t[0], &T.t[1], &T.t[2], &T.t[3], &T.t[4]);
 		init = 1;
 	}
 	return T;
 }
-__host__ __device__ __forceinline__ int wfs_first_tier(int32_t tl, int32_t ql) { const wfs_thr_t T = { { 64, 128, 256, 512, 2048, 4096 } }; return wfs_first_tier_thr(tl, ql, T); }
+__host__ __device__ __forceinline__ int wfs_first_tier(int32_t tl, int32_t ql) { const wfs_thr_t T = { { 64, 128, 192, 256, 512, 2048, 4096 } }; return wfs_first_tier_thr(tl, ql, T); }
 
 extern "C" int mga_wfa_first_tier(int32_t tl, int32_t ql) { return wfs_first_tier(tl, ql); }
 
@@ -176,8 +176,8 @@ extern "C" int mga_dev_wfa_gather(mga_sctx_t *sc, int n, const mga_wfa_res_t *d_
 extern "C" int mga_dev_wfa_tier(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 								mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier, mga_wfa_retry_t rt)
 {
-	if (tier < 6) return mga_dev_wfa_reg(sc, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier, rt);
-	return mga_dev_wfa(sc, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier - 6, rt); /* HBM tiers with 4096 / 32768 diagonals */
+	if (tier < 7) return mga_dev_wfa_reg(sc, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier, rt);
+	return mga_dev_wfa(sc, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier - 7, rt); /* HBM tiers with 4096 / 32768 diagonals */
 }
 
 extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
@@ -226,7 +226,7 @@ extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_
 		if (pass == 0 && bulk_done && !mga_wfa_tiers_serial()) { // the narrow tiers carry >95 % of the work: once they are done the caller may let the next chunk's
 			// WFA phase start; the long tails of the wide tiers and the retry passes then overlap with it instead of idling the GPU
 			struct timespec ts = { 0, 50000 };
-			for (int t = 0; t < 4; ++t)
+			for (int t = 0; t < 5; ++t)
 				while (cnt[t] > 0 && hipEventQuery((hipEvent_t)sc->ev_done[t]) == hipErrorNotReady) nanosleep(&ts, 0);
 			bulk_done(bulk_arg);
 		}

@@ -35,13 +35,13 @@ void mga_dbuf_free(mga_dbuf_t *b);
  * two contexts let the mapping pipeline overlap the GPU work of one chunk with the host work of another. ---- */
 typedef struct mga_sctx_s {
 	void *stream;              /* hipStream_t */
-	mga_dbuf_t wfa_ws[8];      /* per-tier WFA workspaces */
+	mga_dbuf_t wfa_ws[10];     /* per-tier WFA workspaces */
 	mga_dbuf_t wfa_cnt;        /* work-queue counters, one 64-byte line per tier */
 	mga_dbuf_t scan_tmp;       /* tile sums of mga_dev_scan_i32_to_i64 */
 	mga_dbuf_t txt_cnt, txt_off, txt_vwb, txt_el; /* text kernel scratch (k_text.hip) */
 	mga_dbuf_t wfa_list[2], wfa_key, wfa_ctl; /* tier scheduler (k_wfa_sched.hip): double-buffered work lists, sort keys, counters */
-	void *tier_stream[8];      /* WFA tiers run concurrently on their own streams (long-tailed wide problems next to the small ones) */
-	void *ev_ready, *ev_done[8];
+	void *tier_stream[10];      /* WFA tiers run concurrently on their own streams (long-tailed wide problems next to the small ones) */
+	void *ev_ready, *ev_done[10];
 	void *ev_sync;             /* event behind mga_ssync() */
 	void *stage;               /* pinned staging for small device-to-host read-backs, delivered by mga_ssync() */
 } mga_sctx_t;
@@ -62,8 +62,9 @@ int  mga_hbuf_reserve(mga_hbuf_t *b, size_t bytes);
 void mga_hbuf_free(mga_hbuf_t *b);
 
 /* per-kernel HIP-event timing on the launch stream (bench.py reads it through mga_prof_get) */
-enum { MGA_K_SKETCH = 0, MGA_K_SEED_COUNT, MGA_K_SEED_FILL, MGA_K_LCHAIN, MGA_K_WFA0 /* +tier: 0-1 single-wave register tiers (band 64,128), 2-5 multi-wave register tiers (256..2048), 6-7 HBM tiers */, MGA_K_SCAN = MGA_K_WFA0 + 8, MGA_K_TEXT, MGA_K_N };
-#define MGA_WFA_N_TIER 8
+enum { MGA_K_SKETCH = 0, MGA_K_SEED_COUNT, MGA_K_SEED_FILL, MGA_K_LCHAIN, MGA_K_WFA0 /* +tier: 0-2 single-wave register tiers (band 64,128,192), 3-6 multi-wave register tiers (256..2048), 7-8 HBM tiers */, MGA_K_SCAN = MGA_K_WFA0 + 9, MGA_K_TEXT, MGA_K_N };
+#define MGA_WFA_N_TIER 9
+#define MGA_WFA_MAX_TIER 10 /* array size of the per-tier resources */
 void mga_prof_enable(int on);
 void mga_prof_begin(void *stream, int kid);
 void mga_prof_end(void *stream, int kid);
@@ -130,10 +131,10 @@ typedef struct { int32_t *list; int *cnt; int *err; } mga_wfa_retry_t;
  * appended to d_pool (capacity pool_cap ops, *d_pool_used bumped atomically); sequences must be padded by >= 8 readable bytes */
 int mga_dev_wfa(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 				mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier, mga_wfa_retry_t rt);
-/* register-resident tiers (k_wfa_r.hip): tier 0-1 one wave per problem (64, 128 diagonals), 2-5 four to sixteen waves (256, 512, 1024, 2048) */
+/* register-resident tiers (k_wfa_r.hip): tier 0-2 one wave per problem (64, 128, 192 diagonals), 3-6 two to sixteen waves (256, 512, 1024, 2048) */
 int mga_dev_wfa_reg(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 					mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier, mga_wfa_retry_t rt);
-/* tier 0..7: register tiers (one wave, then 4-16 waves per problem), then the HBM-resident tiers */
+/* tier 0..8: register tiers (one wave, then 2-16 waves per problem), then the HBM-resident tiers */
 int mga_wfa_first_tier(int32_t tl, int32_t ql); /* cheapest tier likely to fit, from the sequence lengths */
 int mga_dev_wfa_tier(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 					 mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier, mga_wfa_retry_t rt);
