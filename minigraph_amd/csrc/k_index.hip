@@ -76,7 +76,7 @@ extern "C" int mga_dev_index_build(mga_sctx_t *sc, int n_seg, const char *d_seq,
 {
 	hipStream_t st = (hipStream_t)sc->stream;
 	int64_t n_mz = 0;
-	void *d_rid = 0, *d_cnt = 0, *d_mzoff = 0, *d_mz = 0, *d_key = 0, *d_key2 = 0, *d_val = 0, *d_val2 = 0, *d_tmp = 0, *d_hc = 0, *d_ctl = 0, *d_hist = 0;
+	void *d_rid = 0, *d_cnt = 0, *d_mzoff = 0, *d_mz = 0, *d_key = 0, *d_key2 = 0, *d_val = 0, *d_val2 = 0, *d_tmp = 0, *d_hc = 0, *d_ctl = 0, *d_hist = 0, *d_items = 0;
 	int rc = -1;
 	*h_occ_hist = 0, *h_n_keys = *h_n_mz = *h_max_occ = 0;
 #define IDX_CK(x) do { if ((x) < 0) goto done; } while (0)
@@ -90,13 +90,40 @@ extern "C" int mga_dev_index_build(mga_sctx_t *sc, int n_seg, const char *d_seq,
 		free(h_rid);
 		if (!ok) goto done;
 	}
-	IDX_ALLOC(d_cnt, (size_t)(n_seg + 1) * 4); IDX_ALLOC(d_mzoff, (size_t)(n_seg + 2) * 8);
-	IDX_CK(mga_dev_sketch(sc, n_seg, d_seq, d_off, (const uint32_t*)d_rid, w, k, (int32_t*)d_cnt, 0, 0));
-	IDX_CK(mga_dev_scan_i32_to_i64(sc, (const int32_t*)d_cnt, n_seg, (int64_t*)d_mzoff));
-	IDX_CK(mga_d2h_s(sc, &n_mz, (int64_t*)d_mzoff + n_seg, 8)); IDX_CK(mga_ssync(sc));
-	if (n_mz >= 0xffffffffLL) { mga_set_error("index build: %lld minimizers do not fit the 32-bit list offsets of the table", (long long)n_mz); goto done; }
-	IDX_ALLOC(d_mz, (size_t)n_mz * 16 + 16);
-	IDX_CK(mga_dev_sketch(sc, n_seg, d_seq, d_off, (const uint32_t*)d_rid, w, k, 0, (const int64_t*)d_mzoff, (mg128_t*)d_mz));
+	{ // work items: long segments (a chromosome of a linear reference is ONE segment) are cut into pieces so that they fill the device
+		const int32_t PIECE = 1 << 16;
+		int64_t *h_off = (int64_t*)malloc((size_t)(n_seg + 1) * 8);
+		int32_t *h_items = 0;
+		int64_t n_items = 0;
+		if (h_off == 0 || mga_d2h(h_off, d_off, (size_t)(n_seg + 1) * 8) < 0) { free(h_off); goto done; }
+		if (k & 1) {
+			for (int i = 0; i < n_seg; ++i) { const int64_t l = h_off[i + 1] - h_off[i]; n_items += l > 0 ? (l + PIECE - 1) / PIECE : 1; }
+			if (n_items > 0x7fffffff) { free(h_off); mga_set_error("index build: too many sketch pieces"); goto done; }
+			h_items = (int32_t*)malloc((size_t)n_items * 16);
+			n_items = 0;
+			for (int i = 0; i < n_seg; ++i) {
+				const int64_t l = h_off[i + 1] - h_off[i];
+				int64_t b = 0;
+				do {
+					int32_t *it = h_items + 4 * n_items++;
+					it[0] = i, it[1] = (int32_t)b, it[2] = (int32_t)(b + PIECE < l ? b + PIECE : l), it[3] = 0;
+					b += PIECE;
+				} while (b < l);
+			}
+			d_items = mga_dmalloc((size_t)n_items * 16 + 16);
+			if (d_items == 0 || mga_h2d(d_items, h_items, (size_t)n_items * 16) < 0) { free(h_off); free(h_items); goto done; }
+		} else n_items = n_seg; // even k: symmetric k-mers are skipped, the warm-up of a piece would not be exact -- one wave per segment
+		free(h_off); free(h_items);
+		IDX_ALLOC(d_cnt, (size_t)(n_items + 1) * 4); IDX_ALLOC(d_mzoff, (size_t)(n_items + 2) * 8);
+		if (d_items) IDX_CK(mga_dev_sketch_items(sc, (int)n_items, (const int32_t*)d_items, d_seq, d_off, (const uint32_t*)d_rid, w, k, (int32_t*)d_cnt, 0, 0));
+		else IDX_CK(mga_dev_sketch(sc, n_seg, d_seq, d_off, (const uint32_t*)d_rid, w, k, (int32_t*)d_cnt, 0, 0));
+		IDX_CK(mga_dev_scan_i32_to_i64(sc, (const int32_t*)d_cnt, n_items, (int64_t*)d_mzoff));
+		IDX_CK(mga_d2h_s(sc, &n_mz, (int64_t*)d_mzoff + n_items, 8)); IDX_CK(mga_ssync(sc));
+		if (n_mz >= 0xffffffffLL) { mga_set_error("index build: %lld minimizers do not fit the 32-bit list offsets of the table", (long long)n_mz); goto done; }
+		IDX_ALLOC(d_mz, (size_t)n_mz * 16 + 16);
+		if (d_items) IDX_CK(mga_dev_sketch_items(sc, (int)n_items, (const int32_t*)d_items, d_seq, d_off, (const uint32_t*)d_rid, w, k, 0, (const int64_t*)d_mzoff, (mg128_t*)d_mz));
+		else IDX_CK(mga_dev_sketch(sc, n_seg, d_seq, d_off, (const uint32_t*)d_rid, w, k, 0, (const int64_t*)d_mzoff, (mg128_t*)d_mz));
+	}
 	IDX_ALLOC(d_key, (size_t)n_mz * 8 + 8); IDX_ALLOC(d_val, (size_t)n_mz * 8 + 8); IDX_ALLOC(d_key2, (size_t)n_mz * 8 + 8); IDX_ALLOC(d_val2, (size_t)n_mz * 8 + 8);
 	if (n_mz > 0) {
 		const unsigned nb = (unsigned)((n_mz + 255) / 256);
@@ -144,7 +171,7 @@ extern "C" int mga_dev_index_build(mga_sctx_t *sc, int n_seg, const char *d_seq,
 	rc = 0;
 done:
 	mga_dfree(d_rid); mga_dfree(d_cnt); mga_dfree(d_mzoff); mga_dfree(d_mz); mga_dfree(d_key); mga_dfree(d_key2); mga_dfree(d_val); mga_dfree(d_val2);
-	mga_dfree(d_tmp); mga_dfree(d_hc); mga_dfree(d_ctl); mga_dfree(d_hist);
+	mga_dfree(d_tmp); mga_dfree(d_hc); mga_dfree(d_ctl); mga_dfree(d_hist); mga_dfree(d_items);
 	if (rc < 0) { mga_dfree(ix->d_tab); mga_dfree(ix->d_pos); ix->d_tab = 0, ix->d_pos = 0; }
 	return rc;
 }

@@ -42,24 +42,32 @@ __device__ __forceinline__ int sk_nt4(unsigned char ch) // seq_nt4_table, sketch
 
 __global__ void __launch_bounds__(64) k_sketch(int n, const char *__restrict__ seq, const int64_t *__restrict__ off,
 											   const uint32_t *__restrict__ rid_arr, int w, int k,
-											   int32_t *__restrict__ cnt, const int64_t *__restrict__ mz_off, mg128_t *__restrict__ mz)
+											   int32_t *__restrict__ cnt, const int64_t *__restrict__ mz_off, mg128_t *__restrict__ mz,
+											   const int4 *__restrict__ items)
 {
 	__shared__ uint64_t ex[SK_RING], ey[SK_RING];
 	__shared__ int32_t el[SK_RING];
 	__shared__ uint8_t codes[SK_CRING];
 
-	const int r = blockIdx.x;
-	if (r >= n) return;
+	// Work item = a whole sequence, or (items != NULL) the piece [it.y, it.z) of sequence it.x.  A piece warms up on the w+k+64
+	// bases before it -- every decision below looks back at most w events and k bases, and the run-length conditions
+	// saturate at w+k -- and only emits for its own bases; the launcher cuts long sequences only when k is odd (no
+	// symmetric k-mers, so every base is an event and the warm-up length is exact).
+	const int r_item = blockIdx.x;
+	if (r_item >= n) return;
 	const int lane = threadIdx.x;
+	const int r = items ? items[r_item].x : r_item;
 	const char *s = seq + off[r];
 	const int len = (int)(off[r + 1] - off[r]);
+	const int own_beg = items ? items[r_item].y : 0, own_end = items ? items[r_item].z : len;
+	const int warm_beg = own_beg - (w + k + 64) > 0 ? own_beg - (w + k + 64) : 0;
 	const uint32_t rid = rid_arr ? rid_arr[r] : 0u;
 	const uint64_t mask = (1ULL << 2 * k) - 1;
 	const uint64_t MAXV = ~0ULL;
-	mg128_t *out = mz ? mz + mz_off[r] : 0;
+	mg128_t *out = mz ? mz + mz_off[r_item] : 0;
 	// single pass (cnt AND mz given): mz_off holds CAPACITIES, writes beyond the read's slots are dropped and the caller, who sees
 	// cnt[r] > capacity, falls back to count + write
-	const int cap = (mz && cnt) ? (int)(mz_off[r + 1] - mz_off[r]) : 0x7fffffff;
+	const int cap = (mz && cnt) ? (int)(mz_off[r_item + 1] - mz_off[r_item]) : 0x7fffffff;
 #define SK_PUT(o_, x_, y_) do { if ((o_) < cap) { out[(o_)].x = (x_); out[(o_)].y = (y_); } } while (0)
 
 	// k-1 virtual "nothing yet" codes so that the first real base sits at compact index k-1
@@ -70,9 +78,9 @@ __global__ void __launch_bounds__(64) k_sketch(int n, const char *__restrict__ s
 	int n_out = 0;
 	__syncthreads();
 
-	for (int base = 0; base < len; base += 64) {
+	for (int base = warm_beg; base < own_end; base += 64) {
 		const int i = base + lane;
-		const bool valid = i < len;
+		const bool valid = i < own_end;
 		const int c = valid ? sk_nt4((unsigned char)s[i]) : 4;
 		const bool nonN = valid && c < 4;
 		const uint64_t m_non = __ballot(nonN);
@@ -135,6 +143,7 @@ __global__ void __launch_bounds__(64) k_sketch(int n, const char *__restrict__ s
 				}
 			}
 		}
+		if (i < own_beg) c0 = c1 = c2 = 0; // warm-up: the previous piece emits these
 		const int tot = c0 + c1 + c2;
 		const int incl = mga_wave_incl_scan_i32(tot);
 		const int wave_tot = __shfl(incl, 63);
@@ -156,9 +165,9 @@ __global__ void __launch_bounds__(64) k_sketch(int n, const char *__restrict__ s
 		T += __popcll(m_ev);
 		__syncthreads(); // ring slots are reused by the next step
 	}
-	// the final minimum (sketch.c:107-108): rightmost minimum of the last w events
+	// the final minimum (sketch.c:107-108): rightmost minimum of the last w events -- of the sequence, i.e. of its last piece
 	if (lane == 0) {
-		if (T > 0) {
+		if (T > 0 && own_end == len) {
 			uint64_t nx = MAXV; int N = -1;
 			for (int q = (T - w < 0 ? 0 : T - w); q <= T - 1; ++q) {
 				const uint64_t v = ex[q & (SK_RING - 1)];
@@ -169,8 +178,20 @@ __global__ void __launch_bounds__(64) k_sketch(int n, const char *__restrict__ s
 				++n_out;
 			}
 		}
-		if (cnt) cnt[r] = n_out;
+		if (cnt) cnt[r_item] = n_out;
 	}
+}
+
+extern "C" int mga_dev_sketch_items(mga_sctx_t *sc, int n_items, const int32_t *d_items, const char *d_seq, const int64_t *d_off, const uint32_t *d_rid, int w, int k,
+									int32_t *d_cnt, const int64_t *d_mz_off, mg128_t *d_mz)
+{
+	if (n_items <= 0) return 0;
+	if (w < 1 || w > 255 || k < 1 || k > 28 || !(k & 1)) { mga_set_error("sketch pieces: need 0<w<256 and an odd 0<k<=28, got w=%d k=%d", w, k); return -1; }
+	mga_prof_begin(sc->stream, MGA_K_SKETCH);
+	hipLaunchKernelGGL(k_sketch, dim3(n_items), dim3(64), 0, (hipStream_t)sc->stream, n_items, d_seq, d_off, d_rid, w, k, d_cnt, d_mz_off, d_mz, (const int4*)d_items);
+	mga_prof_end(sc->stream, MGA_K_SKETCH);
+	MGA_HIP_CHECK(hipGetLastError());
+	return 0;
 }
 
 extern "C" int mga_dev_sketch(mga_sctx_t *sc, int n, const char *d_seq, const int64_t *d_off, const uint32_t *d_rid, int w, int k,
@@ -179,7 +200,7 @@ extern "C" int mga_dev_sketch(mga_sctx_t *sc, int n, const char *d_seq, const in
 	if (n <= 0) return 0;
 	if (w < 1 || w > 255 || k < 1 || k > 28) { mga_set_error("sketch: need 0<w<256 and 0<k<=28 (sketch.c:62), got w=%d k=%d", w, k); return -1; }
 	mga_prof_begin(sc->stream, MGA_K_SKETCH);
-	hipLaunchKernelGGL(k_sketch, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_seq, d_off, d_rid, w, k, d_cnt, d_mz_off, d_mz);
+	hipLaunchKernelGGL(k_sketch, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_seq, d_off, d_rid, w, k, d_cnt, d_mz_off, d_mz, (const int4*)0);
 	mga_prof_end(sc->stream, MGA_K_SKETCH);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;

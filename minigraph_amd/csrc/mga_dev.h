@@ -73,6 +73,9 @@ void mga_prof_get(double *ms, int64_t *launches, int reset); /* arrays of MGA_K_
 
 
 /* exclusive prefix sum of n int32 counts into n+1 int64 offsets, on device */
+/* same over PIECES of sequences: item i = int32[4] {sequence, first base, end base, 0}; counts / offsets are per item (k must be odd) */
+int mga_dev_sketch_items(mga_sctx_t *sc, int n_items, const int32_t *d_items, const char *d_seq, const int64_t *d_off, const uint32_t *d_rid, int w, int k,
+						 int32_t *d_cnt, const int64_t *d_mz_off, mg128_t *d_mz);
 int mga_dev_scan_i32_to_i64(mga_sctx_t *sc, const int32_t *d_cnt, int64_t n, int64_t *d_off);
 
 /* ---- sketch (k_sketch.hip) ---- */

@@ -33,13 +33,37 @@ extern "C" int mga_sketch_batch(int n, const char *seq, const int64_t *off, cons
 	if (rid && !d_rid.alloc(n * 4)) return -1;
 	if (mga_h2d(d_seq.p, seq, tot) < 0 || mga_h2d(d_off.p, off, (n + 1) * 8) < 0) return -1;
 	if (rid && mga_h2d(d_rid.p, rid, n * 4) < 0) return -1;
-	if (mga_dev_sketch(SC, n, d_seq.as<char>(), d_off.as<int64_t>(), d_rid.as<uint32_t>(), w, k, d_cnt.as<int32_t>(), 0, 0) < 0) return -1;
-	if (mga_dev_scan_i32_to_i64(SC, d_cnt.as<int32_t>(), n, d_mzoff.as<int64_t>()) < 0) return -1;
+	// long sequences are sketched in pieces (k odd: see k_sketch.hip); piece offsets are folded back into per-sequence offsets
+	const int32_t PIECE = 1 << 16;
+	std::vector<int32_t> items, first_item(n + 1);
+	bool pieces = false;
+	if (k & 1) for (int i = 0; i < n; ++i) if (off[i + 1] - off[i] > PIECE) pieces = true;
+	if (pieces) {
+		for (int i = 0; i < n; ++i) {
+			const int64_t l = off[i + 1] - off[i];
+			int64_t b = 0;
+			first_item[i] = (int32_t)(items.size() / 4);
+			do { items.push_back(i); items.push_back((int32_t)b); items.push_back((int32_t)(b + PIECE < l ? b + PIECE : l)); items.push_back(0); b += PIECE; } while (b < l);
+		}
+		first_item[n] = (int32_t)(items.size() / 4);
+	}
+	const int n_items = pieces ? (int)(items.size() / 4) : n;
+	dptr d_items;
+	if (pieces) {
+		mga_dfree(d_cnt.p); mga_dfree(d_mzoff.p); d_cnt.p = d_mzoff.p = 0;
+		if (!d_items.alloc(items.size() * 4) || !d_cnt.alloc((size_t)n_items * 4) || !d_mzoff.alloc((size_t)(n_items + 1) * 8)) return -1;
+		if (mga_h2d(d_items.p, items.data(), items.size() * 4) < 0) return -1;
+		if (mga_dev_sketch_items(SC, n_items, d_items.as<int32_t>(), d_seq.as<char>(), d_off.as<int64_t>(), d_rid.as<uint32_t>(), w, k, d_cnt.as<int32_t>(), 0, 0) < 0) return -1;
+	} else if (mga_dev_sketch(SC, n, d_seq.as<char>(), d_off.as<int64_t>(), d_rid.as<uint32_t>(), w, k, d_cnt.as<int32_t>(), 0, 0) < 0) return -1;
+	if (mga_dev_scan_i32_to_i64(SC, d_cnt.as<int32_t>(), n_items, d_mzoff.as<int64_t>()) < 0) return -1;
+	std::vector<int64_t> it_off((size_t)n_items + 1);
+	if (mga_ssync(SC) < 0 || mga_d2h(it_off.data(), d_mzoff.p, ((size_t)n_items + 1) * 8) < 0) return -1;
+	const int64_t n_mz = it_off[n_items];
 	int64_t *h_off = (int64_t*)malloc((n + 1) * 8);
-	if (mga_ssync(SC) < 0 || mga_d2h(h_off, d_mzoff.p, (n + 1) * 8) < 0) { free(h_off); return -1; }
-	const int64_t n_mz = h_off[n];
+	for (int i = 0; i <= n; ++i) h_off[i] = pieces ? it_off[first_item[i]] : it_off[i];
 	if (!d_mz.alloc((size_t)n_mz * 16 + 16)) { free(h_off); return -1; }
-	if (mga_dev_sketch(SC, n, d_seq.as<char>(), d_off.as<int64_t>(), d_rid.as<uint32_t>(), w, k, 0, d_mzoff.as<int64_t>(), d_mz.as<mg128_t>()) < 0) { free(h_off); return -1; }
+	if (pieces) { if (mga_dev_sketch_items(SC, n_items, d_items.as<int32_t>(), d_seq.as<char>(), d_off.as<int64_t>(), d_rid.as<uint32_t>(), w, k, 0, d_mzoff.as<int64_t>(), d_mz.as<mg128_t>()) < 0) { free(h_off); return -1; } }
+	else if (mga_dev_sketch(SC, n, d_seq.as<char>(), d_off.as<int64_t>(), d_rid.as<uint32_t>(), w, k, 0, d_mzoff.as<int64_t>(), d_mz.as<mg128_t>()) < 0) { free(h_off); return -1; }
 	mg128_t *h_mz = (mg128_t*)malloc((size_t)n_mz * 16 + 16);
 	if (mga_ssync(SC) < 0 || mga_d2h(h_mz, d_mz.p, (size_t)n_mz * 16) < 0) { free(h_off); free(h_mz); return -1; }
 	*mz = h_mz, *mz_off = h_off;

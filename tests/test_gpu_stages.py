@@ -239,3 +239,24 @@ def test_lchain_synthetic_anchor_sets(ora):
             eu, ea = ora.lchain_dp(a, **kw)
             assert np.array_equal(lc[i][0], eu), ("u", i, kw)
             assert np.array_equal(lc[i][1], ea), ("a", i, kw)
+
+
+@pytest.mark.parametrize("w,k", [(11, 17), (10, 19), (5, 15), (200, 27)])
+def test_sketch_long_sequences_in_pieces(ora, w, k):
+    """sequences above 64 kb are sketched in pieces that warm up on the preceding w+k+64 bases (k odd); piece boundaries,
+    N runs across them and low-complexity stretches must not show"""
+    rng = np.random.default_rng(77 + w + k)
+
+    def seq(n):
+        s = bytearray(rand_seq(rng, n))
+        for pos in (65536 - 9, 65536, 65536 + 3, 131072 - (w + k), 131072 - 1, 196608 - k, 200000):
+            if pos + 40 < n:
+                m = int(rng.integers(1, 40))
+                s[pos:pos + m] = b"N" * m   # short ambiguous runs around the piece boundaries
+        if n > 140000:
+            s[131072 - 300:131072 + 300] = (b"AT" * 300)          # a repeat spanning a boundary: many equal minimizers in one window
+        return bytes(s)
+    seqs = [seq(n) for n in (65535, 65536, 65537, 131072 + 5, 300000, 1000, 70000)]
+    got = mga.sketch_batch(seqs, w, k, rid=np.arange(len(seqs)))
+    for i, s in enumerate(seqs):
+        assert np.array_equal(got[i], ora.sketch(s, w, k, i)), (w, k, len(s))
