@@ -63,6 +63,8 @@ class Ref:
         L.mwf_wfa_auto.argtypes = [C.c_void_p, C.POINTER(mwf_opt_t), C.c_int32, C.c_char_p, C.c_int32, C.c_char_p,
                                    C.POINTER(mwf_rst_t)]
         L.mwf_wfa_auto.restype = None
+        L.mwf_wfa_chain.argtypes = L.mwf_wfa_auto.argtypes
+        L.mwf_wfa_chain.restype = None
         L.gfa_read.argtypes = [C.c_char_p]
         L.gfa_read.restype = C.c_void_p
         L.gfa_destroy.argtypes = [C.c_void_p]
@@ -122,6 +124,19 @@ class Ref:
         r = mwf_rst_t()
         self.lib.mwf_wfa_auto(None, C.byref(opt), len(ts), ts, len(qs), qs, C.byref(r))
         cig = np.array([r.cigar[i] for i in range(r.n_cigar)], dtype="<u4")
+        if r.cigar:
+            self.libc.free(r.cigar)
+        return r.s, cig
+
+    def wfa_chain(self, ts: bytes, qs: bytes):
+        """mwf_wfa_chain() with the options mwf_wfa_auto() (miniwfa.c:829-832) gives it after the exact pass gave up"""
+        opt = mwf_opt_t()
+        self.lib.mwf_opt_init(C.byref(opt))
+        opt.flag |= 1
+        opt.step, opt.max_iter = 5000, -1
+        r = mwf_rst_t()
+        self.lib.mwf_wfa_chain(None, C.byref(opt), len(ts), ts, len(qs), qs, C.byref(r))
+        cig = np.ctypeslib.as_array(r.cigar, shape=(r.n_cigar,)).astype("<u4") if r.n_cigar else np.zeros(0, "<u4")
         if r.cigar:
             self.libc.free(r.cigar)
         return r.s, cig
