@@ -289,6 +289,7 @@ __global__ void __launch_bounds__(64) k_wfa(int n_items, const int32_t *__restri
 			r.cig_off = cig_off, r.status = status, r.pad = 0, r.n_iter = n_iter;
 			res[pi] = r;
 			if (status == MGA_WFA_RETRY_TIER) rt.list[atomicAdd(rt.cnt, 1)] = pi; // next tier's work list
+			else if (status == MGA_WFA_MAX_ITER) rt.fb_list[atomicAdd(rt.fb_cnt, 1)] = pi; // for the chained fallback
 			else if (status != MGA_WFA_OK) atomicAdd(rt.err, 1);
 		}
 		__syncthreads();
@@ -298,12 +299,14 @@ __global__ void __launch_bounds__(64) k_wfa(int n_items, const int32_t *__restri
 
 // ---- host driver -------------------------------------------------------------------------------
 
-static const wfa_cfg_t g_tier[2] = {
+static const wfa_cfg_t g_tier[3] = {
 	// x o1 e1 o2 e2   wmax   smax   cigcap   tbcap        max_iter   stride
 	{ 4, 4, 2, 15, 1,  4096,   8192,   65536,  1 << 24,    100000000, 0 },
-	{ 4, 4, 2, 15, 1, 32768,  32768, 1 << 20,  104000000,  100000000, 0 },
+	{ 4, 4, 2, 15, 1, 32768,  32768, 1 << 20,  104000000,  100000000, 0 }, // tbcap just above max_iter: the cap triggers first
+	// the sub-problems of the chained fallback have no cell cap (miniwfa.c:831): last tier for them, 4 GiB of traceback per wave
+	{ 4, 4, 2, 15, 1, 131072, 131072, 1 << 21, 4LL << 30,  -1,        0 },
 };
-static const int g_tier_waves[2] = { 256, 16 };
+static const int g_tier_waves[3] = { 256, 16, 2 };
 
 
 extern "C" int mga_dev_wfa(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
@@ -311,17 +314,20 @@ extern "C" int mga_dev_wfa(mga_sctx_t *sc, int n, const int32_t *d_list, const m
 {
 	if (n <= 0) return 0;
 	if (tier < 0 || tier > 1) { mga_set_error("wfa: bad tier %d", tier); return -1; }
+	if (sc->wfa_uncapped) tier = tier == 1 ? 2 : tier; // ladder of the fallback's sub-problems: same first HBM tier, then the unbounded one
 	wfa_cfg_t cfg = g_tier[tier];
+	if (sc->wfa_uncapped) cfg.max_iter = -1;
 	cfg.ws_stride = (int64_t)wfa_ws_bytes(cfg);
 	int waves = g_tier_waves[tier];
 	if (waves > n) waves = n;
-	if (mga_dbuf_reserve(&sc->wfa_ws[7 + tier], (size_t)cfg.ws_stride * g_tier_waves[tier]) < 0) return -1;
+	if (mga_dbuf_reserve(&sc->wfa_ws[7 + tier], (size_t)cfg.ws_stride * waves) < 0) return -1;
 	hipStream_t st = (hipStream_t)mga_wfa_stream(sc, 7 + tier);
 	int *d_counter = (int*)((char*)sc->wfa_cnt.p + 64 * (7 + tier));
-	mga_prof_begin(st, MGA_K_WFA0 + 7 + tier);
+	const int kid = MGA_K_WFA0 + 7 + (tier > 1 ? 1 : tier); // the unbounded tier is accounted with the widest regular one
+	mga_prof_begin(st, kid);
 	hipLaunchKernelGGL(k_wfa, dim3(waves), dim3(64), 0, st, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap,
 					   d_pool_used, (char*)sc->wfa_ws[7 + tier].p, d_counter, rt, cfg);
-	mga_prof_end(st, MGA_K_WFA0 + 7 + tier);
+	mga_prof_end(st, kid);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;
 }

@@ -12,7 +12,11 @@
 #include <stdlib.h>
 #include <time.h>
 #include <stdio.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
 #include "mga_dev.h"
+#include "wfachain.h"
 #include "dev_common.h"
 
 #define WFS_NBIN (MGA_WFA_N_TIER * 1024)
@@ -180,6 +184,88 @@ extern "C" int mga_dev_wfa_tier(mga_sctx_t *sc, int n, const int32_t *d_list, co
 	return mga_dev_wfa(sc, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier - 7, rt); /* HBM tiers with 4096 / 32768 diagonals */
 }
 
+
+// ---- chained fallback ---------------------------------------------------------------------------
+// mwf_wfa_auto() (miniwfa.c:824-834): when the exact WFA passes 1e8 wavefront cells, mwf_wfa_chain() (miniwfa.c:776-822) anchors the
+// two sequences on shared 13-mers and closes the stretches between the anchors one by one.  The plan (anchors, literal ops, list
+// of stretches; wfachain.c) is integer work on two sequences and runs on the host; the stretches -- all of the DP -- go through the
+// ladder again as ordinary problems (sub-ranges of the same device sequences, no cell cap: miniwfa.c:831), and the stitched
+// CIGAR replaces the result of the problem.  Rare by construction (a gap of tens of kilobases at > 10 % divergence).
+static int wfs_fallback(mga_sctx_t *sc, int n_fb, const int32_t *d_fb, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+						mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used)
+{
+	struct job_t { int32_t pi; mga_wfa_prob_t pb; mga_wfa_res_t r0; mga_wc_plan_t plan; int64_t sub0; };
+	if (sc->wfa_uncapped) { mga_set_error("WFA fallback: nested cell cap"); return -1; } // cannot happen: the nested ladder has no cap
+	std::vector<int32_t> ids(n_fb);
+	std::vector<job_t> job(n_fb);
+	std::vector<mga_wfa_prob_t> sub;
+	std::vector<char> tbuf, qbuf;
+	mga_wc_par_t par;
+	mga_wc_par_default(&par);
+	int ret = -1;
+	if (mga_ssync(sc) < 0 || mga_d2h(ids.data(), d_fb, (size_t)n_fb * 4) < 0) return -1;
+	std::sort(ids.begin(), ids.end()); // the kernels append in completion order; the result does not depend on it, the pool layout would
+	for (int j = 0; j < n_fb; ++j) memset(&job[j].plan, 0, sizeof(mga_wc_plan_t));
+	for (int j = 0; j < n_fb; ++j) {
+		job_t &J = job[j];
+		J.pi = ids[j], J.sub0 = (int64_t)sub.size();
+		if (mga_d2h(&J.pb, d_prob + J.pi, sizeof(mga_wfa_prob_t)) < 0 || mga_d2h(&J.r0, d_res + J.pi, sizeof(mga_wfa_res_t)) < 0) goto done;
+		tbuf.resize((size_t)J.pb.tl + 1); qbuf.resize((size_t)J.pb.ql + 1);
+		if (mga_d2h(tbuf.data(), d_tseq + J.pb.t_off, (size_t)J.pb.tl) < 0 || mga_d2h(qbuf.data(), d_qseq + J.pb.q_off, (size_t)J.pb.ql) < 0) goto done;
+		if (mga_wfa_chain_plan(&par, J.pb.tl, tbuf.data(), J.pb.ql, qbuf.data(), &J.plan) < 0) { mga_set_error("WFA fallback: out of memory"); goto done; }
+		for (int32_t i = 0; i < J.plan.n; ++i) {
+			const mga_wc_el_t &e = J.plan.el[i];
+			if (e.sub) sub.push_back(mga_wfa_prob_t{ J.pb.t_off + e.x0, J.pb.q_off + e.y0, e.tl, e.ql });
+		}
+	}
+	{
+		const int n_sub = (int)sub.size();
+		std::vector<mga_wfa_res_t> sres((size_t)n_sub);
+		if (n_sub > 0) {
+			if (mga_dbuf_reserve(&sc->fb_prob, (size_t)n_sub * sizeof(mga_wfa_prob_t)) < 0 || mga_dbuf_reserve(&sc->fb_res, (size_t)n_sub * sizeof(mga_wfa_res_t)) < 0) goto done;
+			if (mga_h2d(sc->fb_prob.p, sub.data(), (size_t)n_sub * sizeof(mga_wfa_prob_t)) < 0) goto done;
+			sc->wfa_uncapped = 1;
+			const int rc = mga_dev_wfa_solve(sc, n_sub, (const mga_wfa_prob_t*)sc->fb_prob.p, d_tseq, d_qseq, (mga_wfa_res_t*)sc->fb_res.p, d_pool, pool_cap, d_pool_used, 0, 0, 0);
+			sc->wfa_uncapped = 0;
+			if (rc < 0 || mga_ssync(sc) < 0 || mga_d2h(sres.data(), sc->fb_res.p, (size_t)n_sub * sizeof(mga_wfa_res_t)) < 0) goto done;
+		}
+		unsigned long long used = 0;
+		if (mga_d2h(&used, d_pool_used, 8) < 0) goto done;
+		std::vector<uint32_t> cig, out;
+		std::vector<const uint32_t*> cptr;
+		std::vector<int32_t> cn;
+		for (int j = 0; j < n_fb; ++j) {
+			job_t &J = job[j];
+			const int64_t s1 = j + 1 < n_fb ? job[j + 1].sub0 : (int64_t)n_sub;
+			int64_t tot = 0, iter = J.r0.n_iter, score = J.plan.score;
+			for (int64_t k = J.sub0; k < s1; ++k) tot += sres[k].n_cigar;
+			cig.resize((size_t)tot + 1); cptr.clear(); cn.clear();
+			tot = 0;
+			for (int64_t k = J.sub0; k < s1; ++k) {
+				if (sres[k].status != MGA_WFA_OK) { mga_set_error("WFA fallback: sub-problem failed (status %d)", sres[k].status); goto done; }
+				if (sres[k].n_cigar > 0 && mga_d2h(cig.data() + tot, d_pool + sres[k].cig_off, (size_t)sres[k].n_cigar * 4) < 0) goto done;
+				cptr.push_back(cig.data() + tot); cn.push_back(sres[k].n_cigar);
+				tot += sres[k].n_cigar, iter += sres[k].n_iter, score += sres[k].score;
+			}
+			const int64_t cap = tot + J.plan.n + 1;
+			out.resize((size_t)cap);
+			const int64_t n_out = mga_wfa_chain_stitch(&J.plan, cptr.data(), cn.data(), out.data(), cap);
+			if (n_out < 0) { mga_set_error("WFA fallback: stitch overflow"); goto done; }
+			if ((int64_t)used + n_out > pool_cap) { mga_set_error("WFA fallback: CIGAR pool of %ld ops exhausted", (long)pool_cap); goto done; }
+			mga_wfa_res_t r;
+			r.score = (int32_t)score, r.n_cigar = (int32_t)n_out, r.cig_off = (int64_t)used, r.status = MGA_WFA_OK, r.pad = 0, r.n_iter = iter;
+			if (n_out > 0 && mga_h2d(d_pool + used, out.data(), (size_t)n_out * 4) < 0) goto done;
+			if (mga_h2d(d_res + J.pi, &r, sizeof(r)) < 0) goto done;
+			used += (unsigned long long)n_out;
+		}
+		if (mga_h2d(d_pool_used, &used, 8) < 0) goto done;
+	}
+	ret = 0;
+done:
+	for (int j = 0; j < n_fb; ++j) mga_wfa_chain_plan_free(&job[j].plan);
+	return ret;
+}
+
 extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 								 mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int64_t *cells,
 								 void (*bulk_done)(void*), void *bulk_arg)
@@ -189,8 +275,8 @@ extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_
 	static int dbg = -1;
 	if (dbg < 0) { const char *e = getenv("MGA_DEBUG_WFA"); dbg = e && atoi(e) > 0; }
 	hipStream_t st = (hipStream_t)sc->stream;
-	// ctl: hist[NBIN] | tier_off[16] | rc[2][16] | err[2] | cells (8 bytes)
-	constexpr int O_TOFF = WFS_NBIN, O_RC = O_TOFF + 16, O_ERR = O_RC + 32, O_CELLS = O_ERR + 2, N_CTL = O_CELLS + 2;
+	// ctl: hist[NBIN] | tier_off[16] | rc[2][16] | err | fb | cells (8 bytes)
+	constexpr int O_TOFF = WFS_NBIN, O_RC = O_TOFF + 16, O_ERR = O_RC + 32, O_FB = O_ERR + 1, O_CELLS = O_ERR + 2, N_CTL = O_CELLS + 2;
 	if (mga_dbuf_reserve(&sc->wfa_list[0], (size_t)n * 4 + 64) < 0 || mga_dbuf_reserve(&sc->wfa_list[1], (size_t)n * 4 + 64) < 0 ||
 		mga_dbuf_reserve(&sc->wfa_key, (size_t)n * 4 + 64) < 0 || mga_dbuf_reserve(&sc->wfa_ctl, (size_t)N_CTL * 4) < 0 ||
 		mga_dbuf_reserve(&sc->wfa_cnt, 1024) < 0) return -1;
@@ -219,7 +305,8 @@ extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_
 		if (mga_wfa_fork(sc) < 0) return -1;
 		for (int t = 0; t < MGA_WFA_N_TIER; ++t) {
 			if (cnt[t] <= 0) continue;
-			mga_wfa_retry_t rt = { L[cur ^ 1] + nstart[t + 1], rc + t + 1, ctl + O_ERR };
+			// wfa_key is free once the lists are built: it takes the problems that hit the cell cap (only the HBM tiers count cells)
+			mga_wfa_retry_t rt = { L[cur ^ 1] + nstart[t + 1], rc + t + 1, ctl + O_ERR, (int32_t*)sc->wfa_key.p, ctl + O_FB };
 			if (mga_dev_wfa_tier(sc, cnt[t], L[cur] + off[t], d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, t, rt) < 0) return -1;
 		}
 		if (mga_wfa_join(sc) < 0) return -1;
@@ -242,6 +329,12 @@ extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_
 		cnt[0] = 0;
 		for (int u = 1; u < MGA_WFA_N_TIER; ++u) cnt[u] = hr[u], off[u] = nstart[u], left += hr[u];
 		if (left == 0) break;
+	}
+	{ // problems the exact pass gave up on (> 1e8 cells): miniwfa's chained fallback (miniwfa.c:829-832)
+		int n_fb = 0;
+		if (mga_d2h_s(sc, &n_fb, ctl + O_FB, 4) < 0 || mga_ssync(sc) < 0) return -1;
+		if (n_fb > 0 && wfs_fallback(sc, n_fb, (const int32_t*)sc->wfa_key.p, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used) < 0) return -1;
+		ctl = (int*)sc->wfa_ctl.p; // the nested ladder may have grown the buffer
 	}
 	if (cells) {
 		unsigned long long c = 0;

@@ -44,6 +44,8 @@ typedef struct mga_sctx_s {
 	void *ev_ready, *ev_done[10];
 	void *ev_sync;             /* event behind mga_ssync() */
 	void *stage;               /* pinned staging for small device-to-host read-backs, delivered by mga_ssync() */
+	int wfa_uncapped;          /* set while the ladder runs the chained fallback's sub-problems: no 1e8-cell cap, unbounded last tier */
+	mga_dbuf_t fb_prob, fb_res; /* sub-problems of the chained fallback and their results */
 } mga_sctx_t;
 void *mga_wfa_stream(mga_sctx_t *sc, int slot);       /* stream of WFA tier `slot` (the context's own stream unless MGA_WFA_CONCURRENT=1) */
 int mga_wfa_tiers_serial(void);
@@ -128,8 +130,9 @@ size_t mga_dev_lchain_ws_bytes(int64_t total_anchors);
 typedef struct { int64_t t_off, q_off; int32_t tl, ql; } mga_wfa_prob_t;
 typedef struct { int32_t score, n_cigar; int64_t cig_off; int32_t status, pad; int64_t n_iter; } mga_wfa_res_t;
 enum { MGA_WFA_OK = 0, MGA_WFA_PENDING = 1, MGA_WFA_RETRY_TIER = 2, MGA_WFA_POOL_FULL = 3, MGA_WFA_MAX_ITER = 4 };
-/* where a WFA kernel appends the problems that outgrew its tier (device pointers); err counts the other failures */
-typedef struct { int32_t *list; int *cnt; int *err; } mga_wfa_retry_t;
+/* where a WFA kernel appends the problems that outgrew its tier (device pointers); err counts the other failures; fb_list/fb_cnt collect
+ * the problems that hit the reference's 1e8-cell cap (miniwfa.c:827): they are re-done by the chained fallback (k_wfa_sched.hip) */
+typedef struct { int32_t *list; int *cnt; int *err; int32_t *fb_list; int *fb_cnt; } mga_wfa_retry_t;
 /* solves problems d_list[0..n) (identity when d_list == NULL) in HBM-resident capacity tier 0..1 (4096 / 32768 diagonals); cigars are
  * appended to d_pool (capacity pool_cap ops, *d_pool_used bumped atomically); sequences must be padded by >= 8 readable bytes */
 int mga_dev_wfa(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,

@@ -302,3 +302,48 @@ def test_pipeline_knobs_do_not_change_the_output(monkeypatch):
         assert got == want, (chunk, pipe, threads, extra)
     R.close()
     G.close()
+
+
+def test_reads_with_a_gap_beyond_the_exact_wfa_cap_vs_reference_binary():
+    """reads whose middle 9-12 kb are 30-40 % diverged: the anchor gap there passes 1e8 WFA cells and the reference falls back to
+    mwf_wfa_chain() (miniwfa.c:829-832); same bytes expected, incl. the read whose gap takes the D+I shortcut"""
+    import numpy as np
+    if not os.path.exists(rb.REF_BIN):
+        pytest.skip("oracle/_ref/minigraph not present")
+    rng = np.random.default_rng(11)
+
+    def rnd(n):
+        return bytes(rng.choice(list(b"ACGT"), n).tolist())
+
+    def mut(s, sub, indel):
+        out = bytearray()
+        for c in s:
+            r = rng.random()
+            if r < sub:
+                out.append(int(rng.choice([x for x in b"ACGT" if x != c])))
+            elif r < sub + indel / 2:
+                continue
+            elif r < sub + indel:
+                out.append(c)
+                out.append(int(rng.choice(list(b"ACGT"))))
+            else:
+                out.append(c)
+        return bytes(out)
+
+    d = tempfile.mkdtemp()
+    ref = rnd(60000)
+    graph, reads = os.path.join(d, "g.fa"), os.path.join(d, "r.fa")
+    open(graph, "wb").write(b">chr\n" + ref + b"\n")
+    with open(reads, "wb") as f:
+        for i, (n, sub, ind) in enumerate([(9000, 0.3, 0.1), (12000, 0.3, 0.1), (9000, 0.25, 0.05)]):
+            st = 3000 + 1000 * i
+            r = ref[st:st + 6000] + mut(ref[st + 6000:st + 6000 + n], sub, ind) + ref[st + 6000 + n:st + 12000 + n]
+            f.write(b">r%d\n%s\n" % (i, r))
+        f.write(b">plain\n%s\n" % ref[40000:50000])
+    ref_out, got = os.path.join(d, "ref.gaf"), os.path.join(d, "got.gaf")
+    run_ref(["-c", "-x", "lr", "-t", "2", graph, reads], ref_out)
+    mga.map_files(graph, [reads], got, cigar=True)
+    if open(ref_out, "rb").read() != open(got, "rb").read():
+        raise AssertionError(first_diff(ref_out, got))
+    lines = open(got, "rb").read().split(b"\n")
+    assert len(lines) == 5 and int(lines[1].split(b"\t")[10]) > 30000  # r1: block length = both sides of the unrelated stretch

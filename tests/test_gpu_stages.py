@@ -260,3 +260,45 @@ def test_sketch_long_sequences_in_pieces(ora, w, k):
     got = mga.sketch_batch(seqs, w, k, rid=np.arange(len(seqs)))
     for i, s in enumerate(seqs):
         assert np.array_equal(got[i], ora.sketch(s, w, k, i)), (w, k, len(s))
+
+
+def test_wfa_chained_fallback_matches_mwf_wfa_auto():
+    """gaps whose exact WFA passes 1e8 cells take miniwfa's chained fallback (miniwfa.c:829-832): the plan is made on the host
+    (wfachain.c), every stretch of it runs through the device ladder again (k_wfa_sched.hip: wfs_fallback), the stitched CIGAR
+    must equal the reference's mwf_wfa_auto() -- one huge stretch (unbounded tier), the D+I shortcut for unrelated >= 10 kb,
+    a mixed batch around them"""
+    ref = rb.Ref()
+    rng = np.random.default_rng(7)
+
+    def mut(s, sub, indel):
+        out = bytearray()
+        for c in s:
+            r = rng.random()
+            if r < sub:
+                out.append(int(rng.choice([x for x in b"ACGT" if x != c])))
+            elif r < sub + indel / 2:
+                continue
+            elif r < sub + indel:
+                out.append(c)
+                out.append(int(rng.choice(list(b"ACGT"))))
+            else:
+                out.append(c)
+        return bytes(out)
+
+    T, Q = wfa_cases(rng, 40, 300)
+    big = []
+    for n, sub, indel in [(9000, 0.3, 0.1), (12000, 0.3, 0.1), (9500, 0.75, 0.0)]:
+        a, m, b = rand_seq(rng, 500), rand_seq(rng, n), rand_seq(rng, 500)
+        big.append(len(T))
+        T.insert(len(T), a + m + b)
+        Q.insert(len(Q), a + mut(m, sub, indel) + b)
+        t2, q2 = wfa_cases(rng, 10, 300)
+        T += t2
+        Q += q2
+    sc, cg = mga.wfa_batch(T, Q)
+    for i in range(len(T)):
+        es, ec = ref.wfa(T[i], Q[i])
+        assert es == sc[i], i
+        assert np.array_equal(ec, cg[i]), i
+    for i in big:  # the exact pass alone really gives up on these
+        assert rb.Oracle().wfa(T[i], Q[i], max_iter=100000000)[0] < 0
