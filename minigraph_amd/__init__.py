@@ -226,8 +226,10 @@ def lchain_batch(anchor_list, **kw):
     return [(uu[uoff[i]:uoff[i + 1]], bb[boff[i]:boff[i + 1]]) for i in range(n)]
 
 
-def map_files(graph_path, read_paths, out_path, preset="lr", cigar=True, n_threads=8, verbose=1):
-    """gfa_read + mg_map_files: the whole `minigraph -cx lr graph reads > out` job through the C ABI."""
+def map_files(graph_path, read_paths, out_path, preset="lr", cigar=True, n_threads=8, verbose=1, idx_opt=None, map_opt=None, flags=0):
+    """gfa_read + mg_map_files: the whole `minigraph -cx lr graph reads > out` job through the C ABI.
+    idx_opt / map_opt: {field: value} written into mg_idxopt_t / mg_mapopt_t after the preset, the way main.c:131-191 applies
+    command-line options; flags: MG_M_* bits OR-ed into mg_mapopt_t.flag."""
     L = load()
     io, mo, go = idxopt_t(), mapopt_t(), ggopt_t()
     L.mg_opt_set(None, C.byref(io), C.byref(mo), C.byref(go))
@@ -235,6 +237,13 @@ def map_files(graph_path, read_paths, out_path, preset="lr", cigar=True, n_threa
         raise ValueError("unknown preset %r" % preset)
     if cigar:
         mo.flag |= MG_M_CIGAR
+    mo.flag |= flags
+    for k, v in (idx_opt or {}).items():
+        setattr(io, k, v)
+    for k, v in (map_opt or {}).items():
+        setattr(mo, k, v)
+    if L.mg_opt_check(C.byref(io), C.byref(mo), C.byref(go)) != 0:
+        raise ValueError("mg_opt_check rejected the options")
     C.c_int.in_dll(L, "mg_verbose").value = verbose
     g = L.gfa_read(graph_path.encode())
     if not g:

@@ -347,3 +347,86 @@ def test_reads_with_a_gap_beyond_the_exact_wfa_cap_vs_reference_binary():
         raise AssertionError(first_diff(ref_out, got))
     lines = open(got, "rb").read().split(b"\n")
     assert len(lines) == 5 and int(lines[1].split(b"\t")[10]) > 30000  # r1: block length = both sides of the unrelated stretch
+
+
+def _np_mutate(rng, s, err):
+    """numpy ONT-like errors: 40 % substitutions, 30 % insertions, 30 % deletions of `err`"""
+    import numpy as np
+    a = np.frombuffer(s, dtype=np.uint8)
+    u = rng.random(len(a))
+    out = []
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for ch, x in zip(a.tolist(), u.tolist()):
+        if x < err * 0.4:
+            out.append(int(rng.choice(alpha[alpha != ch])))
+        elif x < err * 0.7:
+            out.append(ch)
+            out.append(int(rng.choice(alpha)))
+        elif x < err:
+            continue
+        else:
+            out.append(ch)
+    return bytes(out)
+
+
+def _repeat_workload(d):
+    """two chromosomes, the second carrying a 2 %-diverged 40 kb copy of a stretch of the first: secondary chains, mapq < 60"""
+    import numpy as np
+    rng = np.random.default_rng(23)
+
+    def rnd(n):
+        return bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n).tobytes())
+
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    a = rnd(200000)
+    b = rnd(100000) + _np_mutate(rng, a[50000:90000], 0.02) + rnd(50000)
+    graph, reads = os.path.join(d, "rep.fa"), os.path.join(d, "rep.reads.fa")
+    open(graph, "wb").write(b">chrA\n" + a + b"\n>chrB\n" + b + b"\n")
+    with open(reads, "wb") as f:
+        for i in range(40):
+            src = a if i % 2 == 0 else b
+            lo = 45000 if i % 2 == 0 else 95000
+            st = int(rng.integers(lo, lo + 40000))
+            r = _np_mutate(rng, src[st:st + 8000], 0.08)
+            if i % 3 == 0:
+                r = r.translate(comp)[::-1]
+            f.write(b">q%d\n%s\n" % (i, r))
+        f.write(b">junk\n%s\n" % rnd(3000))
+    return graph, reads
+
+
+OPTION_SETS = [
+    # (tag, reference command line, idx_opt, map_opt, flags)
+    ("kw_bw_gap", ["-k", "15", "-w", "8", "-r", "300,10000", "-g", "3000", "-n", "3,3", "-m", "30,30"],
+     dict(k=15, w=8), dict(bw=300, bw_long=10000, max_gap=3000, min_gc_cnt=3, min_lc_cnt=3, min_gc_score=30, min_lc_score=30), 0),
+    ("occ_2nd_vc", ["-f", "0.001", "-U", "20,100", "-p", "0.5", "-N", "3", "--secondary=yes", "--show-unmap=yes", "--vc"],
+     None, dict(occ_max1_frac=0.001, occ_max1=20, occ_max1_cap=100, pri_ratio=0.5, best_n=3), 0x2000 | 0x100000 | 0x800),
+    ("lchain_out", ["-S", "--no-comp-path", "-j", "0.2", "-M", "0.3"], None, dict(div=0.2, mask_level=0.3), 0x800000 | 0x200000),
+    ("chain_pens", ["--gap-pen", "0.5", "--max-lc-skip", "10", "--max-lc-iter", "1000", "--gdp-max-ed", "2000", "--max-gc-skip", "10",
+                    "--max-gap-pre", "500", "--ref-bonus", "5"],
+     None, dict(chn_pen_gap=0.5, max_lc_skip=10, max_lc_iter=1000, gdp_max_ed=2000, max_gc_skip=10, max_gap_pre=500, ref_bonus=5), 0),
+    ("rmq_primary", ["--rmq=yes"], None, None, 0x8000),
+    ("write_mz", ["--write-mz"], None, None, 0x1000000 | 0x800000),
+]
+
+
+@pytest.mark.parametrize("workload", ["bubbles", "repeat"])
+@pytest.mark.parametrize("tag,cli,idx_opt,map_opt,flags", OPTION_SETS, ids=[o[0] for o in OPTION_SETS])
+def test_command_line_options_vs_reference_binary(workload, tag, cli, idx_opt, map_opt, flags):
+    """every mapping option of the reference's command line (main.c:131-216) set through mg_idxopt_t / mg_mapopt_t: same bytes"""
+    if not os.path.exists(rb.REF_BIN):
+        pytest.skip("oracle/_ref/minigraph not present")
+    d = tempfile.mkdtemp()
+    if workload == "bubbles":
+        subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "1500000", "-H", "3", "-n", "150", "-s", "7"], stderr=subprocess.DEVNULL)
+        graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    else:
+        graph, reads = _repeat_workload(d)
+    ref_out, got = os.path.join(d, "ref.gaf"), os.path.join(d, "got.gaf")
+    run_ref(["-c", "-x", "lr", "-t", "4"] + cli + [graph, reads], ref_out)
+    mga.map_files(graph, [reads], got, idx_opt=idx_opt, map_opt=map_opt, flags=flags)
+    if open(ref_out, "rb").read() != open(got, "rb").read():
+        raise AssertionError(first_diff(ref_out, got))
+    if workload == "repeat" and tag == "occ_2nd_vc":
+        body = open(got, "rb").read()
+        assert b"tp:A:S" in body and b"junk\t3000\t0\t0\t*" in body  # secondaries and the unmapped read were really printed
