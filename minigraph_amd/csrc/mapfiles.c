@@ -294,6 +294,10 @@ int mg_map_files_fp(gfa_t *g, int n_fn, const char **fn, const mg_idxopt_t *ipt,
 	wbuf_t wb[2];
 	pthread_t t_rd, t_wr;
 	fbatch_t *b;
+	if (opt.flag & (MG_M_FRAG_MODE | MG_M_CAL_COV)) { /* gmap.c:44-48,119-126,199-214: multi-segment fragments and --cov are not on the accelerated path */
+		if (mg_verbose >= 1) fprintf(stderr, "[E::%s] --frag and --cov are outside the MI355X long-read path (single-segment reads, GAF output)\n", __func__);
+		return -1;
+	}
 	if ((gi = mg_index(g, ipt, n_threads, &opt)) == 0) return -1;
 	chan_init(&c_in, 1); chan_init(&c_out, 1); chan_init(&c_back, CHAN_CAP); /* one parsed batch ahead, one batch being written; returned buffers never block the writer */
 	memset(wb, 0, sizeof wb);
