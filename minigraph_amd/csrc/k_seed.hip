@@ -148,3 +148,74 @@ extern "C" int mga_dev_seed_fill(mga_sctx_t *sc, const mga_didx_t *ix, int n, co
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;
 }
+
+// ---- long queries (-x asm: contigs of megabases, a handful per batch) ----------------------------------------------
+// One wavefront per read leaves the GPU idle when a read has 10^7 minimizers.  Here every minimizer of the batch is a work item:
+// the kept occurrence counts and kept flags are scanned over the whole (contiguous, exact-offset) minimizer array, which gives
+// each minimizer its first anchor slot and its mini_pos slot directly (the per-read offsets are the same scans sampled at the
+// read boundaries), then one thread per minimizer writes its anchors.  The anchors stay in hit order: under MG_M_RMQ the chainer
+// runs on the host, which sorts them there with the reference's exact radix permutation (ksortx.c) before it chains.
+__global__ void __launch_bounds__(256) k_seed_kept(int64_t n_mz, const int32_t *__restrict__ occ, int max_occ, int32_t *__restrict__ tk, int32_t *__restrict__ kf)
+{
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_mz; i += (int64_t)gridDim.x * blockDim.x) {
+		const int32_t t = occ[i];
+		const bool kept = t < max_occ;
+		tk[i] = kept ? t : 0, kf[i] = kept ? 1 : 0;
+	}
+}
+
+__global__ void __launch_bounds__(256) k_seed_expand(mga_didx_t ix, int n, const mg128_t *__restrict__ mz, const int64_t *__restrict__ mz_off, int64_t n_mz, int max_occ,
+													 const int32_t *__restrict__ occ, const uint64_t *__restrict__ val, const int64_t *__restrict__ off_a, const int64_t *__restrict__ off_m,
+													 mg128_t *__restrict__ a_all, int32_t *__restrict__ mini_all)
+{
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_mz; i += (int64_t)gridDim.x * blockDim.x) {
+		const int32_t t = occ[i];
+		if (t >= max_occ) continue;
+		const mg128_t m = mz[i];
+		const uint64_t key = m.x >> 8;
+		const uint32_t q_pos = (uint32_t)m.y, q_span = (uint32_t)(m.x & 0xff);
+		mini_all[off_m[i]] = (int32_t)(q_pos >> 1);
+		if (t == 0) continue;
+		int lo = 0, hi = n - 1; // the read of minimizer i: last r with mz_off[r] <= i (empty reads share an offset with their successor)
+		while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (mz_off[mid] <= i) lo = mid; else hi = mid - 1; }
+		const int64_t rb = mz_off[lo], re = mz_off[lo + 1];
+		bool tandem = false; // map-algo.c:168-172: the neighbouring minimizer of the same read has the same hash
+		if (i > rb && mz[i - 1].x >> 8 == key) tandem = true;
+		if (i < re - 1 && mz[i + 1].x >> 8 == key) tandem = true;
+		uint64_t y = (uint64_t)q_span << 32 | (uint64_t)(q_pos >> 1);
+		if (tandem) y |= MG_SEED_TANDEM;
+		y |= (uint64_t)(t < 255 ? t : 255) << MG_SEED_OCC_SHIFT;
+		const uint64_t v = val[i];
+		const uint64_t *cr = ix.d_pos + (v >> 32);
+		mg128_t *o = a_all + off_a[i];
+		for (int32_t k = 0; k < t; ++k) {
+			const uint64_t rr = t == 1 ? v : cr[k];
+			const uint64_t seg = rr >> 32;
+			const int32_t rpos = (int32_t)((uint32_t)rr >> 1);
+			uint64_t x;
+			if ((rr & 1) == (q_pos & 1)) x = seg << 33 | (uint64_t)(uint32_t)rpos;
+			else x = seg << 33 | 1ULL << 32 | (uint64_t)(uint32_t)(ix.d_seg_len[seg] - (rpos + 1 - (int32_t)q_span) - 1);
+			o[k].x = x, o[k].y = y;
+		}
+	}
+}
+
+extern "C" int mga_dev_seed_expand(mga_sctx_t *sc, const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, int64_t n_mz, int max_occ,
+								   const int32_t *d_occ, const uint64_t *d_val, mg128_t *d_a, int32_t *d_mini,
+								   int32_t *d_tk, int32_t *d_kf, int64_t *d_off_a, int64_t *d_off_m)
+{
+	if (n <= 0 || n_mz <= 0) return 0;
+	hipStream_t st = (hipStream_t)sc->stream;
+	int nb = (int)((n_mz + 255) / 256);
+	if (nb > 16384) nb = 16384;
+	mga_prof_begin(sc->stream, MGA_K_SEED_FILL);
+	hipLaunchKernelGGL(k_seed_kept, dim3(nb), dim3(256), 0, st, n_mz, d_occ, max_occ, d_tk, d_kf);
+	mga_prof_end(sc->stream, MGA_K_SEED_FILL);
+	MGA_HIP_CHECK(hipGetLastError());
+	if (mga_dev_scan_i32_to_i64(sc, d_tk, n_mz, d_off_a) < 0 || mga_dev_scan_i32_to_i64(sc, d_kf, n_mz, d_off_m) < 0) return -1;
+	mga_prof_begin(sc->stream, MGA_K_SEED_FILL);
+	hipLaunchKernelGGL(k_seed_expand, dim3(nb), dim3(256), 0, st, *ix, n, d_mz, d_mz_off, n_mz, max_occ, d_occ, d_val, d_off_a, d_off_m, d_a, d_mini);
+	mga_prof_end(sc->stream, MGA_K_SEED_FILL);
+	MGA_HIP_CHECK(hipGetLastError());
+	return 0;
+}

@@ -178,6 +178,7 @@ static void chain_worker(void *data, int64_t i, int tid)
 
 	if (b->a_is_raw) { /* MG_M_RMQ: the RMQ chainer is the primary chainer (map-algo.c:397-399) */
 		int64_t na = b->a_off[i + 1] - b->a_off[i];
+		if (na > 1 && b->a_is_raw == 2) mga_ksort_128x(na, (mg128_t*)(b->a + b->a_off[i])); /* hit order from the device: radix_sort_128x (map-algo.c:189), every read has its own slice */
 		if (na > 0) a = mga_lchain_rmq(opt->max_gap, opt->max_gap_pre, opt->bw, opt->max_lc_skip, opt->rmq_size_cap, opt->min_lc_cnt, opt->min_lc_score,
 									   b->pen_gap, b->pen_skip, na, b->a + b->a_off[i], &n_lc, &u);
 	} else { /* chains of the GPU DP */
@@ -462,6 +463,7 @@ typedef struct {
 	mga_sctx_t *sc;
 	mga_dbuf_t seq, qoff, cnt, mzoff, mz, occ, val, na, nmini, rep, aoff, minioff, a, tmp, mini, u, b, nu, nb, ws;
 	mga_dbuf_t tseq, prob, res, pool, used, ncig, cigoff, ord, rflag, item, chain, vert, txtres, txtpool;
+	mga_dbuf_t sk_item, sk_cnt, sk_off, sd_tk, sd_kf, sd_offa, sd_offm; /* long-query path (MG_M_RMQ): sketch pieces, per-minimizer scans */
 	mga_hbuf_t h_b, h_u, h_mini, h_tseq, h_prob, h_pool, h_seq, h_ncig, h_cigoff, h_item, h_chain, h_vert, h_txtres, h_txtpool; /* pinned staging */
 } pipe_ctx_t;
 
@@ -498,6 +500,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	mga_batch_t *b = 0;
 	mga_lchain_par_t par;
 	const int is_rmq = !!(opt->flag & MG_M_RMQ);
+	const int long_q = is_rmq && (gi->k & 1) && !env_int("MGA_NO_LONGQ", 0); /* -x asm: few, very long queries -- intra-query parallel sketch and seed expansion, anchors sorted by the host chainer */
 	const char *d_seq;
 	double t0, t1;
 	gpu_token_t *held = 0; /* GPU phase token currently owned */
@@ -534,7 +537,37 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	CK(mga_dbuf_reserve(&P->cnt, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&P->mzoff, (size_t)(n + 1) * 8));
 	h_mzoff = MGA_MALLOC(int64_t, n + 1);
 	h_nmz = MGA_MALLOC(int32_t, n);
-	{
+	if (long_q) { /* contigs of megabases: pieces of 64 kb are the work items (k_sketch.hip), count + scan + write, exact contiguous offsets */
+		const int32_t PIECE = 1 << 16;
+		int64_t n_items = 0, it = 0, *h_itoff;
+		int32_t *h_item;
+		for (i = 0; i < n; ++i) n_items += qlens[i] > 0 ? (qlens[i] + PIECE - 1) / PIECE : 1;
+		h_item = MGA_MALLOC(int32_t, n_items * 4);
+		h_itoff = MGA_MALLOC(int64_t, n_items + 1);
+		for (i = 0; i < n; ++i) {
+			int32_t beg = 0;
+			do { h_item[it * 4] = i, h_item[it * 4 + 1] = beg, h_item[it * 4 + 2] = beg + PIECE < qlens[i] ? beg + PIECE : qlens[i], h_item[it * 4 + 3] = 0; ++it, beg += PIECE; } while (beg < qlens[i]);
+		}
+		rc = mga_dbuf_reserve(&P->sk_item, (size_t)n_items * 16) < 0 || mga_dbuf_reserve(&P->sk_cnt, (size_t)n_items * 4 + 4) < 0 || mga_dbuf_reserve(&P->sk_off, (size_t)(n_items + 1) * 8) < 0
+			|| mga_h2d_s(sc, P->sk_item.p, h_item, (size_t)n_items * 16) < 0
+			|| mga_dev_sketch_items(sc, (int)n_items, (const int32_t*)P->sk_item.p, d_seq, (const int64_t*)P->qoff.p, 0, gi->w, gi->k, (int32_t*)P->sk_cnt.p, 0, 0) < 0
+			|| mga_dev_scan_i32_to_i64(sc, (const int32_t*)P->sk_cnt.p, n_items, (int64_t*)P->sk_off.p) < 0
+			|| mga_ssync(sc) < 0 || mga_d2h(h_itoff, P->sk_off.p, (size_t)(n_items + 1) * 8) < 0 ? -1 : 0; /* (h_item must stay alive until the copy has been consumed) */
+		if (rc == 0) {
+			for (i = 0, it = 0; i < n; ++i) { h_mzoff[i] = h_itoff[it]; it += qlens[i] > 0 ? (qlens[i] + PIECE - 1) / PIECE : 1; }
+			h_mzoff[n] = n_mz = h_itoff[n_items];
+			for (i = 0; i < n; ++i) {
+				if (h_mzoff[i + 1] - h_mzoff[i] > 0x7fffffff) { mga_set_error("read %d has more than 2^31 minimizers", i); rc = -1; break; }
+				h_nmz[i] = (int32_t)(h_mzoff[i + 1] - h_mzoff[i]);
+			}
+		}
+		free(h_item); free(h_itoff);
+		if (rc < 0) goto done;
+		CK(mga_h2d_s(sc, P->mzoff.p, h_mzoff, (size_t)(n + 1) * 8)); CK(mga_h2d_s(sc, P->cnt.p, h_nmz, (size_t)n * 4));
+		CK(mga_dbuf_reserve(&P->mz, (size_t)n_mz * 16 + 16));
+		CK(mga_dev_sketch_items(sc, (int)n_items, (const int32_t*)P->sk_item.p, d_seq, (const int64_t*)P->qoff.p, 0, gi->w, gi->k, 0, (const int64_t*)P->sk_off.p, (mg128_t*)P->mz.p));
+		CK(mga_ssync(sc)); /* h_mzoff / h_nmz uploads done */
+	} else {
 		int overflow = 0;
 		for (i = 0, n_mz = 0; i < n; ++i) { h_mzoff[i] = n_mz; n_mz += qlens[i] / 2 + 64; }
 		h_mzoff[n] = n_mz; /* capacity of the chunk */
@@ -565,9 +598,17 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	if (g_dbg_pipe > 1) PIPE_LOG(" sketch", n, t0);
 	t1 = mga_wtime(); st->t_sketch += t1 - t0; t0 = t1;
 	n_a = h_aoff[n], n_mini = h_minioff[n];
-	CK(mga_dbuf_reserve(&P->a, (size_t)n_a * 16 + 64)); CK(mga_dbuf_reserve(&P->tmp, (size_t)n_a * 16 + 64)); CK(mga_dbuf_reserve(&P->mini, (size_t)n_mini * 4 + 16));
-	CK(mga_dev_seed_fill(sc, &B->dev, n, (const mg128_t*)P->mz.p, (const int64_t*)P->mzoff.p, (const int32_t*)P->cnt.p, opt->occ_max1, (const int32_t*)P->occ.p, (const uint64_t*)P->val.p,
-						 (const int64_t*)P->aoff.p, (mg128_t*)P->a.p, (const int64_t*)P->minioff.p, (int32_t*)P->mini.p, (mg128_t*)P->tmp.p));
+	CK(mga_dbuf_reserve(&P->a, (size_t)n_a * 16 + 64)); CK(mga_dbuf_reserve(&P->mini, (size_t)n_mini * 4 + 16));
+	if (long_q) {
+		CK(mga_dbuf_reserve(&P->sd_tk, (size_t)n_mz * 4 + 4)); CK(mga_dbuf_reserve(&P->sd_kf, (size_t)n_mz * 4 + 4));
+		CK(mga_dbuf_reserve(&P->sd_offa, (size_t)(n_mz + 1) * 8)); CK(mga_dbuf_reserve(&P->sd_offm, (size_t)(n_mz + 1) * 8));
+		CK(mga_dev_seed_expand(sc, &B->dev, n, (const mg128_t*)P->mz.p, (const int64_t*)P->mzoff.p, n_mz, opt->occ_max1, (const int32_t*)P->occ.p, (const uint64_t*)P->val.p,
+							   (mg128_t*)P->a.p, (int32_t*)P->mini.p, (int32_t*)P->sd_tk.p, (int32_t*)P->sd_kf.p, (int64_t*)P->sd_offa.p, (int64_t*)P->sd_offm.p));
+	} else {
+		CK(mga_dbuf_reserve(&P->tmp, (size_t)n_a * 16 + 64));
+		CK(mga_dev_seed_fill(sc, &B->dev, n, (const mg128_t*)P->mz.p, (const int64_t*)P->mzoff.p, (const int32_t*)P->cnt.p, opt->occ_max1, (const int32_t*)P->occ.p, (const uint64_t*)P->val.p,
+							 (const int64_t*)P->aoff.p, (mg128_t*)P->a.p, (const int64_t*)P->minioff.p, (int32_t*)P->mini.p, (mg128_t*)P->tmp.p));
+	}
 	CK(mga_hbuf_reserve(&P->h_mini, (size_t)n_mini * 4 + 16));
 	CK(mga_d2h_s(sc, P->h_mini.p, P->mini.p, (size_t)n_mini * 4));
 	/* ---- linear chaining ---- */
@@ -604,7 +645,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	/* ---- host: graph chaining + gap list ---- */
 	b = mga_batch_init(gi, opt, n, qlens, seqs, qnames, q_off, n_threads);
 	b->want_text = gaf_part != 0 && (opt->flag & MG_M_CIGAR) && B->dev.d_gseq != 0 && !env_int("MGA_HOST_TEXT", 0); /* only GAF bytes are wanted: cg/ds come from the device */
-	CK(mga_batch_chain(b, h_nmz, h_rep, (const int32_t*)P->h_mini.p, h_minioff, h_nu, h_nb, (const uint64_t*)P->h_u.p, (const mg128_t*)P->h_b.p, h_aoff, is_rmq, h_rflag));
+	CK(mga_batch_chain(b, h_nmz, h_rep, (const int32_t*)P->h_mini.p, h_minioff, h_nu, h_nb, (const uint64_t*)P->h_u.p, (const mg128_t*)P->h_b.p, h_aoff, long_q ? 2 : is_rmq, h_rflag));
 	if (g_dbg_pipe > 1) PIPE_LOG(" hostchain", n, t0);
 	t1 = mga_wtime(); st->t_host_chain += t1 - t0; t0 = t1;
 	/* ---- WFA over all gaps ---- */

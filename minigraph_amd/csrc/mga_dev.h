@@ -111,6 +111,12 @@ int mga_dev_seed_fill(mga_sctx_t *sc, const mga_didx_t *ix, int n, const mg128_t
 					  const int32_t *d_occ, const uint64_t *d_val, const int64_t *d_a_off, mg128_t *d_a,
 					  const int64_t *d_mini_off, int32_t *d_mini, mg128_t *d_tmp);
 
+/* the same expansion with one thread per minimizer of the whole batch and NO sort (long queries under MG_M_RMQ: the host chains, and sorts
+ * first); d_mz_off must be exact and contiguous; scratch: d_tk, d_kf (n_mz int32 each), d_off_a, d_off_m (n_mz + 1 int64 each) */
+int mga_dev_seed_expand(mga_sctx_t *sc, const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, int64_t n_mz, int max_occ,
+						const int32_t *d_occ, const uint64_t *d_val, mg128_t *d_a, int32_t *d_mini,
+						int32_t *d_tk, int32_t *d_kf, int64_t *d_off_a, int64_t *d_off_m);
+
 /* ---- linear chaining (k_lchain.hip) ---- */
 /* per read i with anchors d_a[a_off[i]..a_off[i+1]) (x-sorted): chains u[] (score<<32|cnt) at d_u + a_off[i],
  * compacted anchors at d_b + a_off[i]; d_nu[i], d_nb[i] = their counts.  d_ws: mga_dev_lchain_ws_bytes(total) bytes. */

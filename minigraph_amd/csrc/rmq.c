@@ -28,14 +28,15 @@ typedef struct {
 } rq_pool_t;
 
 #define RQ_MAXD 64
-#define ND(t, x) ((t)->a[(x)])
+#define ND(t, x) (*(rq_node_t*)((char*)(t)->a + (x))) /* handles are BYTE offsets into the pool: base + handle is one addressing mode, no multiply on the pointer-chasing path */
+#define RQ_H(idx) ((int32_t)((idx) * (int32_t)sizeof(rq_node_t)))
 
 static int32_t rq_alloc(rq_pool_t *t)
 {
 	int32_t x;
 	if (t->free_head >= 0) { x = t->free_head; t->free_head = ND(t, x).c[0]; return x; }
 	if (t->n == t->m) { t->m = t->m ? t->m + (t->m >> 1) : 256; t->a = MGA_REALLOC(rq_node_t, t->a, t->m); }
-	return t->n++;
+	return RQ_H(t->n++);
 }
 static void rq_release(rq_pool_t *t, int32_t x) { ND(t, x).c[0] = t->free_head; t->free_head = x; }
 
@@ -138,7 +139,7 @@ static int32_t rq_erase(rq_pool_t *t, int32_t *root, int32_t y, int64_t i)
 	unsigned char dir[RQ_MAXD];
 	int k, d = 0, cmp;
 	if (t->n == t->m) { t->m += (t->m >> 1) + 16; t->a = MGA_REALLOC(rq_node_t, t->a, t->m); }
-	fake = t->n;
+	fake = RQ_H(t->n);
 	ND(t, fake) = ND(t, *root);
 	ND(t, fake).c[0] = *root, ND(t, fake).c[1] = -1;
 	for (cmp = -1, p = fake; cmp; cmp = rq_cmp(t, y, i, p)) {
@@ -334,7 +335,7 @@ mg128_t *mga_lchain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_sk
 		}
 		/* drop active chains out of range (lchain.c:294-302) */
 		while (st < i && (a[i].x >> 32 != a[st].x >> 32 || a[i].x > a[st].x + max_dist || (root >= 0 ? ND(&T, root).size : 0) > cap_rmq_size)) {
-			if (root >= 0 && rq_find(&T, root, (int32_t)a[st].y, st) >= 0) {
+			if (root >= 0) { /* (krmq_find + krmq_erase in the reference: rq_erase leaves the tree untouched when the key is absent) */
 				q = rq_erase(&T, &root, (int32_t)a[st].y, st);
 				if (q >= 0) rq_release(&T, q);
 			}
@@ -342,7 +343,7 @@ mg128_t *mga_lchain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_sk
 		}
 		if (max_dist_inner > 0) { /* lchain.c:303-312 */
 			while (st_inner < i && (a[i].x >> 32 != a[st_inner].x >> 32 || a[i].x > a[st_inner].x + max_dist_inner || (root_inner >= 0 ? ND(&T, root_inner).size : 0) > cap_rmq_size)) {
-				if (root_inner >= 0 && rq_find(&T, root_inner, (int32_t)a[st_inner].y, st_inner) >= 0) {
+				if (root_inner >= 0) {
 					q = rq_erase(&T, &root_inner, (int32_t)a[st_inner].y, st_inner);
 					if (q >= 0) rq_release(&T, q);
 				}
