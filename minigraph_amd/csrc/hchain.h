@@ -11,6 +11,11 @@ mg128_t *mga_compact_a(int32_t n_u, uint64_t *u, int32_t n_v, const int32_t *v, 
 
 mg128_t *mga_lchain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_skip, int cap_rmq_size, int min_cnt, int min_sc,
 						float pen_gap, float pen_skip, int64_t n, const mg128_t *a, int *n_u_, uint64_t **u_);
+/* the same in two steps: forward pass over anchors [beg,end) (beg = 0 or the start of a (segment,strand) group; f, p, v, t are arrays of the
+ * whole read, t zeroed), then backtracking + compaction over all n anchors (frees f, p, v, t) */
+void mga_lchain_rmq_fwd(int max_dist, int max_dist_inner, int bw, int max_chn_skip, int cap_rmq_size, float pen_gap, float pen_skip,
+						int64_t beg, int64_t end, const mg128_t *a, int32_t *f, int64_t *p, int32_t *v, int32_t *t);
+mg128_t *mga_lchain_rmq_finish(int bw, int min_cnt, int min_sc, int64_t n, const mg128_t *a, int32_t *f, int64_t *p, int32_t *v, int32_t *t, int *n_u_, uint64_t **u_);
 
 /* mg_lchain_gen (lchain.c:374-408) */
 mg_lchain_t *mga_lchain_gen(uint32_t hash, int qlen, int n_u, const uint64_t *u, const mg128_t *a);

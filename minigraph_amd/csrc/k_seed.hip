@@ -151,22 +151,61 @@ extern "C" int mga_dev_seed_fill(mga_sctx_t *sc, const mga_didx_t *ix, int n, co
 
 // ---- long queries (-x asm: contigs of megabases, a handful per batch) ----------------------------------------------
 // One wavefront per read leaves the GPU idle when a read has 10^7 minimizers.  Here every minimizer of the batch is a work item:
-// the kept occurrence counts and kept flags are scanned over the whole (contiguous, exact-offset) minimizer array, which gives
-// each minimizer its first anchor slot and its mini_pos slot directly (the per-read offsets are the same scans sampled at the
-// read boundaries), then one thread per minimizer writes its anchors.  The anchors stay in hit order: under MG_M_RMQ the chainer
-// runs on the host, which sorts them there with the reference's exact radix permutation (ksortx.c) before it chains.
-__global__ void __launch_bounds__(256) k_seed_kept(int64_t n_mz, const int32_t *__restrict__ occ, int max_occ, int32_t *__restrict__ tk, int32_t *__restrict__ kf)
+//   k_seedl_probe   table probe per minimizer; kept occurrence count, kept flag, and rid<<32 | (repetitive ? end : 0)
+//   three device scans over the whole (contiguous, exact-offset) minimizer array: the sums give every minimizer its first anchor
+//                   slot and its mini_pos slot (and, sampled at the read boundaries, the per-read offsets); the running MAXIMUM of
+//                   rid<<32|end gives every repetitive minimizer the end of the previous repetitive one of its read -- ends grow
+//                   along a read -- which is all the sequential rep_st/rep_en update of collect_matches (map-algo.c:72-79,88) needs
+//   k_seedl_finish  rep_len per read (a few atomics: repetitive minimizers are rare) and the per-read offsets
+//   k_seedl_expand  one thread per minimizer writes its anchors.
+// The anchors stay in hit order: under MG_M_RMQ the chainer runs on the host, which sorts them there with the reference's exact
+// radix permutation (ksortx.c) before it chains.
+#include <rocprim/device/device_scan.hpp>
+
+__device__ __forceinline__ int seedl_read_of(const int64_t *__restrict__ mz_off, int n, int64_t i)
+{ // last r with mz_off[r] <= i (empty reads share an offset with their successor)
+	int lo = 0, hi = n - 1;
+	while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (mz_off[mid] <= i) lo = mid; else hi = mid - 1; }
+	return lo;
+}
+
+__global__ void __launch_bounds__(256) k_seedl_probe(mga_didx_t ix, int n, const mg128_t *__restrict__ mz, const int64_t *__restrict__ mz_off, int64_t n_mz, int max_occ,
+													 int32_t *__restrict__ occ, uint64_t *__restrict__ val, int32_t *__restrict__ tk, int32_t *__restrict__ kf, uint64_t *__restrict__ rep_key)
 {
 	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_mz; i += (int64_t)gridDim.x * blockDim.x) {
-		const int32_t t = occ[i];
+		const mg128_t m = mz[i];
+		uint64_t v;
+		const int32_t t = seed_probe(ix, m.x >> 8, &v);
 		const bool kept = t < max_occ;
+		occ[i] = t, val[i] = v;
 		tk[i] = kept ? t : 0, kf[i] = kept ? 1 : 0;
+		const uint32_t en = ((uint32_t)m.y >> 1) + 1;
+		rep_key[i] = (uint64_t)seedl_read_of(mz_off, n, i) << 32 | (kept ? 0u : en);
 	}
 }
 
-__global__ void __launch_bounds__(256) k_seed_expand(mga_didx_t ix, int n, const mg128_t *__restrict__ mz, const int64_t *__restrict__ mz_off, int64_t n_mz, int max_occ,
-													 const int32_t *__restrict__ occ, const uint64_t *__restrict__ val, const int64_t *__restrict__ off_a, const int64_t *__restrict__ off_m,
-													 mg128_t *__restrict__ a_all, int32_t *__restrict__ mini_all)
+__global__ void __launch_bounds__(256) k_seedl_finish(int n, const mg128_t *__restrict__ mz, const int64_t *__restrict__ mz_off, int64_t n_mz, const int32_t *__restrict__ kf,
+													  const uint64_t *__restrict__ rep_max, const int64_t *__restrict__ off_a, const int64_t *__restrict__ off_m,
+													  int64_t *__restrict__ a_off, int64_t *__restrict__ mini_off, int32_t *__restrict__ rep_len)
+{
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_mz; i += (int64_t)gridDim.x * blockDim.x) {
+		if (i <= n) a_off[i] = off_a[mz_off[i]], mini_off[i] = off_m[mz_off[i]];
+		if (kf[i]) continue;
+		const mg128_t m = mz[i];
+		const int32_t en = (int32_t)((uint32_t)m.y >> 1) + 1, st = en - (int32_t)(m.x & 0xff);
+		const uint64_t me = rep_max[i]; // inclusive: its high half is this minimizer's read
+		int32_t ep = 0;
+		if (i > 0 && rep_max[i - 1] >> 32 == me >> 32) ep = (int32_t)(uint32_t)rep_max[i - 1];
+		atomicAdd(&rep_len[me >> 32], st > ep ? en - st : en - ep);
+	}
+	if (n_mz <= n) // fewer minimizers than reads: the offsets above did not cover every read
+		for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (int64_t)gridDim.x * blockDim.x)
+			a_off[i] = off_a[mz_off[i]], mini_off[i] = off_m[mz_off[i]];
+}
+
+__global__ void __launch_bounds__(256) k_seedl_expand(mga_didx_t ix, int n, const mg128_t *__restrict__ mz, const int64_t *__restrict__ mz_off, int64_t n_mz, int max_occ,
+													  const int32_t *__restrict__ occ, const uint64_t *__restrict__ val, const int64_t *__restrict__ off_a, const int64_t *__restrict__ off_m,
+													  mg128_t *__restrict__ a_all, int32_t *__restrict__ mini_all)
 {
 	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_mz; i += (int64_t)gridDim.x * blockDim.x) {
 		const int32_t t = occ[i];
@@ -176,9 +215,8 @@ __global__ void __launch_bounds__(256) k_seed_expand(mga_didx_t ix, int n, const
 		const uint32_t q_pos = (uint32_t)m.y, q_span = (uint32_t)(m.x & 0xff);
 		mini_all[off_m[i]] = (int32_t)(q_pos >> 1);
 		if (t == 0) continue;
-		int lo = 0, hi = n - 1; // the read of minimizer i: last r with mz_off[r] <= i (empty reads share an offset with their successor)
-		while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (mz_off[mid] <= i) lo = mid; else hi = mid - 1; }
-		const int64_t rb = mz_off[lo], re = mz_off[lo + 1];
+		const int r = seedl_read_of(mz_off, n, i);
+		const int64_t rb = mz_off[r], re = mz_off[r + 1];
 		bool tandem = false; // map-algo.c:168-172: the neighbouring minimizer of the same read has the same hash
 		if (i > rb && mz[i - 1].x >> 8 == key) tandem = true;
 		if (i < re - 1 && mz[i + 1].x >> 8 == key) tandem = true;
@@ -200,21 +238,45 @@ __global__ void __launch_bounds__(256) k_seed_expand(mga_didx_t ix, int n, const
 	}
 }
 
-extern "C" int mga_dev_seed_expand(mga_sctx_t *sc, const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, int64_t n_mz, int max_occ,
-								   const int32_t *d_occ, const uint64_t *d_val, mg128_t *d_a, int32_t *d_mini,
-								   int32_t *d_tk, int32_t *d_kf, int64_t *d_off_a, int64_t *d_off_m)
+static int seedl_blocks(int64_t n_mz) { int64_t nb = (n_mz + 255) / 256; return (int)(nb > 16384 ? 16384 : nb < 1 ? 1 : nb); }
+
+extern "C" int mga_dev_seed_long_count(mga_sctx_t *sc, const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, int64_t n_mz, int max_occ,
+									   int32_t *d_occ, uint64_t *d_val, int32_t *d_tk, int32_t *d_kf, int64_t *d_off_a, int64_t *d_off_m, uint64_t *d_rep_key, uint64_t *d_rep_max,
+									   int64_t *d_a_off, int64_t *d_mini_off, int32_t *d_rep_len)
 {
-	if (n <= 0 || n_mz <= 0) return 0;
+	if (n <= 0) return 0;
 	hipStream_t st = (hipStream_t)sc->stream;
-	int nb = (int)((n_mz + 255) / 256);
-	if (nb > 16384) nb = 16384;
-	mga_prof_begin(sc->stream, MGA_K_SEED_FILL);
-	hipLaunchKernelGGL(k_seed_kept, dim3(nb), dim3(256), 0, st, n_mz, d_occ, max_occ, d_tk, d_kf);
-	mga_prof_end(sc->stream, MGA_K_SEED_FILL);
+	MGA_HIP_CHECK(hipMemsetAsync(d_rep_len, 0, (size_t)n * 4, st));
+	if (n_mz <= 0) {
+		MGA_HIP_CHECK(hipMemsetAsync(d_a_off, 0, (size_t)(n + 1) * 8, st));
+		MGA_HIP_CHECK(hipMemsetAsync(d_mini_off, 0, (size_t)(n + 1) * 8, st));
+		return 0;
+	}
+	const int nb = seedl_blocks(n_mz);
+	mga_prof_begin(sc->stream, MGA_K_SEED_COUNT);
+	hipLaunchKernelGGL(k_seedl_probe, dim3(nb), dim3(256), 0, st, *ix, n, d_mz, d_mz_off, n_mz, max_occ, d_occ, d_val, d_tk, d_kf, d_rep_key);
+	mga_prof_end(sc->stream, MGA_K_SEED_COUNT);
 	MGA_HIP_CHECK(hipGetLastError());
 	if (mga_dev_scan_i32_to_i64(sc, d_tk, n_mz, d_off_a) < 0 || mga_dev_scan_i32_to_i64(sc, d_kf, n_mz, d_off_m) < 0) return -1;
+	{
+		size_t tmp_bytes = 0;
+		MGA_HIP_CHECK(rocprim::inclusive_scan(nullptr, tmp_bytes, d_rep_key, d_rep_max, (size_t)n_mz, rocprim::maximum<uint64_t>(), st));
+		if (mga_dbuf_reserve(&sc->scan_tmp, tmp_bytes + 64) < 0) return -1;
+		MGA_HIP_CHECK(rocprim::inclusive_scan(sc->scan_tmp.p, tmp_bytes, d_rep_key, d_rep_max, (size_t)n_mz, rocprim::maximum<uint64_t>(), st));
+	}
+	mga_prof_begin(sc->stream, MGA_K_SEED_COUNT);
+	hipLaunchKernelGGL(k_seedl_finish, dim3(nb), dim3(256), 0, st, n, d_mz, d_mz_off, n_mz, (const int32_t*)d_kf, (const uint64_t*)d_rep_max, (const int64_t*)d_off_a, (const int64_t*)d_off_m, d_a_off, d_mini_off, d_rep_len);
+	mga_prof_end(sc->stream, MGA_K_SEED_COUNT);
+	MGA_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+
+extern "C" int mga_dev_seed_long_fill(mga_sctx_t *sc, const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, int64_t n_mz, int max_occ,
+									  const int32_t *d_occ, const uint64_t *d_val, const int64_t *d_off_a, const int64_t *d_off_m, mg128_t *d_a, int32_t *d_mini)
+{
+	if (n <= 0 || n_mz <= 0) return 0;
 	mga_prof_begin(sc->stream, MGA_K_SEED_FILL);
-	hipLaunchKernelGGL(k_seed_expand, dim3(nb), dim3(256), 0, st, *ix, n, d_mz, d_mz_off, n_mz, max_occ, d_occ, d_val, d_off_a, d_off_m, d_a, d_mini);
+	hipLaunchKernelGGL(k_seedl_expand, dim3(seedl_blocks(n_mz)), dim3(256), 0, (hipStream_t)sc->stream, *ix, n, d_mz, d_mz_off, n_mz, max_occ, d_occ, d_val, d_off_a, d_off_m, d_a, d_mini);
 	mga_prof_end(sc->stream, MGA_K_SEED_FILL);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;

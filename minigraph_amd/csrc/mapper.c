@@ -112,6 +112,7 @@ struct mga_batch_s {
 	const uint64_t *u;
 	const mg128_t *a;
 	int a_is_raw;
+	struct rq_read_s *rq;   /* a_is_raw: per-read state of the phased RMQ chaining (see rq_* below) */
 	const int32_t *rescue_flag; /* per read: what the chaining kernel did about the long-join rescue (NULL: decide here) */
 	/* stage-2 inputs */
 	mga_cigsrc_t src;
@@ -153,6 +154,129 @@ void mga_batch_lchain_par(const mg_idx_t *gi, const mg_mapopt_t *opt, int qlen_m
 	par->chn_pen_gap = opt->chn_pen_gap * tmp, par->chn_pen_skip = opt->chn_pen_skip * tmp;
 }
 
+/* ---- MG_M_RMQ (-x asm): the RMQ chainer in phases -------------------------------------------------------------------------
+ * A batch under -x asm is a handful of contigs with up to 10^7 anchors each, and one chaining pass over such a contig is seconds of
+ * sequential tree work.  The forward pass restarts from empty trees wherever the target (segment, strand) changes
+ * (rmq.c: mga_lchain_rmq_fwd), so runs of whole groups are independent: phase 1 sorts every read's anchors (hit order from the
+ * device) and cuts them into such runs, phase 2 runs the forward pass of all runs of all reads on all threads, phase 3 backtracks
+ * per read and decides about the long-join rescue (map-algo.c:407-417), phases 4-5 repeat 2-3 with bw_long for the reads that
+ * need it.  chain_worker then picks the chains up. */
+typedef struct rq_read_s {
+	mg128_t *a; int64_t n;           /* anchors being chained: the read's slice of the batch (pass 1) or `out` of pass 1 (pass 2) */
+	int32_t *f, *v, *t; int64_t *p;
+	int64_t *cut; int32_t n_cut;     /* run boundaries: cut[0] = 0 .. cut[n_cut] = n */
+	mg128_t *out; uint64_t *u; int n_lc, pass2;
+} rq_read_t;
+typedef struct { int32_t read, k; } rq_task_t;
+
+#define RQ_RUN_MIN 16384 /* anchors per work item, at least */
+
+static void rq_cut(rq_read_t *r)
+{
+	int64_t i, last = 0;
+	int32_t m = 16;
+	r->cut = MGA_MALLOC(int64_t, m + 1), r->n_cut = 0;
+	r->cut[0] = 0;
+	for (i = 1; i < r->n; ++i)
+		if (r->a[i].x >> 32 != r->a[i - 1].x >> 32 && i - last >= RQ_RUN_MIN) {
+			if (r->n_cut + 1 == m) { m <<= 1; r->cut = MGA_REALLOC(int64_t, r->cut, m + 1); }
+			r->cut[++r->n_cut] = i, last = i;
+		}
+	r->cut[++r->n_cut] = r->n;
+}
+
+static void rq_arrays(rq_read_t *r)
+{
+	r->p = MGA_MALLOC(int64_t, r->n); r->f = MGA_MALLOC(int32_t, r->n); r->v = MGA_MALLOC(int32_t, r->n); r->t = MGA_CALLOC(int32_t, r->n);
+}
+
+static void rq_prepare_worker(void *data, int64_t i, int tid)
+{
+	mga_batch_t *b = (mga_batch_t*)data;
+	rq_read_t *r = &b->rq[i];
+	int64_t tc = cpu_now();
+	(void)tid;
+	r->n = b->a_off[i + 1] - b->a_off[i];
+	if (b->qlens[i] == 0 || (b->opt.max_qlen > 0 && b->qlens[i] > b->opt.max_qlen)) r->n = 0; /* chain_worker returns early for these */
+	if (r->n <= 0) return;
+	r->a = (mg128_t*)(b->a + b->a_off[i]); /* every read owns its slice of the staging buffer */
+	if (b->a_is_raw == 2 && r->n > 1) mga_ksort_128x(r->n, r->a); /* hit order from the device: radix_sort_128x (map-algo.c:189) */
+	rq_cut(r); rq_arrays(r);
+	CPU_ADD(C_LCCOPY, tc);
+}
+
+static void rq_fwd_worker(void *data, int64_t j, int tid)
+{
+	mga_batch_t *b = ((mga_batch_t**)data)[0];
+	const rq_task_t *task = &((const rq_task_t*)((void**)data)[1])[j];
+	rq_read_t *r = &b->rq[task->read];
+	const mg_mapopt_t *opt = &b->opt;
+	int64_t tc = cpu_now();
+	(void)tid;
+	mga_lchain_rmq_fwd(opt->max_gap, opt->max_gap_pre, r->pass2 ? opt->bw_long : opt->bw, opt->max_lc_skip, opt->rmq_size_cap, b->pen_gap, b->pen_skip,
+					   r->cut[task->k], r->cut[task->k + 1], r->a, r->f, r->p, r->v, r->t);
+	CPU_ADD(r->pass2 ? C_LCRESCUE : C_LCCOPY, tc);
+}
+
+static void rq_finish_worker(void *data, int64_t i, int tid)
+{
+	mga_batch_t *b = (mga_batch_t*)data;
+	rq_read_t *r = &b->rq[i];
+	const mg_mapopt_t *opt = &b->opt;
+	int64_t tc = cpu_now();
+	(void)tid;
+	if (r->n <= 0 || r->f == 0) return;
+	if (!r->pass2) {
+		r->out = mga_lchain_rmq_finish(opt->bw, opt->min_lc_cnt, opt->min_lc_score, r->n, r->a, r->f, r->p, r->v, r->t, &r->n_lc, &r->u);
+		r->f = r->v = r->t = 0, r->p = 0; free(r->cut); r->cut = 0;
+		if (opt->bw_long > opt->bw && (opt->flag & (MG_M_SPLICE | MG_M_SR)) == 0 && r->n_lc > 1) { /* map-algo.c:407-417 */
+			const int32_t qlen = b->qlens[i], st = (int32_t)r->out[0].y, en = (int32_t)r->out[(int32_t)r->u[0] - 1].y;
+			if (qlen - (en - st) > opt->rmq_rescue_size || qlen - (en - st) > qlen * opt->rmq_rescue_ratio) {
+				int32_t k;
+				int64_t n_a = 0;
+				for (k = 0; k < r->n_lc; ++k) n_a += (int32_t)r->u[k];
+				free(r->u); r->u = 0;
+				mga_ksort_128x(n_a, r->out);
+				r->a = r->out, r->n = n_a, r->pass2 = 1;
+				rq_cut(r); rq_arrays(r);
+			}
+		}
+		CPU_ADD(C_LCCOPY, tc);
+	} else {
+		mg128_t *a2 = mga_lchain_rmq_finish(opt->bw_long, opt->min_lc_cnt, opt->min_lc_score, r->n, r->a, r->f, r->p, r->v, r->t, &r->n_lc, &r->u);
+		r->f = r->v = r->t = 0, r->p = 0; free(r->cut); r->cut = 0;
+		free(r->out); r->out = a2;
+		CPU_ADD(C_LCRESCUE, tc);
+	}
+}
+
+static void rq_run_fwd(mga_batch_t *b, int pass2)
+{
+	int64_t n_task = 0, j = 0;
+	int i, k;
+	rq_task_t *task;
+	void *arg[2];
+	for (i = 0; i < b->n; ++i) if (b->rq[i].f && b->rq[i].pass2 == pass2) n_task += b->rq[i].n_cut;
+	if (n_task == 0) return;
+	task = MGA_MALLOC(rq_task_t, n_task);
+	for (i = 0; i < b->n; ++i)
+		if (b->rq[i].f && b->rq[i].pass2 == pass2)
+			for (k = 0; k < b->rq[i].n_cut; ++k) task[j].read = i, task[j++].k = k;
+	arg[0] = b, arg[1] = task;
+	mga_parallel_for(b->n_threads, n_task, rq_fwd_worker, arg);
+	free(task);
+}
+
+static void rq_chain_all(mga_batch_t *b)
+{
+	b->rq = MGA_CALLOC(rq_read_t, b->n > 0 ? b->n : 1);
+	mga_parallel_for(b->n_threads, b->n, rq_prepare_worker, b);
+	rq_run_fwd(b, 0);
+	mga_parallel_for(b->n_threads, b->n, rq_finish_worker, b);
+	rq_run_fwd(b, 1);
+	mga_parallel_for(b->n_threads, b->n, rq_finish_worker, b);
+}
+
 static void chain_worker(void *data, int64_t i, int tid)
 {
 	mga_batch_t *b = (mga_batch_t*)data;
@@ -176,11 +300,9 @@ static void chain_worker(void *data, int64_t i, int tid)
 	hash ^= mga_hash_u32((uint32_t)qlen) + mga_hash_u32((uint32_t)opt->seed);
 	hash = mga_hash_u32(hash);
 
-	if (b->a_is_raw) { /* MG_M_RMQ: the RMQ chainer is the primary chainer (map-algo.c:397-399) */
-		int64_t na = b->a_off[i + 1] - b->a_off[i];
-		if (na > 1 && b->a_is_raw == 2) mga_ksort_128x(na, (mg128_t*)(b->a + b->a_off[i])); /* hit order from the device: radix_sort_128x (map-algo.c:189), every read has its own slice */
-		if (na > 0) a = mga_lchain_rmq(opt->max_gap, opt->max_gap_pre, opt->bw, opt->max_lc_skip, opt->rmq_size_cap, opt->min_lc_cnt, opt->min_lc_score,
-									   b->pen_gap, b->pen_skip, na, b->a + b->a_off[i], &n_lc, &u);
+	if (b->a_is_raw) { /* MG_M_RMQ: the RMQ chainer is the primary chainer (map-algo.c:397-399); both of its passes ran in mga_batch_chain's phases */
+		a = b->rq[i].out, u = b->rq[i].u, n_lc = b->rq[i].n_lc;
+		b->rq[i].out = 0, b->rq[i].u = 0;
 	} else { /* chains of the GPU DP */
 		n_lc = b->nu[i], n_a = b->nb[i];
 		if (n_lc > 0) {
@@ -190,7 +312,8 @@ static void chain_worker(void *data, int64_t i, int tid)
 	}
 	CPU_ADD(C_LCCOPY, tc);
 	/* long-join rescue (map-algo.c:407-417) */
-	if (b->rescue_flag && !b->a_is_raw) { /* the kernel evaluated the condition: 1 = done there, 2 = due but deferred to the host (priority tie) */
+	if (b->a_is_raw) { /* done in the phases */
+	} else if (b->rescue_flag) { /* the kernel evaluated the condition: 1 = done there, 2 = due but deferred to the host (priority tie) */
 		if (b->rescue_flag[i] == 2) goto do_rescue;
 	} else if (opt->bw_long > opt->bw && (opt->flag & (MG_M_SPLICE | MG_M_SR)) == 0 && n_lc > 1) {
 		int32_t st = (int32_t)a[0].y, en = (int32_t)a[(int32_t)u[0] - 1].y;
@@ -275,7 +398,9 @@ int mga_batch_chain(mga_batch_t *b, const int32_t *n_mz, const int32_t *rep_len,
 	b->rescue_flag = rescue_flag;
 	b->n_mz = n_mz, b->rep_len = rep_len, b->mini_pos = mini_pos, b->mini_off = mini_off;
 	b->nu = nu, b->nb = nb, b->u = u, b->a = a, b->a_off = a_off, b->a_is_raw = a_is_raw;
+	if (a_is_raw) rq_chain_all(b);
 	mga_parallel_for(b->n_threads, b->n, chain_worker, b);
+	if (b->rq) { free(b->rq); b->rq = 0; }
 	for (t = 0; t < b->n_threads; ++t) {
 		b->tp_prob_base[t + 1] = b->tp_prob_base[t] + b->tp[t].n_prob;
 		b->tp_t_base[t + 1] = b->tp_t_base[t] + b->tp[t].n_t;
@@ -463,7 +588,7 @@ typedef struct {
 	mga_sctx_t *sc;
 	mga_dbuf_t seq, qoff, cnt, mzoff, mz, occ, val, na, nmini, rep, aoff, minioff, a, tmp, mini, u, b, nu, nb, ws;
 	mga_dbuf_t tseq, prob, res, pool, used, ncig, cigoff, ord, rflag, item, chain, vert, txtres, txtpool;
-	mga_dbuf_t sk_item, sk_cnt, sk_off, sd_tk, sd_kf, sd_offa, sd_offm; /* long-query path (MG_M_RMQ): sketch pieces, per-minimizer scans */
+	mga_dbuf_t sk_item, sk_cnt, sk_off, sd_tk, sd_kf, sd_offa, sd_offm, sd_rkey, sd_rmax; /* long-query path (MG_M_RMQ): sketch pieces, per-minimizer scans */
 	mga_hbuf_t h_b, h_u, h_mini, h_tseq, h_prob, h_pool, h_seq, h_ncig, h_cigoff, h_item, h_chain, h_vert, h_txtres, h_txtpool; /* pinned staging */
 } pipe_ctx_t;
 
@@ -588,10 +713,19 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	CK(mga_dbuf_reserve(&P->occ, (size_t)n_mz * 4 + 4)); CK(mga_dbuf_reserve(&P->val, (size_t)n_mz * 8 + 8));
 	CK(mga_dbuf_reserve(&P->na, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&P->nmini, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&P->rep, (size_t)n * 4 + 4));
 	CK(mga_dbuf_reserve(&P->aoff, (size_t)(n + 1) * 8)); CK(mga_dbuf_reserve(&P->minioff, (size_t)(n + 1) * 8));
-	CK(mga_dev_seed_count(sc, &B->dev, n, (const mg128_t*)P->mz.p, (const int64_t*)P->mzoff.p, (const int32_t*)P->cnt.p, opt->occ_max1, (int32_t*)P->occ.p, (uint64_t*)P->val.p,
+	if (long_q) {
+		CK(mga_dbuf_reserve(&P->sd_tk, (size_t)n_mz * 4 + 4)); CK(mga_dbuf_reserve(&P->sd_kf, (size_t)n_mz * 4 + 4));
+		CK(mga_dbuf_reserve(&P->sd_offa, (size_t)(n_mz + 1) * 8)); CK(mga_dbuf_reserve(&P->sd_offm, (size_t)(n_mz + 1) * 8));
+		CK(mga_dbuf_reserve(&P->sd_rkey, (size_t)n_mz * 8 + 8)); CK(mga_dbuf_reserve(&P->sd_rmax, (size_t)n_mz * 8 + 8));
+		CK(mga_dev_seed_long_count(sc, &B->dev, n, (const mg128_t*)P->mz.p, (const int64_t*)P->mzoff.p, n_mz, opt->occ_max1, (int32_t*)P->occ.p, (uint64_t*)P->val.p,
+								   (int32_t*)P->sd_tk.p, (int32_t*)P->sd_kf.p, (int64_t*)P->sd_offa.p, (int64_t*)P->sd_offm.p, (uint64_t*)P->sd_rkey.p, (uint64_t*)P->sd_rmax.p,
+								   (int64_t*)P->aoff.p, (int64_t*)P->minioff.p, (int32_t*)P->rep.p));
+	} else {
+		CK(mga_dev_seed_count(sc, &B->dev, n, (const mg128_t*)P->mz.p, (const int64_t*)P->mzoff.p, (const int32_t*)P->cnt.p, opt->occ_max1, (int32_t*)P->occ.p, (uint64_t*)P->val.p,
 						  (int32_t*)P->na.p, (int32_t*)P->nmini.p, (int32_t*)P->rep.p));
-	CK(mga_dev_scan_i32_to_i64(sc, (const int32_t*)P->na.p, n, (int64_t*)P->aoff.p));
-	CK(mga_dev_scan_i32_to_i64(sc, (const int32_t*)P->nmini.p, n, (int64_t*)P->minioff.p));
+		CK(mga_dev_scan_i32_to_i64(sc, (const int32_t*)P->na.p, n, (int64_t*)P->aoff.p));
+		CK(mga_dev_scan_i32_to_i64(sc, (const int32_t*)P->nmini.p, n, (int64_t*)P->minioff.p));
+	}
 	h_aoff = MGA_MALLOC(int64_t, n + 1); h_minioff = MGA_MALLOC(int64_t, n + 1); h_rep = MGA_MALLOC(int32_t, n);
 	CK(mga_d2h_s(sc, h_aoff, P->aoff.p, (size_t)(n + 1) * 8)); CK(mga_d2h_s(sc, h_minioff, P->minioff.p, (size_t)(n + 1) * 8)); CK(mga_d2h_s(sc, h_rep, P->rep.p, (size_t)n * 4));
 	CK(mga_ssync(sc));
@@ -600,10 +734,8 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	n_a = h_aoff[n], n_mini = h_minioff[n];
 	CK(mga_dbuf_reserve(&P->a, (size_t)n_a * 16 + 64)); CK(mga_dbuf_reserve(&P->mini, (size_t)n_mini * 4 + 16));
 	if (long_q) {
-		CK(mga_dbuf_reserve(&P->sd_tk, (size_t)n_mz * 4 + 4)); CK(mga_dbuf_reserve(&P->sd_kf, (size_t)n_mz * 4 + 4));
-		CK(mga_dbuf_reserve(&P->sd_offa, (size_t)(n_mz + 1) * 8)); CK(mga_dbuf_reserve(&P->sd_offm, (size_t)(n_mz + 1) * 8));
-		CK(mga_dev_seed_expand(sc, &B->dev, n, (const mg128_t*)P->mz.p, (const int64_t*)P->mzoff.p, n_mz, opt->occ_max1, (const int32_t*)P->occ.p, (const uint64_t*)P->val.p,
-							   (mg128_t*)P->a.p, (int32_t*)P->mini.p, (int32_t*)P->sd_tk.p, (int32_t*)P->sd_kf.p, (int64_t*)P->sd_offa.p, (int64_t*)P->sd_offm.p));
+		CK(mga_dev_seed_long_fill(sc, &B->dev, n, (const mg128_t*)P->mz.p, (const int64_t*)P->mzoff.p, n_mz, opt->occ_max1, (const int32_t*)P->occ.p, (const uint64_t*)P->val.p,
+								  (const int64_t*)P->sd_offa.p, (const int64_t*)P->sd_offm.p, (mg128_t*)P->a.p, (int32_t*)P->mini.p));
 	} else {
 		CK(mga_dbuf_reserve(&P->tmp, (size_t)n_a * 16 + 64));
 		CK(mga_dev_seed_fill(sc, &B->dev, n, (const mg128_t*)P->mz.p, (const int64_t*)P->mzoff.p, (const int32_t*)P->cnt.p, opt->occ_max1, (const int32_t*)P->occ.p, (const uint64_t*)P->val.p,

@@ -111,11 +111,15 @@ int mga_dev_seed_fill(mga_sctx_t *sc, const mga_didx_t *ix, int n, const mg128_t
 					  const int32_t *d_occ, const uint64_t *d_val, const int64_t *d_a_off, mg128_t *d_a,
 					  const int64_t *d_mini_off, int32_t *d_mini, mg128_t *d_tmp);
 
-/* the same expansion with one thread per minimizer of the whole batch and NO sort (long queries under MG_M_RMQ: the host chains, and sorts
- * first); d_mz_off must be exact and contiguous; scratch: d_tk, d_kf (n_mz int32 each), d_off_a, d_off_m (n_mz + 1 int64 each) */
-int mga_dev_seed_expand(mga_sctx_t *sc, const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, int64_t n_mz, int max_occ,
-						const int32_t *d_occ, const uint64_t *d_val, mg128_t *d_a, int32_t *d_mini,
-						int32_t *d_tk, int32_t *d_kf, int64_t *d_off_a, int64_t *d_off_m);
+/* long queries (MG_M_RMQ: contigs of megabases, the host chains): the same two passes with one thread per minimizer of the whole
+ * batch and NO sort.  d_mz_off must be exact and contiguous.  count: probes, per-minimizer scans (d_off_a / d_off_m, n_mz + 1 int64 each),
+ * per-read d_a_off / d_mini_off (n + 1) and d_rep_len; scratch d_tk, d_kf (n_mz int32), d_rep_key, d_rep_max (n_mz uint64).
+ * fill: anchors in hit order at d_a + d_off_a[m], mini_pos at d_mini + d_off_m[m]. */
+int mga_dev_seed_long_count(mga_sctx_t *sc, const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, int64_t n_mz, int max_occ,
+							int32_t *d_occ, uint64_t *d_val, int32_t *d_tk, int32_t *d_kf, int64_t *d_off_a, int64_t *d_off_m, uint64_t *d_rep_key, uint64_t *d_rep_max,
+							int64_t *d_a_off, int64_t *d_mini_off, int32_t *d_rep_len);
+int mga_dev_seed_long_fill(mga_sctx_t *sc, const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, int64_t n_mz, int max_occ,
+						   const int32_t *d_occ, const uint64_t *d_val, const int64_t *d_off_a, const int64_t *d_off_m, mg128_t *d_a, int32_t *d_mini);
 
 /* ---- linear chaining (k_lchain.hip) ---- */
 /* per read i with anchors d_a[a_off[i]..a_off[i+1]) (x-sorted): chains u[] (score<<32|cnt) at d_u + a_off[i],

@@ -121,16 +121,6 @@ static void rq_insert(rq_pool_t *t, int32_t *root, int32_t x) /* krmq_insert, kr
 	if (bq < 0) *root = r; else ND(t, bq).c[bp != ND(t, bq).c[0]] = r;
 }
 
-static int32_t rq_find(const rq_pool_t *t, int32_t root, int32_t y, int64_t i)
-{
-	int32_t p = root;
-	while (p >= 0) {
-		int cmp = rq_cmp(t, y, i, p);
-		if (cmp < 0) p = ND(t, p).c[0]; else if (cmp > 0) p = ND(t, p).c[1]; else break;
-	}
-	return p;
-}
-
 /* erase the node with key (y,i); returns its pool index or -1.  krmq_erase, krmq.h:245-323.
  * Pool slot t->n (never a real node) serves as the reference's stack-allocated "fake" super-root. */
 static int32_t rq_erase(rq_pool_t *t, int32_t *root, int32_t y, int64_t i)
@@ -298,24 +288,20 @@ static inline int32_t score_simple(const mg128_t *ai, const mg128_t *aj, float p
 	return sc;
 }
 
-/* in: n x-sorted anchors a[]; out: chains in u[] (malloc'ed, *n_u_ entries) and the compacted anchor array
- * (malloc'ed, returned).  Same contract as the reference except that a[] is not freed. */
-mg128_t *mga_lchain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_skip, int cap_rmq_size, int min_cnt, int min_sc,
-						float pen_gap, float pen_skip, int64_t n, const mg128_t *a, int *n_u_, uint64_t **u_)
+/* Forward pass of mg_lchain_rmq (lchain.c:275-353) over anchors [beg,end) of the x-sorted array a[]: fills f, p, v and the skip
+ * marks t (zeroed by the caller) with ABSOLUTE indices.  beg must be 0 or the first anchor of a (segment, strand) group: there
+ * the sequential run has just erased every node from both trees (the `a[i].x>>32 != a[st].x>>32` clause of lchain.c:294,304), st,
+ * st_inner and i0 all equal beg, and nothing else is carried over -- so runs of whole groups are independent work items, which
+ * is what lets a contig of 10^7 anchors use every host thread (mapper.c: rmq phases). */
+void mga_lchain_rmq_fwd(int max_dist, int max_dist_inner, int bw, int max_chn_skip, int cap_rmq_size, float pen_gap, float pen_skip,
+						int64_t beg, int64_t end, const mg128_t *a, int32_t *f, int64_t *p, int32_t *v, int32_t *t)
 {
-	int32_t *f, *t, *v, n_u, n_v, max_drop = bw, root = -1, root_inner = -1;
-	int64_t *p, i, i0, st = 0, st_inner = 0;
-	uint64_t *u;
+	int32_t root = -1, root_inner = -1;
+	int64_t i, i0, st = beg, st_inner = beg;
 	rq_pool_t T = {0, 0, 0, -1};
-	mg128_t *ret;
-
-	*u_ = 0, *n_u_ = 0;
-	if (n == 0 || a == 0) return 0;
 	if (max_dist < bw) max_dist = bw;
 	if (max_dist_inner <= 0 || max_dist_inner >= max_dist) max_dist_inner = 0;
-	p = MGA_MALLOC(int64_t, n); f = MGA_MALLOC(int32_t, n); v = MGA_MALLOC(int32_t, n); t = MGA_CALLOC(int32_t, n);
-
-	for (i = i0 = 0; i < n; ++i) {
+	for (i = i0 = beg; i < end; ++i) {
 		int64_t max_j = -1;
 		int32_t q_span = (int32_t)(a[i].y >> 32 & 0xff), max_f = q_span, q;
 		if (i0 < i && a[i0].x != a[i].x) { /* add in-range anchors (lchain.c:279-293) */
@@ -358,7 +344,7 @@ mg128_t *mga_lchain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_sk
 			sc = f[j] + score_simple(&a[i], &a[j], pen_gap, pen_skip, &exact, &width);
 			if (width <= bw && sc > max_f) max_f = sc, max_j = j;
 			if (!exact && root_inner >= 0 && (int32_t)a[i].y > 0) {
-				int32_t lo = rq_lower(&T, root_inner, (int32_t)a[i].y - 1, n);
+				int32_t lo = rq_lower(&T, root_inner, (int32_t)a[i].y - 1, end); /* (the reference's key index n: above every index in the tree) */
 				if (lo >= 0) {
 					rq_itr_t itr;
 					rq_itr_seek(&T, root_inner, lo, &itr);
@@ -385,12 +371,33 @@ mg128_t *mga_lchain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_sk
 		v[i] = max_j >= 0 && v[max_j] > max_f ? v[max_j] : max_f;
 	}
 	free(T.a);
+}
 
-	u = mga_chain_backtrack(n, f, p, v, t, min_cnt, min_sc, max_drop, 0, &n_u, &n_v);
+/* backtracking + compaction after the forward pass over all of a[0..n) (lchain.c:355-371); frees f, p, v, t */
+mg128_t *mga_lchain_rmq_finish(int bw, int min_cnt, int min_sc, int64_t n, const mg128_t *a, int32_t *f, int64_t *p, int32_t *v, int32_t *t, int *n_u_, uint64_t **u_)
+{
+	int32_t n_u, n_v;
+	uint64_t *u;
+	mg128_t *ret;
+	u = mga_chain_backtrack(n, f, p, v, t, min_cnt, min_sc, bw, 0, &n_u, &n_v);
 	*n_u_ = n_u, *u_ = u;
 	free(p); free(f); free(t);
 	if (n_u == 0) { free(v); return 0; }
 	ret = mga_compact_a(n_u, u, n_v, v, a);
 	free(v);
 	return ret;
+}
+
+/* in: n x-sorted anchors a[]; out: chains in u[] (malloc'ed, *n_u_ entries) and the compacted anchor array
+ * (malloc'ed, returned).  Same contract as the reference except that a[] is not freed. */
+mg128_t *mga_lchain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_skip, int cap_rmq_size, int min_cnt, int min_sc,
+						float pen_gap, float pen_skip, int64_t n, const mg128_t *a, int *n_u_, uint64_t **u_)
+{
+	int32_t *f, *t, *v;
+	int64_t *p;
+	*u_ = 0, *n_u_ = 0;
+	if (n == 0 || a == 0) return 0;
+	p = MGA_MALLOC(int64_t, n); f = MGA_MALLOC(int32_t, n); v = MGA_MALLOC(int32_t, n); t = MGA_CALLOC(int32_t, n);
+	mga_lchain_rmq_fwd(max_dist, max_dist_inner, bw, max_chn_skip, cap_rmq_size, pen_gap, pen_skip, 0, n, a, f, p, v, t);
+	return mga_lchain_rmq_finish(bw, min_cnt, min_sc, n, a, f, p, v, t, n_u_, u_);
 }

@@ -8,6 +8,7 @@
 #include "mga_dev.h"
 #include "dev_common.h"
 
+extern "C" void mga_ksort_128x(int64_t n, mg128_t *a); // ksortx.c: radix_sort_128x with the reference's exact permutation
 extern "C" void mga_free(void *p) { free(p); }
 
 namespace {
@@ -130,20 +131,38 @@ extern "C" int mga_seed_batch(const mg_idx_t *gi, int n, const mg128_t *mz, cons
 	if (!d_mz.alloc((size_t)n_mz * 16 + 16) || !d_mzoff.alloc((n + 1) * 8) || !d_occ.alloc((size_t)n_mz * 4 + 4) || !d_val.alloc((size_t)n_mz * 8 + 8) ||
 		!d_na.alloc(n * 4) || !d_nmini.alloc(n * 4) || !d_rep.alloc(n * 4) || !d_aoff.alloc((n + 1) * 8) || !d_minioff.alloc((n + 1) * 8)) return -1;
 	if (mga_h2d(d_mz.p, mz, (size_t)n_mz * 16) < 0 || mga_h2d(d_mzoff.p, mz_off, (n + 1) * 8) < 0) return -1;
-	if (mga_dev_seed_count(SC, ix, n, d_mz.as<mg128_t>(), d_mzoff.as<int64_t>(), 0, max_occ, d_occ.as<int32_t>(), d_val.as<uint64_t>(),
-						   d_na.as<int32_t>(), d_nmini.as<int32_t>(), d_rep.as<int32_t>()) < 0) return -1;
-	if (mga_dev_scan_i32_to_i64(SC, d_na.as<int32_t>(), n, d_aoff.as<int64_t>()) < 0) return -1;
-	if (mga_dev_scan_i32_to_i64(SC, d_nmini.as<int32_t>(), n, d_minioff.as<int64_t>()) < 0) return -1;
+	// MGA_SEED_LONG=1: the intra-read parallel kernels of the long-query path (k_seed.hip), anchors sorted here like the host chainer does
+	const char *e_long = getenv("MGA_SEED_LONG");
+	const bool use_long = e_long && atoi(e_long) > 0;
+	dptr d_tk, d_kf, d_offa, d_offm, d_rkey, d_rmax;
+	if (use_long) {
+		if (!d_tk.alloc((size_t)n_mz * 4 + 4) || !d_kf.alloc((size_t)n_mz * 4 + 4) || !d_offa.alloc((size_t)(n_mz + 1) * 8) || !d_offm.alloc((size_t)(n_mz + 1) * 8) ||
+			!d_rkey.alloc((size_t)n_mz * 8 + 8) || !d_rmax.alloc((size_t)n_mz * 8 + 8)) return -1;
+		if (mga_dev_seed_long_count(SC, ix, n, d_mz.as<mg128_t>(), d_mzoff.as<int64_t>(), n_mz, max_occ, d_occ.as<int32_t>(), d_val.as<uint64_t>(), d_tk.as<int32_t>(), d_kf.as<int32_t>(),
+									d_offa.as<int64_t>(), d_offm.as<int64_t>(), d_rkey.as<uint64_t>(), d_rmax.as<uint64_t>(), d_aoff.as<int64_t>(), d_minioff.as<int64_t>(), d_rep.as<int32_t>()) < 0) return -1;
+	} else {
+		if (mga_dev_seed_count(SC, ix, n, d_mz.as<mg128_t>(), d_mzoff.as<int64_t>(), 0, max_occ, d_occ.as<int32_t>(), d_val.as<uint64_t>(),
+							   d_na.as<int32_t>(), d_nmini.as<int32_t>(), d_rep.as<int32_t>()) < 0) return -1;
+		if (mga_dev_scan_i32_to_i64(SC, d_na.as<int32_t>(), n, d_aoff.as<int64_t>()) < 0) return -1;
+		if (mga_dev_scan_i32_to_i64(SC, d_nmini.as<int32_t>(), n, d_minioff.as<int64_t>()) < 0) return -1;
+	}
 	int64_t *h_aoff = (int64_t*)malloc((n + 1) * 8), *h_moff = (int64_t*)malloc((n + 1) * 8);
 	int32_t *h_rep = (int32_t*)malloc(n * 4);
 	if (mga_ssync(SC) < 0 || mga_d2h(h_aoff, d_aoff.p, (n + 1) * 8) < 0 || mga_d2h(h_moff, d_minioff.p, (n + 1) * 8) < 0 || mga_d2h(h_rep, d_rep.p, n * 4) < 0) return -1;
 	const int64_t n_a = h_aoff[n], n_m = h_moff[n];
-	if (!d_a.alloc((size_t)n_a * 16 + 64) || !d_tmp.alloc((size_t)n_a * 16 + 64) || !d_mini.alloc((size_t)n_m * 4 + 16)) return -1;
-	if (mga_dev_seed_fill(SC, ix, n, d_mz.as<mg128_t>(), d_mzoff.as<int64_t>(), 0, max_occ, d_occ.as<int32_t>(), d_val.as<uint64_t>(),
-						  d_aoff.as<int64_t>(), d_a.as<mg128_t>(), d_minioff.as<int64_t>(), d_mini.as<int32_t>(), d_tmp.as<mg128_t>()) < 0) return -1;
+	if (!d_a.alloc((size_t)n_a * 16 + 64) || !d_mini.alloc((size_t)n_m * 4 + 16)) return -1;
+	if (use_long) {
+		if (mga_dev_seed_long_fill(SC, ix, n, d_mz.as<mg128_t>(), d_mzoff.as<int64_t>(), n_mz, max_occ, d_occ.as<int32_t>(), d_val.as<uint64_t>(), d_offa.as<int64_t>(), d_offm.as<int64_t>(),
+								   d_a.as<mg128_t>(), d_mini.as<int32_t>()) < 0) return -1;
+	} else {
+		if (!d_tmp.alloc((size_t)n_a * 16 + 64)) return -1;
+		if (mga_dev_seed_fill(SC, ix, n, d_mz.as<mg128_t>(), d_mzoff.as<int64_t>(), 0, max_occ, d_occ.as<int32_t>(), d_val.as<uint64_t>(),
+							  d_aoff.as<int64_t>(), d_a.as<mg128_t>(), d_minioff.as<int64_t>(), d_mini.as<int32_t>(), d_tmp.as<mg128_t>()) < 0) return -1;
+	}
 	mg128_t *h_a = (mg128_t*)malloc((size_t)n_a * 16 + 16);
 	int32_t *h_mini = (int32_t*)malloc((size_t)n_m * 4 + 4);
 	if (mga_ssync(SC) < 0 || mga_d2h(h_a, d_a.p, (size_t)n_a * 16) < 0 || mga_d2h(h_mini, d_mini.p, (size_t)n_m * 4) < 0) return -1;
+	if (use_long) for (int i = 0; i < n; ++i) mga_ksort_128x(h_aoff[i + 1] - h_aoff[i], h_a + h_aoff[i]); // radix_sort_128x, map-algo.c:189
 	*a = h_a, *a_off = h_aoff, *rep_len = h_rep, *mini_pos = h_mini, *mini_off = h_moff;
 	return 0;
 }

@@ -242,18 +242,25 @@ def test_reference_fixtures_both_presets(preset, query):
             raise AssertionError("%s %s cigar=%s: %s" % (preset, query, cigar, first_diff(ref_out, got)))
 
 
-def test_asm_preset_long_contigs_vs_reference_binary():
-    """-cx asm on assembly-like queries: 300 kb contigs with 0.5 % divergence against the bubble graph"""
+@pytest.mark.parametrize("contig,n,err", [(300000, 30, 0.005), (4000000, 5, 0.001)])
+def test_asm_preset_long_contigs_vs_reference_binary(contig, n, err, monkeypatch):
+    """-cx asm on assembly-like queries: 300 kb and 4 Mbp contigs against the bubble graph.  This is the long-query path: sketch in
+    64 kb pieces, one thread per minimizer for the seeds, anchors sorted by the host, the RMQ chainer's forward pass spread over
+    (segment, strand) runs.  MGA_NO_LONGQ=1 (one wavefront per contig, device sort) must give the same bytes"""
     if not os.path.exists(rb.REF_BIN):
         pytest.skip("oracle/_ref/minigraph not present")
     d = tempfile.mkdtemp()
-    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "6000000", "-H", "3", "-n", "30", "-l", "300000", "-e", "0.005", "-s", "51"], stderr=subprocess.DEVNULL)
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "6000000", "-H", "3", "-n", str(n), "-l", str(contig), "-e", str(err), "-s", "51"], stderr=subprocess.DEVNULL)
     graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
-    ref_out, got = os.path.join(d, "ref.gaf"), os.path.join(d, "got.gaf")
+    ref_out, got, got2 = os.path.join(d, "ref.gaf"), os.path.join(d, "got.gaf"), os.path.join(d, "got2.gaf")
     run_ref(["-c", "-x", "asm", "-t", "8", graph, reads], ref_out)
     mga.map_files(graph, [reads], got, preset="asm", cigar=True)
     if open(ref_out, "rb").read() != open(got, "rb").read():
         raise AssertionError(first_diff(ref_out, got))
+    if contig <= 300000:
+        monkeypatch.setenv("MGA_NO_LONGQ", "1")
+        mga.map_files(graph, [reads], got2, preset="asm", cigar=True)
+        assert open(got2, "rb").read() == open(got, "rb").read()
 
 
 def test_reference_shaped_c_api_mg_map_and_mg_map_batch():

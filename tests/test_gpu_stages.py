@@ -174,7 +174,12 @@ def sim():
     return d
 
 
-def test_seed_and_lchain_parity(ora, sim):
+@pytest.mark.parametrize("long_path", [False, True])
+def test_seed_and_lchain_parity(ora, sim, long_path, monkeypatch):
+    """long_path: the intra-read parallel seed kernels that -x asm uses for contigs of megabases (probe per minimizer, device scans,
+    rep_len from a running maximum), here on ordinary reads against the same oracle"""
+    if long_path:
+        monkeypatch.setenv("MGA_SEED_LONG", "1")
     gfa, reads = os.path.join(sim, "t.gfa"), read_fa(os.path.join(sim, "t.reads.fa"))
     G = mga.Graph(gfa)
     try:
