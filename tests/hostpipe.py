@@ -46,15 +46,16 @@ def graph_segments(path):
     return [l.split(b"\t")[2].upper() for l in open(path, "rb") if l.startswith(b"S\t")]
 
 
-def run_reference(graph, reads, cigar=True, threads=4):
-    args = [rb.REF_BIN] + (["-c"] if cigar else []) + ["-x", "lr", "-t", str(threads), graph, reads]
+def run_reference(graph, reads, cigar=True, threads=4, preset="lr"):
+    args = [rb.REF_BIN] + (["-c"] if cigar else []) + ["-x", preset, "-t", str(threads), graph, reads]
     p = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
     m = re.search(r"occ_max1=(\d+); lc_max_occ=(\d+)", p.stderr.decode())
     return p.stdout, int(m.group(1)), int(m.group(2))
 
 
-def map_with_oracle_stages(graph, reads, occ_max1, lc_max_occ, cigar=True, n_threads=4):
-    """whole -cx lr job: oracle for the kernel stages, product C code for everything on the host"""
+def map_with_oracle_stages(graph, reads, occ_max1, lc_max_occ, cigar=True, n_threads=4, preset="lr"):
+    """whole -cx lr (or -cx asm) job: oracle for the kernel stages, product C code for everything on the host.  Under asm the RMQ chainer
+    is the primary chainer and runs in the product's host phases (mapper.c: rq_chain_all) on the oracle's sorted anchors"""
     L = mga.load()
     ora = rb.Oracle()
     pp = C.POINTER(C.c_void_p)
@@ -78,7 +79,8 @@ def map_with_oracle_stages(graph, reads, occ_max1, lc_max_occ, cigar=True, n_thr
 
     io, mo, go = mga.idxopt_t(), mga.mapopt_t(), mga.ggopt_t()
     L.mg_opt_set(None, C.byref(io), C.byref(mo), C.byref(go))
-    L.mg_opt_set(b"lr", C.byref(io), C.byref(mo), C.byref(go))
+    L.mg_opt_set(preset.encode(), C.byref(io), C.byref(mo), C.byref(go))
+    is_rmq = 1 if (mo.flag & 0x8000) else 0
     if cigar:
         mo.flag |= mga.MG_M_CIGAR
     mo.occ_max1, mo.lc_max_occ = occ_max1, lc_max_occ  # what mg_opt_update derives from the index
@@ -94,8 +96,11 @@ def map_with_oracle_stages(graph, reads, occ_max1, lc_max_occ, cigar=True, n_thr
     for s in seqs:
         mz = ora.sketch(s, io.w, io.k)
         a, rl, mp = ora.seed_hits(oidx, mz, occ_max1)
-        u, b = ora.lchain_dp(a, max_dist_x=par.max_dist_x, max_dist_y=par.max_dist_y, bw=par.bw, max_skip=par.max_skip,
-                             max_iter=par.max_iter, min_cnt=par.min_cnt, min_sc=par.min_sc, pen_gap=par.chn_pen_gap, pen_skip=par.chn_pen_skip)
+        if is_rmq:
+            u, b = np.zeros(0, dtype=np.uint64), a  # raw x-sorted anchors: the host chains
+        else:
+            u, b = ora.lchain_dp(a, max_dist_x=par.max_dist_x, max_dist_y=par.max_dist_y, bw=par.bw, max_skip=par.max_skip,
+                                 max_iter=par.max_iter, min_cnt=par.min_cnt, min_sc=par.min_sc, pen_gap=par.chn_pen_gap, pen_skip=par.chn_pen_skip)
         n_mz.append(len(mz)); rep.append(rl); minis.append(mp)
         nus.append(len(u)); nbs.append(len(b)); us.append(u); aas.append((len(a), b))
     ora.idx_free(oidx)
@@ -119,7 +124,7 @@ def map_with_oracle_stages(graph, reads, occ_max1, lc_max_occ, cigar=True, n_thr
     N_MZ, REP, NU, NB = i32(n_mz), i32(rep), i32(nus), i32(nbs)
     b = L.mga_batch_init(gi, C.byref(mo), n, qlens, seqp, namep, q_off.ctypes.data, n_threads)
     assert L.mga_batch_chain(b, N_MZ.ctypes.data, REP.ctypes.data, MINI.ctypes.data, mini_off.ctypes.data, NU.ctypes.data, NB.ctypes.data,
-                             U.ctypes.data, A.ctypes.data, a_off.ctypes.data, 0, None) == 0
+                             U.ctypes.data, A.ctypes.data, a_off.ctypes.data, is_rmq, None) == 0
     n_prob, n_tb = L.mga_batch_n_wfa(b), L.mga_batch_wfa_target_bytes(b)
     probs = (wfa_prob_t * max(n_prob, 1))()
     tbuf = C.create_string_buffer(int(n_tb) + 64)

@@ -38,3 +38,16 @@ def test_synthetic_graph_vs_reference_binary(cigar):
     want, occ, lco = hp.run_reference(graph, reads, cigar=cigar)
     got, _ = hp.map_with_oracle_stages(graph, reads, occ, lco, cigar=cigar)
     assert got == want
+
+
+@pytest.mark.skipif(not os.path.exists(rb.REF_BIN), reason="oracle/_ref/minigraph not built")
+@pytest.mark.parametrize("cigar", [True, False])
+def test_asm_preset_host_phases_vs_reference_binary(cigar):
+    """-x asm: the RMQ chainer is the primary chainer and runs in the product's host phases (sorted anchors -> (segment, strand) runs ->
+    forward passes on the thread pool -> backtracking -> rescue pass); 300 kb contigs give several runs per contig"""
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "1500000", "-H", "3", "-n", "6", "-l", "300000", "-e", "0.004", "-s", "9"], stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    want, occ, lco = hp.run_reference(graph, reads, cigar=cigar, preset="asm")
+    got, _ = hp.map_with_oracle_stages(graph, reads, occ, lco, cigar=cigar, preset="asm")
+    assert got == want
