@@ -153,13 +153,14 @@ __global__ void __launch_bounds__(64 * NW) k_wfa_r(int n_items, const int32_t *_
 					const wfr_u2 *tw = (const wfr_u2*)(Tb + (tp & 3) * SEQS + (tp & ~3)), *qw = (const wfr_u2*)(Qb + (qp & 3) * SEQS + (qp & ~3)); // 4-byte aligned
 					int32_t n = 0, m8 = 0; // m8: matched blocks of 8 bases
 					bool act = val && room > 0;
-					while (__ballot(act)) { // uniform loop; finished lanes reload their last block
+					while (__ballot(act)) { // uniform loop, no divergent branch inside: finished lanes reload their last block and add nothing
 						const wfr_u2 a = tw[m8], b = qw[m8];
 						const uint32_t c0 = a.x ^ b.x, c1 = a.y ^ b.y;
-						if (act) {
-							if ((c0 | c1) == 0) { ++m8; n += 8; act = n < room; }
-							else { n += c0 ? (int32_t)(__builtin_ctz(c0) >> 3) : 4 + (int32_t)(__builtin_ctz(c1) >> 3); act = false; }
-						}
+						const int32_t e0 = (int32_t)((c0 ? (uint32_t)__builtin_ctz(c0) : 32u) >> 3), e1 = (int32_t)((c1 ? (uint32_t)__builtin_ctz(c1) : 32u) >> 3); // equal leading bytes of each half: 0..4
+						const int32_t adv = e0 < 4 ? e0 : 4 + e1; // of the block: 0..8
+						n += act ? adv : 0;
+						m8 += (act && adv == 8) ? 1 : 0;
+						act = act && adv == 8 && n < room;
 					}
 					n = min(n, room);
 					const int32_t k = k0 + n;
