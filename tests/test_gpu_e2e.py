@@ -437,3 +437,30 @@ def test_command_line_options_vs_reference_binary(workload, tag, cli, idx_opt, m
     if workload == "repeat" and tag == "occ_2nd_vc":
         body = open(got, "rb").read()
         assert b"tp:A:S" in body and b"junk\t3000\t0\t0\t*" in body  # secondaries and the unmapped read were really printed
+
+
+def test_several_query_files_and_small_minibatches_vs_reference_binary():
+    """minigraph graph a.fa b.fq.gz with -K 300k: the files are mapped one after the other (gmap.c:203-208), each in mini-batches of
+    300 kbp (reader thread -> mapper -> writer thread, output buffers swapped between them); same bytes, same order"""
+    import gzip
+    if not os.path.exists(rb.REF_BIN):
+        pytest.skip("oracle/_ref/minigraph not present")
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "2000000", "-H", "3", "-n", "240", "-s", "77"], stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    recs = open(reads, "rb").read().split(b">")[1:]
+    fa, fq = os.path.join(d, "a.fa"), os.path.join(d, "b.fq.gz")
+    with open(fa, "wb") as f:
+        for r in recs[:150]:
+            f.write(b">" + r)
+    with gzip.open(fq, "wb") as f:
+        for r in recs[150:]:
+            name, seq = r.split(b"\n", 1)
+            seq = seq.replace(b"\n", b"")
+            f.write(b"@" + name + b" some comment\n" + seq + b"\n+\n" + b"I" * len(seq) + b"\n")
+    ref_out, got = os.path.join(d, "ref.gaf"), os.path.join(d, "got.gaf")
+    run_ref(["-c", "-x", "lr", "-t", "4", "-K", "300k", graph, fa, fq], ref_out)
+    mga.map_files(graph, [fa, fq], got, map_opt=dict(mini_batch_size=300000))
+    if open(ref_out, "rb").read() != open(got, "rb").read():
+        raise AssertionError(first_diff(ref_out, got))
+    assert open(got, "rb").read().count(b"\n") >= 240
