@@ -70,6 +70,8 @@ typedef struct {
 	u64map_t ha, ht;       /* visited (vertex, query pos) of the current step ; traceback node dedup */
 	intv_v intv, tmp, swap;
 	diag_v ooo;
+	diag_v wf[2], head; /* the two wavefronts (current / next, swapped every step) and the cells that sit on a vertex or query end: kept across steps */
+	int cur;
 	trace_t *tr; size_t n_tr, m_tr;
 	int32_t s, end_tb;
 	uint32_t end_v; int32_t end_off;
@@ -108,6 +110,12 @@ static inline int32_t extend1(int32_t d, int32_t k, int32_t vl, const char *ts, 
 {
 	int32_t max_k = (ql - d < vl ? ql - d : vl) - 1;
 	const char *t = ts + 1, *q = qs + d + 1;
+	while (k + 8 <= max_k) { /* 8 bases per compare while a whole block is inside both sequences (gfa-ed.c:312-322 does the same on padded copies) */
+		uint64_t x, y;
+		memcpy(&x, t + k, 8); memcpy(&y, q + k, 8);
+		if (x != y) return k + (__builtin_ctzll(x ^ y) >> 3);
+		k += 8;
+	}
 	while (k < max_k && t[k] == q[k]) ++k;
 	return k;
 }
@@ -281,14 +289,17 @@ static void extend_batch(gw_t *z, int32_t n, diag_t *a, diag_v *B, diag_v *A)
 	B->n += m;
 }
 
-/* one edit-distance step: consumes a[] (freed), returns the next wavefront or NULL when (v1,off1) is reached (gfa-ed.c:405-507) */
+/* one edit-distance step: reads the current wavefront a[] (= z->wf[z->cur]), builds the next one in the other buffer and returns it, or NULL when (v1,off1) is reached (gfa-ed.c:405-507) */
 static diag_t *step(gw_t *z, uint32_t v1, int32_t off1, int32_t *n_a_, diag_t *a)
 {
 	int32_t i, x, n = *n_a_, do_dedup = 1;
 	size_t head = 0;
-	diag_v A = {0, 0, 0}, B = {0, 0, 0};
 	const gfa_t *g = z->g;
 	const gfa_edseq_t *es = z->es;
+	diag_v *Bp = &z->wf[z->cur ^ 1], *Ap = &z->head;
+#define A (*Ap)
+#define B (*Bp)
+	A.n = B.n = 0;
 
 	z->end_v = (uint32_t)-1, z->end_off = z->end_tb = -1;
 	z->tmp.n = 0;
@@ -297,7 +308,6 @@ static diag_t *step(gw_t *z, uint32_t v1, int32_t off1, int32_t *n_a_, diag_t *a
 	for (x = 0, i = 1; i <= n; ++i)
 		if (i == n || a[i].vd != a[i-1].vd + 1) { extend_batch(z, i - x, &a[x], &B, &A); x = i; }
 	if (A.n == 0) do_dedup = 0;
-	free(a);
 
 	while (head < A.n) {
 		diag_t t = A.a[head++];
@@ -340,7 +350,6 @@ static diag_t *step(gw_t *z, uint32_t v1, int32_t off1, int32_t *n_a_, diag_t *a
 			if (nv == 0 || n_ext != nv) diag_push(&B, v, d + 1, k, x0 + 1, 1, t.t);
 		} else if (v1 == (uint32_t)-1 || (v == v1 && k == off1)) { /* query finished at the requested end */
 			z->end_v = v, z->end_off = k, z->end_tb = t.t, *n_a_ = 0;
-			free(A.a); free(B.a);
 			return 0;
 		} else if (k + 1 < vl) { /* query finished inside a vertex: delete the next target base */
 			diag_push(&B, v, d - 1, k + 1, x0 + 1, ooo, t.t);
@@ -351,11 +360,13 @@ static diag_t *step(gw_t *z, uint32_t v1, int32_t off1, int32_t *n_a_, diag_t *a
 			for (j = 0; j < nv; ++j) diag_push(&B, av[j].w, qi - av[j].ow, av[j].ow, x0 + 1, 1, tw);
 		}
 	}
-	free(A.a);
 	*n_a_ = n = (int32_t)B.n;
 	if (do_dedup) *n_a_ = n = dedup(z, n, B.a);
 	if (z->max_lag > 0 && n > z->max_chk && ((z->s + 1) & 0xf) == 0) *n_a_ = n = prune(n, B.a, (uint32_t)z->max_lag, z->bw_dyn);
+	z->cur ^= 1;
 	return B.a;
+#undef A
+#undef B
 }
 
 int32_t mga_gwfa_bridge(const gfa_t *g, const gfa_edseq_t *es, int32_t ql, const char *q, uint32_t v0, int32_t off0, uint32_t v1, int32_t off1,
@@ -369,7 +380,8 @@ int32_t mga_gwfa_bridge(const gfa_t *g, const gfa_edseq_t *es, int32_t ql, const
 	memset(&z, 0, sizeof z);
 	z.g = g, z.es = es, z.ql = ql, z.q = q;
 	z.max_chk = 1000, z.bw_dyn = 1000, z.max_lag = max_lag, z.i_term = 500000000LL; /* gchain1.c:361-363 */
-	a = MGA_CALLOC(diag_t, 1);
+	VRESERVE(diag_t, z.wf[0], 16);
+	a = z.wf[0].a; memset(a, 0, sizeof(diag_t));
 	a[0].vd = mk_vd(v0, -off0), a[0].k = off0 - 1, a[0].xo = 0;
 	z.m_tr = 16, z.tr = MGA_MALLOC(trace_t, z.m_tr);
 	z.tr[0].v = -1, z.tr[0].pre = -1, z.n_tr = 1, a[0].t = 0; /* the root of the traceback forest (gfa-ed.c:568); real nodes have v >= 0 */
@@ -393,7 +405,7 @@ int32_t mga_gwfa_bridge(const gfa_t *g, const gfa_edseq_t *es, int32_t ql, const
 		*path = p, *nv = n;
 	}
 	ret = z.end_v != (uint32_t)-1 ? z.s : -1;
-	free(a);
+	free(z.wf[0].a); free(z.wf[1].a); free(z.head.a);
 	u64map_free(&z.ha); u64map_free(&z.ht);
 	free(z.intv.a); free(z.tmp.a); free(z.swap.a); free(z.ooo.a); free(z.tr);
 	return ret;
