@@ -72,6 +72,7 @@ typedef struct {
 	diag_v ooo;
 	diag_v wf[2], head; /* the two wavefronts (current / next, swapped every step) and the cells that sit on a vertex or query end: kept across steps */
 	int cur;
+	uint64_t *sort_key; int64_t *sort_perm; diag_t *sort_tmp; int32_t m_sort; /* diag_sort scratch */
 	trace_t *tr; size_t n_tr, m_tr;
 	int32_t s, end_tb;
 	uint32_t end_v; int32_t end_off;
@@ -150,15 +151,21 @@ static void diag_sort(gw_t *z, int32_t n_a, diag_t *a)
 	n_b = n_a - n_c;
 	b = z->ooo.a, c = b + n_b;
 	for (i = j = k = 0; i < n_a; ++i) { if (a[i].xo & 1) c[k++] = a[i]; else b[j++] = a[i]; }
-	if (n_c > 1) {
-		uint64_t *key = MGA_MALLOC(uint64_t, n_c);
-		int64_t *perm = MGA_MALLOC(int64_t, n_c);
-		diag_t *tmp = MGA_MALLOC(diag_t, n_c);
+	if (n_c > 1) { /* scratch kept in z: one call per step */
+		uint64_t *key;
+		int64_t *perm;
+		diag_t *tmp;
+		if (z->m_sort < n_c) {
+			z->m_sort = n_c + (n_c >> 1) + 16;
+			z->sort_key = MGA_REALLOC(uint64_t, z->sort_key, z->m_sort);
+			z->sort_perm = MGA_REALLOC(int64_t, z->sort_perm, z->m_sort);
+			z->sort_tmp = MGA_REALLOC(diag_t, z->sort_tmp, z->m_sort);
+		}
+		key = z->sort_key, perm = z->sort_perm, tmp = z->sort_tmp;
 		for (i = 0; i < n_c; ++i) key[i] = c[i].vd;
 		mga_ksort_perm(n_c, key, 8, perm);
 		for (i = 0; i < n_c; ++i) tmp[i] = c[perm[i]];
 		memcpy(c, tmp, (size_t)n_c * sizeof(diag_t));
-		free(key); free(perm); free(tmp);
 	}
 	for (k = 0; k < n_c; ++k) c[k].xo &= 0xfffffffeU;
 	i = j = k = 0;
@@ -405,7 +412,7 @@ int32_t mga_gwfa_bridge(const gfa_t *g, const gfa_edseq_t *es, int32_t ql, const
 		*path = p, *nv = n;
 	}
 	ret = z.end_v != (uint32_t)-1 ? z.s : -1;
-	free(z.wf[0].a); free(z.wf[1].a); free(z.head.a);
+	free(z.wf[0].a); free(z.wf[1].a); free(z.head.a); free(z.sort_key); free(z.sort_perm); free(z.sort_tmp);
 	u64map_free(&z.ha); u64map_free(&z.ht);
 	free(z.intv.a); free(z.tmp.a); free(z.swap.a); free(z.ooo.a); free(z.tr);
 	return ret;
