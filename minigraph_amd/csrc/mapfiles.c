@@ -41,7 +41,7 @@ static void rd_line(rd_t *r, str_t *s)
 
 /* one FASTA/FASTQ record (kseq semantics, bseq.c:61-98 via kseq.h); returns 0, or -1 at EOF.  `last` carries a record
  * marker that was read as the first character of a line between calls.  Lines are moved with memchr/memcpy. */
-static int read_record(rd_t *r, int *last, str_t *name, str_t *seq)
+static int read_record_x(rd_t *r, int *last, str_t *name, str_t *seq, int append) /* append: the bases go behind what seq already holds (the caller's slab) */
 {
 	int c;
 	if (*last == 0) { /* find the next record: a marker at the start of a line */
@@ -49,9 +49,10 @@ static int read_record(rd_t *r, int *last, str_t *name, str_t *seq)
 		if (c < 0) return -1;
 		*last = c;
 	}
-	name->l = seq->l = 0;
+	const size_t seq0 = append ? seq->l : 0;
+	name->l = 0, seq->l = seq0;
 	str_room(name, 1); str_room(seq, 1);
-	name->s[0] = seq->s[0] = 0;
+	name->s[0] = seq->s[seq0] = 0;
 	{ /* header line: the name ends at the first white space, the comment is dropped */
 		size_t k;
 		rd_line(r, name);
@@ -68,7 +69,7 @@ static int read_record(rd_t *r, int *last, str_t *name, str_t *seq)
 	if (c == '+') { /* FASTQ: skip the '+' line and as many quality characters as bases */
 		size_t ql = 0;
 		rd_line(r, 0);
-		while (ql < seq->l && rd_fill(r)) {
+		while (ql < seq->l - seq0 && rd_fill(r)) {
 			char *p = r->buf + r->beg, *q = (char*)memchr(p, '\n', (size_t)(r->end - r->beg));
 			size_t n = q ? (size_t)(q - p) : (size_t)(r->end - r->beg);
 			r->beg += (int)n + (q ? 1 : 0);
@@ -79,6 +80,7 @@ static int read_record(rd_t *r, int *last, str_t *name, str_t *seq)
 	}
 	return 0;
 }
+static int read_record(rd_t *r, int *last, str_t *name, str_t *seq) { return read_record_x(r, last, name, seq, 0); }
 
 /* upper case + U -> T, as the reference does per base (gmap.c:81, bseq.c:50-58); branch-free so that it vectorises */
 __attribute__((optimize("O3"))) static void seq_normalize(char *s, size_t l)
@@ -105,13 +107,19 @@ int mga_reads_parse(const char *fn, int64_t *n_reads, int64_t *n_bases, uint64_t
 	r.fp = gzopen(fn, "r");
 	if (r.fp == 0) { mga_set_error("cannot open '%s'", fn); return -1; }
 	r.buf = (char*)malloc(RD_BUF);
-	while (read_record(&r, &last, &name, &seq) == 0) {
-		seq_normalize(seq.s, seq.l);
+	for (;;) { /* the way the file pipeline reads: bases appended to a slab that holds several records */
+		const size_t s0 = seq.l;
+		size_t sl;
+		if (read_record_x(&r, &last, &name, &seq, 1) < 0) break;
+		sl = seq.l - s0;
+		seq_normalize(seq.s + s0, sl);
 		for (k = 0; k < name.l; ++k) h = (h ^ (unsigned char)name.s[k]) * 0x100000001b3ULL;
 		h = (h ^ '\n') * 0x100000001b3ULL;
-		for (k = 0; k < seq.l; ++k) h = (h ^ (unsigned char)seq.s[k]) * 0x100000001b3ULL;
+		for (k = 0; k < sl; ++k) h = (h ^ (unsigned char)seq.s[s0 + k]) * 0x100000001b3ULL;
 		h = (h ^ '\n') * 0x100000001b3ULL;
-		++*n_reads, *n_bases += (int64_t)seq.l;
+		++*n_reads, *n_bases += (int64_t)sl;
+		seq.l += 1; /* terminator, as in the slab */
+		if (seq.l > (1u << 20)) seq.l = 0;
 	}
 	free(name.s); free(seq.s); free(r.buf); gzclose(r.fp);
 	*hash = h;
@@ -242,17 +250,21 @@ static void *reader_main(void *a)
 			int64_t size = 0;
 			int i;
 			while (size < R->batch_bases) {
-				if (read_record(&r, &last, &name, &seq) < 0) { done = 1; break; }
+				size_t s0, sl;
+				if (b->slab.m == 0) str_room(&b->slab, (size_t)(R->batch_bases < (1LL << 30) ? R->batch_bases : (1LL << 30)) / 2 + 65536); /* one allocation for most batches */
+				s0 = b->slab.l;
+				if (read_record_x(&r, &last, &name, &b->slab, 1) < 0) { done = 1; break; } /* the bases go straight into the slab: "SEQ\0name\0" per record */
 				if (b->n == b->m) {
 					b->m = b->m ? b->m << 1 : 1024;
 					b->qlens = MGA_REALLOC(int, b->qlens, b->m); b->name_off = MGA_REALLOC(size_t, b->name_off, b->m); b->seq_off = MGA_REALLOC(size_t, b->seq_off, b->m);
 				}
-				seq_normalize(seq.s, seq.l);
-				str_room(&b->slab, name.l + seq.l + 2);
+				sl = b->slab.l - s0;
+				seq_normalize(b->slab.s + s0, sl);
+				b->seq_off[b->n] = s0; b->slab.l += 1; /* keep the terminator */
+				str_room(&b->slab, name.l + 2);
 				b->name_off[b->n] = b->slab.l; memcpy(b->slab.s + b->slab.l, name.s, name.l + 1); b->slab.l += name.l + 1;
-				b->seq_off[b->n] = b->slab.l; memcpy(b->slab.s + b->slab.l, seq.s, seq.l + 1); b->slab.l += seq.l + 1;
-				b->qlens[b->n++] = (int)seq.l;
-				size += (int64_t)seq.l;
+				b->qlens[b->n++] = (int)sl;
+				size += (int64_t)sl;
 			}
 			if (b->n == 0) { fbatch_free(b); break; }
 			b->seqs = MGA_MALLOC(char*, b->n); b->names = MGA_MALLOC(char*, b->n);
