@@ -17,6 +17,7 @@
 // cell) go to LDS for the first TBLDS cells of a problem and to an HBM scratch beyond that.
 // A problem whose band leaves the 64*J*NW window, or outgrows the score / traceback tables, returns
 // MGA_WFA_RETRY_TIER and is re-run by the next tier.
+#include <type_traits>
 #include "mga_dev.h"
 #include "dev_common.h"
 
@@ -125,20 +126,25 @@ __global__ void __launch_bounds__(64 * NW) k_wfa_r(int n_items, const int32_t *_
 					__syncthreads();
 				} else WFR_LDS_FENCE();
 			}
-			int32_t H[J][17], E1[J][3], F1[J][3], E2[J][2], F2[J][2], GL[J], TBC[J];
+			int32_t H[J][18], E1[J][3], F1[J][3], E2[J][2], F2[J][2], GL[J], TBC[J];
 #pragma unroll
 			for (int j = 0; j < J; ++j) {
 #pragma unroll
-				for (int a = 0; a < 17; ++a) H[j][a] = WF_NEG_INF;
+				for (int a = 0; a < 18; ++a) H[j][a] = WF_NEG_INF;
 #pragma unroll
 				for (int a = 0; a < 3; ++a) E1[j][a] = F1[j][a] = WF_NEG_INF;
 #pragma unroll
 				for (int a = 0; a < 2; ++a) E2[j][a] = F2[j][a] = WF_NEG_INF;
 				GL[j] = -1, TBC[j] = 0;
-				if (W0 + lane + 64 * j == 0) H[j][0] = -1, GL[j] = 0; // score 0: H[d=0] = -1
+				if (W0 + lane + 64 * j == 0) H[j][2] = -1, GL[j] = 0; // score 0: H[d=0] = -1 (age 0 of an even step sits at index 2)
 			}
 
-			for (;;) {
+			// H of the last 16 scores is shifted by TWO registers every second step instead of by one every step: the step body exists twice
+			// (P = 0: age a is H[a + 2] and the new slice goes to H[1]; P = 1: age a is H[a + 1], the new slice goes to H[0]), then
+			// H[a] = H[a - 2].  16 moves per slot and pair of steps instead of 32.
+#define HA(j_, a_) H[j_][(a_) + 2 - P]
+			auto step = [&](auto Pc) __attribute__((always_inline)) -> bool { // false: the problem is finished (or has to leave the tier)
+				constexpr int P = decltype(Pc)::value;
 				const int par = s & 1;
 				// ---- extension of slice s (miniwfa.c:399-411); the end cell lies on the unique diagonal ql - tl
 				bool term = false;
@@ -146,7 +152,7 @@ __global__ void __launch_bounds__(64 * NW) k_wfa_r(int n_items, const int32_t *_
 				for (int j = 0; j < J; ++j) {
 					const int32_t b0 = W0 + 64 * j;
 					if (b0 > chi || b0 + 63 < clo) continue; // slot entirely outside the slice (uniform)
-					const int32_t d = b0 + lane, k0 = H[j][0], i0 = d + k0;
+					const int32_t d = b0 + lane, k0 = HA(j, 0), i0 = d + k0;
 					const bool val = (uint32_t)(k0 + 1) <= (uint32_t)tl && (uint32_t)(i0 + 1) <= (uint32_t)ql; // -1 <= k0 < tl, -1 <= i0 < ql
 					const int32_t tp = val ? k0 + 1 : 0, qp = val ? i0 + 1 : 0;
 					const int32_t room = min(tl - tp, ql - qp);
@@ -164,7 +170,7 @@ __global__ void __launch_bounds__(64 * NW) k_wfa_r(int n_items, const int32_t *_
 					}
 					n = min(n, room);
 					const int32_t k = k0 + n;
-					H[j][0] = val ? k : k0;
+					HA(j, 0) = val ? k : k0;
 					const uint64_t m = __ballot(val && k == tl - 1 && d + k == ql - 1);
 					if (m) {
 						const int32_t ls = __shfl(n == 0 ? (TBC[j] & 7) : 0, (int)__builtin_ctzll(m));
@@ -172,14 +178,14 @@ __global__ void __launch_bounds__(64 * NW) k_wfa_r(int n_items, const int32_t *_
 						else if (lane == 0) { flags[1] = ls; flags[0] = s + 1; }
 					}
 				}
-				if (NW == 1 && term) break;
+				if (NW == 1 && term) return false;
 				// ---- slice s+1 (miniwfa.c:281-325,412-415).  With NW > 1 it is computed speculatively: the terminating
 				// wave cannot tell the others before the barrier.
 				const int32_t nlo = wlo > -tl ? wlo - 1 : -tl;
 				const int32_t nhi = whi < ql ? whi + 1 : ql;
 				const int32_t width = nhi - nlo + 1;
 				const bool fits = !(nlo < D0 || nhi > D0 + NV - 1 || s + 1 > SMAX || tb_used + width > tbcap);
-				if (NW == 1 && !fits) { status = MGA_WFA_RETRY_TIER; break; }
+				if (NW == 1 && !fits) { status = MGA_WFA_RETRY_TIER; return false; }
 				bool reach_lo = false, reach_hi = false; // uniform
 				if (fits) {
 					const bool track_alive = TRIM && (((s + 1) & 0xff) >= 239 || ((s + 1) & 0xff) == 0); // the trimming at score 256k looks back 17 scores only
@@ -202,11 +208,11 @@ __global__ void __launch_bounds__(64 * NW) k_wfa_r(int n_items, const int32_t *_
 						// predecessors: score s+1-p is age p-1 now (ages are shifted at the end of the step)
 #define WFR_L(R, a, q) wfr_from_left(j > 0 ? __builtin_amdgcn_readlane(R[j > 0 ? j - 1 : 0][a], 63) : eL[q], R[j][a])
 #define WFR_R(R, a, q) wfr_from_right(j < J - 1 ? __builtin_amdgcn_readlane(R[j < J - 1 ? j + 1 : j][a], 0) : eR[q], R[j][a])
-						const int32_t ho1l = WFR_L(H, 5, 0), e1l = WFR_L(E1, 1, 1), ho2l = WFR_L(H, 15, 2), e2l = WFR_L(E2, 0, 3);
-						const int32_t ho1r = WFR_R(H, 5, 0), f1r = WFR_R(F1, 1, 1), ho2r = WFR_R(H, 15, 2), f2r = WFR_R(F2, 0, 3);
+						const int32_t ho1l = WFR_L(H, 5 + 2 - P, 0), e1l = WFR_L(E1, 1, 1), ho2l = WFR_L(H, 15 + 2 - P, 2), e2l = WFR_L(E2, 0, 3);
+						const int32_t ho1r = WFR_R(H, 5 + 2 - P, 0), f1r = WFR_R(F1, 1, 1), ho2r = WFR_R(H, 15 + 2 - P, 2), f2r = WFR_R(F2, 0, 3);
 #undef WFR_L
 #undef WFR_R
-						const int32_t hx1 = H[j][3] + 1;
+						const int32_t hx1 = HA(j, 3) + 1;
 						int32_t vE1 = wfr_max(ho1l, e1l), vE2 = wfr_max(ho2l, e2l);
 						int32_t vF1 = wfr_max(ho1r, f1r) + 1, vF2 = wfr_max(ho2r, f2r) + 1;
 						uint32_t bits = (ho1l < e1l ? 0x08u : 0u) | (ho2l < e2l ? 0x20u : 0u) | (ho1r < f1r ? 0x10u : 0u) | (ho2r < f2r ? 0x40u : 0u);
@@ -237,19 +243,22 @@ __global__ void __launch_bounds__(64 * NW) k_wfa_r(int n_items, const int32_t *_
 						nE2[j] = inb ? vE2 : WF_NEG_INF, nF2[j] = inb ? vF2 : WF_NEG_INF;
 					}
 #pragma unroll
-					for (int j = 0; j < J; ++j) { // age shift
+					for (int j = 0; j < J; ++j) { // age shift (H: every second step, by two)
+						HA(j, -1) = nH[j];
+						if (P == 1) {
 #pragma unroll
-						for (int a = 16; a > 0; --a) H[j][a] = H[j][a - 1];
-						H[j][0] = nH[j];
+							for (int a = 17; a > 1; --a) H[j][a] = H[j][a - 2];
+						}
 						E1[j][2] = E1[j][1]; E1[j][1] = E1[j][0]; E1[j][0] = nE1[j];
 						F1[j][2] = F1[j][1]; F1[j][1] = F1[j][0]; F1[j][0] = nF1[j];
 						E2[j][1] = E2[j][0]; E2[j][0] = nE2[j];
 						F2[j][1] = F2[j][0]; F2[j][0] = nF2[j];
 					}
 					if (NW > 1) { // publish what the neighbours read in the NEXT step (post-shift ages) into the other parity's buffers
-						if (lane == 63) *(int4*)&xch[par ^ 1][wv + 1][0] = make_int4(H[J - 1][5], E1[J - 1][1], H[J - 1][15], E2[J - 1][0]);
+						// (after this step's shift the next step is the other copy: its age a is H[a + 2 - (1 - P)])
+						if (lane == 63) *(int4*)&xch[par ^ 1][wv + 1][0] = make_int4(H[J - 1][5 + 1 + P], E1[J - 1][1], H[J - 1][15 + 1 + P], E2[J - 1][0]);
 						if (lane == 0) {
-							*(int4*)&xch[par ^ 1][wv + 1][4] = make_int4(H[0][5], F1[0][1], H[0][15], F2[0][0]);
+							*(int4*)&xch[par ^ 1][wv + 1][4] = make_int4(H[0][5 + 1 + P], F1[0][1], H[0][15 + 1 + P], F2[0][0]);
 							if (reach_lo) flags[2 + 2 * (par ^ 1)] = s + 1;
 							if (reach_hi) flags[3 + 2 * (par ^ 1)] = s + 1;
 						}
@@ -258,8 +267,8 @@ __global__ void __launch_bounds__(64 * NW) k_wfa_r(int n_items, const int32_t *_
 				if (NW > 1) {
 					WFR_BAR();
 					// "== s + 1": a faster wave may already have stamped the NEXT slice as terminating
-					if (flags[0] == s + 1) { last_state = flags[1]; break; } // slice s reached the end: the speculative slice is dropped
-					if (!fits) { status = MGA_WFA_RETRY_TIER; break; }
+					if (flags[0] == s + 1) { last_state = flags[1]; return false; } // slice s reached the end: the speculative slice is dropped
+					if (!fits) { status = MGA_WFA_RETRY_TIER; return false; }
 					reach_lo = flags[2 + 2 * (par ^ 1)] == s + 1;
 					reach_hi = flags[3 + 2 * (par ^ 1)] == s + 1;
 				}
@@ -290,7 +299,13 @@ __global__ void __launch_bounds__(64 * NW) k_wfa_r(int n_items, const int32_t *_
 					if (mn != 0x7fffffff) wlo = mn, whi = mx;
 					else { const int32_t e0 = whi + 1; wlo = e0; whi = e0 - 1; }
 				}
+				return true;
+			};
+			for (;;) {
+				if (!step(std::integral_constant<int, 0>())) break;
+				if (!step(std::integral_constant<int, 1>())) break;
 			}
+#undef HA
 		}
 		if (NW > 1) __syncthreads(); // HBM traceback rows complete and visible to wave 0
 		else { WFR_LDS_FENCE(); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
