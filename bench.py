@@ -198,7 +198,7 @@ def main():
             import glob
             pf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))[-1]
             pk = json.load(open(pf))["kernels"]
-            sel = [v for k, v in pk.items() if k.startswith(dom)]
+            sel = [v for k, v in pk.items() if (k == "k_wfa" or k.startswith("k_wfa_r<") if dom == "k_wfa" else k.startswith(dom))]  # the tier kernels, not the scheduler's helpers
             nl = sum(v.get("launches_fetch", 0) for v in sel)
             if nl:
                 traffic = sum(v.get("fetch_kb", 0) + v.get("write_kb", 0) for v in sel) * 1024.0 / nl
