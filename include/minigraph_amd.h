@@ -263,6 +263,21 @@ int mg_map_files_fp(gfa_t *g, int n_fn, const char **fn, const mg_idxopt_t *ipt,
 /* same, to a file path (convenience for bindings that cannot pass a FILE*) */
 int mga_map_files_to_path(gfa_t *g, int n_fn, const char **fn, const mg_idxopt_t *ipt, const mg_mapopt_t *opt0, int n_threads, const char *out_path);
 
+/* the mapping phase of mg_map_files() alone, against an existing index: GAF (input order) to fp, or (fp == NULL) into one malloc'ed
+ * buffer *mem / *mem_len (release with mga_free()).  *t_map (optional): wall seconds from the first byte read to the last byte handed
+ * to the sink -- the interval between the reference's mg_opt_update and its last worker_pipeline log line (gmap.c:186-211). */
+int mga_map_files_idx(const mg_idx_t *gi, int n_fn, const char **fn, const mg_mapopt_t *opt, int n_threads, FILE *fp, char **mem, int64_t *mem_len, double *t_map);
+/* one shard of the same job (one process per GPU, gmap.c:98-100 fanned out over devices): rank shard_rank of shard_world maps a
+ * contiguous part of every output SEGMENT -- a plain FASTA file is one segment, cut by byte range at record starts; any other input is
+ * parsed by every rank and each mini-batch is a segment, cut by read index.  seg_len[0..n_seg) (malloc'ed) are this rank's bytes of each
+ * segment: concatenating, segment by segment, the ranks' parts in rank order gives the single-process output. */
+int mga_map_files_shard(const mg_idx_t *gi, int n_fn, const char **fn, const mg_mapopt_t *opt, int n_threads, int shard_rank, int shard_world,
+						FILE *fp, char **mem, int64_t *mem_len, int64_t **seg_len, int *n_seg, double *t_map);
+int mga_reads_parse_x(const char *fn, int64_t batch_bases, int n_threads, int64_t *n_reads, int64_t *n_bases, uint64_t *hash);
+/* the reads of shard rank/world, exactly as mga_map_files_shard() cuts them, as one-line FASTA in out_path; seg_n[0..n_seg) (malloc'ed) =
+ * records per output segment.  No device needed. */
+int mga_reads_shard_dump(const char *fn, int64_t batch_bases, int n_threads, int rank, int world, const char *out_path, int64_t **seg_n, int *n_seg);
+
 /* a read set kept resident in HBM across calls (repeated passes over one batch, as the benchmark does) */
 typedef struct mga_reads_s mga_reads_t;
 mga_reads_t *mga_reads_load(const char *fn, int64_t max_reads);   /* FASTA/FASTQ(.gz) -> host copy + HBM copy; NULL on error */

@@ -96,6 +96,9 @@ def load():
     L.mga_lchain_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.POINTER(lchain_par_t), pp, pp, pp, pp]
     L.mga_map_files_to_path.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(idxopt_t),
                                         C.POINTER(mapopt_t), C.c_int, C.c_char_p]
+    L.mga_map_files_shard.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(mapopt_t), C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                      pp, C.POINTER(C.c_int64), pp, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    L.mga_reads_shard_dump.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_char_p, pp, C.POINTER(C.c_int)]
     L.mga_reads_load.argtypes = [C.c_char_p, C.c_int64]
     L.mga_reads_load.restype = C.c_void_p
     L.mga_reads_free.argtypes = [C.c_void_p]
@@ -253,6 +256,55 @@ def map_files(graph_path, read_paths, out_path, preset="lr", cigar=True, n_threa
     L.gfa_destroy(g)
     if rc != 0:
         raise RuntimeError("mapping failed: %s" % L.mga_last_error().decode())
+
+
+class MappedGaf:
+    """GAF text of one mga_map_files_shard() call: a malloc'ed buffer owned by this object (zero-copy numpy view, bytes on request)"""
+
+    def __init__(self, ptr, n, seg_len, t_map):
+        self.ptr, self.n, self.seg_len, self.t_map = ptr, n, seg_len, t_map
+
+    def __len__(self):
+        return self.n
+
+    def view(self):
+        return np.ctypeslib.as_array(C.cast(self.ptr, C.POINTER(C.c_uint8)), shape=(self.n,)) if self.n else np.zeros(0, dtype=np.uint8)
+
+    def bytes(self):
+        return C.string_at(self.ptr, self.n) if self.n else b""
+
+    def free(self):
+        if self.ptr is not None and self.ptr.value:
+            load().mga_free(self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def map_files_idx(graph, read_paths, n_threads=8, rank=0, world=1):
+    """the mapping phase of mg_map_files() against an existing index: FASTA/FASTQ files -> GAF text in memory (MappedGaf).
+    world > 1: this process maps shard `rank` (see mga_map_files_shard in include/minigraph_amd.h); .seg_len lists its bytes per
+    output segment, .t_map is the wall time of the phase (reader + pipeline + sink) measured inside the library."""
+    L = load()
+    fns = (C.c_char_p * len(read_paths))(*[p.encode() for p in read_paths])
+    mem, n, seg, nseg, t = C.c_void_p(), C.c_int64(0), C.c_void_p(), C.c_int(0), C.c_double(0.0)
+    _check(L.mga_map_files_shard(graph.gi, len(read_paths), fns, C.byref(graph.mo), n_threads, rank, world, None,
+                                 C.byref(mem), C.byref(n), C.byref(seg), C.byref(nseg), C.byref(t)), "mga_map_files_shard")
+    seg_len = _take(seg, nseg.value, np.int64)
+    return MappedGaf(mem, n.value, seg_len, t.value)
+
+
+def reads_shard_dump(path, out_path, rank, world, batch_bases=500000000, n_threads=4):
+    """the reads of shard rank/world as the sharded reader cuts them -> one-line FASTA in out_path; returns records per segment"""
+    L = load()
+    seg, nseg = C.c_void_p(), C.c_int(0)
+    _check(L.mga_reads_shard_dump(path.encode(), batch_bases, n_threads, rank, world, out_path.encode(), C.byref(seg), C.byref(nseg)),
+           "mga_reads_shard_dump")
+    return _take(seg, nseg.value, np.int64)
 
 
 class kstring_t(C.Structure):

@@ -199,6 +199,17 @@ extern "C" int mga_ssync(mga_sctx_t *sc)
 	return 0;
 }
 
+// error path of a pipeline stage: wait for whatever is still queued on the stream and DROP the staged read-backs -- their
+// destinations (stack variables, per-chunk arrays) are about to go away, and the next mga_ssync() on this context must not
+// deliver into them
+extern "C" void mga_sctx_abort(mga_sctx_t *sc)
+{
+	if (sc == 0) return;
+	(void)hipStreamSynchronize((hipStream_t)sc->stream);
+	stage_t *S = (stage_t*)sc->stage;
+	if (S) S->n = 0, S->used = 0;
+}
+
 extern "C" int mga_hbuf_reserve(mga_hbuf_t *b, size_t bytes)
 {
 	if (bytes <= b->cap && b->p) return 0;

@@ -78,9 +78,6 @@ static void strbuf_put(char *p, size_t m)
 	free(p);
 }
 
-struct mg_tbuf_s { int dummy; };
-mg_tbuf_t *mg_tbuf_init(void) { return (mg_tbuf_t*)calloc(1, sizeof(mg_tbuf_t)); } /* map-algo.c:14-20: scratch is per batch here */
-void mg_tbuf_destroy(mg_tbuf_t *b) { free(b); }
 
 /* ------------------------------------------------------------------------------------------------ */
 
@@ -584,16 +581,24 @@ static void gaf_worker(void *data, int64_t t, int tid)
  * ---------------------------------------------------------------------------------------------- */
 #include <pthread.h>
 
-typedef struct {
+typedef struct { /* one pipeline context: HIP stream + grow-only device and pinned buffers, reused from chunk to chunk */
 	mga_sctx_t *sc;
-	mga_dbuf_t seq, qoff, cnt, mzoff, mz, occ, val, na, nmini, rep, aoff, minioff, a, tmp, mini, u, b, nu, nb, ws;
-	mga_dbuf_t tseq, prob, res, pool, used, ncig, cigoff, ord, rflag, item, chain, vert, txtres, txtpool;
-	mga_dbuf_t sk_item, sk_cnt, sk_off, sd_tk, sd_kf, sd_offa, sd_offm, sd_rkey, sd_rmax; /* long-query path (MG_M_RMQ): sketch pieces, per-minimizer scans */
-	mga_hbuf_t h_b, h_u, h_mini, h_tseq, h_prob, h_pool, h_seq, h_ncig, h_cigoff, h_item, h_chain, h_vert, h_txtres, h_txtpool; /* pinned staging */
+	union {
+		struct {
+			mga_dbuf_t seq, qoff, cnt, mzoff, mz, occ, val, na, nmini, rep, aoff, minioff, a, tmp, mini, u, b, nu, nb, ws;
+			mga_dbuf_t tseq, prob, res, pool, used, ncig, cigoff, ord, rflag, item, chain, vert, txtres, txtpool;
+			mga_dbuf_t sk_item, sk_cnt, sk_off, sd_tk, sd_kf, sd_offa, sd_offm, sd_rkey, sd_rmax; /* long-query path (MG_M_RMQ): sketch pieces, per-minimizer scans */
+		};
+		mga_dbuf_t dall[43];
+	};
+	union {
+		struct { mga_hbuf_t h_b, h_u, h_mini, h_tseq, h_prob, h_pool, h_seq, h_ncig, h_cigoff, h_item, h_chain, h_vert, h_txtres, h_txtpool; }; /* pinned staging */
+		mga_hbuf_t hall[14];
+	};
 } pipe_ctx_t;
+_Static_assert(sizeof(((pipe_ctx_t*)0)->dall) == 43 * sizeof(mga_dbuf_t) && sizeof(((pipe_ctx_t*)0)->hall) == 14 * sizeof(mga_hbuf_t), "pipe_ctx_t: buffer lists out of sync");
 
 #define MGA_MAX_PIPE 4
-static pipe_ctx_t g_pipe[MGA_MAX_PIPE]; /* grow-only, reused across batches (one GPU per process) */
 
 static double g_job_t0;
 static int g_dbg_pipe = -1;
@@ -614,7 +619,7 @@ static int env_int(const char *name, int dflt) { const char *s = getenv(name); r
 static void release_token_cb(void *a) { gpu_token_t **held = (gpu_token_t**)a; if (*held) { token_release(*held); *held = 0; } }
 
 static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs_out,
-					 const mg_mapopt_t *opt, int n_threads, const char *d_seq_res, const int64_t *q_off_res, mga_stats_t *st, kstring_t *gaf_part)
+					 const mg_mapopt_t *opt, int n_threads, const char *d_seq_res, const int64_t *q_off_res, int seqs_pinned, mga_stats_t *st, kstring_t *gaf_part)
 {
 	struct mg_idx_bucket_s *B = gi->B;
 	mga_sctx_t *sc = P->sc;
@@ -637,25 +642,31 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	}
 	/* ---- reads -> HBM, back to back, 64 readable bytes of padding at the end (8-byte compares in k_wfa);
 	 *      skipped when the caller keeps the batch resident (d_seq_res + absolute offsets q_off_res) ---- */
-	GPU_ACQUIRE(&g_gpu_front);
 	t0 = mga_wtime();
-	CK(mga_dbuf_reserve(&P->qoff, (size_t)(n + 1) * 8));
 	if (d_seq_res) {
 		memcpy(q_off, q_off_res, (size_t)(n + 1) * 8);
 		tot = q_off[n] - q_off[0];
+		GPU_ACQUIRE(&g_gpu_front);
 		d_seq = d_seq_res;
 	} else {
-		char *h_seq;
+		const char *h_seq;
 		for (i = 0; i < n; ++i) { q_off[i] = tot; tot += qlens[i]; }
 		q_off[n] = tot;
-		CK(mga_hbuf_reserve(&P->h_seq, (size_t)tot + 64));
-		h_seq = (char*)P->h_seq.p;
-		for (i = 0; i < n; ++i) memcpy(h_seq + q_off[i], seqs[i], (size_t)qlens[i]);
-		memset(h_seq + tot, 0, 64);
+		if (seqs_pinned) h_seq = seqs[0]; /* the reader parsed the batch into pinned memory, reads back to back: no staging copy */
+		else { /* staged before the GPU phase token is taken: the copy is host work */
+			char *h;
+			CK(mga_hbuf_reserve(&P->h_seq, (size_t)tot + 64));
+			h = (char*)P->h_seq.p;
+			for (i = 0; i < n; ++i) memcpy(h + q_off[i], seqs[i], (size_t)qlens[i]);
+			memset(h + tot, 0, 64);
+			h_seq = h;
+		}
+		GPU_ACQUIRE(&g_gpu_front);
 		CK(mga_dbuf_reserve(&P->seq, (size_t)tot + 64));
 		CK(mga_h2d_s(sc, P->seq.p, h_seq, (size_t)tot + 64));
 		d_seq = (const char*)P->seq.p;
 	}
+	CK(mga_dbuf_reserve(&P->qoff, (size_t)(n + 1) * 8));
 	CK(mga_h2d_s(sc, P->qoff.p, q_off, (size_t)(n + 1) * 8));
 	/* ---- sketch: ONE pass into per-read slots of qlen/2 + 64 minimizers (the density is 2/(w+1), ~3x less); a read that would
 	 *      overflow its slots (never seen) sends the chunk through count + scan + write ---- */
@@ -866,177 +877,346 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	for (i = 0; i < n && h_rflag; ++i) st->n_rescue_dev += h_rflag[i] == 1, st->n_rescue_host += h_rflag[i] == 2;
 	mga_batch_stats(b, st);
 done:
+	if (rc < 0) mga_sctx_abort(sc); /* nothing of this chunk may still be in flight, and no staged read-back may outlive this frame */
 	GPU_RELEASE();
 	if (b) mga_batch_destroy(b);
 	free(q_off); free(h_mzoff); free(h_aoff); free(h_minioff); free(h_nmz); free(h_rep); free(h_nu); free(h_nb); free(h_rflag);
 	return rc;
 }
 
-typedef struct {
-	const mg_idx_t *gi;
-	const mg_mapopt_t *opt;
-	int n, chunk, n_threads;
+/* ------------------------------------------------------------------------------------------------
+ * stream: the chunk pipeline as a persistent object
+ *
+ * A stream owns MGA_PIPE pipeline threads (each with its own HIP stream context and device / pinned buffers) that live as long
+ * as the stream.  Batches are SUBMITTED (cut into chunks, queued) and COLLECTED in submission order; chunks of consecutive
+ * batches follow each other through the workers without a drain in between -- the reference overlaps its mini-batches the same
+ * way (kt_pipeline, gmap.c:163-184).  mg_map_files() keeps one stream for the whole job, the single-batch entry points
+ * (mg_map_batch, mga_map_reads) use the index's own stream, one call at a time.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sbatch_s {
+	struct sbatch_s *next;
+	int n, flags;
 	const int *qlens;
 	const char **seqs, **qnames;
-	mg_gchains_t **gcs;
-	const char *d_seq;
-	const int64_t *q_off;
-	volatile int next, err;
-	pthread_mutex_t mtx;
-	char errmsg[512];
-	kstring_t *gaf_part; /* when non-NULL: n_chunks * n_threads GAF pieces, in read order; chains are freed after formatting */
-	/* ordered commit of finished chunks into the index-owned output buffer, overlapped with the pipeline */
+	mg_gchains_t **gcs;            /* chain mode: results; text mode: scratch array of NULLs */
+	int own_gcs;
+	const char *d_seq; const int64_t *q_off;
+	int seqs_pinned;               /* seqs[] lie back to back in pinned host memory (+64 readable bytes): chunks upload straight from there */
+	int want_gaf, n_threads;
+	int n_chunks, *cstart, next_chunk, n_done;
+	kstring_t *gaf_part; char *done; int next_commit;
 	pthread_mutex_t cmtx;
-	char *done;
-	int n_chunks, next_commit;
-	int *cstart; /* n_chunks + 1 chunk boundaries: small chunks first and last shorten the pipeline's fill and drain */
-	int64_t out_len;
-} pipe_job_t;
+	char *out; int64_t out_len, out_cap;
+	int err, complete;
+	char errmsg[512];
+	void *user;
+} sbatch_t;
 
-typedef struct { pipe_job_t *job; pipe_ctx_t *P; mga_stats_t st; } pipe_thr_t;
+struct mga_stream_s {
+	const mg_idx_t *gi;
+	mg_mapopt_t opt;
+	int n_threads, n_pipe, chunk, max_inflight;
+	pthread_mutex_t m;
+	pthread_cond_t c_work, c_done, c_space;
+	sbatch_t *head, *tail, *cur;   /* submitted and not yet collected (FIFO); cur = first batch that still has chunks to hand out */
+	int n_inflight, closing, started, n_submitted;
+	pipe_ctx_t P[MGA_MAX_PIPE];
+	pthread_t thr[MGA_MAX_PIPE];
+	pthread_mutex_t api;           /* single-batch entry points on the index's stream: one call at a time */
+};
 
 typedef struct { kstring_t *part; int64_t *off; char *dst; } gcopy_t;
 static void gaf_copy_worker(void *data, int64_t i, int tid) { gcopy_t *g = (gcopy_t*)data; (void)tid; if (g->part[i].l) memcpy(g->dst + g->off[i], g->part[i].s, g->part[i].l); strbuf_put(g->part[i].s, g->part[i].m); g->part[i].s = 0, g->part[i].m = g->part[i].l = 0; }
 
-/* chunk c is formatted: append every chunk that is now complete AND next in read order to the index-owned output buffer */
-static void commit_chunks(pipe_job_t *J, int c)
+/* chunk c of batch b is formatted: append every chunk that is now complete AND next in read order to the batch's output buffer */
+static void commit_chunks(sbatch_t *b, int c)
 {
-	struct mg_idx_bucket_s *B = J->gi->B;
-	pthread_mutex_lock(&J->cmtx);
-	J->done[c] = 1;
-	while (J->next_commit < J->n_chunks && J->done[J->next_commit]) {
-		const int T = J->n_threads;
+	pthread_mutex_lock(&b->cmtx);
+	b->done[c] = 1;
+	while (b->next_commit < b->n_chunks && b->done[b->next_commit]) {
+		const int T = b->n_threads;
 		gcopy_t g;
 		int64_t off[T + 1], tot = 0;
 		int k;
-		g.part = J->gaf_part + (size_t)J->next_commit * T, g.off = off;
+		g.part = b->gaf_part + (size_t)b->next_commit * T, g.off = off;
 		for (k = 0; k < T; ++k) off[k] = tot, tot += g.part[k].l;
-		if (J->out_len + tot + 1 > B->gaf_cap) {
-			B->gaf_cap = (J->out_len + tot + 1) * 3 / 2 + (1 << 20);
-			B->gaf_out = (char*)realloc(B->gaf_out, (size_t)B->gaf_cap);
+		if (b->out_len + tot + 1 > b->out_cap) {
+			b->out_cap = (b->out_len + tot + 1) * 3 / 2 + (1 << 20);
+			b->out = (char*)realloc(b->out, (size_t)b->out_cap);
 		}
-		g.dst = B->gaf_out + J->out_len;
+		g.dst = b->out + b->out_len;
 		mga_parallel_for(T < 16 ? T : 16, T, gaf_copy_worker, &g);
-		J->out_len += tot;
-		++J->next_commit;
+		b->out_len += tot;
+		++b->next_commit;
 	}
-	pthread_mutex_unlock(&J->cmtx);
+	pthread_mutex_unlock(&b->cmtx);
 }
 
-static void *pipe_worker(void *a)
+static pthread_mutex_t g_stats_mtx = PTHREAD_MUTEX_INITIALIZER; /* the index's counters are shared by every stream and mg_tbuf_t */
+static void stats_merge(mga_stats_t *d, const mga_stats_t *s)
 {
-	pipe_thr_t *t = (pipe_thr_t*)a;
-	pipe_job_t *J = t->job;
-	if (mga_dev_bind_thread() < 0) { J->err = 1; return 0; }
-	for (;;) {
-		int c = __sync_fetch_and_add(&J->next, 1), st, en;
-		if (c >= J->n_chunks || J->err) break;
-		st = J->cstart[c], en = J->cstart[c + 1];
-		double tc = mga_wtime();
-		if (map_chunk(t->P, J->gi, en - st, J->qlens + st, J->seqs + st, J->qnames ? J->qnames + st : 0, J->gcs + st, J->opt, J->n_threads,
-					  J->d_seq, J->q_off ? J->q_off + st : 0, &t->st, J->gaf_part ? J->gaf_part + (size_t)c * J->n_threads : 0) < 0) {
-			pthread_mutex_lock(&J->mtx);
-			if (!J->err) { J->err = 1; snprintf(J->errmsg, sizeof J->errmsg, "%s", mga_last_error()); }
-			pthread_mutex_unlock(&J->mtx);
-			break;
-		}
-		PIPE_LOG("map_chunk", c, tc);
-		if (J->gaf_part) { /* the chunk's GAF text was formatted inside map_chunk(); append it to the output in read order */
-			double t0 = mga_wtime();
-			commit_chunks(J, c);
-			t->st.t_gaf += mga_wtime() - t0;
-		}
+	d->n_reads += s->n_reads, d->n_bases += s->n_bases, d->n_mz += s->n_mz, d->n_probe += s->n_probe, d->n_hit += s->n_hit;
+	d->n_anchor_chained += s->n_anchor_chained, d->n_wfa += s->n_wfa, d->wfa_t_bases += s->wfa_t_bases, d->wfa_q_bases += s->wfa_q_bases;
+	d->wfa_cells += s->wfa_cells;
+	d->t_sketch += s->t_sketch, d->t_seed += s->t_seed, d->t_lchain += s->t_lchain, d->t_host_chain += s->t_host_chain, d->t_wfa += s->t_wfa, d->t_host_post += s->t_host_post;
+	d->t_gaf += s->t_gaf;
+	d->n_rescue_dev += s->n_rescue_dev, d->n_rescue_host += s->n_rescue_host;
+	d->gaf_bytes += s->gaf_bytes;
+}
+
+static void pipe_ctx_free(pipe_ctx_t *P)
+{
+	size_t i;
+	if (P->sc) mga_sctx_abort(P->sc);
+	for (i = 0; i < sizeof P->dall / sizeof P->dall[0]; ++i) mga_dbuf_free(&P->dall[i]);
+	for (i = 0; i < sizeof P->hall / sizeof P->hall[0]; ++i) mga_hbuf_free(&P->hall[i]);
+	mga_sctx_destroy(P->sc);
+	memset(P, 0, sizeof *P);
+}
+
+/* one chunk of one batch on pipeline context P; the caller holds no lock */
+static void stream_run_chunk(mga_stream_t *S, pipe_ctx_t *P, sbatch_t *b, int c)
+{
+	const int st = b->cstart[c], en = b->cstart[c + 1];
+	mga_stats_t cst;
+	double tc = mga_wtime();
+	int rc;
+	memset(&cst, 0, sizeof cst);
+	rc = b->err ? 0 : map_chunk(P, S->gi, en - st, b->qlens + st, b->seqs + st, b->qnames ? b->qnames + st : 0, b->gcs + st, &S->opt, b->n_threads,
+								b->d_seq, b->q_off ? b->q_off + st : 0, b->seqs_pinned, &cst, b->gaf_part ? b->gaf_part + (size_t)c * b->n_threads : 0);
+	PIPE_LOG("map_chunk", c, tc);
+	if (rc == 0 && b->gaf_part && !b->err) { /* the chunk's GAF text was formatted inside map_chunk(); append it to the output in read order */
+		double t0 = mga_wtime();
+		int k;
+		for (k = 0; k < b->n_threads; ++k) cst.gaf_bytes += b->gaf_part[(size_t)c * b->n_threads + k].l;
+		commit_chunks(b, c);
+		cst.t_gaf += mga_wtime() - t0;
 	}
+	pthread_mutex_lock(&g_stats_mtx); stats_merge(&S->gi->B->st, &cst); pthread_mutex_unlock(&g_stats_mtx);
+	pthread_mutex_lock(&S->m);
+	if (rc < 0 && !b->err) { b->err = 1; snprintf(b->errmsg, sizeof b->errmsg, "%s", mga_last_error()); }
+	if (++b->n_done == b->n_chunks) { b->complete = 1; pthread_cond_broadcast(&S->c_done); }
+	pthread_mutex_unlock(&S->m);
+}
+
+typedef struct { mga_stream_t *S; int k; } stream_thr_t;
+
+static void *stream_worker(void *a)
+{
+	stream_thr_t *t = (stream_thr_t*)a;
+	mga_stream_t *S = t->S;
+	pipe_ctx_t *P = &S->P[t->k];
+	free(t);
+	if (mga_dev_bind_thread() < 0) return 0;
+	pthread_mutex_lock(&S->m);
+	for (;;) {
+		sbatch_t *b;
+		int c;
+		while (!S->closing && (S->cur == 0 || S->cur->next_chunk >= S->cur->n_chunks)) {
+			if (S->cur && S->cur->next) { S->cur = S->cur->next; continue; }
+			pthread_cond_wait(&S->c_work, &S->m);
+		}
+		if (S->cur == 0 || S->cur->next_chunk >= S->cur->n_chunks) break; /* closing and nothing left */
+		b = S->cur, c = b->next_chunk++;
+		pthread_mutex_unlock(&S->m);
+		stream_run_chunk(S, P, b, c);
+		pthread_mutex_lock(&S->m);
+	}
+	pthread_mutex_unlock(&S->m);
 	return 0;
 }
 
-
-static int map_all(const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs,
-				   const mg_mapopt_t *opt, int n_threads, const char *d_seq, const int64_t *q_off, char **gaf, int64_t *gaf_len)
+mga_stream_t *mga_stream_open(const mg_idx_t *gi, const mg_mapopt_t *opt, int n_threads)
 {
-	pipe_job_t J;
-	pipe_thr_t thr[MGA_MAX_PIPE];
-	pthread_t tid[MGA_MAX_PIPE];
-	int i, n_pipe = env_int("MGA_PIPE", 4), n_chunks;
-	if (n <= 0) return 0;
-	if (mga_dev_init() < 0) return -1;
+	mga_stream_t *S;
+	int i;
+	if (mga_dev_init() < 0) return 0;
 	if (g_dbg_pipe < 0) { g_dbg_pipe = env_int("MGA_DEBUG_PIPE", 0); g_gpu_wfa.avail = env_int("MGA_WFA_SLOTS", 2); /* two chunks may be in their WFA phase: the second one fills the tails of the first */ }
 	g_cpu_on = g_dbg_pipe > 0;
-	if (g_cpu_on) memset((void*)g_cpu_ns, 0, sizeof g_cpu_ns);
-	g_job_t0 = mga_wtime();
-	for (i = 0; i < n; ++i) gcs[i] = 0;
-	memset(&J, 0, sizeof J);
-	J.gi = gi, J.opt = opt, J.n = n, J.qlens = qlens, J.seqs = seqs, J.qnames = qnames, J.gcs = gcs, J.d_seq = d_seq, J.q_off = q_off;
-	J.chunk = env_int("MGA_CHUNK", 16384); /* [measured] larger launches amortise the tails of the WFA tiers: 4096 -> 8192 reads +5 %, -> 16384 another +5 % */
-	if (J.chunk < 1) J.chunk = 1;
-	{ /* chunk boundaries: ramp up from chunk/4 at the start and down at the end (fill/drain of the pipeline cost one chunk
-	   * time each, ~8 % of a 100k-read batch); everything in between is MGA_CHUNK reads */
-		const int ramp = env_int("MGA_RAMP", 1) && n > 6 * J.chunk;
-		int pos = 0, m = 0, cap = n / (J.chunk / 4 > 0 ? J.chunk / 4 : 1) + 8;
-		J.cstart = MGA_MALLOC(int, cap + 1);
-		while (pos < n) {
-			int sz = J.chunk, left = n - pos;
-			if (ramp) {
-				if (m == 0) sz = J.chunk / 4; else if (m == 1) sz = J.chunk / 2;
-				if (left <= J.chunk + J.chunk / 2) sz = left > J.chunk / 2 + J.chunk / 8 ? left - J.chunk / 2 : left; /* tail: the last chunk is chunk/2 (or what is left) */
-			}
-			if (sz < 1) sz = 1;
-			if (sz > left) sz = left;
-			J.cstart[m++] = pos; pos += sz;
+	S = MGA_CALLOC(mga_stream_t, 1);
+	S->gi = gi, S->opt = *opt, S->n_threads = n_threads > 0 ? n_threads : 1;
+	S->n_pipe = env_int("MGA_PIPE", 4);
+	if (S->n_pipe > MGA_MAX_PIPE) S->n_pipe = MGA_MAX_PIPE;
+	if (S->n_pipe < 1) S->n_pipe = 1;
+	S->chunk = env_int("MGA_CHUNK", 16384); /* [measured] larger launches amortise the tails of the WFA tiers: 4096 -> 8192 reads +5 %, -> 16384 another +5 % */
+	if (S->chunk < 1) S->chunk = 1;
+	S->max_inflight = env_int("MGA_INFLIGHT", 3);
+	pthread_mutex_init(&S->m, 0); pthread_mutex_init(&S->api, 0);
+	pthread_cond_init(&S->c_work, 0); pthread_cond_init(&S->c_done, 0); pthread_cond_init(&S->c_space, 0);
+	for (i = 0; i < S->n_pipe; ++i)
+		if ((S->P[i].sc = mga_sctx_create()) == 0) { while (--i >= 0) pipe_ctx_free(&S->P[i]); free(S); return 0; }
+	return S;
+}
+
+static void stream_start(mga_stream_t *S) /* worker threads are created with the first multi-chunk batch: one-read calls never need them */
+{
+	int i;
+	if (S->started) return;
+	for (i = 0; i < S->n_pipe; ++i) {
+		stream_thr_t *t = MGA_CALLOC(stream_thr_t, 1);
+		t->S = S, t->k = i;
+		pthread_create(&S->thr[i], 0, stream_worker, t);
+	}
+	S->started = 1;
+}
+
+void mga_stream_set_opt(mga_stream_t *S, const mg_mapopt_t *opt, int n_threads) { S->opt = *opt; if (n_threads > 0) S->n_threads = n_threads; } /* only while nothing is in flight */
+
+/* chunk boundaries of a batch: MGA_CHUNK reads each; the FIRST batch of a job ramps up from chunk/4 and the LAST one ramps down
+ * (fill and drain of the pipeline cost about one chunk time each) */
+static void batch_cut(mga_stream_t *S, sbatch_t *b)
+{
+	const int n = b->n, chunk = S->chunk, ramp = env_int("MGA_RAMP", 1) && n > 6 * chunk;
+	int pos = 0, m = 0, cap = n / (chunk / 4 > 0 ? chunk / 4 : 1) + 8;
+	b->cstart = MGA_MALLOC(int, cap + 1);
+	while (pos < n) {
+		int sz = chunk, left = n - pos;
+		if (ramp) {
+			if (b->flags & MGA_SB_FIRST) { if (m == 0) sz = chunk / 4; else if (m == 1) sz = chunk / 2; }
+			if ((b->flags & MGA_SB_LAST) && left <= chunk + chunk / 2) sz = left > chunk / 2 + chunk / 8 ? left - chunk / 2 : left; /* tail: the last chunk is chunk/2 (or what is left) */
 		}
-		J.cstart[m] = n;
-		n_chunks = m;
+		if (sz < 1) sz = 1;
+		if (sz > left) sz = left;
+		b->cstart[m++] = pos; pos += sz;
 	}
-	if (n_pipe > MGA_MAX_PIPE) n_pipe = MGA_MAX_PIPE;
-	if (n_pipe > n_chunks) n_pipe = n_chunks;
-	if (n_pipe < 1) n_pipe = 1;
-	J.n_threads = env_int("MGA_SPLIT_THREADS", 0) ? (n_threads / n_pipe > 0 ? n_threads / n_pipe : 1) : n_threads; /* host stages of different chunks rarely coincide */
-	J.n_chunks = n_chunks;
-	if (gaf) { J.gaf_part = MGA_CALLOC(kstring_t, (size_t)n_chunks * J.n_threads); J.done = MGA_CALLOC(char, n_chunks); }
-	pthread_mutex_init(&J.mtx, 0); pthread_mutex_init(&J.cmtx, 0);
-	for (i = 0; i < n_pipe; ++i) {
-		if (g_pipe[i].sc == 0 && (g_pipe[i].sc = mga_sctx_create()) == 0) return -1;
-		thr[i].job = &J, thr[i].P = &g_pipe[i];
-		memset(&thr[i].st, 0, sizeof(mga_stats_t));
+	b->cstart[m] = n;
+	b->n_chunks = m;
+}
+
+/* Queue a batch.  Everything passed in is BORROWED until the batch has been collected.  gcs != NULL: chain mode (results in gcs[]);
+ * want_gaf: text mode (GAF bytes of the batch, input order).  out/out_cap: an output buffer to reuse (may be NULL).  Blocks while
+ * MGA_INFLIGHT batches are already in flight. */
+int mga_stream_submit(mga_stream_t *S, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs, int want_gaf,
+					  const char *d_seq, const int64_t *q_off, int seqs_pinned, int flags, char *out, int64_t out_cap, void *user)
+{
+	sbatch_t *b = MGA_CALLOC(sbatch_t, 1);
+	int i;
+	b->n = n, b->flags = flags, b->qlens = qlens, b->seqs = seqs, b->qnames = qnames, b->d_seq = d_seq, b->q_off = q_off, b->seqs_pinned = seqs_pinned;
+	b->want_gaf = want_gaf, b->user = user, b->out = out, b->out_cap = out ? out_cap : 0;
+	b->n_threads = S->n_threads;
+	if (gcs) b->gcs = gcs; else b->gcs = MGA_CALLOC(mg_gchains_t*, n > 0 ? n : 1), b->own_gcs = 1;
+	for (i = 0; i < n; ++i) b->gcs[i] = 0;
+	batch_cut(S, b);
+	if (want_gaf) { b->gaf_part = MGA_CALLOC(kstring_t, (size_t)(b->n_chunks > 0 ? b->n_chunks : 1) * b->n_threads); b->done = MGA_CALLOC(char, b->n_chunks > 0 ? b->n_chunks : 1); }
+	pthread_mutex_init(&b->cmtx, 0);
+	if (b->n_chunks == 0) b->complete = 1;
+	pthread_mutex_lock(&S->m);
+	while (S->n_inflight >= S->max_inflight) pthread_cond_wait(&S->c_space, &S->m);
+	if (S->n_submitted++ == 0) { g_job_t0 = mga_wtime(); if (g_cpu_on) memset((void*)g_cpu_ns, 0, sizeof g_cpu_ns); }
+	if (S->tail) S->tail->next = b; else S->head = b;
+	S->tail = b;
+	if (S->cur == 0) S->cur = b;
+	++S->n_inflight;
+	if (b->n_chunks > 1 || S->started) { stream_start(S); pthread_cond_broadcast(&S->c_work); }
+	pthread_mutex_unlock(&S->m);
+	return 0;
+}
+
+/* Collect the oldest batch: blocks until all of its chunks are done.  Returns 1 (a batch: out, out_len and out_cap receive its GAF buffer,
+ * now owned by the caller), 0 (nothing in flight) or -1 (the batch failed: message in mga_last_error()). */
+int mga_stream_collect(mga_stream_t *S, char **out, int64_t *out_len, int64_t *out_cap, void **user)
+{
+	sbatch_t *b;
+	int rc = 1, i;
+	pthread_mutex_lock(&S->m);
+	b = S->head;
+	if (b == 0) { pthread_mutex_unlock(&S->m); return 0; }
+	if (!S->started) { /* single-chunk batches on a stream without workers run right here, on context 0 (one-read calls: no thread hand-off) */
+		while (b->next_chunk < b->n_chunks) {
+			int c = b->next_chunk++;
+			pthread_mutex_unlock(&S->m);
+			stream_run_chunk(S, &S->P[0], b, c);
+			pthread_mutex_lock(&S->m);
+		}
 	}
-	if (n_pipe == 1) pipe_worker(&thr[0]);
-	else {
-		for (i = 0; i < n_pipe; ++i) pthread_create(&tid[i], 0, pipe_worker, &thr[i]);
-		for (i = 0; i < n_pipe; ++i) pthread_join(tid[i], 0);
+	while (!b->complete) pthread_cond_wait(&S->c_done, &S->m);
+	S->head = b->next;
+	if (S->head == 0) S->tail = 0;
+	if (S->cur == b) S->cur = b->next;
+	--S->n_inflight;
+	pthread_cond_broadcast(&S->c_space);
+	pthread_mutex_unlock(&S->m);
+	if (b->err) {
+		for (i = 0; i < b->n; ++i) { mg_gchain_free(b->gcs[i]); b->gcs[i] = 0; }
+		if (b->gaf_part) for (i = 0; i < b->n_chunks * b->n_threads; ++i) strbuf_put(b->gaf_part[i].s, b->gaf_part[i].m);
+		mga_set_error("%s", b->errmsg[0] ? b->errmsg : "mapping pipeline failed");
+		rc = -1;
 	}
-	pthread_mutex_destroy(&J.mtx); pthread_mutex_destroy(&J.cmtx);
-	free(J.cstart);
-	for (i = 0; i < n_pipe; ++i) { /* merge the per-thread counters */
-		mga_stats_t *d = &gi->B->st, *s = &thr[i].st;
-		d->n_reads += s->n_reads, d->n_bases += s->n_bases, d->n_mz += s->n_mz, d->n_probe += s->n_probe, d->n_hit += s->n_hit;
-		d->n_anchor_chained += s->n_anchor_chained, d->n_wfa += s->n_wfa, d->wfa_t_bases += s->wfa_t_bases, d->wfa_q_bases += s->wfa_q_bases;
-		d->wfa_cells += s->wfa_cells;
-		d->t_sketch += s->t_sketch, d->t_seed += s->t_seed, d->t_lchain += s->t_lchain, d->t_host_chain += s->t_host_chain, d->t_wfa += s->t_wfa, d->t_host_post += s->t_host_post;
-		d->t_gaf += s->t_gaf;
-		d->n_rescue_dev += s->n_rescue_dev, d->n_rescue_host += s->n_rescue_host;
+	if (b->want_gaf) {
+		if (b->out == 0) b->out = (char*)malloc(1), b->out_cap = 1;
+		b->out[b->out_len] = 0;
 	}
-	if (J.err) {
-		for (i = 0; i < n; ++i) { mg_gchain_free(gcs[i]); gcs[i] = 0; }
-		if (J.gaf_part) { for (i = 0; i < n_chunks * J.n_threads; ++i) free(J.gaf_part[i].s); free(J.gaf_part); free(J.done); }
-		mga_set_error("%s", J.errmsg[0] ? J.errmsg : "mapping pipeline failed");
-		return -1;
-	}
-	if (g_cpu_on) {
+	if (out) *out = b->out; else free(b->out);
+	if (out_len) *out_len = b->out_len;
+	if (out_cap) *out_cap = b->out_cap;
+	if (user) *user = b->user;
+	if (g_cpu_on && rc > 0) {
 		struct timespec ts;
-		fprintf(stderr, "[pipe] host CPU seconds by stage (%d reads):", n);
+		fprintf(stderr, "[pipe] host CPU seconds by stage (cumulative, batch of %d reads done at %.3f s):", b->n, mga_wtime() - g_job_t0);
 		for (i = 0; i < C_N; ++i) fprintf(stderr, " %s %.3f", g_cname[i], g_cpu_ns[i] * 1e-9);
 		clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts);
 		fprintf(stderr, "; process total so far %.3f\n", ts.tv_sec + ts.tv_nsec * 1e-9);
 	}
-	if (gaf) { /* every chunk was committed in read order while the pipeline ran */
-		struct mg_idx_bucket_s *B = gi->B;
-		if (B->gaf_out == 0) B->gaf_out = (char*)malloc(1), B->gaf_cap = 1;
-		B->gaf_out[J.out_len] = 0;
-		*gaf = B->gaf_out, *gaf_len = J.out_len;
-		B->st.gaf_bytes += J.out_len;
-		free(J.gaf_part); free(J.done);
+	pthread_mutex_destroy(&b->cmtx);
+	if (b->own_gcs) free(b->gcs);
+	free(b->cstart); free(b->gaf_part); free(b->done); free(b);
+	return rc;
+}
+
+void mga_stream_close(mga_stream_t *S)
+{
+	int i;
+	if (S == 0) return;
+	while (mga_stream_collect(S, 0, 0, 0, 0) != 0) {} /* drop what was never collected */
+	pthread_mutex_lock(&S->m);
+	S->closing = 1;
+	pthread_cond_broadcast(&S->c_work);
+	pthread_mutex_unlock(&S->m);
+	if (S->started) for (i = 0; i < S->n_pipe; ++i) pthread_join(S->thr[i], 0);
+	for (i = 0; i < S->n_pipe; ++i) pipe_ctx_free(&S->P[i]);
+	pthread_mutex_destroy(&S->m); pthread_mutex_destroy(&S->api);
+	pthread_cond_destroy(&S->c_work); pthread_cond_destroy(&S->c_done); pthread_cond_destroy(&S->c_space);
+	free(S);
+}
+
+/* the index's own stream: created on first use, closed by mg_idx_destroy() */
+static pthread_mutex_t g_idx_stream_mtx = PTHREAD_MUTEX_INITIALIZER;
+static mga_stream_t *idx_stream(const mg_idx_t *gi, const mg_mapopt_t *opt, int n_threads)
+{
+	struct mg_idx_bucket_s *B = gi->B;
+	pthread_mutex_lock(&g_idx_stream_mtx);
+	if (B->stream == 0) B->stream = mga_stream_open(gi, opt, n_threads);
+	pthread_mutex_unlock(&g_idx_stream_mtx);
+	return (mga_stream_t*)B->stream;
+}
+void mga_idx_stream_close(mg_idx_t *gi) { if (gi && gi->B && gi->B->stream) { mga_stream_close((mga_stream_t*)gi->B->stream); gi->B->stream = 0; } }
+
+/* one batch through the index's stream, start to finish.  Calls are serialized per index (the pipeline contexts are
+ * shared state); callers that want concurrency use one mg_tbuf_t per thread with mg_map()/mg_map_frag(), or their own stream. */
+static int map_all(const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs,
+				   const mg_mapopt_t *opt, int n_threads, const char *d_seq, const int64_t *q_off, char **gaf, int64_t *gaf_len)
+{
+	mga_stream_t *S;
+	struct mg_idx_bucket_s *B = gi->B;
+	int rc, i;
+	for (i = 0; i < n; ++i) gcs[i] = 0;
+	if (n <= 0) return 0;
+	if ((S = idx_stream(gi, opt, n_threads)) == 0) return -1;
+	pthread_mutex_lock(&S->api);
+	mga_stream_set_opt(S, opt, n_threads);
+	if (gaf) {
+		char *out = B->gaf_out; int64_t cap = B->gaf_cap, len = 0;
+		B->gaf_out = 0, B->gaf_cap = 0;
+		mga_stream_submit(S, n, qlens, seqs, qnames, gcs, 1, d_seq, q_off, 0, MGA_SB_FIRST | MGA_SB_LAST, out, cap, 0);
+		rc = mga_stream_collect(S, &out, &len, &cap, 0);
+		B->gaf_out = out, B->gaf_cap = cap; /* the GAF text stays owned by the index */
+		*gaf = out, *gaf_len = rc > 0 ? len : 0;
+	} else {
+		mga_stream_submit(S, n, qlens, seqs, qnames, gcs, 0, d_seq, q_off, 0, MGA_SB_FIRST | MGA_SB_LAST, 0, 0, 0);
+		rc = mga_stream_collect(S, 0, 0, 0, 0);
 	}
-	return 0;
+	pthread_mutex_unlock(&S->api);
+	return rc > 0 ? 0 : -1;
 }
 
 /* map + format: the GAF text (input order) of n reads; *gaf points into a grow-only buffer OWNED BY THE INDEX, valid until the
@@ -1059,20 +1239,37 @@ int mg_map_batch(const mg_idx_t *gi, int n, const int *qlens, const char **seqs,
 }
 
 /* same as mg_map_batch() for reads that already sit in HBM: d_seq holds the reads back to back (+64 readable bytes),
- * q_off[n+1] are their absolute offsets.  This is the region bench.py times ("inputs resident in HBM"). */
+ * q_off[n+1] are their absolute offsets. */
 int mga_map_batch_resident(const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs,
 						   const mg_mapopt_t *opt, int n_threads, const char *d_seq, const int64_t *q_off)
 {
 	return map_all(gi, n, qlens, seqs, qnames, gcs, opt, n_threads, d_seq, q_off, 0, 0);
 }
 
+/* ---- the reference's per-read API (map-algo.c:14-32,340-502).  Its threading contract is one mg_tbuf_t per worker thread
+ * (gmap.c:84-86, ggen.c:36): here a mg_tbuf_t owns a pipeline context (HIP stream + device buffers), created on first use, so
+ * that kt_for workers calling mg_map() concurrently never share device state.  b == NULL falls back to the index's stream. ---- */
+struct mg_tbuf_s { pipe_ctx_t P; };
+mg_tbuf_t *mg_tbuf_init(void) { return (mg_tbuf_t*)calloc(1, sizeof(mg_tbuf_t)); }
+void mg_tbuf_destroy(mg_tbuf_t *b) { if (b == 0) return; if (b->P.sc) { mga_dev_bind_thread(); pipe_ctx_free(&b->P); } free(b); }
+
 void mg_map_frag(const mg_idx_t *gi, int n_segs, const int *qlens, const char **seqs, mg_gchains_t **gcs, mg_tbuf_t *b, const mg_mapopt_t *opt, const char *qname)
 {
 	int i;
-	(void)b;
 	for (i = 0; i < n_segs; ++i) gcs[i] = 0;
 	if (n_segs != 1) { /* multi-segment (paired short reads) is outside the accelerated path: the reference itself returns NULLs for n_segs out of range */
 		if (mg_verbose >= 1) fprintf(stderr, "[E::%s] only single-segment reads are supported by the MI355X path\n", __func__);
+		return;
+	}
+	if (b) { /* the caller's own pipeline context: concurrent callers with distinct mg_tbuf_t never share device state */
+		mga_stats_t cst;
+		int rc;
+		memset(&cst, 0, sizeof cst);
+		if (g_dbg_pipe < 0) { g_dbg_pipe = env_int("MGA_DEBUG_PIPE", 0); g_gpu_wfa.avail = env_int("MGA_WFA_SLOTS", 2); }
+		rc = mga_dev_init() < 0 || mga_dev_bind_thread() < 0 || (b->P.sc == 0 && (b->P.sc = mga_sctx_create()) == 0) ? -1 : 0;
+		if (rc == 0) rc = map_chunk(&b->P, gi, 1, qlens, seqs, &qname, gcs, opt, 1, 0, 0, 0, &cst, 0);
+		if (rc < 0) { fprintf(stderr, "[E::%s] %s\n", __func__, mga_last_error()); abort(); /* no CPU fallback */ }
+		pthread_mutex_lock(&g_stats_mtx); stats_merge(&gi->B->st, &cst); pthread_mutex_unlock(&g_stats_mtx);
 		return;
 	}
 	if (mg_map_batch(gi, 1, qlens, seqs, &qname, gcs, opt, 1) < 0) {
@@ -1090,6 +1287,8 @@ mg_gchains_t *mg_map(const mg_idx_t *gi, int qlen, const char *seq, mg_tbuf_t *b
 
 void mga_get_stats(const mg_idx_t *gi, mga_stats_t *st, int reset)
 {
+	pthread_mutex_lock(&g_stats_mtx);
 	*st = gi->B->st;
 	if (reset) memset(&gi->B->st, 0, sizeof(mga_stats_t));
+	pthread_mutex_unlock(&g_stats_mtx);
 }

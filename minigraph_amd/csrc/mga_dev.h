@@ -59,6 +59,7 @@ int  mga_h2d_s(mga_sctx_t *sc, void *d, const void *h, size_t bytes);   /* async
 int  mga_d2h_s(mga_sctx_t *sc, void *h, const void *d, size_t bytes); /* <= 256 KB: any host memory, valid after mga_ssync(); larger: h must be pinned */
 int  mga_dmemset_s(mga_sctx_t *sc, void *d, int v, size_t bytes);
 int  mga_ssync(mga_sctx_t *sc);
+void mga_sctx_abort(mga_sctx_t *sc);           /* error path: drain the stream, drop the staged read-backs (their destinations die with the caller's frame) */
 typedef struct { void *p; size_t cap; } mga_hbuf_t;                     /* grow-only PINNED host buffer */
 int  mga_hbuf_reserve(mga_hbuf_t *b, size_t bytes);
 void mga_hbuf_free(mga_hbuf_t *b);

@@ -64,7 +64,19 @@ struct mg_idx_bucket_s {
 	mga_stats_t st;
 	char *gaf_out;           /* GAF text of the last mga_map_reads() pass; grow-only, owned by the index */
 	int64_t gaf_cap;
+	void *stream;            /* mga_stream_t of the single-batch entry points (mapper.c), created on first use */
 };
+
+/* ---- the chunk pipeline as a persistent object (mapper.c) ---- */
+typedef struct mga_stream_s mga_stream_t;
+#define MGA_SB_FIRST 1   /* first batch of a job: small chunks first (pipeline fill) */
+#define MGA_SB_LAST  2   /* last batch: small chunks last (pipeline drain) */
+mga_stream_t *mga_stream_open(const mg_idx_t *gi, const mg_mapopt_t *opt, int n_threads);
+int mga_stream_submit(mga_stream_t *S, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs, int want_gaf,
+					  const char *d_seq, const int64_t *q_off, int seqs_pinned, int flags, char *out, int64_t out_cap, void *user);
+int mga_stream_collect(mga_stream_t *S, char **out, int64_t *out_len, int64_t *out_cap, void **user);
+void mga_stream_close(mga_stream_t *S);
+void mga_idx_stream_close(mg_idx_t *gi);
 
 typedef struct { const char *cg, *ds; int32_t cg_len, ds_len, mlen, blen; } mga_chain_text_t; /* cg == NULL: format from the chain itself */
 void mga_write_gaf_append(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, int32_t n_seg, const int32_t *qlens, const char *qname, uint64_t flag,

@@ -1,6 +1,6 @@
-"""Multi-GPU plumbing: reads are sharded across ranks with no data-path collective; the only
-exchange is the variable-length gather of GAF bytes to the writer rank.  Backend "nccl" is RCCL over
-xGMI on the GPU box; the same code runs on "gloo" CPU tensors in the tests."""
+"""Multi-GPU plumbing: ONE input is sharded across ranks (one process per GPU, index replicated) with no data-path collective
+(SURVEY 8e); the only exchange is the variable-length gather of GAF bytes to the writer rank, which re-assembles ONE output in input
+order.  Backend "nccl" is RCCL over xGMI on the GPU box; the same code runs on "gloo" CPU tensors in the tests."""
 import torch
 import torch.distributed as dist
 
@@ -37,3 +37,39 @@ def gather_bytes(payload, dst=0, device="cpu", as_tensors=False):
     if as_tensors:
         return [out[r][:sizes[r]] for r in range(world)]
     return [out[r][:sizes[r]].cpu().numpy().tobytes() for r in range(world)]
+
+
+def assemble_segments(parts, seg_lens):
+    """rank-order concatenation PER SEGMENT: parts[r] = the bytes rank r produced (its segments back to back), seg_lens[r][s] = how many
+    of them belong to output segment s (a memory-mapped FASTA file is one segment cut by byte range; any other input has one segment per
+    mini-batch cut by read index: mga_map_files_shard in include/minigraph_amd.h).  Returns the single-process output."""
+    n_seg = max((len(s) for s in seg_lens), default=0)
+    pos = [0] * len(parts)
+    out = []
+    for s in range(n_seg):
+        for r, p in enumerate(parts):
+            ln = int(seg_lens[r][s]) if s < len(seg_lens[r]) else 0
+            out.append(bytes(memoryview(p)[pos[r]:pos[r] + ln]))
+            pos[r] += ln
+    return b"".join(out)
+
+
+def map_sharded(mapper, dst=0, device="cpu"):
+    """one input -> world ranks -> one GAF on `dst` (gmap.c:98-141 fanned out over devices).  mapper(rank, world) maps this rank's shard
+    and returns (payload, seg_len): its GAF bytes (bytes or a uint8 numpy view) and the per-segment byte counts.  One all_gather of the
+    segment tables + one gather of the payloads (RCCL when device == "cuda"); returns the assembled bytes on dst, None elsewhere."""
+    import numpy as np
+    world, rank = dist.get_world_size(), dist.get_rank()
+    payload, seg_len = mapper(rank, world)
+    seg_len = [int(x) for x in seg_len]
+    n_seg = torch.tensor([len(seg_len)], dtype=torch.int64, device=device)
+    dist.all_reduce(n_seg, op=dist.ReduceOp.MAX)
+    tab = torch.zeros(max(int(n_seg.item()), 1), dtype=torch.int64, device=device)
+    if seg_len:
+        tab[:len(seg_len)] = torch.tensor(seg_len, dtype=torch.int64)
+    tabs = [torch.zeros_like(tab) for _ in range(world)]
+    dist.all_gather(tabs, tab)
+    parts = gather_bytes(payload, dst=dst, device=device)
+    if rank != dst:
+        return None
+    return assemble_segments(parts, [t.cpu().tolist() for t in tabs])

@@ -53,7 +53,7 @@ def run_reference(graph, reads, cigar=True, threads=4, preset="lr"):
     return p.stdout, int(m.group(1)), int(m.group(2))
 
 
-def map_with_oracle_stages(graph, reads, occ_max1, lc_max_occ, cigar=True, n_threads=4, preset="lr"):
+def map_with_oracle_stages(graph, reads, occ_max1, lc_max_occ, cigar=True, n_threads=4, preset="lr", per_read=False):
     """whole -cx lr (or -cx asm) job: oracle for the kernel stages, product C code for everything on the host.  Under asm the RMQ chainer
     is the primary chainer and runs in the product's host phases (mapper.c: rq_chain_all) on the oracle's sorted anchors"""
     L = mga.load()
@@ -146,8 +146,8 @@ def map_with_oracle_stages(graph, reads, occ_max1, lc_max_occ, cigar=True, n_thr
     for i in range(n):
         ql = C.c_int32(len(seqs[i]))
         L.mg_write_gaf(C.byref(ks), g, gcs[i], 1, C.byref(ql), names[i], mo.flag, None)
-        if ks.l:
-            out.append(C.string_at(ks.s, ks.l))
+        if ks.l or per_read:
+            out.append(C.string_at(ks.s, ks.l) if ks.l else b"")
         L.mg_gchain_free(gcs[i])
     L.mga_batch_destroy(b)
-    return b"".join(out), n_prob
+    return (out if per_read else b"".join(out)), n_prob

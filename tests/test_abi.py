@@ -42,6 +42,24 @@ def test_struct_sizes_match_reference_abi():
     assert L.mg_opt_set(b"nope", ctypes.byref(io), ctypes.byref(mo), ctypes.byref(go)) == -1
 
 
+def test_struct_layouts_match_reference_headers():
+    """every struct of the boundary: sizeof and every field offset of include/minigraph_amd.h, measured by a compiled C
+    probe, against the same probe compiled with the reference's minigraph.h / gfa.h / mgpriv.h (tests/golden/abi_layout.json, made by
+    tests/golden/make_abi_layout.py; re-derived here when /root/reference is present so that the committed file cannot go stale)"""
+    import json
+    import abi_probe
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "abi_layout.json")))
+    ours = abi_probe.run_probe(["-I" + os.path.join(ROOT, "include")], ['#include "minigraph_amd.h"'])
+    assert ours == gold, {k: (gold.get(k), ours.get(k)) for k in set(gold) | set(ours) if gold.get(k) != ours.get(k)}
+    for k, v in (("mg128_t", 16), ("mg_idxopt_t", 12), ("mg_mapopt_t", 168), ("mg_idx_t", 48), ("mg_lchain_t", 40), ("mg_llchain_t", 20),
+                 ("mg_cigar_t", 24), ("mg_ds_t", 24), ("mg_gchain_t", 104), ("mg_gchain_t.p", 72), ("mg_gchain_t.ds", 80),
+                 ("mg_gchains_t", 48), ("gfa_arc_t", 32), ("gfa_seg_t", 64), ("gfa_edseq_t", 16)):
+        assert gold[k] == v, (k, gold[k], v)   # the numbers SURVEY 8b quotes
+    if os.path.exists("/root/reference/minigraph.h"):
+        ref = abi_probe.run_probe(["-I/root/reference"], ['#include "minigraph.h"', '#include "gfa.h"', '#include "mgpriv.h"'])
+        assert ref == gold
+
+
 def test_no_gpu_fails_loudly():
     """without a GPU every compute entry point must fail with an error, never fall back to the CPU"""
     L = mga.load()

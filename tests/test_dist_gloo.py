@@ -1,7 +1,13 @@
-"""CPU, world_size 2, gloo: the N>1 path of bench.py -- contiguous read sharding and the gather of
-GAF bytes to rank 0 (RCCL on the GPU box, same code)."""
+"""CPU, world_size 2, gloo: the N>1 path -- ONE input sharded over the ranks by the library's own reader, every rank running the
+product's real host pipeline on its shard (the oracle stands in for the HIP kernels, tests/hostpipe.py), the GAF bytes gathered to
+rank 0 and re-assembled per segment; the result must be the single-rank bytes (RCCL on the GPU box, same code)."""
 import os
 import socket
+import subprocess
+import sys
+import tempfile
+
+import pytest
 
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -46,3 +52,60 @@ def test_shard_range_covers_everything():
             assert parts[0][0] == 0 and parts[-1][1] == n
             assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
             assert max(e - s for s, e in parts) - min(e - s for s, e in parts) <= 1
+
+
+def _shard_worker(rank, world, port, q, graph, reads, occ, lco, batch_bases):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import hostpipe as hp
+    import minigraph_amd as mga
+    from minigraph_amd.dist import map_sharded
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def mapper(r, w):  # what mga_map_files_shard does on a GPU: this rank's shard of the ONE input -> GAF bytes + bytes per segment
+        shard = reads + ".shard%d.fa" % r
+        seg_n = mga.reads_shard_dump(reads, shard, r, w, batch_bases=batch_bases)
+        lines, _ = hp.map_with_oracle_stages(graph, shard, occ, lco, per_read=True) if int(seg_n.sum()) else ([], 0)
+        seg_len, pos = [], 0
+        for n in seg_n:
+            seg_len.append(sum(len(x) for x in lines[pos:pos + int(n)]))
+            pos += int(n)
+        return b"".join(lines), seg_len
+
+    got = map_sharded(mapper, dst=0)
+    if rank == 0:
+        q.put(got)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_one_input_two_ranks_one_gaf(gz):
+    """plain FASTA: the file is cut by byte range at record starts (one segment); gzip: every rank parses everything and keeps its slice
+    of every mini-batch (several segments with -K 40k)"""
+    import gzip
+    import hostpipe as hp
+    import minigraph_amd as mga
+    import refbind as rb
+    if not (rb.have_oracle() and os.path.exists(rb.REF_BIN)):
+        pytest.skip("oracle/_ref not built")
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "400000", "-H", "3", "-n", "23", "-l", "6000", "-s", "4"], stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    want, occ, lco = hp.run_reference(graph, reads)
+    single, _ = hp.map_with_oracle_stages(graph, reads, occ, lco)
+    assert single == want
+    if gz:
+        open(reads + ".gz", "wb").write(gzip.compress(open(reads, "rb").read()))
+        reads += ".gz"
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q, graph, reads, occ, lco, 40000)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got == want

@@ -14,7 +14,15 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+def need_ref():
+    """the reference binary (oracle/_ref/minigraph, built by oracle/Makefile, shipped with the gpurun snapshot) is the checker
+    of these tests: its absence on a GPU box is a FAILURE, never a skip -- a suite that skips its parity checks is not green"""
+    assert os.path.exists(rb.REF_BIN), ("oracle/_ref/minigraph is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                        "where /root/reference exists; oracle/_ref/ must travel to the GPU box")
+
+
 def run_ref(args, out):
+    need_ref()
     with open(out, "wb") as fo:
         subprocess.check_call([rb.REF_BIN] + args, stdout=fo, stderr=subprocess.DEVNULL)
 
@@ -42,8 +50,7 @@ def test_mt_known_answer():
 @pytest.mark.parametrize("cigar", [True, False])
 @pytest.mark.parametrize("target", ["gfa", "lin.fa"])
 def test_synthetic_vs_reference_binary(cigar, target):
-    if not os.path.exists(rb.REF_BIN):
-        pytest.skip("oracle/_ref/minigraph not present")
+    need_ref()
     d = tempfile.mkdtemp()
     subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "3000000", "-H", "3", "-n", "400", "-s", "5"], stderr=subprocess.DEVNULL)
     graph, reads = os.path.join(d, "t." + target), os.path.join(d, "t.reads.fa")
@@ -133,8 +140,7 @@ def test_error_free_reads_need_no_wfa_problem():
 def test_parity_sweep_vs_reference_binary(tag, simargs, cigar):
     """shapes the benchmark workload does not reach: wide WFA tiers (long gaps of long / noisy reads), many short reads,
     several stable sequences, the chains-only output"""
-    if not os.path.exists(rb.REF_BIN):
-        pytest.skip("oracle/_ref/minigraph not present")
+    need_ref()
     d = tempfile.mkdtemp()
     subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t")] + simargs, stderr=subprocess.DEVNULL)
     graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
@@ -153,8 +159,7 @@ def test_parity_sweep_vs_reference_binary(tag, simargs, cigar):
 def test_edge_case_reads_vs_reference_binary():
     """the shapes the reference's own callers have to survive: empty and tiny reads, reads without a single
     minimizer hit, runs of N, lower case, U, FASTQ input, duplicated names"""
-    if not os.path.exists(rb.REF_BIN):
-        pytest.skip("oracle/_ref/minigraph not present")
+    need_ref()
     import random
     rng = random.Random(17)
     human = b"".join(l.strip() for l in open(os.path.join(GOLD, "MT-human.fa"), "rb") if not l.startswith(b">")).upper()
@@ -231,8 +236,7 @@ def test_device_index_build_equals_host_build(monkeypatch):
 def test_reference_fixtures_both_presets(preset, query):
     """the reference's own fixtures (test/MT*.fa vs test/MT.gfa) under -x lr and -x asm (RMQ chainer as the primary chainer,
     lchain.c:252-372), with and without base alignment"""
-    if not os.path.exists(rb.REF_BIN):
-        pytest.skip("oracle/_ref/minigraph not present")
+    need_ref()
     d = tempfile.mkdtemp()
     for cigar in (True, False):
         ref_out, got = os.path.join(d, "ref.gaf"), os.path.join(d, "got.gaf")
@@ -247,8 +251,7 @@ def test_asm_preset_long_contigs_vs_reference_binary(contig, n, err, monkeypatch
     """-cx asm on assembly-like queries: 300 kb and 4 Mbp contigs against the bubble graph.  This is the long-query path: sketch in
     64 kb pieces, one thread per minimizer for the seeds, anchors sorted by the host, the RMQ chainer's forward pass spread over
     (segment, strand) runs.  MGA_NO_LONGQ=1 (one wavefront per contig, device sort) must give the same bytes"""
-    if not os.path.exists(rb.REF_BIN):
-        pytest.skip("oracle/_ref/minigraph not present")
+    need_ref()
     d = tempfile.mkdtemp()
     subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "6000000", "-H", "3", "-n", str(n), "-l", str(contig), "-e", str(err), "-s", "51"], stderr=subprocess.DEVNULL)
     graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
@@ -315,8 +318,7 @@ def test_reads_with_a_gap_beyond_the_exact_wfa_cap_vs_reference_binary():
     """reads whose middle 9-12 kb are 30-40 % diverged: the anchor gap there passes 1e8 WFA cells and the reference falls back to
     mwf_wfa_chain() (miniwfa.c:829-832); same bytes expected, incl. the read whose gap takes the D+I shortcut"""
     import numpy as np
-    if not os.path.exists(rb.REF_BIN):
-        pytest.skip("oracle/_ref/minigraph not present")
+    need_ref()
     rng = np.random.default_rng(11)
 
     def rnd(n):
@@ -421,8 +423,7 @@ OPTION_SETS = [
 @pytest.mark.parametrize("tag,cli,idx_opt,map_opt,flags", OPTION_SETS, ids=[o[0] for o in OPTION_SETS])
 def test_command_line_options_vs_reference_binary(workload, tag, cli, idx_opt, map_opt, flags):
     """every mapping option of the reference's command line (main.c:131-216) set through mg_idxopt_t / mg_mapopt_t: same bytes"""
-    if not os.path.exists(rb.REF_BIN):
-        pytest.skip("oracle/_ref/minigraph not present")
+    need_ref()
     d = tempfile.mkdtemp()
     if workload == "bubbles":
         subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "1500000", "-H", "3", "-n", "150", "-s", "7"], stderr=subprocess.DEVNULL)
@@ -443,8 +444,7 @@ def test_several_query_files_and_small_minibatches_vs_reference_binary():
     """minigraph graph a.fa b.fq.gz with -K 300k: the files are mapped one after the other (gmap.c:203-208), each in mini-batches of
     300 kbp (reader thread -> mapper -> writer thread, output buffers swapped between them); same bytes, same order"""
     import gzip
-    if not os.path.exists(rb.REF_BIN):
-        pytest.skip("oracle/_ref/minigraph not present")
+    need_ref()
     d = tempfile.mkdtemp()
     subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "2000000", "-H", "3", "-n", "240", "-s", "77"], stderr=subprocess.DEVNULL)
     graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")

@@ -75,3 +75,52 @@ def test_reader_large_records_cross_buffer_boundaries():
             f.write(b">" + name + b"\n" + seq + b"\n")
     n, nb, h = parse(path)
     assert n == 3 and nb == sum(len(s) for _, s in recs) and h == fnv(recs)
+
+
+def parse_x(path, batch_bases, threads):
+    L = mga.load()
+    L.mga_reads_parse_x.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
+    n, nb, h = C.c_int64(), C.c_int64(), C.c_uint64()
+    assert L.mga_reads_parse_x(path.encode(), batch_bases, threads, C.byref(n), C.byref(nb), C.byref(h)) == 0
+    return n.value, nb.value, h.value
+
+
+def test_parallel_fasta_reader_windows_batches_and_fallback(monkeypatch):
+    """the memory-mapped parallel reader (mapfiles.c: fa_*): many windows and mini-batches, several threads, records of very different
+    sizes, CRLF, empty records; the same file through the sequential reader (MGA_NO_FAST_READER=1) and a Python parser; and a file
+    that turns FASTQ-like half-way (a line starting with '+'), where the rest goes through the sequential reader"""
+    rng = random.Random(17)
+    d = tempfile.mkdtemp()
+    for crlf in (False, True):
+        nl = b"\r\n" if crlf else b"\n"
+        recs, text = [], []
+        for i in range(3000):
+            ln = rng.choice([0, 1, 79, 80, 81, 1000, 10000, 10000, 10000, 200000 if i % 500 == 0 else 3000])
+            seq = bytes(rng.choices(b"ACGTacgtNu", k=ln))
+            name = b"r%d" % i
+            recs.append((name, norm(seq)))
+            text.append(b">" + name + (b"\tcomment here" if i % 4 == 0 else b"") + nl)
+            text.append(b"".join(seq[k:k + 80] + nl for k in range(0, ln, 80)))
+        path = os.path.join(d, "p%d.fa" % crlf)
+        open(path, "wb").write(b"".join(text))
+        want = (len(recs), sum(len(s) for _, s in recs), fnv(recs))
+        for bb, th in ((10 ** 9, 1), (10 ** 9, 8), (1_000_000, 4), (100_000, 3), (1, 2)):
+            assert parse_x(path, bb, th) == want, (crlf, bb, th)
+        monkeypatch.setenv("MGA_NO_FAST_READER", "1")
+        assert parse_x(path, 1_000_000, 4) == want
+        monkeypatch.delenv("MGA_NO_FAST_READER")
+    # FASTA, then FASTQ records from the middle on
+    recs, text = [], []
+    for i in range(400):
+        seq = bytes(rng.choices(b"ACGT", k=5000))
+        recs.append((b"a%d" % i, seq))
+        text.append(b">a%d\n" % i + b"".join(seq[k:k + 60] + b"\n" for k in range(0, 5000, 60)))
+    for i in range(300):
+        seq = bytes(rng.choices(b"ACGT", k=700))
+        recs.append((b"q%d" % i, seq))
+        text.append(b"@q%d\n" % i + seq + b"\n+\n" + bytes(rng.choices(b"!#>@+5I", k=700)) + b"\n")
+    path = os.path.join(d, "mixed.fx")
+    open(path, "wb").write(b"".join(text))
+    want = (len(recs), sum(len(s) for _, s in recs), fnv(recs))
+    for bb, th in ((10 ** 9, 4), (300_000, 4)):
+        assert parse_x(path, bb, th) == want, (bb, th)
