@@ -4,11 +4,17 @@
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One STEP = one pass of the whole hot path (sketch -> seeds -> linear chaining -> graph chaining ->
-WFA base alignment -> CIGAR/ds -> GAF text) over one batch of synthetic 10 kb ONT-like reads that is
-already resident in HBM.  Workload = BASELINE.json configs[2]: 50 Mbp 3-haplotype bubble graph,
-`-cx lr -c`.  Reads are sharded across ranks (each rank draws its own reads against the same graph:
-weak scaling); the only inter-GPU traffic is the gather of GAF bytes to rank 0 over RCCL.
+Workload = the configuration BASELINE.json's metric is quoted on (configs[3] shape): a 3 Gbp 5-haplotype bubble graph in 24
+chromosomes and 125 000 x 10 kb synthetic ONT reads PER GPU (1 M reads at 8 GPUs), `-cx lr -c`.
+
+One STEP = one pass of the whole mapping phase over that read set: FASTA file -> parse -> H2D -> sketch -> seeds -> linear chaining ->
+graph chaining -> WFA base alignment -> CIGAR/ds -> GAF text in ONE buffer in memory -- the interval between the reference's
+`mg_opt_update` and its last `worker_pipeline` log line (gmap.c:186-211), which is also what the
+`cpu_baseline` leg reports for the unmodified reference.  Graph load and index build are outside it on both sides (`index_s`).
+N > 1: ONE read file (125 000 x N reads, written by rank 0) is cut into N contiguous byte ranges by the library's reader, every rank
+maps its range against its own replica of the index, and the GAF bytes are gathered to rank 0 over RCCL and re-assembled in input
+order inside the timed region.  Extra keys: `resident` (the same reads already in HBM, no parse / upload), `isolated`
+(one pass with ONE chunk in flight, so that per-kernel HIP-event times do not overlap: the per-kernel roofline comes from there).
 
 Rank 0 prints ONE JSON line (metric / roofline / cpu_baseline); everything else goes to stderr.
 """
@@ -26,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+METRIC = "mapped Gbp/sec (whole node), -cx lr 10kb reads vs 3Gbp graph, 1/2/4/8 GPU"  # BASELINE.json, verbatim
 
 
 def log(*a):
@@ -47,18 +54,16 @@ def cpu_baseline(ref_bin, graph, reads_fa, n_reads, out_dir, threads, cores):
     gaf, err = os.path.join(out_dir, "cpu.gaf"), os.path.join(out_dir, "cpu.log")
     with open(gaf, "wb") as fo, open(err, "w") as fe:
         subprocess.check_call([ref_bin, "-cx", "lr", "-t", str(threads), graph, sample], stdout=fo, stderr=fe)
-    t_upd = t_map = None
+    ts = {}
     for line in open(err):
         m = re.match(r"\[M::(\w+)::([\d.]+)\*", line)
         if m:
-            if m.group(1) == "mg_opt_update":
-                t_upd = float(m.group(2))
-            elif m.group(1) == "worker_pipeline":
-                t_map = float(m.group(2))
+            ts[m.group(1)] = float(m.group(2))
+    t_upd, t_map = ts.get("mg_opt_update"), ts.get("worker_pipeline")
     bases = sum(len(l.strip()) for l in open(sample) if not l.startswith(">"))
     dt = (t_map - t_upd) if (t_upd is not None and t_map is not None) else float("nan")
-    return dict(value=bases / dt / 1e9, unit="Gbp/s", cores=cores, kind="reference",
-                sample="%d reads (%d bp) of the same workload, minigraph -cx lr -t %d on %d usable cores (affinity capped by the cgroup CPU quota), map phase only (worker_pipeline - mg_opt_update)" % (n, bases, threads, cores)), gaf, n
+    return dict(value=bases / dt / 1e9, unit="Gbp/s", cores=cores, kind="reference", index_s=round(ts.get("mg_index", 0) - ts.get("main", 0), 1),
+                sample="%d reads (%d bp) of the same workload, minigraph -cx lr -t %d on %d usable cores (affinity capped by the cgroup CPU quota), map phase only (worker_pipeline - mg_opt_update: FASTA parse + mapping + GAF write, as in `value`)" % (n, bases, threads, cores)), gaf, n
 
 
 def usable_cores():
@@ -92,14 +97,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=100000, help="reads per GPU per step (BASELINE configs[2]: 100k reads)")
-    ap.add_argument("--genome", type=int, default=50000000)
-    ap.add_argument("--hap", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=125000, help="reads per GPU (BASELINE configs[3]: 1M reads over 8 GPUs)")
+    ap.add_argument("--genome", type=int, default=2350000000, help="backbone bp (2.35 Gbp backbone + 4 alt haplotypes = 3.02 Gbp of graph sequence)")
+    ap.add_argument("--chr", type=int, default=24)
+    ap.add_argument("--hap", type=int, default=5)
     ap.add_argument("--cpu-reads", type=int, default=20000)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--gather", action="store_true", help="N>1: also gather every rank's GAF bytes to rank 0 over RCCL inside the timed region "
-                    "(off by default: the shards are independent, each rank keeps / writes its own GAF)")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: leave every rank's GAF shard where it is (the gather to rank 0 over RCCL is ON by default)")
+    ap.add_argument("--resident-steps", type=int, default=2)
     ap.add_argument("--threads", type=int, default=0, help="host threads per rank (0: min(64, usable cores / ranks))")
+    ap.add_argument("--keep", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -118,7 +125,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import minigraph_amd as mga
-    from minigraph_amd.dist import gather_bytes
+    from minigraph_amd.dist import map_sharded
     L = mga.load()
     if L.mga_device_count() <= 0:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
@@ -126,121 +133,210 @@ def main():
     quota = usable_cores()
     threads = args.threads or max(2, min(64, quota // world))  # [measured] more threads than usable cores only adds contention + CFS throttling
 
-    # ---- synthetic workload (untimed) ----
-    d = tempfile.mkdtemp(prefix="mga_bench_r%d_" % rank)
+    # ---- synthetic workload (untimed): ONE graph + ONE read file for the whole job, written by rank 0 ----
+    if rank == 0:
+        d = tempfile.mkdtemp(prefix="mga_bench_")
+        t0 = time.time()
+        p = subprocess.run([mga.MGSIM, "-p", os.path.join(d, "w"), "-G", str(args.genome), "-c", str(args.chr), "-H", str(args.hap),
+                            "-n", str(args.reads * world), "-s", "11"], stderr=subprocess.PIPE, check=True)
+        m = re.search(r"graph=(\d+) bp", p.stderr.decode())
+        graph_bp = int(m.group(1)) if m else int(args.genome * (1 + 0.071 * (args.hap - 1)))
+        try:
+            os.remove(os.path.join(d, "w.lin.fa"))
+        except OSError:
+            pass
+        t_gen = time.time() - t0
+    else:
+        d, t_gen, graph_bp = None, 0.0, 0
+    if dist is not None:
+        box = [d]
+        dist.broadcast_object_list(box, src=0)
+        d = box[0]
     pre = os.path.join(d, "w")
-    t0 = time.time()
-    subprocess.check_call([mga.MGSIM, "-p", pre, "-G", str(args.genome), "-H", str(args.hap), "-n", str(args.reads),
-                           "-s", "11", "-S", str(1000 + rank)], stderr=subprocess.DEVNULL)
-    t_gen = time.time() - t0
     graph_path, reads_path = pre + ".gfa", pre + ".reads.fa"
     t0 = time.time()
     G = mga.Graph(graph_path, preset="lr", cigar=True, n_threads=threads)
     t_index = time.time() - t0
-    R = mga.Reads(reads_path)
-    log("[bench] rank %d: gen %.1fs, load+index %.1fs, %d reads / %d bp resident, %d host threads" % (rank, t_gen, t_index, R.n, R.bases, threads))
+    log("[bench] rank %d: gen %.1fs, load+index %.1fs, %d host threads" % (rank, t_gen, t_index, threads))
+
+    last = {}
 
     def step():
-        gaf = mga.map_reads(G, R, n_threads=threads, copy=False)   # GAF text stays in the C library's buffer
-        if dist is not None and args.gather:  # optional: one output stream on rank 0; zero-copy view -> GPU -> RCCL gather
-            gather_bytes(gaf.view(), dst=0, device="cuda", as_tensors=True)
-        return gaf
+        if dist is None:
+            last["gaf"] = mga.map_files_idx(G, [reads_path], n_threads=threads)
+        elif args.no_gather:
+            last["gaf"] = mga.map_files_idx(G, [reads_path], n_threads=threads, rank=rank, world=world)
+        else:  # one input -> N GPUs -> one GAF on rank 0: size table all_gather + one RCCL gather of the bytes
+            def mapper(r, w):
+                m = mga.map_files_idx(G, [reads_path], n_threads=threads, rank=r, world=w)
+                last["shard"] = m
+                return m.view(), m.seg_len
+            last["gaf_bytes"] = map_sharded(mapper, dst=0, device="cuda")
 
     def sync():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    gaf = None
     for _ in range(args.warmup):
-        gaf = step()
+        step()
     mga.get_stats(G, reset=True)
-    mga.prof_enable(True)
-    mga.prof_get(reset=True)
     sync()
     cpu0, thr0 = time.process_time(), cgroup_throttled()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        gaf = step()
+        step()
     torch.cuda.synchronize()
     sync()
     dt = time.perf_counter() - t0
     cpu1, thr1 = time.process_time(), cgroup_throttled()
+    st = mga.get_stats(G, reset=True)
+    n_reads_rank, n_bases_rank = st["n_reads"] // max(1, args.steps), st["n_bases"] // max(1, args.steps)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        tb = torch.tensor([R.bases], dtype=torch.int64, device="cuda")
+        tb = torch.tensor([n_bases_rank, n_reads_rank] + [st[k] for k in ("n_mz", "n_hit", "wfa_t_bases", "wfa_q_bases", "gaf_bytes")], dtype=torch.int64, device="cuda")
         dist.all_reduce(tb)
-        total_bases = int(tb.item())
+        total_bases, total_reads = int(tb[0].item()), int(tb[1].item())
+        agg = dict(zip(("n_mz", "n_hit", "wfa_t_bases", "wfa_q_bases", "gaf_bytes"), (int(x) for x in tb[2:].tolist())))
     else:
-        total_bases = R.bases
-    st, prof = mga.get_stats(G), mga.prof_get()
+        total_bases, total_reads = n_bases_rank, n_reads_rank
+        agg = {k: st[k] for k in ("n_mz", "n_hit", "wfa_t_bases", "wfa_q_bases", "gaf_bytes")}
+
+    # ---- second key: the same reads resident in HBM (no parse, no upload), rank 0 only, untimed extras ----
+    resident = isolated = None
+    if rank == 0:
+        gaf_first = None
+        if dist is None:
+            gaf_first = last["gaf"].bytes()
+            last["gaf"].free()
+        elif not args.no_gather:
+            gaf_first = last["gaf_bytes"]
+        if args.resident_steps > 0:
+            R = mga.Reads(reads_path, max_reads=args.reads)
+            mga.map_reads(G, R, n_threads=threads, copy=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.resident_steps):
+                mga.map_reads(G, R, n_threads=threads, copy=False)
+            torch.cuda.synchronize()
+            dtr = (time.perf_counter() - t0) / args.resident_steps
+            resident = dict(value=R.bases / dtr / 1e9, unit="Gbp/s", ms_per_step=dtr * 1e3, reads=R.n,
+                            note="one GPU, reads already in HBM (mga_reads_load), GAF text into the library's buffer: no FASTA parse, no upload")
+            # ---- isolated pass: ONE chunk in flight (MGA_PIPE=1), per-kernel HIP-event times on the launch stream do not overlap ----
+            os.environ["MGA_PIPE"] = "1"
+            mga.get_stats(G, reset=True)
+            mga.prof_enable(True)
+            mga.prof_get(reset=True)
+            t0 = time.perf_counter()
+            m = mga.map_files_idx(G, [reads_path], n_threads=threads, rank=0, world=world)
+            torch.cuda.synchronize()
+            dti = time.perf_counter() - t0
+            m.free()
+            del os.environ["MGA_PIPE"]
+            prof, sti = mga.prof_get(), mga.get_stats(G)
+            mga.prof_enable(False)
+            isolated = dict(ms=dti * 1e3, prof=prof, st=sti)
+            R.close()
+    if dist is not None:
+        dist.barrier()
 
     if rank == 0:
         value = total_bases * args.steps / dt / 1e9
-        # dominant kernel by HIP-event time on its launch stream
-        fam = {"k_wfa": sum(prof[k][0] for k in prof if k.startswith("k_wfa")), "k_sketch": prof["k_sketch"][0],
-               "k_seed": prof["k_seed_count"][0] + prof["k_seed_fill"][0], "k_lchain": prof["k_lchain"][0]}
-        launches = {"k_wfa": sum(prof[k][1] for k in prof if k.startswith("k_wfa")), "k_sketch": prof["k_sketch"][1],
-                    "k_seed": prof["k_seed_count"][1] + prof["k_seed_fill"][1], "k_lchain": prof["k_lchain"][1]}
-        alg = {  # algorithmic bytes of each kernel family over the timed steps
-            "k_wfa": st["wfa_t_bases"] + st["wfa_q_bases"],
-            "k_sketch": 2 * st["n_bases"] + 16 * st["n_mz"],           # two passes over the bases (count, write) + minimizers out
-            "k_seed": 16 * st["n_probe"] + 8 * st["n_hit"] + 16 * st["n_hit"],
-            "k_lchain": 32 * st["n_hit"],
-        }
-        dom = max(fam, key=lambda k: fam[k])
-        # HBM traffic of the dominant family per launch, from the committed PMC passes of this same command (profiles/*_pmc.json;
-        # bench.py cannot run rocprofv3 around itself).  KB of FETCH_SIZE + WRITE_SIZE, uncorrected (see the file's "source").
-        traffic, traffic_src = None, None
-        try:
-            import glob
-            pf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))[-1]
-            pk = json.load(open(pf))["kernels"]
-            sel = [v for k, v in pk.items() if (k == "k_wfa" or k.startswith("k_wfa_r<") if dom == "k_wfa" else k.startswith(dom))]  # the tier kernels, not the scheduler's helpers
-            nl = sum(v.get("launches_fetch", 0) for v in sel)
-            if nl:
-                traffic = sum(v.get("fetch_kb", 0) + v.get("write_kb", 0) for v in sel) * 1024.0 / nl
-                traffic_src = os.path.relpath(pf, ROOT)
-        except Exception:
-            pass
-        ach = alg[dom] / (fam[dom] * 1e-3) / 1e9 if fam[dom] > 0 else 0.0
-        roof = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
-                    launches=launches[dom], avg_launch_ms=fam[dom] / max(1, launches[dom]),
-                    alg_bytes_per_launch=alg[dom] / max(1, launches[dom]))
-        res = dict(metric="mapped Gbp/sec (whole node), -cx lr 10kb reads, graph base alignment (-c)", value=value, unit="Gbp/s",
+        # algorithmic bytes of the whole path per read = L + 16 n_mz + 8 n_hit + 32 n_hit + T + Q + O, from this run's counters
+        b_alg = (total_bases * args.steps + 16 * agg["n_mz"] + 40 * agg["n_hit"] + agg["wfa_t_bases"] + agg["wfa_q_bases"] + agg["gaf_bytes"])
+        path_ach = b_alg / dt / 1e9
+        roof_path = dict(bound="hbm", scope="whole path (SURVEY 8d: B_alg = L + 16 n_mz + 8 n_hit + 32 n_hit + T + Q + O, summed over this run's reads)",
+                         achieved=path_ach, peak=HBM_PEAK_GBS * n_gpus, unit="GB/s", frac=path_ach / (HBM_PEAK_GBS * n_gpus),
+                         alg_bytes_per_read=b_alg / max(1, total_reads * args.steps))
+        roof = None
+        kernels_ms = {}
+        if isolated:
+            prof, sti = isolated["prof"], isolated["st"]
+            kernels_ms = {k: round(v[0], 3) for k, v in prof.items()}
+            wfa = [k for k in prof if k.startswith("k_wfa")]
+            fam = {"k_wfa": sum(prof[k][0] for k in wfa), "k_sketch": prof["k_sketch"][0],
+                   "k_seed": prof["k_seed_count"][0] + prof["k_seed_fill"][0], "k_lchain": prof["k_lchain"][0], "k_text": prof["k_text"][0]}
+            launches = {"k_wfa": sum(prof[k][1] for k in wfa), "k_sketch": prof["k_sketch"][1],
+                        "k_seed": prof["k_seed_count"][1] + prof["k_seed_fill"][1], "k_lchain": prof["k_lchain"][1], "k_text": prof["k_text"][1]}
+            alg = {  # algorithmic bytes of each kernel family over the isolated pass
+                "k_wfa": sti["wfa_t_bases"] + sti["wfa_q_bases"],
+                "k_sketch": sti["n_bases"] + 16 * sti["n_mz"],
+                "k_seed": 16 * sti["n_probe"] + 8 * sti["n_hit"] + 16 * sti["n_hit"],
+                "k_lchain": 32 * sti["n_hit"],
+                "k_text": sti["gaf_bytes"],
+            }
+            dom = max(fam, key=lambda k: fam[k])
+            # HBM traffic of the dominant family per launch: from the committed PMC passes of this command (profiles/*_pmc.json); bench.py
+            # cannot run rocprofv3 around itself, so the figure is labelled with its source and is NOT measured in this run
+            traffic, traffic_src = None, None
+            try:
+                import glob
+                pf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_pmc.json")))[-1]
+                pk = json.load(open(pf))["kernels"]
+                sel = [v for k, v in pk.items() if (k == "k_wfa" or k.startswith("k_wfa_r<") if dom == "k_wfa" else k.startswith(dom))]
+                nl = sum(v.get("launches_fetch", 0) for v in sel)
+                if nl:
+                    traffic = sum(v.get("fetch_kb", 0) + v.get("write_kb", 0) for v in sel) * 1024.0 / nl
+                    traffic_src = os.path.relpath(pf, ROOT) + " (committed rocprofv3 --pmc passes of this command, not measured in this run)"
+            except Exception:
+                pass
+            ach = alg[dom] / (fam[dom] * 1e-3) / 1e9 if fam[dom] > 0 else 0.0
+            roof = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
+                        launches=launches[dom], avg_launch_ms=fam[dom] / max(1, launches[dom]), alg_bytes_per_launch=alg[dom] / max(1, launches[dom]),
+                        family_ms_per_pass=fam[dom], pass_ms=isolated["ms"],
+                        note="dominant kernel family by HIP-event time in the ISOLATED pass (one chunk in flight: launch durations do not overlap, sum <= pass_ms); "
+                             "the family is bound by vector-instruction issue, not HBM (DESIGN.md 4): see int_issue",
+                        families={k: dict(ms=round(fam[k], 2), launches=launches[k], alg_GBps=round(alg[k] / max(fam[k], 1e-9) / 1e6, 2)) for k in fam})
+            # integer-issue roofline of the WFA family: wavefront cells per second against what the vector ALUs could issue
+            cells = sti["wfa_cells"]
+            if fam["k_wfa"] > 0 and cells > 0:
+                clk, simd = 2.4e9, 256 * 4
+                instr_per_cell_floor = 40.0 / 64.0   # the five recurrences + DPP operands + traceback byte + one extension round: ~40 wave instructions per 64-cell slot step
+                peak_cells = simd * clk / instr_per_cell_floor
+                roof["int_issue"] = dict(bound="valu-issue", achieved=cells / (fam["k_wfa"] * 1e-3), peak=peak_cells, unit="wavefront cells/s",
+                                         frac=cells / (fam["k_wfa"] * 1e-3) / peak_cells,
+                                         note="peak = 256 CU x 4 SIMD x 2.4 GHz / (40 wave64 instructions per 64-diagonal slot step)")
+        res = dict(metric=METRIC, value=value, unit="Gbp/s",
                    n_gpus=n_gpus, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="u8/int32", data="synthetic",
-                   config=dict(workload="configs[2]: %d x 10kb synthetic ONT reads per GPU vs %d bp %d-haplotype bubble graph, -cx lr -c"
-                               % (R.n, args.genome, args.hap), reads_per_gpu=R.n, read_len=10000, err=0.1, sharding="reads/%dgpu, no data-path collective%s" % (n_gpus, " + RCCL gather of GAF bytes" if (args.gather and n_gpus > 1) else ""),
+                   config=dict(workload="configs[3] shape: %d x 10kb synthetic ONT reads per GPU (%d in all, ONE file) vs %.2f Gbp %d-haplotype bubble graph in %d chromosomes, -cx lr -c"
+                               % (args.reads, total_reads, graph_bp / 1e9, args.hap, args.chr),
+                               interval="FASTA file -> parse -> H2D -> map -> GAF text in one memory buffer per rank%s (reference: worker_pipeline - mg_opt_update); graph load + index build excluded (index_s)"
+                               % (" -> RCCL gather to rank 0 -> one GAF in input order" if (n_gpus > 1 and not args.no_gather) else ""),
+                               reads_per_gpu=args.reads, read_len=10000, err=0.1,
+                               sharding="1 input file cut into %d contiguous byte ranges at record starts, index replicated%s" % (n_gpus, ", GAF gathered to rank 0 over RCCL" if (n_gpus > 1 and not args.no_gather) else ""),
                                host_threads_per_rank=threads),
-                   roofline=roof,
-                   kernels_ms={k: round(v[0], 3) for k, v in prof.items()},
-                   stage_s={k: round(v, 4) for k, v in st.items() if k.startswith("t_")},
-                   per_read=dict(n_mz=st["n_mz"] / max(1, st["n_reads"]), n_hit=st["n_hit"] / max(1, st["n_reads"]),
+                   roofline=roof if roof else roof_path, roofline_path=roof_path,
+                   resident=resident,
+                   kernels_ms_isolated=kernels_ms,
+                   per_read=dict(n_mz=agg["n_mz"] / max(1, total_reads * args.steps), n_hit=agg["n_hit"] / max(1, total_reads * args.steps),
                                  n_wfa=st["n_wfa"] / max(1, st["n_reads"]), wfa_cells=st["wfa_cells"] / max(1, st["n_reads"]),
-                                 gaf_bytes=st["gaf_bytes"] / max(1, st["n_reads"])),
+                                 gaf_bytes=agg["gaf_bytes"] / max(1, total_reads * args.steps)),
                    index_s=round(t_index, 2),
                    host=dict(logical_cpus=ncpu, usable_cores=quota, cpu_s_per_step=round((cpu1 - cpu0) / args.steps, 3),
                              cfs_throttled_periods=thr1[0] - thr0[0], cfs_throttled_s=round((thr1[1] - thr0[1]) * 1e-6, 3)))
         ref_bin = os.path.join(ROOT, "oracle", "_ref", "minigraph")
-        if not args.no_cpu and os.path.exists(ref_bin) and n_gpus == 1:
+        if not args.no_cpu and os.path.exists(ref_bin):
             try:
                 cb, cpu_gaf, n_cpu = cpu_baseline(ref_bin, graph_path, reads_path, args.cpu_reads, d, min(ncpu, 2 * quota), quota)
                 res["cpu_baseline"] = cb
-                want = open(cpu_gaf, "rb").read()
-                gaf = gaf.bytes()
-                res["parity"] = "GAF byte-identical to the reference on the %d-read sample" % n_cpu if gaf[:len(want)] == want and (len(gaf) == len(want) or gaf[len(want) - 1:len(want)] == b"\n") else "MISMATCH vs reference GAF"
+                if gaf_first is not None:
+                    want = open(cpu_gaf, "rb").read()
+                    ok = gaf_first[:len(want)] == want and (len(gaf_first) == len(want) or gaf_first[len(want) - 1:len(want)] == b"\n")
+                    res["parity"] = ("GAF byte-identical to the reference on ALL %d reads of the CPU sample (%d bytes)" % (n_cpu, len(want))) if ok else "MISMATCH vs reference GAF"
             except Exception as e:  # the baseline is a reported number, never a reason to lose the bench line
                 res["cpu_baseline"] = dict(value=None, unit="Gbp/s", cores=quota, kind="reference", sample="failed: %r" % (e,))
         else:
             res["cpu_baseline"] = dict(value=None, unit="Gbp/s", cores=quota, kind="reference",
-                                       sample="not run (N>1, --no-cpu, or oracle/_ref/minigraph absent)")
+                                       sample="not run (--no-cpu, or oracle/_ref/minigraph absent)")
         print(json.dumps(res), flush=True)
-    R.close()
     G.close()
-    shutil.rmtree(d, ignore_errors=True)
+    if dist is not None:
+        dist.barrier()
+    if rank == 0 and not args.keep:
+        shutil.rmtree(d, ignore_errors=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -242,6 +242,9 @@ int mg_map_files(gfa_t *g, int n_fn, const char **fn, const mg_idxopt_t *ipt, co
 /* mgpriv.h:117 / format.c:121-291 */
 void mg_write_gaf(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, int32_t n_seg, const int32_t *qlens, const char *qname, uint64_t flag, void *km);
 
+void mg_sprintf_lite(kstring_t *s, const char *fmt, ...);     /* mgpriv.h:118 / format.c:75-80: %d %u %s %c, appends */
+extern unsigned char seq_nt4_table[256];                      /* sketch.c:9-26 */
+
 /* gfa.h:125-128 / gfa-io.c:294-340: rGFA or FASTA (one segment per record) reader */
 gfa_t *gfa_read(const char *fn);
 void gfa_destroy(gfa_t *g);

@@ -36,6 +36,32 @@ static void ks_path_piece(kstring_t *s, int rev, const char *name, int32_t st, i
 	ks_c(s, "><"[rev]); ks_s(s, name); ks_c(s, ':'); ks_d(s, st); ks_c(s, '-'); ks_d(s, en);
 }
 
+/* mgpriv.h:118 / format.c:36-80: the reference's light formatter (%d %u %s %c only), exported because its consumers of mg_gchains_t
+ * (asm-call.c:122-137, --call) print with it; appends to s like the original */
+#include <stdarg.h>
+void mg_sprintf_lite(kstring_t *s, const char *fmt, ...)
+{
+	va_list ap;
+	const char *p;
+	va_start(ap, fmt);
+	for (p = fmt; *p; ++p) {
+		if (*p != '%') { ks_c(s, *p); continue; }
+		++p;
+		if (*p == 'd') ks_d(s, va_arg(ap, int));
+		else if (*p == 'u') {
+			char buf[16];
+			int l = 0;
+			uint32_t x = va_arg(ap, uint32_t);
+			do { buf[l++] = (char)('0' + x % 10); x /= 10; } while (x > 0);
+			while (l > 0) ks_c(s, buf[--l]);
+		} else if (*p == 's') ks_s(s, va_arg(ap, const char*));
+		else if (*p == 'c') ks_c(s, (char)va_arg(ap, int));
+		else abort(); /* format.c:68 */
+	}
+	va_end(ap);
+	ks_room(s, 0); s->s[s->l] = 0;
+}
+
 void mg_write_gaf(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, int32_t n_seg, const int32_t *qlens, const char *qname, uint64_t flag, void *km)
 {
 	(void)km;

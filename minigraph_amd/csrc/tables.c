@@ -25,4 +25,8 @@ static void tables_fill(void)
 	mga_nt4_table[0] = 0, mga_nt4_table[1] = 1, mga_nt4_table[2] = 2, mga_nt4_table[3] = 3; /* sketch.c:10: codes map to themselves */
 }
 
+/* sketch.c:9: the reference exports its code table as data (miniwfa.c:648 reads it from other objects); same contents, ready at load time */
+unsigned char seq_nt4_table[256];
+__attribute__((constructor)) static void tables_export(void) { pthread_once(&g_tables_once, tables_fill); memcpy(seq_nt4_table, mga_nt4_table, 256); }
+
 void mga_tables_init(void) { pthread_once(&g_tables_once, tables_fill); } /* callable from any thread, any number of times */

@@ -464,3 +464,158 @@ def test_several_query_files_and_small_minibatches_vs_reference_binary():
     if open(ref_out, "rb").read() != open(got, "rb").read():
         raise AssertionError(first_diff(ref_out, got))
     assert open(got, "rb").read().count(b"\n") >= 240
+
+
+def test_half_gigabase_graph_20k_reads_with_batch_seams(monkeypatch):
+    """scale: 0.56 Gbp 5-haplotype graph in 8 chromosomes (2^28-slot table, 32-bit list offsets in use), 20 000 x 10 kb
+    reads through mga_map_files_to_path with -K 30M (7 mini-batch seams inside ONE chunk pipeline, parallel FASTA reader), against the
+    reference binary; then the same job through the sequential reader"""
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "440000000", "-c", "8", "-H", "5", "-n", "20000", "-s", "11"], stderr=subprocess.DEVNULL)
+    os.remove(os.path.join(d, "t.lin.fa"))
+    graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    ref_out, got = os.path.join(d, "ref.gaf"), os.path.join(d, "got.gaf")
+    run_ref(["-c", "-x", "lr", "-t", "16", graph, reads], ref_out)
+    mga.map_files(graph, [reads], got, n_threads=16, map_opt=dict(mini_batch_size=30000000))
+    if subprocess.call(["cmp", "-s", ref_out, got]) != 0:
+        raise AssertionError(first_diff(ref_out, got))
+    monkeypatch.setenv("MGA_NO_FAST_READER", "1")
+    mga.map_files(graph, [reads], got, n_threads=16, map_opt=dict(mini_batch_size=70000000))
+    assert subprocess.call(["cmp", "-s", ref_out, got]) == 0
+
+
+def test_one_input_four_shards_one_gaf():
+    """mga_map_files_shard: the ranks' outputs of one FASTA file (byte ranges) and of its gzip copy (slices of every mini-batch),
+    assembled per segment in rank order, are the single-process bytes and the reference's"""
+    import gzip
+    from minigraph_amd.dist import assemble_segments
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "6000000", "-H", "3", "-n", "3001", "-s", "12"], stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    ref_out = os.path.join(d, "ref.gaf")
+    run_ref(["-c", "-x", "lr", "-t", "8", graph, reads], ref_out)
+    want = open(ref_out, "rb").read()
+    open(reads + ".gz", "wb").write(gzip.compress(open(reads, "rb").read(), 1))
+    G = mga.Graph(graph, preset="lr", cigar=True, n_threads=8)
+    G.mo.mini_batch_size = 4000000
+    one = mga.map_files_idx(G, [reads], n_threads=8)
+    assert one.bytes() == want and len(one.seg_len) == 1
+    for path, world in ((reads, 4), (reads + ".gz", 3), (reads, 7)):
+        parts = [mga.map_files_idx(G, [path], n_threads=8, rank=r, world=world) for r in range(world)]
+        assert all(len(p) > 0 for p in parts)
+        if path.endswith(".gz"):
+            assert len(parts[0].seg_len) > 3   # every mini-batch is a segment
+        assert assemble_segments([p.bytes() for p in parts], [p.seg_len for p in parts]) == want, (path, world)
+    G.close()
+
+
+def test_mg_map_from_several_threads_with_own_tbufs():
+    """the reference's threading contract (gmap.c:84-99): one mg_tbuf_t per worker thread, mg_map() called concurrently against one
+    shared index.  A small C harness (pthreads, no Python in the timed part) maps every read from 6 threads, each with its own
+    mg_tbuf_t, through the public API of libminigraph_amd.so; per-read GAF must equal the serial run's and the reference's"""
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "3000000", "-H", "3", "-n", "360", "-l", "6000", "-s", "14"], stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    src = os.path.join(d, "mt.c")
+    open(src, "w").write(r'''
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <pthread.h>
+#include "minigraph_amd.h"
+typedef struct { const mg_idx_t *gi; const mg_mapopt_t *opt; int n, tid, nt; char **name, **seq; int *len; kstring_t *out; const gfa_t *g; } job_t;
+static void *worker(void *a) {
+	job_t *j = (job_t*)a; int i;
+	mg_tbuf_t *b = mg_tbuf_init();
+	for (i = j->tid; i < j->n; i += j->nt) {
+		mg_gchains_t *gc = mg_map(j->gi, j->len[i], j->seq[i], b, j->opt, j->name[i]);
+		int32_t ql = j->len[i];
+		mg_write_gaf(&j->out[i], j->g, gc, 1, &ql, j->name[i], j->opt->flag, 0);
+		mg_gchain_free(gc);
+	}
+	mg_tbuf_destroy(b);
+	return 0;
+}
+int main(int argc, char **argv) {
+	int nt = atoi(argv[3]), n = 0, m = 0, i; char line[1 << 16];
+	char **name = 0, **seq = 0; int *len = 0;
+	FILE *fp = fopen(argv[2], "r");
+	mg_idxopt_t io; mg_mapopt_t mo; mg_ggopt_t go;
+	mg_verbose = 1;
+	mg_opt_set(0, &io, &mo, &go); mg_opt_set("lr", &io, &mo, &go); mo.flag |= MG_M_CIGAR;
+	while (fgets(line, sizeof line, fp)) {
+		line[strcspn(line, "\r\n")] = 0;
+		if (line[0] == '>') { if (n == m) { m = m ? m * 2 : 256; name = realloc(name, m * sizeof *name); seq = realloc(seq, m * sizeof *seq); len = realloc(len, m * sizeof *len); } name[n] = strdup(line + 1); seq[n] = strdup(""); len[n++] = 0; }
+		else { int l = strlen(line); seq[n-1] = realloc(seq[n-1], len[n-1] + l + 1); memcpy(seq[n-1] + len[n-1], line, l + 1); len[n-1] += l; }
+	}
+	gfa_t *g = gfa_read(argv[1]);
+	mg_idx_t *gi = mg_index(g, &io, 4, &mo);
+	kstring_t *out = calloc(n, sizeof *out);
+	pthread_t th[64]; job_t job[64];
+	for (i = 0; i < nt; ++i) { job_t J = { gi, &mo, n, i, nt, name, seq, len, out, g }; job[i] = J; pthread_create(&th[i], 0, worker, &job[i]); }
+	for (i = 0; i < nt; ++i) pthread_join(th[i], 0);
+	for (i = 0; i < n; ++i) if (out[i].l) fwrite(out[i].s, 1, out[i].l, stdout);
+	mg_idx_destroy(gi); gfa_destroy(g);
+	return 0;
+}
+''')
+    exe = os.path.join(d, "mt")
+    subprocess.check_call(["gcc", "-O1", "-I" + os.path.join(mga.ROOT, "include"), src, "-o", exe, mga.LIB_PATH, "-lpthread",
+                           "-Wl,-rpath," + os.path.dirname(mga.LIB_PATH)])
+    ref_out = os.path.join(d, "ref.gaf")
+    run_ref(["-c", "-x", "lr", "-t", "4", graph, reads], ref_out)
+    want = open(ref_out, "rb").read()
+    for nt in (1, 6):
+        got = subprocess.run([exe, graph, reads, str(nt)], stdout=subprocess.PIPE, check=True, timeout=600).stdout
+        assert got == want, nt
+
+
+DROPIN = os.path.join(os.path.dirname(rb.REF_BIN), "minigraph_dropin")
+DROPIN_UNPATCHED = os.path.join(os.path.dirname(rb.REF_BIN), "minigraph_dropin_unpatched")
+
+
+def run_bin(exe, args, out):
+    with open(out, "wb") as fo:
+        subprocess.check_call([exe] + args, stdout=fo, stderr=subprocess.DEVNULL, timeout=900)
+
+
+def test_link_level_dropin_reference_front_end_on_this_library():
+    """INTEGRATION.md 1a/1b as an executable fact: the reference's own main.c / gmap.c / ggen.c / asm-call.c / ggsimple.c ... compiled from
+    the reference sources and LINKED AGAINST libminigraph_amd.so in place of its mapping-path objects (oracle/Makefile, target dropin).
+    patched = the kt_for(worker_for) lines replaced by mg_map_batch(); unpatched = mg_map() per read from kt_for workers, one mg_tbuf_t each."""
+    assert os.path.exists(DROPIN) and os.path.exists(DROPIN_UNPATCHED), "oracle/_ref/minigraph_dropin missing: make -C oracle dropin (needs /root/reference)"
+    need_ref()
+    d = tempfile.mkdtemp()
+    mt, orang, chimp = (os.path.join(GOLD, f) for f in ("MT.gfa", "MT-orangA.fa", "MT-chimp.fa"))
+    # (1) the reference's known answer through its own CLI and its own kt_pipeline, mapping on the GPU
+    for exe, th in ((DROPIN, "4"), (DROPIN_UNPATCHED, "4"), (DROPIN_UNPATCHED, "1")):
+        out = os.path.join(d, "mt.gaf")
+        run_bin(exe, ["-cx", "lr", "-t", th, mt, orang], out)
+        assert hashlib.md5(open(out, "rb").read()).hexdigest() == "22bf23ebe2039e8353f56f4a324a2eaa", (exe, th)
+    # (2) synthetic bubble graph, 300 reads, both binaries against the reference binary
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "2000000", "-H", "3", "-n", "300", "-s", "8"], stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    ref_out = os.path.join(d, "ref.gaf")
+    run_ref(["-cx", "lr", "-t", "4", graph, reads], ref_out)
+    for exe in (DROPIN, DROPIN_UNPATCHED):
+        out = os.path.join(d, "syn.gaf")
+        run_bin(exe, ["-cx", "lr", "-t", "6", graph, reads], out)
+        if open(out, "rb").read() != open(ref_out, "rb").read():
+            raise AssertionError(exe + ": " + first_diff(ref_out, out))
+
+
+@pytest.mark.parametrize("args", [["-cxasm", "--call"], ["-cxggs"], ["-cxasm", "--cov"]])
+def test_dropin_call_and_graph_generation_consume_our_chains(args):
+    """SURVEY 8 f2: `--call` (ggen.c:128-139 -> mg_call_asm, asm-call.c:21), incremental graph generation (`-x ggs`, ggsimple.c) and `--cov`
+    are the reference's own code consuming the mg_gchains_t objects THIS library returns from mg_map_batch() (chains, lc[], anchors a[],
+    CIGARs): their outputs must equal the all-reference binary's byte for byte -- parity of the in-memory results, not just of GAF text"""
+    assert os.path.exists(DROPIN), "oracle/_ref/minigraph_dropin missing: make -C oracle dropin"
+    need_ref()
+    d = tempfile.mkdtemp()
+    mt = os.path.join(GOLD, "MT.gfa")
+    for q in ("MT-orangA.fa", "MT-chimp.fa"):
+        want, got = os.path.join(d, "want.out"), os.path.join(d, "got.out")
+        run_bin(rb.REF_BIN, args + ["-t", "4", mt, os.path.join(GOLD, q)], want)
+        run_bin(DROPIN, args + ["-t", "4", mt, os.path.join(GOLD, q)], got)
+        a, b = open(want, "rb").read(), open(got, "rb").read()
+        assert len(a) > 100 and a == b, (args, q, len(a), len(b))
