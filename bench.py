@@ -19,6 +19,7 @@ order inside the timed region.  Extra keys: `resident` (the same rea
 Rank 0 prints ONE JSON line (metric / roofline / cpu_baseline); everything else goes to stderr.
 """
 import argparse
+import ctypes
 import json
 import os
 import re
@@ -162,13 +163,13 @@ def main():
     last = {}
 
     def step():
-        if dist is None:
-            last["gaf"] = mga.map_files_idx(G, [reads_path], n_threads=threads)
+        if dist is None:   # (the output buffer of the previous step is handed back for reuse, like a writer thread would recycle its buffers)
+            last["gaf"] = mga.map_files_idx(G, [reads_path], n_threads=threads, reuse=last.get("gaf"))
         elif args.no_gather:
-            last["gaf"] = mga.map_files_idx(G, [reads_path], n_threads=threads, rank=rank, world=world)
+            last["gaf"] = mga.map_files_idx(G, [reads_path], n_threads=threads, rank=rank, world=world, reuse=last.get("gaf"))
         else:  # one input -> N GPUs -> one GAF on rank 0: size table all_gather + one RCCL gather of the bytes
             def mapper(r, w):
-                m = mga.map_files_idx(G, [reads_path], n_threads=threads, rank=r, world=w)
+                m = mga.map_files_idx(G, [reads_path], n_threads=threads, rank=r, world=w, reuse=last.get("shard"))
                 last["shard"] = m
                 return m.view(), m.seg_len
             last["gaf_bytes"] = map_sharded(mapper, dst=0, device="cuda")
@@ -226,6 +227,8 @@ def main():
                             note="one GPU, reads already in HBM (mga_reads_load), GAF text into the library's buffer: no FASTA parse, no upload")
             # ---- isolated pass: ONE chunk in flight (MGA_PIPE=1), per-kernel HIP-event times on the launch stream do not overlap ----
             os.environ["MGA_PIPE"] = "1"
+            L.mga_idx_stream_close.argtypes = [ctypes.c_void_p]
+            L.mga_idx_stream_close(G.gi)        # the index's chunk pipeline is rebuilt with one pipeline thread for this pass
             mga.get_stats(G, reset=True)
             mga.prof_enable(True)
             mga.prof_get(reset=True)
@@ -235,6 +238,7 @@ def main():
             dti = time.perf_counter() - t0
             m.free()
             del os.environ["MGA_PIPE"]
+            L.mga_idx_stream_close(G.gi)
             prof, sti = mga.prof_get(), mga.get_stats(G)
             mga.prof_enable(False)
             isolated = dict(ms=dti * 1e3, prof=prof, st=sti)

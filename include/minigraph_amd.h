@@ -275,7 +275,8 @@ int mga_map_files_idx(const mg_idx_t *gi, int n_fn, const char **fn, const mg_ma
  * parsed by every rank and each mini-batch is a segment, cut by read index.  seg_len[0..n_seg) (malloc'ed) are this rank's bytes of each
  * segment: concatenating, segment by segment, the ranks' parts in rank order gives the single-process output. */
 int mga_map_files_shard(const mg_idx_t *gi, int n_fn, const char **fn, const mg_mapopt_t *opt, int n_threads, int shard_rank, int shard_world,
-						FILE *fp, char **mem, int64_t *mem_len, int64_t **seg_len, int *n_seg, double *t_map);
+						FILE *fp, char **mem, int64_t *mem_len, int64_t *mem_cap /* in: capacity of a buffer passed in *mem for reuse; out: capacity of *mem */,
+						int64_t **seg_len, int *n_seg, double *t_map);
 int mga_reads_parse_x(const char *fn, int64_t batch_bases, int n_threads, int64_t *n_reads, int64_t *n_bases, uint64_t *hash);
 /* the reads of shard rank/world, exactly as mga_map_files_shard() cuts them, as one-line FASTA in out_path; seg_n[0..n_seg) (malloc'ed) =
  * records per output segment.  No device needed. */

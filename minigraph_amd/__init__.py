@@ -97,7 +97,7 @@ def load():
     L.mga_map_files_to_path.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(idxopt_t),
                                         C.POINTER(mapopt_t), C.c_int, C.c_char_p]
     L.mga_map_files_shard.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(mapopt_t), C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                      pp, C.POINTER(C.c_int64), pp, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+                                      pp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), pp, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.mga_reads_shard_dump.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_char_p, pp, C.POINTER(C.c_int)]
     L.mga_reads_load.argtypes = [C.c_char_p, C.c_int64]
     L.mga_reads_load.restype = C.c_void_p
@@ -261,8 +261,8 @@ def map_files(graph_path, read_paths, out_path, preset="lr", cigar=True, n_threa
 class MappedGaf:
     """GAF text of one mga_map_files_shard() call: a malloc'ed buffer owned by this object (zero-copy numpy view, bytes on request)"""
 
-    def __init__(self, ptr, n, seg_len, t_map):
-        self.ptr, self.n, self.seg_len, self.t_map = ptr, n, seg_len, t_map
+    def __init__(self, ptr, n, seg_len, t_map, cap=0):
+        self.ptr, self.n, self.seg_len, self.t_map, self.cap = ptr, n, seg_len, t_map, cap
 
     def __len__(self):
         return self.n
@@ -285,17 +285,21 @@ class MappedGaf:
             pass
 
 
-def map_files_idx(graph, read_paths, n_threads=8, rank=0, world=1):
+def map_files_idx(graph, read_paths, n_threads=8, rank=0, world=1, reuse=None):
     """the mapping phase of mg_map_files() against an existing index: FASTA/FASTQ files -> GAF text in memory (MappedGaf).
     world > 1: this process maps shard `rank` (see mga_map_files_shard in include/minigraph_amd.h); .seg_len lists its bytes per
-    output segment, .t_map is the wall time of the phase (reader + pipeline + sink) measured inside the library."""
+    output segment, .t_map is the wall time of the phase (reader + pipeline + sink) measured inside the library.
+    reuse: a MappedGaf of an earlier call whose buffer may be overwritten (it is consumed)."""
     L = load()
     fns = (C.c_char_p * len(read_paths))(*[p.encode() for p in read_paths])
-    mem, n, seg, nseg, t = C.c_void_p(), C.c_int64(0), C.c_void_p(), C.c_int(0), C.c_double(0.0)
+    mem, n, cap, seg, nseg, t = C.c_void_p(), C.c_int64(0), C.c_int64(0), C.c_void_p(), C.c_int(0), C.c_double(0.0)
+    if reuse is not None and reuse.ptr is not None and reuse.ptr.value and reuse.cap > 0:
+        mem, cap = reuse.ptr, C.c_int64(reuse.cap)
+        reuse.ptr, reuse.n = None, 0
     _check(L.mga_map_files_shard(graph.gi, len(read_paths), fns, C.byref(graph.mo), n_threads, rank, world, None,
-                                 C.byref(mem), C.byref(n), C.byref(seg), C.byref(nseg), C.byref(t)), "mga_map_files_shard")
+                                 C.byref(mem), C.byref(n), C.byref(cap), C.byref(seg), C.byref(nseg), C.byref(t)), "mga_map_files_shard")
     seg_len = _take(seg, nseg.value, np.int64)
-    return MappedGaf(mem, n.value, seg_len, t.value)
+    return MappedGaf(mem, n.value, seg_len, t.value, cap.value)
 
 
 def reads_shard_dump(path, out_path, rank, world, batch_bases=500000000, n_threads=4):

@@ -217,6 +217,7 @@ void mg_idx_destroy(mg_idx_t *gi)
 	int32_t i;
 	if (gi == 0) return;
 	if (gi->B) {
+		mga_idx_mf_free(gi);
 		mga_idx_stream_close(gi); /* pipeline threads, HIP streams and buffers of the single-batch entry points */
 		mga_dfree(gi->B->dev.d_tab); mga_dfree(gi->B->dev.d_pos); mga_dfree(gi->B->dev.d_seg_len); mga_dfree(gi->B->dev.d_gseq); mga_dfree(gi->B->dev.d_gseq_off);
 		free(gi->B->occ_hist); free(gi->B->gaf_out);

@@ -41,6 +41,7 @@ struct lc_rescue_t {
 	float pen_gap, pen_skip;
 	int32_t rescue_size;
 	float rescue_ratio;
+	int32_t frag_len, frag_min_gap; // -F: per-read reference gap max(max_frag_len - qlen, max_gap) (map-algo.c:383-386); 0 = off
 };
 
 __device__ __forceinline__ float lc_log2(float x) // mgpriv.h:63-71
@@ -400,6 +401,10 @@ __global__ void __launch_bounds__(64) k_lchain(int n_reads, const mg128_t *__res
 	W.z = ws_z + off;                                                     // 1 mg128 per anchor
 	uint64_t *u = u_all + off;
 	mg128_t *b = b_all + off;
+	if (R.frag_len > 0 && q_off) { // map-algo.c:383-386: max_chain_gap_ref depends on the read's length when -F is given
+		const int32_t g = R.frag_len - (int32_t)(q_off[r + 1] - q_off[r]);
+		P.max_dist_x = g > R.frag_min_gap ? g : R.frag_min_gap;
+	}
 	if (P.max_dist_x < P.bw) P.max_dist_x = P.bw;
 	if (P.max_dist_y < P.bw) P.max_dist_y = P.bw;
 
@@ -457,6 +462,7 @@ extern "C" int mga_dev_lchain(mga_sctx_t *sc, int n, const mg128_t *d_a, const i
 		R.min_cnt = resc->min_cnt, R.min_sc = resc->min_sc, R.pen_gap = resc->chn_pen_gap, R.pen_skip = resc->chn_pen_skip;
 		R.rescue_size = resc->rescue_size, R.rescue_ratio = resc->rescue_ratio;
 	}
+	if (resc && d_q_off) R.frag_len = resc->frag_len, R.frag_min_gap = resc->frag_min_gap;
 	mga_prof_begin(sc->stream, MGA_K_LCHAIN);
 	hipLaunchKernelGGL(k_lchain, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, R, d_q_off, d_u, d_b, d_nu, d_nb, d_flag, ws_i32, ws_z, ws_keep);
 	mga_prof_end(sc->stream, MGA_K_LCHAIN);

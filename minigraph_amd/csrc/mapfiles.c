@@ -373,7 +373,7 @@ static int fa_fast_batch(fa_fast_t *F, int64_t batch_bases, fbatch_t *b, int wan
 	return (int)n;
 }
 
-typedef struct { int n_fn; const char **fn; int64_t batch_bases; chan_t *out, *free_b; int n_threads, want_pinned; int rank, world; volatile int err; } reader_t;
+typedef struct { int n_fn; const char **fn; int64_t batch_bases, first_bases; chan_t *out, *free_b; int n_threads, want_pinned; int rank, world; volatile int err; } reader_t;
 
 /* sharded jobs, sequential reader: every rank parses the whole input and keeps the contiguous slice [n*rank/world, n*(rank+1)/world) of
  * each mini-batch */
@@ -411,7 +411,7 @@ static int seq_batch(rd_t *r, int *last, str_t *name, int64_t batch_bases, fbatc
 static void *reader_main(void *a)
 {
 	reader_t *R = (reader_t*)a;
-	int f, seg = 0;
+	int f, seg = 0, n_out = 0;
 	fbatch_t *b = 0;
 	const int world = R->world > 1 ? R->world : 1, rank = R->world > 1 ? R->rank : 0;
 	for (f = 0; f < R->n_fn && !R->err; ++f) {
@@ -451,7 +451,7 @@ static void *reader_main(void *a)
 			int n;
 			if (b == 0) b = (fbatch_t*)chan_get(R->free_b);
 			if (use_fast && !seq_mode) {
-				n = fa_fast_batch(&F, R->batch_bases, b, R->want_pinned);
+				n = fa_fast_batch(&F, n_out == 0 && R->first_bases > 0 ? R->first_bases : R->batch_bases, b, R->want_pinned);
 				if (n < 0) { R->err = 1; break; }
 				if (n == 0) { /* the fast part is exhausted: either the file is, or the sequential reader takes over at F.pos */
 					if (!F.fallback || F.pos >= F.size) { eof = 1; break; }
@@ -461,7 +461,7 @@ static void *reader_main(void *a)
 				}
 				if (F.pos >= F.size && F.head >= F.n_pend) eof = 1;
 			} else {
-				n = seq_batch(&r, &last, &name, R->batch_bases, b, &eof);
+				n = seq_batch(&r, &last, &name, n_out == 0 && R->first_bases > 0 && world == 1 ? R->first_bases : R->batch_bases, b, &eof);
 				if (n > 0 && world > 1 && !use_fast) fbatch_keep_slice(b, rank, world);
 			}
 			if (n == 0) break;
@@ -470,7 +470,7 @@ static void *reader_main(void *a)
 			b->last = eof && f == R->n_fn - 1;
 			fbatch_finish(b);
 			chan_put(R->out, b);
-			b = 0;
+			b = 0, ++n_out;
 		}
 		free(name.s);
 		if (use_fast) { free(F.pend); munmap((void*)F.map, (size_t)map_size); ++seg; /* memory-mapped input: the file is one segment */ }
@@ -516,7 +516,7 @@ static int reads_parse_shard(const char *fn, int64_t batch_bases, int n_threads,
 	*n_reads = *n_bases = 0, *hash = 0;
 	chan_init(&c_in, 1); chan_init(&c_free, 2);
 	for (i = 0; i < 2; ++i) { fb[i] = MGA_CALLOC(fbatch_t, 1); chan_put(&c_free, fb[i]); }
-	R.n_fn = 1, R.fn = &fn, R.batch_bases = batch_bases > 0 ? batch_bases : 500000000, R.out = &c_in, R.free_b = &c_free, R.err = 0, R.n_threads = n_threads > 0 ? n_threads : 1, R.want_pinned = 0, R.rank = rank, R.world = world;
+	R.n_fn = 1, R.fn = &fn, R.batch_bases = batch_bases > 0 ? batch_bases : 500000000, R.out = &c_in, R.free_b = &c_free, R.err = 0, R.n_threads = n_threads > 0 ? n_threads : 1, R.want_pinned = 0, R.rank = rank, R.world = world, R.first_bases = 0;
 	pthread_create(&t_rd, 0, reader_main, &R);
 	while ((b = (fbatch_t*)chan_get(&c_in)) != 0) {
 		while (b->seg >= nsn) { MGA_GROW(int64_t, sn, nsn, msn); sn[nsn++] = 0; }
@@ -542,7 +542,7 @@ static int reads_parse_shard(const char *fn, int64_t batch_bases, int n_threads,
 int mga_reads_parse(const char *fn, int64_t *n_reads, int64_t *n_bases, uint64_t *hash) { return mga_reads_parse_x(fn, 0, 4, n_reads, n_bases, hash); }
 
 /* where the GAF text goes: a stream, or one buffer in memory (bench.py's "file -> GAF buffer" interval) */
-typedef struct { FILE *fp; char *mem; int64_t mem_len, mem_cap; int64_t *seg_len; int n_seg, m_seg; } sink_t;
+typedef struct { FILE *fp; int to_mem; char *mem; int64_t mem_len, mem_cap; int64_t *seg_len; int n_seg, m_seg; } sink_t;
 typedef struct { char *buf; int64_t len, cap; fbatch_t *fb; int seg; } wbuf_t;
 typedef struct { sink_t *sink; chan_t *in; pthread_mutex_t *pool_m; wbuf_t **pool; int *n_pool; volatile int err; } writer_t;
 
@@ -556,9 +556,8 @@ static void *writer_main(void *a)
 		s->seg_len[w->seg] += w->len;
 		if (!W->err && w->len > 0) {
 			if (s->fp) { if (fwrite(w->buf, 1, (size_t)w->len, s->fp) != (size_t)w->len) { fprintf(stderr, "[E::%s] failed to write the results\n", __func__); W->err = 1; } }
-			else if (s->mem == 0) { s->mem = w->buf, s->mem_len = w->len, s->mem_cap = w->cap; w->buf = 0, w->cap = 0; } /* the first batch's buffer becomes the result */
 			else {
-				if (s->mem_len + w->len + 1 > s->mem_cap) { s->mem_cap = (s->mem_len + w->len + 1) * 2; s->mem = (char*)realloc(s->mem, (size_t)s->mem_cap); }
+				if (s->mem_len + w->len + 1 > s->mem_cap) { s->mem_cap = (s->mem_len + w->len + 1) * 3 / 2; s->mem = (char*)realloc(s->mem, (size_t)s->mem_cap); }
 				memcpy(s->mem + s->mem_len, w->buf, (size_t)w->len); s->mem_len += w->len;
 			}
 		}
@@ -587,12 +586,26 @@ static void *collector_main(void *a)
 }
 
 #define MF_NB 5 /* read batches in rotation: one being parsed, one parsed, up to three in the pipeline */
+typedef struct { fbatch_t *fb[MF_NB]; wbuf_t wb[MF_NB + 2]; } mf_cache_t;
 
-/* map the files against an existing index; GAF to fp, or (fp == NULL) into one malloc'ed buffer *mem (release with mga_free()).
+void mga_idx_mf_free(mg_idx_t *gi)
+{
+	mf_cache_t *c;
+	int k;
+	if (gi == 0 || gi->B == 0 || (c = (mf_cache_t*)gi->B->mf_cache) == 0) return;
+	for (k = 0; k < MF_NB; ++k) fbatch_free(c->fb[k]);
+	for (k = 0; k < MF_NB + 2; ++k) free(c->wb[k].buf);
+	free(c);
+	gi->B->mf_cache = 0;
+}
+
+/* map the files against an existing index; GAF to fp, or (fp == NULL) into one buffer in memory: *mem / *mem_cap on entry = a buffer to
+ * reuse (or NULL), on return the GAF text (*mem_len bytes, NUL-terminated; release with mga_free()).
  * *t_map (optional): seconds from the first byte read to the last byte handed to the sink -- the interval between the reference's
- * mg_opt_update and its last worker_pipeline log line (gmap.c:186-211). */
+ * mg_opt_update and its last worker_pipeline log line (gmap.c:186-211).  The job runs on the index's own chunk pipeline and keeps its
+ * read batches and output buffers with the index, so a second job on the same index allocates nothing. */
 int mga_map_files_shard(const mg_idx_t *gi, int n_fn, const char **fn, const mg_mapopt_t *opt, int n_threads, int shard_rank, int shard_world,
-						FILE *fp, char **mem, int64_t *mem_len, int64_t **seg_len, int *n_seg, double *t_map)
+						FILE *fp, char **mem, int64_t *mem_len, int64_t *mem_cap, int64_t **seg_len, int *n_seg, double *t_map)
 {
 	int ret = 0, k, n_sub = 0, n_pool = 0;
 	chan_t c_in, c_free, c_sub, c_out;
@@ -600,26 +613,42 @@ int mga_map_files_shard(const mg_idx_t *gi, int n_fn, const char **fn, const mg_
 	writer_t W;
 	collector_t C;
 	sink_t sink;
-	wbuf_t wb[MF_NB + 2], *pool[MF_NB + 2];
-	fbatch_t *fb[MF_NB], *b;
+	wbuf_t *pool[MF_NB + 2];
+	fbatch_t *b;
+	mf_cache_t *mc;
 	pthread_mutex_t pool_m = PTHREAD_MUTEX_INITIALIZER;
 	pthread_t t_rd, t_wr, t_co;
 	mga_stream_t *S;
 	const double t0 = mga_wtime();
-	if (mem) *mem = 0, *mem_len = 0;
+	memset(&sink, 0, sizeof sink);
+	if (mem) { sink.mem = *mem, sink.mem_cap = *mem && mem_cap ? *mem_cap : 0; if (sink.mem_cap == 0) sink.mem = 0; *mem = 0, *mem_len = 0; sink.to_mem = 1; }
 	if (opt->flag & (MG_M_FRAG_MODE | MG_M_CAL_COV)) { /* gmap.c:44-48,119-126,199-214: multi-segment fragments and --cov are not on the accelerated path */
 		if (mg_verbose >= 1) fprintf(stderr, "[E::%s] --frag and --cov are outside the MI355X long-read path (single-segment reads, GAF output)\n", __func__);
+		free(sink.mem);
 		return -1;
 	}
 	if (n_threads < 1) n_threads = 1;
-	if ((S = mga_stream_open(gi, opt, n_threads)) == 0) return -1;
+	if ((S = mga_idx_stream_acquire(gi, opt, n_threads)) == 0) { free(sink.mem); return -1; }
+	if (gi->B->mf_cache == 0) { /* (under the stream's job lock) */
+		mc = MGA_CALLOC(mf_cache_t, 1);
+		for (k = 0; k < MF_NB; ++k) mc->fb[k] = MGA_CALLOC(fbatch_t, 1);
+		gi->B->mf_cache = mc;
+	}
+	mc = (mf_cache_t*)gi->B->mf_cache;
+	if (sink.to_mem && sink.mem == 0) { /* one allocation of about the size of the input for the whole output (a base-aligned read prints ~0.9 bytes per base) */
+		struct stat st;
+		int64_t tot = 0;
+		for (k = 0; k < n_fn; ++k) if (fn[k] && stat(fn[k], &st) == 0 && S_ISREG(st.st_mode)) tot += st.st_size;
+		sink.mem_cap = (shard_world > 1 ? tot / shard_world : tot) + (tot >> 4) + (1 << 20);
+		sink.mem = (char*)malloc((size_t)sink.mem_cap);
+	}
 	chan_init(&c_in, 1); chan_init(&c_free, MF_NB); chan_init(&c_sub, MF_NB + 2); chan_init(&c_out, 2);
-	memset(wb, 0, sizeof wb); memset(&sink, 0, sizeof sink);
 	sink.fp = fp;
-	for (k = 0; k < MF_NB; ++k) { fb[k] = MGA_CALLOC(fbatch_t, 1); chan_put(&c_free, fb[k]); }
-	for (k = 0; k < MF_NB + 2; ++k) pool[n_pool++] = &wb[k];
+	for (k = 0; k < MF_NB; ++k) chan_put(&c_free, mc->fb[k]);
+	for (k = 0; k < MF_NB + 2; ++k) pool[n_pool++] = &mc->wb[k];
 	R.n_fn = n_fn, R.fn = fn, R.batch_bases = opt->mini_batch_size, R.out = &c_in, R.free_b = &c_free, R.err = 0;
 	R.n_threads = n_threads < 8 ? n_threads : 8, R.want_pinned = 1, R.rank = shard_rank, R.world = shard_world;
+	R.first_bases = 64000000 < opt->mini_batch_size ? 64000000 : opt->mini_batch_size; /* a short first batch: the GPU starts while the reader is still on the second one */
 	W.sink = &sink, W.in = &c_out, W.pool_m = &pool_m, W.pool = pool, W.n_pool = &n_pool, W.err = 0;
 	C.S = S, C.sub = &c_sub, C.out = &c_out, C.free_b = &c_free, C.err = 0, C.errmsg[0] = 0;
 	pthread_create(&t_rd, 0, reader_main, &R);
@@ -628,7 +657,7 @@ int mga_map_files_shard(const mg_idx_t *gi, int n_fn, const char **fn, const mg_
 	while ((b = (fbatch_t*)chan_get(&c_in)) != 0) {
 		wbuf_t *w = 0;
 		if (C.err || W.err) { chan_put(&c_free, b); continue; } /* keep draining the reader */
-		for (;;) { /* an output buffer: at most MF_NB + 2 circulate, the submit below blocks long before they run out */
+		for (;;) { /* an output buffer: MF_NB + 2 circulate, the submit below blocks long before they run out */
 			pthread_mutex_lock(&pool_m); if (n_pool > 0) w = pool[--n_pool]; pthread_mutex_unlock(&pool_m);
 			if (w) break;
 			usleep(200);
@@ -643,10 +672,8 @@ int mga_map_files_shard(const mg_idx_t *gi, int n_fn, const char **fn, const mg_
 	pthread_join(t_rd, 0); pthread_join(t_co, 0); pthread_join(t_wr, 0);
 	if (C.err) { mga_set_error("%s", C.errmsg); ret = -1; }
 	if (R.err || W.err) ret = -1;
-	mga_stream_close(S);
-	for (k = 0; k < MF_NB + 2; ++k) free(wb[k].buf);
-	for (k = 0; k < MF_NB; ++k) fbatch_free(fb[k]);
-	if (mem && ret == 0) { if (sink.mem == 0) sink.mem = (char*)calloc(1, 1); else sink.mem[sink.mem_len] = 0; *mem = sink.mem, *mem_len = sink.mem_len; }
+	mga_idx_stream_release(S);
+	if (mem && ret == 0) { if (sink.mem == 0) sink.mem = (char*)calloc(1, 1), sink.mem_cap = 1; sink.mem[sink.mem_len] = 0; *mem = sink.mem, *mem_len = sink.mem_len; if (mem_cap) *mem_cap = sink.mem_cap; }
 	else free(sink.mem);
 	if (seg_len && ret == 0) *seg_len = sink.seg_len, *n_seg = sink.n_seg; else free(sink.seg_len);
 	if (t_map) *t_map = mga_wtime() - t0;
@@ -655,7 +682,7 @@ int mga_map_files_shard(const mg_idx_t *gi, int n_fn, const char **fn, const mg_
 
 int mga_map_files_idx(const mg_idx_t *gi, int n_fn, const char **fn, const mg_mapopt_t *opt, int n_threads, FILE *fp, char **mem, int64_t *mem_len, double *t_map)
 {
-	return mga_map_files_shard(gi, n_fn, fn, opt, n_threads, 0, 1, fp, mem, mem_len, 0, 0, t_map);
+	return mga_map_files_shard(gi, n_fn, fn, opt, n_threads, 0, 1, fp, mem, mem_len, 0, 0, 0, t_map);
 }
 
 int mg_map_files_fp(gfa_t *g, int n_fn, const char **fn, const mg_idxopt_t *ipt, const mg_mapopt_t *opt0, int n_threads, FILE *out)

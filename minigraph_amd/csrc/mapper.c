@@ -143,7 +143,7 @@ void mga_batch_lchain_par(const mg_idx_t *gi, const mg_mapopt_t *opt, int qlen_m
 	int gap_ref;
 	(void)qlen_max;
 	if (opt->max_gap_ref > 0) gap_ref = opt->max_gap_ref;
-	else if (opt->max_frag_len > 0) gap_ref = opt->max_gap; /* max_frag_len - qlen < max_gap is clamped per read; long reads never set -F */
+	else if (opt->max_frag_len > 0) gap_ref = opt->max_gap; /* the per-read value max(max_frag_len - qlen, max_gap) is applied inside k_lchain (mga_rescue_par_t::frag_len) */
 	else gap_ref = opt->max_gap;
 	par->max_dist_x = gap_ref, par->max_dist_y = opt->max_gap;
 	par->bw = opt->bw, par->max_skip = opt->max_lc_skip, par->max_iter = opt->max_lc_iter;
@@ -768,6 +768,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 			rs.max_dist = opt->max_gap, rs.max_dist_inner = opt->max_gap_pre, rs.bw = opt->bw_long, rs.max_skip = opt->max_lc_skip, rs.cap = opt->rmq_size_cap;
 			rs.min_cnt = opt->min_lc_cnt, rs.min_sc = opt->min_lc_score, rs.chn_pen_gap = par.chn_pen_gap, rs.chn_pen_skip = par.chn_pen_skip;
 			rs.rescue_size = opt->rmq_rescue_size, rs.rescue_ratio = opt->rmq_rescue_ratio;
+			if (opt->max_gap_ref <= 0 && opt->max_frag_len > 0) rs.frag_len = opt->max_frag_len, rs.frag_min_gap = opt->max_gap; /* -F */
 			CK(mga_dbuf_reserve(&P->rflag, (size_t)n * 4 + 4));
 			CK(mga_dev_lchain(sc, n, (const mg128_t*)P->a.p, (const int64_t*)P->aoff.p, &par, &rs, (const int64_t*)P->qoff.p, (uint64_t*)P->u.p, (mg128_t*)P->b.p,
 							  (int32_t*)P->nu.p, (int32_t*)P->nb.p, (int32_t*)P->rflag.p, P->ws.p, wsb, n_a));
@@ -1066,7 +1067,8 @@ void mga_stream_set_opt(mga_stream_t *S, const mg_mapopt_t *opt, int n_threads) 
  * (fill and drain of the pipeline cost about one chunk time each) */
 static void batch_cut(mga_stream_t *S, sbatch_t *b)
 {
-	const int n = b->n, chunk = S->chunk, ramp = env_int("MGA_RAMP", 1) && n > 6 * chunk;
+	const int n = b->n, chunk = S->chunk;
+	const int ramp = env_int("MGA_RAMP", 1) && (n > 6 * chunk || (b->flags & (MGA_SB_FIRST | MGA_SB_LAST)) != (MGA_SB_FIRST | MGA_SB_LAST)); /* a batch of a longer job always ramps */
 	int pos = 0, m = 0, cap = n / (chunk / 4 > 0 ? chunk / 4 : 1) + 8;
 	b->cstart = MGA_MALLOC(int, cap + 1);
 	while (pos < n) {
@@ -1189,6 +1191,19 @@ static mga_stream_t *idx_stream(const mg_idx_t *gi, const mg_mapopt_t *opt, int 
 	pthread_mutex_unlock(&g_idx_stream_mtx);
 	return (mga_stream_t*)B->stream;
 }
+/* the index's stream for a whole job (mg_map_files): locked until released, so that its pipeline contexts -- device buffers, pinned staging,
+ * HIP streams: hundreds of MB that are expensive to allocate -- are reused from job to job instead of being rebuilt */
+mga_stream_t *mga_idx_stream_acquire(const mg_idx_t *gi, const mg_mapopt_t *opt, int n_threads)
+{
+	mga_stream_t *S = idx_stream(gi, opt, n_threads);
+	if (S == 0) return 0;
+	pthread_mutex_lock(&S->api);
+	mga_stream_set_opt(S, opt, n_threads);
+	S->n_submitted = 0; /* a new job: its first batch restarts the debug clocks */
+	return S;
+}
+void mga_idx_stream_release(mga_stream_t *S) { pthread_mutex_unlock(&S->api); }
+
 void mga_idx_stream_close(mg_idx_t *gi) { if (gi && gi->B && gi->B->stream) { mga_stream_close((mga_stream_t*)gi->B->stream); gi->B->stream = 0; } }
 
 /* one batch through the index's stream, start to finish.  Calls are serialized per index (the pipeline contexts are

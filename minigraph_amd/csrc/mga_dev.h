@@ -131,6 +131,7 @@ typedef struct {
 	float chn_pen_gap, chn_pen_skip;
 	int32_t rescue_size;
 	float rescue_ratio;
+	int32_t frag_len, frag_min_gap; /* -F (max_frag_len > 0, no max_gap_ref): the DP's reference gap is max(frag_len - qlen, frag_min_gap) per read (map-algo.c:383-386) */
 } mga_rescue_par_t;
 /* resc/d_q_off/d_flag may be NULL (no rescue).  d_flag[i]: 0 first-pass chains, 1 rescued on the device, 2 rescue due but left to the host */
 int mga_dev_lchain(mga_sctx_t *sc, int n, const mg128_t *d_a, const int64_t *d_a_off, const mga_lchain_par_t *par, const mga_rescue_par_t *resc,

@@ -65,6 +65,7 @@ struct mg_idx_bucket_s {
 	char *gaf_out;           /* GAF text of the last mga_map_reads() pass; grow-only, owned by the index */
 	int64_t gaf_cap;
 	void *stream;            /* mga_stream_t of the single-batch entry points (mapper.c), created on first use */
+	void *mf_cache;          /* read batches (pinned) and output buffers of mg_map_files jobs on this index (mapfiles.c), reused from job to job */
 };
 
 /* ---- the chunk pipeline as a persistent object (mapper.c) ---- */
@@ -77,6 +78,9 @@ int mga_stream_submit(mga_stream_t *S, int n, const int *qlens, const char **seq
 int mga_stream_collect(mga_stream_t *S, char **out, int64_t *out_len, int64_t *out_cap, void **user);
 void mga_stream_close(mga_stream_t *S);
 void mga_idx_stream_close(mg_idx_t *gi);
+mga_stream_t *mga_idx_stream_acquire(const mg_idx_t *gi, const mg_mapopt_t *opt, int n_threads);
+void mga_idx_stream_release(mga_stream_t *S);
+void mga_idx_mf_free(mg_idx_t *gi);
 
 typedef struct { const char *cg, *ds; int32_t cg_len, ds_len, mlen, blen; } mga_chain_text_t; /* cg == NULL: format from the chain itself */
 void mga_write_gaf_append(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, int32_t n_seg, const int32_t *qlens, const char *qname, uint64_t flag,

@@ -416,6 +416,7 @@ OPTION_SETS = [
      None, dict(chn_pen_gap=0.5, max_lc_skip=10, max_lc_iter=1000, gdp_max_ed=2000, max_gc_skip=10, max_gap_pre=500, ref_bonus=5), 0),
     ("rmq_primary", ["--rmq=yes"], None, None, 0x8000),
     ("write_mz", ["--write-mz"], None, None, 0x1000000 | 0x800000),
+    ("frag_len", ["-F", "40000"], None, dict(max_frag_len=40000), 0),     # per-read reference gap max(F - qlen, max_gap) in the DP (map-algo.c:383-386)
 ]
 
 
@@ -612,10 +613,15 @@ def test_dropin_call_and_graph_generation_consume_our_chains(args):
     assert os.path.exists(DROPIN), "oracle/_ref/minigraph_dropin missing: make -C oracle dropin"
     need_ref()
     d = tempfile.mkdtemp()
-    mt = os.path.join(GOLD, "MT.gfa")
-    for q in ("MT-orangA.fa", "MT-chimp.fa"):
+    # the reference's own fixtures, then a bubble graph with eight 300 kb contigs (0.4 % divergence) that walk through ~100 bubbles
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "1500000", "-H", "3", "-n", "8", "-l", "300000", "-e", "0.004", "-s", "19"], stderr=subprocess.DEVNULL)
+    jobs = [(os.path.join(GOLD, "MT.gfa"), os.path.join(GOLD, q)) for q in ("MT-orangA.fa", "MT-chimp.fa")] + [(os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa"))]
+    total = 0
+    for graph, q in jobs:
         want, got = os.path.join(d, "want.out"), os.path.join(d, "got.out")
-        run_bin(rb.REF_BIN, args + ["-t", "4", mt, os.path.join(GOLD, q)], want)
-        run_bin(DROPIN, args + ["-t", "4", mt, os.path.join(GOLD, q)], got)
+        run_bin(rb.REF_BIN, args + ["-t", "4", graph, q], want)
+        run_bin(DROPIN, args + ["-t", "4", graph, q], got)
         a, b = open(want, "rb").read(), open(got, "rb").read()
-        assert len(a) > 100 and a == b, (args, q, len(a), len(b))
+        assert a == b, (args, q, len(a), len(b))
+        total += len(a)
+    assert total > 1000, total
