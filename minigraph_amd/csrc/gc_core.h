@@ -1,0 +1,1651 @@
+/*
+ * gc_core.h -- graph chaining of ONE read, from the linear chains of k_lchain to the filtered graph chains, as ONE
+ * allocation-free routine that runs on a GPU lane and on a host thread from the same source:
+ *
+ *   chain records (lchain.c:374-408) -> end / seed clean-up (map-algo.c:194-330,424-445) -> anchor rewrite (lchain.c:410-441)
+ *   -> DP over the chains with graph reachability (gchain1.c:62-240 + shortk.c:41-242)
+ *   -> walk assembly with GWFA / shortest-walk bridging (gchain1.c:242-520 + gfa-ed.c:44-617)
+ *   -> ordering, primary / secondary assignment, filtering (gcmisc.c:6-188)
+ *
+ * Design (this file is NOT a transcription of those files; it restates what they compute):
+ *   * every container lives in a bump ARENA owned by the executing lane (HBM scratch on the device, malloc'ed blocks on the
+ *     host): vectors grow by re-allocation at the arena top, a whole call is released by resetting one offset, and running out
+ *     of arena is a status the caller handles by re-running the read in a larger arena -- no malloc / free / kalloc anywhere;
+ *   * the stages talk through index-based records (gc_chain_t, gc_frag_t, gc_cand_t, gc_walk_t ...) instead of pointers into
+ *     each other's arrays, so that the same bytes are valid on both sides of PCIe;
+ *   * everything that decides a tie in the reference is reproduced exactly: the klib radix-sort permutation (gc_ksort), the
+ *     15-slot max-heap sifts of the walk lists, the settle order of the shortest-walk search, the append / merge / dedup order
+ *     of the GWFA wavefronts;
+ *   * arithmetic is integer or single IEEE operations in float / double (compiled with -ffp-contract=off); the two libm calls
+ *     of the post-processing (log in div, logf in MAPQ) stay on the host, which gets their integer inputs.
+ *
+ * On the device the routine is executed by lane 0 of a wavefront per read (k_gchain.hip); the host instantiation serves
+ * -x asm (where the chainer is host code anyway), the last capacity tier, and the CPU parity tests.
+ */
+#ifndef MGA_GC_CORE_H
+#define MGA_GC_CORE_H
+
+#include <stdint.h>
+#include <string.h>
+#include <stdlib.h>
+#include "../../include/minigraph_amd.h"
+
+#if defined(__HIPCC__)
+#define GC_HD __host__ __device__ inline
+#else
+#define GC_HD static inline
+#endif
+
+#define GC_OK        0
+#define GC_E_ARENA   1   /* ran out of arena: re-run in a larger one */
+#define GC_E_BUG     2   /* the "logical bug" exit of the shortest-walk search (shortk.c:182-186): the read gets no chains, as in the reference */
+
+/* ------------------------------------------------------------------------------------------------ arena */
+
+typedef struct gc_block_s { struct gc_block_s *prev; int64_t cap; } gc_block_t;
+typedef struct {
+	char *base;          /* current block */
+	int64_t top, cap;
+	int32_t ovf;         /* set once an allocation failed (device: fixed capacity) */
+	int32_t growable;    /* host: chain further malloc'ed blocks instead of failing */
+	gc_block_t *blocks;  /* host: extra blocks, newest first */
+	int64_t peak;
+} gc_arena_t;
+
+GC_HD void gc_arena_init(gc_arena_t *A, void *mem, int64_t cap, int growable) { A->base = (char*)mem, A->top = 0, A->cap = cap, A->ovf = 0, A->growable = growable, A->blocks = 0, A->peak = 0; }
+
+GC_HD void *gc_alloc(gc_arena_t *A, int64_t bytes)
+{
+	const int64_t need = (bytes + 15) & ~(int64_t)15;
+	if (A->top + need > A->cap) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+		if (A->growable) { /* host: a new block, at least twice the request; the old block stays alive until gc_arena_free() */
+			int64_t cap = A->cap * 2 > need * 2 ? A->cap * 2 : need * 2;
+			gc_block_t *b = (gc_block_t*)malloc((size_t)cap + sizeof(gc_block_t));
+			if (b) {
+				b->prev = A->blocks, b->cap = cap, A->blocks = b;
+				A->base = (char*)(b + 1), A->top = 0, A->cap = cap;
+			} else { A->ovf = 1; return 0; }
+		} else
+#endif
+		{ A->ovf = 1; return 0; }
+	}
+	void *p = A->base + A->top;
+	A->top += need;
+	if (A->top > A->peak) A->peak = A->top;
+	return p;
+}
+static inline void gc_arena_free_blocks(gc_arena_t *A) { while (A->blocks) { gc_block_t *b = A->blocks; A->blocks = b->prev; free(b); } } /* host */
+
+/* overlapping move in 4-byte units (every record moved here is a multiple of 4 bytes) */
+GC_HD void gc_move(void *dst, const void *src, int64_t bytes)
+{
+	uint32_t *d = (uint32_t*)dst;
+	const uint32_t *s = (const uint32_t*)src;
+	const int64_t n = bytes >> 2;
+	if (d == s || n <= 0) return;
+	if (d < s) for (int64_t i = 0; i < n; ++i) d[i] = s[i];
+	else for (int64_t i = n - 1; i >= 0; --i) d[i] = s[i];
+}
+
+/* growable array in the arena: {a, n, m}; growth re-allocates at the top (in place when the array is the last allocation) */
+#define GC_VEC(T) struct { T *a; int32_t n, m; }
+#define gc_vec_zero(v) ((v).a = 0, (v).n = (v).m = 0)
+GC_HD int gc_vec_grow_(gc_arena_t *A, void **pa, int32_t *pm, int32_t n_used, int32_t need, int32_t esz)
+{
+	if (need <= *pm) return GC_OK;
+	int32_t m = *pm < 8 ? 8 : *pm + (*pm >> 1);
+	if (m < need) m = need;
+	char *old = (char*)*pa;
+	if (old && old + (((int64_t)*pm * esz + 15) & ~(int64_t)15) == A->base + A->top && A->top + (((int64_t)m * esz + 15) & ~(int64_t)15) - (((int64_t)*pm * esz + 15) & ~(int64_t)15) <= A->cap) {
+		A->top += (((int64_t)m * esz + 15) & ~(int64_t)15) - (((int64_t)*pm * esz + 15) & ~(int64_t)15); /* last allocation: extend in place */
+		if (A->top > A->peak) A->peak = A->top;
+		*pm = m;
+		return GC_OK;
+	}
+	char *p = (char*)gc_alloc(A, (int64_t)m * esz);
+	if (p == 0) return GC_E_ARENA;
+	if (old && n_used > 0) memcpy(p, old, (size_t)n_used * esz);
+	*pa = p, *pm = m;
+	return GC_OK;
+}
+#define gc_vec_reserve(A, v, need) gc_vec_grow_((A), (void**)&(v).a, &(v).m, (v).n, (need), (int32_t)sizeof(*(v).a))
+#define GC_TRY(expr) do { int rc_ = (expr); if (rc_ != GC_OK) return rc_; } while (0)
+#define GC_PUSH(A, v, ptr) do { GC_TRY(gc_vec_reserve((A), (v), (v).n + 1)); (ptr) = &(v).a[(v).n++]; } while (0)
+#define GC_ALLOC(A, T, ptr, count) do { (ptr) = (T*)gc_alloc((A), (int64_t)(count) * (int64_t)sizeof(T)); if ((ptr) == 0) return GC_E_ARENA; } while (0)
+
+/* ------------------------------------------------------------------------------------------------ small helpers */
+
+GC_HD uint32_t gc_hash32(uint32_t key) /* kh_hash_uint32, khashl.h:321-327 */
+{
+	key += ~(key << 15); key ^= (key >> 10); key += (key << 3);
+	key ^= (key >> 6);   key += ~(key << 11); key ^= (key >> 16);
+	return key;
+}
+
+GC_HD float gc_log2f(float x) /* mg_log2, mgpriv.h:63-71 (x >= 2) */
+{
+	union { float f; uint32_t i; } z;
+	z.f = x;
+	float r = (float)((int32_t)(z.i >> 23 & 255) - 128);
+	z.i &= ~(255U << 23);
+	z.i += 127U << 23;
+	r += (-0.34484843f * z.f + 2.02466578f) * z.f - 0.67487759f;
+	return r;
+}
+
+/* anchor field accessors (minigraph.h:41, mgpriv.h:18-27) */
+#define GC_AX(p) ((int32_t)(p).x)                       /* target end position */
+#define GC_AY(p) ((int32_t)(p).y)                       /* query end position */
+#define GC_ASPAN(p) ((int32_t)((p).y >> 32 & 0xff))
+#define GC_ASEG(p) ((int32_t)(((p).y & MG_SEED_SEG_MASK) >> MG_SEED_SEG_SHIFT))
+
+/* ---- exact permutation of klib's in-place MSD byte radix sort (ksort.h:112-162) on {key, val} records.  The sort is unstable
+ * for n > 64 and results depend on where ties land, so the algorithm's moves are replayed: counting pass, displacement cycles from
+ * the lowest bucket up, buckets of <= 64 records by (stable) insertion sort, larger ones recursively on the next byte.  Ranges
+ * wait on an explicit stack in the arena; ranges are disjoint, so their processing order does not change the result. ---- */
+typedef struct { uint64_t key, val; } gc_kv_t;
+
+GC_HD void gc_isort(gc_kv_t *a, int32_t n)
+{
+	for (int32_t i = 1; i < n; ++i) {
+		gc_kv_t t = a[i];
+		int32_t j = i;
+		for (; j > 0 && t.key < a[j - 1].key; --j) a[j] = a[j - 1];
+		a[j] = t;
+	}
+}
+
+GC_HD int gc_ksort(gc_arena_t *A, gc_kv_t *a, int32_t n, int key_bytes)
+{
+	if (n <= 64) { gc_isort(a, n); return GC_OK; }
+	const int64_t mark = A->top;
+	typedef struct { int32_t b, e, sh; } rng_t;
+	GC_VEC(rng_t) stk;
+	gc_vec_zero(stk);
+	int32_t *head, *tail, *cnt;
+	GC_ALLOC(A, int32_t, head, 768);
+	tail = head + 256, cnt = head + 512;
+	rng_t *r0;
+	GC_PUSH(A, stk, r0);
+	r0->b = 0, r0->e = n, r0->sh = (key_bytes - 1) * 8;
+	while (stk.n > 0) {
+		const rng_t r = stk.a[--stk.n];
+		for (int k = 0; k < 256; ++k) cnt[k] = 0;
+		for (int32_t i = r.b; i < r.e; ++i) ++cnt[a[i].key >> r.sh & 0xff];
+		for (int32_t k = 0, pos = r.b; k < 256; ++k) head[k] = pos, pos += cnt[k], tail[k] = pos;
+		for (int k = 0; k < 256; ++k)
+			while (head[k] != tail[k]) {
+				gc_kv_t carry = a[head[k]];
+				int l = (int)(carry.key >> r.sh & 0xff);
+				if (l == k) { ++head[k]; continue; }
+				do {
+					gc_kv_t t = a[head[l]];
+					a[head[l]++] = carry;
+					carry = t;
+					l = (int)(carry.key >> r.sh & 0xff);
+				} while (l != k);
+				a[head[k]++] = carry;
+			}
+		if (r.sh > 0) {
+			const int nsh = r.sh > 8 ? r.sh - 8 : 0;
+			for (int k = 0; k < 256; ++k) {
+				const int32_t st = tail[k] - cnt[k];
+				if (cnt[k] > 64) { rng_t *q; GC_PUSH(A, stk, q); q->b = st, q->e = tail[k], q->sh = nsh; }
+				else if (cnt[k] > 1) gc_isort(a + st, cnt[k]);
+			}
+		}
+	}
+	A->top = mark;
+	return GC_OK;
+}
+
+/* plain ascending sort of 64-bit values whose order among equals cannot matter (whole value is the key) */
+GC_HD void gc_sort_u64(uint64_t *a, int32_t n)
+{
+	for (int32_t i = n / 2 - 1; i >= 0; --i) { /* heap sort: O(n log n) without scratch */
+		int32_t k = i; uint64_t t = a[k];
+		for (;;) { int32_t c = 2 * k + 1; if (c >= n) break; if (c + 1 < n && a[c + 1] > a[c]) ++c; if (a[c] <= t) break; a[k] = a[c], k = c; }
+		a[k] = t;
+	}
+	for (int32_t m = n - 1; m > 0; --m) {
+		uint64_t t = a[m]; a[m] = a[0];
+		int32_t k = 0;
+		for (;;) { int32_t c = 2 * k + 1; if (c >= m) break; if (c + 1 < m && a[c + 1] > a[c]) ++c; if (a[c] <= t) break; a[k] = a[c], k = c; }
+		a[k] = t;
+	}
+}
+
+/* ------------------------------------------------------------------------------------------------ graph view */
+
+typedef struct { uint64_t v_lv; uint32_t w; int32_t rank; int32_t ov, ow; uint64_t link_bits; } gc_arc_t; /* byte layout of gfa_arc_t (gfa.h:33-39) */
+
+typedef struct {
+	const gc_arc_t *arc;
+	const uint64_t *idx;          /* per vertex: first arc << 32 | number of arcs (gfa.h:99-101) */
+	const int32_t *seg_len;
+	/* oriented vertex sequences: either one pointer per vertex (host: gfa_edseq_t[]) or two flat copies (device) */
+	const gfa_edseq_t *es;
+	const char *seq_fw, *seq_rc;
+	const int64_t *seq_off;
+} gc_graph_t;
+
+GC_HD const char *gc_vseq(const gc_graph_t *G, uint32_t v) { return G->es ? G->es[v].seq : ((v & 1) ? G->seq_rc : G->seq_fw) + G->seq_off[v >> 1]; }
+GC_HD int32_t gc_vlen(const gc_graph_t *G, uint32_t v) { return G->seg_len[v >> 1]; }
+GC_HD int32_t gc_n_arc(const gc_graph_t *G, uint32_t v) { return (int32_t)(uint32_t)G->idx[v]; }
+GC_HD const gc_arc_t *gc_arcs(const gc_graph_t *G, uint32_t v) { return G->arc + (G->idx[v] >> 32); }
+
+/* ------------------------------------------------------------------------------------------------ parameters, records */
+
+typedef struct {
+	int32_t k;                                  /* minimizer length of the index */
+	int32_t bw, bw_long, max_gap;               /* mg_mapopt_t */
+	int32_t min_lc_cnt, lc_max_occ, lc_max_trim;
+	int32_t max_gc_skip, ref_bonus, min_gc_cnt, min_gc_score, gdp_max_ed;
+	int32_t best_n, sub_diff;
+	float chn_pen_gap;                          /* already scaled by exp(-div * k) (map-algo.c:388-390) */
+	float mask_level, pri_ratio;
+} gc_par_t;
+
+typedef struct { /* one linear chain (what mg_lchain_t carries, mgpriv/minigraph.h:100-106) */
+	int32_t off, cnt;          /* anchors */
+	uint32_t v;
+	int32_t rs, re, qs, qe, score;
+	int32_t dist_pre; uint32_t hash_pre; int32_t inner_pre;   /* link to the predecessor chosen by the DP */
+} gc_chain_t;
+
+typedef struct { /* one graph chain, integer fields only; div and mapq are derived on the host (libm) */
+	int32_t off, cnt, n_anchor, score;
+	int32_t qs, qe, plen, ps, pe, blen, mlen;
+	int32_t n_mini, q_span;    /* inputs of div (gchain1.c:299) */
+	int32_t id, parent, subsc, n_sub, flt;
+	uint32_t hash;
+} gc_rec_t;
+
+typedef struct {
+	int32_t n_gc, n_lc, n_a;
+	gc_rec_t *gc;              /* arena */
+	mg_llchain_t *lc;          /* arena */
+	mg128_t *a;                /* caller's buffer (capacity: the read's chained anchors) */
+	int32_t n_gwfa, n_shortk;  /* counters */
+} gc_result_t;
+
+/* ------------------------------------------------------------------------------------------------ chain records + clean-up */
+
+/* chain records in the order of the reference: by query start, then score, through the klib sort on qs<<32|score (lchain.c:374-408) */
+GC_HD int gc_make_chains(gc_arena_t *A, int32_t n_u, const uint64_t *u, const mg128_t *a, gc_chain_t **out)
+{
+	gc_chain_t *c;
+	gc_kv_t *z;
+	*out = 0;
+	if (n_u <= 0) return GC_OK;
+	GC_ALLOC(A, gc_chain_t, c, n_u);
+	const int64_t mark = A->top;
+	GC_ALLOC(A, gc_kv_t, z, n_u);
+	for (int32_t i = 0, k = 0; i < n_u; ++i) {
+		const int32_t qs = GC_AY(a[k]) + 1 - GC_ASPAN(a[k]);
+		z[i].key = (uint64_t)qs << 32 | u[i] >> 32;
+		z[i].val = (uint64_t)k << 32 | (uint32_t)u[i];
+		k += (int32_t)u[i];
+	}
+	GC_TRY(gc_ksort(A, z, n_u, 8));
+	for (int32_t i = 0; i < n_u; ++i) {
+		gc_chain_t *r = &c[i];
+		const int32_t k = (int32_t)(z[i].val >> 32), span = GC_ASPAN(a[k]);
+		r->off = k, r->cnt = (int32_t)(uint32_t)z[i].val, r->score = (int32_t)(uint32_t)z[i].key;
+		r->v = (uint32_t)(a[k].x >> 32);
+		r->rs = GC_AX(a[k]) + 1 > span ? GC_AX(a[k]) + 1 - span : 0;
+		r->qs = (int32_t)(z[i].key >> 32);
+		r->re = GC_AX(a[k + r->cnt - 1]) + 1, r->qe = GC_AY(a[k + r->cnt - 1]) + 1;
+		r->dist_pre = -1, r->hash_pre = 0, r->inner_pre = 0;
+	}
+	A->top = mark;
+	*out = c;
+	return GC_OK;
+}
+
+/* The clean-up of a chain works on a window [s, s+n) of its anchors.  Four passes (map-algo.c:194-330):
+ *   1. ends made of high-occurrence seeds are trimmed (at most max_trim per side);
+ *   2. ends that sit behind a gap larger than half of what has been matched so far are trimmed;
+ *   3. seeds between an insertion-like and a deletion-like long gap that nearly cancel are flagged IGNORE;
+ *   4. seeds in runs of long gaps that follow each other closely are flagged IGNORE, the last one FIXED. */
+GC_HD int32_t gc_gap_at(const mg128_t *a, int32_t i) { return (GC_AY(a[i]) - GC_AY(a[i - 1])) - (GC_AX(a[i]) - GC_AX(a[i - 1])); }
+
+GC_HD void gc_trim_repetitive_ends(const mg128_t *a, int32_t max_occ, int32_t max_trim, int32_t *s, int32_t *n)
+{
+	int32_t cut = 0;
+	while (cut < max_trim && cut < *n && (int32_t)(a[*s + *n - 1 - cut].y >> MG_SEED_OCC_SHIFT) > max_occ) ++cut;
+	*n -= cut;
+	cut = 0;
+	while (cut < *n && cut < max_trim && (int32_t)(a[*s + cut].y >> MG_SEED_OCC_SHIFT) > max_occ) ++cut;
+	*s += cut, *n -= cut;
+}
+
+/* one direction of pass 2: walk inwards from an end, remember the innermost anchor that follows a disproportionate gap */
+GC_HD void gc_trim_gapped_ends(const mg128_t *a, int32_t score, int32_t bw, int32_t min_match, int32_t *s, int32_t *n)
+{
+	const int32_t s0 = *s, e0 = *s + *n; /* [s0, e0) */
+	if (*n < 3) return;
+	int32_t len = GC_ASPAN(a[s0]), mat = len;
+	for (int32_t i = s0 + 1; i < e0 - 1; ++i) {
+		const int32_t dr = GC_AX(a[i]) - GC_AX(a[i - 1]), dq = GC_AY(a[i]) - GC_AY(a[i - 1]);
+		const int32_t lo = dr < dq ? dr : dq, hi = dr > dq ? dr : dq, span = GC_ASPAN(a[i]);
+		if (hi - lo > len >> 1) *s = i;
+		len += lo, mat += lo < span ? lo : span;
+		if (len >= bw << 1 || (mat >= min_match && mat >= bw) || mat >= score >> 1) break;
+	}
+	*n = e0 - *s;
+	len = mat = GC_ASPAN(a[e0 - 1]);
+	for (int32_t i = e0 - 2; i > *s; --i) {
+		const int32_t dr = GC_AX(a[i + 1]) - GC_AX(a[i]), dq = GC_AY(a[i + 1]) - GC_AY(a[i]);
+		const int32_t lo = dr < dq ? dr : dq, hi = dr > dq ? dr : dq, span = GC_ASPAN(a[i + 1]);
+		if (hi - lo > len >> 1) *n = i + 1 - *s;
+		len += lo, mat += lo < span ? lo : span;
+		if (len >= bw << 1 || (mat >= min_match && mat >= bw) || mat >= score >> 1) break;
+	}
+}
+
+/* positions (relative to s) of the gaps longer than min_gap; returns the count, 0 when there are fewer than two */
+GC_HD int gc_long_gaps(gc_arena_t *A, const mg128_t *a, int32_t s, int32_t n, int32_t min_gap, int32_t **pos, int32_t *n_pos)
+{
+	int32_t m = 0, *K;
+	*pos = 0, *n_pos = 0;
+	for (int32_t i = 1; i < n; ++i) { const int32_t g = gc_gap_at(a, s + i); m += (g < -min_gap || g > min_gap); }
+	if (m <= 1) return GC_OK;
+	GC_ALLOC(A, int32_t, K, m);
+	m = 0;
+	for (int32_t i = 1; i < n; ++i) { const int32_t g = gc_gap_at(a, s + i); if (g < -min_gap || g > min_gap) K[m++] = i; }
+	*pos = K, *n_pos = m;
+	return GC_OK;
+}
+
+GC_HD int gc_flag_cancelling_gaps(gc_arena_t *A, mg128_t *a, int32_t s, int32_t n, int32_t min_gap, int32_t diff_thres, int32_t max_ext_len, int32_t max_ext_cnt)
+{
+	const int64_t mark = A->top;
+	int32_t *K, m;
+	GC_TRY(gc_long_gaps(A, a, s, n, min_gap, &K, &m));
+	if (K == 0) return GC_OK;
+	int32_t best = 0, best_st = -1, best_en = -1;
+	for (int32_t k = 0;; ++k) {
+		if (k == m || k >= best_en) { /* the best window found so far ends here: flag what lies inside it */
+			if (best_en > 0) for (int32_t i = K[best_st]; i < K[best_en]; ++i) a[s + i].y |= MG_SEED_IGNORE;
+			best = 0, best_st = best_en = -1;
+			if (k == m) break;
+		}
+		int32_t ins = 0, del = 0, top_diff = 0, top_l = -1;
+		int32_t g = gc_gap_at(a, s + K[k]);
+		if (g > 0) ins += g; else del -= g;
+		const int32_t q0 = GC_AY(a[s + K[k] - 1]), r0 = GC_AX(a[s + K[k] - 1]);
+		for (int32_t l = k + 1; l < m && l <= k + max_ext_cnt; ++l) {
+			const int32_t j = K[l];
+			if (GC_AY(a[s + j]) - q0 > max_ext_len || GC_AX(a[s + j]) - r0 > max_ext_len) break;
+			g = gc_gap_at(a, s + j);
+			if (g > 0) ins += g; else del -= g;
+			const int32_t diff = ins + del - (ins > del ? ins - del : del - ins);
+			if (top_diff < diff) top_diff = diff, top_l = l;
+		}
+		if (top_diff > diff_thres && top_diff > best) best = top_diff, best_st = k, best_en = top_l;
+	}
+	A->top = mark;
+	return GC_OK;
+}
+
+GC_HD int gc_flag_gap_runs(gc_arena_t *A, mg128_t *a, int32_t s, int32_t n, int32_t min_gap, int32_t max_ext)
+{
+	const int64_t mark = A->top;
+	int32_t *K, m;
+	GC_TRY(gc_long_gaps(A, a, s, n, min_gap, &K, &m));
+	if (K == 0) return GC_OK;
+	for (int32_t k = 0; k < m;) {
+		int32_t g1 = gc_gap_at(a, s + K[k]), l;
+		int32_t re = GC_AX(a[s + K[k]]), qe = GC_AY(a[s + K[k]]);
+		if (g1 < 0) g1 = -g1;
+		for (l = k + 1; l < m; ++l) {
+			const int32_t j = K[l];
+			if (GC_AY(a[s + j]) - qe > max_ext || GC_AX(a[s + j]) - re > max_ext) break;
+			int32_t g2 = gc_gap_at(a, s + j);
+			const int32_t span = GC_ASPAN(a[s + j - 1]);
+			const int32_t r2 = GC_AX(a[s + j - 1]) + span, q2 = GC_AY(a[s + j - 1]) + span;
+			const int32_t between = r2 - re < q2 - qe ? r2 - re : q2 - qe;
+			if (g2 < 0) g2 = -g2;
+			if (between > g1 + g2) break;
+			re = GC_AX(a[s + j]), qe = GC_AY(a[s + j]), g1 = g2;
+		}
+		if (l > k + 1) {
+			const int32_t end = K[l - 1];
+			for (int32_t j = K[k]; j < end; ++j) a[s + j].y |= MG_SEED_IGNORE;
+			a[s + end].y |= MG_SEED_FIXED;
+		}
+		k = l;
+	}
+	A->top = mark;
+	return GC_OK;
+}
+
+/* only reads with several chains are cleaned (map-algo.c:424); chains left with fewer than min_lc_cnt anchors are dropped */
+GC_HD int gc_clean_chains(gc_arena_t *A, const gc_par_t *P, mg128_t *a, gc_chain_t *c, int32_t *n_c)
+{
+	int32_t kept = 0;
+	for (int32_t i = 0; i < *n_c; ++i) {
+		gc_chain_t r = c[i];
+		int32_t s = r.off, n = r.cnt;
+		gc_trim_repetitive_ends(a, P->lc_max_occ, P->lc_max_trim, &s, &n);
+		gc_trim_gapped_ends(a, r.score, P->bw, 100, &s, &n);
+		GC_TRY(gc_flag_cancelling_gaps(A, a, s, n, 10, 40, P->max_gap >> 1, 10));
+		GC_TRY(gc_flag_gap_runs(A, a, s, n, 30, P->max_gap >> 1));
+		if (n < P->min_lc_cnt) continue;
+		const int32_t span = GC_ASPAN(a[s]);
+		r.off = s, r.cnt = n;
+		r.rs = GC_AX(a[s]) + 1 - span, r.qs = GC_AY(a[s]) + 1 - span;
+		r.re = GC_AX(a[s + n - 1]) + 1, r.qe = GC_AY(a[s + n - 1]) + 1;
+		c[kept++] = r;
+	}
+	*n_c = kept;
+	return GC_OK;
+}
+
+/* anchor.x high word := rank of the anchor's minimizer among the read's kept minimizers (lchain.c:410-441) */
+GC_HD int gc_index_anchors(mg128_t *a, int32_t n_a, const int32_t *mini_pos, int32_t n_mini)
+{
+	if (n_a <= 0) return GC_OK;
+	int32_t lo = 0, hi = n_mini - 1, st = -1;
+	const int32_t x = GC_AY(a[0]);
+	while (lo <= hi) {
+		const int32_t mid = (int32_t)(((uint32_t)lo + (uint32_t)hi) >> 1), y = mini_pos[mid];
+		if (y < x) lo = mid + 1; else if (y > x) hi = mid - 1; else { st = mid; break; }
+	}
+	if (st < 0) return GC_E_BUG;
+	int32_t k = 0;
+	for (int32_t j = st; j < n_mini && k < n_a; ++j)
+		if (GC_AY(a[k]) == mini_pos[j]) a[k].x = (uint64_t)j << 32 | (a[k].x & 0xffffffffU), ++k;
+	return k == n_a ? GC_OK : GC_E_BUG;
+}
+
+/* ------------------------------------------------------------------------------------------------ shortest walks */
+
+#define GC_SK_EXT 1000 /* MG_SHORT_K_EXT, shortk.c:31 */
+
+typedef struct { /* a destination of the search: in/out (what mg_path_dst_t carries, mgpriv.h:40-52) */
+	uint32_t v;
+	int32_t target_dist;
+	uint32_t target_hash;
+	int32_t meta, check_hash, inner;
+	int32_t n_path, is_0, path_end, dist;
+	uint32_t hash;
+} gc_dst_t;
+
+typedef struct { uint32_t v, d; int32_t pre; } gc_walkv_t;
+
+typedef struct { uint64_t di; uint32_t v; int32_t pre; uint32_t hash; int32_t is_0, hpos; } gc_sknode_t; /* di = dist<<32 | serial (settle rank once settled) */
+typedef struct { int32_t k; int32_t p[MG_MAX_SHORT_K]; } gc_sklist_t;                                   /* walks ending at one vertex, a max-heap on di */
+
+typedef struct {
+	GC_VEC(gc_sknode_t) nd;
+	GC_VEC(int32_t) heap;
+	uint32_t *hk; int32_t *hv; uint32_t hcap, hcnt;   /* vertex -> index into tk, open addressing */
+	GC_VEC(gc_sklist_t) tk;
+} gc_sk_t;
+
+GC_HD void gc_fh_up(gc_sk_t *s, int32_t i)
+{
+	const int32_t x = s->heap.a[i];
+	while (i > 0) {
+		const int32_t par = (i - 1) >> 1;
+		if (s->nd.a[s->heap.a[par]].di <= s->nd.a[x].di) break;
+		s->heap.a[i] = s->heap.a[par], s->nd.a[s->heap.a[i]].hpos = i, i = par;
+	}
+	s->heap.a[i] = x, s->nd.a[x].hpos = i;
+}
+GC_HD void gc_fh_down(gc_sk_t *s, int32_t i)
+{
+	const int32_t x = s->heap.a[i], n = s->heap.n;
+	for (;;) {
+		int32_t c = 2 * i + 1;
+		if (c >= n) break;
+		if (c + 1 < n && s->nd.a[s->heap.a[c + 1]].di < s->nd.a[s->heap.a[c]].di) ++c;
+		if (s->nd.a[s->heap.a[c]].di >= s->nd.a[x].di) break;
+		s->heap.a[i] = s->heap.a[c], s->nd.a[s->heap.a[i]].hpos = i, i = c;
+	}
+	s->heap.a[i] = x, s->nd.a[x].hpos = i;
+}
+GC_HD int gc_fh_push(gc_arena_t *A, gc_sk_t *s, int32_t x)
+{
+	GC_TRY(gc_vec_reserve(A, s->heap, s->heap.n + 1));
+	s->heap.a[s->heap.n] = x;
+	gc_fh_up(s, s->heap.n++);
+	return GC_OK;
+}
+GC_HD void gc_fh_erase(gc_sk_t *s, int32_t pos)
+{
+	const int32_t x = s->heap.a[pos], last = s->heap.a[--s->heap.n];
+	s->nd.a[x].hpos = -1;
+	if (pos == s->heap.n) return;
+	s->heap.a[pos] = last, s->nd.a[last].hpos = pos;
+	gc_fh_up(s, pos);
+	gc_fh_down(s, s->nd.a[last].hpos);
+}
+GC_HD int gc_sk_node(gc_arena_t *A, gc_sk_t *s, uint32_t v, int32_t d, uint32_t id, int32_t *out)
+{
+	gc_sknode_t *p;
+	GC_PUSH(A, s->nd, p);
+	p->v = v, p->di = (uint64_t)d << 32 | id, p->pre = -1, p->is_0 = 1, p->hpos = -1, p->hash = 0;
+	*out = s->nd.n - 1;
+	return GC_OK;
+}
+GC_HD int gc_sk_vertex(gc_arena_t *A, gc_sk_t *s, uint32_t v, int32_t *slot, int *absent) /* slot = index into tk */
+{
+	if (s->hcnt * 2 >= s->hcap) {
+		const uint32_t ocap = s->hcap, ncap = ocap ? ocap * 2 : 64;
+		const uint32_t *ok = s->hk; const int32_t *ov = s->hv;
+		uint32_t *nk; int32_t *nv;
+		GC_ALLOC(A, uint32_t, nk, ncap); GC_ALLOC(A, int32_t, nv, ncap);
+		for (uint32_t j = 0; j < ncap; ++j) nv[j] = -1;
+		for (uint32_t j = 0; j < ocap; ++j)
+			if (ov[j] >= 0) {
+				uint32_t q = gc_hash32(ok[j]) & (ncap - 1);
+				while (nv[q] >= 0) q = (q + 1) & (ncap - 1);
+				nk[q] = ok[j], nv[q] = ov[j];
+			}
+		s->hk = nk, s->hv = nv, s->hcap = ncap;
+	}
+	uint32_t i = gc_hash32(v) & (s->hcap - 1);
+	while (s->hv[i] >= 0 && s->hk[i] != v) i = (i + 1) & (s->hcap - 1);
+	*absent = s->hv[i] < 0;
+	if (*absent) {
+		gc_sklist_t *t;
+		GC_PUSH(A, s->tk, t);
+		t->k = 0;
+		s->hk[i] = v, s->hv[i] = s->tk.n - 1, ++s->hcnt;
+	}
+	*slot = s->hv[i];
+	return GC_OK;
+}
+/* the reference's max-heap sifts (ksort.h:44-66) on node indices compared by di */
+GC_HD void gc_tk_up(const gc_sk_t *s, int32_t n, int32_t *l)
+{
+	int32_t k = n - 1;
+	const int32_t tmp = l[k];
+	while (k) {
+		const int32_t i = (k - 1) >> 1;
+		if (s->nd.a[tmp].di < s->nd.a[l[i]].di) break;
+		l[k] = l[i], k = i;
+	}
+	l[k] = tmp;
+}
+GC_HD void gc_tk_down(const gc_sk_t *s, int32_t i, int32_t n, int32_t *l)
+{
+	int32_t k = i;
+	const int32_t tmp = l[i];
+	while ((k = (k << 1) + 1) < n) {
+		if (k != n - 1 && s->nd.a[l[k]].di < s->nd.a[l[k + 1]].di) ++k;
+		if (s->nd.a[l[k]].di < s->nd.a[tmp].di) break;
+		l[i] = l[k], i = k;
+	}
+	l[i] = tmp;
+}
+GC_HD int32_t gc_grp_find(int32_t n, const uint64_t *grp, uint32_t v, int32_t *cnt) /* destinations grouped by vertex (sorted v<<32|index) */
+{
+	int32_t lo = 0, hi = n, e;
+	while (lo < hi) { const int32_t m = (lo + hi) >> 1; if ((uint32_t)(grp[m] >> 32) < v) lo = m + 1; else hi = m; }
+	if (lo == n || (uint32_t)(grp[lo] >> 32) != v) return -1;
+	for (e = lo; e < n && (uint32_t)(grp[e] >> 32) == v; ++e) {}
+	*cnt = e - lo;
+	return lo;
+}
+
+/* Up to max_k shortest walks from src to every destination vertex within max_dist (shortk.c:41-242): a Dijkstra search in which a
+ * vertex may be settled max_k times.  The frontier key dist<<32|serial is unique, so the settle order is a function of the arc
+ * order alone.  walk != NULL: also return the settled walks needed to backtrack to the destinations (gc_walkv_t[], *n_walk). */
+GC_HD int gc_shortest_k(gc_arena_t *A, const gc_graph_t *G, uint32_t src, int32_t n_dst, gc_dst_t *dst, int32_t max_dist, int32_t max_k,
+						gc_walkv_t **walk, int32_t *n_walk)
+{
+	if (walk) *walk = 0, *n_walk = 0;
+	if (n_dst <= 0) return GC_OK;
+	for (int32_t i = 0; i < n_dst; ++i) {
+		gc_dst_t *t = &dst[i];
+		if (t->inner) t->dist = 0, t->n_path = 1, t->path_end = -1;
+		else t->dist = -1, t->n_path = 0, t->path_end = -1;
+	}
+	if (max_k > MG_MAX_SHORT_K) max_k = MG_MAX_SHORT_K;
+	gc_sk_t S;
+	memset(&S, 0, sizeof S);
+	int8_t *dst_done;
+	uint64_t *grp;
+	GC_VEC(int32_t) out;
+	gc_vec_zero(out);
+	GC_ALLOC(A, int8_t, dst_done, n_dst);
+	GC_ALLOC(A, uint64_t, grp, n_dst);
+	for (int32_t i = 0; i < n_dst; ++i) dst_done[i] = 0, grp[i] = (uint64_t)dst[i].v << 32 | (uint32_t)i;
+	gc_sort_u64(grp, n_dst);
+	uint32_t id = 0;
+	int32_t x, slot, n_done = 0;
+	int absent;
+	GC_TRY(gc_sk_node(A, &S, src, 0, id++, &x));
+	S.nd.a[x].hash = gc_hash32(src);
+	GC_TRY(gc_fh_push(A, &S, x));
+	GC_TRY(gc_sk_vertex(A, &S, src, &slot, &absent));
+	S.tk.a[slot].k = 1, S.tk.a[slot].p[0] = x;
+
+	while (S.heap.n > 0) {
+		const int32_t r = S.heap.a[0];
+		int32_t cnt;
+		gc_fh_erase(&S, 0); /* the closest unsettled walk */
+		GC_TRY(gc_vec_reserve(A, out, out.n + 1));
+		S.nd.a[r].di = S.nd.a[r].di >> 32 << 32 | (uint32_t)out.n;
+		out.a[out.n++] = r;
+		const uint32_t rv = S.nd.a[r].v, rhash = S.nd.a[r].hash;
+		const int32_t rdist = (int32_t)(S.nd.a[r].di >> 32), ris0 = S.nd.a[r].is_0;
+
+		const int32_t off = gc_grp_find(n_dst, grp, rv, &cnt);
+		if (off >= 0) { /* a destination vertex was reached (shortk.c:116-153) */
+			for (int32_t j = 0; j < cnt; ++j) {
+				gc_dst_t *t = &dst[(int32_t)(uint32_t)grp[off + j]];
+				int done = 0;
+				if (t->inner) done = 1;
+				else {
+					int copy = 0;
+					const int exact = rdist == t->target_dist && t->check_hash && rhash == t->target_hash;
+					if (t->n_path == 0) copy = 1;
+					else if (t->target_dist >= 0) {
+						if (exact) copy = 1, done = 1;
+						else {
+							const int32_t d0 = t->dist > t->target_dist ? t->dist - t->target_dist : t->target_dist - t->dist;
+							const int32_t d1 = rdist > t->target_dist ? rdist - t->target_dist : t->target_dist - rdist;
+							if (d1 < d0) copy = 1;
+						}
+					}
+					if (copy) {
+						t->path_end = out.n - 1, t->dist = rdist, t->hash = rhash, t->is_0 = ris0;
+						if (t->target_dist >= 0) {
+							if (exact) done = 1;
+							else if (rdist > t->target_dist + GC_SK_EXT) done = 1;
+						}
+					}
+					if (++t->n_path >= max_k) done = 1;
+				}
+				if (dst_done[off + j] == 0 && done) dst_done[off + j] = 1, ++n_done;
+			}
+			if (n_done == n_dst) break;
+		}
+
+		const int32_t nv = gc_n_arc(G, rv);
+		const gc_arc_t *av = gc_arcs(G, rv);
+		for (int32_t i = 0; i < nv; ++i) { /* relax every arc, in arc order (shortk.c:157-188) */
+			const uint32_t w = av[i].w;
+			const int32_t d = rdist + (int32_t)(uint32_t)av[i].v_lv;
+			if (d > max_dist) continue;
+			GC_TRY(gc_sk_vertex(A, &S, w, &slot, &absent));
+			gc_sklist_t *q = &S.tk.a[slot];
+			if (q->k < max_k) {
+				GC_TRY(gc_sk_node(A, &S, w, d, id++, &x));
+				gc_sknode_t *nx = &S.nd.a[x];
+				nx->pre = out.n - 1, nx->hash = rhash + gc_hash32(w), nx->is_0 = av[i].rank > 0 ? 0 : ris0;
+				GC_TRY(gc_fh_push(A, &S, x));
+				q->p[q->k++] = x;
+				gc_tk_up(&S, q->k, q->p);
+			} else if ((int32_t)(S.nd.a[q->p[0]].di >> 32) > d) { /* shorter than the longest kept walk to w: that one is replaced */
+				x = q->p[0];
+				if (S.nd.a[x].hpos < 0) return GC_E_BUG; /* shortk.c:182-186 */
+				gc_fh_erase(&S, S.nd.a[x].hpos);
+				gc_sknode_t *nx = &S.nd.a[x];
+				nx->di = (uint64_t)d << 32 | (id++);
+				nx->pre = out.n - 1, nx->hash = rhash + gc_hash32(w), nx->is_0 = av[i].rank > 0 ? 0 : ris0;
+				GC_TRY(gc_fh_push(A, &S, x));
+				gc_tk_down(&S, 0, q->k, q->p);
+			}
+		}
+	}
+
+	if (walk) { /* the settled walks that lead to a found destination, re-numbered (shortk.c:202-236) */
+		int32_t n_found = 0;
+		for (int32_t i = 0; i < n_dst; ++i) n_found += dst[i].n_path > 0;
+		if (n_found > 0) {
+			int32_t *trans, n = 0, cnt;
+			GC_ALLOC(A, int32_t, trans, out.n > 0 ? out.n : 1);
+			for (int32_t i = 0; i < out.n; ++i) trans[i] = 0;
+			for (int32_t i = 0; i < n_dst; ++i) {
+				const gc_dst_t *t = &dst[i];
+				if (t->n_path > 0 && t->target_dist >= 0 && t->path_end >= 0) trans[(int32_t)(uint32_t)S.nd.a[out.a[t->path_end]].di] = 1;
+			}
+			for (int32_t i = 0; i < out.n; ++i) {
+				const int32_t off = gc_grp_find(n_dst, grp, S.nd.a[out.a[i]].v, &cnt);
+				if (off >= 0)
+					for (int32_t j = off; j < off + cnt; ++j)
+						if (dst[j].target_dist < 0) trans[i] = 1; /* NB: dst[] indexed by group position, as the reference does (shortk.c:215-217) */
+			}
+			for (int32_t i = out.n - 1; i >= 0; --i)
+				if (trans[i] && S.nd.a[out.a[i]].pre >= 0) trans[S.nd.a[out.a[i]].pre] = 1;
+			for (int32_t i = 0; i < out.n; ++i) trans[i] = trans[i] ? n++ : -1;
+			gc_walkv_t *ret;
+			GC_ALLOC(A, gc_walkv_t, ret, n > 0 ? n : 1);
+			for (int32_t i = 0; i < out.n; ++i) {
+				if (trans[i] < 0) continue;
+				const gc_sknode_t *p = &S.nd.a[out.a[i]];
+				ret[trans[i]].v = p->v, ret[trans[i]].d = (uint32_t)(p->di >> 32), ret[trans[i]].pre = p->pre < 0 ? p->pre : trans[p->pre];
+			}
+			for (int32_t i = 0; i < n_dst; ++i) if (dst[i].path_end >= 0) dst[i].path_end = trans[dst[i].path_end];
+			*walk = ret, *n_walk = n;
+		}
+	}
+	return GC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ DP over the chains */
+
+typedef struct { uint32_t srt; int32_t i; } gc_frag_t; /* srt = isolated<<31 | query end; i = chain index */
+
+/* where the scan for predecessors of fragment n starts (find_max, gchain1.c:16-30): the last of f[0..n) when all query ends are below x,
+ * none (-1) when none is, otherwise the FIRST fragment whose query end is >= x -- one past the last one below x, which the scan then
+ * rejects or accepts on its own tests; the choice is the reference's and decides which candidates are seen */
+GC_HD int32_t gc_scan_start(int32_t n, const gc_frag_t *f, uint32_t x)
+{
+	if (n == 0) return -1;
+	if (f[n - 1].srt < x) return n - 1;
+	if (f[0].srt >= x) return -1;
+	int32_t lo = 0, hi = n;
+	while (lo < hi) { const int32_t m = lo + ((hi - lo) >> 1); if (f[m].srt >= x) hi = m; else lo = m + 1; }
+	return lo;
+}
+
+/* score of appending chain i behind destination dj (gchain1.c:39-60) */
+GC_HD int32_t gc_link_score(const gc_dst_t *dj, const gc_chain_t *ci, const gc_chain_t *c, const mg128_t *an, const gc_frag_t *fr, const int32_t *f,
+							int32_t bw, int32_t ref_bonus, float pen_gap, int32_t *ok)
+{
+	*ok = 0;
+	if (dj->n_path == 0) return 0;
+	const gc_chain_t *cj = &c[fr[dj->meta].i];
+	int32_t gap = dj->dist - dj->target_dist, sc;
+	if (gap < 0) gap = -gap;
+	if (GC_ASEG(an[ci->off]) == GC_ASEG(an[cj->off + cj->cnt - 1]) && gap > bw) return 0;
+	if (cj->qe <= ci->qs) sc = ci->score;
+	else sc = (int32_t)((double)(ci->qe - cj->qe) / (ci->qe - ci->qs) * ci->score + .499); /* the part of chain i beyond the query overlap */
+	if (dj->is_0) sc += ref_bonus;
+	{
+		const float lin = pen_gap * (float)gap, lg = gap >= 2 ? gc_log2f((float)gap) : 0.0f;
+		sc -= (int32_t)(lin + lg);
+	}
+	sc += f[dj->meta];
+	*ok = 1;
+	return sc;
+}
+
+/* backtrack of a chaining DP (lchain.c:9-77) as gchain1.c:216 uses it (min_cnt = min_sc = 0, no drop limit): chain ends are taken in
+ * descending f through the klib order; from an end the predecessors are followed up to a fragment already used, and the chain is CUT
+ * where the score gained since that point is largest (first such point).  u[] gets score<<32|count, v[] the fragments, end first. */
+GC_HD int gc_backtrack_all(gc_arena_t *A, int32_t n, const int32_t *f, const int64_t *p, int32_t *t, uint64_t *u, int32_t *v, int32_t *n_u_, int32_t *n_v_)
+{
+	const int64_t mark = A->top;
+	gc_kv_t *z;
+	int32_t n_z = 0, n_u = 0, n_v = 0;
+	*n_u_ = *n_v_ = 0;
+	for (int32_t i = 0; i < n; ++i) n_z += f[i] >= 0;
+	if (n_z == 0) return GC_OK;
+	GC_ALLOC(A, gc_kv_t, z, n_z);
+	for (int32_t i = 0, k = 0; i < n; ++i) if (f[i] >= 0) z[k].key = (uint64_t)(int64_t)f[i], z[k++].val = (uint64_t)i;
+	GC_TRY(gc_ksort(A, z, n_z, 8));
+	for (int32_t i = 0; i < n; ++i) t[i] = 0;
+	for (int32_t k = n_z - 1; k >= 0; --k) {
+		const int32_t e = (int32_t)z[k].val, end_sc = (int32_t)z[k].key, n_v0 = n_v;
+		if (t[e] != 0) continue;
+		int64_t i = e, cut = e;
+		int32_t best = 0;
+		do { /* where to cut: the predecessor position with the largest partial score */
+			i = p[i];
+			const int32_t sc = i < 0 ? end_sc : end_sc - f[i];
+			if (sc > best) best = sc, cut = i;
+		} while (i >= 0 && t[i] == 0);
+		for (i = e; i != cut; i = p[i]) v[n_v++] = (int32_t)i, t[i] = 1;
+		const int32_t sc = i < 0 ? end_sc : end_sc - f[i];
+		if (sc >= 0 && n_v > n_v0) u[n_u++] = (uint64_t)sc << 32 | (uint32_t)(n_v - n_v0);
+		else n_v = n_v0;
+	}
+	A->top = mark;
+	*n_u_ = n_u, *n_v_ = n_v;
+	return GC_OK;
+}
+
+/* DP over the linear chains of a read in the order of their query ends; a chain may follow another one on the same segment
+ * (colinear, within the band) or on a different one when the graph offers a walk of a fitting length (gchain1.c:62-240).
+ * c[] is re-ordered chain by chain (each graph chain's members in query order); u[] gets score<<32|count per graph chain. */
+GC_HD int gc_chain_dp(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, int32_t qlen, const mg128_t *an, gc_chain_t *c, int32_t *n_c_, uint64_t **u_, int32_t *n_u_, int32_t *n_shortk)
+{
+	const int32_t n_c = *n_c_, max_dist_g = P->bw_long, max_dist_q = P->bw_long, bw = P->bw_long;
+	*u_ = 0, *n_u_ = 0;
+	if (n_c == 0) return GC_OK;
+	uint64_t *u;
+	GC_ALLOC(A, uint64_t, u, n_c);
+	gc_frag_t *fr;
+	gc_kv_t *z;
+	int32_t n_ext = 0;
+	GC_ALLOC(A, gc_frag_t, fr, n_c);
+	/* a chain far from both ends of its segment (or short relative to that distance) cannot be linked through the graph */
+	for (int32_t i = 0; i < n_c; ++i) {
+		gc_chain_t *r = &c[i];
+		int32_t to_end = gc_vlen(G, r->v) - r->re;
+		r->dist_pre = -1;
+		if (r->rs < to_end) to_end = r->rs;
+		const int isolated = to_end > max_dist_g || (to_end >> 3) > r->score;
+		fr[i].srt = (uint32_t)isolated << 31 | (uint32_t)r->qe, fr[i].i = i;
+		n_ext += !isolated;
+	}
+	if (n_ext < 2) { /* nothing to link: every chain is a graph chain of its own */
+		for (int32_t i = 0; i < n_c; ++i) u[i] = (uint64_t)c[i].score << 32 | 1;
+		*u_ = u, *n_u_ = n_c;
+		return GC_OK;
+	}
+	{ /* radix_sort_gc: klib sort on the 4-byte key (gchain1.c:13-14,100) */
+		const int64_t mark = A->top;
+		GC_ALLOC(A, gc_kv_t, z, n_c);
+		for (int32_t i = 0; i < n_c; ++i) z[i].key = fr[i].srt, z[i].val = (uint64_t)fr[i].i;
+		GC_TRY(gc_ksort(A, z, n_c, 4));
+		for (int32_t i = 0; i < n_c; ++i) fr[i].srt = (uint32_t)z[i].key, fr[i].i = (int32_t)z[i].val;
+		A->top = mark;
+	}
+	int32_t *f, *v, *t;
+	int64_t *p;
+	GC_ALLOC(A, int32_t, v, n_c); GC_ALLOC(A, int32_t, f, n_ext); GC_ALLOC(A, int64_t, p, n_ext); GC_ALLOC(A, int32_t, t, n_ext);
+	for (int32_t i = 0; i < n_ext; ++i) t[i] = 0;
+	GC_VEC(gc_dst_t) cand;
+	gc_vec_zero(cand);
+	for (int32_t i = 0; i < n_ext; ++i) {
+		gc_chain_t *ci = &c[fr[i].i];
+		const int32_t segi = GC_ASEG(an[ci->off]);
+		cand.n = 0;
+		{ /* candidate predecessors, nearest query end first (gchain1.c:113-175) */
+			int32_t x = ci->qs + bw, n_skip = 0;
+			if (x > qlen) x = qlen;
+			for (int32_t j = gc_scan_start(i, fr, (uint32_t)x); j >= 0; --j) {
+				const gc_chain_t *cj = &c[fr[j].i];
+				int32_t target;
+				if (cj->qs >= ci->qs) continue; /* contained on the query */
+				if (cj->qe > ci->qs) { /* query overlap */
+					const int32_t o = cj->qe - ci->qs;
+					if ((float)o > (float)(cj->qe - cj->qs) * P->mask_level || (float)o > (float)(ci->qe - ci->qs) * P->mask_level) continue;
+				}
+				const int32_t dq = ci->qs - cj->qe, segj = GC_ASEG(an[cj->off + cj->cnt - 1]);
+				if (segi == segj) { if (dq > max_dist_q) break; }
+				else if (dq > max_dist_g && dq > max_dist_q) break;
+				if (ci->v != cj->v) { /* different segments: the graph gap is at least what is left of both segments */
+					const int32_t min_dist = ci->rs + (gc_vlen(G, cj->v) - cj->re);
+					if (min_dist > max_dist_g) continue;
+					if (segi == segj && min_dist - bw > ci->qs - cj->qe) continue;
+					target = (ci->qs - cj->qe) - (gc_vlen(G, cj->v) - cj->re) + (gc_vlen(G, ci->v) - ci->rs); /* mg_target_dist, gchain1.c:32-37 */
+					if (target < 0) continue;
+				} else {
+					if (cj->rs >= ci->rs || cj->re >= ci->re) continue; /* not colinear */
+					const int32_t dr = ci->rs - cj->re, w = dr > dq ? dr - dq : dq - dr;
+					if (segi == segj && w > bw) continue;
+					if (dr > max_dist_g || dr < -max_dist_g) continue;
+					if (cj->re > ci->rs) {
+						const int32_t o = cj->re - ci->rs;
+						if ((float)o > (float)(cj->re - cj->rs) * P->mask_level || (float)o > (float)(ci->re - ci->rs) * P->mask_level) continue;
+					}
+					target = (ci->qs - cj->qe) - (gc_vlen(G, cj->v) - cj->re) + (gc_vlen(G, ci->v) - ci->rs);
+				}
+				gc_dst_t *q;
+				GC_PUSH(A, cand, q);
+				memset(q, 0, sizeof *q);
+				q->inner = ci->v == cj->v, q->v = cj->v ^ 1, q->meta = j, q->target_dist = target;
+				if (t[j] == i && ++n_skip > P->max_gc_skip) break;
+				if (p[j] >= 0) t[p[j]] = i;
+			}
+		}
+		{ /* reachability + distance through the graph, no sequences involved */
+			const int64_t mark = A->top;
+			const int rc = gc_shortest_k(A, G, ci->v ^ 1, cand.n, cand.a, max_dist_g + (gc_vlen(G, ci->v) - ci->rs), MG_MAX_SHORT_K, 0, 0);
+			if (rc == GC_E_ARENA) return rc; /* (GC_E_BUG: the search stopped early, what it had found stands -- the reference tears its allocator down there) */
+			A->top = mark; /* the search's scratch; cand was allocated before it */
+			++*n_shortk;
+		}
+		int32_t best_f = ci->score, best_j = -1, best_d = -1, best_inner = 0;
+		uint32_t best_hash = 0;
+		for (int32_t j = 0; j < cand.n; ++j) {
+			const gc_dst_t *dj = &cand.a[j];
+			int32_t ok;
+			const int32_t sc = gc_link_score(dj, ci, c, an, fr, f, bw, P->ref_bonus, P->chn_pen_gap, &ok);
+			if (!ok || sc + ci->score < 0) continue;
+			if (sc > best_f) best_f = sc, best_j = dj->meta, best_d = dj->dist, best_hash = dj->hash, best_inner = dj->inner;
+		}
+		f[i] = best_f, p[i] = best_j;
+		ci->dist_pre = best_d, ci->hash_pre = best_hash, ci->inner_pre = best_inner;
+		v[i] = best_j >= 0 && v[best_j] > best_f ? v[best_j] : best_f;
+	}
+	int32_t n_u, n_v;
+	GC_TRY(gc_backtrack_all(A, n_ext, f, p, t, u, v, &n_u, &n_v));
+	for (int32_t i = 0; i < n_c - n_ext; ++i) { /* the isolated chains behind the linked ones */
+		u[n_u++] = (uint64_t)c[fr[n_ext + i].i].score << 32 | 1;
+		v[n_v++] = n_ext + i;
+	}
+	gc_chain_t *tmp;
+	GC_ALLOC(A, gc_chain_t, tmp, n_v > 0 ? n_v : 1);
+	for (int32_t i = 0, k = 0; i < n_u; ++i) {
+		const int32_t k0 = k, ni = (int32_t)(uint32_t)u[i];
+		for (int32_t j = 0; j < ni; ++j) tmp[k++] = c[fr[v[k0 + (ni - j - 1)]].i];
+	}
+	memcpy(c, tmp, (size_t)n_v * sizeof(gc_chain_t));
+	*n_c_ = n_v, *u_ = u, *n_u_ = n_u;
+	return GC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ GWFA */
+
+#define GC_DSHIFT 0x40000000
+typedef struct { uint64_t vd; int32_t k, len; uint32_t xo; int32_t t; } gc_diag_t;   /* vd = vertex<<32 | (DSHIFT + diagonal); xo = edits-ish<<1 | out-of-order */
+typedef struct { uint64_t vd0, vd1; } gc_intv_t;
+typedef struct { int32_t v, pre; } gc_trace_t;
+typedef GC_VEC(gc_diag_t) gc_diag_v;
+typedef GC_VEC(gc_intv_t) gc_intv_v;
+typedef struct { uint64_t *k; int32_t *v; uint32_t cap, cnt; } gc_u64map_t;
+
+GC_HD uint64_t gc_mk_vd(uint32_t v, int32_t d) { return (uint64_t)v << 32 | (uint32_t)(GC_DSHIFT + d); }
+GC_HD uint32_t gc_u64slot(uint64_t key, uint32_t cap) { return (uint32_t)((key ^ key >> 29) * 0x9E3779B97F4A7C15ULL >> 40) & (cap - 1); }
+GC_HD int gc_u64map_put(gc_arena_t *A, gc_u64map_t *h, uint64_t key, int32_t **val, int *absent)
+{
+	if (h->cnt * 2 >= h->cap) {
+		const uint32_t ocap = h->cap, ncap = ocap ? ocap * 2 : 64;
+		const uint64_t *ok = h->k; const int32_t *ov = h->v;
+		uint64_t *nk; int32_t *nv;
+		GC_ALLOC(A, uint64_t, nk, ncap); GC_ALLOC(A, int32_t, nv, ncap);
+		for (uint32_t j = 0; j < ncap; ++j) nk[j] = ~0ULL;
+		for (uint32_t j = 0; j < ocap; ++j)
+			if (ok[j] != ~0ULL) { uint32_t q = gc_u64slot(ok[j], ncap); while (nk[q] != ~0ULL) q = (q + 1) & (ncap - 1); nk[q] = ok[j], nv[q] = ov[j]; }
+		h->k = nk, h->v = nv, h->cap = ncap;
+	}
+	uint32_t i = gc_u64slot(key, h->cap);
+	while (h->k[i] != ~0ULL && h->k[i] != key) i = (i + 1) & (h->cap - 1);
+	*absent = h->k[i] == ~0ULL;
+	if (*absent) h->k[i] = key, ++h->cnt;
+	*val = &h->v[i];
+	return GC_OK;
+}
+GC_HD void gc_u64map_clear(gc_u64map_t *h) { for (uint32_t j = 0; j < h->cap; ++j) h->k[j] = ~0ULL; h->cnt = 0; }
+
+typedef struct {
+	const gc_graph_t *G;
+	int32_t ql; const char *q;
+	int32_t max_chk, bw_dyn, max_lag;
+	int64_t i_term;
+	gc_u64map_t seen, tnode;      /* (vertex, query position) entered in the current step; traceback node dedup */
+	gc_intv_v done, fresh, swap;  /* finished diagonals: merged list, this step's additions, scratch */
+	gc_diag_v ooo, wf[2], head;   /* sort scratch; the two wavefronts; the cells sitting on a vertex or query end */
+	gc_kv_t *sort_kv; gc_diag_t *sort_tmp; int32_t m_sort;
+	GC_VEC(gc_trace_t) tr;
+	int32_t cur, s, end_tb, end_off;
+	uint32_t end_v;
+} gc_gw_t;
+
+GC_HD int gc_trace_push(gc_arena_t *A, gc_gw_t *z, int32_t v, int32_t pre, int32_t *id) /* gfa-ed.c:213-227 */
+{
+	int absent;
+	int32_t *val;
+	GC_TRY(gc_u64map_put(A, &z->tnode, (uint64_t)(uint32_t)v << 32 | (uint32_t)pre, &val, &absent));
+	if (absent) {
+		gc_trace_t *t;
+		GC_PUSH(A, z->tr, t);
+		t->v = v, t->pre = pre;
+		*val = z->tr.n - 1;
+	}
+	*id = *val;
+	return GC_OK;
+}
+GC_HD int gc_diag_push(gc_arena_t *A, gc_diag_v *a, uint32_t v, int32_t d, int32_t k, uint32_t x, uint32_t ooo, int32_t t)
+{
+	gc_diag_t *p;
+	GC_PUSH(A, *a, p);
+	p->vd = gc_mk_vd(v, d), p->k = k, p->xo = x << 1 | ooo, p->t = t, p->len = 0;
+	return GC_OK;
+}
+GC_HD int gc_diag_update(gc_diag_t *p, uint32_t v, int32_t d, int32_t k, uint32_t x, uint32_t ooo, int32_t t) /* gfa-ed.c:120-131 */
+{
+	if (p->vd == gc_mk_vd(v, d)) {
+		if (!(p->k > k)) p->xo = x << 1 | ooo, p->t = t, p->k = k;
+		return 0;
+	}
+	return 1;
+}
+/* furthest target offset reachable by exact matches from k on diagonal d of a vertex of length vl (gfa-ed.c:305-329), 8 bases per compare */
+GC_HD int32_t gc_extend1(int32_t d, int32_t k, int32_t vl, const char *ts, int32_t ql, const char *qs)
+{
+	const int32_t max_k = (ql - d < vl ? ql - d : vl) - 1;
+	const char *t = ts + 1, *q = qs + d + 1;
+	while (k + 8 <= max_k) {
+		uint64_t x, y;
+		memcpy(&x, t + k, 8); memcpy(&y, q + k, 8);
+		if (x != y) {
+			const uint64_t z = x ^ y;
+#if defined(__HIP_DEVICE_COMPILE__)
+			return k + ((__ffsll((long long)z) - 1) >> 3);
+#else
+			return k + (__builtin_ctzll(z) >> 3);
+#endif
+		}
+		k += 8;
+	}
+	while (k < max_k && t[k] == q[k]) ++k;
+	return k;
+}
+GC_HD int32_t gc_intv_merge(int32_t n, gc_intv_t *a) /* gfa-ed.c:69-82 */
+{
+	if (n == 0) return 0;
+	uint64_t st = a[0].vd0, en = a[0].vd1;
+	int32_t k = 0;
+	for (int32_t i = 1; i < n; ++i) {
+		if (a[i].vd0 > en) { a[k].vd0 = st, a[k++].vd1 = en; st = a[i].vd0, en = a[i].vd1; }
+		else en = en > a[i].vd1 ? en : a[i].vd1;
+	}
+	a[k].vd0 = st, a[k++].vd1 = en;
+	return k;
+}
+/* sort a[] by vd: in-order cells keep their place, the flagged subset goes through the klib sort, stable merge (gfa-ed.c:143-171) */
+GC_HD int gc_diag_sort(gc_arena_t *A, gc_gw_t *z, int32_t n_a, gc_diag_t *a)
+{
+	int32_t n_c = 0;
+	GC_TRY(gc_vec_reserve(A, z->ooo, n_a));
+	for (int32_t i = 0; i < n_a; ++i) n_c += a[i].xo & 1;
+	const int32_t n_b = n_a - n_c;
+	gc_diag_t *b = z->ooo.a, *c = b + n_b;
+	for (int32_t i = 0, j = 0, k = 0; i < n_a; ++i) { if (a[i].xo & 1) c[k++] = a[i]; else b[j++] = a[i]; }
+	if (n_c > 1) {
+		if (z->m_sort < n_c) {
+			z->m_sort = n_c + (n_c >> 1) + 16;
+			GC_ALLOC(A, gc_kv_t, z->sort_kv, z->m_sort);
+			GC_ALLOC(A, gc_diag_t, z->sort_tmp, z->m_sort);
+		}
+		for (int32_t i = 0; i < n_c; ++i) z->sort_kv[i].key = c[i].vd, z->sort_kv[i].val = (uint64_t)i;
+		GC_TRY(gc_ksort(A, z->sort_kv, n_c, 8));
+		for (int32_t i = 0; i < n_c; ++i) z->sort_tmp[i] = c[z->sort_kv[i].val];
+		memcpy(c, z->sort_tmp, (size_t)n_c * sizeof(gc_diag_t));
+	}
+	for (int32_t k = 0; k < n_c; ++k) c[k].xo &= 0xfffffffeU;
+	int32_t i = 0, j = 0, k = 0;
+	while (i < n_b && j < n_c) { if (b[i].vd <= c[j].vd) a[k++] = b[i++]; else a[k++] = c[j++]; }
+	while (i < n_b) a[k++] = b[i++];
+	while (j < n_c) a[k++] = c[j++];
+	return GC_OK;
+}
+GC_HD int gc_gw_dedup(gc_arena_t *A, gc_gw_t *z, int32_t *n_a_, gc_diag_t *a) /* gwf_dedup, gfa-ed.c:258-271 */
+{
+	int32_t n_a = *n_a_;
+	if (z->done.n + z->fresh.n > 0) {
+		int sorted = 1;
+		for (int32_t i = 1; i < z->fresh.n; ++i) if (z->fresh.a[i - 1].vd0 > z->fresh.a[i].vd0) { sorted = 0; break; }
+		if (!sorted) { /* ties are merged away below: any correct sort */
+			for (int32_t i = 1; i < z->fresh.n; ++i) { gc_intv_t t = z->fresh.a[i]; int32_t j = i; for (; j > 0 && t.vd0 < z->fresh.a[j - 1].vd0; --j) z->fresh.a[j] = z->fresh.a[j - 1]; z->fresh.a[j] = t; }
+		}
+		GC_TRY(gc_vec_reserve(A, z->swap, z->done.n + 1));
+		memcpy(z->swap.a, z->done.a, (size_t)z->done.n * sizeof(gc_intv_t)); z->swap.n = z->done.n;
+		GC_TRY(gc_vec_reserve(A, z->done, z->done.n + z->fresh.n + 1));
+		int32_t ii = 0, jj = 0, kk = 0;
+		while (ii < z->swap.n && jj < z->fresh.n) {
+			if (z->swap.a[ii].vd0 <= z->fresh.a[jj].vd0) z->done.a[kk++] = z->swap.a[ii++];
+			else z->done.a[kk++] = z->fresh.a[jj++];
+		}
+		while (ii < z->swap.n) z->done.a[kk++] = z->swap.a[ii++];
+		while (jj < z->fresh.n) z->done.a[kk++] = z->fresh.a[jj++];
+		z->done.n = gc_intv_merge(kk, z->done.a);
+	}
+	{
+		int sorted = 1;
+		for (int32_t i = 1; i < n_a; ++i) if (a[i - 1].vd > a[i].vd) { sorted = 0; break; }
+		if (!sorted) GC_TRY(gc_diag_sort(A, z, n_a, a));
+	}
+	int32_t n = 0;
+	for (int32_t i = 1, st = 0; i <= n_a; ++i) /* keep the furthest cell of every (vertex, diagonal): the first of equals */
+		if (i == n_a || a[i].vd != a[st].vd) {
+			int32_t max_j = st;
+			for (int32_t j = st + 1; j < i; ++j) if (a[max_j].k < a[j].k) max_j = j;
+			a[n++] = a[max_j];
+			st = i;
+		}
+	n_a = n;
+	if (z->done.n > 0) { /* drop cells on finished diagonals (gfa-ed.c:192-202) */
+		int32_t ii = 0, jj = 0, kk = 0;
+		const int32_t n_b = z->done.n;
+		const gc_intv_t *b = z->done.a;
+		while (ii < n_a && jj < n_b) {
+			if (a[ii].vd >= b[jj].vd0 && a[ii].vd < b[jj].vd1) ++ii;
+			else if (a[ii].vd >= b[jj].vd1) ++jj;
+			else a[kk++] = a[ii++];
+		}
+		while (ii < n_a) a[kk++] = a[ii++];
+		n_a = kk;
+	}
+	*n_a_ = n_a;
+	return GC_OK;
+}
+GC_HD int32_t gc_gw_prune(int32_t n_a, gc_diag_t *a, uint32_t max_lag, int32_t bw_dyn) /* gfa-ed.c:286-307 */
+{
+	int32_t max_i = -1, j = 0;
+	uint32_t max_x = 0;
+	for (int32_t i = 0; i < n_a; ++i) if (a[i].xo >> 1 > max_x) max_x = a[i].xo >> 1, max_i = i;
+	const int32_t iq = (int32_t)a[max_i].vd - GC_DSHIFT + a[max_i].k, dq = (int32_t)(a[max_i].xo >> 1) - iq - iq;
+	for (int32_t i = 0; i < n_a; ++i) {
+		const gc_diag_t p = a[i];
+		const int32_t ip = (int32_t)p.vd - GC_DSHIFT + p.k, dp = (int32_t)(p.xo >> 1) - ip - ip, w = dp > dq ? dp - dq : dq - dp;
+		if (bw_dyn >= 0 && w > bw_dyn) continue;
+		if ((p.xo >> 1) + max_lag < max_x) continue;
+		a[j++] = p;
+	}
+	return j;
+}
+/* Landau-Vishkin over a run of adjacent diagonals on one vertex (gfa-ed.c:331-403) */
+GC_HD int gc_gw_extend_run(gc_arena_t *A, gc_gw_t *z, int32_t n, gc_diag_t *a, gc_diag_v *B, gc_diag_v *H)
+{
+	const uint32_t v = (uint32_t)(a->vd >> 32);
+	const int32_t vl = gc_vlen(z->G, v);
+	const char *ts = gc_vseq(z->G, v);
+	for (int32_t j = 0; j < n; ++j) {
+		const int32_t k = gc_extend1((int32_t)a[j].vd - GC_DSHIFT, a[j].k, vl, ts, z->ql, z->q);
+		a[j].len = k - a[j].k, a[j].xo += (uint32_t)a[j].len << 2, a[j].k = k;
+	}
+	GC_TRY(gc_vec_reserve(A, *B, B->n + n + 2));
+	gc_diag_t *b = &B->a[B->n];
+	b[0].vd = a[0].vd - 1, b[0].xo = a[0].xo + 2, b[0].k = a[0].k + 1, b[0].t = a[0].t;
+	{
+		const int first = n == 1 || a[0].k > a[1].k;
+		b[1].vd = a[0].vd, b[1].xo = first ? a[0].xo + 4 : a[1].xo + 2, b[1].t = first ? a[0].t : a[1].t, b[1].k = (first ? a[0].k : a[1].k) + 1;
+	}
+	for (int32_t j = 1; j < n - 1; ++j) {
+		uint32_t x = a[j - 1].xo + 2;
+		int32_t k = a[j - 1].k, t = a[j - 1].t;
+		if (!(k > a[j].k + 1)) x = a[j].xo + 4, t = a[j].t, k = a[j].k + 1;
+		if (!(k > a[j + 1].k + 1)) x = a[j + 1].xo + 2, t = a[j + 1].t, k = a[j + 1].k + 1;
+		b[j + 1].vd = a[j].vd, b[j + 1].k = k, b[j + 1].xo = x, b[j + 1].t = t;
+	}
+	if (n >= 2) {
+		const int left = a[n - 2].k > a[n - 1].k + 1;
+		b[n].vd = a[n - 1].vd, b[n].xo = left ? a[n - 2].xo + 2 : a[n - 1].xo + 4, b[n].t = left ? a[n - 2].t : a[n - 1].t, b[n].k = left ? a[n - 2].k : a[n - 1].k + 1;
+	}
+	b[n + 1].vd = a[n - 1].vd + 1, b[n + 1].xo = a[n - 1].xo + 2, b[n + 1].t = a[n - 1].t, b[n + 1].k = a[n - 1].k;
+	for (int32_t j = 0; j < n; ++j) { /* cells at a vertex / query end are handled one by one by the caller */
+		gc_diag_t *p = &a[j];
+		if (p->k == vl - 1 || (int32_t)p->vd - GC_DSHIFT + p->k == z->ql - 1) {
+			gc_diag_t *q;
+			p->xo |= 1;
+			GC_PUSH(A, *H, q);
+			*q = *p;
+		}
+	}
+	b = &B->a[B->n]; /* (H and B are different vectors, but the arena may have moved B when H grew in place? no: only H can move) */
+	int32_t m = 0;
+	for (int32_t j = 0; j < n + 2; ++j) {
+		const gc_diag_t p = b[j];
+		const int32_t d = (int32_t)p.vd - GC_DSHIFT;
+		if (d + p.k < z->ql && p.k < vl) b[m++] = p;
+		else if (p.k == vl) {
+			gc_intv_t *iv;
+			GC_PUSH(A, z->fresh, iv);
+			iv->vd0 = gc_mk_vd(v, d), iv->vd1 = iv->vd0 + 1;
+		}
+	}
+	B->n += m;
+	return GC_OK;
+}
+/* one edit-distance step: consumes wf[cur], builds wf[cur^1]; *reached = 1 when (v1, off1) was hit (gfa-ed.c:405-507) */
+GC_HD int gc_gw_step(gc_arena_t *A, gc_gw_t *z, uint32_t v1, int32_t off1, int *reached)
+{
+	const gc_graph_t *G = z->G;
+	gc_diag_v *Cur = &z->wf[z->cur], *B = &z->wf[z->cur ^ 1], *H = &z->head;
+	gc_diag_t *a = Cur->a;
+	int32_t n = Cur->n, head = 0, do_dedup = 1;
+	*reached = 0;
+	H->n = B->n = 0;
+	z->end_v = (uint32_t)-1, z->end_off = z->end_tb = -1;
+	z->fresh.n = 0;
+	gc_u64map_clear(&z->seen);
+	GC_TRY(gc_vec_reserve(A, *B, n * 2 + 4));
+	for (int32_t x = 0, i = 1; i <= n; ++i)
+		if (i == n || a[i].vd != a[i - 1].vd + 1) { GC_TRY(gc_gw_extend_run(A, z, i - x, &a[x], B, H)); x = i; }
+	if (H->n == 0) do_dedup = 0;
+	while (head < H->n) {
+		const gc_diag_t t = H->a[head++];
+		const uint32_t v = (uint32_t)(t.vd >> 32), ooo = t.xo & 1;
+		const int32_t d = (int32_t)t.vd - GC_DSHIFT, vl = gc_vlen(G, v);
+		const int32_t k = gc_extend1(d, t.k, vl, gc_vseq(G, v), z->ql, z->q), qi = k + d;
+		const uint32_t x0 = (t.xo >> 1) + ((uint32_t)(k - t.k) << 1);
+		if (k + 1 < vl && qi + 1 < z->ql) { /* inside a vertex */
+			int push1 = 1, push2 = 1;
+			if (B->n >= 2) push1 = gc_diag_update(&B->a[B->n - 2], v, d - 1, k + 1, x0 + 1, ooo, t.t);
+			if (B->n >= 1) push2 = gc_diag_update(&B->a[B->n - 1], v, d, k + 1, x0 + 2, ooo, t.t);
+			if (push1) GC_TRY(gc_diag_push(A, B, v, d - 1, k + 1, x0 + 1, 1, t.t));
+			if (push2 || push1) GC_TRY(gc_diag_push(A, B, v, d, k + 1, x0 + 2, 1, t.t));
+			GC_TRY(gc_diag_push(A, B, v, d + 1, k, x0 + 1, ooo, t.t));
+		} else if (qi + 1 < z->ql) { /* end of the vertex, query not finished: fan out over the arcs */
+			const int32_t nv = gc_n_arc(G, v);
+			const gc_arc_t *av = gc_arcs(G, v);
+			int32_t n_ext = 0, tw;
+			gc_intv_t *iv;
+			GC_PUSH(A, z->fresh, iv);
+			iv->vd0 = gc_mk_vd(v, d), iv->vd1 = iv->vd0 + 1;
+			GC_TRY(gc_trace_push(A, z, (int32_t)v, t.t, &tw));
+			for (int32_t j = 0; j < nv; ++j) {
+				const uint32_t w = av[j].w;
+				const int32_t ol = av[j].ow;
+				int absent;
+				int32_t *dummy;
+				GC_TRY(gc_u64map_put(A, &z->seen, (uint64_t)w << 32 | (uint32_t)(qi + 1), &dummy, &absent));
+				if (z->q[qi + 1] == gc_vseq(G, w)[ol]) {
+					++n_ext;
+					if (absent) {
+						gc_diag_t *p;
+						GC_PUSH(A, *H, p);
+						p->vd = gc_mk_vd(w, qi + 1 - ol), p->k = ol, p->xo = (x0 + 2) << 1 | 1, p->t = tw, p->len = 0;
+					}
+				} else if (absent) {
+					GC_TRY(gc_diag_push(A, B, w, qi - ol, ol, x0 + 1, 1, tw));
+					GC_TRY(gc_diag_push(A, B, w, qi + 1 - ol, ol, x0 + 2, 1, tw));
+				}
+			}
+			if (nv == 0 || n_ext != nv) GC_TRY(gc_diag_push(A, B, v, d + 1, k, x0 + 1, 1, t.t));
+		} else if (v1 == (uint32_t)-1 || (v == v1 && k == off1)) { /* query finished at the requested end */
+			z->end_v = v, z->end_off = k, z->end_tb = t.t;
+			B->n = 0;
+			*reached = 1;
+			return GC_OK;
+		} else if (k + 1 < vl) { /* query finished inside a vertex: delete the next target base */
+			GC_TRY(gc_diag_push(A, B, v, d - 1, k + 1, x0 + 1, ooo, t.t));
+		} else if (v != v1) { /* query and vertex both finished, not the last vertex */
+			const int32_t nv = gc_n_arc(G, v);
+			const gc_arc_t *av = gc_arcs(G, v);
+			int32_t tw;
+			GC_TRY(gc_trace_push(A, z, (int32_t)v, t.t, &tw));
+			for (int32_t j = 0; j < nv; ++j) GC_TRY(gc_diag_push(A, B, av[j].w, qi - av[j].ow, av[j].ow, x0 + 1, 1, tw));
+		}
+	}
+	if (do_dedup) GC_TRY(gc_gw_dedup(A, z, &B->n, B->a));
+	if (z->max_lag > 0 && B->n > z->max_chk && ((z->s + 1) & 0xf) == 0) B->n = gc_gw_prune(B->n, B->a, (uint32_t)z->max_lag, z->bw_dyn);
+	z->cur ^= 1;
+	return GC_OK;
+}
+/* unit-cost edit distance of q[0..ql) against the walks from (v0, off0) that end at (v1, off1); *ed = -1 when not reached within
+ * s_term edits.  The vertex walk goes to a vector in the arena (gfa_ed_init/step, gfa-ed.c:524-617, as gchain1.c:349-381 calls them). */
+GC_HD int gc_gwfa(gc_arena_t *A, const gc_graph_t *G, int32_t ql, const char *q, uint32_t v0, int32_t off0, uint32_t v1, int32_t off1,
+				  int32_t max_lag, int32_t s_term, int32_t *ed, int32_t **path, int32_t *n_path)
+{
+	gc_gw_t z;
+	memset(&z, 0, sizeof z);
+	*ed = -1, *path = 0, *n_path = 0;
+	z.G = G, z.ql = ql, z.q = q;
+	z.max_chk = 1000, z.bw_dyn = 1000, z.max_lag = max_lag, z.i_term = 500000000LL; /* gchain1.c:361-363 */
+	GC_TRY(gc_vec_reserve(A, z.wf[0], 16));
+	memset(&z.wf[0].a[0], 0, sizeof(gc_diag_t));
+	z.wf[0].a[0].vd = gc_mk_vd(v0, -off0), z.wf[0].a[0].k = off0 - 1, z.wf[0].a[0].xo = 0, z.wf[0].a[0].t = 0;
+	z.wf[0].n = 1;
+	{ gc_trace_t *t; GC_PUSH(A, z.tr, t); t->v = -1, t->pre = -1; } /* root of the traceback forest (gfa-ed.c:568) */
+	z.end_v = (uint32_t)-1, z.end_off = -1;
+	int64_t n_iter = 0;
+	while (z.wf[z.cur].n > 0) {
+		int reached;
+		GC_TRY(gc_gw_step(A, &z, v1, off1, &reached));
+		n_iter += z.wf[z.cur].n;
+		if (reached || z.end_off >= 0 || z.wf[z.cur].n == 0) break;
+		if (s_term >= 0 && z.s >= s_term) break;
+		if (z.i_term > 0 && n_iter > z.i_term) break;
+		++z.s;
+	}
+	if (z.end_off >= 0) { /* gwf_traceback, gfa-ed.c:509-522 */
+		int32_t i = z.end_tb, n = 1, *p;
+		while (i >= 0 && z.tr.a[i].v >= 0) ++n, i = z.tr.a[i].pre;
+		GC_ALLOC(A, int32_t, p, n);
+		i = z.end_tb, n = 0;
+		p[n++] = (int32_t)z.end_v;
+		while (i >= 0 && z.tr.a[i].v >= 0) p[n++] = z.tr.a[i].v, i = z.tr.a[i].pre;
+		for (i = 0; i < n >> 1; ++i) { const int32_t k = p[i]; p[i] = p[n - 1 - i], p[n - 1 - i] = k; }
+		*path = p, *n_path = n;
+	}
+	*ed = z.end_v != (uint32_t)-1 ? z.s : -1;
+	return GC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ walk assembly */
+
+typedef struct {
+	GC_VEC(mg_llchain_t) lc;   /* vertices of all graph chains, in walk order; anchor-free vertices have cnt == 0 */
+	int32_t n_a;               /* anchors copied to the output so far */
+	mg128_t *a_out;
+	int32_t n_gwfa, n_shortk;
+} gc_asm_t;
+
+GC_HD int gc_asm_vertex(gc_arena_t *A, gc_asm_t *S, uint32_t v)
+{
+	mg_llchain_t *q;
+	GC_PUSH(A, S->lc, q);
+	q->off = q->cnt = q->score = 0, q->v = v, q->ed = -1;
+	return GC_OK;
+}
+GC_HD int gc_asm_chain(gc_arena_t *A, gc_asm_t *S, const gc_chain_t *c, const mg128_t *a, int32_t ed)
+{
+	mg_llchain_t *q;
+	GC_PUSH(A, S->lc, q);
+	q->cnt = c->cnt, q->v = c->v, q->score = c->score, q->ed = ed, q->off = S->n_a;
+	memcpy(&S->a_out[S->n_a], &a[c->off], (size_t)c->cnt * sizeof(mg128_t));
+	S->n_a += c->cnt;
+	return GC_OK;
+}
+
+/* two consecutive chains of a graph chain may share anchors at the junction: cut the tail of the first / the head of the second
+ * back to where they are monotone on the query (and on the segment when they share it) (gchain1.c:409-441) */
+GC_HD void gc_untangle(gc_chain_t *c0, gc_chain_t *c1, const mg128_t *a)
+{
+	int32_t j, x = GC_AX(a[c1->off]), y = GC_AY(a[c1->off]);
+	const int same = c0->v == c1->v;
+	for (j = c0->cnt - 1; j >= 0; --j)
+		if (GC_AY(a[c0->off + j]) <= y && (!same || GC_AX(a[c0->off + j]) <= x)) break;
+	const int32_t drop0 = c0->cnt - 1 - j;
+	x = GC_AX(a[c0->off + c0->cnt - 1]), y = GC_AY(a[c0->off + c0->cnt - 1]);
+	for (j = 0; j < c1->cnt; ++j)
+		if (GC_AY(a[c1->off + j]) >= y && (!same || GC_AX(a[c1->off + j]) >= x)) break;
+	const int32_t drop1 = j;
+	if (drop0 > 0) {
+		c0->cnt -= drop0;
+		if (c0->cnt) c0->qe = GC_AY(a[c0->off + c0->cnt - 1]) + 1, c0->re = GC_AX(a[c0->off + c0->cnt - 1]) + 1;
+	}
+	if (drop1 > 0) {
+		c1->off += drop1, c1->cnt -= drop1;
+		c1->qs = GC_AY(a[c1->off]) + 1 - GC_ASPAN(a[c1->off]), c1->rs = GC_AX(a[c1->off]) + 1 - GC_ASPAN(a[c1->off]);
+	}
+	if (c0->cnt == 0) c0->qs = c0->qe = c1->qs, c0->rs = c0->re = c1->rs;
+}
+
+/* the vertices between chain c0 and chain c1 (different segments): by aligning the query between them to the graph, or, when that
+ * gives up, by the shortest walk of the length the DP chose (gchain1.c:319-407); returns 1 when c1 could not be attached */
+GC_HD int gc_bridge(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, gc_asm_t *S, int32_t span, const gc_chain_t *c0, const gc_chain_t *c1,
+					const mg128_t *a, const char *qseq, int *failed)
+{
+	*failed = 0;
+	if (c1->v != c0->v) {
+		int32_t ed = -1, *path = 0, n_path = 0, n_mid = 0;
+		GC_TRY(gc_vec_reserve(A, S->lc, S->lc.n + 66)); /* room for the usual walk, so that the search's scratch can be released afterwards */
+		const int64_t mark = A->top;
+		const char *base = A->base;
+		{
+			const int32_t qs = c0->qe - span, qe = c1->qs + span;
+			GC_TRY(gc_gwfa(A, G, qe - qs, qseq + qs, c0->v, c0->re - span, c1->v, c1->rs + span - 1, P->gdp_max_ed / 2, P->gdp_max_ed, &ed, &path, &n_path));
+			++S->n_gwfa;
+		}
+		if (ed >= 0) {
+			n_mid = n_path - 2 > 0 ? n_path - 2 : 0;
+			if (n_mid) gc_move(path, path + 1, (int64_t)n_mid * 4); /* the inner vertices */
+		} else {
+			gc_dst_t dst;
+			gc_walkv_t *w = 0;
+			int32_t n_w = 0;
+			if (A->base == base) A->top = mark;
+			memset(&dst, 0, sizeof dst);
+			dst.v = c0->v ^ 1, dst.target_dist = c1->dist_pre, dst.target_hash = c1->hash_pre, dst.check_hash = 1;
+			const int rc = gc_shortest_k(A, G, c1->v ^ 1, 1, &dst, dst.target_dist, MG_MAX_SHORT_K, &w, &n_w);
+			if (rc == GC_E_ARENA) return rc;
+			++S->n_shortk;
+			if (rc != GC_OK || n_w == 0 || dst.target_hash != dst.hash) { if (A->base == base) A->top = mark; *failed = 1; return GC_OK; } /* "chain skiped" (gchain1.c:333-338) */
+			n_mid = n_w - 2 > 0 ? n_w - 2 : 0;
+			GC_ALLOC(A, int32_t, path, n_mid > 0 ? n_mid : 1);
+			for (int32_t s = n_w - 2, k = 0; s >= 1; --s) path[k++] = (int32_t)(w[s].v ^ 1); /* found backwards: reverse and flip */
+		}
+		if (S->lc.n + n_mid + 1 <= S->lc.m) { /* fits the reserved room: nothing is allocated while the vertices are appended */
+			for (int32_t j = 0; j < n_mid; ++j) GC_TRY(gc_asm_vertex(A, S, (uint32_t)path[j]));
+			if (A->base == base) A->top = mark;
+		} else for (int32_t j = 0; j < n_mid; ++j) GC_TRY(gc_asm_vertex(A, S, (uint32_t)path[j])); /* long walk: the scratch stays until the read is done */
+		GC_TRY(gc_asm_chain(A, S, c1, a, ed));
+	} else { /* same segment: the anchors of c1 beyond the end of c0 extend the last vertex */
+		mg_llchain_t *t = &S->lc.a[S->lc.n - 1];
+		int32_t k = 0;
+		while (k < c1->cnt && !(GC_AX(a[c1->off + k]) > c0->re && GC_AY(a[c1->off + k]) > c0->qe)) ++k;
+		if (k < c1->cnt) {
+			t->cnt += c1->cnt - k, t->score += c1->score;
+			memcpy(&S->a_out[S->n_a], &a[c1->off + k], (size_t)(c1->cnt - k) * sizeof(mg128_t));
+			S->n_a += c1->cnt - k;
+		}
+	}
+	return GC_OK;
+}
+
+/* coordinates and alignment-length estimates of every graph chain (gchain1.c:242-301), integers only */
+GC_HD void gc_measure(const gc_graph_t *G, gc_result_t *R)
+{
+	for (int32_t i = 0; i < R->n_gc; ++i) {
+		gc_rec_t *p = &R->gc[i];
+		p->qs = p->qe = p->ps = p->pe = -1, p->plen = p->blen = p->mlen = 0, p->n_mini = 0, p->q_span = 0;
+		if (p->cnt == 0) continue;
+		const mg_llchain_t *first = &R->lc[p->off], *last = &R->lc[p->off + p->cnt - 1];
+		const mg128_t *a0 = &R->a[first->off], *a1 = &R->a[last->off + last->cnt - 1];
+		p->q_span = GC_ASPAN(*a0);
+		p->qs = GC_AY(*a0) + 1 - p->q_span, p->ps = GC_AX(*a0) + 1 - p->q_span;
+		p->qe = GC_AY(*a1) + 1;
+		const int32_t tail = gc_vlen(G, last->v) - GC_AX(*a1) - 1;
+		int32_t n_mini = (int32_t)(a1->x >> 32) - (int32_t)(a0->x >> 32) + 1, rest = 0;
+		const mg128_t *prev = a0;
+		for (int32_t j = 0; j < p->cnt; ++j) {
+			const mg_llchain_t *q = &R->lc[p->off + j];
+			const int32_t vlen = gc_vlen(G, q->v);
+			p->plen += vlen;
+			for (int32_t k = 0; k < q->cnt; ++k) {
+				const mg128_t *r = &R->a[q->off + k];
+				const int32_t span = GC_ASPAN(*r);
+				int32_t pl, ql = GC_AY(*r) - GC_AY(*prev);
+				if (j == 0 && k == 0) pl = ql = span;
+				else if (k == 0) pl = GC_AX(*r) + 1 + rest;
+				else pl = GC_AX(*r) - GC_AX(*prev);
+				if (ql < 0) ql = -ql, n_mini += (int32_t)(prev->x >> 32) - (int32_t)(r->x >> 32); /* query overlap at a junction */
+				p->blen += pl > ql ? pl : ql;
+				p->mlen += pl > span && ql > span ? span : pl < ql ? pl : ql;
+				prev = r;
+			}
+			if (q->cnt == 0) rest += vlen;
+			else rest = vlen - GC_AX(R->a[q->off + q->cnt - 1]) - 1;
+		}
+		p->pe = p->plen - tail;
+		p->n_mini = n_mini;
+	}
+}
+
+/* graph chains in descending (score, hash) order through the klib sort; lc[] and a[] follow (gcmisc.c:6-71) */
+GC_HD int gc_order_by_score(gc_arena_t *A, gc_result_t *R)
+{
+	const int64_t mark = A->top;
+	const int32_t n = R->n_gc;
+	if (n == 0) return GC_OK;
+	gc_kv_t *z;
+	gc_rec_t *g2;
+	mg_llchain_t *l2;
+	mg128_t *a2;
+	GC_ALLOC(A, gc_kv_t, z, n); GC_ALLOC(A, gc_rec_t, g2, n);
+	GC_ALLOC(A, mg_llchain_t, l2, R->n_lc > 0 ? R->n_lc : 1); GC_ALLOC(A, mg128_t, a2, R->n_a > 0 ? R->n_a : 1);
+	for (int32_t i = 0; i < n; ++i) z[i].key = (uint64_t)(uint32_t)R->gc[i].score << 32 | R->gc[i].hash, z[i].val = (uint64_t)i;
+	GC_TRY(gc_ksort(A, z, n, 8));
+	int32_t n_lc = 0, n_a = 0;
+	for (int32_t i = n - 1; i >= 0; --i) {
+		gc_rec_t g = R->gc[z[i].val];
+		memcpy(&l2[n_lc], &R->lc[g.off], (size_t)g.cnt * sizeof(mg_llchain_t));
+		memcpy(&a2[n_a], &R->a[R->lc[g.off].off], (size_t)g.n_anchor * sizeof(mg128_t));
+		g.off = n_lc;
+		g2[n - 1 - i] = g;
+		n_lc += g.cnt, n_a += g.n_anchor;
+	}
+	memcpy(R->gc, g2, (size_t)n * sizeof(gc_rec_t));
+	memcpy(R->lc, l2, (size_t)R->n_lc * sizeof(mg_llchain_t));
+	memcpy(R->a, a2, (size_t)R->n_a * sizeof(mg128_t));
+	for (int32_t i = 0, k = 0; i < R->n_lc; ++i) R->lc[i].off = k, k += R->lc[i].cnt;
+	A->top = mark;
+	return GC_OK;
+}
+
+/* from the DP's grouping of the chains (u[], c[]) to graph chains with their vertex walks (gchain1.c:443-520) */
+GC_HD int gc_assemble(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, int32_t n_u, const uint64_t *u, gc_chain_t *c, const mg128_t *a, uint32_t hash,
+					  const char *qseq, gc_result_t *R)
+{
+	int32_t n_gc = 0;
+	R->n_gc = R->n_lc = R->n_a = 0, R->gc = 0, R->lc = 0;
+	for (int32_t i = 0, st = 0; i < n_u; ++i) {
+		const int32_t ni = (int32_t)(uint32_t)u[i];
+		int32_t m = 0;
+		for (int32_t j = 0; j < ni; ++j) m += c[st + j].cnt;
+		n_gc += m >= P->min_gc_cnt && (int64_t)(u[i] >> 32) >= P->min_gc_score;
+		st += ni;
+	}
+	if (n_gc == 0) return GC_OK;
+	GC_ALLOC(A, gc_rec_t, R->gc, n_gc);
+	memset(R->gc, 0, (size_t)n_gc * sizeof(gc_rec_t));
+	gc_asm_t S;
+	memset(&S, 0, sizeof S);
+	S.a_out = R->a;
+	const int32_t span = GC_ASPAN(a[0]);
+	int32_t k = 0;
+	for (int32_t i = 0, st = 0; i < n_u; st += (int32_t)(uint32_t)u[i], ++i) {
+		const int32_t ni = (int32_t)(uint32_t)u[i], n_a0 = S.n_a, n_lc0 = S.lc.n;
+		int32_t m = 0;
+		for (int32_t j = 0; j < ni; ++j) m += c[st + j].cnt;
+		if (!(m >= P->min_gc_cnt && (int64_t)(u[i] >> 32) >= P->min_gc_score)) continue;
+		gc_rec_t *g = &R->gc[k];
+		uint32_t h = hash;
+		g->score = (int32_t)(u[i] >> 32), g->off = n_lc0;
+		for (int32_t j = 0; j < ni; ++j) h += gc_hash32((uint32_t)c[st + j].qs) + gc_hash32((uint32_t)c[st + j].re) + gc_hash32(c[st + j].v);
+		g->hash = gc_hash32(h);
+		for (int32_t j = 1; j < ni; ++j) gc_untangle(&c[st + j - 1], &c[st + j], a);
+		GC_TRY(gc_asm_chain(A, &S, &c[st], a, -1));
+		for (int32_t j0 = 0, j = 1; j < ni; ++j) {
+			if (c[st + j].cnt <= 0) continue; /* emptied by the untangling: skipped, its neighbours are bridged directly */
+			int failed;
+			GC_TRY(gc_bridge(A, G, P, &S, span, &c[st + j0], &c[st + j], a, qseq, &failed));
+			if (failed) /* no walk of the chosen length between the two: go through the emptied chains in between, pair by pair */
+				for (int32_t t = j0; t < j; ++t) { GC_TRY(gc_bridge(A, G, P, &S, span, &c[st + t], &c[st + t + 1], a, qseq, &failed)); if (failed) return GC_E_BUG; }
+			j0 = j;
+		}
+		g->cnt = S.lc.n - n_lc0, g->n_anchor = S.n_a - n_a0;
+		++k;
+	}
+	R->n_gc = n_gc, R->n_lc = S.lc.n, R->n_a = S.n_a, R->lc = S.lc.a;
+	R->n_gwfa = S.n_gwfa, R->n_shortk += S.n_shortk;
+	gc_measure(G, R);
+	return gc_order_by_score(A, R);
+}
+
+/* ------------------------------------------------------------------------------------------------ primary / secondary, filters */
+
+/* a chain whose query interval is mostly covered by a better one becomes its secondary (gcmisc.c:73-128) */
+GC_HD int gc_assign_parents(gc_arena_t *A, const gc_par_t *P, int32_t n, gc_rec_t *r)
+{
+	if (n <= 0) return GC_OK;
+	const int64_t mark = A->top;
+	uint64_t *cov;
+	int32_t *prim, n_prim = 1;
+	GC_ALLOC(A, uint64_t, cov, n); GC_ALLOC(A, int32_t, prim, n);
+	for (int32_t i = 0; i < n; ++i) r[i].id = i;
+	prim[0] = 0, r[0].parent = 0;
+	for (int32_t i = 1; i < n; ++i) {
+		gc_rec_t *ri = &r[i];
+		const int32_t si = ri->qs, ei = ri->qe;
+		int32_t n_cov = 0, uncov = 0, j;
+		for (j = 0; j < n_prim; ++j) { /* the parts of [si, ei) covered by primaries */
+			int32_t sj = r[prim[j]].qs, ej = r[prim[j]].qe;
+			if (ej <= si || sj >= ei) continue;
+			if (sj < si) sj = si;
+			if (ej > ei) ej = ei;
+			cov[n_cov++] = (uint64_t)(uint32_t)sj << 32 | (uint32_t)ej;
+		}
+		j = n_prim;
+		if (n_cov > 0) {
+			int32_t x = si;
+			gc_sort_u64(cov, n_cov);
+			for (int32_t c = 0; c < n_cov; ++c) {
+				if ((int32_t)(cov[c] >> 32) > x) uncov += (int32_t)(cov[c] >> 32) - x;
+				x = (int32_t)(uint32_t)cov[c] > x ? (int32_t)(uint32_t)cov[c] : x;
+			}
+			if (ei > x) uncov += ei - x;
+			for (j = 0; j < n_prim; ++j) {
+				gc_rec_t *rp = &r[prim[j]];
+				const int32_t sj = rp->qs, ej = rp->qe;
+				if (ej <= si || sj >= ei) continue;
+				const int32_t lo = ej - sj < ei - si ? ej - sj : ei - si, hi = ej - sj > ei - si ? ej - sj : ei - si;
+				const int32_t ol = (ei < ej ? ei : ej) - (si > sj ? si : sj); /* > 0 here */
+				if ((float)ol / lo - (float)uncov / hi > P->mask_level) {
+					ri->parent = rp->parent;
+					if (rp->subsc < ri->score) rp->subsc = ri->score;
+					if (ri->cnt >= rp->cnt) ++rp->n_sub;
+					break;
+				}
+			}
+		}
+		if (j == n_prim) prim[n_prim++] = i, ri->parent = i, ri->n_sub = 0;
+	}
+	A->top = mark;
+	return GC_OK;
+}
+
+/* secondaries far below their primary, or beyond best_n, or identical to it in coordinates, are filtered (gcmisc.c:130-148) */
+GC_HD void gc_filter_secondaries(const gc_par_t *P, int32_t n, gc_rec_t *r)
+{
+	if (!(P->pri_ratio > 0.0f) || n <= 0) return;
+	int32_t n_2nd = 0;
+	for (int32_t i = 0; i < n; ++i) {
+		const gc_rec_t *rp = &r[r[i].parent];
+		if (r[i].parent == i) { r[i].flt = 0; continue; }
+		const int close = (float)r[i].score >= (float)rp->score * P->pri_ratio || r[i].score + P->k * 2 >= rp->score;
+		const int same = r[i].qs == rp->qs && r[i].qe == rp->qe && r[i].ps == rp->ps && r[i].pe == rp->pe;
+		if (close && n_2nd < P->best_n && !same) r[i].flt = 0, ++n_2nd;
+		else r[i].flt = 1;
+	}
+}
+
+/* remove the filtered chains, close the gaps in lc[] and a[] (gcmisc.c:150-188) */
+GC_HD int gc_drop_filtered(gc_arena_t *A, gc_result_t *R)
+{
+	if (R->n_gc == 0) return GC_OK;
+	const int64_t mark = A->top;
+	int32_t *o2n, n_gc = 0, n_lc = 0, n_a = 0, lc0 = 0, a0 = 0;
+	GC_ALLOC(A, int32_t, o2n, R->n_gc);
+	for (int32_t i = 0; i < R->n_gc; ++i) o2n[i] = (R->gc[i].flt || R->gc[i].cnt == 0) ? -1 : n_gc++;
+	n_gc = 0;
+	for (int32_t i = 0; i < R->n_gc; ++i) {
+		const gc_rec_t r = R->gc[i];
+		if (o2n[i] >= 0) {
+			gc_move(&R->a[n_a], &R->a[a0], (int64_t)r.n_anchor * (int64_t)sizeof(mg128_t));
+			gc_move(&R->lc[n_lc], &R->lc[lc0], (int64_t)r.cnt * (int64_t)sizeof(mg_llchain_t));
+			R->gc[n_gc] = r;
+			R->gc[n_gc].id = n_gc, R->gc[n_gc].parent = o2n[r.parent];
+			++n_gc, n_lc += r.cnt, n_a += r.n_anchor;
+		}
+		lc0 += r.cnt, a0 += r.n_anchor;
+	}
+	R->n_gc = n_gc, R->n_lc = n_lc, R->n_a = n_a;
+	for (int32_t i = 0, l = 0, k = 0; i < n_gc; ++i) { /* offsets again */
+		gc_rec_t *g = &R->gc[i];
+		g->off = l, g->n_anchor = 0;
+		for (int32_t j = 0; j < g->cnt; ++j) { mg_llchain_t *q = &R->lc[l + j]; q->off = k, k += q->cnt, g->n_anchor += q->cnt; }
+		l += g->cnt;
+	}
+	A->top = mark;
+	return GC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ one read */
+
+typedef struct {
+	int32_t qlen; uint32_t hash;
+	int32_t n_u; const uint64_t *u;      /* linear chains: score<<32 | count */
+	mg128_t *a;                          /* their anchors, chain after chain; MODIFIED in place (flags, minimizer ranks) */
+	int32_t n_mini; const int32_t *mini_pos;
+	const char *qseq;
+} gc_read_t;
+
+/* R->a must point to a buffer for as many anchors as the chains hold.  Returns GC_OK, GC_E_ARENA (nothing usable in R), or GC_E_BUG
+ * (R holds zero chains: the reference's own bail-out paths). */
+GC_HD int gc_map_read(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, const gc_read_t *rd, gc_result_t *R)
+{
+	gc_chain_t *c = 0;
+	uint64_t *u2 = 0;
+	int32_t n_c = rd->n_u, n_u2 = 0;
+	R->n_gc = R->n_lc = R->n_a = 0, R->gc = 0, R->lc = 0, R->n_gwfa = R->n_shortk = 0;
+	if (rd->n_u <= 0) return GC_OK;
+	GC_TRY(gc_make_chains(A, rd->n_u, rd->u, rd->a, &c));
+	if (n_c > 1) GC_TRY(gc_clean_chains(A, P, rd->a, c, &n_c));
+	for (int32_t i = 0; i < n_c; ++i) GC_TRY(gc_index_anchors(&rd->a[c[i].off], c[i].cnt, rd->mini_pos, rd->n_mini));
+	GC_TRY(gc_chain_dp(A, G, P, rd->qlen, rd->a, c, &n_c, &u2, &n_u2, &R->n_shortk));
+	if (n_u2 == 0) return GC_OK;
+	GC_TRY(gc_assemble(A, G, P, n_u2, u2, c, rd->a, rd->hash, rd->qseq, R));
+	for (int32_t i = 0; i < R->n_gc; ++i) R->gc[i].parent = R->gc[i].id = i, R->gc[i].subsc = R->gc[i].n_sub = R->gc[i].flt = 0;
+	GC_TRY(gc_assign_parents(A, P, R->n_gc, R->gc));
+	gc_filter_secondaries(P, R->n_gc, R->gc);
+	return gc_drop_filtered(A, R);
+}
+
+#endif

@@ -1,0 +1,345 @@
+// k_gchain.hip -- graph chaining on the device: one wavefront per read runs gc_map_read() (gc_core.h) on its lane 0, from the
+// linear chains k_lchain left in HBM to the filtered graph chains (chain records, clean-up, DP with shortest-walk reachability,
+// GWFA / shortest-walk bridging, ordering, primary/secondary, filters).  Reference: map-algo.c:422-474, gchain1.c, shortk.c,
+// gfa-ed.c, gcmisc.c.
+//
+// Why one lane: the work is a chain of dependent, data-driven decisions over a handful of records per read (1.9 linear chains,
+// <1 graph search, <1 GWFA on 10 kb reads) -- latency-bound pointer chasing with nothing for 64 lanes to share.  Parallelism comes
+// from the 10^4-10^5 reads of a chunk: persistent wavefronts pull reads from an atomic counter, each with a private scratch ARENA
+// in HBM (1 MiB; a read that outgrows it is re-run by a second launch with 256 MiB arenas, beyond that the job stops with an
+// error).  The other 63 lanes help with the bulk copies (anchors in, anchors out).  [measured] see DESIGN.md 4.
+//
+// The same source runs on the host (mga_gchain_host_read below: -x asm where the chainer is host code, and the CPU parity tests).
+#include <stdio.h>
+#include <math.h>
+#include "mga_dev.h"
+#include "dev_common.h"
+#include "gc_core.h"
+
+static_assert(sizeof(gc_arc_t) == sizeof(gfa_arc_t) && sizeof(gc_arc_t) == 32, "gc_arc_t must mirror gfa_arc_t");
+
+// ---- reverse complements of all segments, same offsets as the forward copy ----
+__constant__ unsigned char c_gc_comp[256];
+
+__global__ void __launch_bounds__(256) k_revcomp(int n_seg, const char *__restrict__ fw, const int64_t *__restrict__ off, char *__restrict__ rc)
+{
+	for (int s = blockIdx.x; s < n_seg; s += gridDim.x) {
+		const int64_t b = off[s], len = off[s + 1] - b;
+		for (int64_t i = threadIdx.x; i < len; i += blockDim.x) rc[b + len - 1 - i] = (char)c_gc_comp[(unsigned char)fw[b + i]];
+	}
+}
+
+extern "C" int mga_dev_graph_upload(mga_sctx_t *sc, const gfa_t *g, const unsigned char *comp, mga_didx_t *ix)
+{
+	const uint32_t n_vtx = gfa_n_vtx(g);
+	const int64_t tot = 0;
+	(void)tot;
+	MGA_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_gc_comp), comp, 256));
+	ix->d_arc = mga_dmalloc((size_t)(g->n_arc + 1) * sizeof(gfa_arc_t));
+	ix->d_arc_idx = (uint64_t*)mga_dmalloc((size_t)(n_vtx + 1) * 8);
+	if (ix->d_arc == 0 || ix->d_arc_idx == 0) return -1;
+	if (mga_h2d(ix->d_arc, g->arc, (size_t)g->n_arc * sizeof(gfa_arc_t)) < 0 || mga_h2d(ix->d_arc_idx, g->idx, (size_t)n_vtx * 8) < 0) return -1;
+	{
+		int64_t total = 0;
+		if (mga_d2h(&total, ix->d_gseq_off + ix->n_seg, 8) < 0) return -1;
+		ix->d_gseq_rc = (char*)mga_dmalloc((size_t)total + 64);
+		if (ix->d_gseq_rc == 0) return -1;
+		MGA_HIP_CHECK(hipMemsetAsync(ix->d_gseq_rc + total, 0, 64, (hipStream_t)sc->stream));
+		const int nb = ix->n_seg < 65536 ? (ix->n_seg > 0 ? ix->n_seg : 1) : 65536;
+		hipLaunchKernelGGL(k_revcomp, dim3(nb), dim3(256), 0, (hipStream_t)sc->stream, ix->n_seg, (const char*)ix->d_gseq, (const int64_t*)ix->d_gseq_off, ix->d_gseq_rc);
+		MGA_HIP_CHECK(hipGetLastError());
+		if (mga_ssync(sc) < 0) return -1;
+	}
+	return 0;
+}
+
+// ---- the kernel ----
+struct gck_in_t {
+	int n;
+	const int32_t *list;             // reads to do (NULL: 0..n)
+	const int64_t *a_off;            // anchors / chains of read i at a_off[i]
+	const int32_t *nu, *nb;
+	const uint64_t *u;
+	const mg128_t *b;
+	const int64_t *mini_off; const int32_t *mini;
+	const int64_t *q_off; const char *seq;
+	const uint32_t *hash;
+};
+struct gck_out_t {
+	mga_gc_hdr_t *hdr;
+	mg128_t *ga;                     // output anchors of read i at a_off[i]
+	gc_rec_t *gc_pool; int64_t gc_cap;
+	mg_llchain_t *lc_pool; int64_t lc_cap;
+	unsigned long long *ctl;         // [0] next read, [1] gc pool used, [2] lc pool used, [3] reads to retry, [4] gwfa calls, [5] shortest-walk calls
+	int32_t *retry;
+};
+
+__global__ void __launch_bounds__(64) k_gchain(gck_in_t in, gck_out_t out, gc_graph_t G, gc_par_t P, char *arena_mem, int64_t arena_bytes)
+{
+	const int lane = threadIdx.x;
+	char *my_arena = arena_mem + (int64_t)blockIdx.x * arena_bytes;
+	for (;;) {
+		int slot = 0;
+		if (lane == 0) slot = (int)atomicAdd(&out.ctl[0], 1ULL);
+		slot = __shfl(slot, 0);
+		if (slot >= in.n) break;
+		const int r = in.list ? in.list[slot] : slot;
+		const int64_t off = in.a_off[r];
+		const int32_t n_u = in.nu[r], n_b = in.nb[r];
+		mga_gc_hdr_t *H = &out.hdr[r];
+		if (n_u <= 0 || n_b <= 0) { if (lane == 0) { H->n_gc = H->n_lc = H->n_a = 0, H->status = 0, H->gc_off = H->lc_off = 0; } continue; }
+		gc_arena_t A;
+		gc_arena_init(&A, my_arena, arena_bytes, 0);
+		mg128_t *work = (mg128_t*)gc_alloc(&A, (int64_t)n_b * 16); // the chains' anchors: flags and minimizer ranks are written into this copy
+		if (work) for (int32_t i = lane; i < n_b; i += 64) work[i] = in.b[off + i];
+		mga_wave_sync();
+		int32_t status = GC_E_ARENA, n_gc = 0, n_lc = 0, n_a = 0;
+		int64_t gc_off = 0, lc_off = 0;
+		if (lane == 0 && work) {
+			gc_read_t rd;
+			gc_result_t R;
+			rd.qlen = (int32_t)(in.q_off[r + 1] - in.q_off[r]), rd.hash = in.hash[r];
+			rd.n_u = n_u, rd.u = in.u + off, rd.a = work;
+			rd.n_mini = (int32_t)(in.mini_off[r + 1] - in.mini_off[r]), rd.mini_pos = in.mini + in.mini_off[r];
+			rd.qseq = in.seq + in.q_off[r];
+			R.a = out.ga + off;
+			status = gc_map_read(&A, &G, &P, &rd, &R);
+			if (status == GC_E_BUG) status = GC_OK, R.n_gc = R.n_lc = R.n_a = 0; // the reference's own bail-outs: the read gets no chains
+			if (status == GC_OK) {
+				n_gc = R.n_gc, n_lc = R.n_lc, n_a = R.n_a;
+				gc_off = (int64_t)atomicAdd(&out.ctl[1], (unsigned long long)n_gc);
+				lc_off = (int64_t)atomicAdd(&out.ctl[2], (unsigned long long)n_lc);
+				if (gc_off + n_gc > out.gc_cap || lc_off + n_lc > out.lc_cap) status = MGA_GC_E_POOL;
+				else {
+					for (int32_t i = 0; i < n_gc; ++i) out.gc_pool[gc_off + i] = R.gc[i];
+					for (int32_t i = 0; i < n_lc; ++i) out.lc_pool[lc_off + i] = R.lc[i];
+				}
+				atomicAdd(&out.ctl[4], (unsigned long long)R.n_gwfa);
+				atomicAdd(&out.ctl[5], (unsigned long long)R.n_shortk);
+			}
+			if (status != GC_OK) out.retry[atomicAdd(&out.ctl[3], 1ULL)] = r;
+			H->n_gc = n_gc, H->n_lc = n_lc, H->n_a = n_a, H->status = status, H->gc_off = gc_off, H->lc_off = lc_off;
+		}
+		mga_wave_sync();
+	}
+}
+
+extern "C" size_t mga_dev_gchain_arena_bytes(int tier) { return tier == 0 ? (size_t)1 << 20 : (size_t)256 << 20; }
+extern "C" int mga_dev_gchain_waves(int tier) { return tier == 0 ? 6144 : 24; }
+
+static void gc_par_from_opt(const mg_mapopt_t *opt, int k, float pen_gap, gc_par_t *P)
+{
+	memset(P, 0, sizeof *P);
+	P->k = k, P->bw = opt->bw, P->bw_long = opt->bw_long, P->max_gap = opt->max_gap;
+	P->min_lc_cnt = opt->min_lc_cnt, P->lc_max_occ = opt->lc_max_occ, P->lc_max_trim = opt->lc_max_trim;
+	P->max_gc_skip = opt->max_gc_skip, P->ref_bonus = opt->ref_bonus, P->min_gc_cnt = opt->min_gc_cnt, P->min_gc_score = opt->min_gc_score, P->gdp_max_ed = opt->gdp_max_ed;
+	P->best_n = opt->best_n, P->sub_diff = opt->sub_diff;
+	P->chn_pen_gap = pen_gap, P->mask_level = opt->mask_level, P->pri_ratio = opt->pri_ratio;
+}
+
+// One launch over n reads (d_list == NULL: all of them; otherwise the listed ones, tier 1 arenas).  Device pointers throughout.
+// ctl: 8 x uint64 (zeroed by the caller before the FIRST launch of a chunk; a retry launch resets only the read counter).
+extern "C" int mga_dev_gchain(mga_sctx_t *sc, const mga_didx_t *ix, const mg_mapopt_t *opt, int k, float pen_gap, int n, const int32_t *d_list, int tier,
+							  const int64_t *d_a_off, const int32_t *d_nu, const int32_t *d_nb, const uint64_t *d_u, const mg128_t *d_b,
+							  const int64_t *d_mini_off, const int32_t *d_mini, const int64_t *d_q_off, const char *d_seq, const uint32_t *d_hash,
+							  mga_gc_hdr_t *d_hdr, mg128_t *d_ga, void *d_gc_pool, int64_t gc_cap, mg_llchain_t *d_lc_pool, int64_t lc_cap,
+							  unsigned long long *d_ctl, int32_t *d_retry)
+{
+	if (n <= 0) return 0;
+	if (ix->d_arc == 0 || ix->d_gseq_rc == 0) { mga_set_error("graph chaining on the device needs the graph replica (mga_dev_graph_upload)"); return -1; }
+	const size_t ab = mga_dev_gchain_arena_bytes(tier);
+	int waves = mga_dev_gchain_waves(tier);
+	if (waves > n) waves = n;
+	mga_dbuf_t *arena = &sc->gc_arena[tier ? 1 : 0];
+	if (mga_dbuf_reserve(arena, ab * (size_t)mga_dev_gchain_waves(tier)) < 0) return -1;
+	gck_in_t in;
+	gck_out_t out;
+	gc_graph_t G;
+	gc_par_t P;
+	in.n = n, in.list = d_list, in.a_off = d_a_off, in.nu = d_nu, in.nb = d_nb, in.u = d_u, in.b = d_b, in.mini_off = d_mini_off, in.mini = d_mini;
+	in.q_off = d_q_off, in.seq = d_seq, in.hash = d_hash;
+	out.hdr = d_hdr, out.ga = d_ga, out.gc_pool = (gc_rec_t*)d_gc_pool, out.gc_cap = gc_cap, out.lc_pool = d_lc_pool, out.lc_cap = lc_cap, out.ctl = d_ctl, out.retry = d_retry;
+	memset(&G, 0, sizeof G);
+	G.arc = (const gc_arc_t*)ix->d_arc, G.idx = ix->d_arc_idx, G.seg_len = ix->d_seg_len, G.es = 0, G.seq_fw = ix->d_gseq, G.seq_rc = ix->d_gseq_rc, G.seq_off = ix->d_gseq_off;
+	gc_par_from_opt(opt, k, pen_gap, &P);
+	mga_prof_begin(sc->stream, MGA_K_GCHAIN);
+	hipLaunchKernelGGL(k_gchain, dim3(waves), dim3(64), 0, (hipStream_t)sc->stream, in, out, G, P, (char*)arena->p, (int64_t)ab);
+	mga_prof_end(sc->stream, MGA_K_GCHAIN);
+	MGA_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+
+extern "C" size_t mga_gc_rec_bytes(void) { return sizeof(gc_rec_t); }
+
+// ---- flat records -> mg_gchains_t (host).  div (gchain1.c:299) and MAPQ (gcmisc.c:190-223) are computed here: they are the only
+// places of the path that go through libm (log, logf), which has to be the host's. ----
+static void gc_fill_public(mg_gchain_t *g, const gc_rec_t *r)
+{
+	memset(g, 0, sizeof *g);
+	g->id = r->id, g->parent = r->parent, g->off = r->off, g->cnt = r->cnt, g->n_anchor = r->n_anchor, g->score = r->score;
+	g->qs = r->qs, g->qe = r->qe, g->plen = r->plen, g->ps = r->ps, g->pe = r->pe, g->blen = r->blen, g->mlen = r->mlen;
+	g->hash = r->hash, g->subsc = r->subsc, g->n_sub = r->n_sub, g->flt = (uint32_t)r->flt;
+	g->div = -1.0f;
+	if (r->cnt > 0) { // ratio of minimizers spanned to minimizers chained, per base of a minimizer
+		const double ratio = r->n_mini >= r->n_anchor ? (double)r->n_mini / r->n_anchor : (double)r->n_anchor / r->n_mini;
+		g->div = (float)(log(ratio) / r->q_span);
+	}
+}
+
+static void gc_mapq(mg_gchains_t *gs, int qlen, int n_mz, int min_gc_score)
+{
+	if (gs->n_gc == 0) return;
+	const int cap_sc = qlen < 100 ? qlen : 100;
+	int cap_cnt = n_mz < 10 ? n_mz : 10;
+	if (cap_cnt < 5) cap_cnt = 5;
+	const float inv_sc = 1.0 / cap_sc, inv_cnt = 1.0 / cap_cnt;
+	int64_t prim_sum = 0;
+	for (int i = 0; i < gs->n_gc; ++i) if (gs->gc[i].parent == gs->gc[i].id) prim_sum += gs->gc[i].score;
+	const float uniq = (float)prim_sum / (prim_sum + gs->rep_len);
+	for (int i = 0; i < gs->n_gc; ++i) {
+		mg_gchain_t *r = &gs->gc[i];
+		int q = 0;
+		if (r->parent == r->id) {
+			const float by_score = (r->score > cap_sc ? 1.0f : r->score * inv_sc) * uniq;
+			const float by_cnt = r->n_anchor > cap_cnt ? 1.0f : r->n_anchor * inv_cnt;
+			const float pen = by_score < by_cnt ? by_score : by_cnt;
+			const int sub = r->subsc > min_gc_score ? r->subsc : min_gc_score;
+			const float x = (float)sub / r->score;
+			q = (int)(pen * 40.0f * (1.0f - x) * logf(r->score));
+			q -= (int)(4.343f * logf(r->n_sub + 1) + .499f);
+			if (q < 0) q = 0;
+			if (r->score > sub && q == 0) q = 1;
+			if (q > 60) q = 60;
+		}
+		r->mapq = (uint32_t)q;
+	}
+}
+
+extern "C" mg_gchains_t *mga_gchains_from_flat(int32_t n_gc, const void *gc_recs, int32_t n_lc, const mg_llchain_t *lc, int32_t n_a, const mg128_t *a,
+											   int32_t rep_len, int32_t qlen, int32_t n_mz, int32_t min_gc_score)
+{
+	mg_gchains_t *gs = (mg_gchains_t*)calloc(1, sizeof(mg_gchains_t));
+	const gc_rec_t *r = (const gc_rec_t*)gc_recs;
+	gs->rep_len = rep_len;
+	if (n_gc <= 0) return gs; // gchain1.c:460: a valid object without chains
+	gs->n_gc = n_gc, gs->n_lc = n_lc, gs->n_a = n_a;
+	gs->gc = (mg_gchain_t*)malloc((size_t)n_gc * sizeof(mg_gchain_t));
+	gs->lc = (mg_llchain_t*)malloc((size_t)(n_lc > 0 ? n_lc : 1) * sizeof(mg_llchain_t));
+	gs->a = (mg128_t*)malloc((size_t)(n_a > 0 ? n_a : 1) * sizeof(mg128_t));
+	for (int32_t i = 0; i < n_gc; ++i) gc_fill_public(&gs->gc[i], &r[i]);
+	memcpy(gs->lc, lc, (size_t)n_lc * sizeof(mg_llchain_t));
+	memcpy(gs->a, a, (size_t)n_a * sizeof(mg128_t));
+	gc_mapq(gs, qlen, n_mz, min_gc_score);
+	return gs;
+}
+
+// ---- the same routine on a host thread ----
+extern "C" mg_gchains_t *mga_gchain_host_read(const mg_idx_t *gi, const int32_t *seg_len, const mg_mapopt_t *opt, float pen_gap, int32_t qlen, uint32_t hash,
+											  int32_t n_u, const uint64_t *u, mg128_t *a, int32_t n_a, int32_t n_mini, const int32_t *mini_pos, const char *qseq,
+											  int32_t rep_len, int32_t n_mz, int32_t *n_gwfa, int32_t *n_shortk)
+{
+	static __thread char *t_mem = 0;
+	const int64_t first = 1 << 20;
+	gc_arena_t A;
+	gc_graph_t G;
+	gc_par_t P;
+	gc_read_t rd;
+	gc_result_t R;
+	if (t_mem == 0) t_mem = (char*)malloc((size_t)first);
+	gc_arena_init(&A, t_mem, first, 1);
+	memset(&G, 0, sizeof G);
+	G.arc = (const gc_arc_t*)gi->g->arc, G.idx = gi->g->idx, G.seg_len = seg_len, G.es = gi->es;
+	gc_par_from_opt(opt, gi->k, pen_gap, &P);
+	rd.qlen = qlen, rd.hash = hash, rd.n_u = n_u, rd.u = u, rd.a = a, rd.n_mini = n_mini, rd.mini_pos = mini_pos, rd.qseq = qseq;
+	R.a = (mg128_t*)malloc((size_t)(n_a > 0 ? n_a : 1) * sizeof(mg128_t));
+	int rc = gc_map_read(&A, &G, &P, &rd, &R);
+	if (rc != GC_OK) R.n_gc = R.n_lc = R.n_a = 0; // GC_E_BUG: no chains; GC_E_ARENA cannot happen on a growable arena short of malloc failing
+	mg_gchains_t *gs = mga_gchains_from_flat(R.n_gc, R.gc, R.n_lc, R.lc, R.n_a, R.a, rep_len, qlen, n_mz, opt->min_gc_score);
+	if (n_gwfa) *n_gwfa = R.n_gwfa;
+	if (n_shortk) *n_shortk = R.n_shortk;
+	free(R.a);
+	gc_arena_free_blocks(&A);
+	return gs;
+}
+
+// ---- stage-level host entry points over the same core (CPU parity tests against the reference's mg_shortest_k / gfa_ed_step) ----
+typedef struct { // mg_path_dst_t, mgpriv.h:40-52
+	uint32_t v;
+	int32_t target_dist;
+	uint32_t target_hash;
+	uint32_t meta:30, check_hash:1, inner:1;
+	int32_t qlen;
+	uint32_t n_path:31, is_0:1;
+	int32_t path_end;
+	int32_t dist;
+	uint32_t hash;
+} mga_path_dst_t;
+typedef struct { uint32_t v, d; int32_t pre; } mga_pathv_t; // mg_pathv_t, mgpriv.h:54-57
+
+static int32_t *gc_host_seg_len(const gfa_t *g)
+{
+	int32_t *len = (int32_t*)malloc((size_t)(g->n_seg + 1) * 4);
+	for (uint32_t s = 0; s < g->n_seg; ++s) len[s] = g->seg[s].len;
+	return len;
+}
+
+extern "C" mga_pathv_t *mga_shortest_k(const gfa_t *g, uint32_t src, int32_t n_dst, mga_path_dst_t *dst, int32_t max_dist, int32_t max_k, int32_t *n_pathv)
+{
+	gc_arena_t A;
+	gc_graph_t G;
+	gc_walkv_t *w = 0;
+	int32_t n_w = 0;
+	mga_pathv_t *ret = 0;
+	if (n_pathv) *n_pathv = 0;
+	if (n_dst <= 0) return 0;
+	int32_t *seg_len = gc_host_seg_len(g);
+	gc_dst_t *d = (gc_dst_t*)calloc((size_t)n_dst, sizeof(gc_dst_t));
+	gc_arena_init(&A, malloc(1 << 16), 1 << 16, 1);
+	char *first = A.base;
+	memset(&G, 0, sizeof G);
+	G.arc = (const gc_arc_t*)g->arc, G.idx = g->idx, G.seg_len = seg_len;
+	for (int32_t i = 0; i < n_dst; ++i) {
+		d[i].v = dst[i].v, d[i].target_dist = dst[i].target_dist, d[i].target_hash = dst[i].target_hash, d[i].meta = (int32_t)dst[i].meta;
+		d[i].check_hash = dst[i].check_hash, d[i].inner = dst[i].inner, d[i].n_path = (int32_t)dst[i].n_path, d[i].is_0 = dst[i].is_0;
+		d[i].path_end = dst[i].path_end, d[i].dist = dst[i].dist, d[i].hash = dst[i].hash;
+	}
+	const int rc = gc_shortest_k(&A, &G, src, n_dst, d, max_dist, max_k, n_pathv ? &w : 0, n_pathv ? &n_w : 0);
+	for (int32_t i = 0; i < n_dst; ++i) {
+		dst[i].n_path = (uint32_t)d[i].n_path, dst[i].is_0 = (uint32_t)d[i].is_0, dst[i].path_end = d[i].path_end, dst[i].dist = d[i].dist, dst[i].hash = d[i].hash;
+	}
+	if (rc == GC_OK && n_pathv && n_w > 0) {
+		ret = (mga_pathv_t*)malloc((size_t)n_w * sizeof(mga_pathv_t));
+		for (int32_t i = 0; i < n_w; ++i) ret[i].v = w[i].v, ret[i].d = w[i].d, ret[i].pre = w[i].pre;
+		*n_pathv = n_w;
+	}
+	gc_arena_free_blocks(&A);
+	free(first); free(d); free(seg_len);
+	return ret;
+}
+
+extern "C" int32_t mga_gwfa_bridge(const gfa_t *g, const gfa_edseq_t *es, int32_t ql, const char *q, uint32_t v0, int32_t off0, uint32_t v1, int32_t off1,
+								   int32_t max_lag, int32_t s_term, int32_t **path, int32_t *nv)
+{
+	gc_arena_t A;
+	gc_graph_t G;
+	int32_t ed = -1, *p = 0, n = 0;
+	*path = 0, *nv = 0;
+	int32_t *seg_len = gc_host_seg_len(g);
+	gc_arena_init(&A, malloc(1 << 16), 1 << 16, 1);
+	char *first = A.base;
+	memset(&G, 0, sizeof G);
+	G.arc = (const gc_arc_t*)g->arc, G.idx = g->idx, G.seg_len = seg_len, G.es = es;
+	if (gc_gwfa(&A, &G, ql, q, v0, off0, v1, off1, max_lag, s_term, &ed, &p, &n) != GC_OK) ed = -1, n = 0;
+	if (n > 0) { *path = (int32_t*)malloc((size_t)n * 4); memcpy(*path, p, (size_t)n * 4); *nv = n; }
+	gc_arena_free_blocks(&A);
+	free(first); free(seg_len);
+	return ed;
+}
+
+extern "C" void mg_gchain_free(mg_gchains_t *gs) // mgpriv.h:101 / gchain1.c:522-535: everything is malloc-owned (km == NULL)
+{
+	if (gs == 0) return;
+	for (int32_t i = 0; i < gs->n_gc; ++i) { free(gs->gc[i].p); free(gs->gc[i].ds.ds); free(gs->gc[i].ds.off); }
+	free(gs->gc); free(gs->a); free(gs->lc);
+	free(gs);
+}

@@ -110,6 +110,7 @@ struct mga_batch_s {
 	const mg128_t *a;
 	int a_is_raw;
 	struct rq_read_s *rq;   /* a_is_raw: per-read state of the phased RMQ chaining (see rq_* below) */
+	int32_t *seg_len;       /* segment lengths as a flat array (the graph view of gc_core.h on the host) */
 	const int32_t *rescue_flag; /* per read: what the chaining kernel did about the long-join rescue (NULL: decide here) */
 	/* stage-2 inputs */
 	mga_cigsrc_t src;
@@ -282,11 +283,10 @@ static void chain_worker(void *data, int64_t i, int tid)
 	const int qlen = b->qlens[i];
 	const char *seq = b->seqs[i], *qname = b->qnames ? b->qnames[i] : 0;
 	uint32_t hash;
-	int32_t n_lc = 0, n_gc, k;
+	int32_t n_lc = 0, k;
 	int64_t n_a = 0;
-	uint64_t *u = 0, *u2 = 0;
+	uint64_t *u = 0;
 	mg128_t *a = 0;
-	mg_lchain_t *lc = 0;
 	mg_gchains_t *gcs;
 
 	int64_t tc = cpu_now();
@@ -326,28 +326,17 @@ do_rescue:;
 		}
 	}
 	CPU_ADD(C_LCRESCUE, tc);
-	if (n_lc) { /* map-algo.c:423-448 */
+	{ /* chain records, clean-up, graph chaining, bridging, ordering and filters: gc_core.h on this host thread (map-algo.c:422-474) */
 		const int32_t *mini = b->mini_pos + b->mini_off[i];
 		const int32_t n_mini = (int32_t)(b->mini_off[i + 1] - b->mini_off[i]);
-		lc = mga_lchain_gen(hash, qlen, n_lc, u, a);
-		if (n_lc > 1) n_lc = mga_lchain_cleanup(opt, n_lc, lc, a);
-		for (k = 0; k < n_lc; ++k) mga_update_anchors(lc[k].cnt, &a[lc[k].off], n_mini, mini);
+		int64_t n_anchor = 0;
+		for (k = 0; k < n_lc; ++k) n_anchor += (int32_t)u[k];
+		gcs = mga_gchain_host_read(gi, b->seg_len, opt, b->pen_gap, qlen, hash, n_lc, u, a, (int32_t)n_anchor, n_mini, mini, seq, b->rep_len[i], b->n_mz[i], 0, 0);
 	}
 	free(u); u = 0;
-	CPU_ADD(C_LCPREP, tc);
-	n_gc = mga_gchain1_dp(gi->g, &n_lc, lc, qlen, opt->bw_long, opt->bw_long, opt->bw_long, opt->max_gc_skip, opt->ref_bonus,
-						  b->pen_gap, b->pen_skip, opt->mask_level, a, &u2);
-	CPU_ADD(C_GCDP, tc);
-	gcs = mga_gchain_gen(gi->g, gi->es, n_gc, u2, lc, a, hash, opt->min_gc_cnt, opt->min_gc_score, opt->gdp_max_ed, 1, seq);
-	gcs->rep_len = b->rep_len[i];
-	free(a); free(lc); free(u2);
+	free(a);
 	CPU_ADD(C_GCGEN, tc);
-	mga_gchain_set_parent(opt->mask_level, gcs->n_gc, gcs->gc, opt->sub_diff, 0);
-	mga_gchain_flt_sub(opt->pri_ratio, gi->k * 2, opt->best_n, gcs->n_gc, gcs->gc);
-	mga_gchain_drop_flt(gcs);
-	mga_gchain_set_mapq(gcs, qlen, b->n_mz[i], opt->min_gc_score);
 	b->gcs[i] = gcs;
-	CPU_ADD(C_GCPOST, tc);
 	if (opt->flag & MG_M_CIGAR) { /* list the gaps of every chain for the WFA kernel */
 		read_plan_t *pl = &b->plan[i];
 		mga_tpool_t *tp = &b->tp[tid];
@@ -392,6 +381,7 @@ int mga_batch_chain(mga_batch_t *b, const int32_t *n_mz, const int32_t *rep_len,
 					const int32_t *nu, const int32_t *nb, const uint64_t *u, const mg128_t *a, const int64_t *a_off, int a_is_raw, const int32_t *rescue_flag)
 {
 	int t;
+	if (b->seg_len == 0) { uint32_t s_; b->seg_len = MGA_MALLOC(int32_t, b->gi->g->n_seg + 1); for (s_ = 0; s_ < b->gi->g->n_seg; ++s_) b->seg_len[s_] = b->gi->g->seg[s_].len; }
 	b->rescue_flag = rescue_flag;
 	b->n_mz = n_mz, b->rep_len = rep_len, b->mini_pos = mini_pos, b->mini_off = mini_off;
 	b->nu = nu, b->nb = nb, b->u = u, b->a = a, b->a_off = a_off, b->a_is_raw = a_is_raw;
@@ -524,6 +514,7 @@ void mga_batch_destroy(mga_batch_t *b)
 	for (i = 0; i < b->n; ++i) { free(b->plan[i].item_off); free(b->plan[i].chain_id); }
 	for (i = 0; i < b->n_threads; ++i) tpool_put(&b->tp[i]);
 	if (b->gcs) { for (i = 0; i < b->n; ++i) mg_gchain_free(b->gcs[i]); free(b->gcs); }
+	free(b->seg_len);
 	free(b->plan); free(b->tp); free(b->tp_prob_base); free(b->tp_t_base); free(b->tp_item_base); free(b->tp_chain_base); free(b->tp_vert_base);
 	free(b);
 }

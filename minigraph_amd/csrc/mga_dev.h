@@ -44,6 +44,7 @@ typedef struct mga_sctx_s {
 	void *ev_ready, *ev_done[10];
 	void *ev_sync;             /* event behind mga_ssync() */
 	void *stage;               /* pinned staging for small device-to-host read-backs, delivered by mga_ssync() */
+	mga_dbuf_t gc_arena[2];    /* per-wave scratch arenas of k_gchain: 1 MiB x resident waves, and the large tier for the reads that outgrow that */
 	int wfa_uncapped;          /* set while the ladder runs the chained fallback's sub-problems: no 1e8-cell cap, unbounded last tier */
 	mga_dbuf_t fb_prob, fb_res; /* sub-problems of the chained fallback and their results */
 } mga_sctx_t;
@@ -65,7 +66,7 @@ int  mga_hbuf_reserve(mga_hbuf_t *b, size_t bytes);
 void mga_hbuf_free(mga_hbuf_t *b);
 
 /* per-kernel HIP-event timing on the launch stream (bench.py reads it through mga_prof_get) */
-enum { MGA_K_SKETCH = 0, MGA_K_SEED_COUNT, MGA_K_SEED_FILL, MGA_K_LCHAIN, MGA_K_WFA0 /* +tier: 0-2 single-wave register tiers (band 64,128,192), 3-6 multi-wave register tiers (256..2048), 7-8 HBM tiers */, MGA_K_SCAN = MGA_K_WFA0 + 9, MGA_K_TEXT, MGA_K_N };
+enum { MGA_K_SKETCH = 0, MGA_K_SEED_COUNT, MGA_K_SEED_FILL, MGA_K_LCHAIN, MGA_K_WFA0 /* +tier: 0-2 single-wave register tiers (band 64,128,192), 3-6 multi-wave register tiers (256..2048), 7-8 HBM tiers */, MGA_K_SCAN = MGA_K_WFA0 + 9, MGA_K_TEXT, MGA_K_GCHAIN, MGA_K_N };
 #define MGA_WFA_N_TIER 9
 #define MGA_WFA_MAX_TIER 10 /* array size of the per-tier resources */
 void mga_prof_enable(int on);
@@ -98,6 +99,10 @@ typedef struct {
 	int32_t *d_seg_len;      /* n_seg segment lengths */
 	char *d_gseq;            /* forward segment sequences back to back (text kernel: target bases of ds:Z) */
 	int64_t *d_gseq_off;     /* n_seg + 1 offsets into d_gseq */
+	/* graph replica for chaining on the device (k_gchain.hip): arcs in the host's order (gfa_arc_t[]), per-vertex arc index, reverse complements */
+	void *d_arc;
+	uint64_t *d_arc_idx;
+	char *d_gseq_rc;         /* reverse complement of every segment at the same offsets as d_gseq */
 } mga_didx_t;
 
 /* collect_matches (map-algo.c:58-91), pass 1: probe every minimizer.  Flat per-minimizer outputs
@@ -184,6 +189,26 @@ int mga_dev_text_tables(const unsigned char *comp, const unsigned char *nt4); /*
 int mga_dev_text(mga_sctx_t *sc, int n_chain, const mga_txt_chain_t *d_chain, const mga_cigitem_t *d_item, int64_t n_vert, const uint32_t *d_vert,
 				 const mga_didx_t *ix, const char *d_reads, int64_t n_el_max, const int32_t *d_ncig, const int64_t *d_cigoff, const uint32_t *d_ord,
 				 mga_txt_res_t *d_res, char *d_pool, int64_t pool_cap, unsigned long long *d_pool_used);
+
+/* ---- graph chaining on the device (k_gchain.hip, gc_core.h): from the chains of k_lchain to filtered graph chains ---- */
+typedef struct { int32_t n_gc, n_lc, n_a, status; int64_t gc_off, lc_off; } mga_gc_hdr_t; /* per read: records at gc_pool + gc_off, lc_pool + lc_off, anchors at ga + a_off[i] */
+#define MGA_GC_E_POOL 3   /* status: the chunk's record pools were too small: grow and re-run the listed reads */
+int mga_dev_graph_upload(mga_sctx_t *sc, const gfa_t *g, const unsigned char *comp, mga_didx_t *ix); /* arcs, arc index, reverse complements -> HBM */
+size_t mga_gc_rec_bytes(void);
+size_t mga_dev_gchain_arena_bytes(int tier);
+int mga_dev_gchain_waves(int tier);
+int mga_dev_gchain(mga_sctx_t *sc, const mga_didx_t *ix, const mg_mapopt_t *opt, int k, float pen_gap, int n, const int32_t *d_list, int tier,
+				   const int64_t *d_a_off, const int32_t *d_nu, const int32_t *d_nb, const uint64_t *d_u, const mg128_t *d_b,
+				   const int64_t *d_mini_off, const int32_t *d_mini, const int64_t *d_q_off, const char *d_seq, const uint32_t *d_hash,
+				   mga_gc_hdr_t *d_hdr, mg128_t *d_ga, void *d_gc_pool, int64_t gc_cap, mg_llchain_t *d_lc_pool, int64_t lc_cap,
+				   unsigned long long *d_ctl, int32_t *d_retry);
+/* flat records of one read -> a malloc'ed mg_gchains_t (div and MAPQ computed here, on the host's libm) */
+mg_gchains_t *mga_gchains_from_flat(int32_t n_gc, const void *gc_recs, int32_t n_lc, const mg_llchain_t *lc, int32_t n_a, const mg128_t *a,
+									int32_t rep_len, int32_t qlen, int32_t n_mz, int32_t min_gc_score);
+/* the same routine on a host thread (gc_core.h compiled for the host): -x asm, CPU parity tests.  a[] is modified. */
+mg_gchains_t *mga_gchain_host_read(const mg_idx_t *gi, const int32_t *seg_len, const mg_mapopt_t *opt, float pen_gap, int32_t qlen, uint32_t hash,
+								   int32_t n_u, const uint64_t *u, mg128_t *a, int32_t n_a, int32_t n_mini, const int32_t *mini_pos, const char *qseq,
+								   int32_t rep_len, int32_t n_mz, int32_t *n_gwfa, int32_t *n_shortk);
 
 /* CIGARs of all problems copied into problem order: d_ncig[i] operators at d_ord + d_off[i] (d_off has n+1 entries); *h_total = d_off[n] */
 int mga_dev_wfa_gather(mga_sctx_t *sc, int n, const mga_wfa_res_t *d_res, const uint32_t *d_pool, int32_t *d_ncig, int64_t *d_off, uint32_t *d_ord,

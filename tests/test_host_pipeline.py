@@ -51,3 +51,60 @@ def test_asm_preset_host_phases_vs_reference_binary(cigar):
     want, occ, lco = hp.run_reference(graph, reads, cigar=cigar, preset="asm")
     got, _ = hp.map_with_oracle_stages(graph, reads, occ, lco, cigar=cigar, preset="asm")
     assert got == want
+
+
+def _mutate(rng, s, rate):
+    import numpy as np
+    out = bytearray()
+    for ch in s:
+        u = rng.random()
+        if u < rate * 0.4:
+            out.append(int(rng.choice([c for c in b"ACGT" if c != ch])))
+        elif u < rate * 0.7:
+            out.append(int(rng.choice(list(b"ACGT"))))
+            out.append(ch)
+        elif u < rate:
+            pass
+        else:
+            out.append(ch)
+    return bytes(out)
+
+
+@pytest.mark.skipif(not os.path.exists(rb.REF_BIN), reason="oracle/_ref/minigraph not built")
+def test_graph_chaining_core_many_reads_five_haplotypes():
+    """gc_core.h on the host (chain records, clean-up, DP + shortest walks, GWFA / walk bridging, ordering, parents, filters) over 500 reads
+    that cross ~1.5 bubbles each on a 5-haplotype graph; no CIGAR, so the oracle's Python WFA loop does not dominate the test"""
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "3000000", "-H", "5", "-n", "500", "-l", "12000", "-s", "41"], stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    want, occ, lco = hp.run_reference(graph, reads, cigar=False)
+    got, _ = hp.map_with_oracle_stages(graph, reads, occ, lco, cigar=False)
+    assert got == want
+    assert sum(1 for l in want.split(b"\n") if l.count(b">") + l.count(b"<") >= 3) > 50   # walks over several segments (through alt alleles: not compacted into one stable interval) were really bridged
+
+
+@pytest.mark.skipif(not os.path.exists(rb.REF_BIN), reason="oracle/_ref/minigraph not built")
+def test_graph_chaining_core_repeats_secondaries():
+    """two chromosomes sharing a 2 %-diverged 40 kb stretch: several graph chains per read, parents / secondaries / sub-scores / MAPQ < 60"""
+    import numpy as np
+    rng = np.random.default_rng(23)
+    d = tempfile.mkdtemp()
+    rnd = lambda n: bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n).tobytes())
+    a = rnd(200000)
+    b = rnd(100000) + _mutate(rng, a[50000:90000], 0.02) + rnd(50000)
+    graph, reads = os.path.join(d, "rep.fa"), os.path.join(d, "rep.reads.fa")
+    open(graph, "wb").write(b">chrA\n" + a + b"\n>chrB\n" + b + b"\n")
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    with open(reads, "wb") as f:
+        for i in range(60):
+            src, lo = (a, 45000) if i % 2 == 0 else (b, 95000)
+            st = int(rng.integers(lo, lo + 40000))
+            r = _mutate(rng, src[st:st + 8000], 0.08)
+            if i % 3 == 0:
+                r = r.translate(comp)[::-1]
+            f.write(b">q%d\n%s\n" % (i, r))
+    want, occ, lco = hp.run_reference(graph, reads, cigar=False)
+    got, _ = hp.map_with_oracle_stages(graph, reads, occ, lco, cigar=False)
+    assert got == want
+    mapqs = [int(l.split(b"\t")[11]) for l in want.split(b"\n") if l]
+    assert min(mapqs) < 60 and max(mapqs) == 60   # sub-optimal chains pulled some MAPQs down
