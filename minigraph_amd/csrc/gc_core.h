@@ -36,6 +36,9 @@
 #define GC_HD static inline
 #endif
 
+#ifndef GC_PARSORT
+#define GC_PARSORT 7   /* which parts of gc_diag_sort are split over the lanes (1 split, 2 sort fill, 4 merge): a debugging aid */
+#endif
 #define GC_OK        0
 #define GC_E_ARENA   1   /* ran out of arena: re-run in a larger one */
 #define GC_E_BUG     2   /* the "logical bug" exit of the shortest-walk search (shortk.c:182-186): the read gets no chains, as in the reference */
@@ -43,16 +46,25 @@
 /* ------------------------------------------------------------------------------------------------ arena */
 
 typedef struct gc_block_s { struct gc_block_s *prev; int64_t cap; } gc_block_t;
-typedef struct {
+typedef struct gc_arena_s {
 	char *base;          /* current block */
 	int64_t top, cap;
 	int32_t ovf;         /* set once an allocation failed (device: fixed capacity) */
 	int32_t growable;    /* host: chain further malloc'ed blocks instead of failing */
 	gc_block_t *blocks;  /* host: extra blocks, newest first */
 	int64_t peak;
+	unsigned long long *ticks; long long tick_last; /* profiling (device): cycles between consecutive GC_TICKs, summed per stage; NULL = off */
+	char *fast_base; int64_t fast_cap; /* device: a small block of LDS for the scratch of ONE graph search / GWFA call at a time (a tenth of the latency
+	                          * of HBM); a call that outgrows it is simply run again in the main arena.  NULL: everything in the main arena */
 } gc_arena_t;
 
-GC_HD void gc_arena_init(gc_arena_t *A, void *mem, int64_t cap, int growable) { A->base = (char*)mem, A->top = 0, A->cap = cap, A->ovf = 0, A->growable = growable, A->blocks = 0, A->peak = 0; }
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GC_TICK(A, id) do { if ((A)->ticks && (threadIdx.x & 63) == 0) { const long long now_ = (long long)clock64(); atomicAdd(&(A)->ticks[id], (unsigned long long)(now_ - (A)->tick_last)); (A)->tick_last = now_; } } while (0)
+#else
+#define GC_TICK(A, id) ((void)0)
+#endif
+
+GC_HD void gc_arena_init(gc_arena_t *A, void *mem, int64_t cap, int growable) { A->base = (char*)mem, A->top = 0, A->cap = cap, A->ovf = 0, A->growable = growable, A->blocks = 0, A->peak = 0, A->ticks = 0, A->tick_last = 0, A->fast_base = 0, A->fast_cap = 0; }
 
 GC_HD void *gc_alloc(gc_arena_t *A, int64_t bytes)
 {
@@ -88,6 +100,53 @@ GC_HD void gc_move(void *dst, const void *src, int64_t bytes)
 	else for (int64_t i = n - 1; i >= 0; --i) d[i] = s[i];
 }
 
+/* ------------------------------------------------------------------------------------------------ execution model
+ * On the device the routine runs REPLICATED on the 64 lanes of a wavefront: every lane executes the same control flow on the same
+ * values (scalar state lives in identical private copies, memory is shared, stores of identical values to one address are benign),
+ * so the hot per-element loops can be handed to the lanes -- 64 independent loads in flight instead of one dependent chain --
+ * with a wavefront-scope fence between a loop and the code that reads what it wrote.  Order-preserving appends use ballots.
+ * On the host the same code runs with one lane. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GC_LANE ((int32_t)(threadIdx.x & 63))
+#define GC_NLANE 64
+GC_HD void gc_sync(void) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+GC_HD uint64_t gc_ballot(int pred) { return __ballot(pred); }
+GC_HD int32_t gc_rank(uint64_t mask) { return (int32_t)__popcll(mask & ((1ULL << (threadIdx.x & 63)) - 1ULL)); } /* set bits below this lane */
+GC_HD int32_t gc_popc(uint64_t mask) { return (int32_t)__popcll(mask); }
+#else
+#define GC_LANE 0
+#define GC_NLANE 1
+GC_HD void gc_sync(void) {}
+GC_HD uint64_t gc_ballot(int pred) { return pred ? 1ULL : 0ULL; }
+GC_HD int32_t gc_rank(uint64_t mask) { (void)mask; return 0; }
+GC_HD int32_t gc_popc(uint64_t mask) { return (int32_t)(mask & 1ULL); }
+#endif
+#define GC_PAR_FOR(i, n) for (int32_t i = GC_LANE; i < (n); i += GC_NLANE)   /* no allocation, no gc_sync() inside */
+
+/* non-overlapping copy in 4-byte units by all lanes */
+GC_HD void gc_pcopy(void *dst, const void *src, int64_t bytes)
+{
+	uint32_t *d = (uint32_t*)dst;
+	const uint32_t *s = (const uint32_t*)src;
+	for (int64_t i = GC_LANE, n = bytes >> 2; i < n; i += GC_NLANE) d[i] = s[i];
+	gc_sync();
+}
+/* move to a LOWER address (dst <= src), regions may overlap: block by block, every block loaded by all lanes before it is stored */
+GC_HD void gc_pmove_down(void *dst, const void *src, int64_t bytes)
+{
+	uint32_t *d = (uint32_t*)dst;
+	const uint32_t *s = (const uint32_t*)src;
+	const int64_t n = bytes >> 2;
+	if (d == s) return;
+	for (int64_t b = 0; b < n; b += GC_NLANE) {
+		const int64_t i = b + GC_LANE;
+		const uint32_t v = i < n ? s[i] : 0;
+		gc_sync();
+		if (i < n) d[i] = v;
+		gc_sync();
+	}
+}
+
 /* growable array in the arena: {a, n, m}; growth re-allocates at the top (in place when the array is the last allocation) */
 #define GC_VEC(T) struct { T *a; int32_t n, m; }
 #define gc_vec_zero(v) ((v).a = 0, (v).n = (v).m = 0)
@@ -105,7 +164,7 @@ GC_HD int gc_vec_grow_(gc_arena_t *A, void **pa, int32_t *pm, int32_t n_used, in
 	}
 	char *p = (char*)gc_alloc(A, (int64_t)m * esz);
 	if (p == 0) return GC_E_ARENA;
-	if (old && n_used > 0) memcpy(p, old, (size_t)n_used * esz);
+	if (old && n_used > 0) gc_pcopy(p, old, (((int64_t)n_used * esz) + 3) & ~(int64_t)3); /* (allocations are 16-byte multiples: rounding up stays inside) */
 	*pa = p, *pm = m;
 	return GC_OK;
 }
@@ -444,21 +503,23 @@ GC_HD int gc_clean_chains(gc_arena_t *A, const gc_par_t *P, mg128_t *a, gc_chain
 	return GC_OK;
 }
 
-/* anchor.x high word := rank of the anchor's minimizer among the read's kept minimizers (lchain.c:410-441) */
+/* anchor.x high word := rank of the anchor's minimizer among the read's kept minimizers (lchain.c:410-441).  The reference walks the two
+ * ascending lists side by side; query positions are strictly ascending in both, so a binary search per anchor finds the same rank. */
 GC_HD int gc_index_anchors(mg128_t *a, int32_t n_a, const int32_t *mini_pos, int32_t n_mini)
 {
-	if (n_a <= 0) return GC_OK;
-	int32_t lo = 0, hi = n_mini - 1, st = -1;
-	const int32_t x = GC_AY(a[0]);
-	while (lo <= hi) {
-		const int32_t mid = (int32_t)(((uint32_t)lo + (uint32_t)hi) >> 1), y = mini_pos[mid];
-		if (y < x) lo = mid + 1; else if (y > x) hi = mid - 1; else { st = mid; break; }
+	int bad = 0;
+	GC_PAR_FOR(k, n_a) {
+		const int32_t x = GC_AY(a[k]);
+		int32_t lo = 0, hi = n_mini - 1, at = -1;
+		while (lo <= hi) {
+			const int32_t mid = (int32_t)(((uint32_t)lo + (uint32_t)hi) >> 1), y = mini_pos[mid];
+			if (y < x) lo = mid + 1; else if (y > x) hi = mid - 1; else { at = mid; break; }
+		}
+		if (at < 0) bad = 1;
+		else a[k].x = (uint64_t)at << 32 | (a[k].x & 0xffffffffU);
 	}
-	if (st < 0) return GC_E_BUG;
-	int32_t k = 0;
-	for (int32_t j = st; j < n_mini && k < n_a; ++j)
-		if (GC_AY(a[k]) == mini_pos[j]) a[k].x = (uint64_t)j << 32 | (a[k].x & 0xffffffffU), ++k;
-	return k == n_a ? GC_OK : GC_E_BUG;
+	gc_sync();
+	return gc_ballot(bad) ? GC_E_BUG : GC_OK;
 }
 
 /* ------------------------------------------------------------------------------------------------ shortest walks */
@@ -892,7 +953,9 @@ GC_HD int gc_chain_dp(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, int
 		}
 		{ /* reachability + distance through the graph, no sequences involved */
 			const int64_t mark = A->top;
-			const int rc = gc_shortest_k(A, G, ci->v ^ 1, cand.n, cand.a, max_dist_g + (gc_vlen(G, ci->v) - ci->rs), MG_MAX_SHORT_K, 0, 0);
+			int rc = GC_E_ARENA;
+			if (A->fast_base) { gc_arena_t F; gc_arena_init(&F, A->fast_base, A->fast_cap, 0); rc = gc_shortest_k(&F, G, ci->v ^ 1, cand.n, cand.a, max_dist_g + (gc_vlen(G, ci->v) - ci->rs), MG_MAX_SHORT_K, 0, 0); }
+			if (rc == GC_E_ARENA) rc = gc_shortest_k(A, G, ci->v ^ 1, cand.n, cand.a, max_dist_g + (gc_vlen(G, ci->v) - ci->rs), MG_MAX_SHORT_K, 0, 0);
 			if (rc == GC_E_ARENA) return rc; /* (GC_E_BUG: the search stopped early, what it had found stands -- the reference tears its allocator down there) */
 			A->top = mark; /* the search's scratch; cand was allocated before it */
 			++*n_shortk;
@@ -958,7 +1021,7 @@ GC_HD int gc_u64map_put(gc_arena_t *A, gc_u64map_t *h, uint64_t key, int32_t **v
 	*val = &h->v[i];
 	return GC_OK;
 }
-GC_HD void gc_u64map_clear(gc_u64map_t *h) { for (uint32_t j = 0; j < h->cap; ++j) h->k[j] = ~0ULL; h->cnt = 0; }
+GC_HD void gc_u64map_clear(gc_u64map_t *h) { GC_PAR_FOR(j, (int32_t)h->cap) h->k[j] = ~0ULL; gc_sync(); h->cnt = 0; }
 
 typedef struct {
 	const gc_graph_t *G;
@@ -1036,44 +1099,109 @@ GC_HD int32_t gc_intv_merge(int32_t n, gc_intv_t *a) /* gfa-ed.c:69-82 */
 	a[k].vd0 = st, a[k++].vd1 = en;
 	return k;
 }
-/* sort a[] by vd: in-order cells keep their place, the flagged subset goes through the klib sort, stable merge (gfa-ed.c:143-171) */
+/* sort a[] by vd: in-order cells keep their place, the flagged subset goes through the klib sort, stable merge (gfa-ed.c:143-171).
+ * The split and the merge are done by rank -- an element's place is its own index plus the number of elements of the OTHER list that go
+ * in front of it (ties: the in-order list first), found by binary search -- so every lane moves its own elements. */
 GC_HD int gc_diag_sort(gc_arena_t *A, gc_gw_t *z, int32_t n_a, gc_diag_t *a)
 {
 	int32_t n_c = 0;
 	GC_TRY(gc_vec_reserve(A, z->ooo, n_a));
+#if (GC_PARSORT & 1)
+	for (int32_t base = 0; base < n_a; base += GC_NLANE) { const int32_t i = base + GC_LANE; n_c += gc_popc(gc_ballot(i < n_a && (a[i].xo & 1))); }
+#else
 	for (int32_t i = 0; i < n_a; ++i) n_c += a[i].xo & 1;
+#endif
 	const int32_t n_b = n_a - n_c;
 	gc_diag_t *b = z->ooo.a, *c = b + n_b;
+#if (GC_PARSORT & 1)
+	for (int32_t base = 0, kb = 0, kc = 0; base < n_a; base += GC_NLANE) {
+		const int32_t i = base + GC_LANE;
+		const int in = i < n_a, flag = in && (a[i].xo & 1);
+		const uint64_t mb = gc_ballot(in && !flag), mc = gc_ballot(flag);
+		if (in) { if (flag) c[kc + gc_rank(mc)] = a[i]; else b[kb + gc_rank(mb)] = a[i]; }
+		kb += gc_popc(mb), kc += gc_popc(mc);
+	}
+	gc_sync();
+#else
 	for (int32_t i = 0, j = 0, k = 0; i < n_a; ++i) { if (a[i].xo & 1) c[k++] = a[i]; else b[j++] = a[i]; }
+#endif
 	if (n_c > 1) {
 		if (z->m_sort < n_c) {
 			z->m_sort = n_c + (n_c >> 1) + 16;
 			GC_ALLOC(A, gc_kv_t, z->sort_kv, z->m_sort);
 			GC_ALLOC(A, gc_diag_t, z->sort_tmp, z->m_sort);
 		}
+#if (GC_PARSORT & 2)
+		GC_PAR_FOR(i, n_c) z->sort_kv[i].key = c[i].vd, z->sort_kv[i].val = (uint64_t)i;
+		gc_sync();
+		GC_TRY(gc_ksort(A, z->sort_kv, n_c, 8));
+		GC_PAR_FOR(i, n_c) z->sort_tmp[i] = c[z->sort_kv[i].val];
+		gc_sync();
+		GC_PAR_FOR(i, n_c) c[i] = z->sort_tmp[i];
+		gc_sync();
+#elif (GC_PARSORT & 8)
+		for (int32_t i = 0; i < n_c; ++i) z->sort_kv[i].key = c[i].vd, z->sort_kv[i].val = (uint64_t)i;
+		GC_TRY(gc_ksort(A, z->sort_kv, n_c, 8));
+		gc_sync();
+		GC_PAR_FOR(i, n_c) z->sort_tmp[i] = c[z->sort_kv[i].val];
+		gc_sync();
+		GC_PAR_FOR(i, n_c) c[i] = z->sort_tmp[i];
+		gc_sync();
+#else
 		for (int32_t i = 0; i < n_c; ++i) z->sort_kv[i].key = c[i].vd, z->sort_kv[i].val = (uint64_t)i;
 		GC_TRY(gc_ksort(A, z->sort_kv, n_c, 8));
 		for (int32_t i = 0; i < n_c; ++i) z->sort_tmp[i] = c[z->sort_kv[i].val];
 		memcpy(c, z->sort_tmp, (size_t)n_c * sizeof(gc_diag_t));
+#endif
 	}
+#if (GC_PARSORT & 4)
+	GC_PAR_FOR(k, n_c) c[k].xo &= 0xfffffffeU;
+	int b_unsorted = 0;
+	GC_PAR_FOR(i, n_b) if (i > 0 && b[i - 1].vd > b[i].vd) b_unsorted = 1;
+	gc_sync();
+	if (!gc_ballot(b_unsorted)) {
+		GC_PAR_FOR(i, n_b) { /* b[i] goes behind the c's that are strictly smaller */
+			const uint64_t vd = b[i].vd;
+			int32_t lo = 0, hi = n_c;
+			while (lo < hi) { const int32_t m = (lo + hi) >> 1; if (c[m].vd < vd) lo = m + 1; else hi = m; }
+			a[i + lo] = b[i];
+		}
+		GC_PAR_FOR(j, n_c) { /* c[j] goes behind the b's that are smaller or equal */
+			const uint64_t vd = c[j].vd;
+			int32_t lo = 0, hi = n_b;
+			while (lo < hi) { const int32_t m = (lo + hi) >> 1; if (b[m].vd <= vd) lo = m + 1; else hi = m; }
+			a[j + lo] = c[j];
+		}
+		gc_sync();
+		return GC_OK;
+	}
+#else
 	for (int32_t k = 0; k < n_c; ++k) c[k].xo &= 0xfffffffeU;
-	int32_t i = 0, j = 0, k = 0;
-	while (i < n_b && j < n_c) { if (b[i].vd <= c[j].vd) a[k++] = b[i++]; else a[k++] = c[j++]; }
-	while (i < n_b) a[k++] = b[i++];
-	while (j < n_c) a[k++] = c[j++];
+#endif
+	{ /* sequential stable merge (with in-order cells that are not in order -- never seen -- it is what the reference would do) */
+		int32_t i = 0, j = 0, k = 0;
+		while (i < n_b && j < n_c) { if (b[i].vd <= c[j].vd) a[k++] = b[i++]; else a[k++] = c[j++]; }
+		while (i < n_b) a[k++] = b[i++];
+		while (j < n_c) a[k++] = c[j++];
+	}
 	return GC_OK;
 }
+/* in-place, order-preserving removal of the elements of a[0..n) that `drop` marks; the verdict of element i is computed by the lane that
+ * owns it, a ballot gives every kept element its new place.  dst <= src, and a block is loaded completely before it is stored. */
+#define GC_COMPACT_BEGIN(n_) { const int32_t gcn_ = (n_); int32_t gcm_ = 0; for (int32_t gcb_ = 0; gcb_ < gcn_; gcb_ += GC_NLANE) { const int32_t gci_ = gcb_ + GC_LANE; const int gcin_ = gci_ < gcn_;
+#define GC_COMPACT_END(a_, val_, keep_, n_out_) const uint64_t gck_ = gc_ballot(gcin_ && (keep_)); gc_sync(); if (gcin_ && (keep_)) (a_)[gcm_ + gc_rank(gck_)] = (val_); gcm_ += gc_popc(gck_); gc_sync(); } (n_out_) = gcm_; }
+
 GC_HD int gc_gw_dedup(gc_arena_t *A, gc_gw_t *z, int32_t *n_a_, gc_diag_t *a) /* gwf_dedup, gfa-ed.c:258-271 */
 {
 	int32_t n_a = *n_a_;
-	if (z->done.n + z->fresh.n > 0) {
+	if (z->fresh.n > 0) { /* (nothing new this step: the merged list stays what it is) */
 		int sorted = 1;
 		for (int32_t i = 1; i < z->fresh.n; ++i) if (z->fresh.a[i - 1].vd0 > z->fresh.a[i].vd0) { sorted = 0; break; }
 		if (!sorted) { /* ties are merged away below: any correct sort */
 			for (int32_t i = 1; i < z->fresh.n; ++i) { gc_intv_t t = z->fresh.a[i]; int32_t j = i; for (; j > 0 && t.vd0 < z->fresh.a[j - 1].vd0; --j) z->fresh.a[j] = z->fresh.a[j - 1]; z->fresh.a[j] = t; }
 		}
 		GC_TRY(gc_vec_reserve(A, z->swap, z->done.n + 1));
-		memcpy(z->swap.a, z->done.a, (size_t)z->done.n * sizeof(gc_intv_t)); z->swap.n = z->done.n;
+		gc_pcopy(z->swap.a, z->done.a, (int64_t)z->done.n * (int64_t)sizeof(gc_intv_t)); z->swap.n = z->done.n;
 		GC_TRY(gc_vec_reserve(A, z->done, z->done.n + z->fresh.n + 1));
 		int32_t ii = 0, jj = 0, kk = 0;
 		while (ii < z->swap.n && jj < z->fresh.n) {
@@ -1085,30 +1213,39 @@ GC_HD int gc_gw_dedup(gc_arena_t *A, gc_gw_t *z, int32_t *n_a_, gc_diag_t *a) /*
 		z->done.n = gc_intv_merge(kk, z->done.a);
 	}
 	{
-		int sorted = 1;
-		for (int32_t i = 1; i < n_a; ++i) if (a[i - 1].vd > a[i].vd) { sorted = 0; break; }
-		if (!sorted) GC_TRY(gc_diag_sort(A, z, n_a, a));
+		int unsorted = 0;
+		GC_PAR_FOR(i, n_a) if (i > 0 && a[i - 1].vd > a[i].vd) unsorted = 1;
+		if (gc_ballot(unsorted)) GC_TRY(gc_diag_sort(A, z, n_a, a));
 	}
-	int32_t n = 0;
-	for (int32_t i = 1, st = 0; i <= n_a; ++i) /* keep the furthest cell of every (vertex, diagonal): the first of equals */
-		if (i == n_a || a[i].vd != a[st].vd) {
-			int32_t max_j = st;
-			for (int32_t j = st + 1; j < i; ++j) if (a[max_j].k < a[j].k) max_j = j;
-			a[n++] = a[max_j];
-			st = i;
-		}
-	n_a = n;
-	if (z->done.n > 0) { /* drop cells on finished diagonals (gfa-ed.c:192-202) */
-		int32_t ii = 0, jj = 0, kk = 0;
+	/* keep the furthest cell of every (vertex, diagonal): the first of equals.  Groups are a handful of cells: every lane looks left and right
+	 * of its own cell inside the group and leaves its verdict in the cell's (otherwise unused here) len field; then the survivors close ranks */
+	GC_PAR_FOR(i, n_a) {
+		const uint64_t vd = a[i].vd;
+		const int32_t k = a[i].k;
+		int keep = 1;
+		for (int32_t j = i - 1; j >= 0 && a[j].vd == vd; --j) if (!(a[j].k < k)) { keep = 0; break; } /* an earlier cell at least as far */
+		if (keep) for (int32_t j = i + 1; j < n_a && a[j].vd == vd; ++j) if (k < a[j].k) { keep = 0; break; } /* a later cell strictly further */
+		a[i].len = keep;
+	}
+	gc_sync();
+	GC_COMPACT_BEGIN(n_a)
+		gc_diag_t me;
+		int keep = 0;
+		if (gcin_) { me = a[gci_]; keep = me.len; me.len = 0; }
+	GC_COMPACT_END(a, me, keep, n_a)
+	if (z->done.n > 0) { /* drop cells on finished diagonals (gfa-ed.c:192-202): the intervals are disjoint and ascending */
 		const int32_t n_b = z->done.n;
 		const gc_intv_t *b = z->done.a;
-		while (ii < n_a && jj < n_b) {
-			if (a[ii].vd >= b[jj].vd0 && a[ii].vd < b[jj].vd1) ++ii;
-			else if (a[ii].vd >= b[jj].vd1) ++jj;
-			else a[kk++] = a[ii++];
-		}
-		while (ii < n_a) a[kk++] = a[ii++];
-		n_a = kk;
+		GC_COMPACT_BEGIN(n_a)
+			gc_diag_t me;
+			int keep = 0;
+			if (gcin_) {
+				me = a[gci_];
+				int32_t lo = 0, hi = n_b; /* first interval whose end lies beyond the cell */
+				while (lo < hi) { const int32_t m = (lo + hi) >> 1; if (b[m].vd1 <= me.vd) lo = m + 1; else hi = m; }
+				keep = !(lo < n_b && me.vd >= b[lo].vd0);
+			}
+		GC_COMPACT_END(a, me, keep, n_a)
 	}
 	*n_a_ = n_a;
 	return GC_OK;
@@ -1128,57 +1265,63 @@ GC_HD int32_t gc_gw_prune(int32_t n_a, gc_diag_t *a, uint32_t max_lag, int32_t b
 	}
 	return j;
 }
-/* Landau-Vishkin over a run of adjacent diagonals on one vertex (gfa-ed.c:331-403) */
+/* Landau-Vishkin over a run of n adjacent diagonals on one vertex (gfa-ed.c:331-403): every diagonal is extended along its matches, then
+ * the next wavefront takes, per diagonal, the furthest of {insertion from the left neighbour, mismatch, deletion from the right neighbour};
+ * cells that reached the end of the vertex or of the query go to H (handled one by one by the caller).  One lane per diagonal. */
 GC_HD int gc_gw_extend_run(gc_arena_t *A, gc_gw_t *z, int32_t n, gc_diag_t *a, gc_diag_v *B, gc_diag_v *H)
 {
 	const uint32_t v = (uint32_t)(a->vd >> 32);
 	const int32_t vl = gc_vlen(z->G, v);
 	const char *ts = gc_vseq(z->G, v);
-	for (int32_t j = 0; j < n; ++j) {
-		const int32_t k = gc_extend1((int32_t)a[j].vd - GC_DSHIFT, a[j].k, vl, ts, z->ql, z->q);
-		a[j].len = k - a[j].k, a[j].xo += (uint32_t)a[j].len << 2, a[j].k = k;
-	}
 	GC_TRY(gc_vec_reserve(A, *B, B->n + n + 2));
+	GC_TRY(gc_vec_reserve(A, *H, H->n + n));
+	GC_TRY(gc_vec_reserve(A, z->fresh, z->fresh.n + n + 2));
+	GC_PAR_FOR(j, n) {
+		const int32_t k = gc_extend1((int32_t)a[j].vd - GC_DSHIFT, a[j].k, vl, ts, z->ql, z->q);
+		a[j].len = k - a[j].k, a[j].xo += (uint32_t)(k - a[j].k) << 2, a[j].k = k;
+	}
+	gc_sync();
 	gc_diag_t *b = &B->a[B->n];
-	b[0].vd = a[0].vd - 1, b[0].xo = a[0].xo + 2, b[0].k = a[0].k + 1, b[0].t = a[0].t;
-	{
-		const int first = n == 1 || a[0].k > a[1].k;
-		b[1].vd = a[0].vd, b[1].xo = first ? a[0].xo + 4 : a[1].xo + 2, b[1].t = first ? a[0].t : a[1].t, b[1].k = (first ? a[0].k : a[1].k) + 1;
+	GC_PAR_FOR(j, n) { /* b[j + 1]: the cell of diagonal a[j].vd in the next wavefront */
+		uint32_t x;
+		int32_t k, t;
+		if (j > 0) {
+			x = a[j - 1].xo + 2, k = a[j - 1].k, t = a[j - 1].t;
+			if (!(k > a[j].k + 1)) x = a[j].xo + 4, t = a[j].t, k = a[j].k + 1;
+		} else x = a[0].xo + 4, t = a[0].t, k = a[0].k + 1;
+		if (j + 1 < n && !(k > a[j + 1].k + 1)) x = a[j + 1].xo + 2, t = a[j + 1].t, k = a[j + 1].k + 1;
+		b[j + 1].vd = a[j].vd, b[j + 1].k = k, b[j + 1].xo = x, b[j + 1].t = t, b[j + 1].len = 0;
 	}
-	for (int32_t j = 1; j < n - 1; ++j) {
-		uint32_t x = a[j - 1].xo + 2;
-		int32_t k = a[j - 1].k, t = a[j - 1].t;
-		if (!(k > a[j].k + 1)) x = a[j].xo + 4, t = a[j].t, k = a[j].k + 1;
-		if (!(k > a[j + 1].k + 1)) x = a[j + 1].xo + 2, t = a[j + 1].t, k = a[j + 1].k + 1;
-		b[j + 1].vd = a[j].vd, b[j + 1].k = k, b[j + 1].xo = x, b[j + 1].t = t;
+	b[0].vd = a[0].vd - 1, b[0].xo = a[0].xo + 2, b[0].k = a[0].k + 1, b[0].t = a[0].t, b[0].len = 0;
+	b[n + 1].vd = a[n - 1].vd + 1, b[n + 1].xo = a[n - 1].xo + 2, b[n + 1].t = a[n - 1].t, b[n + 1].k = a[n - 1].k, b[n + 1].len = 0;
+	gc_sync();
+	for (int32_t base = 0; base < n; base += GC_NLANE) { /* cells at a vertex / query end, in diagonal order */
+		const int32_t j = base + GC_LANE;
+		const int at_end = j < n && (a[j].k == vl - 1 || (int32_t)a[j].vd - GC_DSHIFT + a[j].k == z->ql - 1);
+		const uint64_t m = gc_ballot(at_end);
+		if (at_end) { a[j].xo |= 1; H->a[H->n + gc_rank(m)] = a[j]; }
+		H->n += gc_popc(m);
 	}
-	if (n >= 2) {
-		const int left = a[n - 2].k > a[n - 1].k + 1;
-		b[n].vd = a[n - 1].vd, b[n].xo = left ? a[n - 2].xo + 2 : a[n - 1].xo + 4, b[n].t = left ? a[n - 2].t : a[n - 1].t, b[n].k = left ? a[n - 2].k : a[n - 1].k + 1;
-	}
-	b[n + 1].vd = a[n - 1].vd + 1, b[n + 1].xo = a[n - 1].xo + 2, b[n + 1].t = a[n - 1].t, b[n + 1].k = a[n - 1].k;
-	for (int32_t j = 0; j < n; ++j) { /* cells at a vertex / query end are handled one by one by the caller */
-		gc_diag_t *p = &a[j];
-		if (p->k == vl - 1 || (int32_t)p->vd - GC_DSHIFT + p->k == z->ql - 1) {
-			gc_diag_t *q;
-			p->xo |= 1;
-			GC_PUSH(A, *H, q);
-			*q = *p;
+	gc_sync();
+	int32_t n_keep = 0;
+	for (int32_t base = 0; base < n + 2; base += GC_NLANE) { /* cells that left the vertex or the query are dropped; a diagonal that ran off the vertex end is finished */
+		const int32_t j = base + GC_LANE;
+		gc_diag_t p;
+		int keep = 0, fin = 0;
+		if (j < n + 2) {
+			p = b[j];
+			const int32_t d = (int32_t)p.vd - GC_DSHIFT;
+			keep = d + p.k < z->ql && p.k < vl;
+			fin = !keep && p.k == vl;
 		}
+		const uint64_t mk = gc_ballot(keep), mf = gc_ballot(fin);
+		gc_sync();
+		if (keep) b[n_keep + gc_rank(mk)] = p;
+		if (fin) { gc_intv_t *iv = &z->fresh.a[z->fresh.n + gc_rank(mf)]; iv->vd0 = gc_mk_vd(v, (int32_t)p.vd - GC_DSHIFT), iv->vd1 = iv->vd0 + 1; }
+		n_keep += gc_popc(mk), z->fresh.n += gc_popc(mf);
+		gc_sync();
 	}
-	b = &B->a[B->n]; /* (H and B are different vectors, but the arena may have moved B when H grew in place? no: only H can move) */
-	int32_t m = 0;
-	for (int32_t j = 0; j < n + 2; ++j) {
-		const gc_diag_t p = b[j];
-		const int32_t d = (int32_t)p.vd - GC_DSHIFT;
-		if (d + p.k < z->ql && p.k < vl) b[m++] = p;
-		else if (p.k == vl) {
-			gc_intv_t *iv;
-			GC_PUSH(A, z->fresh, iv);
-			iv->vd0 = gc_mk_vd(v, d), iv->vd1 = iv->vd0 + 1;
-		}
-	}
-	B->n += m;
+	B->n += n_keep;
 	return GC_OK;
 }
 /* one edit-distance step: consumes wf[cur], builds wf[cur^1]; *reached = 1 when (v1, off1) was hit (gfa-ed.c:405-507) */
@@ -1192,11 +1335,30 @@ GC_HD int gc_gw_step(gc_arena_t *A, gc_gw_t *z, uint32_t v1, int32_t off1, int *
 	H->n = B->n = 0;
 	z->end_v = (uint32_t)-1, z->end_off = z->end_tb = -1;
 	z->fresh.n = 0;
+	GC_TICK(A, 8);
 	gc_u64map_clear(&z->seen);
 	GC_TRY(gc_vec_reserve(A, *B, n * 2 + 4));
-	for (int32_t x = 0, i = 1; i <= n; ++i)
-		if (i == n || a[i].vd != a[i - 1].vd + 1) { GC_TRY(gc_gw_extend_run(A, z, i - x, &a[x], B, H)); x = i; }
+	GC_TICK(A, 11);
+	{ /* runs of adjacent diagonals on one vertex: the lanes look for the run ends, the runs are then taken in order */
+		int32_t x = 0;
+		for (int32_t base = 0; base < n; base += GC_NLANE) {
+			const int32_t i = base + GC_LANE + 1; /* a run ends in front of position i */
+			uint64_t m = gc_ballot(i <= n && (i == n || a[i].vd != a[i - 1].vd + 1));
+			while (m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+				const int32_t bit = (int32_t)__ffsll((long long)m) - 1;
+#else
+				const int32_t bit = 0;
+#endif
+				const int32_t e = base + bit + 1;
+				m &= m - 1;
+				GC_TRY(gc_gw_extend_run(A, z, e - x, &Cur->a[x], B, H));
+				x = e;
+			}
+		}
+	}
 	if (H->n == 0) do_dedup = 0;
+	GC_TICK(A, 12);
 	while (head < H->n) {
 		const gc_diag_t t = H->a[head++];
 		const uint32_t v = (uint32_t)(t.vd >> 32), ooo = t.xo & 1;
@@ -1252,7 +1414,9 @@ GC_HD int gc_gw_step(gc_arena_t *A, gc_gw_t *z, uint32_t v1, int32_t off1, int *
 			for (int32_t j = 0; j < nv; ++j) GC_TRY(gc_diag_push(A, B, av[j].w, qi - av[j].ow, av[j].ow, x0 + 1, 1, tw));
 		}
 	}
+	GC_TICK(A, 13);
 	if (do_dedup) GC_TRY(gc_gw_dedup(A, z, &B->n, B->a));
+	GC_TICK(A, 14);
 	if (z->max_lag > 0 && B->n > z->max_chk && ((z->s + 1) & 0xf) == 0) B->n = gc_gw_prune(B->n, B->a, (uint32_t)z->max_lag, z->bw_dyn);
 	z->cur ^= 1;
 	return GC_OK;
@@ -1318,7 +1482,7 @@ GC_HD int gc_asm_chain(gc_arena_t *A, gc_asm_t *S, const gc_chain_t *c, const mg
 	mg_llchain_t *q;
 	GC_PUSH(A, S->lc, q);
 	q->cnt = c->cnt, q->v = c->v, q->score = c->score, q->ed = ed, q->off = S->n_a;
-	memcpy(&S->a_out[S->n_a], &a[c->off], (size_t)c->cnt * sizeof(mg128_t));
+	gc_pcopy(&S->a_out[S->n_a], &a[c->off], (int64_t)c->cnt * (int64_t)sizeof(mg128_t));
 	S->n_a += c->cnt;
 	return GC_OK;
 }
@@ -1360,12 +1524,17 @@ GC_HD int gc_bridge(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, gc_as
 		const char *base = A->base;
 		{
 			const int32_t qs = c0->qe - span, qe = c1->qs + span;
-			GC_TRY(gc_gwfa(A, G, qe - qs, qseq + qs, c0->v, c0->re - span, c1->v, c1->rs + span - 1, P->gdp_max_ed / 2, P->gdp_max_ed, &ed, &path, &n_path));
+			int rc = GC_E_ARENA;
+			GC_TICK(A, 5);
+			if (A->fast_base) { gc_arena_t F; gc_arena_init(&F, A->fast_base, A->fast_cap, 0); F.ticks = A->ticks, F.tick_last = A->tick_last; rc = gc_gwfa(&F, G, qe - qs, qseq + qs, c0->v, c0->re - span, c1->v, c1->rs + span - 1, P->gdp_max_ed / 2, P->gdp_max_ed, &ed, &path, &n_path); A->tick_last = F.tick_last; }
+			if (rc == GC_E_ARENA) rc = gc_gwfa(A, G, qe - qs, qseq + qs, c0->v, c0->re - span, c1->v, c1->rs + span - 1, P->gdp_max_ed / 2, P->gdp_max_ed, &ed, &path, &n_path);
+			if (rc != GC_OK) return rc;
+			GC_TICK(A, 8);
 			++S->n_gwfa;
 		}
 		if (ed >= 0) {
 			n_mid = n_path - 2 > 0 ? n_path - 2 : 0;
-			if (n_mid) gc_move(path, path + 1, (int64_t)n_mid * 4); /* the inner vertices */
+			if (n_mid) gc_pmove_down(path, path + 1, (int64_t)n_mid * 4); /* the inner vertices */
 		} else {
 			gc_dst_t dst;
 			gc_walkv_t *w = 0;
@@ -1373,7 +1542,9 @@ GC_HD int gc_bridge(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, gc_as
 			if (A->base == base) A->top = mark;
 			memset(&dst, 0, sizeof dst);
 			dst.v = c0->v ^ 1, dst.target_dist = c1->dist_pre, dst.target_hash = c1->hash_pre, dst.check_hash = 1;
-			const int rc = gc_shortest_k(A, G, c1->v ^ 1, 1, &dst, dst.target_dist, MG_MAX_SHORT_K, &w, &n_w);
+			int rc = GC_E_ARENA;
+			if (A->fast_base) { gc_arena_t F; gc_arena_init(&F, A->fast_base, A->fast_cap, 0); rc = gc_shortest_k(&F, G, c1->v ^ 1, 1, &dst, dst.target_dist, MG_MAX_SHORT_K, &w, &n_w); }
+			if (rc == GC_E_ARENA) { memset(&dst, 0, sizeof dst); dst.v = c0->v ^ 1, dst.target_dist = c1->dist_pre, dst.target_hash = c1->hash_pre, dst.check_hash = 1; rc = gc_shortest_k(A, G, c1->v ^ 1, 1, &dst, dst.target_dist, MG_MAX_SHORT_K, &w, &n_w); }
 			if (rc == GC_E_ARENA) return rc;
 			++S->n_shortk;
 			if (rc != GC_OK || n_w == 0 || dst.target_hash != dst.hash) { if (A->base == base) A->top = mark; *failed = 1; return GC_OK; } /* "chain skiped" (gchain1.c:333-338) */
@@ -1392,7 +1563,7 @@ GC_HD int gc_bridge(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, gc_as
 		while (k < c1->cnt && !(GC_AX(a[c1->off + k]) > c0->re && GC_AY(a[c1->off + k]) > c0->qe)) ++k;
 		if (k < c1->cnt) {
 			t->cnt += c1->cnt - k, t->score += c1->score;
-			memcpy(&S->a_out[S->n_a], &a[c1->off + k], (size_t)(c1->cnt - k) * sizeof(mg128_t));
+			gc_pcopy(&S->a_out[S->n_a], &a[c1->off + k], (int64_t)(c1->cnt - k) * (int64_t)sizeof(mg128_t));
 			S->n_a += c1->cnt - k;
 		}
 	}
@@ -1455,15 +1626,15 @@ GC_HD int gc_order_by_score(gc_arena_t *A, gc_result_t *R)
 	int32_t n_lc = 0, n_a = 0;
 	for (int32_t i = n - 1; i >= 0; --i) {
 		gc_rec_t g = R->gc[z[i].val];
-		memcpy(&l2[n_lc], &R->lc[g.off], (size_t)g.cnt * sizeof(mg_llchain_t));
-		memcpy(&a2[n_a], &R->a[R->lc[g.off].off], (size_t)g.n_anchor * sizeof(mg128_t));
+		gc_pcopy(&l2[n_lc], &R->lc[g.off], (int64_t)g.cnt * (int64_t)sizeof(mg_llchain_t));
+		gc_pcopy(&a2[n_a], &R->a[R->lc[g.off].off], (int64_t)g.n_anchor * (int64_t)sizeof(mg128_t));
 		g.off = n_lc;
 		g2[n - 1 - i] = g;
 		n_lc += g.cnt, n_a += g.n_anchor;
 	}
-	memcpy(R->gc, g2, (size_t)n * sizeof(gc_rec_t));
-	memcpy(R->lc, l2, (size_t)R->n_lc * sizeof(mg_llchain_t));
-	memcpy(R->a, a2, (size_t)R->n_a * sizeof(mg128_t));
+	gc_pcopy(R->gc, g2, (int64_t)n * (int64_t)sizeof(gc_rec_t));
+	gc_pcopy(R->lc, l2, (int64_t)R->n_lc * (int64_t)sizeof(mg_llchain_t));
+	gc_pcopy(R->a, a2, (int64_t)R->n_a * (int64_t)sizeof(mg128_t));
 	for (int32_t i = 0, k = 0; i < R->n_lc; ++i) R->lc[i].off = k, k += R->lc[i].cnt;
 	A->top = mark;
 	return GC_OK;
@@ -1515,8 +1686,10 @@ GC_HD int gc_assemble(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, int
 	}
 	R->n_gc = n_gc, R->n_lc = S.lc.n, R->n_a = S.n_a, R->lc = S.lc.a;
 	R->n_gwfa = S.n_gwfa, R->n_shortk += S.n_shortk;
+	GC_TICK(A, 5);
 	gc_measure(G, R);
-	return gc_order_by_score(A, R);
+	GC_TICK(A, 9);
+	{ const int rc_ = gc_order_by_score(A, R); GC_TICK(A, 10); return rc_; }
 }
 
 /* ------------------------------------------------------------------------------------------------ primary / secondary, filters */
@@ -1598,8 +1771,8 @@ GC_HD int gc_drop_filtered(gc_arena_t *A, gc_result_t *R)
 	for (int32_t i = 0; i < R->n_gc; ++i) {
 		const gc_rec_t r = R->gc[i];
 		if (o2n[i] >= 0) {
-			gc_move(&R->a[n_a], &R->a[a0], (int64_t)r.n_anchor * (int64_t)sizeof(mg128_t));
-			gc_move(&R->lc[n_lc], &R->lc[lc0], (int64_t)r.cnt * (int64_t)sizeof(mg_llchain_t));
+			gc_pmove_down(&R->a[n_a], &R->a[a0], (int64_t)r.n_anchor * (int64_t)sizeof(mg128_t));
+			gc_pmove_down(&R->lc[n_lc], &R->lc[lc0], (int64_t)r.cnt * (int64_t)sizeof(mg_llchain_t));
 			R->gc[n_gc] = r;
 			R->gc[n_gc].id = n_gc, R->gc[n_gc].parent = o2n[r.parent];
 			++n_gc, n_lc += r.cnt, n_a += r.n_anchor;
@@ -1636,16 +1809,22 @@ GC_HD int gc_map_read(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, con
 	int32_t n_c = rd->n_u, n_u2 = 0;
 	R->n_gc = R->n_lc = R->n_a = 0, R->gc = 0, R->lc = 0, R->n_gwfa = R->n_shortk = 0;
 	if (rd->n_u <= 0) return GC_OK;
+	GC_TICK(A, 0);
 	GC_TRY(gc_make_chains(A, rd->n_u, rd->u, rd->a, &c));
+	GC_TICK(A, 1);
 	if (n_c > 1) GC_TRY(gc_clean_chains(A, P, rd->a, c, &n_c));
+	GC_TICK(A, 2);
 	for (int32_t i = 0; i < n_c; ++i) GC_TRY(gc_index_anchors(&rd->a[c[i].off], c[i].cnt, rd->mini_pos, rd->n_mini));
+	GC_TICK(A, 3);
 	GC_TRY(gc_chain_dp(A, G, P, rd->qlen, rd->a, c, &n_c, &u2, &n_u2, &R->n_shortk));
+	GC_TICK(A, 4);
 	if (n_u2 == 0) return GC_OK;
 	GC_TRY(gc_assemble(A, G, P, n_u2, u2, c, rd->a, rd->hash, rd->qseq, R));
+	GC_TICK(A, 5);
 	for (int32_t i = 0; i < R->n_gc; ++i) R->gc[i].parent = R->gc[i].id = i, R->gc[i].subsc = R->gc[i].n_sub = R->gc[i].flt = 0;
 	GC_TRY(gc_assign_parents(A, P, R->n_gc, R->gc));
 	gc_filter_secondaries(P, R->n_gc, R->gc);
-	return gc_drop_filtered(A, R);
+	{ const int rc_ = gc_drop_filtered(A, R); GC_TICK(A, 6); return rc_; }
 }
 
 #endif

@@ -135,6 +135,11 @@ mg_idx_t *mg_index(gfa_t *g, const mg_idxopt_t *io, int n_threads, mg_mapopt_t *
 			return 0;
 		}
 		free(off); free(seg_len); free(cat);
+		if (mga_dev_graph_upload(sc, g, mga_comp_table, &B->dev) < 0) { /* arcs + reverse complements: graph chaining runs on the device (k_gchain.hip) */
+			mga_dfree(B->dev.d_seg_len); mga_dfree(B->dev.d_gseq); mga_dfree(B->dev.d_gseq_off); mga_dfree(B->dev.d_tab); mga_dfree(B->dev.d_pos);
+			mga_dfree(B->dev.d_arc); mga_dfree(B->dev.d_arc_idx); mga_dfree(B->dev.d_gseq_rc); free(B->occ_hist); free(B);
+			return 0;
+		}
 		gi = mga_idx_hostpart_mt(g, io, n_threads);
 		gi->B = B;
 		if (mg_verbose >= 3)
@@ -203,6 +208,7 @@ mg_idx_t *mg_index(gfa_t *g, const mg_idxopt_t *io, int n_threads, mg_mapopt_t *
 	}
 	free(tab); free(pos); free(seg_len); free(cat); free(off);
 
+	if (mga_dev_graph_upload(mga_sctx_default(), g, mga_comp_table, &B->dev) < 0) { free(B->occ_hist); free(B); return 0; }
 	gi = mga_idx_hostpart(g, io);
 	gi->B = B;
 	if (mg_verbose >= 3)
@@ -220,6 +226,7 @@ void mg_idx_destroy(mg_idx_t *gi)
 		mga_idx_mf_free(gi);
 		mga_idx_stream_close(gi); /* pipeline threads, HIP streams and buffers of the single-batch entry points */
 		mga_dfree(gi->B->dev.d_tab); mga_dfree(gi->B->dev.d_pos); mga_dfree(gi->B->dev.d_seg_len); mga_dfree(gi->B->dev.d_gseq); mga_dfree(gi->B->dev.d_gseq_off);
+		mga_dfree(gi->B->dev.d_arc); mga_dfree(gi->B->dev.d_arc_idx); mga_dfree(gi->B->dev.d_gseq_rc);
 		free(gi->B->occ_hist); free(gi->B->gaf_out);
 		free(gi->B);
 	}

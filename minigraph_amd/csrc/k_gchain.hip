@@ -3,17 +3,19 @@
 // GWFA / shortest-walk bridging, ordering, primary/secondary, filters).  Reference: map-algo.c:422-474, gchain1.c, shortk.c,
 // gfa-ed.c, gcmisc.c.
 //
-// Why one lane: the work is a chain of dependent, data-driven decisions over a handful of records per read (1.9 linear chains,
-// <1 graph search, <1 GWFA on 10 kb reads) -- latency-bound pointer chasing with nothing for 64 lanes to share.  Parallelism comes
-// from the 10^4-10^5 reads of a chunk: persistent wavefronts pull reads from an atomic counter, each with a private scratch ARENA
-// in HBM (1 MiB; a read that outgrows it is re-run by a second launch with 256 MiB arenas, beyond that the job stops with an
-// error).  The other 63 lanes help with the bulk copies (anchors in, anchors out).  [measured] see DESIGN.md 4.
+// Execution model: the routine runs REPLICATED on the 64 lanes of the read's wavefront -- the control flow is a chain of dependent,
+// data-driven decisions over a handful of records (1.9 linear chains, <1 graph search, <1 GWFA per 10 kb read), identical on every
+// lane -- and its per-element loops (GWFA extension and wavefront construction, dedup, anchor copies, minimizer ranks) are split over
+// the lanes, 64 loads in flight instead of one dependent chain.  Persistent wavefronts pull reads from an atomic counter, each with a
+// private scratch ARENA in HBM (1 MiB; a read that outgrows it is re-run by a second launch with 256 MiB arenas, beyond that the job
+// stops with an error).  [measured] see DESIGN.md 4.
 //
 // The same source runs on the host (mga_gchain_host_read below: -x asm where the chainer is host code, and the CPU parity tests).
 #include <stdio.h>
 #include <math.h>
 #include "mga_dev.h"
 #include "dev_common.h"
+#define GC_PARSORT 5   /* [measured] gathering the sorted subset by lanes (bit 2 / 8) faults on the device; the split and the merge by rank are fine */
 #include "gc_core.h"
 
 static_assert(sizeof(gc_arc_t) == sizeof(gfa_arc_t) && sizeof(gc_arc_t) == 32, "gc_arc_t must mirror gfa_arc_t");
@@ -64,17 +66,25 @@ struct gck_in_t {
 	const int64_t *mini_off; const int32_t *mini;
 	const int64_t *q_off; const char *seq;
 	const uint32_t *hash;
+	const int32_t *rflag;            // k_lchain's verdict on the long-join rescue: 2 = this read's chains come from the host tree, not from here
 };
 struct gck_out_t {
 	mga_gc_hdr_t *hdr;
-	mg128_t *ga;                     // output anchors of read i at a_off[i]
 	gc_rec_t *gc_pool; int64_t gc_cap;
 	mg_llchain_t *lc_pool; int64_t lc_cap;
-	unsigned long long *ctl;         // [0] next read, [1] gc pool used, [2] lc pool used, [3] reads to retry, [4] gwfa calls, [5] shortest-walk calls
+	mg128_t *a_pool; int64_t a_cap;
+	unsigned long long *ctl;         // [0] next read, [1] gc pool used, [2] lc pool used, [3] reads to retry, [4] gwfa calls, [5] shortest-walk calls, [6] anchor pool used, [7] peak arena
 	int32_t *retry;
 };
 
-__global__ void __launch_bounds__(64) k_gchain(gck_in_t in, gck_out_t out, gc_graph_t G, gc_par_t P, char *arena_mem, int64_t arena_bytes)
+__device__ __forceinline__ void gck_copy_words(void *dst, const void *src, int64_t bytes, int lane) // both 4-byte aligned
+{
+	uint32_t *d = (uint32_t*)dst;
+	const uint32_t *s = (const uint32_t*)src;
+	for (int64_t i = lane, n = bytes >> 2; i < n; i += 64) d[i] = s[i];
+}
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_gchain(gck_in_t in, gck_out_t out, gc_graph_t G, gc_par_t P, char *arena_mem, int64_t arena_bytes)
 {
 	const int lane = threadIdx.x;
 	char *my_arena = arena_mem + (int64_t)blockIdx.x * arena_bytes;
@@ -87,45 +97,60 @@ __global__ void __launch_bounds__(64) k_gchain(gck_in_t in, gck_out_t out, gc_gr
 		const int64_t off = in.a_off[r];
 		const int32_t n_u = in.nu[r], n_b = in.nb[r];
 		mga_gc_hdr_t *H = &out.hdr[r];
-		if (n_u <= 0 || n_b <= 0) { if (lane == 0) { H->n_gc = H->n_lc = H->n_a = 0, H->status = 0, H->gc_off = H->lc_off = 0; } continue; }
+		if (in.rflag && in.rflag[r] == 2) { if (lane == 0) { H->n_gc = H->n_lc = H->n_a = 0, H->status = MGA_GC_HOST, H->gc_off = H->lc_off = H->a_off = 0; } continue; }
+		if (n_u <= 0 || n_b <= 0) { if (lane == 0) { H->n_gc = H->n_lc = H->n_a = 0, H->status = 0, H->gc_off = H->lc_off = H->a_off = 0; } continue; }
 		gc_arena_t A;
 		gc_arena_init(&A, my_arena, arena_bytes, 0);
+		// (gc_arena_t::fast_base -- a block of LDS for the scratch of one graph search / GWFA call -- stays unset: flat accesses of the 24-byte
+		// wavefront cells into the LDS aperture raised MEMORY_APERTURE_VIOLATION on gfx950 [measured]; the mechanism is kept for a later look)
+		if (out.ctl[15]) A.ticks = out.ctl + 16, A.tick_last = (long long)clock64(); // profiling: ctl[15] != 0 asks for per-stage cycle sums in ctl[16..31]
 		mg128_t *work = (mg128_t*)gc_alloc(&A, (int64_t)n_b * 16); // the chains' anchors: flags and minimizer ranks are written into this copy
-		if (work) for (int32_t i = lane; i < n_b; i += 64) work[i] = in.b[off + i];
+		mg128_t *res_a = (mg128_t*)gc_alloc(&A, (int64_t)n_b * 16); // anchors of the graph chains
+		if (work && res_a) gck_copy_words(work, in.b + off, (int64_t)n_b * 16, lane);
 		mga_wave_sync();
 		int32_t status = GC_E_ARENA, n_gc = 0, n_lc = 0, n_a = 0;
-		int64_t gc_off = 0, lc_off = 0;
-		if (lane == 0 && work) {
+		long long gc_off = 0, lc_off = 0, a_off = 0;
+		gc_result_t R;
+		R.gc = 0, R.lc = 0;
+		if (work && res_a) { // every lane runs the routine on the same values (replicated execution, gc_core.h); its hot loops are split over the lanes
 			gc_read_t rd;
-			gc_result_t R;
 			rd.qlen = (int32_t)(in.q_off[r + 1] - in.q_off[r]), rd.hash = in.hash[r];
 			rd.n_u = n_u, rd.u = in.u + off, rd.a = work;
 			rd.n_mini = (int32_t)(in.mini_off[r + 1] - in.mini_off[r]), rd.mini_pos = in.mini + in.mini_off[r];
 			rd.qseq = in.seq + in.q_off[r];
-			R.a = out.ga + off;
+			R.a = res_a;
 			status = gc_map_read(&A, &G, &P, &rd, &R);
 			if (status == GC_E_BUG) status = GC_OK, R.n_gc = R.n_lc = R.n_a = 0; // the reference's own bail-outs: the read gets no chains
+			if (status == GC_OK) n_gc = R.n_gc, n_lc = R.n_lc, n_a = R.n_a;
+		}
+		mga_wave_sync();
+		if (lane == 0) { // one lane talks to the chunk's pools and counters
 			if (status == GC_OK) {
-				n_gc = R.n_gc, n_lc = R.n_lc, n_a = R.n_a;
-				gc_off = (int64_t)atomicAdd(&out.ctl[1], (unsigned long long)n_gc);
-				lc_off = (int64_t)atomicAdd(&out.ctl[2], (unsigned long long)n_lc);
-				if (gc_off + n_gc > out.gc_cap || lc_off + n_lc > out.lc_cap) status = MGA_GC_E_POOL;
-				else {
-					for (int32_t i = 0; i < n_gc; ++i) out.gc_pool[gc_off + i] = R.gc[i];
-					for (int32_t i = 0; i < n_lc; ++i) out.lc_pool[lc_off + i] = R.lc[i];
-				}
+				gc_off = (long long)atomicAdd(&out.ctl[1], (unsigned long long)n_gc);
+				lc_off = (long long)atomicAdd(&out.ctl[2], (unsigned long long)n_lc);
+				a_off = (long long)atomicAdd(&out.ctl[6], (unsigned long long)n_a);
+				if (gc_off + n_gc > out.gc_cap || lc_off + n_lc > out.lc_cap || a_off + n_a > out.a_cap) status = MGA_GC_E_POOL;
 				atomicAdd(&out.ctl[4], (unsigned long long)R.n_gwfa);
 				atomicAdd(&out.ctl[5], (unsigned long long)R.n_shortk);
+				atomicMax(&out.ctl[7], (unsigned long long)A.peak);
 			}
-			if (status != GC_OK) out.retry[atomicAdd(&out.ctl[3], 1ULL)] = r;
-			H->n_gc = n_gc, H->n_lc = n_lc, H->n_a = n_a, H->status = status, H->gc_off = gc_off, H->lc_off = lc_off;
+			if (status != GC_OK) out.retry[atomicAdd(&out.ctl[3], 1ULL)] = r, n_gc = n_lc = n_a = 0;
+			H->n_gc = n_gc, H->n_lc = n_lc, H->n_a = n_a, H->status = status, H->gc_off = gc_off, H->lc_off = lc_off, H->a_off = a_off;
+		}
+		// the records leave the arena on all 64 lanes
+		status = __shfl(status, 0), n_gc = __shfl(n_gc, 0), n_lc = __shfl(n_lc, 0), n_a = __shfl(n_a, 0);
+		gc_off = __shfl(gc_off, 0), lc_off = __shfl(lc_off, 0), a_off = __shfl(a_off, 0);
+		if (status == GC_OK) {
+			gck_copy_words(out.gc_pool + gc_off, R.gc, (int64_t)n_gc * (int64_t)sizeof(gc_rec_t), lane);
+			gck_copy_words(out.lc_pool + lc_off, R.lc, (int64_t)n_lc * (int64_t)sizeof(mg_llchain_t), lane);
+			gck_copy_words(out.a_pool + a_off, res_a, (int64_t)n_a * 16, lane);
 		}
 		mga_wave_sync();
 	}
 }
 
 extern "C" size_t mga_dev_gchain_arena_bytes(int tier) { return tier == 0 ? (size_t)1 << 20 : (size_t)256 << 20; }
-extern "C" int mga_dev_gchain_waves(int tier) { return tier == 0 ? 6144 : 24; }
+extern "C" int mga_dev_gchain_waves(int tier) { return tier == 0 ? 4096 : 24; } /* tier 0: 256 CUs x 4 SIMDs x 4 resident waves */
 
 static void gc_par_from_opt(const mg_mapopt_t *opt, int k, float pen_gap, gc_par_t *P)
 {
@@ -141,8 +166,8 @@ static void gc_par_from_opt(const mg_mapopt_t *opt, int k, float pen_gap, gc_par
 // ctl: 8 x uint64 (zeroed by the caller before the FIRST launch of a chunk; a retry launch resets only the read counter).
 extern "C" int mga_dev_gchain(mga_sctx_t *sc, const mga_didx_t *ix, const mg_mapopt_t *opt, int k, float pen_gap, int n, const int32_t *d_list, int tier,
 							  const int64_t *d_a_off, const int32_t *d_nu, const int32_t *d_nb, const uint64_t *d_u, const mg128_t *d_b,
-							  const int64_t *d_mini_off, const int32_t *d_mini, const int64_t *d_q_off, const char *d_seq, const uint32_t *d_hash,
-							  mga_gc_hdr_t *d_hdr, mg128_t *d_ga, void *d_gc_pool, int64_t gc_cap, mg_llchain_t *d_lc_pool, int64_t lc_cap,
+							  const int64_t *d_mini_off, const int32_t *d_mini, const int64_t *d_q_off, const char *d_seq, const uint32_t *d_hash, const int32_t *d_rflag,
+							  mga_gc_hdr_t *d_hdr, void *d_gc_pool, int64_t gc_cap, mg_llchain_t *d_lc_pool, int64_t lc_cap, mg128_t *d_a_pool, int64_t a_cap,
 							  unsigned long long *d_ctl, int32_t *d_retry)
 {
 	if (n <= 0) return 0;
@@ -151,14 +176,15 @@ extern "C" int mga_dev_gchain(mga_sctx_t *sc, const mga_didx_t *ix, const mg_map
 	int waves = mga_dev_gchain_waves(tier);
 	if (waves > n) waves = n;
 	mga_dbuf_t *arena = &sc->gc_arena[tier ? 1 : 0];
-	if (mga_dbuf_reserve(arena, ab * (size_t)mga_dev_gchain_waves(tier)) < 0) return -1;
+	if (mga_dbuf_reserve(arena, ab * (size_t)waves) < 0) return -1; /* (grow-only: a context that only ever maps single reads keeps a single arena) */
 	gck_in_t in;
 	gck_out_t out;
 	gc_graph_t G;
 	gc_par_t P;
 	in.n = n, in.list = d_list, in.a_off = d_a_off, in.nu = d_nu, in.nb = d_nb, in.u = d_u, in.b = d_b, in.mini_off = d_mini_off, in.mini = d_mini;
-	in.q_off = d_q_off, in.seq = d_seq, in.hash = d_hash;
-	out.hdr = d_hdr, out.ga = d_ga, out.gc_pool = (gc_rec_t*)d_gc_pool, out.gc_cap = gc_cap, out.lc_pool = d_lc_pool, out.lc_cap = lc_cap, out.ctl = d_ctl, out.retry = d_retry;
+	in.q_off = d_q_off, in.seq = d_seq, in.hash = d_hash, in.rflag = d_rflag;
+	out.hdr = d_hdr, out.gc_pool = (gc_rec_t*)d_gc_pool, out.gc_cap = gc_cap, out.lc_pool = d_lc_pool, out.lc_cap = lc_cap, out.a_pool = d_a_pool, out.a_cap = a_cap;
+	out.ctl = d_ctl, out.retry = d_retry;
 	memset(&G, 0, sizeof G);
 	G.arc = (const gc_arc_t*)ix->d_arc, G.idx = ix->d_arc_idx, G.seg_len = ix->d_seg_len, G.es = 0, G.seq_fw = ix->d_gseq, G.seq_rc = ix->d_gseq_rc, G.seq_off = ix->d_gseq_off;
 	gc_par_from_opt(opt, k, pen_gap, &P);

@@ -146,12 +146,17 @@ __global__ void __launch_bounds__(64 * NW) k_wfa_r(int n_items, const int32_t *_
 			auto step = [&](auto Pc) __attribute__((always_inline)) -> bool { // false: the problem is finished (or has to leave the tier)
 				constexpr int P = decltype(Pc)::value;
 				const int par = s & 1;
+				// Scores that no alignment can have under x=4, o1+e1=6, e1=2, o2+e2=16, e2=1 (the penalties the register ages are built for): 1, 2, 3 and the
+				// odd ones below 17.  Their slices hold nothing but unreachable cells in all five arrays, whatever the sequences: the reference computes
+				// them anyway (NEG_INF plus a few), here the step only keeps the books -- traceback rows, band, ages -- and writes NEG_INF.  Nothing a
+				// reachable cell or its traceback byte depends on differs: an unreachable operand loses every max against a reachable one either way.
+				const bool empty_cur = s < 16 && ((0xAAAEu >> s) & 1u), empty_next = s + 1 < 16 && ((0xAAAEu >> (s + 1)) & 1u);
 				// ---- extension of slice s (miniwfa.c:399-411); the end cell lies on the unique diagonal ql - tl
 				bool term = false;
 #pragma unroll
 				for (int j = 0; j < J; ++j) {
 					const int32_t b0 = W0 + 64 * j;
-					if (b0 > chi || b0 + 63 < clo) continue; // slot entirely outside the slice (uniform)
+					if (empty_cur || b0 > chi || b0 + 63 < clo) continue; // nothing to extend / slot entirely outside the slice (uniform)
 					const int32_t d = b0 + lane, k0 = HA(j, 0), i0 = d + k0;
 					const bool val = (uint32_t)(k0 + 1) <= (uint32_t)tl && (uint32_t)(i0 + 1) <= (uint32_t)ql; // -1 <= k0 < tl, -1 <= i0 < ql
 					const int32_t tp = val ? k0 + 1 : 0, qp = val ? i0 + 1 : 0;
@@ -203,7 +208,7 @@ __global__ void __launch_bounds__(64 * NW) k_wfa_r(int n_items, const int32_t *_
 #pragma unroll
 					for (int j = 0; j < J; ++j) {
 						const int32_t b0 = W0 + 64 * j;
-						if (b0 > nhi || b0 + 63 < nlo) { nH[j] = nE1[j] = nF1[j] = nE2[j] = nF2[j] = WF_NEG_INF; continue; } // uniform
+						if (empty_next || b0 > nhi || b0 + 63 < nlo) { nH[j] = nE1[j] = nF1[j] = nE2[j] = nF2[j] = WF_NEG_INF; continue; } // uniform
 						const int32_t d = b0 + lane;
 						// predecessors: score s+1-p is age p-1 now (ages are shifted at the end of the step)
 #define WFR_L(R, a, q) wfr_from_left(j > 0 ? __builtin_amdgcn_readlane(R[j > 0 ? j - 1 : 0][a], 63) : eL[q], R[j][a])

@@ -111,6 +111,8 @@ struct mga_batch_s {
 	int a_is_raw;
 	struct rq_read_s *rq;   /* a_is_raw: per-read state of the phased RMQ chaining (see rq_* below) */
 	int32_t *seg_len;       /* segment lengths as a flat array (the graph view of gc_core.h on the host) */
+	/* graph chains made on the device (k_gchain.hip): per-read headers + record pools; status != 0 marks the reads the host still chains */
+	const mga_gc_hdr_t *gc_hdr; const char *gc_pool; const mg_llchain_t *gc_lc; const mg128_t *gc_a; size_t gc_rec;
 	const int32_t *rescue_flag; /* per read: what the chaining kernel did about the long-join rescue (NULL: decide here) */
 	/* stage-2 inputs */
 	mga_cigsrc_t src;
@@ -136,6 +138,11 @@ mga_batch_t *mga_batch_init(const mg_idx_t *gi, const mg_mapopt_t *opt, int n, c
 	b->tp_chain_base = MGA_CALLOC(int64_t, b->n_threads + 1);
 	b->tp_vert_base = MGA_CALLOC(int64_t, b->n_threads + 1);
 	return b;
+}
+
+void mga_batch_set_device_chains(mga_batch_t *b, const mga_gc_hdr_t *hdr, const void *gc_pool, const mg_llchain_t *lc_pool, const mg128_t *a_pool)
+{
+	b->gc_hdr = hdr, b->gc_pool = (const char*)gc_pool, b->gc_lc = lc_pool, b->gc_a = a_pool, b->gc_rec = mga_gc_rec_bytes();
 }
 
 void mga_batch_lchain_par(const mg_idx_t *gi, const mg_mapopt_t *opt, int qlen_max, mga_lchain_par_t *par) /* map-algo.c:377-403 for long reads */
@@ -275,6 +282,13 @@ static void rq_chain_all(mga_batch_t *b)
 	mga_parallel_for(b->n_threads, b->n, rq_finish_worker, b);
 }
 
+uint32_t mga_read_hash(const char *qname, int qlen, int seed) /* map-algo.c:362-364 */
+{
+	uint32_t hash = qname ? mga_hash_str(qname) : 0;
+	hash ^= mga_hash_u32((uint32_t)qlen) + mga_hash_u32((uint32_t)seed);
+	return mga_hash_u32(hash);
+}
+
 static void chain_worker(void *data, int64_t i, int tid)
 {
 	mga_batch_t *b = (mga_batch_t*)data;
@@ -293,9 +307,15 @@ static void chain_worker(void *data, int64_t i, int tid)
 	b->gcs[i] = 0;
 	if (qlen == 0) return; /* map-algo.c:359-360 */
 	if (opt->max_qlen > 0 && qlen > opt->max_qlen) return;
-	hash = qname ? mga_hash_str(qname) : 0; /* map-algo.c:362-364 */
-	hash ^= mga_hash_u32((uint32_t)qlen) + mga_hash_u32((uint32_t)opt->seed);
-	hash = mga_hash_u32(hash);
+	if (b->gc_hdr && b->gc_hdr[i].status == 0) { /* chained on the device: flat records -> the reference's object (div and MAPQ through the host's libm) */
+		const mga_gc_hdr_t *h = &b->gc_hdr[i];
+		gcs = mga_gchains_from_flat(h->n_gc, b->gc_pool + (size_t)h->gc_off * b->gc_rec, h->n_lc, b->gc_lc + h->lc_off, h->n_a, b->gc_a + h->a_off,
+									b->rep_len[i], qlen, b->n_mz[i], opt->min_gc_score);
+		b->gcs[i] = gcs;
+		CPU_ADD(C_GCPOST, tc);
+		goto plan;
+	}
+	hash = mga_read_hash(qname, qlen, opt->seed);
 
 	if (b->a_is_raw) { /* MG_M_RMQ: the RMQ chainer is the primary chainer (map-algo.c:397-399); both of its passes ran in mga_batch_chain's phases */
 		a = b->rq[i].out, u = b->rq[i].u, n_lc = b->rq[i].n_lc;
@@ -337,6 +357,7 @@ do_rescue:;
 	free(a);
 	CPU_ADD(C_GCGEN, tc);
 	b->gcs[i] = gcs;
+plan:
 	if (opt->flag & MG_M_CIGAR) { /* list the gaps of every chain for the WFA kernel */
 		read_plan_t *pl = &b->plan[i];
 		mga_tpool_t *tp = &b->tp[tid];
@@ -579,15 +600,16 @@ typedef struct { /* one pipeline context: HIP stream + grow-only device and pinn
 			mga_dbuf_t seq, qoff, cnt, mzoff, mz, occ, val, na, nmini, rep, aoff, minioff, a, tmp, mini, u, b, nu, nb, ws;
 			mga_dbuf_t tseq, prob, res, pool, used, ncig, cigoff, ord, rflag, item, chain, vert, txtres, txtpool;
 			mga_dbuf_t sk_item, sk_cnt, sk_off, sd_tk, sd_kf, sd_offa, sd_offm, sd_rkey, sd_rmax; /* long-query path (MG_M_RMQ): sketch pieces, per-minimizer scans */
+			mga_dbuf_t hash, gchdr, gcpool, lcpool, apool, gcctl, gcretry; /* graph chaining on the device (k_gchain.hip) */
 		};
-		mga_dbuf_t dall[43];
+		mga_dbuf_t dall[50];
 	};
 	union {
-		struct { mga_hbuf_t h_b, h_u, h_mini, h_tseq, h_prob, h_pool, h_seq, h_ncig, h_cigoff, h_item, h_chain, h_vert, h_txtres, h_txtpool; }; /* pinned staging */
-		mga_hbuf_t hall[14];
+		struct { mga_hbuf_t h_b, h_u, h_mini, h_tseq, h_prob, h_pool, h_seq, h_ncig, h_cigoff, h_item, h_chain, h_vert, h_txtres, h_txtpool, h_gchdr, h_gcpool, h_lcpool, h_apool; }; /* pinned staging */
+		mga_hbuf_t hall[18];
 	};
 } pipe_ctx_t;
-_Static_assert(sizeof(((pipe_ctx_t*)0)->dall) == 43 * sizeof(mga_dbuf_t) && sizeof(((pipe_ctx_t*)0)->hall) == 14 * sizeof(mga_hbuf_t), "pipe_ctx_t: buffer lists out of sync");
+_Static_assert(sizeof(((pipe_ctx_t*)0)->dall) == 50 * sizeof(mga_dbuf_t) && sizeof(((pipe_ctx_t*)0)->hall) == 18 * sizeof(mga_hbuf_t), "pipe_ctx_t: buffer lists out of sync");
 
 #define MGA_MAX_PIPE 4
 
@@ -618,6 +640,9 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	int64_t tot = 0, n_mz, n_a, n_mini, n_prob = 0, n_tb = 0, pool_cap;
 	int64_t *q_off = MGA_MALLOC(int64_t, n + 2), *h_mzoff = 0, *h_aoff = 0, *h_minioff = 0;
 	int32_t *h_nmz = 0, *h_rep = 0, *h_nu = 0, *h_nb = 0, *h_rflag = 0;
+	mga_gc_hdr_t *h_gchdr_p = 0;
+	int64_t gc_cap = 0, lc_cap = 0, ga_cap = 0;
+	int dev_gc = 0;
 	mga_batch_t *b = 0;
 	mga_lchain_par_t par;
 	const int is_rmq = !!(opt->flag & MG_M_RMQ);
@@ -744,35 +769,112 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 							 (const int64_t*)P->aoff.p, (mg128_t*)P->a.p, (const int64_t*)P->minioff.p, (int32_t*)P->mini.p, (mg128_t*)P->tmp.p));
 	}
 	CK(mga_hbuf_reserve(&P->h_mini, (size_t)n_mini * 4 + 16));
-	CK(mga_d2h_s(sc, P->h_mini.p, P->mini.p, (size_t)n_mini * 4));
 	/* ---- linear chaining ---- */
 	CK(mga_hbuf_reserve(&P->h_b, (size_t)n_a * 16 + 16));
 	if (!is_rmq) {
 		size_t wsb = mga_dev_lchain_ws_bytes(n_a);
+		mga_rescue_par_t rs;
 		mga_batch_lchain_par(gi, opt, 0, &par);
 		CK(mga_dbuf_reserve(&P->u, (size_t)n_a * 8 + 8)); CK(mga_dbuf_reserve(&P->b, (size_t)n_a * 16 + 16));
 		CK(mga_dbuf_reserve(&P->nu, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&P->nb, (size_t)n * 4 + 4)); CK(mga_dbuf_reserve(&P->ws, wsb));
-		{ /* the long-join rescue (map-algo.c:407-417) runs inside the same kernel; MGA_HOST_RESCUE=1 keeps it on the host (A/B testing) */
-			mga_rescue_par_t rs;
-			memset(&rs, 0, sizeof rs);
-			rs.enabled = opt->bw_long > opt->bw && (opt->flag & (MG_M_SPLICE | MG_M_SR)) == 0 && !env_int("MGA_HOST_RESCUE", 0);
-			rs.max_dist = opt->max_gap, rs.max_dist_inner = opt->max_gap_pre, rs.bw = opt->bw_long, rs.max_skip = opt->max_lc_skip, rs.cap = opt->rmq_size_cap;
-			rs.min_cnt = opt->min_lc_cnt, rs.min_sc = opt->min_lc_score, rs.chn_pen_gap = par.chn_pen_gap, rs.chn_pen_skip = par.chn_pen_skip;
-			rs.rescue_size = opt->rmq_rescue_size, rs.rescue_ratio = opt->rmq_rescue_ratio;
-			if (opt->max_gap_ref <= 0 && opt->max_frag_len > 0) rs.frag_len = opt->max_frag_len, rs.frag_min_gap = opt->max_gap; /* -F */
-			CK(mga_dbuf_reserve(&P->rflag, (size_t)n * 4 + 4));
-			CK(mga_dev_lchain(sc, n, (const mg128_t*)P->a.p, (const int64_t*)P->aoff.p, &par, &rs, (const int64_t*)P->qoff.p, (uint64_t*)P->u.p, (mg128_t*)P->b.p,
-							  (int32_t*)P->nu.p, (int32_t*)P->nb.p, (int32_t*)P->rflag.p, P->ws.p, wsb, n_a));
-			if (rs.enabled) { /* otherwise the host evaluates the rescue condition itself */
-				h_rflag = MGA_MALLOC(int32_t, n);
-				CK(mga_d2h_s(sc, h_rflag, P->rflag.p, (size_t)n * 4));
-			}
-		}
+		/* the long-join rescue (map-algo.c:407-417) runs inside the same kernel; MGA_HOST_RESCUE=1 keeps it on the host (A/B testing) */
+		memset(&rs, 0, sizeof rs);
+		rs.enabled = opt->bw_long > opt->bw && (opt->flag & (MG_M_SPLICE | MG_M_SR)) == 0 && !env_int("MGA_HOST_RESCUE", 0);
+		rs.max_dist = opt->max_gap, rs.max_dist_inner = opt->max_gap_pre, rs.bw = opt->bw_long, rs.max_skip = opt->max_lc_skip, rs.cap = opt->rmq_size_cap;
+		rs.min_cnt = opt->min_lc_cnt, rs.min_sc = opt->min_lc_score, rs.chn_pen_gap = par.chn_pen_gap, rs.chn_pen_skip = par.chn_pen_skip;
+		rs.rescue_size = opt->rmq_rescue_size, rs.rescue_ratio = opt->rmq_rescue_ratio;
+		if (opt->max_gap_ref <= 0 && opt->max_frag_len > 0) rs.frag_len = opt->max_frag_len, rs.frag_min_gap = opt->max_gap; /* -F */
+		CK(mga_dbuf_reserve(&P->rflag, (size_t)n * 4 + 4));
+		CK(mga_dev_lchain(sc, n, (const mg128_t*)P->a.p, (const int64_t*)P->aoff.p, &par, &rs, (const int64_t*)P->qoff.p, (uint64_t*)P->u.p, (mg128_t*)P->b.p,
+						  (int32_t*)P->nu.p, (int32_t*)P->nb.p, (int32_t*)P->rflag.p, P->ws.p, wsb, n_a));
 		h_nu = MGA_MALLOC(int32_t, n); h_nb = MGA_MALLOC(int32_t, n);
 		CK(mga_hbuf_reserve(&P->h_u, (size_t)n_a * 8 + 8));
 		CK(mga_d2h_s(sc, h_nu, P->nu.p, (size_t)n * 4)); CK(mga_d2h_s(sc, h_nb, P->nb.p, (size_t)n * 4));
-		CK(mga_d2h_s(sc, P->h_u.p, P->u.p, (size_t)n_a * 8)); CK(mga_d2h_s(sc, P->h_b.p, P->b.p, (size_t)n_a * 16));
-	} else CK(mga_d2h_s(sc, P->h_b.p, P->a.p, (size_t)n_a * 16));
+		if (rs.enabled) { /* otherwise the host evaluates the rescue condition itself */
+			h_rflag = MGA_MALLOC(int32_t, n);
+			CK(mga_d2h_s(sc, h_rflag, P->rflag.p, (size_t)n * 4));
+		}
+		dev_gc = rs.enabled && B->dev.d_arc != 0 && env_int("MGA_DEV_GCHAIN", 0) && !env_int("MGA_HOST_GCHAIN", 0); /* graph chaining: gc_core.h on host threads, or (MGA_DEV_GCHAIN=1) on the device, one wavefront per read (k_gchain.hip; see DESIGN.md 4 for why that is not the default yet) */
+		if (dev_gc) {
+			/* ---- graph chaining: chain records, clean-up, DP + shortest walks, GWFA bridging, ordering, filters -- one wavefront per read ---- */
+			const size_t rec = mga_gc_rec_bytes();
+			uint32_t *h_hash = MGA_MALLOC(uint32_t, n);
+			unsigned long long ctl[8];
+			int attempt;
+			for (i = 0; i < n; ++i) h_hash[i] = mga_read_hash(qnames ? qnames[i] : 0, qlens[i], opt->seed);
+			gc_cap = n_a / (opt->min_lc_cnt > 0 ? opt->min_lc_cnt : 1) + n + 64, lc_cap = gc_cap * 3 + 4096, ga_cap = n_a + 64;
+			rc = mga_dbuf_reserve(&P->hash, (size_t)n * 4 + 4) < 0 || mga_h2d_s(sc, P->hash.p, h_hash, (size_t)n * 4) < 0 || mga_ssync(sc) < 0 ? -1 : 0;
+			free(h_hash);
+			if (rc < 0) goto done;
+			CK(mga_dbuf_reserve(&P->gchdr, (size_t)n * sizeof(mga_gc_hdr_t) + 64)); CK(mga_dbuf_reserve(&P->gcctl, 256)); CK(mga_dbuf_reserve(&P->gcretry, (size_t)n * 4 + 4));
+			CK(mga_hbuf_reserve(&P->h_gchdr, (size_t)n * sizeof(mga_gc_hdr_t) + 64)); /* (large read-backs go to pinned memory) */
+			for (attempt = 0;; ++attempt) {
+				int64_t n_retry;
+				CK(mga_dbuf_reserve(&P->gcpool, (size_t)gc_cap * rec)); CK(mga_dbuf_reserve(&P->lcpool, (size_t)lc_cap * sizeof(mg_llchain_t))); CK(mga_dbuf_reserve(&P->apool, (size_t)ga_cap * 16));
+				CK(mga_dmemset_s(sc, P->gcctl.p, 0, 256));
+				if (env_int("MGA_GC_PROF", 0)) { unsigned long long one = 1; CK(mga_h2d_s(sc, (char*)P->gcctl.p + 15 * 8, &one, 8)); CK(mga_ssync(sc)); }
+				CK(mga_dev_gchain(sc, &B->dev, opt, gi->k, par.chn_pen_gap, n, 0, 0, (const int64_t*)P->aoff.p, (const int32_t*)P->nu.p, (const int32_t*)P->nb.p, (const uint64_t*)P->u.p,
+								  (const mg128_t*)P->b.p, (const int64_t*)P->minioff.p, (const int32_t*)P->mini.p, (const int64_t*)P->qoff.p, d_seq, (const uint32_t*)P->hash.p,
+								  (const int32_t*)P->rflag.p, (mga_gc_hdr_t*)P->gchdr.p, P->gcpool.p, gc_cap, (mg_llchain_t*)P->lcpool.p, lc_cap, (mg128_t*)P->apool.p, ga_cap,
+								  (unsigned long long*)P->gcctl.p, (int32_t*)P->gcretry.p));
+				CK(mga_d2h_s(sc, ctl, P->gcctl.p, 64)); CK(mga_ssync(sc));
+				n_retry = (int64_t)ctl[3];
+				if ((int64_t)ctl[1] > gc_cap || (int64_t)ctl[2] > lc_cap || (int64_t)ctl[6] > ga_cap) { /* a record pool was too small: size it to what the kernel asked for and run the chunk again */
+					if (attempt >= 2) { mga_set_error("graph chaining: record pools keep overflowing (%lld/%lld/%lld)", (long long)ctl[1], (long long)ctl[2], (long long)ctl[6]); rc = -1; goto done; }
+					if ((int64_t)ctl[1] > gc_cap) gc_cap = (int64_t)ctl[1] * 2;
+					if ((int64_t)ctl[2] > lc_cap) lc_cap = (int64_t)ctl[2] * 2;
+					if ((int64_t)ctl[6] > ga_cap) ga_cap = (int64_t)ctl[6] * 2;
+					continue;
+				}
+				if (n_retry > 0) { /* reads that outgrew the 1 MiB arena: once more with the large arenas, records appended to the same pools */
+					unsigned long long zero2[1] = { 0 };
+					CK(mga_h2d_s(sc, (char*)P->gcctl.p, zero2, 8)); CK(mga_h2d_s(sc, (char*)P->gcctl.p + 24, zero2, 8)); CK(mga_ssync(sc));
+					CK(mga_dev_gchain(sc, &B->dev, opt, gi->k, par.chn_pen_gap, (int)n_retry, (const int32_t*)P->gcretry.p, 1, (const int64_t*)P->aoff.p, (const int32_t*)P->nu.p, (const int32_t*)P->nb.p,
+									  (const uint64_t*)P->u.p, (const mg128_t*)P->b.p, (const int64_t*)P->minioff.p, (const int32_t*)P->mini.p, (const int64_t*)P->qoff.p, d_seq,
+									  (const uint32_t*)P->hash.p, (const int32_t*)P->rflag.p, (mga_gc_hdr_t*)P->gchdr.p, P->gcpool.p, gc_cap, (mg_llchain_t*)P->lcpool.p, lc_cap,
+									  (mg128_t*)P->apool.p, ga_cap, (unsigned long long*)P->gcctl.p, (int32_t*)P->gcretry.p));
+					CK(mga_d2h_s(sc, ctl, P->gcctl.p, 64)); CK(mga_ssync(sc));
+					if ((int64_t)ctl[3] > 0 || (int64_t)ctl[1] > gc_cap || (int64_t)ctl[2] > lc_cap || (int64_t)ctl[6] > ga_cap) {
+						mga_set_error("graph chaining: %lld read(s) need more than %zu MiB of scratch each, or the record pools overflowed on the retry", (long long)ctl[3], mga_dev_gchain_arena_bytes(1) >> 20);
+						rc = -1; goto done;
+					}
+					st->n_gc_retry += n_retry;
+				}
+				break;
+			}
+			st->n_gwfa += (int64_t)ctl[4], st->n_shortk += (int64_t)ctl[5];
+			if (env_int("MGA_GC_PROF", 0)) { /* per-stage cycle sums of this chunk (profiling aid) */
+				unsigned long long tk[16];
+				static const char *nm[16] = { "", "records", "cleanup", "index", "dp+shortk", "assemble(rest)", "post", "", "gwfa(rest)", "measure", "order", "gw:clear", "gw:runs", "gw:heads", "gw:dedup", "" };
+				int q_;
+				CK(mga_d2h_s(sc, tk, (char*)P->gcctl.p + 128, 128)); CK(mga_ssync(sc));
+				fprintf(stderr, "[gc-prof] %d reads, Mcycles:", n);
+				for (q_ = 1; q_ < 15; ++q_) if (nm[q_][0]) fprintf(stderr, " %s %.1f", nm[q_], tk[q_] * 1e-6);
+				fprintf(stderr, "\n");
+			}
+			if ((int64_t)ctl[7] > st->gc_arena_peak) st->gc_arena_peak = (int64_t)ctl[7];
+			CK(mga_hbuf_reserve(&P->h_gcpool, (size_t)ctl[1] * rec + 16)); CK(mga_hbuf_reserve(&P->h_lcpool, (size_t)ctl[2] * sizeof(mg_llchain_t) + 16)); CK(mga_hbuf_reserve(&P->h_apool, (size_t)ctl[6] * 16 + 16));
+			h_gchdr_p = (mga_gc_hdr_t*)P->h_gchdr.p;
+			CK(mga_d2h_s(sc, h_gchdr_p, P->gchdr.p, (size_t)n * sizeof(mga_gc_hdr_t)));
+			CK(mga_d2h_s(sc, P->h_gcpool.p, P->gcpool.p, (size_t)ctl[1] * rec)); CK(mga_d2h_s(sc, P->h_lcpool.p, P->lcpool.p, (size_t)ctl[2] * sizeof(mg_llchain_t)));
+			CK(mga_d2h_s(sc, P->h_apool.p, P->apool.p, (size_t)ctl[6] * 16));
+			CK(mga_ssync(sc)); /* (h_nu / h_nb / h_rflag arrived with the first sync) */
+			for (i = 0; i < n; ++i) /* the few reads whose rescue k_lchain left to the host tree: their chains, anchors and minimizer positions come down for the host path */
+				if (h_gchdr_p[i].status == MGA_GC_HOST) {
+					const int64_t ao = h_aoff[i], mo = h_minioff[i];
+					CK(mga_d2h_s(sc, (uint64_t*)P->h_u.p + ao, (const uint64_t*)P->u.p + ao, (size_t)h_nu[i] * 8));
+					CK(mga_d2h_s(sc, (mg128_t*)P->h_b.p + ao, (const mg128_t*)P->b.p + ao, (size_t)h_nb[i] * 16));
+					CK(mga_d2h_s(sc, (int32_t*)P->h_mini.p + mo, (const int32_t*)P->mini.p + mo, (size_t)(h_minioff[i + 1] - mo) * 4));
+					CK(mga_ssync(sc));
+				}
+		} else {
+			CK(mga_d2h_s(sc, P->h_mini.p, P->mini.p, (size_t)n_mini * 4));
+			CK(mga_d2h_s(sc, P->h_u.p, P->u.p, (size_t)n_a * 8)); CK(mga_d2h_s(sc, P->h_b.p, P->b.p, (size_t)n_a * 16));
+		}
+	} else {
+		CK(mga_d2h_s(sc, P->h_mini.p, P->mini.p, (size_t)n_mini * 4));
+		CK(mga_d2h_s(sc, P->h_b.p, P->a.p, (size_t)n_a * 16));
+	}
 	CK(mga_ssync(sc));
 	GPU_RELEASE();
 	if (g_dbg_pipe > 1) PIPE_LOG(" lchain", n, t0);
@@ -780,6 +882,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	/* ---- host: graph chaining + gap list ---- */
 	b = mga_batch_init(gi, opt, n, qlens, seqs, qnames, q_off, n_threads);
 	b->want_text = gaf_part != 0 && (opt->flag & MG_M_CIGAR) && B->dev.d_gseq != 0 && !env_int("MGA_HOST_TEXT", 0); /* only GAF bytes are wanted: cg/ds come from the device */
+	if (dev_gc) mga_batch_set_device_chains(b, h_gchdr_p, P->h_gcpool.p, (const mg_llchain_t*)P->h_lcpool.p, (const mg128_t*)P->h_apool.p);
 	CK(mga_batch_chain(b, h_nmz, h_rep, (const int32_t*)P->h_mini.p, h_minioff, h_nu, h_nb, (const uint64_t*)P->h_u.p, (const mg128_t*)P->h_b.p, h_aoff, long_q ? 2 : is_rmq, h_rflag));
 	if (g_dbg_pipe > 1) PIPE_LOG(" hostchain", n, t0);
 	t1 = mga_wtime(); st->t_host_chain += t1 - t0; t0 = t1;
@@ -953,6 +1056,8 @@ static void stats_merge(mga_stats_t *d, const mga_stats_t *s)
 	d->t_sketch += s->t_sketch, d->t_seed += s->t_seed, d->t_lchain += s->t_lchain, d->t_host_chain += s->t_host_chain, d->t_wfa += s->t_wfa, d->t_host_post += s->t_host_post;
 	d->t_gaf += s->t_gaf;
 	d->n_rescue_dev += s->n_rescue_dev, d->n_rescue_host += s->n_rescue_host;
+	d->n_gwfa += s->n_gwfa, d->n_shortk += s->n_shortk, d->n_gc_retry += s->n_gc_retry;
+	if (s->gc_arena_peak > d->gc_arena_peak) d->gc_arena_peak = s->gc_arena_peak;
 	d->gaf_bytes += s->gaf_bytes;
 }
 

@@ -191,16 +191,17 @@ int mga_dev_text(mga_sctx_t *sc, int n_chain, const mga_txt_chain_t *d_chain, co
 				 mga_txt_res_t *d_res, char *d_pool, int64_t pool_cap, unsigned long long *d_pool_used);
 
 /* ---- graph chaining on the device (k_gchain.hip, gc_core.h): from the chains of k_lchain to filtered graph chains ---- */
-typedef struct { int32_t n_gc, n_lc, n_a, status; int64_t gc_off, lc_off; } mga_gc_hdr_t; /* per read: records at gc_pool + gc_off, lc_pool + lc_off, anchors at ga + a_off[i] */
+typedef struct { int32_t n_gc, n_lc, n_a, status; int64_t gc_off, lc_off, a_off; } mga_gc_hdr_t; /* per read: records at gc_pool + gc_off, lc_pool + lc_off, anchors at a_pool + a_off */
 #define MGA_GC_E_POOL 3   /* status: the chunk's record pools were too small: grow and re-run the listed reads */
+#define MGA_GC_HOST   4   /* status: not chained here (k_lchain left the read's long-join rescue to the host tree): the host chains it */
 int mga_dev_graph_upload(mga_sctx_t *sc, const gfa_t *g, const unsigned char *comp, mga_didx_t *ix); /* arcs, arc index, reverse complements -> HBM */
 size_t mga_gc_rec_bytes(void);
 size_t mga_dev_gchain_arena_bytes(int tier);
 int mga_dev_gchain_waves(int tier);
 int mga_dev_gchain(mga_sctx_t *sc, const mga_didx_t *ix, const mg_mapopt_t *opt, int k, float pen_gap, int n, const int32_t *d_list, int tier,
 				   const int64_t *d_a_off, const int32_t *d_nu, const int32_t *d_nb, const uint64_t *d_u, const mg128_t *d_b,
-				   const int64_t *d_mini_off, const int32_t *d_mini, const int64_t *d_q_off, const char *d_seq, const uint32_t *d_hash,
-				   mga_gc_hdr_t *d_hdr, mg128_t *d_ga, void *d_gc_pool, int64_t gc_cap, mg_llchain_t *d_lc_pool, int64_t lc_cap,
+				   const int64_t *d_mini_off, const int32_t *d_mini, const int64_t *d_q_off, const char *d_seq, const uint32_t *d_hash, const int32_t *d_rflag,
+				   mga_gc_hdr_t *d_hdr, void *d_gc_pool, int64_t gc_cap, mg_llchain_t *d_lc_pool, int64_t lc_cap, mg128_t *d_a_pool, int64_t a_cap,
 				   unsigned long long *d_ctl, int32_t *d_retry);
 /* flat records of one read -> a malloc'ed mg_gchains_t (div and MAPQ computed here, on the host's libm) */
 mg_gchains_t *mga_gchains_from_flat(int32_t n_gc, const void *gc_recs, int32_t n_lc, const mg_llchain_t *lc, int32_t n_a, const mg128_t *a,

@@ -224,11 +224,31 @@ def test_device_index_build_equals_host_build(monkeypatch):
         monkeypatch.setenv("MGA_HOST_INDEX", host)
         G = mga.Graph(graph, preset="lr", cigar=True, n_threads=8)
         R = mga.Reads(reads)
-        out[host] = (G.mo.occ_max1, G.mo.max_lc_skip, mga.map_reads(G, R, n_threads=8))
+        out[host] = (G.mo.occ_max1, G.mo.lc_max_occ, mga.map_reads(G, R, n_threads=8))
         R.close()
         G.close()
     assert out["0"][:2] == out["1"][:2]
     assert out["0"][2] == out["1"][2] and out["0"][2].count(b"\n") >= 600
+    # anchored to the reference: mg_index + mg_opt_update of libmgref.so on the same graph give the same occurrence thresholds
+    # (mg_idx_cal_quantile, index.c:74-93 over ITS hash tables), and the mapping bytes are the reference binary's
+    import ctypes as C
+    need_ref()
+    L = rb.Ref().lib
+    L.mg_opt_set.argtypes = [C.c_char_p, C.POINTER(mga.idxopt_t), C.POINTER(mga.mapopt_t), C.POINTER(mga.ggopt_t)]
+    L.mg_index.argtypes = [C.c_void_p, C.POINTER(mga.idxopt_t), C.c_int, C.POINTER(mga.mapopt_t)]
+    L.mg_index.restype = C.c_void_p
+    L.mg_idx_destroy.argtypes = [C.c_void_p]
+    io, mo, go = mga.idxopt_t(), mga.mapopt_t(), mga.ggopt_t()
+    L.mg_opt_set(None, C.byref(io), C.byref(mo), C.byref(go))
+    L.mg_opt_set(b"lr", C.byref(io), C.byref(mo), C.byref(go))
+    g = L.gfa_read(graph.encode())
+    gi = L.mg_index(g, C.byref(io), 4, C.byref(mo))
+    assert (mo.occ_max1, mo.lc_max_occ) == out["0"][:2], ((mo.occ_max1, mo.lc_max_occ), out["0"][:2])
+    L.mg_idx_destroy(gi)
+    L.gfa_destroy(g)
+    ref_out = os.path.join(d, "ref.gaf")
+    run_ref(["-c", "-x", "lr", "-t", "8", graph, reads], ref_out)
+    assert open(ref_out, "rb").read() == out["0"][2]
 
 
 @pytest.mark.parametrize("preset", ["lr", "asm"])
@@ -625,3 +645,36 @@ def test_dropin_call_and_graph_generation_consume_our_chains(args):
         assert a == b, (args, q, len(a), len(b))
         total += len(a)
     assert total > 1000, total
+
+
+@pytest.mark.parametrize("workload", ["bubbles5", "repeat"])
+def test_graph_chaining_on_device_equals_host_instantiation_and_reference(monkeypatch, workload):
+    """k_gchain (gc_core.h on one GPU lane per read: chain records, clean-up, DP + shortest walks, GWFA bridging, ordering, parents, filters)
+    against the SAME routine on host threads (MGA_HOST_GCHAIN=1) and against the reference binary; the device path must really have run
+    (GWFA bridges and shortest-walk searches counted by the kernel)"""
+    need_ref()
+    d = tempfile.mkdtemp()
+    if workload == "bubbles5":
+        subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "8000000", "-H", "5", "-n", "3000", "-l", "12000", "-s", "61"], stderr=subprocess.DEVNULL)
+        graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    else:
+        graph, reads = _repeat_workload(d)
+    G = mga.Graph(graph, preset="lr", cigar=True, n_threads=8)
+    R = mga.Reads(reads)
+    mga.get_stats(G, reset=True)
+    monkeypatch.setenv("MGA_DEV_GCHAIN", "1")
+    dev = mga.map_reads(G, R, n_threads=8)
+    st = mga.get_stats(G, reset=True)
+    if workload == "bubbles5":
+        assert st["n_gwfa"] > 500 and st["n_shortk"] > 500, st
+    assert st["n_gc_retry"] == 0 and 0 < st["gc_arena_peak"] < (1 << 20), st
+    monkeypatch.delenv("MGA_DEV_GCHAIN")
+    host = mga.map_reads(G, R, n_threads=8)
+    st2 = mga.get_stats(G, reset=True)
+    assert st2["n_gwfa"] == 0          # nothing was counted by the kernel on the host pass
+    R.close()
+    G.close()
+    assert dev == host
+    ref_out = os.path.join(d, "ref.gaf")
+    run_ref(["-c", "-x", "lr", "-t", "8", graph, reads], ref_out)
+    assert open(ref_out, "rb").read() == dev
