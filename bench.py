@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--resident-steps", type=int, default=2)
     ap.add_argument("--threads", type=int, default=0, help="host threads per rank (0: min(64, usable cores / ranks))")
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1: nccl (= RCCL over xGMI, the default) or gloo (host tensors: lets one GPU box run 2 ranks on the same device to test the sharded path)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,9 +123,14 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
+            dist.init_process_group(args.backend)
 
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"
     import minigraph_amd as mga
     from minigraph_amd.dist import map_sharded
     L = mga.load()
@@ -172,7 +178,7 @@ def main():
                 m = mga.map_files_idx(G, [reads_path], n_threads=threads, rank=r, world=w, reuse=last.get("shard"))
                 last["shard"] = m
                 return m.view(), m.seg_len
-            last["gaf_bytes"] = map_sharded(mapper, dst=0, device="cuda")
+            last["gaf_bytes"] = map_sharded(mapper, dst=0, device=coll_dev, as_tensor=True)   # ONE uint8 tensor on rank 0, input order
 
     def sync():
         if dist is not None:
@@ -194,10 +200,10 @@ def main():
     st = mga.get_stats(G, reset=True)
     n_reads_rank, n_bases_rank = st["n_reads"] // max(1, args.steps), st["n_bases"] // max(1, args.steps)
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        tb = torch.tensor([n_bases_rank, n_reads_rank] + [st[k] for k in ("n_mz", "n_hit", "wfa_t_bases", "wfa_q_bases", "gaf_bytes")], dtype=torch.int64, device="cuda")
+        tb = torch.tensor([n_bases_rank, n_reads_rank] + [st[k] for k in ("n_mz", "n_hit", "wfa_t_bases", "wfa_q_bases", "gaf_bytes")], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(tb)
         total_bases, total_reads = int(tb[0].item()), int(tb[1].item())
         agg = dict(zip(("n_mz", "n_hit", "wfa_t_bases", "wfa_q_bases", "gaf_bytes"), (int(x) for x in tb[2:].tolist())))
@@ -213,7 +219,7 @@ def main():
             gaf_first = last["gaf"].bytes()
             last["gaf"].free()
         elif not args.no_gather:
-            gaf_first = last["gaf_bytes"]
+            gaf_first = last["gaf_bytes"][:min(int(last["gaf_bytes"].numel()), 12000 * args.cpu_reads)].cpu().numpy().tobytes()   # enough for the CPU sample
         if args.resident_steps > 0:
             R = mga.Reads(reads_path, max_reads=args.reads)
             mga.map_reads(G, R, n_threads=threads, copy=False)
@@ -328,7 +334,7 @@ def main():
                 res["cpu_baseline"] = cb
                 if gaf_first is not None:
                     want = open(cpu_gaf, "rb").read()
-                    ok = gaf_first[:len(want)] == want and (len(gaf_first) == len(want) or gaf_first[len(want) - 1:len(want)] == b"\n")
+                    ok = len(gaf_first) >= len(want) and gaf_first[:len(want)] == want and (len(gaf_first) == len(want) or gaf_first[len(want) - 1:len(want)] == b"\n")
                     res["parity"] = ("GAF byte-identical to the reference on ALL %d reads of the CPU sample (%d bytes)" % (n_cpu, len(want))) if ok else "MISMATCH vs reference GAF"
             except Exception as e:  # the baseline is a reported number, never a reason to lose the bench line
                 res["cpu_baseline"] = dict(value=None, unit="Gbp/s", cores=quota, kind="reference", sample="failed: %r" % (e,))

@@ -794,7 +794,10 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 			h_rflag = MGA_MALLOC(int32_t, n);
 			CK(mga_d2h_s(sc, h_rflag, P->rflag.p, (size_t)n * 4));
 		}
-		dev_gc = rs.enabled && B->dev.d_arc != 0 && env_int("MGA_DEV_GCHAIN", 0) && !env_int("MGA_HOST_GCHAIN", 0); /* graph chaining: gc_core.h on host threads, or (MGA_DEV_GCHAIN=1) on the device, one wavefront per read (k_gchain.hip; see DESIGN.md 4 for why that is not the default yet) */
+		/* graph chaining (gc_core.h) runs where it fits: on the device, one wavefront per read (k_gchain.hip, [measured] ~0.18 s of GPU time per 100k reads),
+		 * when this GPU has few host threads to itself -- a node whose CPU quota does not grow with its GPUs -- and on the host threads
+		 * ([measured] ~2 CPU-s per 100k reads) when there are enough of them to keep up.  MGA_DEV_GCHAIN=1 / 0 forces one or the other; same bytes either way. */
+		dev_gc = rs.enabled && B->dev.d_arc != 0 && env_int("MGA_DEV_GCHAIN", n_threads <= 6) && !env_int("MGA_HOST_GCHAIN", 0);
 		if (dev_gc) {
 			/* ---- graph chaining: chain records, clean-up, DP + shortest walks, GWFA bridging, ordering, filters -- one wavefront per read ---- */
 			const size_t rec = mga_gc_rec_bytes();
@@ -901,8 +904,10 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 		/* uploads ride the copy engine while another chunk owns the WFA phase */
 		CK(mga_h2d_s(sc, P->tseq.p, P->h_tseq.p, (size_t)n_tb + 64)); CK(mga_h2d_s(sc, P->prob.p, h_prob, (size_t)n_prob * sizeof(mga_wfa_prob_t)));
 		GPU_ACQUIRE(&g_gpu_wfa);
-		pool_cap = (n_tb + n_prob * 8) / 2 + 4096 + 40000LL * 512; /* + abandoned block tails (<= 512 ops) of every resident wave */
-		for (i = 0; i < b->n_threads; ++i) pool_cap += b->tp[i].wfa_q_bases / 2;
+		/* CIGAR pool: a global alignment has at most tl + ql operators, so target bases + query bases bound the chunk; + the abandoned block
+		 * tails (<= 512 ops) of every resident wave.  Sized to the bound, the pool cannot overflow whatever the divergence. */
+		pool_cap = n_tb + 4096 + 40000LL * 512;
+		for (i = 0; i < b->n_threads; ++i) pool_cap += b->tp[i].wfa_q_bases;
 		CK(mga_dbuf_reserve(&P->pool, (size_t)pool_cap * 4)); CK(mga_dmemset_s(sc, P->used.p, 0, 8));
 		/* the tier ladder runs on the device (k_wfa_sched.hip); the host never walks the problems */
 		CK(mga_dev_wfa_solve(sc, (int)n_prob, (const mga_wfa_prob_t*)P->prob.p, (const char*)P->tseq.p, d_seq, (mga_wfa_res_t*)P->res.p,
@@ -917,20 +922,25 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 				const int64_t n_item = mga_batch_n_items(b), n_chain = mga_batch_n_chains(b), n_vert = mga_batch_n_verts(b);
 				int64_t txt_cap = 4096, k;
 				unsigned long long txt_used = 0;
-				for (k = 0; k < n; ++k) txt_cap += 3 * (int64_t)qlens[k] + 1024;
+				for (k = 0; k < n; ++k) txt_cap += (env_int("MGA_TXT_TIGHT", 0) ? 1 : 3) * (int64_t)qlens[k] / (env_int("MGA_TXT_TIGHT", 0) ? 4 : 1) + 1024; /* (MGA_TXT_TIGHT=1: a deliberately small pool, so that a test sees the second launch) */
 				CK(mga_hbuf_reserve(&P->h_item, (size_t)n_item * sizeof(mga_cigitem_t) + 16)); CK(mga_hbuf_reserve(&P->h_chain, (size_t)n_chain * sizeof(mga_txt_chain_t) + 16));
 				CK(mga_hbuf_reserve(&P->h_vert, (size_t)n_vert * 4 + 16));
 				mga_batch_text_export(b, (mga_cigitem_t*)P->h_item.p, (mga_txt_chain_t*)P->h_chain.p, (uint32_t*)P->h_vert.p);
 				CK(mga_dbuf_reserve(&P->item, (size_t)n_item * sizeof(mga_cigitem_t) + 16)); CK(mga_dbuf_reserve(&P->chain, (size_t)n_chain * sizeof(mga_txt_chain_t) + 16));
 				CK(mga_dbuf_reserve(&P->vert, (size_t)n_vert * 4 + 16)); CK(mga_dbuf_reserve(&P->txtres, (size_t)n_chain * sizeof(mga_txt_res_t) + 16));
-				CK(mga_dbuf_reserve(&P->txtpool, (size_t)txt_cap)); CK(mga_dmemset_s(sc, P->used.p, 0, 8));
 				CK(mga_h2d_s(sc, P->item.p, P->h_item.p, (size_t)n_item * sizeof(mga_cigitem_t))); CK(mga_h2d_s(sc, P->chain.p, P->h_chain.p, (size_t)n_chain * sizeof(mga_txt_chain_t)));
 				CK(mga_h2d_s(sc, P->vert.p, P->h_vert.p, (size_t)n_vert * 4));
-				CK(mga_dev_text(sc, (int)n_chain, (const mga_txt_chain_t*)P->chain.p, (const mga_cigitem_t*)P->item.p, n_vert, (const uint32_t*)P->vert.p, &B->dev, d_seq,
-								n_item + n_ops, (const int32_t*)P->ncig.p, (const int64_t*)P->cigoff.p, (const uint32_t*)P->ord.p, (mga_txt_res_t*)P->txtres.p,
-								(char*)P->txtpool.p, txt_cap, (unsigned long long*)P->used.p));
-				CK(mga_d2h_s(sc, &txt_used, P->used.p, 8)); CK(mga_ssync(sc));
-				if ((int64_t)txt_used > txt_cap) { mga_set_error("text kernel: output of %lld bytes exceeds the pool of %lld", (long long)txt_used, (long long)txt_cap); rc = -1; goto done; }
+				for (k = 0;; ++k) { /* the pool is sized for ordinary reads (~1 byte of cg + ds per base); the kernel counts what it WOULD have written, so a chunk of
+				                     * very divergent reads or many printed secondaries gets a pool of exactly that size and a second launch */
+					CK(mga_dbuf_reserve(&P->txtpool, (size_t)txt_cap)); CK(mga_dmemset_s(sc, P->used.p, 0, 8));
+					CK(mga_dev_text(sc, (int)n_chain, (const mga_txt_chain_t*)P->chain.p, (const mga_cigitem_t*)P->item.p, n_vert, (const uint32_t*)P->vert.p, &B->dev, d_seq,
+									n_item + n_ops, (const int32_t*)P->ncig.p, (const int64_t*)P->cigoff.p, (const uint32_t*)P->ord.p, (mga_txt_res_t*)P->txtres.p,
+									(char*)P->txtpool.p, txt_cap, (unsigned long long*)P->used.p));
+					CK(mga_d2h_s(sc, &txt_used, P->used.p, 8)); CK(mga_ssync(sc));
+					if ((int64_t)txt_used <= txt_cap) break;
+					if (k >= 2) { mga_set_error("text kernel: output of %lld bytes exceeds the pool of %lld", (long long)txt_used, (long long)txt_cap); rc = -1; goto done; }
+					txt_cap = (int64_t)txt_used + ((int64_t)txt_used >> 4) + 4096;
+				}
 				CK(mga_hbuf_reserve(&P->h_txtres, (size_t)n_chain * sizeof(mga_txt_res_t) + 16)); CK(mga_hbuf_reserve(&P->h_txtpool, (size_t)txt_used + 16));
 				CK(mga_d2h_s(sc, P->h_txtres.p, P->txtres.p, (size_t)n_chain * sizeof(mga_txt_res_t))); CK(mga_d2h_s(sc, P->h_txtpool.p, P->txtpool.p, (size_t)txt_used));
 				CK(mga_ssync(sc));

@@ -54,10 +54,11 @@ def assemble_segments(parts, seg_lens):
     return b"".join(out)
 
 
-def map_sharded(mapper, dst=0, device="cpu"):
+def map_sharded(mapper, dst=0, device="cpu", as_tensor=False):
     """one input -> world ranks -> one GAF on `dst` (gmap.c:98-141 fanned out over devices).  mapper(rank, world) maps this rank's shard
     and returns (payload, seg_len): its GAF bytes (bytes or a uint8 numpy view) and the per-segment byte counts.  One all_gather of the
-    segment tables + one gather of the payloads (RCCL when device == "cuda"); returns the assembled bytes on dst, None elsewhere."""
+    segment tables + one gather of the payloads (RCCL when device == "cuda"); returns the assembled output on dst, None elsewhere:
+    bytes, or with as_tensor=True ONE uint8 tensor on `device` (the parts are put in order by torch.cat, no host round trip)."""
     import numpy as np
     world, rank = dist.get_world_size(), dist.get_rank()
     payload, seg_len = mapper(rank, world)
@@ -69,7 +70,16 @@ def map_sharded(mapper, dst=0, device="cpu"):
         tab[:len(seg_len)] = torch.tensor(seg_len, dtype=torch.int64)
     tabs = [torch.zeros_like(tab) for _ in range(world)]
     dist.all_gather(tabs, tab)
-    parts = gather_bytes(payload, dst=dst, device=device)
+    parts = gather_bytes(payload, dst=dst, device=device, as_tensors=as_tensor)
     if rank != dst:
         return None
-    return assemble_segments(parts, [t.cpu().tolist() for t in tabs])
+    tabs = [t.cpu().tolist() for t in tabs]
+    if not as_tensor:
+        return assemble_segments(parts, tabs)
+    pos, out = [0] * world, []
+    for s in range(len(tabs[0])):
+        for r in range(world):
+            ln = int(tabs[r][s])
+            out.append(parts[r][pos[r]:pos[r] + ln])
+            pos[r] += ln
+    return torch.cat(out) if out else torch.empty(0, dtype=torch.uint8, device=device)

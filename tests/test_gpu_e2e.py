@@ -678,3 +678,19 @@ def test_graph_chaining_on_device_equals_host_instantiation_and_reference(monkey
     ref_out = os.path.join(d, "ref.gaf")
     run_ref(["-c", "-x", "lr", "-t", "8", graph, reads], ref_out)
     assert open(ref_out, "rb").read() == dev
+
+
+def test_text_pool_is_regrown_and_relaunched(monkeypatch):
+    """the device text pool is sized for ordinary reads; when a chunk needs more (very divergent reads, many printed secondaries) the kernel
+    reports what it would have written and the stage runs again with a pool of that size -- forced here with a tiny pool"""
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "2000000", "-H", "3", "-n", "500", "-s", "71"], stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    G = mga.Graph(graph, preset="lr", cigar=True, n_threads=8)
+    R = mga.Reads(reads)
+    want = mga.map_reads(G, R, n_threads=8)
+    monkeypatch.setenv("MGA_TXT_TIGHT", "1")
+    got = mga.map_reads(G, R, n_threads=8)
+    R.close()
+    G.close()
+    assert got == want and want.count(b"\tcg:Z:") >= 490
