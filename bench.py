@@ -314,9 +314,9 @@ def main():
                    config=dict(workload="configs[3] shape: %d x 10kb synthetic ONT reads per GPU (%d in all, ONE file) vs %.2f Gbp %d-haplotype bubble graph in %d chromosomes, -cx lr -c"
                                % (args.reads, total_reads, graph_bp / 1e9, args.hap, args.chr),
                                interval="FASTA file -> parse -> H2D -> map -> GAF text in one memory buffer per rank%s (reference: worker_pipeline - mg_opt_update); graph load + index build excluded (index_s)"
-                               % (" -> RCCL gather to rank 0 -> one GAF in input order" if (n_gpus > 1 and not args.no_gather) else ""),
+                               % ((" -> %s gather to rank 0 -> one GAF in input order" % ("RCCL" if args.backend == "nccl" else args.backend)) if (n_gpus > 1 and not args.no_gather) else ""),
                                reads_per_gpu=args.reads, read_len=10000, err=0.1,
-                               sharding="1 input file cut into %d contiguous byte ranges at record starts, index replicated%s" % (n_gpus, ", GAF gathered to rank 0 over RCCL" if (n_gpus > 1 and not args.no_gather) else ""),
+                               sharding="1 input file cut into %d contiguous byte ranges at record starts, index replicated%s" % (n_gpus, (", GAF gathered to rank 0 over %s" % ("RCCL" if args.backend == "nccl" else args.backend)) if (n_gpus > 1 and not args.no_gather) else ""),
                                host_threads_per_rank=threads),
                    roofline=roof if roof else roof_path, roofline_path=roof_path,
                    resident=resident,
