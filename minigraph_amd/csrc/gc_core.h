@@ -147,6 +147,22 @@ GC_HD void gc_pmove_down(void *dst, const void *src, int64_t bytes)
 	}
 }
 
+/* move to a HIGHER address (dst >= src), regions may overlap: blocks from the top down */
+GC_HD void gc_pmove_up(void *dst, const void *src, int64_t bytes)
+{
+	uint32_t *d = (uint32_t*)dst;
+	const uint32_t *s = (const uint32_t*)src;
+	const int64_t n = bytes >> 2;
+	if (d == s) return;
+	for (int64_t e = n; e > 0; e -= GC_NLANE) {
+		const int64_t i = e - 1 - GC_LANE;
+		const uint32_t v = i >= 0 ? s[i] : 0;
+		gc_sync();
+		if (i >= 0) d[i] = v;
+		gc_sync();
+	}
+}
+
 /* growable array in the arena: {a, n, m}; growth re-allocates at the top (in place when the array is the last allocation) */
 #define GC_VEC(T) struct { T *a; int32_t n, m; }
 #define gc_vec_zero(v) ((v).a = 0, (v).n = (v).m = 0)
@@ -1131,28 +1147,23 @@ GC_HD int gc_diag_sort(gc_arena_t *A, gc_gw_t *z, int32_t n_a, gc_diag_t *a)
 			GC_ALLOC(A, gc_kv_t, z->sort_kv, z->m_sort);
 			GC_ALLOC(A, gc_diag_t, z->sort_tmp, z->m_sort);
 		}
-#if (GC_PARSORT & 2)
-		GC_PAR_FOR(i, n_c) z->sort_kv[i].key = c[i].vd, z->sort_kv[i].val = (uint64_t)i;
-		gc_sync();
-		GC_TRY(gc_ksort(A, z->sort_kv, n_c, 8));
-		GC_PAR_FOR(i, n_c) z->sort_tmp[i] = c[z->sort_kv[i].val];
-		gc_sync();
-		GC_PAR_FOR(i, n_c) c[i] = z->sort_tmp[i];
-		gc_sync();
-#elif (GC_PARSORT & 8)
-		for (int32_t i = 0; i < n_c; ++i) z->sort_kv[i].key = c[i].vd, z->sort_kv[i].val = (uint64_t)i;
-		GC_TRY(gc_ksort(A, z->sort_kv, n_c, 8));
-		gc_sync();
-		GC_PAR_FOR(i, n_c) z->sort_tmp[i] = c[z->sort_kv[i].val];
-		gc_sync();
-		GC_PAR_FOR(i, n_c) c[i] = z->sort_tmp[i];
-		gc_sync();
-#else
-		for (int32_t i = 0; i < n_c; ++i) z->sort_kv[i].key = c[i].vd, z->sort_kv[i].val = (uint64_t)i;
-		GC_TRY(gc_ksort(A, z->sort_kv, n_c, 8));
-		for (int32_t i = 0; i < n_c; ++i) z->sort_tmp[i] = c[z->sort_kv[i].val];
-		memcpy(c, z->sort_tmp, (size_t)n_c * sizeof(gc_diag_t));
-#endif
+		if (n_c <= 64) { /* klib sorts up to 64 records by insertion (ksort.h:118-128,160), a STABLE sort: every lane finds the place of its own record --
+			              * records with a smaller key, plus equal ones in front of it -- and puts it there */
+			GC_PAR_FOR(i, n_c) {
+				const gc_diag_t me = c[i];
+				int32_t r = 0;
+				for (int32_t j = 0; j < n_c; ++j) { const uint64_t kj = c[j].vd; r += (kj < me.vd) | ((kj == me.vd) & (j < i)); }
+				z->sort_tmp[r] = me;
+			}
+			gc_sync();
+			GC_PAR_FOR(i, n_c) c[i] = z->sort_tmp[i];
+			gc_sync();
+		} else { /* the radix passes of the klib sort are not stable: replayed move by move */
+			for (int32_t i = 0; i < n_c; ++i) z->sort_kv[i].key = c[i].vd, z->sort_kv[i].val = (uint64_t)i;
+			GC_TRY(gc_ksort(A, z->sort_kv, n_c, 8));
+			for (int32_t i = 0; i < n_c; ++i) z->sort_tmp[i] = c[z->sort_kv[i].val];
+			memcpy(c, z->sort_tmp, (size_t)n_c * sizeof(gc_diag_t));
+		}
 	}
 #if (GC_PARSORT & 4)
 	GC_PAR_FOR(k, n_c) c[k].xo &= 0xfffffffeU;
@@ -1186,6 +1197,31 @@ GC_HD int gc_diag_sort(gc_arena_t *A, gc_gw_t *z, int32_t n_a, gc_diag_t *a)
 	}
 	return GC_OK;
 }
+/* add [x0, x1) to a canonical list of finished-diagonal ranges (ascending, disjoint, not touching): what sorting the new intervals in and
+ * coalescing everything that overlaps or touches (gfa-ed.c:69-82,258-264) leaves, without walking the whole list -- a binary search, then
+ * the ranges the new one reaches are replaced by their union.  The union of intervals has ONE canonical form, so the list is the reference's. */
+GC_HD int gc_intv_add(gc_arena_t *A, gc_intv_v *L, uint64_t x0, uint64_t x1)
+{
+	int32_t lo = 0, hi = L->n;
+	while (lo < hi) { const int32_t m = (lo + hi) >> 1; if (L->a[m].vd1 < x0) lo = m + 1; else hi = m; } /* first range that ends at or behind x0 */
+	int32_t e = lo; /* ranges lo..e-1 overlap or touch [x0, x1) */
+	while (e < L->n && L->a[e].vd0 <= x1) ++e;
+	if (e == lo) { /* touches nothing: a new range at lo */
+		GC_TRY(gc_vec_reserve(A, *L, L->n + 1));
+		if (lo < L->n) gc_pmove_up(&L->a[lo + 1], &L->a[lo], (int64_t)(L->n - lo) * (int64_t)sizeof(gc_intv_t));
+		L->a[lo].vd0 = x0, L->a[lo].vd1 = x1;
+		++L->n;
+		return GC_OK;
+	}
+	const uint64_t n0 = L->a[lo].vd0 < x0 ? L->a[lo].vd0 : x0, n1 = L->a[e - 1].vd1 > x1 ? L->a[e - 1].vd1 : x1;
+	L->a[lo].vd0 = n0, L->a[lo].vd1 = n1;
+	if (e - lo > 1) {
+		if (e < L->n) gc_pmove_down(&L->a[lo + 1], &L->a[e], (int64_t)(L->n - e) * (int64_t)sizeof(gc_intv_t));
+		L->n -= e - lo - 1;
+	}
+	return GC_OK;
+}
+
 /* in-place, order-preserving removal of the elements of a[0..n) that `drop` marks; the verdict of element i is computed by the lane that
  * owns it, a ballot gives every kept element its new place.  dst <= src, and a block is loaded completely before it is stored. */
 #define GC_COMPACT_BEGIN(n_) { const int32_t gcn_ = (n_); int32_t gcm_ = 0; for (int32_t gcb_ = 0; gcb_ < gcn_; gcb_ += GC_NLANE) { const int32_t gci_ = gcb_ + GC_LANE; const int gcin_ = gci_ < gcn_;
@@ -1194,24 +1230,7 @@ GC_HD int gc_diag_sort(gc_arena_t *A, gc_gw_t *z, int32_t n_a, gc_diag_t *a)
 GC_HD int gc_gw_dedup(gc_arena_t *A, gc_gw_t *z, int32_t *n_a_, gc_diag_t *a) /* gwf_dedup, gfa-ed.c:258-271 */
 {
 	int32_t n_a = *n_a_;
-	if (z->fresh.n > 0) { /* (nothing new this step: the merged list stays what it is) */
-		int sorted = 1;
-		for (int32_t i = 1; i < z->fresh.n; ++i) if (z->fresh.a[i - 1].vd0 > z->fresh.a[i].vd0) { sorted = 0; break; }
-		if (!sorted) { /* ties are merged away below: any correct sort */
-			for (int32_t i = 1; i < z->fresh.n; ++i) { gc_intv_t t = z->fresh.a[i]; int32_t j = i; for (; j > 0 && t.vd0 < z->fresh.a[j - 1].vd0; --j) z->fresh.a[j] = z->fresh.a[j - 1]; z->fresh.a[j] = t; }
-		}
-		GC_TRY(gc_vec_reserve(A, z->swap, z->done.n + 1));
-		gc_pcopy(z->swap.a, z->done.a, (int64_t)z->done.n * (int64_t)sizeof(gc_intv_t)); z->swap.n = z->done.n;
-		GC_TRY(gc_vec_reserve(A, z->done, z->done.n + z->fresh.n + 1));
-		int32_t ii = 0, jj = 0, kk = 0;
-		while (ii < z->swap.n && jj < z->fresh.n) {
-			if (z->swap.a[ii].vd0 <= z->fresh.a[jj].vd0) z->done.a[kk++] = z->swap.a[ii++];
-			else z->done.a[kk++] = z->fresh.a[jj++];
-		}
-		while (ii < z->swap.n) z->done.a[kk++] = z->swap.a[ii++];
-		while (jj < z->fresh.n) z->done.a[kk++] = z->fresh.a[jj++];
-		z->done.n = gc_intv_merge(kk, z->done.a);
-	}
+	for (int32_t i = 0; i < z->fresh.n; ++i) GC_TRY(gc_intv_add(A, &z->done, z->fresh.a[i].vd0, z->fresh.a[i].vd1)); /* this step's finished diagonals */
 	{
 		int unsorted = 0;
 		GC_PAR_FOR(i, n_a) if (i > 0 && a[i - 1].vd > a[i].vd) unsorted = 1;
@@ -1276,6 +1295,54 @@ GC_HD int gc_gw_extend_run(gc_arena_t *A, gc_gw_t *z, int32_t n, gc_diag_t *a, g
 	GC_TRY(gc_vec_reserve(A, *B, B->n + n + 2));
 	GC_TRY(gc_vec_reserve(A, *H, H->n + n));
 	GC_TRY(gc_vec_reserve(A, z->fresh, z->fresh.n + n + 2));
+#if defined(__HIP_DEVICE_COMPILE__)
+	if (n <= 64) { /* the usual case, a run fits the wavefront: a lane keeps its diagonal in registers from the extension to the compacted output, the
+	                * neighbours' cells come by lane shuffles, places in H / B / the finished list by ballots -- one pass over memory, one fence */
+		const int32_t j = GC_LANE;
+		const int in = j < n;
+		gc_diag_t me;
+		me.vd = 0, me.k = 0, me.len = 0, me.xo = 0, me.t = 0;
+		if (in) {
+			me = a[j];
+			const int32_t k2 = gc_extend1((int32_t)me.vd - GC_DSHIFT, me.k, vl, ts, z->ql, z->q);
+			me.len = k2 - me.k, me.xo += (uint32_t)me.len << 2, me.k = k2;
+		}
+		const int32_t kL = __shfl_up(me.k, 1), tL = __shfl_up(me.t, 1), kR = __shfl_down(me.k, 1), tR = __shfl_down(me.t, 1);
+		const uint32_t xL = __shfl_up(me.xo, 1), xR = __shfl_down(me.xo, 1);
+		/* the cell of my diagonal in the next wavefront */
+		uint32_t mx = me.xo + 4;
+		int32_t mk = me.k + 1, mt = me.t;
+		if (in && j > 0 && kL > me.k + 1) mx = xL + 2, mk = kL, mt = tL;
+		if (in && j + 1 < n && !(mk > kR + 1)) mx = xR + 2, mt = tR, mk = kR + 1;
+		const int32_t d = (int32_t)me.vd - GC_DSHIFT;
+		/* cells at a vertex / query end go to H, flagged, in diagonal order */
+		{
+			const int at_end = in && (me.k == vl - 1 || d + me.k == z->ql - 1);
+			const uint64_t m = gc_ballot(at_end);
+			if (at_end) { gc_diag_t h = me; h.xo |= 1; H->a[H->n + gc_rank(m)] = h; }
+			H->n += gc_popc(m);
+		}
+		/* output order: the cell left of the run (lane 0), the run's cells, the cell right of it (lane n - 1) */
+		const int is0 = in && j == 0, isN = in && j == n - 1;
+		const int32_t k0 = me.k + 1, kN = me.k; /* left edge: vd - 1, xo + 2, k + 1; right edge: vd + 1, xo + 2, k */
+		const int keep0 = is0 && (d - 1) + k0 < z->ql && k0 < vl, fin0 = is0 && !keep0 && k0 == vl;
+		const int keepM = in && d + mk < z->ql && mk < vl, finM = in && !keepM && mk == vl;
+		const int keepN = isN && (d + 1) + kN < z->ql && kN < vl, finN = isN && !keepN && kN == vl;
+		const uint64_t b0 = gc_ballot(keep0), bM = gc_ballot(keepM), bN = gc_ballot(keepN), f0 = gc_ballot(fin0), fM = gc_ballot(finM), fN = gc_ballot(finN);
+		gc_diag_t *b = &B->a[B->n];
+		gc_intv_t *fr = &z->fresh.a[z->fresh.n];
+		if (keep0) { gc_diag_t c; c.vd = me.vd - 1, c.k = k0, c.len = 0, c.xo = me.xo + 2, c.t = me.t; b[0] = c; }
+		if (keepM) { gc_diag_t c; c.vd = me.vd, c.k = mk, c.len = 0, c.xo = mx, c.t = mt; b[gc_popc(b0) + gc_rank(bM)] = c; }
+		if (keepN) { gc_diag_t c; c.vd = me.vd + 1, c.k = kN, c.len = 0, c.xo = me.xo + 2, c.t = me.t; b[gc_popc(b0) + gc_popc(bM)] = c; }
+		if (fin0) { fr[0].vd0 = gc_mk_vd(v, d - 1), fr[0].vd1 = fr[0].vd0 + 1; }
+		if (finM) { gc_intv_t *iv = &fr[gc_popc(f0) + gc_rank(fM)]; iv->vd0 = gc_mk_vd(v, d), iv->vd1 = iv->vd0 + 1; }
+		if (finN) { gc_intv_t *iv = &fr[gc_popc(f0) + gc_popc(fM)]; iv->vd0 = gc_mk_vd(v, d + 1), iv->vd1 = iv->vd0 + 1; }
+		B->n += gc_popc(b0) + gc_popc(bM) + gc_popc(bN);
+		z->fresh.n += gc_popc(f0) + gc_popc(fM) + gc_popc(fN);
+		gc_sync();
+		return GC_OK;
+	}
+#endif
 	GC_PAR_FOR(j, n) {
 		const int32_t k = gc_extend1((int32_t)a[j].vd - GC_DSHIFT, a[j].k, vl, ts, z->ql, z->q);
 		a[j].len = k - a[j].k, a[j].xo += (uint32_t)(k - a[j].k) << 2, a[j].k = k;

@@ -84,7 +84,7 @@ __device__ __forceinline__ void gck_copy_words(void *dst, const void *src, int64
 	for (int64_t i = lane, n = bytes >> 2; i < n; i += 64) d[i] = s[i];
 }
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_gchain(gck_in_t in, gck_out_t out, gc_graph_t G, gc_par_t P, char *arena_mem, int64_t arena_bytes)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) k_gchain(gck_in_t in, gck_out_t out, gc_graph_t G, gc_par_t P, char *arena_mem, int64_t arena_bytes)
 {
 	const int lane = threadIdx.x;
 	char *my_arena = arena_mem + (int64_t)blockIdx.x * arena_bytes;
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 }
 
 extern "C" size_t mga_dev_gchain_arena_bytes(int tier) { return tier == 0 ? (size_t)1 << 20 : (size_t)256 << 20; }
-extern "C" int mga_dev_gchain_waves(int tier) { return tier == 0 ? 4096 : 24; } /* tier 0: 256 CUs x 4 SIMDs x 4 resident waves */
+extern "C" int mga_dev_gchain_waves(int tier) { return tier == 0 ? 2048 : 24; } /* tier 0: 256 CUs x 4 SIMDs x 2 resident waves (246 VGPRs, no spills: [measured] same kernel time as 4 waves with 513 spills) */
 
 static void gc_par_from_opt(const mg_mapopt_t *opt, int k, float pen_gap, gc_par_t *P)
 {
