@@ -12,7 +12,13 @@ static inline void ks_room(kstring_t *s, size_t extra)
 {
 	if (s->l + extra + 1 > s->m) {
 		size_t m = s->l + extra + 1;
+		if (m > 0xfffffff0u) { /* kstring_t (mgpriv.h:31-37) counts in 32 bits: fail loudly instead of wrapping.  A piece is one thread's share of a 16384-read chunk;
+		                        * with the default -K 500M it stays far below this */
+			fprintf(stderr, "[E::%s] more than 4 GB of GAF text in one output piece: use a smaller -K or more threads\n", __func__);
+			abort();
+		}
 		m += m >> 1;
+		if (m > 0xfffffff0u) m = 0xfffffff0u;
 		s->m = (unsigned)(m < 64 ? 64 : m);
 		s->s = (char*)realloc(s->s, s->m);
 	}

@@ -16,6 +16,8 @@
 // truncation by (int) -- identical to the reference built with -msse4.
 // Backtrack + compaction follow the reference order of operations; the two klib sorts use the exact
 // permutation emulation of dev_klibsort.h.
+#include <stdio.h>
+#include <stdlib.h>
 #include "mga_dev.h"
 #include "dev_common.h"
 #include "dev_klibsort.h"
@@ -35,6 +37,11 @@
 //   (2) gathers the <= 64 candidates, rank-sorts them by (y, index) and replays the heuristic from ballot masks
 //       exactly like the first pass; more than 64 candidates also defers the read to the host.
 // [measured] the rescue fires on ~48 % of 10 kb reads and cost 46 us/read of host CPU, a third of the host budget.
+// profiling aid (MGA_LC_PROF=1): cycles per phase summed over reads: [0] first-pass DP, [1] its backtrack + compaction, [2] rescue sort, [3] rescue DP, [4] rescue backtrack
+__device__ unsigned long long g_lc_prof[8];
+__device__ int g_lc_prof_on;
+#define LC_TICK(id) do { if (g_lc_prof_on && lane == 0) { const long long now_ = (long long)clock64(); atomicAdd(&g_lc_prof[id], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
+#define LC_RESCUE_DEV_MAX 16384 // chained anchors of a read beyond which the long-join rescue is left to the host tree (~0.5 Mbp of read)
 struct lc_rescue_t {
 	int32_t enabled;          // bw_long > bw, long-read mode
 	int32_t max_dist, max_dist_inner, bw, max_skip, cap, min_cnt, min_sc;
@@ -84,6 +91,30 @@ __device__ void lc_dp(const mg128_t *__restrict__ a, int32_t n, mga_lchain_par_t
 	__syncthreads();
 	int32_t st = 0, max_ii = -1;
 	for (int32_t i = 0; i < n; ++i) {
+		{ // Anchors without any predecessor in reach -- the previous anchor (by x) lies on another (segment, strand) or more than max_dist_x back:
+		  // on a multi-gigabase graph more than half of a read's seed hits are such strays -- leave no trace in the sequential state of the loop:
+		  // f = v = span, p = -1, and the "best anchor in reach" becomes the anchor itself (the recomputation at lchain.c:191-196 finds nothing, the
+		  // update at :203 then takes i).  A run of them is written by the lanes at once instead of costing one trip of the loop each.
+			const int32_t k = i + lane;
+			bool iso = false;
+			uint64_t yk = 0;
+			if (k < n) {
+				const uint64_t xk = a[k].x;
+				yk = a[k].y;
+				if (k == 0) iso = true;
+				else { const uint64_t xp = a[k - 1].x; iso = xk >> 32 != xp >> 32 || xk > xp + (uint64_t)(int64_t)P.max_dist_x; }
+			}
+			const uint64_t m = __ballot(iso);
+			const int r = (~m) ? (int)__builtin_ctzll(~m) : 64; // leading run of strays
+			if (r > 0) {
+				if (lane < r) { const int32_t sp = (int32_t)(yk >> 32 & 0xff); f[k] = sp, p[k] = -1, v[k] = sp; }
+				max_ii = i + r - 1;
+				if (st < i + r - 1) st = i + r - 1; // nothing left of the last stray is in reach of what follows (x ascending)
+				i += r - 1;
+				__syncthreads();
+				continue;
+			}
+		}
 		const uint64_t xi = a[i].x, yi = a[i].y;
 		while (st < i) { // lchain.c:171
 			const uint64_t xs = a[st].x;
@@ -409,15 +440,23 @@ __global__ void __launch_bounds__(64) k_lchain(int n_reads, const mg128_t *__res
 	if (P.max_dist_y < P.bw) P.max_dist_y = P.bw;
 
 	int32_t n_u = 0, n_v = 0;
+	long long tick_ = g_lc_prof_on ? (long long)clock64() : 0;
 	lc_dp(a, n, P, W, lane);
+	LC_TICK(0);
 	lc_backtrack_compact(a, n, P.min_sc, P.min_cnt, P.bw, W, u, b, &n_u, &n_v, &L, lane);
+	LC_TICK(1);
 
 	// ---- long-join rescue (map-algo.c:407-417) ----
 	if (R.enabled && n_u > 1 && q_off) {
 		const int32_t qlen = (int32_t)(q_off[r + 1] - q_off[r]);
 		const int32_t st = (int32_t)b[0].y, en = (int32_t)b[(int32_t)u[0] - 1].y;
 		const int32_t unc = qlen - (en - st);
-		if (unc > R.rescue_size || (float)unc > (float)qlen * R.rescue_ratio) {
+		if ((unc > R.rescue_size || (float)unc > (float)qlen * R.rescue_ratio) && n_v > LC_RESCUE_DEV_MAX) {
+			// an ultra-long read (hundreds of kb and up): the rescue's per-anchor window searches on ONE wavefront would take longer than the host's
+			// tree over the same anchors ([measured] round 1: 2 x 5 Mbp reads 2.2 s in here against 0.9 s for the whole reference job), so the read
+			// goes the way of the tied ones -- first-pass chains out, flag 2, the host re-chains it with the RMQ tree (and chains it through the graph)
+			if (lane == 0 && d_flag) d_flag[r] = 2;
+		} else if (unc > R.rescue_size || (float)unc > (float)qlen * R.rescue_ratio) {
 			mg128_t *keep = (mg128_t*)((char*)ws_keep + off * 24); // the first-pass result (16 B/anchor + 8 B/chain), should the host have to take over
 			uint64_t *keep_u = (uint64_t*)(keep + n_v);
 			for (int32_t i = lane; i < n_v; i += 64) keep[i] = b[i];
@@ -425,11 +464,15 @@ __global__ void __launch_bounds__(64) k_lchain(int n_reads, const mg128_t *__res
 			__syncthreads();
 			klib_sort128x(b, n_v, W.t, &L); // all chained anchors, by x (n_v = sum of the chain sizes)
 			__syncthreads();
+			LC_TICK(2);
 			int32_t n_u2 = 0, n_v2 = 0;
 			const int32_t n_a = n_v;
-			if (lc_dp_rmq(b, n_a, R, W, lane)) {
+			const bool rq_ok = lc_dp_rmq(b, n_a, R, W, lane);
+			LC_TICK(3);
+			if (rq_ok) {
 				// mg_lchain_rmq backtracks with max_drop = its bw (lchain.c:267,359); the anchors are read from b, the result overwrites b
 				lc_backtrack_compact(b, n_a, R.min_sc, R.min_cnt, R.bw, W, u, b, &n_u2, &n_v2, &L, lane);
+				LC_TICK(4);
 				n_u = n_u2, n_v = n_v2;
 				if (lane == 0 && d_flag) d_flag[r] = 1;
 			} else {
@@ -463,6 +506,15 @@ extern "C" int mga_dev_lchain(mga_sctx_t *sc, int n, const mg128_t *d_a, const i
 		R.rescue_size = resc->rescue_size, R.rescue_ratio = resc->rescue_ratio;
 	}
 	if (resc && d_q_off) R.frag_len = resc->frag_len, R.frag_min_gap = resc->frag_min_gap;
+	{
+		static int prof_on = -1;
+		if (prof_on < 0) { const char *e = getenv("MGA_LC_PROF"); prof_on = e && atoi(e) > 0; if (prof_on) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lc_prof_on), &prof_on, sizeof(int)); }
+		if (prof_on) { // print what the previous launches accumulated
+			unsigned long long h[8];
+			if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lc_prof), sizeof h) == hipSuccess)
+				fprintf(stderr, "[lc-prof] Mcycles so far: dp %.1f backtrack %.1f rescue-sort %.1f rescue-dp %.1f rescue-backtrack %.1f\n", h[0] * 1e-6, h[1] * 1e-6, h[2] * 1e-6, h[3] * 1e-6, h[4] * 1e-6);
+		}
+	}
 	mga_prof_begin(sc->stream, MGA_K_LCHAIN);
 	hipLaunchKernelGGL(k_lchain, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, R, d_q_off, d_u, d_b, d_nu, d_nb, d_flag, ws_i32, ws_z, ws_keep);
 	mga_prof_end(sc->stream, MGA_K_LCHAIN);

@@ -12,6 +12,32 @@ def shard_range(n_items, rank, world):
     return st, st + base + (1 if rank < rem else 0)
 
 
+_pinned = {}   # base address -> bytes registered with the HIP runtime
+
+
+def _pin_for_dma(arr):
+    """hipHostRegister the memory behind a numpy view (the library's GAF buffer, handed back for reuse from step to step, so its address is
+    stable).  Best effort: any failure leaves the copy on the pageable path."""
+    try:
+        ptr, n = arr.ctypes.data, arr.nbytes
+        if n < (1 << 20):
+            return
+        old = _pinned.get(ptr, 0)
+        if old >= n:
+            return
+        rt = torch.cuda.cudart()
+        if old:
+            rt.cudaHostUnregister(ptr)
+            _pinned.pop(ptr, None)
+        for q in [q for q in _pinned if q != ptr and not (q + _pinned[q] <= ptr or ptr + n <= q)]:   # a buffer that moved: drop stale overlapping registrations
+            rt.cudaHostUnregister(q)
+            _pinned.pop(q, None)
+        if int(rt.cudaHostRegister(ptr, n, 0)) == 0:
+            _pinned[ptr] = n
+    except Exception:
+        pass
+
+
 def gather_bytes(payload, dst=0, device="cpu", as_tensors=False):
     """gather one byte string per rank to `dst`; returns the list in rank order on dst, None elsewhere.
     payload: bytes, or any C-contiguous uint8 buffer (e.g. the zero-copy numpy view of the library's GAF buffer).
@@ -29,6 +55,8 @@ def gather_bytes(payload, dst=0, device="cpu", as_tensors=False):
     if src.size:
         if not src.flags.writeable:
             src = src.copy()  # torch.from_numpy wants a writable array (bytes objects are not)
+        if device != "cpu":
+            _pin_for_dma(src)   # page-lock the (reused) output buffer once: the upload then runs at DMA speed instead of through a bounce buffer
         buf[:src.size].copy_(torch.from_numpy(src), non_blocking=False)
     out = [torch.empty(mx, dtype=torch.uint8, device=device) for _ in range(world)] if rank == dst else None
     dist.gather(buf, out, dst=dst)

@@ -136,6 +136,7 @@ def test_error_free_reads_need_no_wfa_problem():
     ("20% errors", ["-G", "3000000", "-H", "3", "-n", "800", "-e", "0.2", "-s", "34"], True),
     ("5 haplotypes, 3 chromosomes", ["-G", "6000000", "-H", "5", "-c", "3", "-n", "1500", "-s", "35"], True),
     ("chains only", ["-G", "3000000", "-H", "3", "-n", "1500", "-s", "36"], False),
+    ("1.5 Mbp reads (long-join rescue left to the host tree, strays batched in k_lchain)", ["-G", "12000000", "-H", "3", "-n", "4", "-l", "1500000", "-e", "0.05", "-s", "37"], True),
 ])
 def test_parity_sweep_vs_reference_binary(tag, simargs, cigar):
     """shapes the benchmark workload does not reach: wide WFA tiers (long gaps of long / noisy reads), many short reads,
