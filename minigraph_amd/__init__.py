@@ -61,14 +61,14 @@ class ggopt_t(C.Structure):
 MG_M_CIGAR = 0x4000000
 
 KERNELS = ["k_sketch", "k_seed_count", "k_seed_fill", "k_lchain", "k_wfa_r[64]", "k_wfa_r[128]", "k_wfa_r[192]", "k_wfa_r[256]", "k_wfa_r[512]",
-           "k_wfa_r[1024]", "k_wfa_r[2048]", "k_wfa[hbm4096]", "k_wfa[hbm32768]", "k_scan", "k_text", "k_gchain"]
+           "k_wfa_r[1024]", "k_wfa_r[2048]", "k_wfa[hbm4096]", "k_wfa[hbm32768]", "k_scan", "k_text", "k_gchain", "k_plan"]
 
 
 class stats_t(C.Structure):  # mga_stats_t
     _fields_ = [(n, C.c_int64) for n in ("n_reads", "n_bases", "n_mz", "n_probe", "n_hit", "n_anchor_chained", "n_wfa",
                                          "wfa_t_bases", "wfa_q_bases", "wfa_cells", "gaf_bytes")] + \
                [(n, C.c_double) for n in ("t_sketch", "t_seed", "t_lchain", "t_host_chain", "t_wfa", "t_host_post", "t_gaf")] + \
-               [(n, C.c_int64) for n in ("n_rescue_dev", "n_rescue_host", "n_gwfa", "n_shortk", "n_gc_retry", "gc_arena_peak")]
+               [(n, C.c_int64) for n in ("n_rescue_dev", "n_rescue_host", "n_gwfa", "n_shortk", "n_gc_retry", "gc_arena_peak", "n_wfa_dev_plan")]
 
 
 def load():

@@ -184,8 +184,11 @@ extern "C" int mga_dmemset_s(mga_sctx_t *sc, void *d, int v, size_t bytes)
 // created with hipEventBlockingSync under this runtime (4 pipeline threads waiting = 2 CPU-s per 0.55 s step).  The
 // host stages of the other chunks need every core the (often CPU-quota-limited) box gives us, so poll the event and
 // sleep in between; a sync happens ~12 times per chunk of ~45 ms, the added latency (<= 100 us each) is noise.
+extern "C" void mga_cpu_note(int which, int64_t ns);
+extern "C" int64_t mga_cpu_now(void);
 extern "C" int mga_ssync(mga_sctx_t *sc)
 {
+	struct cpu_scope_t { int64_t t0; cpu_scope_t() : t0(mga_cpu_now()) {} ~cpu_scope_t() { if (t0) mga_cpu_note(12, mga_cpu_now() - t0); } } cpu_scope; // MGA_DEBUG_PIPE accounting
 	MGA_HIP_CHECK(hipEventRecord((hipEvent_t)sc->ev_sync, (hipStream_t)sc->stream));
 	struct timespec ts = { 0, 20000 };
 	for (int spin = 0;; ++spin) {

@@ -196,6 +196,9 @@ extern "C" int mga_dev_gchain(mga_sctx_t *sc, const mga_didx_t *ix, const mg_map
 }
 
 extern "C" size_t mga_gc_rec_bytes(void) { return sizeof(gc_rec_t); }
+static_assert(sizeof(gc_rec_t) == sizeof(mga_gc_rec_t) && offsetof(gc_rec_t, n_anchor) == offsetof(mga_gc_rec_t, n_anchor) && offsetof(gc_rec_t, qs) == offsetof(mga_gc_rec_t, qs)
+			  && offsetof(gc_rec_t, ps) == offsetof(mga_gc_rec_t, ps) && offsetof(gc_rec_t, id) == offsetof(mga_gc_rec_t, id) && offsetof(gc_rec_t, parent) == offsetof(mga_gc_rec_t, parent)
+			  && offsetof(gc_rec_t, hash) == offsetof(mga_gc_rec_t, hash), "mga_gc_rec_t (mga_dev.h) must mirror gc_rec_t");
 
 // ---- flat records -> mg_gchains_t (host).  div (gchain1.c:299) and MAPQ (gcmisc.c:190-223) are computed here: they are the only
 // places of the path that go through libm (log, logf), which has to be the host's. ----
@@ -254,7 +257,7 @@ extern "C" mg_gchains_t *mga_gchains_from_flat(int32_t n_gc, const void *gc_recs
 	gs->a = (mg128_t*)malloc((size_t)(n_a > 0 ? n_a : 1) * sizeof(mg128_t));
 	for (int32_t i = 0; i < n_gc; ++i) gc_fill_public(&gs->gc[i], &r[i]);
 	memcpy(gs->lc, lc, (size_t)n_lc * sizeof(mg_llchain_t));
-	memcpy(gs->a, a, (size_t)n_a * sizeof(mg128_t));
+	if (n_a > 0) memcpy(gs->a, a, (size_t)n_a * sizeof(mg128_t));
 	gc_mapq(gs, qlen, n_mz, min_gc_score);
 	return gs;
 }

@@ -257,8 +257,13 @@ static const char *fa_next_rec(const char *p, const char *end) /* first '>' at t
 	return end;
 }
 
+/* MGA_DEBUG_PIPE accounting (mapper.c) */
+void mga_cpu_note(int which, int64_t ns);
+int64_t mga_cpu_now(void);
 typedef struct { const char **cut; fa_list_t *list; } fa_scan_t;
-static void fa_scan_worker(void *data, int64_t j, int tid)
+static void fa_scan_worker1(void *data, int64_t j, int tid);
+static void fa_scan_worker(void *data, int64_t j, int tid) { int64_t t0 = mga_cpu_now(); fa_scan_worker1(data, j, tid); if (t0) mga_cpu_note(15, mga_cpu_now() - t0); }
+static void fa_scan_worker1(void *data, int64_t j, int tid)
 {
 	fa_scan_t *S = (fa_scan_t*)data;
 	fa_list_t *L = &S->list[j];
@@ -326,7 +331,9 @@ static int fa_scan_window(fa_fast_t *F, int64_t want)
 }
 
 typedef struct { const fa_rec_t *rec; fbatch_t *b; } fa_fill_t;
-static void fa_fill_worker(void *data, int64_t i, int tid)
+static void fa_fill_worker1(void *data, int64_t i, int tid);
+static void fa_fill_worker(void *data, int64_t i, int tid) { int64_t t0 = mga_cpu_now(); fa_fill_worker1(data, i, tid); if (t0) mga_cpu_note(15, mga_cpu_now() - t0); }
+static void fa_fill_worker1(void *data, int64_t i, int tid)
 {
 	fa_fill_t *f = (fa_fill_t*)data;
 	const fa_rec_t *r = &f->rec[i];
@@ -408,7 +415,9 @@ static int seq_batch(rd_t *r, int *last, str_t *name, int64_t batch_bases, fbatc
 	return b->n;
 }
 
-static void *reader_main(void *a)
+static void *reader_main1(void *a);
+static void *reader_main(void *a) { int64_t t0 = mga_cpu_now(); void *r = reader_main1(a); if (t0) mga_cpu_note(14, mga_cpu_now() - t0); return r; }
+static void *reader_main1(void *a)
 {
 	reader_t *R = (reader_t*)a;
 	int f, seg = 0, n_out = 0;
@@ -552,6 +561,7 @@ static void *writer_main(void *a)
 	wbuf_t *w;
 	while ((w = (wbuf_t*)chan_get(W->in)) != 0) {
 		sink_t *s = W->sink;
+		int64_t t0_ = mga_cpu_now();
 		while (w->seg >= s->n_seg) { MGA_GROW(int64_t, s->seg_len, s->n_seg, s->m_seg); s->seg_len[s->n_seg++] = 0; }
 		s->seg_len[w->seg] += w->len;
 		if (!W->err && w->len > 0) {
@@ -561,6 +571,7 @@ static void *writer_main(void *a)
 				memcpy(s->mem + s->mem_len, w->buf, (size_t)w->len); s->mem_len += w->len;
 			}
 		}
+		if (t0_) mga_cpu_note(16, mga_cpu_now() - t0_);
 		pthread_mutex_lock(W->pool_m); W->pool[(*W->n_pool)++] = w; pthread_mutex_unlock(W->pool_m); /* the buffer goes back to the submitter */
 	}
 	return 0;

@@ -24,11 +24,13 @@
 
 /* MGA_DEBUG_PIPE: per-stage host CPU time (thread clocks), summed over worker threads */
 #include <time.h>
-enum { C_LCCOPY, C_LCRESCUE, C_LCPREP, C_GCDP, C_GCGEN, C_GCPOST, C_PLAN, C_APPLY, C_DS, C_GAF, C_EXPORT, C_N };
-static const char *g_cname[C_N] = { "lchain_copy", "lchain_rescue", "lchain_gen", "gchain_dp", "gchain_gen", "gchain_post", "plan_cigar", "apply_cigar", "gen_ds", "gaf", "export" };
+enum { C_LCCOPY, C_LCRESCUE, C_LCPREP, C_GCDP, C_GCGEN, C_GCPOST, C_PLAN, C_APPLY, C_DS, C_GAF, C_EXPORT, C_PIPE, C_SYNC, C_COMMIT, C_READER, C_FASCAN, C_WRITER, C_N };
+static const char *g_cname[C_N] = { "lchain_copy", "lchain_rescue", "lchain_gen", "gchain_dp", "gchain_gen", "gchain_post", "plan_cigar", "apply_cigar", "gen_ds", "gaf", "export", "pipe_thread(all)", "of_which_ssync", "commit", "reader_thread", "fasta_scan_fill", "writer+collector" };
 static volatile int64_t g_cpu_ns[C_N];
 static int g_cpu_on = 0;
 static inline int64_t cpu_now(void) { struct timespec ts; if (!g_cpu_on) return 0; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (int64_t)ts.tv_sec * 1000000000LL + ts.tv_nsec; }
+void mga_cpu_note(int which, int64_t ns) { if (g_cpu_on) __sync_fetch_and_add(&g_cpu_ns[which], ns); } /* (other files: 11 pipe, 12 ssync, 13 commit, 14 reader, 15 fasta scan/fill, 16 writer) */
+int64_t mga_cpu_now(void) { return cpu_now(); }
 #define CPU_ADD(which, t0) do { if (g_cpu_on) { int64_t t1_ = cpu_now(); __sync_fetch_and_add(&g_cpu_ns[which], t1_ - (t0)); (t0) = t1_; } } while (0)
 
 /* Grow-only scratch that is recycled across chunks instead of being freed: the per-thread planning pools and the GAF
@@ -114,6 +116,9 @@ struct mga_batch_s {
 	/* graph chains made on the device (k_gchain.hip): per-read headers + record pools; status != 0 marks the reads the host still chains */
 	const mga_gc_hdr_t *gc_hdr; const char *gc_pool; const mg_llchain_t *gc_lc; const mg128_t *gc_a; size_t gc_rec;
 	const int32_t *rescue_flag; /* per read: what the chaining kernel did about the long-join rescue (NULL: decide here) */
+	/* gap list made on the device (k_plan.hip) for the device-chained reads: first printed chain of read i in the device's chain table; the host
+	 * fills one strand flag per printed chain (dp_rev); the pools above then only hold the plans of the reads chained HERE, appended after the device's */
+	const int64_t *dp_chain_off; int32_t *dp_rev; int64_t dp_n_chain;
 	/* stage-2 inputs */
 	mga_cigsrc_t src;
 	int err;
@@ -144,6 +149,8 @@ void mga_batch_set_device_chains(mga_batch_t *b, const mga_gc_hdr_t *hdr, const 
 {
 	b->gc_hdr = hdr, b->gc_pool = (const char*)gc_pool, b->gc_lc = lc_pool, b->gc_a = a_pool, b->gc_rec = mga_gc_rec_bytes();
 }
+
+void mga_batch_set_device_plan(mga_batch_t *b, const int64_t *chain_off, int32_t *rev, int64_t n_chain) { b->dp_chain_off = chain_off, b->dp_rev = rev, b->dp_n_chain = n_chain; }
 
 void mga_batch_lchain_par(const mg_idx_t *gi, const mg_mapopt_t *opt, int qlen_max, mga_lchain_par_t *par) /* map-algo.c:377-403 for long reads */
 {
@@ -309,7 +316,7 @@ static void chain_worker(void *data, int64_t i, int tid)
 	if (opt->max_qlen > 0 && qlen > opt->max_qlen) return;
 	if (b->gc_hdr && b->gc_hdr[i].status == 0) { /* chained on the device: flat records -> the reference's object (div and MAPQ through the host's libm) */
 		const mga_gc_hdr_t *h = &b->gc_hdr[i];
-		gcs = mga_gchains_from_flat(h->n_gc, b->gc_pool + (size_t)h->gc_off * b->gc_rec, h->n_lc, b->gc_lc + h->lc_off, h->n_a, b->gc_a + h->a_off,
+		gcs = mga_gchains_from_flat(h->n_gc, b->gc_pool + (size_t)h->gc_off * b->gc_rec, h->n_lc, b->gc_lc + h->lc_off, b->gc_a ? h->n_a : 0, b->gc_a ? b->gc_a + h->a_off : 0, /* (no anchors on the host when the gap list was made on the device) */
 									b->rep_len[i], qlen, b->n_mz[i], opt->min_gc_score);
 		b->gcs[i] = gcs;
 		CPU_ADD(C_GCPOST, tc);
@@ -358,7 +365,23 @@ do_rescue:;
 	CPU_ADD(C_GCGEN, tc);
 	b->gcs[i] = gcs;
 plan:
-	if (opt->flag & MG_M_CIGAR) { /* list the gaps of every chain for the WFA kernel */
+	if ((opt->flag & MG_M_CIGAR) && b->dp_chain_off && b->gc_hdr && b->gc_hdr[i].status == 0) { /* the gaps were listed on the device (k_plan.hip): only the strand of each printed line is decided here */
+		read_plan_t *pl = &b->plan[i];
+		int64_t c = b->dp_chain_off[i];
+		int rev_sign = 0;
+		pl->tid = -1, pl->n_gc = gcs->n_gc;
+		pl->chain_id = MGA_MALLOC(int64_t, gcs->n_gc > 0 ? gcs->n_gc : 1);
+		for (k = 0; k < gcs->n_gc; ++k) {
+			const mg_gchain_t *gc = &gcs->gc[k];
+			pl->chain_id[k] = -1;
+			if ((gc->id != gc->parent && !(opt->flag & MG_M_PRINT_2ND)) || gc->cnt == 0) continue;
+			if (mga_gaf_chain_rev(gi->g, gcs, gc, opt->flag)) rev_sign = 1;
+			b->dp_rev[c] = rev_sign;
+			pl->chain_id[k] = c++;
+		}
+		assert(c == b->dp_chain_off[i + 1]);
+		CPU_ADD(C_PLAN, tc);
+	} else if (opt->flag & MG_M_CIGAR) { /* list the gaps of every chain for the WFA kernel */
 		read_plan_t *pl = &b->plan[i];
 		mga_tpool_t *tp = &b->tp[tid];
 		pl->tid = tid, pl->n_gc = gcs->n_gc;
@@ -569,7 +592,7 @@ static void gaf_worker(void *data, int64_t t, int tid)
 			for (k = 0; k < gcs->n_gc; ++k) {
 				txt[k].cg = txt[k].ds = 0;
 				if (pl->chain_id[k] >= 0) {
-					const mga_txt_res_t *r = &bt->txt_res[bt->tp_chain_base[pl->tid] + pl->chain_id[k]];
+					const mga_txt_res_t *r = &bt->txt_res[pl->tid < 0 ? pl->chain_id[k] : bt->dp_n_chain + bt->tp_chain_base[pl->tid] + pl->chain_id[k]]; /* device-planned chains first, then the pools' */
 					txt[k].cg = bt->txt_pool + r->txt_off, txt[k].ds = txt[k].cg + r->cg_len;
 					txt[k].cg_len = r->cg_len, txt[k].ds_len = r->ds_len, txt[k].mlen = r->mlen, txt[k].blen = r->blen;
 				}
@@ -601,15 +624,16 @@ typedef struct { /* one pipeline context: HIP stream + grow-only device and pinn
 			mga_dbuf_t tseq, prob, res, pool, used, ncig, cigoff, ord, rflag, item, chain, vert, txtres, txtpool;
 			mga_dbuf_t sk_item, sk_cnt, sk_off, sd_tk, sd_kf, sd_offa, sd_offm, sd_rkey, sd_rmax; /* long-query path (MG_M_RMQ): sketch pieces, per-minimizer scans */
 			mga_dbuf_t hash, gchdr, gcpool, lcpool, apool, gcctl, gcretry; /* graph chaining on the device (k_gchain.hip) */
+			mga_dbuf_t plcnt, ploff, pltot, plsrc, plrev; /* gap list on the device (k_plan.hip) */
 		};
-		mga_dbuf_t dall[50];
+		mga_dbuf_t dall[55];
 	};
 	union {
-		struct { mga_hbuf_t h_b, h_u, h_mini, h_tseq, h_prob, h_pool, h_seq, h_ncig, h_cigoff, h_item, h_chain, h_vert, h_txtres, h_txtpool, h_gchdr, h_gcpool, h_lcpool, h_apool; }; /* pinned staging */
-		mga_hbuf_t hall[18];
+		struct { mga_hbuf_t h_b, h_u, h_mini, h_tseq, h_prob, h_pool, h_seq, h_ncig, h_cigoff, h_item, h_chain, h_vert, h_txtres, h_txtpool, h_gchdr, h_gcpool, h_lcpool, h_apool, h_plrev, h_ploff; }; /* pinned staging */
+		mga_hbuf_t hall[20];
 	};
 } pipe_ctx_t;
-_Static_assert(sizeof(((pipe_ctx_t*)0)->dall) == 50 * sizeof(mga_dbuf_t) && sizeof(((pipe_ctx_t*)0)->hall) == 18 * sizeof(mga_hbuf_t), "pipe_ctx_t: buffer lists out of sync");
+_Static_assert(sizeof(((pipe_ctx_t*)0)->dall) == 55 * sizeof(mga_dbuf_t) && sizeof(((pipe_ctx_t*)0)->hall) == 20 * sizeof(mga_hbuf_t), "pipe_ctx_t: buffer lists out of sync");
 
 #define MGA_MAX_PIPE 4
 
@@ -642,7 +666,10 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	int32_t *h_nmz = 0, *h_rep = 0, *h_nu = 0, *h_nb = 0, *h_rflag = 0;
 	mga_gc_hdr_t *h_gchdr_p = 0;
 	int64_t gc_cap = 0, lc_cap = 0, ga_cap = 0;
-	int dev_gc = 0;
+	int dev_gc = 0, dev_plan = 0, need_a = 1;
+	unsigned long long ptot[8] = { 0 }; /* device-made gap list: printed chains, plan items, problems, walk vertices, target bytes, query bases, overflow flag */
+	int64_t *h_ploff = 0;               /* its first printed chain per read */
+	const int want_text = gaf_part != 0 && (opt->flag & MG_M_CIGAR) && B->dev.d_gseq != 0 && !env_int("MGA_HOST_TEXT", 0); /* only GAF bytes are wanted: cg/ds come from the device */
 	mga_batch_t *b = 0;
 	mga_lchain_par_t par;
 	const int is_rmq = !!(opt->flag & MG_M_RMQ);
@@ -856,11 +883,21 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 				fprintf(stderr, "\n");
 			}
 			if ((int64_t)ctl[7] > st->gc_arena_peak) st->gc_arena_peak = (int64_t)ctl[7];
+			dev_plan = want_text && env_int("MGA_DEV_PLAN", 1);
+			if (dev_plan) { /* the gap list of the chains just made (k_plan.hip), pass 1: sizes; the fill pass follows the host's strand flags */
+				CK(mga_dbuf_reserve(&P->plcnt, (size_t)n * 5 * 4 + 64)); CK(mga_dbuf_reserve(&P->ploff, (size_t)(n + 1) * 5 * 8 + 64)); CK(mga_dbuf_reserve(&P->pltot, 64));
+				CK(mga_dev_plan_count(sc, &B->dev, n, (opt->flag & MG_M_PRINT_2ND) != 0, (const mga_gc_hdr_t*)P->gchdr.p, P->gcpool.p, (const mg_llchain_t*)P->lcpool.p,
+									  (const mg128_t*)P->apool.p, (int32_t*)P->plcnt.p, (int64_t*)P->ploff.p, (unsigned long long*)P->pltot.p));
+				CK(mga_hbuf_reserve(&P->h_ploff, (size_t)(n + 1) * 8 + 16));
+				h_ploff = (int64_t*)P->h_ploff.p;
+				CK(mga_d2h_s(sc, ptot, P->pltot.p, 64)); CK(mga_d2h_s(sc, h_ploff, P->ploff.p, (size_t)(n + 1) * 8));
+			}
 			CK(mga_hbuf_reserve(&P->h_gcpool, (size_t)ctl[1] * rec + 16)); CK(mga_hbuf_reserve(&P->h_lcpool, (size_t)ctl[2] * sizeof(mg_llchain_t) + 16)); CK(mga_hbuf_reserve(&P->h_apool, (size_t)ctl[6] * 16 + 16));
 			h_gchdr_p = (mga_gc_hdr_t*)P->h_gchdr.p;
 			CK(mga_d2h_s(sc, h_gchdr_p, P->gchdr.p, (size_t)n * sizeof(mga_gc_hdr_t)));
 			CK(mga_d2h_s(sc, P->h_gcpool.p, P->gcpool.p, (size_t)ctl[1] * rec)); CK(mga_d2h_s(sc, P->h_lcpool.p, P->lcpool.p, (size_t)ctl[2] * sizeof(mg_llchain_t)));
-			CK(mga_d2h_s(sc, P->h_apool.p, P->apool.p, (size_t)ctl[6] * 16));
+			need_a = !dev_plan || (mg_dbg_flag & 0x8) || (opt->flag & MG_M_WRITE_LCHAIN); /* with the gap list made on the device, only the per-vertex lines (-S / --write-mz) read anchors on the host */
+			if (need_a) CK(mga_d2h_s(sc, P->h_apool.p, P->apool.p, (size_t)ctl[6] * 16));
 			CK(mga_ssync(sc)); /* (h_nu / h_nb / h_rflag arrived with the first sync) */
 			for (i = 0; i < n; ++i) /* the few reads whose rescue k_lchain left to the host tree: their chains, anchors and minimizer positions come down for the host path */
 				if (h_gchdr_p[i].status == MGA_GC_HOST) {
@@ -884,29 +921,50 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	t1 = mga_wtime(); st->t_lchain += t1 - t0; t0 = t1;
 	/* ---- host: graph chaining + gap list ---- */
 	b = mga_batch_init(gi, opt, n, qlens, seqs, qnames, q_off, n_threads);
-	b->want_text = gaf_part != 0 && (opt->flag & MG_M_CIGAR) && B->dev.d_gseq != 0 && !env_int("MGA_HOST_TEXT", 0); /* only GAF bytes are wanted: cg/ds come from the device */
-	if (dev_gc) mga_batch_set_device_chains(b, h_gchdr_p, P->h_gcpool.p, (const mg_llchain_t*)P->h_lcpool.p, (const mg128_t*)P->h_apool.p);
+	b->want_text = want_text;
+	if (dev_plan) {
+		if (ptot[6] != 0 || ptot[2] > 0x7fffffffULL) { mga_set_error("gap list: too many WFA problems or target bases in one chunk (%llu problems); lower MGA_CHUNK", ptot[2]); rc = -1; goto done; }
+		CK(mga_hbuf_reserve(&P->h_plrev, (size_t)ptot[0] * 4 + 16));
+		mga_batch_set_device_plan(b, h_ploff, (int32_t*)P->h_plrev.p, (int64_t)ptot[0]);
+	}
+	if (dev_gc) mga_batch_set_device_chains(b, h_gchdr_p, P->h_gcpool.p, (const mg_llchain_t*)P->h_lcpool.p, need_a ? (const mg128_t*)P->h_apool.p : 0);
 	CK(mga_batch_chain(b, h_nmz, h_rep, (const int32_t*)P->h_mini.p, h_minioff, h_nu, h_nb, (const uint64_t*)P->h_u.p, (const mg128_t*)P->h_b.p, h_aoff, long_q ? 2 : is_rmq, h_rflag));
 	if (g_dbg_pipe > 1) PIPE_LOG(" hostchain", n, t0);
 	t1 = mga_wtime(); st->t_host_chain += t1 - t0; t0 = t1;
 	/* ---- WFA over all gaps ---- */
-	n_prob = mga_batch_n_wfa(b), n_tb = mga_batch_wfa_target_bytes(b);
-	if ((opt->flag & MG_M_CIGAR) && (n_prob > 0 || (b->want_text && mga_batch_n_chains(b) > 0))) { /* (text mode: chains made of ready operators only still need their text) */
+	/* the device-made gap list (dev_plan) comes first in every array; what the host threads planned (all reads, or with dev_plan the few reads chained here) follows */
+	const int64_t dp_chain = (int64_t)ptot[0], dp_item = (int64_t)ptot[1], dp_prob = (int64_t)ptot[2], dp_vert = (int64_t)ptot[3], dp_tb = (int64_t)ptot[4];
+	const int64_t hp_prob = mga_batch_n_wfa(b), hp_tb = mga_batch_wfa_target_bytes(b);
+	n_prob = dp_prob + hp_prob, n_tb = dp_tb + hp_tb;
+	if ((opt->flag & MG_M_CIGAR) && (n_prob > 0 || (b->want_text && dp_chain + mga_batch_n_chains(b) > 0))) { /* (text mode: chains made of ready operators only still need their text) */
 		mga_wfa_prob_t *h_prob;
 		int64_t cells = 0;
+		const int64_t n_item = dp_item + (b->want_text ? mga_batch_n_items(b) : 0), n_chain = dp_chain + (b->want_text ? mga_batch_n_chains(b) : 0), n_vert = dp_vert + (b->want_text ? mga_batch_n_verts(b) : 0);
 		if (n_prob > 0x7fffffff) { mga_set_error("too many WFA problems in one chunk (%ld); lower MGA_CHUNK", (long)n_prob); rc = -1; goto done; }
-		CK(mga_hbuf_reserve(&P->h_prob, (size_t)n_prob * sizeof(mga_wfa_prob_t) + 16)); CK(mga_hbuf_reserve(&P->h_tseq, (size_t)n_tb + 64));
+		CK(mga_hbuf_reserve(&P->h_prob, (size_t)hp_prob * sizeof(mga_wfa_prob_t) + 16)); CK(mga_hbuf_reserve(&P->h_tseq, (size_t)hp_tb + 64));
 		h_prob = (mga_wfa_prob_t*)P->h_prob.p;
 		mga_batch_wfa_export(b, h_prob, (char*)P->h_tseq.p);
-		memset((char*)P->h_tseq.p + n_tb, 0, 64);
+		memset((char*)P->h_tseq.p + hp_tb, 0, 64);
+		for (i = 0; dp_tb > 0 && i < hp_prob; ++i) h_prob[i].t_off += dp_tb;
 		CK(mga_dbuf_reserve(&P->tseq, (size_t)n_tb + 64)); CK(mga_dbuf_reserve(&P->prob, (size_t)n_prob * sizeof(mga_wfa_prob_t) + 16)); CK(mga_dbuf_reserve(&P->res, (size_t)n_prob * sizeof(mga_wfa_res_t) + 16));
 		CK(mga_dbuf_reserve(&P->used, 64));
+		if (b->want_text) {
+			CK(mga_dbuf_reserve(&P->item, (size_t)n_item * sizeof(mga_cigitem_t) + 16)); CK(mga_dbuf_reserve(&P->chain, (size_t)n_chain * sizeof(mga_txt_chain_t) + 16));
+			CK(mga_dbuf_reserve(&P->vert, (size_t)n_vert * 4 + 16)); CK(mga_dbuf_reserve(&P->txtres, (size_t)n_chain * sizeof(mga_txt_res_t) + 16));
+		}
+		if (dev_plan) { /* pass 2 of k_plan.hip: items, problems + their targets, printed chains and walks, straight from the record pools in HBM */
+			CK(mga_dbuf_reserve(&P->plrev, (size_t)dp_chain * 4 + 16)); CK(mga_dbuf_reserve(&P->plsrc, (size_t)dp_prob * sizeof(mga_plan_src_t) + 16));
+			CK(mga_h2d_s(sc, P->plrev.p, P->h_plrev.p, (size_t)dp_chain * 4));
+			CK(mga_dev_plan_fill(sc, &B->dev, n, (opt->flag & MG_M_PRINT_2ND) != 0, (const mga_gc_hdr_t*)P->gchdr.p, P->gcpool.p, (const mg_llchain_t*)P->lcpool.p, (const mg128_t*)P->apool.p,
+								 (const int64_t*)P->qoff.p, (const int64_t*)P->ploff.p, (const int32_t*)P->plrev.p, dp_prob, (mga_cigitem_t*)P->item.p, (mga_wfa_prob_t*)P->prob.p,
+								 (mga_plan_src_t*)P->plsrc.p, (mga_txt_chain_t*)P->chain.p, (uint32_t*)P->vert.p, (char*)P->tseq.p));
+		}
 		/* uploads ride the copy engine while another chunk owns the WFA phase */
-		CK(mga_h2d_s(sc, P->tseq.p, P->h_tseq.p, (size_t)n_tb + 64)); CK(mga_h2d_s(sc, P->prob.p, h_prob, (size_t)n_prob * sizeof(mga_wfa_prob_t)));
+		CK(mga_h2d_s(sc, (char*)P->tseq.p + dp_tb, P->h_tseq.p, (size_t)hp_tb + 64)); CK(mga_h2d_s(sc, (mga_wfa_prob_t*)P->prob.p + dp_prob, h_prob, (size_t)hp_prob * sizeof(mga_wfa_prob_t)));
 		GPU_ACQUIRE(&g_gpu_wfa);
 		/* CIGAR pool: a global alignment has at most tl + ql operators, so target bases + query bases bound the chunk; + the abandoned block
 		 * tails (<= 512 ops) of every resident wave.  Sized to the bound, the pool cannot overflow whatever the divergence. */
-		pool_cap = n_tb + 4096 + 40000LL * 512;
+		pool_cap = n_tb + 4096 + 40000LL * 512 + (int64_t)ptot[5];
 		for (i = 0; i < b->n_threads; ++i) pool_cap += b->tp[i].wfa_q_bases;
 		CK(mga_dbuf_reserve(&P->pool, (size_t)pool_cap * 4)); CK(mga_dmemset_s(sc, P->used.p, 0, 8));
 		/* the tier ladder runs on the device (k_wfa_sched.hip); the host never walks the problems */
@@ -919,17 +977,20 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 								  (uint32_t*)P->ord.p, pool_cap, &n_ops));
 			GPU_RELEASE(); /* the gather kernel and what follows trail on this chunk's stream while the next chunk's kernels start */
 			if (b->want_text) { /* stitching, statistics, cg:Z and ds:Z on the device (k_text.hip): one lane per printed chain */
-				const int64_t n_item = mga_batch_n_items(b), n_chain = mga_batch_n_chains(b), n_vert = mga_batch_n_verts(b);
+				const int64_t hp_item = n_item - dp_item, hp_chain = n_chain - dp_chain, hp_vert = n_vert - dp_vert;
 				int64_t txt_cap = 4096, k;
 				unsigned long long txt_used = 0;
 				for (k = 0; k < n; ++k) txt_cap += (env_int("MGA_TXT_TIGHT", 0) ? 1 : 3) * (int64_t)qlens[k] / (env_int("MGA_TXT_TIGHT", 0) ? 4 : 1) + 1024; /* (MGA_TXT_TIGHT=1: a deliberately small pool, so that a test sees the second launch) */
-				CK(mga_hbuf_reserve(&P->h_item, (size_t)n_item * sizeof(mga_cigitem_t) + 16)); CK(mga_hbuf_reserve(&P->h_chain, (size_t)n_chain * sizeof(mga_txt_chain_t) + 16));
-				CK(mga_hbuf_reserve(&P->h_vert, (size_t)n_vert * 4 + 16));
+				CK(mga_hbuf_reserve(&P->h_item, (size_t)hp_item * sizeof(mga_cigitem_t) + 16)); CK(mga_hbuf_reserve(&P->h_chain, (size_t)hp_chain * sizeof(mga_txt_chain_t) + 16));
+				CK(mga_hbuf_reserve(&P->h_vert, (size_t)hp_vert * 4 + 16));
 				mga_batch_text_export(b, (mga_cigitem_t*)P->h_item.p, (mga_txt_chain_t*)P->h_chain.p, (uint32_t*)P->h_vert.p);
-				CK(mga_dbuf_reserve(&P->item, (size_t)n_item * sizeof(mga_cigitem_t) + 16)); CK(mga_dbuf_reserve(&P->chain, (size_t)n_chain * sizeof(mga_txt_chain_t) + 16));
-				CK(mga_dbuf_reserve(&P->vert, (size_t)n_vert * 4 + 16)); CK(mga_dbuf_reserve(&P->txtres, (size_t)n_chain * sizeof(mga_txt_res_t) + 16));
-				CK(mga_h2d_s(sc, P->item.p, P->h_item.p, (size_t)n_item * sizeof(mga_cigitem_t))); CK(mga_h2d_s(sc, P->chain.p, P->h_chain.p, (size_t)n_chain * sizeof(mga_txt_chain_t)));
-				CK(mga_h2d_s(sc, P->vert.p, P->h_vert.p, (size_t)n_vert * 4));
+				for (k = 0; dev_plan && k < hp_chain; ++k) { /* behind the device-made part */
+					mga_txt_chain_t *c = (mga_txt_chain_t*)P->h_chain.p + k;
+					c->item_beg += dp_item, c->item_end += dp_item, c->vert_beg += dp_vert, c->prob_base += dp_prob;
+				}
+				CK(mga_h2d_s(sc, (mga_cigitem_t*)P->item.p + dp_item, P->h_item.p, (size_t)hp_item * sizeof(mga_cigitem_t)));
+				CK(mga_h2d_s(sc, (mga_txt_chain_t*)P->chain.p + dp_chain, P->h_chain.p, (size_t)hp_chain * sizeof(mga_txt_chain_t)));
+				CK(mga_h2d_s(sc, (uint32_t*)P->vert.p + dp_vert, P->h_vert.p, (size_t)hp_vert * 4));
 				for (k = 0;; ++k) { /* the pool is sized for ordinary reads (~1 byte of cg + ds per base); the kernel counts what it WOULD have written, so a chunk of
 				                     * very divergent reads or many printed secondaries gets a pool of exactly that size and a second launch */
 					CK(mga_dbuf_reserve(&P->txtpool, (size_t)txt_cap)); CK(mga_dmemset_s(sc, P->used.p, 0, 8));
@@ -954,6 +1015,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 			}
 		}
 		st->wfa_cells += cells;
+		st->n_wfa += dp_prob, st->n_wfa_dev_plan += dp_prob, st->wfa_t_bases += dp_tb, st->wfa_q_bases += (int64_t)ptot[5];
 	}
 	if (g_dbg_pipe > 1) PIPE_LOG(" wfa", n, t0);
 	t1 = mga_wtime(); st->t_wfa += t1 - t0; t0 = t1;
@@ -1068,6 +1130,7 @@ static void stats_merge(mga_stats_t *d, const mga_stats_t *s)
 	d->n_rescue_dev += s->n_rescue_dev, d->n_rescue_host += s->n_rescue_host;
 	d->n_gwfa += s->n_gwfa, d->n_shortk += s->n_shortk, d->n_gc_retry += s->n_gc_retry;
 	if (s->gc_arena_peak > d->gc_arena_peak) d->gc_arena_peak = s->gc_arena_peak;
+	d->n_wfa_dev_plan += s->n_wfa_dev_plan;
 	d->gaf_bytes += s->gaf_bytes;
 }
 
@@ -1087,6 +1150,7 @@ static void stream_run_chunk(mga_stream_t *S, pipe_ctx_t *P, sbatch_t *b, int c)
 	const int st = b->cstart[c], en = b->cstart[c + 1];
 	mga_stats_t cst;
 	double tc = mga_wtime();
+	int64_t tcpu = cpu_now();
 	int rc;
 	memset(&cst, 0, sizeof cst);
 	rc = b->err ? 0 : map_chunk(P, S->gi, en - st, b->qlens + st, b->seqs + st, b->qnames ? b->qnames + st : 0, b->gcs + st, &S->opt, b->n_threads,
@@ -1096,9 +1160,10 @@ static void stream_run_chunk(mga_stream_t *S, pipe_ctx_t *P, sbatch_t *b, int c)
 		double t0 = mga_wtime();
 		int k;
 		for (k = 0; k < b->n_threads; ++k) cst.gaf_bytes += b->gaf_part[(size_t)c * b->n_threads + k].l;
-		commit_chunks(b, c);
+		{ int64_t t_ = cpu_now(); commit_chunks(b, c); CPU_ADD(C_COMMIT, t_); }
 		cst.t_gaf += mga_wtime() - t0;
 	}
+	CPU_ADD(C_PIPE, tcpu);
 	pthread_mutex_lock(&g_stats_mtx); stats_merge(&S->gi->B->st, &cst); pthread_mutex_unlock(&g_stats_mtx);
 	pthread_mutex_lock(&S->m);
 	if (rc < 0 && !b->err) { b->err = 1; snprintf(b->errmsg, sizeof b->errmsg, "%s", mga_last_error()); }

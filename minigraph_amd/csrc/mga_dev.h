@@ -66,7 +66,7 @@ int  mga_hbuf_reserve(mga_hbuf_t *b, size_t bytes);
 void mga_hbuf_free(mga_hbuf_t *b);
 
 /* per-kernel HIP-event timing on the launch stream (bench.py reads it through mga_prof_get) */
-enum { MGA_K_SKETCH = 0, MGA_K_SEED_COUNT, MGA_K_SEED_FILL, MGA_K_LCHAIN, MGA_K_WFA0 /* +tier: 0-2 single-wave register tiers (band 64,128,192), 3-6 multi-wave register tiers (256..2048), 7-8 HBM tiers */, MGA_K_SCAN = MGA_K_WFA0 + 9, MGA_K_TEXT, MGA_K_GCHAIN, MGA_K_N };
+enum { MGA_K_SKETCH = 0, MGA_K_SEED_COUNT, MGA_K_SEED_FILL, MGA_K_LCHAIN, MGA_K_WFA0 /* +tier: 0-2 single-wave register tiers (band 64,128,192), 3-6 multi-wave register tiers (256..2048), 7-8 HBM tiers */, MGA_K_SCAN = MGA_K_WFA0 + 9, MGA_K_TEXT, MGA_K_GCHAIN, MGA_K_PLAN, MGA_K_N };
 #define MGA_WFA_N_TIER 9
 #define MGA_WFA_MAX_TIER 10 /* array size of the per-tier resources */
 void mga_prof_enable(int on);
@@ -210,6 +210,24 @@ mg_gchains_t *mga_gchains_from_flat(int32_t n_gc, const void *gc_recs, int32_t n
 mg_gchains_t *mga_gchain_host_read(const mg_idx_t *gi, const int32_t *seg_len, const mg_mapopt_t *opt, float pen_gap, int32_t qlen, uint32_t hash,
 								   int32_t n_u, const uint64_t *u, mg128_t *a, int32_t n_a, int32_t n_mini, const int32_t *mini_pos, const char *qseq,
 								   int32_t rep_len, int32_t n_mz, int32_t *n_gwfa, int32_t *n_shortk);
+
+/* ---- the gap list on the device (k_plan.hip): what align.c:mga_plan_cigar makes on the host, for chains that never left the device ---- */
+typedef struct { /* one graph chain as k_gchain leaves it in the record pool (gc_core.h:gc_rec_t; k_gchain.hip asserts the layouts agree) */
+	int32_t off, cnt, n_anchor, score;
+	int32_t qs, qe, plen, ps, pe, blen, mlen;
+	int32_t n_mini, q_span;
+	int32_t id, parent, subsc, n_sub, flt;
+	uint32_t hash;
+} mga_gc_rec_t;
+typedef struct { int64_t lc0; int32_t n_lc, x0, x1, pad; } mga_plan_src_t; /* target of a problem: base x0+1 of vertex lc_pool[lc0] .. base x1 of vertex lc_pool[lc0 + n_lc] */
+/* pass 1: d_cnt = int32[5][n] scratch; d_off = int64[5][n+1] exclusive scans of printed chains, plan items, problems, walk vertices, target bytes;
+ * d_tot = 8 x uint64: the five totals, [5] query bases of all problems, [6] reads whose target bytes do not fit 31 bits */
+int mga_dev_plan_count(mga_sctx_t *sc, const mga_didx_t *ix, int n, int print_2nd, const mga_gc_hdr_t *d_hdr, const void *d_gc_pool, const mg_llchain_t *d_lc_pool,
+					   const mg128_t *d_a_pool, int32_t *d_cnt, int64_t *d_off, unsigned long long *d_tot);
+/* pass 2: items, problems (+ their targets in d_tseq), printed chains (rev_sign from d_rev, one flag per printed chain) and walk vertices at the scanned offsets */
+int mga_dev_plan_fill(mga_sctx_t *sc, const mga_didx_t *ix, int n, int print_2nd, const mga_gc_hdr_t *d_hdr, const void *d_gc_pool, const mg_llchain_t *d_lc_pool,
+					  const mg128_t *d_a_pool, const int64_t *d_q_off, const int64_t *d_off, const int32_t *d_rev, int64_t n_prob,
+					  mga_cigitem_t *d_item, mga_wfa_prob_t *d_prob, mga_plan_src_t *d_src, mga_txt_chain_t *d_chain, uint32_t *d_vert, char *d_tseq);
 
 /* CIGARs of all problems copied into problem order: d_ncig[i] operators at d_ord + d_off[i] (d_off has n+1 entries); *h_total = d_off[n] */
 int mga_dev_wfa_gather(mga_sctx_t *sc, int n, const mga_wfa_res_t *d_res, const uint32_t *d_pool, int32_t *d_ncig, int64_t *d_off, uint32_t *d_ord,

@@ -669,6 +669,13 @@ def test_graph_chaining_on_device_equals_host_instantiation_and_reference(monkey
     if workload == "bubbles5":
         assert st["n_gwfa"] > 500 and st["n_shortk"] > 500, st
     assert st["n_gc_retry"] == 0 and 0 < st["gc_arena_peak"] < (1 << 20), st
+    assert st["n_wfa_dev_plan"] > 0.99 * st["n_wfa"] > 0, st   # the gap list was made on the device too (k_plan.hip; all but the reads the host chained)
+    monkeypatch.setenv("MGA_DEV_PLAN", "0")                     # device chains, gap list by host threads (align.c)
+    dev_hostplan = mga.map_reads(G, R, n_threads=8)
+    st1 = mga.get_stats(G, reset=True)
+    assert st1["n_wfa_dev_plan"] == 0 and st1["n_wfa"] == st["n_wfa"] and st1["wfa_t_bases"] == st["wfa_t_bases"] and st1["wfa_q_bases"] == st["wfa_q_bases"], (st, st1)
+    assert dev_hostplan == dev
+    monkeypatch.delenv("MGA_DEV_PLAN")
     monkeypatch.delenv("MGA_DEV_GCHAIN")
     host = mga.map_reads(G, R, n_threads=8)
     st2 = mga.get_stats(G, reset=True)
