@@ -307,3 +307,31 @@ def test_wfa_chained_fallback_matches_mwf_wfa_auto():
         assert np.array_equal(ec, cg[i]), i
     for i in big:  # the exact pass alone really gives up on these
         assert rb.Oracle().wfa(T[i], Q[i], max_iter=100000000)[0] < 0
+
+@pytest.mark.gpu
+def test_wfa_parity_ring_layout_shapes(ora):
+    """the register tiers fold their window of diagonals into rings around a centre (k_wfa_r.hip): shapes that push the band to one side (short target,
+    long query and the reverse: the centre moves off diagonal 0), to the window's edge (the problem leaves the tier mid-way) and across every ring
+    boundary (multiples of 32 diagonals), for every tier size"""
+    rng = np.random.default_rng(31)
+    T, Q = [], []
+    for L in (40, 64, 100, 128, 160, 192, 250, 256, 400, 512, 900, 1024, 1800):
+        t = rand_seq(rng, L)
+        for g in (1, 15, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 129, 200):
+            if g >= L:
+                continue
+            cut = int(rng.integers(0, L - g + 1))
+            T.append(t); Q.append(t[:cut] + t[cut + g:])                       # deletion of g bases: band grows to -g
+            T.append(t[:cut] + t[cut + g:]); Q.append(t)                       # insertion of g bases: band grows to +g
+            T.append(mutate(rng, t, 0.1)[:max(1, L - g)]); Q.append(t)         # + noise, end clipped
+        for short in (1, 3, 17, 40):
+            T.append(rand_seq(rng, short)); Q.append(t)                        # matrix narrower than the window on the target side
+            T.append(t); Q.append(rand_seq(rng, short))                        # ... on the query side
+        T.append(t); Q.append(rand_seq(rng, L))                                # unrelated: the band runs to the window's edge
+        T.append(t); Q.append(mutate(rng, t, 0.3))
+    sc, cg = mga.wfa_batch(T, Q)
+    for i in range(len(T)):
+        es, ec = ora.wfa(T[i], Q[i])
+        assert es == sc[i], (i, len(T[i]), len(Q[i]))
+        assert np.array_equal(ec, cg[i]), (i, len(T[i]), len(Q[i]))
+
