@@ -980,7 +980,8 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 				const int64_t hp_item = n_item - dp_item, hp_chain = n_chain - dp_chain, hp_vert = n_vert - dp_vert;
 				int64_t txt_cap = 4096, k;
 				unsigned long long txt_used = 0;
-				for (k = 0; k < n; ++k) txt_cap += (env_int("MGA_TXT_TIGHT", 0) ? 1 : 3) * (int64_t)qlens[k] / (env_int("MGA_TXT_TIGHT", 0) ? 4 : 1) + 1024; /* (MGA_TXT_TIGHT=1: a deliberately small pool, so that a test sees the second launch) */
+				const int tight = env_int("MGA_TXT_TIGHT", 0); /* (MGA_TXT_TIGHT=1: a deliberately small pool, so that a test sees the second launch) */
+				for (k = 0; k < n; ++k) txt_cap += (tight ? 1 : 3) * (int64_t)qlens[k] / (tight ? 4 : 1) + 1024;
 				CK(mga_hbuf_reserve(&P->h_item, (size_t)hp_item * sizeof(mga_cigitem_t) + 16)); CK(mga_hbuf_reserve(&P->h_chain, (size_t)hp_chain * sizeof(mga_txt_chain_t) + 16));
 				CK(mga_hbuf_reserve(&P->h_vert, (size_t)hp_vert * 4 + 16));
 				mga_batch_text_export(b, (mga_cigitem_t*)P->h_item.p, (mga_txt_chain_t*)P->h_chain.p, (uint32_t*)P->h_vert.p);
