@@ -821,10 +821,11 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 			h_rflag = MGA_MALLOC(int32_t, n);
 			CK(mga_d2h_s(sc, h_rflag, P->rflag.p, (size_t)n * 4));
 		}
-		/* graph chaining (gc_core.h) runs where it fits: on the device, one wavefront per read (k_gchain.hip, [measured] ~0.18 s of GPU time per 100k reads),
+		/* graph chaining (gc_core.h) runs where it fits: on the device, one wavefront per read (k_gchain.hip, [measured] ~0.13 s of GPU time per 100k reads),
 		 * when this GPU has few host threads to itself -- a node whose CPU quota does not grow with its GPUs -- and on the host threads
-		 * ([measured] ~2 CPU-s per 100k reads) when there are enough of them to keep up.  MGA_DEV_GCHAIN=1 / 0 forces one or the other; same bytes either way. */
-		dev_gc = rs.enabled && B->dev.d_arc != 0 && env_int("MGA_DEV_GCHAIN", n_threads <= 6) && !env_int("MGA_HOST_GCHAIN", 0);
+		 * ([measured] ~3 CPU-s per 100k reads on a 3 Gbp graph) when there are enough of them to keep up.  [measured, cores = threads] 8: 1.42 (host) vs 1.78 Gbp/s
+		 * (device); 10: 1.59 vs 1.83; 16: 2.00 vs 1.84.  MGA_DEV_GCHAIN=1 / 0 forces one or the other; same bytes either way. */
+		dev_gc = rs.enabled && B->dev.d_arc != 0 && env_int("MGA_DEV_GCHAIN", n_threads <= 12) && !env_int("MGA_HOST_GCHAIN", 0);
 		if (dev_gc) {
 			/* ---- graph chaining: chain records, clean-up, DP + shortest walks, GWFA bridging, ordering, filters -- one wavefront per read ---- */
 			const size_t rec = mga_gc_rec_bytes();

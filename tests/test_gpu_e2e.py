@@ -2,6 +2,7 @@
 the unmodified reference (golden files, and the reference binary itself where oracle/_ref travelled)."""
 import hashlib
 import os
+import zlib
 import subprocess
 import tempfile
 
@@ -138,7 +139,8 @@ def test_error_free_reads_need_no_wfa_problem():
     ("chains only", ["-G", "3000000", "-H", "3", "-n", "1500", "-s", "36"], False),
     ("1.5 Mbp reads (long-join rescue left to the host tree, strays batched in k_lchain)", ["-G", "12000000", "-H", "3", "-n", "4", "-l", "1500000", "-e", "0.05", "-s", "37"], True),
 ])
-def test_parity_sweep_vs_reference_binary(tag, simargs, cigar):
+def test_parity_sweep_vs_reference_binary(tag, simargs, cigar, monkeypatch):
+    monkeypatch.setenv("MGA_DEV_GCHAIN", "0" if zlib.crc32(tag.encode()) & 1 else "1")  # both placements of graph chaining over the sweep
     """shapes the benchmark workload does not reach: wide WFA tiers (long gaps of long / noisy reads), many short reads,
     several stable sequences, the chains-only output"""
     need_ref()
@@ -443,7 +445,10 @@ OPTION_SETS = [
 
 @pytest.mark.parametrize("workload", ["bubbles", "repeat"])
 @pytest.mark.parametrize("tag,cli,idx_opt,map_opt,flags", OPTION_SETS, ids=[o[0] for o in OPTION_SETS])
-def test_command_line_options_vs_reference_binary(workload, tag, cli, idx_opt, map_opt, flags):
+def test_command_line_options_vs_reference_binary(workload, tag, cli, idx_opt, map_opt, flags, monkeypatch):
+    # graph chaining is placed by the host threads a rank has (device when <= 12): every option set is run through BOTH placements,
+    # the device one (k_gchain + k_plan) on the bubble graph, the host instantiation of the same routine on the repeat workload
+    monkeypatch.setenv("MGA_DEV_GCHAIN", "1" if workload == "bubbles" else "0")
     """every mapping option of the reference's command line (main.c:131-216) set through mg_idxopt_t / mg_mapopt_t: same bytes"""
     need_ref()
     d = tempfile.mkdtemp()
@@ -676,7 +681,7 @@ def test_graph_chaining_on_device_equals_host_instantiation_and_reference(monkey
     assert st1["n_wfa_dev_plan"] == 0 and st1["n_wfa"] == st["n_wfa"] and st1["wfa_t_bases"] == st["wfa_t_bases"] and st1["wfa_q_bases"] == st["wfa_q_bases"], (st, st1)
     assert dev_hostplan == dev
     monkeypatch.delenv("MGA_DEV_PLAN")
-    monkeypatch.delenv("MGA_DEV_GCHAIN")
+    monkeypatch.setenv("MGA_DEV_GCHAIN", "0")
     host = mga.map_reads(G, R, n_threads=8)
     st2 = mga.get_stats(G, reset=True)
     assert st2["n_gwfa"] == 0          # nothing was counted by the kernel on the host pass
