@@ -113,6 +113,7 @@ GC_HD void gc_sync(void) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront")
 GC_HD uint64_t gc_ballot(int pred) { return __ballot(pred); }
 GC_HD int32_t gc_rank(uint64_t mask) { return (int32_t)__popcll(mask & ((1ULL << (threadIdx.x & 63)) - 1ULL)); } /* set bits below this lane */
 GC_HD int32_t gc_popc(uint64_t mask) { return (int32_t)__popcll(mask); }
+GC_HD int32_t gc_sum(int32_t v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d); return v; } /* sum over the lanes, the same in every lane */
 #else
 #define GC_LANE 0
 #define GC_NLANE 1
@@ -120,6 +121,7 @@ GC_HD void gc_sync(void) {}
 GC_HD uint64_t gc_ballot(int pred) { return pred ? 1ULL : 0ULL; }
 GC_HD int32_t gc_rank(uint64_t mask) { (void)mask; return 0; }
 GC_HD int32_t gc_popc(uint64_t mask) { return (int32_t)(mask & 1ULL); }
+GC_HD int32_t gc_sum(int32_t v) { return v; }
 #endif
 #define GC_PAR_FOR(i, n) for (int32_t i = GC_LANE; i < (n); i += GC_NLANE)   /* no allocation, no gc_sync() inside */
 
@@ -425,11 +427,24 @@ GC_HD int gc_long_gaps(gc_arena_t *A, const mg128_t *a, int32_t s, int32_t n, in
 {
 	int32_t m = 0, *K;
 	*pos = 0, *n_pos = 0;
-	for (int32_t i = 1; i < n; ++i) { const int32_t g = gc_gap_at(a, s + i); m += (g < -min_gap || g > min_gap); }
+	for (int32_t base = 1; base < n; base += GC_NLANE) { /* (lanes: one anchor each; the count is the same in every lane) */
+		const int32_t i = base + GC_LANE;
+		int big = 0;
+		if (i < n) { const int32_t g = gc_gap_at(a, s + i); big = g < -min_gap || g > min_gap; }
+		m += gc_popc(gc_ballot(big));
+	}
 	if (m <= 1) return GC_OK;
 	GC_ALLOC(A, int32_t, K, m);
 	m = 0;
-	for (int32_t i = 1; i < n; ++i) { const int32_t g = gc_gap_at(a, s + i); if (g < -min_gap || g > min_gap) K[m++] = i; }
+	for (int32_t base = 1; base < n; base += GC_NLANE) {
+		const int32_t i = base + GC_LANE;
+		int big = 0;
+		if (i < n) { const int32_t g = gc_gap_at(a, s + i); big = g < -min_gap || g > min_gap; }
+		const uint64_t mk = gc_ballot(big);
+		if (big) K[m + gc_rank(mk)] = i;
+		m += gc_popc(mk);
+	}
+	gc_sync();
 	*pos = K, *n_pos = m;
 	return GC_OK;
 }
@@ -1651,28 +1666,29 @@ GC_HD void gc_measure(const gc_graph_t *G, gc_result_t *R)
 		p->qe = GC_AY(*a1) + 1;
 		const int32_t tail = gc_vlen(G, last->v) - GC_AX(*a1) - 1;
 		int32_t n_mini = (int32_t)(a1->x >> 32) - (int32_t)(a0->x >> 32) + 1, rest = 0;
-		const mg128_t *prev = a0;
+		int32_t blen = 0, mlen = 0, plen = 0, d_mini = 0; /* blen, mlen, d_mini: this lane's share of the sums */
+		const mg128_t *before = a0; /* the anchor before the first one of the current vertex */
 		for (int32_t j = 0; j < p->cnt; ++j) {
 			const mg_llchain_t *q = &R->lc[p->off + j];
 			const int32_t vlen = gc_vlen(G, q->v);
-			p->plen += vlen;
-			for (int32_t k = 0; k < q->cnt; ++k) {
-				const mg128_t *r = &R->a[q->off + k];
+			plen += vlen;
+			GC_PAR_FOR(k, q->cnt) { /* an anchor is compared with the one before it, wherever that lies */
+				const mg128_t *r = &R->a[q->off + k], *prev = k == 0 ? before : r - 1;
 				const int32_t span = GC_ASPAN(*r);
 				int32_t pl, ql = GC_AY(*r) - GC_AY(*prev);
 				if (j == 0 && k == 0) pl = ql = span;
 				else if (k == 0) pl = GC_AX(*r) + 1 + rest;
 				else pl = GC_AX(*r) - GC_AX(*prev);
-				if (ql < 0) ql = -ql, n_mini += (int32_t)(prev->x >> 32) - (int32_t)(r->x >> 32); /* query overlap at a junction */
-				p->blen += pl > ql ? pl : ql;
-				p->mlen += pl > span && ql > span ? span : pl < ql ? pl : ql;
-				prev = r;
+				if (ql < 0) ql = -ql, d_mini += (int32_t)(prev->x >> 32) - (int32_t)(r->x >> 32); /* query overlap at a junction */
+				blen += pl > ql ? pl : ql;
+				mlen += pl > span && ql > span ? span : pl < ql ? pl : ql;
 			}
 			if (q->cnt == 0) rest += vlen;
-			else rest = vlen - GC_AX(R->a[q->off + q->cnt - 1]) - 1;
+			else rest = vlen - GC_AX(R->a[q->off + q->cnt - 1]) - 1, before = &R->a[q->off + q->cnt - 1];
 		}
+		p->plen = plen, p->blen = gc_sum(blen), p->mlen = gc_sum(mlen);
 		p->pe = p->plen - tail;
-		p->n_mini = n_mini;
+		p->n_mini = n_mini + gc_sum(d_mini);
 	}
 }
 
