@@ -297,7 +297,7 @@ def main():
                         launches=launches[dom], avg_launch_ms=fam[dom] / max(1, launches[dom]), alg_bytes_per_launch=alg[dom] / max(1, launches[dom]),
                         family_ms_per_pass=fam[dom], pass_ms=isolated["ms"],
                         note="dominant kernel family by HIP-event time in the ISOLATED pass (one chunk in flight: launch durations do not overlap, sum <= pass_ms); "
-                             "the family is bound by vector-instruction issue, not HBM (DESIGN.md 4): see int_issue",
+                             "the family is not bound by HBM: a score step is a dependent chain at 4-5 resident waves per SIMD, int_issue prices it against the vector-issue ceiling (DESIGN.md 4, 'Measured and not kept': the ring-layout experiment)",
                         families={k: dict(ms=round(fam[k], 2), launches=launches[k], alg_GBps=round(alg[k] / max(fam[k], 1e-9) / 1e6, 2)) for k in fam})
             # integer-issue roofline of the WFA family: wavefront cells per second against what the vector ALUs could issue
             cells = sti["wfa_cells"]
