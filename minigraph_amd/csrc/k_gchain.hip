@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
 }
 
 extern "C" size_t mga_dev_gchain_arena_bytes(int tier) { return tier == 0 ? (size_t)1 << 20 : (size_t)256 << 20; }
-extern "C" int mga_dev_gchain_waves(int tier) { return tier == 0 ? 2048 : 24; } /* tier 0: 256 CUs x 4 SIMDs x 2 resident waves (246 VGPRs, no spills: [measured] same kernel time as 4 waves with 513 spills) */
+extern "C" int mga_dev_gchain_waves(int tier) { static int w0 = 0; if (w0 == 0) { const char *e = getenv("MGA_GC_WAVES"); w0 = e && atoi(e) > 0 ? atoi(e) : 2048; } return tier == 0 ? w0 : 24; } /* tier 0: 256 CUs x 4 SIMDs x 2 resident waves (246 VGPRs, no spills: [measured] same kernel time as 4 waves with 513 spills) */
 
 static void gc_par_from_opt(const mg_mapopt_t *opt, int k, float pen_gap, gc_par_t *P)
 {
