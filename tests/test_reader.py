@@ -124,3 +124,46 @@ def test_parallel_fasta_reader_windows_batches_and_fallback(monkeypatch):
     want = (len(recs), sum(len(s) for _, s in recs), fnv(recs))
     for bb, th in ((10 ** 9, 4), (300_000, 4)):
         assert parse_x(path, bb, th) == want, (bb, th)
+
+
+def _dump_records(path):
+    recs, name = [], None
+    for line in open(path, "rb"):
+        if line.startswith(b">"):
+            name = line[1:].rstrip(b"\n")
+        else:
+            recs.append((name, line.rstrip(b"\n")))
+    return recs
+
+
+def test_sharded_reader_any_world_size_reassembles_the_input():
+    """ONE input cut for `world` ranks by the library's reader (byte ranges at record starts for a memory-mapped FASTA, read-index slices of
+    every mini-batch otherwise): for world sizes that do and do not divide anything, tiny and huge records, CRLF, empty records, more ranks
+    than records -- the shards put back in (segment, rank) order are the input, record for record"""
+    rng = random.Random(23)
+    d = tempfile.mkdtemp()
+    for case, (n, crlf, gz) in enumerate([(700, False, False), (700, True, False), (3, False, False), (1, False, False), (250, False, True)]):
+        nl = b"\r\n" if crlf else b"\n"
+        recs, text = [], []
+        for i in range(n):
+            ln = rng.choice([0, 1, 59, 60, 61, 2000, 2000, 30000 if i % 97 == 0 else 500])
+            seq = bytes(rng.choices(b"ACGTacgtNu", k=ln))
+            recs.append((b"r%d" % i, norm(seq)))
+            text.append(b">r%d" % i + (b" c=%d" % i if i % 3 == 0 else b"") + nl + b"".join(seq[k:k + 60] + nl for k in range(0, ln, 60)))
+        path = os.path.join(d, "s%d.fa" % case + (".gz" if gz else ""))
+        (gzip.open if gz else open)(path, "wb").write(b"".join(text))
+        for world in (1, 2, 3, 5, 8, 13):
+            for bb in ((10 ** 9, 150_000) if n > 10 else (10 ** 9,)):
+                shards, segs = [], []
+                for r in range(world):
+                    out = os.path.join(d, "o%d_%d_%d.fa" % (case, world, r))
+                    segs.append([int(x) for x in mga.reads_shard_dump(path, out, r, world, batch_bases=bb, n_threads=3)])
+                    shards.append(_dump_records(out))
+                    assert sum(segs[-1]) == len(shards[-1])
+                got, pos = [], [0] * world
+                for s in range(max(len(x) for x in segs)):
+                    for r in range(world):
+                        k = segs[r][s] if s < len(segs[r]) else 0
+                        got += shards[r][pos[r]:pos[r] + k]
+                        pos[r] += k
+                assert got == recs, (case, world, bb)
