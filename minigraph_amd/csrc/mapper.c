@@ -920,6 +920,19 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	GPU_RELEASE();
 	if (g_dbg_pipe > 1) PIPE_LOG(" lchain", n, t0);
 	t1 = mga_wtime(); st->t_lchain += t1 - t0; t0 = t1;
+	if (env_int("MGA_CHECK", 0) && !is_rmq && !dev_gc) { /* debugging aid: invariants of what the device stages handed back (host placement) */
+		int64_t bad = 0;
+		for (i = 0; i < n && bad < 5; ++i) {
+			const int64_t na_i = h_aoff[i + 1] - h_aoff[i], nm_i = h_minioff[i + 1] - h_minioff[i];
+			int64_t k_;
+			int why = 0;
+			if (na_i < 0 || nm_i < 0 || nm_i > qlens[i]) why = 1;
+			else if (h_nb[i] < 0 || h_nb[i] > na_i || h_nu[i] < 0 || h_nu[i] > h_nb[i]) why = 2;
+			else for (k_ = 0; k_ < nm_i; ++k_) { const int32_t y = ((const int32_t*)P->h_mini.p)[h_minioff[i] + k_]; if (y < 0 || y >= qlens[i] || (k_ > 0 && y <= ((const int32_t*)P->h_mini.p)[h_minioff[i] + k_ - 1])) { why = 3; break; } }
+			if (why) { fprintf(stderr, "[check] chunk of %d reads: read %ld fails check %d: aoff %ld..%ld minioff %ld..%ld nu %d nb %d nmz %d qlen %d\n", n, (long)i, why, (long)h_aoff[i], (long)h_aoff[i + 1], (long)h_minioff[i], (long)h_minioff[i + 1], h_nu[i], h_nb[i], h_nmz[i], qlens[i]); ++bad; }
+		}
+		fprintf(stderr, "[check] chunk of %d reads: %ld bad (n_a %ld n_mini %ld n_mz capacity %ld)\n", n, (long)bad, (long)n_a, (long)n_mini, (long)n_mz);
+	}
 	/* ---- host: graph chaining + gap list ---- */
 	b = mga_batch_init(gi, opt, n, qlens, seqs, qnames, q_off, n_threads);
 	b->want_text = want_text;
@@ -1220,7 +1233,7 @@ mga_stream_t *mga_stream_open(const mg_idx_t *gi, const mg_mapopt_t *opt, int n_
 	if (S->n_pipe < 1) S->n_pipe = 1;
 	S->chunk = env_int("MGA_CHUNK", 16384); /* [measured] larger launches amortise the tails of the WFA tiers: 4096 -> 8192 reads +5 %, -> 16384 another +5 % */
 	if (S->chunk < 1) S->chunk = 1;
-	if (S->chunk > 16384) S->chunk = 16384; /* KNOWN LIMIT (round 2, not understood yet): chunks of more than 16384 reads crashed -- MGA_CHUNK=32768: host instantiation of graph chaining
+	if (S->chunk > 16384 && !env_int("MGA_CHUNK_UNSAFE", 0)) S->chunk = 16384; /* KNOWN LIMIT (round 2, not understood yet): chunks of more than 16384 reads crashed -- MGA_CHUNK=32768: host instantiation of graph chaining
 	                                          * at a 17216-read chunk (minimizer offsets of the chunk garbled), GPU memory fault with the device placement at 32768; every tested configuration has <= 16384 */
 	S->max_inflight = env_int("MGA_INFLIGHT", 3);
 	pthread_mutex_init(&S->m, 0); pthread_mutex_init(&S->api, 0);
