@@ -79,10 +79,10 @@ def _shard_worker(rank, world, port, q, graph, reads, occ, lco, batch_bases):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("gz", [False, True])
-def test_one_input_two_ranks_one_gaf(gz):
+@pytest.mark.parametrize("gz,world", [(False, 2), (True, 2), (False, 3)])
+def test_one_input_n_ranks_one_gaf(gz, world):
     """plain FASTA: the file is cut by byte range at record starts (one segment); gzip: every rank parses everything and keeps its slice
-    of every mini-batch (several segments with -K 40k)"""
+    of every mini-batch (several segments with -K 40k); three ranks: a world size that divides nothing"""
     import gzip
     import hostpipe as hp
     import minigraph_amd as mga
@@ -101,7 +101,7 @@ def test_one_input_two_ranks_one_gaf(gz):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q, graph, reads, occ, lco, 40000)) for r in range(2)]
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, q, graph, reads, occ, lco, 40000)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=300)
