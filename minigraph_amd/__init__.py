@@ -108,6 +108,7 @@ def load():
     L.mga_map_reads.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(mapopt_t), C.c_int, pp, C.POINTER(C.c_int64)]
     L.mga_get_stats.argtypes = [C.c_void_p, C.POINTER(stats_t), C.c_int]
     L.mga_prof_enable.argtypes = [C.c_int]
+    L.mga_idx_stream_close.argtypes = [C.c_void_p]
     L.mga_prof_get.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     _lib = L
     return L

@@ -62,8 +62,9 @@ extern "C" int mga_dev_bind_thread(void)
 }
 
 // pinned staging of small read-backs, see mga_d2h_s()
-#define MGA_STAGE_BYTES (1 << 20)
-#define MGA_STAGE_MAX   (256 << 10)
+static size_t g_stage_bytes = 1 << 20, g_stage_max = 256 << 10; // MGA_STAGE_KB=<n>: copies of up to n KB are staged (block of 4n KB)
+#define MGA_STAGE_BYTES g_stage_bytes
+#define MGA_STAGE_MAX   g_stage_max
 #define MGA_STAGE_SLOTS 64
 struct stage_ent_t { void *dst; size_t off, bytes; };
 struct stage_t { char *buf; size_t used; int n; stage_ent_t e[MGA_STAGE_SLOTS]; };
@@ -84,6 +85,7 @@ extern "C" mga_sctx_t *mga_sctx_create(void)
 	{ hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return 0; sc->ev_sync = (void*)e; }
 	{
 		stage_t *S = (stage_t*)calloc(1, sizeof(stage_t));
+		{ const char *e = getenv("MGA_STAGE_KB"); if (e && atoi(e) >= 0) g_stage_max = (size_t)atoi(e) << 10, g_stage_bytes = g_stage_max * 4 + 4096; }
 		S->buf = (char*)mga_hmalloc_pinned(MGA_STAGE_BYTES);
 		if (S->buf == 0) { free(S); return 0; }
 		sc->stage = S;

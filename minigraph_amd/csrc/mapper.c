@@ -1089,7 +1089,7 @@ typedef struct sbatch_s {
 	kstring_t *gaf_part; char *done; int next_commit;
 	pthread_mutex_t cmtx;
 	char *out; int64_t out_len, out_cap;
-	int err, complete;
+	int err, complete, inline_ok;
 	char errmsg[512];
 	void *user;
 } sbatch_t;
@@ -1233,8 +1233,6 @@ mga_stream_t *mga_stream_open(const mg_idx_t *gi, const mg_mapopt_t *opt, int n_
 	if (S->n_pipe < 1) S->n_pipe = 1;
 	S->chunk = env_int("MGA_CHUNK", 16384); /* [measured] larger launches amortise the tails of the WFA tiers: 4096 -> 8192 reads +5 %, -> 16384 another +5 % */
 	if (S->chunk < 1) S->chunk = 1;
-	if (S->chunk > 16384 && !env_int("MGA_CHUNK_UNSAFE", 0)) S->chunk = 16384; /* KNOWN LIMIT (round 2, not understood yet): chunks of more than 16384 reads crashed -- MGA_CHUNK=32768: host instantiation of graph chaining
-	                                          * at a 17216-read chunk (minimizer offsets of the chunk garbled), GPU memory fault with the device placement at 32768; every tested configuration has <= 16384 */
 	S->max_inflight = env_int("MGA_INFLIGHT", 3);
 	pthread_mutex_init(&S->m, 0); pthread_mutex_init(&S->api, 0);
 	pthread_cond_init(&S->c_work, 0); pthread_cond_init(&S->c_done, 0); pthread_cond_init(&S->c_space, 0);
@@ -1263,16 +1261,23 @@ static void batch_cut(mga_stream_t *S, sbatch_t *b)
 {
 	const int n = b->n, chunk = S->chunk;
 	const int ramp = env_int("MGA_RAMP", 1) && (n > 6 * chunk || (b->flags & (MGA_SB_FIRST | MGA_SB_LAST)) != (MGA_SB_FIRST | MGA_SB_LAST)); /* a batch of a longer job always ramps */
+	/* a chunk is also bounded in BASES: its device buffers grow with bases and anchors, not with reads, and a chunk of 16384 reads of 100 kb
+	 * each would be ten times the footprint every measurement was taken at.  MGA_CHUNK reads of 12 kb is the cap (10 kb reads: never reached). */
+	const int64_t base_cap = (S->opt.flag & MG_M_RMQ) ? INT64_MAX : (int64_t)chunk * env_int("MGA_CHUNK_READ_BASES", 12288); /* (-x asm: a batch is a handful of contigs chained in phases over ALL of them) */
 	int pos = 0, m = 0, cap = n / (chunk / 4 > 0 ? chunk / 4 : 1) + 8;
 	b->cstart = MGA_MALLOC(int, cap + 1);
 	while (pos < n) {
-		int sz = chunk, left = n - pos;
+		int sz = chunk, left = n - pos, k;
+		int64_t bases = 0;
 		if (ramp) {
 			if (b->flags & MGA_SB_FIRST) { if (m == 0) sz = chunk / 4; else if (m == 1) sz = chunk / 2; }
 			if ((b->flags & MGA_SB_LAST) && left <= chunk + chunk / 2) sz = left > chunk / 2 + chunk / 8 ? left - chunk / 2 : left; /* tail: the last chunk is chunk/2 (or what is left) */
 		}
 		if (sz < 1) sz = 1;
 		if (sz > left) sz = left;
+		for (k = 0; k < sz; ++k) { bases += b->qlens[pos + k]; if (bases > base_cap && k > 0) break; } /* (a single read longer than the cap is a chunk of its own) */
+		sz = k;
+		if (m == cap) { cap += cap / 2 + 8; b->cstart = MGA_REALLOC(int, b->cstart, cap + 1); }
 		b->cstart[m++] = pos; pos += sz;
 	}
 	b->cstart[m] = n;
@@ -1303,7 +1308,12 @@ int mga_stream_submit(mga_stream_t *S, int n, const int *qlens, const char **seq
 	S->tail = b;
 	if (S->cur == 0) S->cur = b;
 	++S->n_inflight;
-	if (b->n_chunks > 1 || S->started) { stream_start(S); pthread_cond_broadcast(&S->c_work); }
+	/* Only a job that is ONE single-chunk batch (FIRST|LAST: one-read calls, small mg_map_batch calls) may run inline on the collecting thread
+	 * (mga_stream_collect, context 0).  Any other batch starts the workers NOW: a single-chunk first batch of a longer job (e.g. 64 Mbp of 50 kb reads)
+	 * used to run inline on P[0] while the next batch started worker 0 on the SAME context -- two threads on one set of device / staging buffers
+	 * (the "chunks of more than 16384 reads" fault of round 2: any chunk size that made the job's first batch a single chunk). */
+	b->inline_ok = b->n_chunks <= 1 && !S->started && (flags & (MGA_SB_FIRST | MGA_SB_LAST)) == (MGA_SB_FIRST | MGA_SB_LAST);
+	if (!b->inline_ok) { stream_start(S); pthread_cond_broadcast(&S->c_work); }
 	pthread_mutex_unlock(&S->m);
 	return 0;
 }
@@ -1317,7 +1327,7 @@ int mga_stream_collect(mga_stream_t *S, char **out, int64_t *out_len, int64_t *o
 	pthread_mutex_lock(&S->m);
 	b = S->head;
 	if (b == 0) { pthread_mutex_unlock(&S->m); return 0; }
-	if (!S->started) { /* single-chunk batches on a stream without workers run right here, on context 0 (one-read calls: no thread hand-off) */
+	if (b->inline_ok && !S->started) { /* a single-chunk, single-batch job on a stream without workers runs right here, on context 0 (one-read calls: no thread hand-off) */
 		while (b->next_chunk < b->n_chunks) {
 			int c = b->next_chunk++;
 			pthread_mutex_unlock(&S->m);

@@ -82,7 +82,7 @@ def test_long_join_rescue_on_device_matches_host_tree_and_reference(monkeypatch)
     assert dev == host
     R.close()
     G.close()
-    if os.path.exists(rb.REF_BIN):
+    if need_ref() is None:   # (asserts: a GPU box without the reference binary FAILS these tests)
         ref_out = os.path.join(d, "ref.gaf")
         run_ref(["-c", "-x", "lr", "-t", "4", graph, reads], ref_out)
         assert open(ref_out, "rb").read() == dev
@@ -105,7 +105,7 @@ def test_device_text_equals_host_text_and_reference(monkeypatch, target):
     assert dev.count(b"\n") > 1000 and b"\tds:Z:" in dev
     assert sum(1 for l in dev.split(b"\n") if l and l.split(b"\t")[4] == b"-") > 100   # reverse-strand lines are exercised
     assert dev == host
-    if os.path.exists(rb.REF_BIN):
+    if need_ref() is None:   # (asserts: a GPU box without the reference binary FAILS these tests)
         ref_out = os.path.join(d, "ref.gaf")
         run_ref(["-c", "-x", "lr", "-t", "4", graph, reads], ref_out)
         assert open(ref_out, "rb").read() == dev
@@ -124,7 +124,7 @@ def test_error_free_reads_need_no_wfa_problem():
     G.close()
     import re
     assert len(re.findall(rb"\tcg:Z:\d+=\tds:Z::\d+\n", dev)) > 250   # whole reads in one '=' run (minus the ends before the first / after the last minimizer)
-    if os.path.exists(rb.REF_BIN):
+    if need_ref() is None:   # (asserts: a GPU box without the reference binary FAILS these tests)
         ref_out = os.path.join(d, "ref.gaf")
         run_ref(["-c", "-x", "lr", "-t", "4", graph, reads], ref_out)
         assert open(ref_out, "rb").read() == dev
@@ -310,7 +310,7 @@ def test_reference_shaped_c_api_mg_map_and_mg_map_batch():
     G.close()
     assert batch == want
     assert single == b"".join(want.split(b"\n")[k] + b"\n" for k in range(40))
-    if os.path.exists(rb.REF_BIN):
+    if need_ref() is None:   # (asserts: a GPU box without the reference binary FAILS these tests)
         ref_out = os.path.join(d, "ref.gaf")
         run_ref(["-c", "-x", "lr", "-t", "4", graph, reads], ref_out)
         assert open(ref_out, "rb").read() == batch
@@ -334,6 +334,59 @@ def test_pipeline_knobs_do_not_change_the_output(monkeypatch):
             monkeypatch.delenv(k)
         assert got == want, (chunk, pipe, threads, extra)
     R.close()
+    G.close()
+
+
+def test_chunks_beyond_16384_reads_in_both_placements(monkeypatch):
+    """chunk sizes 17 216 / 32 768 / 65 536 with graph chaining on the host and on the device.  (The round-2 fault was a job whose FIRST
+    mini-batch is one chunk -- it ran inline on pipeline context 0 while the next batch started worker 0 on the same context; any MGA_CHUNK with
+    chunk/4 >= the 6 400 reads of the first 64 Mbp batch triggered it.)  70 000 x 3 kb reads; the default-chunk output is the yardstick, and that
+    configuration is compared with the reference in the other tests of this file."""
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "20000000", "-c", "2", "-H", "3", "-n", "70000", "-l", "3000", "-s", "9"], stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    G = mga.Graph(graph, preset="lr", cigar=True, n_threads=8)
+    m = mga.map_files_idx(G, [reads], n_threads=8)
+    want = hashlib.md5(m.view().tobytes()).hexdigest()
+    n_want = len(m)
+    m.free()
+    assert n_want > 70000 * 2000
+    L = mga.load()
+    for chunk in (17216, 32768, 65536):
+        for dev in ("0", "1"):
+            monkeypatch.setenv("MGA_CHUNK", str(chunk))
+            monkeypatch.setenv("MGA_DEV_GCHAIN", dev)
+            L.mga_idx_stream_close(G.gi)   # the index's pipeline re-reads its knobs when it is rebuilt
+            m = mga.map_files_idx(G, [reads], n_threads=8)
+            got = hashlib.md5(m.view().tobytes()).hexdigest()
+            m.free()
+            assert got == want, (chunk, dev)
+    G.close()
+
+
+def test_long_reads_whose_first_batch_is_one_chunk_vs_reference_binary(monkeypatch):
+    """50 kb reads.  The first mini-batch of a job is 64 Mbp = 1 280 such reads = ONE chunk at any chunk size >= 5 120, the second
+    (500 Mbp, 10 000 reads) is several: the shape that made two threads share a pipeline context in round 2.  Default chunking (bounded by
+    bases here) and MGA_CHUNK=6000, both placements of graph chaining, against the reference binary."""
+    need_ref()
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "30000000", "-c", "2", "-H", "3", "-n", "11300", "-l", "50000", "-s", "13"], stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    ref_out = os.path.join(d, "ref.gaf")
+    run_ref(["-c", "-x", "lr", "-t", "32", graph, reads], ref_out)
+    want = hashlib.md5(open(ref_out, "rb").read()).hexdigest()
+    G = mga.Graph(graph, preset="lr", cigar=True, n_threads=8)
+    L = mga.load()
+    for chunk in ("", "6000"):
+        for dev in ("0", "1"):
+            if chunk:
+                monkeypatch.setenv("MGA_CHUNK", chunk)
+            monkeypatch.setenv("MGA_DEV_GCHAIN", dev)
+            L.mga_idx_stream_close(G.gi)
+            m = mga.map_files_idx(G, [reads], n_threads=8)
+            got = hashlib.md5(m.view().tobytes()).hexdigest()
+            m.free()
+            assert got == want, (chunk, dev)
     G.close()
 
 
