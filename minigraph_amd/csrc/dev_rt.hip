@@ -97,7 +97,8 @@ extern "C" void mga_sctx_destroy(mga_sctx_t *sc)
 {
 	if (sc == 0) return;
 	(void)hipStreamSynchronize((hipStream_t)sc->stream);
-	for (int i = 0; i < MGA_WFA_MAX_TIER; ++i) mga_dbuf_free(&sc->wfa_ws[i]);
+	for (int i = 0; i < 10; ++i) mga_dbuf_free(&sc->wfa_ws[i]);
+	for (int i = 0; i < 8; ++i) mga_dbuf_free(&sc->wfa_tbuf[i]);
 	mga_dbuf_free(&sc->wfa_cnt);
 	mga_dbuf_free(&sc->scan_tmp); mga_dbuf_free(&sc->txt_cnt); mga_dbuf_free(&sc->txt_off); mga_dbuf_free(&sc->txt_vwb); mga_dbuf_free(&sc->txt_el);
 	mga_dbuf_free(&sc->wfa_list[0]); mga_dbuf_free(&sc->wfa_list[1]); mga_dbuf_free(&sc->wfa_key); mga_dbuf_free(&sc->wfa_ctl);

@@ -19,32 +19,51 @@
 #include "wfachain.h"
 #include "dev_common.h"
 
-#define WFS_NBIN (MGA_WFA_N_TIER * 1024)
+#define WFS_NBIN (MGA_WFA_N_SLOT * 1024)
 
-// the band of a 10%-error gap is about as wide as the gap is long ([measured] on the benchmark workload:
-// mean length 76 -> mean score 40 -> band 81), so start where a band equal to the length fits: [measured] 2-5 % of the
-// problems then outgrow their tier and are re-run one tier up, which is cheaper than starting everything wider
-struct wfs_thr_t { int32_t t[7]; };
-__host__ __device__ __forceinline__ int wfs_first_tier_thr(int32_t tl, int32_t ql, const wfs_thr_t &T)
+// The ladder (round 3).  Rungs W0-W5 are the WINDOWED tiers of k_wfa_w.hip (16 / 32 / 64 / 128 / 192 / 256 diagonals, exact for scores below the
+// window's bound, < 256 in any case); what they cannot decide -- scores >= 256, sequences beyond 512 bases -- goes to the register tiers with the
+// reference's full band (k_wfa_r.hip: 512 / 1024 / 2048 diagonals) and the HBM tiers (k_wfa.hip).  MGA_WFA_LADDER=old brings back the round-2 ladder
+// (register tiers 64 .. 2048, HBM) for A/B measurements; the chained fallback's sub-problems always use it (their results must sit in the pool).
+// A rung: kind (0 windowed, 1 register / HBM), tier index of that kind, the longest sequence that STARTS there, the rung a problem that gives up goes to.
+// First rungs by length, [measured on 359 519 gaps of the bench workload, cost model = steps x lanes-share]: 90 % of the gaps of length L score <= 0.68 L,
+// and a gap that gives up has wasted its steps up to the bound, so a gap starts in the narrowest window whose bound most gaps of its length stay under.
+struct wfs_rung_t { int kind, idx, maxlen, next; };
+struct wfs_ladder_t { int n; wfs_rung_t r[MGA_WFA_N_SLOT]; };
+struct wfs_thr_t { int32_t n, t[MGA_WFA_N_SLOT]; };
+static const wfs_ladder_t g_ladder_win = { 11, {
+	{ 0, 0, 71, 1 }, { 0, 1, 111, 2 }, { 0, 2, 167, 3 }, { 0, 3, 255, 4 }, { 0, 4, 343, 5 }, { 0, 5, 512, 7 }, // (W5 stops at score 256: the 512-diagonal band would stop there too)
+	{ 1, 4, 1024, 7 }, { 1, 5, 2048, 8 }, { 1, 6, 4096, 9 }, { 1, 7, 0x7fffffff, 10 }, { 1, 8, 0x7fffffff, -1 } } };
+static const wfs_ladder_t g_ladder_old = { 9, {
+	{ 1, 0, 64, 1 }, { 1, 1, 128, 2 }, { 1, 2, 192, 3 }, { 1, 3, 256, 4 }, { 1, 4, 512, 5 }, { 1, 5, 2048, 6 }, { 1, 6, 4096, 7 }, { 1, 7, 0x7fffffff, 8 }, { 1, 8, 0x7fffffff, -1 } } };
+
+static const wfs_ladder_t *wfs_ladder(int force_old)
 {
-	const int32_t m = tl > ql ? tl : ql;
-	for (int k = 0; k < 7; ++k) if (m <= T.t[k]) return k;
-	return 7;
-}
-static wfs_thr_t wfs_thresholds(void)
-{
-	static wfs_thr_t T = { { 64, 128, 192, 256, 512, 2048, 4096 } };
+	static wfs_ladder_t L[2];
 	static int init = 0;
-	if (!init) { // MGA_WFA_THR="a,b,c,d,e": first-tier length limits of the 64/128/192/256/512-diagonal tiers (tuning aid)
-		const char *e = getenv("MGA_WFA_THR");
-		if (e) sscanf(e, "%d,%d,%d,%d,%d", &T.t[0], &T.t[1], &T.t[2], &T.t[3], &T.t[4]);
+	if (!init) { // MGA_WFA_THR="a,b,c,...": first-rung length limits, in rung order (tuning aid)
+		const char *e = getenv("MGA_WFA_LADDER"), *thr = getenv("MGA_WFA_THR");
+		L[0] = g_ladder_win, L[1] = g_ladder_old;
+		if (e && strcmp(e, "old") == 0) L[0] = g_ladder_old;
+		for (int k = 0; thr && *thr && k < L[0].n; ++k) { L[0].r[k].maxlen = atoi(thr); thr = strchr(thr, ','); if (thr) ++thr; }
 		init = 1;
 	}
-	return T;
+	return &L[force_old ? 1 : 0];
 }
-__host__ __device__ __forceinline__ int wfs_first_tier(int32_t tl, int32_t ql) { const wfs_thr_t T = { { 64, 128, 192, 256, 512, 2048, 4096 } }; return wfs_first_tier_thr(tl, ql, T); }
+__host__ __device__ __forceinline__ int wfs_first_rung(int32_t tl, int32_t ql, const wfs_thr_t &T)
+{
+	const int32_t m = tl > ql ? tl : ql;
+	for (int k = 0; k < T.n - 1; ++k) if (m <= T.t[k]) return k;
+	return T.n - 1;
+}
 
-extern "C" int mga_wfa_first_tier(int32_t tl, int32_t ql) { return wfs_first_tier(tl, ql); }
+extern "C" int mga_wfa_first_tier(int32_t tl, int32_t ql) // (round-2 stage API: first register tier by length)
+{
+	const wfs_ladder_t *L = &g_ladder_old;
+	const int32_t m = tl > ql ? tl : ql;
+	for (int k = 0; k < L->n; ++k) if (m <= L->r[k].maxlen) return k;
+	return L->n - 1;
+}
 
 __global__ void __launch_bounds__(1024) k_wfa_bin_count(int n, const mga_wfa_prob_t *__restrict__ prob, int32_t *__restrict__ key, int *__restrict__ hist, wfs_thr_t T)
 {
@@ -55,7 +74,7 @@ __global__ void __launch_bounds__(1024) k_wfa_bin_count(int n, const mga_wfa_pro
 		const int32_t tl = prob[i].tl, ql = prob[i].ql;
 		int lb = (tl + ql) >> 3;
 		if (lb > 1023) lb = 1023;
-		const int k = wfs_first_tier_thr(tl, ql, T) << 10 | (1023 - lb);
+		const int k = wfs_first_rung(tl, ql, T) << 10 | (1023 - lb);
 		key[i] = k;
 		atomicAdd(&h[k], 1);
 	}
@@ -87,7 +106,7 @@ __global__ void __launch_bounds__(1024) k_wfa_bin_scan(int *__restrict__ hist, i
 		if ((b & 1023) == 0) tier_off[b >> 10] = run;
 		run += v[i];
 	}
-	if (tid == 1023) tier_off[MGA_WFA_N_TIER] = run;
+	if (tid == 1023) tier_off[MGA_WFA_N_SLOT] = run;
 }
 
 // tile of 8192 ids per workgroup: LDS histogram of the tile, ONE global atomic per non-empty bin to reserve its slots,
@@ -275,6 +294,9 @@ extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_
 	static int dbg = -1;
 	if (dbg < 0) { const char *e = getenv("MGA_DEBUG_WFA"); dbg = e && atoi(e) > 0; }
 	hipStream_t st = (hipStream_t)sc->stream;
+	const wfs_ladder_t *LD = wfs_ladder(sc->wfa_uncapped); // (the fallback's sub-problems: register / HBM tiers only, results in the pool at once)
+	const int NR = LD->n;
+	constexpr int NS = MGA_WFA_N_SLOT;
 	// ctl: hist[NBIN] | tier_off[16] | rc[2][16] | err | fb | cells (8 bytes)
 	constexpr int O_TOFF = WFS_NBIN, O_RC = O_TOFF + 16, O_ERR = O_RC + 32, O_FB = O_ERR + 1, O_CELLS = O_ERR + 2, N_CTL = O_CELLS + 2;
 	if (mga_dbuf_reserve(&sc->wfa_list[0], (size_t)n * 4 + 64) < 0 || mga_dbuf_reserve(&sc->wfa_list[1], (size_t)n * 4 + 64) < 0 ||
@@ -286,49 +308,76 @@ extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_
 	{
 		int nb = (n + 1023) / 1024;
 		if (nb > 1024) nb = 1024;
+		wfs_thr_t T;
+		T.n = NR;
+		for (int k = 0; k < NS; ++k) T.t[k] = k < NR ? LD->r[k].maxlen : 0x7fffffff;
 		mga_prof_begin(st, MGA_K_SCAN);
-		hipLaunchKernelGGL(k_wfa_bin_count, dim3(nb), dim3(1024), 0, st, n, d_prob, (int32_t*)sc->wfa_key.p, ctl, wfs_thresholds());
+		hipLaunchKernelGGL(k_wfa_bin_count, dim3(nb), dim3(1024), 0, st, n, d_prob, (int32_t*)sc->wfa_key.p, ctl, T);
 		hipLaunchKernelGGL(k_wfa_bin_scan, dim3(1), dim3(1024), 0, st, ctl, ctl + O_TOFF);
 		hipLaunchKernelGGL(k_wfa_bin_scatter, dim3((n + 8191) / 8192), dim3(1024), 0, st, n, (const int32_t*)sc->wfa_key.p, ctl, L[0]);
 		mga_prof_end(st, MGA_K_SCAN);
 		MGA_HIP_CHECK(hipGetLastError());
 	}
-	int h[MGA_WFA_N_TIER + 2], off[MGA_WFA_N_TIER + 1], cnt[MGA_WFA_N_TIER + 1];
-	if (mga_d2h_s(sc, h, ctl + O_TOFF, (MGA_WFA_N_TIER + 1) * 4) < 0 || mga_ssync(sc) < 0) return -1;
-	for (int t = 0; t < MGA_WFA_N_TIER; ++t) off[t] = h[t], cnt[t] = h[t + 1] - h[t];
+	int h[NS + 2], off[NS + 1], cnt[NS + 1];
+	bool any_tb = false;
+	if (mga_d2h_s(sc, h, ctl + O_TOFF, (NS + 1) * 4) < 0 || mga_ssync(sc) < 0) return -1;
+	for (int t = 0; t < NS; ++t) off[t] = h[t], cnt[t] = t < NR ? h[t + 1] - h[t] : 0;
 	for (int pass = 0, cur = 0;; ++pass, cur ^= 1) {
-		int *rc = ctl + O_RC + 16 * (pass & 1), nstart[MGA_WFA_N_TIER + 2];
+		int *rc = ctl + O_RC + 16 * (pass & 1), nstart[NS + 2], incoming[NS + 1];
 		MGA_HIP_CHECK(hipMemsetAsync(rc, 0, 16 * 4, st));
-		MGA_HIP_CHECK(hipMemsetAsync(sc->wfa_cnt.p, 0, 1024, st)); // the tiers' work-queue counters (one 64-byte line each)
-		nstart[0] = nstart[1] = 0; // region of tier u in the next pass's list: as many slots as tier u-1 runs problems now
-		for (int u = 1; u <= MGA_WFA_N_TIER; ++u) nstart[u + 1] = nstart[u] + cnt[u - 1];
+		MGA_HIP_CHECK(hipMemsetAsync(sc->wfa_cnt.p, 0, 1024, st)); // the rungs' work-queue counters (one 64-byte line each)
+		// region of rung u in the next pass's list: room for everything the rungs that feed it run now
+		for (int u = 0; u <= NS; ++u) incoming[u] = 0;
+		for (int t = 0; t < NR; ++t) if (LD->r[t].next >= 0) incoming[LD->r[t].next] += cnt[t];
+		nstart[0] = 0;
+		for (int u = 0; u < NS; ++u) nstart[u + 1] = nstart[u] + incoming[u];
+		// traceback regions of this pass's windowed rungs
+		int64_t tb_off[NS], tb_bytes = 0;
+		for (int t = 0; t < NR; ++t) { tb_off[t] = tb_bytes; if (LD->r[t].kind == 0 && cnt[t] > 0) tb_bytes += (int64_t)cnt[t] * mga_dev_wfa_win_tb_stride(LD->r[t].idx); }
+		if (tb_bytes > 0) {
+			if (pass >= 8) { mga_set_error("WFA ladder: windowed rung in pass %d", pass); return -1; } // cannot happen: a problem leaves the windowed rungs within six passes
+			if (mga_dbuf_reserve(&sc->wfa_tbuf[pass], (size_t)tb_bytes + 256) < 0) return -1;
+			any_tb = true;
+		}
 		if (mga_wfa_fork(sc) < 0) return -1;
-		for (int t = 0; t < MGA_WFA_N_TIER; ++t) {
+		for (int t = 0; t < NR; ++t) {
 			if (cnt[t] <= 0) continue;
-			// wfa_key is free once the lists are built: it takes the problems that hit the cell cap (only the HBM tiers count cells)
-			mga_wfa_retry_t rt = { L[cur ^ 1] + nstart[t + 1], rc + t + 1, ctl + O_ERR, (int32_t*)sc->wfa_key.p, ctl + O_FB };
-			if (mga_dev_wfa_tier(sc, cnt[t], L[cur] + off[t], d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, t, rt) < 0) return -1;
+			const int nx = LD->r[t].next;
+			// wfa_key is free once the lists are built: it takes the problems that hit the cell cap (only the HBM tiers count cells); rc[15]: problems beyond the last rung
+			mga_wfa_retry_t rt = { L[cur ^ 1] + (nx >= 0 ? nstart[nx] : 0), rc + (nx >= 0 ? nx : 15), ctl + O_ERR, (int32_t*)sc->wfa_key.p, ctl + O_FB };
+			if (LD->r[t].kind == 0) {
+				if (mga_dev_wfa_win(sc, cnt[t], L[cur] + off[t], d_prob, d_tseq, d_qseq, d_res, (char*)sc->wfa_tbuf[pass].p + tb_off[t], LD->r[t].idx, 9 + LD->r[t].idx, rt) < 0) return -1;
+			} else if (mga_dev_wfa_tier(sc, cnt[t], L[cur] + off[t], d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, LD->r[t].idx, rt) < 0) return -1;
 		}
 		if (mga_wfa_join(sc) < 0) return -1;
-		if (pass == 0 && bulk_done && !mga_wfa_tiers_serial()) { // the narrow tiers carry >95 % of the work: once they are done the caller may let the next chunk's
-			// WFA phase start; the long tails of the wide tiers and the retry passes then overlap with it instead of idling the GPU
+		if (pass == 0 && bulk_done && !mga_wfa_tiers_serial()) { // the narrow rungs carry > 95 % of the work: once they are done the caller may let the next chunk's
+			// WFA phase start; the long tails of the wide ones and the retry passes then overlap with it instead of idling the GPU
 			struct timespec ts = { 0, 50000 };
-			for (int t = 0; t < 5; ++t)
-				while (cnt[t] > 0 && hipEventQuery((hipEvent_t)sc->ev_done[t]) == hipErrorNotReady) nanosleep(&ts, 0);
+			for (int t = 0; t < NR && t < 6; ++t) {
+				const int slot = LD->r[t].kind == 0 ? 9 + LD->r[t].idx : LD->r[t].idx;
+				while (cnt[t] > 0 && hipEventQuery((hipEvent_t)sc->ev_done[slot]) == hipErrorNotReady) nanosleep(&ts, 0);
+			}
 			bulk_done(bulk_arg);
 		}
-		int hr[MGA_WFA_N_TIER + 1], herr = 0, left = 0;
-		if (mga_d2h_s(sc, hr, rc, (MGA_WFA_N_TIER + 1) * 4) < 0 || mga_d2h_s(sc, &herr, ctl + O_ERR, 4) < 0 || mga_ssync(sc) < 0) return -1;
+		int hr[16], herr = 0, left = 0;
+		if (mga_d2h_s(sc, hr, rc, 16 * 4) < 0 || mga_d2h_s(sc, &herr, ctl + O_ERR, 4) < 0 || mga_ssync(sc) < 0) return -1;
 		if (dbg) {
 			fprintf(stderr, "[wfa] pass %d:", pass);
-			for (int t = 0; t < MGA_WFA_N_TIER; ++t) if (cnt[t]) fprintf(stderr, " tier %d: %d (%d retry)", t, cnt[t], hr[t + 1]);
+			for (int t = 0; t < NR; ++t) if (cnt[t]) fprintf(stderr, " %s%d: %d", LD->r[t].kind == 0 ? "W" : "R", LD->r[t].idx, cnt[t]);
+			fprintf(stderr, " | given up ->");
+			for (int t = 0; t < NR; ++t) if (hr[t]) fprintf(stderr, " rung %d: %d", t, hr[t]);
 			fprintf(stderr, "\n");
 		}
 		if (herr) { mga_set_error("WFA: %d problems failed (CIGAR pool of %ld ops exhausted, or iteration cap)", herr, (long)pool_cap); return -1; }
-		if (hr[MGA_WFA_N_TIER] > 0) { mga_set_error("%d WFA problems exceed the largest capacity tier", hr[MGA_WFA_N_TIER]); return -1; }
-		cnt[0] = 0;
-		for (int u = 1; u < MGA_WFA_N_TIER; ++u) cnt[u] = hr[u], off[u] = nstart[u], left += hr[u];
+		if (hr[15] > 0) { mga_set_error("%d WFA problems exceed the largest capacity tier", hr[15]); return -1; }
+		for (int u = 0; u < NS; ++u) cnt[u] = u < NR ? hr[u] : 0, off[u] = nstart[u], left += cnt[u];
 		if (left == 0) break;
+	}
+	if (any_tb) { // the windowed rungs left scores + traceback regions: CIGARs into the pool, one lane per problem
+		int herr = 0;
+		if (mga_dev_wfa_traceback(sc, n, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, ctl + O_ERR) < 0) return -1;
+		if (mga_d2h_s(sc, &herr, ctl + O_ERR, 4) < 0 || mga_ssync(sc) < 0) return -1;
+		if (herr) { mga_set_error("WFA traceback: CIGAR pool of %ld ops exhausted (%d problems)", (long)pool_cap, herr); return -1; }
 	}
 	{ // problems the exact pass gave up on (> 1e8 cells): miniwfa's chained fallback (miniwfa.c:829-832)
 		int n_fb = 0;

@@ -1,0 +1,465 @@
+// k_wfa_w.hip -- WINDOWED exact 2-piece affine WFA (round 3): the gap filler's fast tiers for alignments scoring < 256.
+//
+// Why a window is exact.  miniwfa's exact mode (miniwfa.c:380-435) widens its band by one diagonal per score on both sides, so a
+// problem of score S costs ~S^2 cells although its optimal paths stay near the line between the start diagonal 0 and the end
+// diagonal e = ql - tl.  Moving n diagonals costs at least g(n) = min(o1 + n e1, o2 + n e2) = min(4 + 2n, 15 + n): a path that
+// visits diagonal d scores at least g(|d|) + g(|e - d|).  Fix a window [lo, hi] of diagonals and let B be that bound for the
+// first diagonals outside it (lo - 1, hi + 1; none if the window reaches the matrix edge -tl / ql).  If the alignment found
+// INSIDE the window scores S < B, then no cell outside the window lies on ANY optimal path, and every cell that does lie on
+// one has the same value, the same winning predecessor and the same tie-break bits as in the reference's wider band: a pruned
+// predecessor can only lower a value (furthest-reaching values are monotone in their inputs, extension included), never raise
+// it, and a predecessor that wins or ties at a cell of an optimal path is itself on an optimal path, hence inside the window
+// and exact by induction over the score.  The traceback (miniwfa.c:329-377) only ever visits cells of optimal paths, so score
+// and CIGAR are the reference's.  A problem that reaches score B undecided leaves the tier (MGA_WFA_RETRY_TIER) and is run
+// again in a wider window; the windowed tiers stop at score 256, below the reference's first band trimming (miniwfa.c:139-169,
+// :420), so its band is still the complete set of reachable diagonals there.  [measured, 359 519 gaps of the bench workload,
+// CPU model of this file against the reference's own mwf_wfa_auto: 0 differences; 61.5 % of the gaps decide in 16 diagonals,
+// 80 % in 32, 91.5 % in 64 -- the reference's band for the same gaps averages 2 S + 1 = 80.]
+//
+// What that buys on a 64-lane wavefront: FOUR problems per wave in 16-lane groups (tier W0), TWO in 32-lane groups (W1), one
+// in 64 lanes (W2) and one in 2-4 slots of 64 lanes (W3-W5) -- no multi-wave tiers, no barrier, no band bookkeeping (the window
+// is computed whole; cells the reference's band has not reached hold NEG_INF + small, which loses every comparison exactly
+// like the NEG_INF of the reference's padding).
+//
+// Forward pass (k_wfa_fw): lane l of a group owns diagonal lo + l (+ 64 j for slot j).  H of the last 17 scores, E1/F1 (3),
+// E2/F2 (2) live in VGPRs indexed by age as in k_wfa_r.hip; neighbours come from DPP row / wave shifts that stay inside the
+// group.  Sequences are staged in LDS (four byte-shifted copies: any 8 bases are one aligned ds_read2_b32).  The groups of a wave
+// run in lockstep but on independent problems: a group that finishes (or gives up) is retired and refilled from the work
+// queue while the others carry on.  Traceback bytes never touch LDS: four scores are packed into one dword per lane and stored
+// with one coalesced global_store_dword per four steps into the problem's own region of a scratch pool.
+// Traceback (k_wfa_tb): one LANE per problem walks its region backwards (miniwfa.c:329-377), twice -- count, then write the
+// operators into the CIGAR pool at an offset reserved with one atomic per wavefront -- and leaves the same mga_wfa_res_t the
+// register tiers of k_wfa_r.hip leave.
+#include <type_traits>
+#include "mga_dev.h"
+#include "dev_common.h"
+
+#define WF_NEG_INF (-0x40000000)
+#define WFW_SMAX 256 // the windowed tiers decide scores < 256 only (see above)
+
+__host__ __device__ __forceinline__ int32_t wfw_gap(int32_t n) // cheapest way to move n diagonals (penalties 4 / 4,2 / 15,1: miniwfa.c:11-18)
+{
+	if (n < 0) n = -n;
+	if (n == 0) return 0;
+	const int32_t a = 4 + 2 * n, b = 15 + n;
+	return a < b ? a : b;
+}
+
+// window of W diagonals for a tl x ql problem, centred between diagonal 0 and the end diagonal ql - tl, clipped to the matrix's [-tl, ql];
+// returns the bound B (capped at WFW_SMAX): an alignment inside [*lo, *lo + W - 1] that scores < B is THE alignment
+__host__ __device__ __forceinline__ int32_t wfw_window(int32_t W, int32_t tl, int32_t ql, int32_t *lo_)
+{
+	const int32_t e = ql - tl, c = e / 2;
+	int32_t lo = c - W / 2, hi;
+	if (lo < -tl) lo = -tl;
+	hi = lo + W - 1;
+	if (hi > ql) { hi = ql; lo = hi - W + 1; if (lo < -tl) lo = -tl; }
+	*lo_ = lo;
+	const int32_t blo = lo - 1 >= -tl ? wfw_gap(lo - 1) + wfw_gap(e - (lo - 1)) : WFW_SMAX;
+	const int32_t bhi = hi + 1 <= ql ? wfw_gap(hi + 1) + wfw_gap(hi + 1 - e) : WFW_SMAX;
+	const int32_t b = blo < bhi ? blo : bhi;
+	return b < WFW_SMAX ? b : WFW_SMAX;
+}
+extern "C" int32_t mga_wfw_window(int32_t W, int32_t tl, int32_t ql, int32_t *lo) { return wfw_window(W, tl, ql, lo); } // (tests)
+
+// furthest diagonal any path of score <= s can have reached: max n with wfw_gap(n) <= s
+__device__ __forceinline__ int32_t wfw_reach(int32_t s) { return s < 6 ? 0 : max((s - 4) >> 1, s - 15); }
+
+__device__ __forceinline__ int32_t wfw_max(int32_t a, int32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ int32_t wfw_sel(int32_t mask, int32_t a, int32_t b) { return (a & mask) | (b & ~mask); } // v_bfi_b32: a where mask is all ones
+
+struct wfw_u2 { uint32_t x, y; }; // 8 bytes with 4-byte alignment: loads become ds_read2_b32
+
+// neighbour diagonals inside a group of G lanes.  from_left: lane l <- src[l-1], the group's first lane gets NEG_INF (or `edge`: the previous slot's last lane)
+template<int G> __device__ __forceinline__ int32_t wfw_from_left(int32_t edge, int32_t src, int32_t m_first)
+{
+	if (G == 16) return __builtin_amdgcn_update_dpp(edge, src, 0x111, 0xf, 0xf, false); // row_shr:1 -- lane 0 of every row of 16 keeps `edge`
+	const int32_t v = __builtin_amdgcn_update_dpp(edge, src, 0x138, 0xf, 0xf, false);   // wave_shr:1
+	return G == 32 ? wfw_sel(m_first, edge, v) : v;                                      // (lane 32 must not see lane 31)
+}
+template<int G> __device__ __forceinline__ int32_t wfw_from_right(int32_t edge, int32_t src, int32_t m_last)
+{
+	if (G == 16) return __builtin_amdgcn_update_dpp(edge, src, 0x101, 0xf, 0xf, false); // row_shl:1
+	const int32_t v = __builtin_amdgcn_update_dpp(edge, src, 0x130, 0xf, 0xf, false);   // wave_shl:1
+	return G == 32 ? wfw_sel(m_last, edge, v) : v;
+}
+
+// per-lane problem state: 0 idle, 1 running, 2 reached the end cell (this lane holds it), 3 gives up (score bound / lengths)
+enum { WFW_IDLE = 0, WFW_RUN = 1, WFW_DONE = 2, WFW_BAIL = 3 };
+
+template<int G, int J, int SEQCAP>
+__global__ void __launch_bounds__(64) k_wfa_fw(int n_items, const int32_t *__restrict__ list, const mga_wfa_prob_t *__restrict__ prob,
+											  const char *__restrict__ tseq, const char *__restrict__ qseq, mga_wfa_res_t *__restrict__ res,
+											  char *__restrict__ tb, long long tb_stride, int *__restrict__ counter, mga_wfa_retry_t rt)
+{
+	static_assert(G == 16 || G == 32 || G == 64, "group size");
+	static_assert(J == 1 || G == 64, "several slots per lane only with one problem per wave");
+	constexpr int P = 64 / G;      // problems per wavefront
+	constexpr int W = G * J;       // diagonals of the window = dwords per traceback row
+	constexpr int SEQS = SEQCAP + 16;
+	__shared__ __attribute__((aligned(16))) uint8_t Tb[P][4 * SEQS], Qb[P][4 * SEQS];
+	const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
+	uint8_t *const Tg = Tb[grp], *const Qg = Qb[grp];
+	const int32_t m_first = gl == 0 ? -1 : 0, m_last = gl == G - 1 ? -1 : 0;
+	const uint64_t gmask = (G == 64 ? ~0ULL : ((1ULL << G) - 1ULL)) << (grp * G);
+#define WFW_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+	int32_t st = WFW_IDLE, pi = -1, tl = 0, ql = 0, lo = 0, e = 0, s = 0, bnd = 0, lst = 0, ph = 0;
+	int32_t okv[J];               // all ones where this lane's diagonal exists in the matrix (-tl <= d <= ql)
+	uint32_t acc[J];              // traceback bytes of the last (up to) four steps
+	uint32_t *tbp = 0;            // this lane's dword in the current traceback row (slot j: + 64 j)
+	char *region = 0;
+	int32_t H[J][18], E1[J][3], F1[J][3], E2[J][2], F2[J][2];
+	int32_t t = 0;                // steps this wavefront has made (all groups advance together)
+	bool q_empty = false;
+#pragma unroll
+	for (int j = 0; j < J; ++j) {
+		okv[j] = 0, acc[j] = 0;
+#pragma unroll
+		for (int a = 0; a < 18; ++a) H[j][a] = WF_NEG_INF;
+#pragma unroll
+		for (int a = 0; a < 3; ++a) E1[j][a] = F1[j][a] = WF_NEG_INF;
+#pragma unroll
+		for (int a = 0; a < 2; ++a) E2[j][a] = F2[j][a] = WF_NEG_INF;
+	}
+
+	// H of the last 16 scores is shifted by TWO registers every second step (k_wfa_r.hip): the step body exists twice, P = t & 1.
+	// P = 0: age a is H[a + 2], the new slice goes to H[1]; P = 1: age a is H[a + 1], the new slice goes to H[0], then H[a] = H[a - 2].
+	// The parity is the WAVE's, not the problem's: a problem that starts on an odd step puts its score-0 cell where age 0 is then.
+#define HA(j_, a_) H[j_][(a_) + 2 - P]
+	auto step = [&](auto Pc) __attribute__((always_inline)) -> bool { // false: the queue is empty and every group is idle
+		constexpr int P = decltype(Pc)::value;
+		// ---- retire the groups that are through, refill idle groups from the queue
+		if (__ballot(st >= WFW_DONE || (st == WFW_IDLE && !q_empty))) {
+			const uint64_t m_done = __ballot(st == WFW_DONE);
+			const bool g_done = (m_done & gmask) != 0;
+			if (g_done || st == WFW_BAIL) { // (a group gives up as a whole: s and bnd are the same in all of its lanes; one lane reaching the end cell in the same step wins)
+				if (g_done) { // the rest of the last traceback row (bytes of steps t & ~3 .. t - 1)
+					if (t & 3) {
+#pragma unroll
+						for (int j = 0; j < J; ++j) tbp[64 * j] = acc[j] << (8 * (4 - (t & 3)));
+					}
+					if (st == WFW_DONE) {
+						mga_wfa_res_t r;
+						r.score = s, r.n_cigar = 0, r.cig_off = (int64_t)(uintptr_t)region, r.status = MGA_WFA_TB, r.pad = lst | ph << 4 | W << 8, r.n_iter = 0;
+						res[pi] = r;
+					}
+				} else if (gl == 0) {
+					mga_wfa_res_t r;
+					r.score = -1, r.n_cigar = 0, r.cig_off = 0, r.status = MGA_WFA_RETRY_TIER, r.pad = 0, r.n_iter = 0;
+					res[pi] = r;
+					rt.list[atomicAdd(rt.cnt, 1)] = pi; // next tier's work list
+				}
+				st = WFW_IDLE;
+			}
+			if (!q_empty) {
+				const uint64_t m_idle = __ballot(st == WFW_IDLE && gl == 0);
+				if (m_idle) {
+					int32_t base = 0;
+					if (lane == 0) base = atomicAdd(counter, (int)__popcll(m_idle));
+					base = __builtin_amdgcn_readfirstlane(base);
+					const int32_t item = base + (int32_t)__popcll(m_idle & ((1ULL << (grp * G)) - 1ULL));
+					const bool fill = st == WFW_IDLE && item < n_items;
+					if (__ballot(st == WFW_IDLE && item >= n_items)) q_empty = true;
+					int32_t ntl = 0, nql = 0;
+					const char *ts = tseq, *qs = qseq;
+					if (fill) {
+						pi = list ? list[item] : item;
+						const mga_wfa_prob_t pb = prob[pi];
+						ntl = pb.tl, nql = pb.ql, ts = tseq + pb.t_off, qs = qseq + pb.q_off;
+						region = tb + (long long)item * tb_stride;
+						tbp = (uint32_t*)region + gl;
+						ph = t & 3, s = 0, lst = 0, e = nql - ntl;
+						if (ntl > SEQCAP || nql > SEQCAP) bnd = 0, ntl = nql = 0; // too long for this tier's LDS: gives up at once
+						else { bnd = wfw_window(W, ntl, nql, &lo); if (bnd > W + 30) bnd = W + 30; } // (W + 30 bounds every window's B; the traceback rows are sized for it)
+						tl = ntl, ql = nql;
+						st = WFW_RUN;
+					}
+					// stage the sequences of the refilled groups; 16 bytes of padding so that the 8-byte compares may overrun
+					WFW_LDS_FENCE(); // (the previous problem's reads of these LDS bytes are complete: same wave, in order)
+					for (int32_t i0 = 0; __ballot(fill && i0 < ntl + 16); i0 += G) {
+						const int32_t i = i0 + gl;
+						if (fill && i < ntl + 16) {
+							const uint8_t c = i < ntl ? (uint8_t)ts[i] : (uint8_t)0;
+							Tg[i] = c;
+							if (i >= 1) Tg[SEQS + i - 1] = c;
+							if (i >= 2) Tg[2 * SEQS + i - 2] = c;
+							if (i >= 3) Tg[3 * SEQS + i - 3] = c;
+						}
+					}
+					for (int32_t i0 = 0; __ballot(fill && i0 < nql + 16); i0 += G) {
+						const int32_t i = i0 + gl;
+						if (fill && i < nql + 16) {
+							const uint8_t c = i < nql ? (uint8_t)qs[i] : (uint8_t)1;
+							Qg[i] = c;
+							if (i >= 1) Qg[SEQS + i - 1] = c;
+							if (i >= 2) Qg[2 * SEQS + i - 2] = c;
+							if (i >= 3) Qg[3 * SEQS + i - 3] = c;
+						}
+					}
+					WFW_LDS_FENCE();
+					const int32_t mf = fill ? -1 : 0;
+#pragma unroll
+					for (int j = 0; j < J; ++j) {
+						const int32_t d = lo + gl + 64 * j;
+#pragma unroll
+						for (int a = 0; a < 18; ++a) H[j][a] = wfw_sel(mf, WF_NEG_INF, H[j][a]);
+#pragma unroll
+						for (int a = 0; a < 3; ++a) E1[j][a] = wfw_sel(mf, WF_NEG_INF, E1[j][a]), F1[j][a] = wfw_sel(mf, WF_NEG_INF, F1[j][a]);
+#pragma unroll
+						for (int a = 0; a < 2; ++a) E2[j][a] = wfw_sel(mf, WF_NEG_INF, E2[j][a]), F2[j][a] = wfw_sel(mf, WF_NEG_INF, F2[j][a]);
+						if (fill) {
+							acc[j] = 0;
+							okv[j] = (d >= -tl && d <= ql) ? -1 : 0;
+							if (d == 0) HA(j, 0) = -1; // score 0: H[d = 0] = -1 (miniwfa.c:103-119)
+						}
+					}
+				}
+			}
+		}
+		if (!__ballot(st == WFW_RUN)) return false;
+		// ---- extension of slice s (miniwfa.c:399-411); the end cell lies on the unique diagonal ql - tl
+		const int32_t rs = (J > 1) ? wfw_reach(s) : 0; // (J > 1: one problem per wave, s is uniform)
+#pragma unroll
+		for (int j = 0; j < J; ++j) {
+			const int32_t d = lo + gl + 64 * j;
+			if (J > 1) { const int32_t b0 = __builtin_amdgcn_readfirstlane(lo) + 64 * j; if (b0 > rs || b0 + 63 < -rs) continue; } // no diagonal of the slot is reachable yet
+			const int32_t k0 = HA(j, 0), i0 = d + k0;
+			const bool val = st == WFW_RUN && (uint32_t)(k0 + 1) <= (uint32_t)tl && (uint32_t)(i0 + 1) <= (uint32_t)ql; // -1 <= k0 < tl, -1 <= i0 < ql
+			const int32_t tp = val ? k0 + 1 : 0, qp = val ? i0 + 1 : 0;
+			const int32_t room = min(tl - tp, ql - qp);
+			const wfw_u2 *tw = (const wfw_u2*)(Tg + (tp & 3) * SEQS + (tp & ~3)), *qw = (const wfw_u2*)(Qg + (qp & 3) * SEQS + (qp & ~3)); // 4-byte aligned
+			int32_t n = 0, m8 = 0; // m8: matched blocks of 8 bases
+			bool act = val && room > 0;
+			while (__ballot(act)) { // uniform loop, no divergent branch inside: finished lanes reload their last block and add nothing
+				const wfw_u2 a = tw[m8], b = qw[m8];
+				const uint32_t c0 = a.x ^ b.x, c1 = a.y ^ b.y;
+				const int32_t e0 = (int32_t)((c0 ? (uint32_t)__builtin_ctz(c0) : 32u) >> 3), e1 = (int32_t)((c1 ? (uint32_t)__builtin_ctz(c1) : 32u) >> 3);
+				const int32_t adv = e0 < 4 ? e0 : 4 + e1; // equal leading bytes of the block: 0..8
+				n += act ? adv : 0;
+				m8 += (act && adv == 8) ? 1 : 0;
+				act = act && adv == 8 && n < room;
+			}
+			n = min(n, room);
+			const int32_t k = k0 + n;
+			HA(j, 0) = val ? k : k0;
+			if (val && d == e && k == tl - 1) { // the end cell (then d + k == ql - 1)
+				st = WFW_DONE;
+				lst = n == 0 ? (int32_t)(acc[j] & 7u) : 0; // it was entered by a gap state and not extended: the traceback starts in that state (miniwfa.c:406-407)
+			}
+		}
+		if (st == WFW_RUN && s + 1 >= bnd) st = WFW_BAIL; // (uniform inside a group; the lane that just reached the end cell keeps WFW_DONE, and that wins)
+		// ---- slice s + 1 (miniwfa.c:281-308).  Computed for every group; a group that is through ignores it.
+		const int32_t rn = (J > 1) ? wfw_reach(s + 1) : 0;
+		int32_t nH[J], nE1[J], nF1[J], nE2[J], nF2[J];
+#pragma unroll
+		for (int j = 0; j < J; ++j) {
+			if (J > 1) {
+				const int32_t b0 = __builtin_amdgcn_readfirstlane(lo) + 64 * j;
+				if (b0 > rn || b0 + 63 < -rn) { nH[j] = nE1[j] = nF1[j] = nE2[j] = nF2[j] = WF_NEG_INF; continue; }
+			}
+			// predecessors: score s+1-p is age p-1 now (ages are shifted at the end of the step)
+#define WFW_L(R, a) wfw_from_left<G>(j > 0 ? __builtin_amdgcn_readlane(R[j > 0 ? j - 1 : 0][a], 63) : WF_NEG_INF, R[j][a], m_first)
+#define WFW_R(R, a) wfw_from_right<G>(j < J - 1 ? __builtin_amdgcn_readlane(R[j < J - 1 ? j + 1 : j][a], 0) : WF_NEG_INF, R[j][a], m_last)
+			const int32_t ho1l = WFW_L(H, 5 + 2 - P), e1l = WFW_L(E1, 1), ho2l = WFW_L(H, 15 + 2 - P), e2l = WFW_L(E2, 0);
+			const int32_t ho1r = WFW_R(H, 5 + 2 - P), f1r = WFW_R(F1, 1), ho2r = WFW_R(H, 15 + 2 - P), f2r = WFW_R(F2, 0);
+#undef WFW_L
+#undef WFW_R
+			const int32_t hx1 = HA(j, 3) + 1;
+			const int32_t vE1 = wfw_max(ho1l, e1l), vE2 = wfw_max(ho2l, e2l);
+			const int32_t vF1 = wfw_max(ho1r, f1r) + 1, vF2 = wfw_max(ho2r, f2r) + 1;
+			const uint32_t bits = (ho1l < e1l ? 0x08u : 0u) | (ho2l < e2l ? 0x20u : 0u) | (ho1r < f1r ? 0x10u : 0u) | (ho2r < f2r ? 0x40u : 0u);
+			const int32_t ee = wfw_max(vE1, vE2), ff = wfw_max(vF1, vF2), hh = wfw_max(ee, ff);
+			const uint32_t ze = vE1 >= vE2 ? 1u : 3u, zf = vF1 >= vF2 ? 2u : 4u;
+			uint32_t z = ee >= ff ? ze : zf;
+			z = hx1 >= hh ? 0u : z;
+			const int32_t vH = wfw_max(hx1, hh);
+			acc[j] = acc[j] << 8 | (bits | z);
+			nH[j] = wfw_sel(okv[j], vH, WF_NEG_INF), nE1[j] = wfw_sel(okv[j], vE1, WF_NEG_INF), nF1[j] = wfw_sel(okv[j], vF1, WF_NEG_INF);
+			nE2[j] = wfw_sel(okv[j], vE2, WF_NEG_INF), nF2[j] = wfw_sel(okv[j], vF2, WF_NEG_INF);
+		}
+#pragma unroll
+		for (int j = 0; j < J; ++j) { // age shift (H: every second step, by two)
+			HA(j, -1) = nH[j];
+			if (P == 1) {
+#pragma unroll
+				for (int a = 17; a > 1; --a) H[j][a] = H[j][a - 2];
+			}
+			E1[j][2] = E1[j][1]; E1[j][1] = E1[j][0]; E1[j][0] = nE1[j];
+			F1[j][2] = F1[j][1]; F1[j][1] = F1[j][0]; F1[j][0] = nF1[j];
+			E2[j][1] = E2[j][0]; E2[j][0] = nE2[j];
+			F2[j][1] = F2[j][0]; F2[j][0] = nF2[j];
+		}
+		if ((t & 3) == 3) { // a row of traceback dwords is full: one coalesced store, next row
+			if (st != WFW_IDLE) { // (lanes of a group that gives up in the very step another lane of it reaches the end cell must store too)
+#pragma unroll
+				for (int j = 0; j < J; ++j) tbp[64 * j] = acc[j];
+			}
+			tbp += W;
+		}
+		if (st == WFW_RUN) ++s;
+		++t;
+		return true;
+	};
+	for (;;) {
+		if (!step(std::integral_constant<int, 0>())) break;
+		if (!step(std::integral_constant<int, 1>())) break;
+	}
+#undef HA
+}
+
+// ---- traceback: one lane per problem (miniwfa.c:329-377) ----------------------------------------------------------------------------
+
+// byte of cell (score sc, window index idx) in a problem's region: rows of W dwords, four scores per dword, the earliest in the top byte
+__device__ __forceinline__ uint32_t wfw_tb_byte(const uint32_t *__restrict__ reg, int32_t W, int32_t ph, int32_t sc, int32_t idx)
+{
+	const int32_t p = ph + sc - 1;
+	return reg[(size_t)(p >> 2) * W + idx] >> (8 * (3 - (p & 3))) & 0xffu;
+}
+
+// walks the alignment from the end cell to the start; WRITE: operators go to out[n_total - 1 - k] (the walk finds them last to first).  Returns their number.
+template<bool WRITE>
+__device__ __forceinline__ int32_t wfw_trace(int32_t tl, int32_t ql, const char *__restrict__ ts, const char *__restrict__ qs, int32_t S, int32_t last,
+											 const uint32_t *__restrict__ reg, int32_t W, int32_t ph, int32_t lo, uint32_t *__restrict__ out, int32_t n_total)
+{
+	int32_t i = ql - 1, k = tl - 1, sc = S, n = 0, cur_op = -1, cur_len = 0;
+#define PUSH(op_, len_) do { \
+		if (cur_op == (op_)) cur_len += (len_); \
+		else { \
+			if (cur_op >= 0) { if (WRITE) out[n_total - 1 - n] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; ++n; } \
+			cur_op = (op_), cur_len = (len_); \
+		} \
+	} while (0)
+	while (i >= 0 && k >= 0) {
+		if (last == 0) { // a run of matches, eight bases at a time
+			int32_t run = 0;
+			while (i >= 7 && k >= 7) {
+				uint64_t x, y;
+				__builtin_memcpy(&x, qs + i - 7, 8);
+				__builtin_memcpy(&y, ts + k - 7, 8);
+				const uint64_t c = x ^ y;
+				const int32_t m = c ? (int32_t)(__builtin_clzll(c) >> 3) : 8;
+				i -= m, k -= m, run += m;
+				if (m < 8) goto run_done;
+			}
+			while (i >= 0 && k >= 0 && qs[i] == ts[k]) --i, --k, ++run;
+run_done:
+			if (run > 0) PUSH(7, run);
+			if (i < 0 || k < 0) break;
+		}
+		const uint32_t x = wfw_tb_byte(reg, W, ph, sc, (i - k) - lo);
+		const int32_t state = last == 0 ? (int32_t)(x & 7) : last;
+		const int32_t ext = state > 0 ? (int32_t)(x >> (state + 2) & 1) : 0;
+		if (state == 0) { PUSH(8, 1); --i, --k, sc -= 4; }
+		else if (state == 1) { PUSH(1, 1); --i, sc -= ext ? 2 : 6; }
+		else if (state == 3) { PUSH(1, 1); --i, sc -= ext ? 1 : 16; }
+		else if (state == 2) { PUSH(2, 1); --k, sc -= ext ? 2 : 6; }
+		else { PUSH(2, 1); --k, sc -= ext ? 1 : 16; }
+		last = state > 0 && ext ? state : 0;
+	}
+	if (i >= 0) PUSH(1, i + 1);
+	else if (k >= 0) PUSH(2, k + 1);
+	PUSH(15, 0);
+#undef PUSH
+	return n;
+}
+
+__global__ void __launch_bounds__(256) k_wfa_tb(int n, const mga_wfa_prob_t *__restrict__ prob, const char *__restrict__ tseq, const char *__restrict__ qseq,
+												mga_wfa_res_t *__restrict__ res, uint32_t *__restrict__ pool, long long pool_cap, unsigned long long *pool_used, int *__restrict__ err)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+	mga_wfa_res_t r;
+	r.status = MGA_WFA_OK;
+	if (i < n) r = res[i];
+	const bool mine = i < n && r.status == MGA_WFA_TB;
+	if (!__ballot(mine)) return;
+	mga_wfa_prob_t pb;
+	pb.tl = pb.ql = 0, pb.t_off = pb.q_off = 0;
+	if (mine) pb = prob[i];
+	const int32_t W = r.pad >> 8, ph = r.pad >> 4 & 3, last = r.pad & 7;
+	const uint32_t *reg = (const uint32_t*)(uintptr_t)r.cig_off;
+	const char *ts = tseq + pb.t_off, *qs = qseq + pb.q_off;
+	int32_t lo = 0, n_cig = 0;
+	if (mine) {
+		(void)wfw_window(W, pb.tl, pb.ql, &lo);
+		n_cig = wfw_trace<false>(pb.tl, pb.ql, ts, qs, r.score, last, reg, W, ph, lo, 0, 0);
+	}
+	// one reservation per wavefront
+	int32_t incl = n_cig;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { const int32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+	const int32_t tot = __shfl(incl, 63);
+	unsigned long long base = 0;
+	if (lane == 63 && tot > 0) base = atomicAdd(pool_used, (unsigned long long)tot);
+	base = __shfl(base, 63);
+	if (!mine) return;
+	if ((long long)(base + (unsigned long long)tot) > pool_cap) {
+		r.status = MGA_WFA_POOL_FULL, r.score = -1, r.n_cigar = 0, r.cig_off = 0;
+		res[i] = r;
+		atomicAdd(err, 1);
+		return;
+	}
+	const long long off = (long long)base + (incl - n_cig);
+	(void)wfw_trace<true>(pb.tl, pb.ql, ts, qs, r.score, last, reg, W, ph, lo, pool + off, n_cig);
+	// the reference's cell count for this alignment (n_iter, miniwfa.c:421): its band at score s is the reachable diagonals +- 1, clipped to the matrix
+	long long cells = 0;
+	for (int32_t s = 0; s < r.score; ++s) { const int32_t w = wfw_reach(s) + 1; cells += min(w, pb.tl) + min(w, pb.ql) + 1; }
+	r.n_cigar = n_cig, r.cig_off = off, r.status = MGA_WFA_OK, r.pad = 0, r.n_iter = cells;
+	res[i] = r;
+}
+
+// ---- host drivers ---------------------------------------------------------------------------------------------------------
+
+struct wfw_tier_t { int W, n_wg; };
+static const wfw_tier_t g_wtier[MGA_WFW_N] = {
+	// window, resident workgroups (one wavefront each)
+	{  16, 8192 },   // four problems per wavefront; scores < 46 (bound of a centred 16-diagonal window)
+	{  32, 8192 },   // two per wavefront; < 62
+	{  64, 8192 },   // < 94
+	{ 128, 6144 },   // < 158
+	{ 192, 6144 },   // < 222
+	{ 256, 4096 },   // < 256
+};
+// traceback rows per problem: four scores each, scores < min(W + 30, 256), + the phase of the first row (<= 3) and the step after the last score
+static int wfw_rows(int W) { const int smax = W + 30 < WFW_SMAX ? W + 30 : WFW_SMAX; return (smax + 3) / 4 + 2; }
+
+extern "C" int64_t mga_dev_wfa_win_tb_stride(int wt) { return (int64_t)wfw_rows(g_wtier[wt].W) * g_wtier[wt].W * 4; }
+
+extern "C" int mga_dev_wfa_win(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+							   mga_wfa_res_t *d_res, char *d_tb, int wt, int slot, mga_wfa_retry_t rt)
+{
+	if (n <= 0) return 0;
+	if (wt < 0 || wt >= MGA_WFW_N) { mga_set_error("wfa_win: bad tier %d", wt); return -1; }
+	const wfw_tier_t &T = g_wtier[wt];
+	const int per = 64 / (T.W < 64 ? T.W : 64);
+	int wgs = (n + per * 4 - 1) / (per * 4);
+	if (wgs > T.n_wg) wgs = T.n_wg;
+	if (wgs < 1) wgs = 1;
+	hipStream_t st = (hipStream_t)mga_wfa_stream(sc, slot);
+	int *d_counter = (int*)((char*)sc->wfa_cnt.p + 64 * slot);
+	const long long stride = (long long)mga_dev_wfa_win_tb_stride(wt);
+	mga_prof_begin(st, MGA_K_WFAW0 + wt);
+#define LAUNCH(GG, JJ, SEQ) hipLaunchKernelGGL((k_wfa_fw<GG, JJ, SEQ>), dim3(wgs), dim3(64), 0, st, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_tb, stride, d_counter, rt)
+	if (wt == 0) LAUNCH(16, 1, 128);
+	else if (wt == 1) LAUNCH(32, 1, 192);
+	else if (wt == 2) LAUNCH(64, 1, 256);
+	else if (wt == 3) LAUNCH(64, 2, 384);
+	else if (wt == 4) LAUNCH(64, 3, 512);
+	else LAUNCH(64, 4, 512);
+#undef LAUNCH
+	mga_prof_end(st, MGA_K_WFAW0 + wt);
+	MGA_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+
+extern "C" int mga_dev_wfa_traceback(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq, mga_wfa_res_t *d_res,
+									 uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int *d_err)
+{
+	if (n <= 0) return 0;
+	hipStream_t st = (hipStream_t)sc->stream;
+	mga_prof_begin(st, MGA_K_WFATB);
+	hipLaunchKernelGGL(k_wfa_tb, dim3((n + 255) / 256), dim3(256), 0, st, n, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap, d_pool_used, d_err);
+	mga_prof_end(st, MGA_K_WFATB);
+	MGA_HIP_CHECK(hipGetLastError());
+	return 0;
+}

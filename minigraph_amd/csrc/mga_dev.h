@@ -35,13 +35,14 @@ void mga_dbuf_free(mga_dbuf_t *b);
  * two contexts let the mapping pipeline overlap the GPU work of one chunk with the host work of another. ---- */
 typedef struct mga_sctx_s {
 	void *stream;              /* hipStream_t */
-	mga_dbuf_t wfa_ws[10];     /* per-tier WFA workspaces */
+	mga_dbuf_t wfa_ws[10];     /* per-tier WFA workspaces (register / HBM tiers) */
+	mga_dbuf_t wfa_tbuf[8];    /* traceback regions of the windowed tiers, one buffer per pass of the ladder (k_wfa_w.hip) */
 	mga_dbuf_t wfa_cnt;        /* work-queue counters, one 64-byte line per tier */
 	mga_dbuf_t scan_tmp;       /* tile sums of mga_dev_scan_i32_to_i64 */
 	mga_dbuf_t txt_cnt, txt_off, txt_vwb, txt_el; /* text kernel scratch (k_text.hip) */
 	mga_dbuf_t wfa_list[2], wfa_key, wfa_ctl; /* tier scheduler (k_wfa_sched.hip): double-buffered work lists, sort keys, counters */
-	void *tier_stream[10];      /* WFA tiers run concurrently on their own streams (long-tailed wide problems next to the small ones) */
-	void *ev_ready, *ev_done[10];
+	void *tier_stream[16];      /* WFA tiers run concurrently on their own streams (long-tailed wide problems next to the small ones) */
+	void *ev_ready, *ev_done[16];
 	void *ev_sync;             /* event behind mga_ssync() */
 	void *stage;               /* pinned staging for small device-to-host read-backs, delivered by mga_ssync() */
 	mga_dbuf_t gc_arena[2];    /* per-wave scratch arenas of k_gchain: 1 MiB x resident waves, and the large tier for the reads that outgrow that */
@@ -66,9 +67,12 @@ int  mga_hbuf_reserve(mga_hbuf_t *b, size_t bytes);
 void mga_hbuf_free(mga_hbuf_t *b);
 
 /* per-kernel HIP-event timing on the launch stream (bench.py reads it through mga_prof_get) */
-enum { MGA_K_SKETCH = 0, MGA_K_SEED_COUNT, MGA_K_SEED_FILL, MGA_K_LCHAIN, MGA_K_WFA0 /* +tier: 0-2 single-wave register tiers (band 64,128,192), 3-6 multi-wave register tiers (256..2048), 7-8 HBM tiers */, MGA_K_SCAN = MGA_K_WFA0 + 9, MGA_K_TEXT, MGA_K_GCHAIN, MGA_K_PLAN, MGA_K_N };
-#define MGA_WFA_N_TIER 9
-#define MGA_WFA_MAX_TIER 10 /* array size of the per-tier resources */
+enum { MGA_K_SKETCH = 0, MGA_K_SEED_COUNT, MGA_K_SEED_FILL, MGA_K_LCHAIN, MGA_K_WFA0 /* +tier: 0-2 single-wave register tiers (band 64,128,192), 3-6 multi-wave register tiers (256..2048), 7-8 HBM tiers */, MGA_K_SCAN = MGA_K_WFA0 + 9, MGA_K_TEXT, MGA_K_GCHAIN, MGA_K_PLAN,
+	   MGA_K_WFAW0 /* +0..5: windowed tiers of 16 (4 problems per wave), 32 (2), 64, 128, 192, 256 diagonals (k_wfa_w.hip) */, MGA_K_WFATB = MGA_K_WFAW0 + 6 /* their traceback */, MGA_K_N };
+#define MGA_WFW_N 6         /* windowed tiers */
+#define MGA_WFA_N_TIER 9    /* register + HBM tiers (k_wfa_r.hip 0-6, k_wfa.hip 7-8) */
+#define MGA_WFA_N_SLOT 11   /* rungs of the ladder: W0-W5, R4-R6, H0-H1 (MGA_WFA_LADDER=old: R0-R6, H0-H1) */
+#define MGA_WFA_MAX_TIER 16 /* array size of the per-rung resources */
 void mga_prof_enable(int on);
 void mga_prof_begin(void *stream, int kid);
 void mga_prof_end(void *stream, int kid);
@@ -146,7 +150,8 @@ size_t mga_dev_lchain_ws_bytes(int64_t total_anchors);
 /* ---- WFA (k_wfa.hip) ---- */
 typedef struct { int64_t t_off, q_off; int32_t tl, ql; } mga_wfa_prob_t;
 typedef struct { int32_t score, n_cigar; int64_t cig_off; int32_t status, pad; int64_t n_iter; } mga_wfa_res_t;
-enum { MGA_WFA_OK = 0, MGA_WFA_PENDING = 1, MGA_WFA_RETRY_TIER = 2, MGA_WFA_POOL_FULL = 3, MGA_WFA_MAX_ITER = 4 };
+enum { MGA_WFA_OK = 0, MGA_WFA_PENDING = 1, MGA_WFA_RETRY_TIER = 2, MGA_WFA_POOL_FULL = 3, MGA_WFA_MAX_ITER = 4,
+	   MGA_WFA_TB = 5 /* forward pass of a windowed tier done: score set, cig_off = address of the traceback region, pad = last state | phase << 4 | window << 8 */ };
 /* where a WFA kernel appends the problems that outgrew its tier (device pointers); err counts the other failures; fb_list/fb_cnt collect
  * the problems that hit the reference's 1e8-cell cap (miniwfa.c:827): they are re-done by the chained fallback (k_wfa_sched.hip) */
 typedef struct { int32_t *list; int *cnt; int *err; int32_t *fb_list; int *fb_cnt; } mga_wfa_retry_t;
@@ -157,6 +162,14 @@ int mga_dev_wfa(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob
 /* register-resident tiers (k_wfa_r.hip): tier 0-2 one wave per problem (64, 128, 192 diagonals), 3-6 two to sixteen waves (256, 512, 1024, 2048) */
 int mga_dev_wfa_reg(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 					mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier, mga_wfa_retry_t rt);
+/* windowed tiers (k_wfa_w.hip): forward pass of tier wt (0..5) over d_list; traceback bytes go to d_tb + item * mga_dev_wfa_win_tb_stride(wt); `slot` picks the
+ * work-queue counter / stream.  mga_dev_wfa_traceback() then turns every MGA_WFA_TB result of d_res[0..n) into score + CIGAR in the pool (MGA_WFA_OK). */
+int64_t mga_dev_wfa_win_tb_stride(int wt);
+int mga_dev_wfa_win(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+					mga_wfa_res_t *d_res, char *d_tb, int wt, int slot, mga_wfa_retry_t rt);
+int mga_dev_wfa_traceback(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq, mga_wfa_res_t *d_res,
+						  uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int *d_err);
+int32_t mga_wfw_window(int32_t W, int32_t tl, int32_t ql, int32_t *lo);
 /* tier 0..8: register tiers (one wave, then 2-16 waves per problem), then the HBM-resident tiers */
 int mga_wfa_first_tier(int32_t tl, int32_t ql); /* cheapest tier likely to fit, from the sequence lengths */
 int mga_dev_wfa_tier(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,

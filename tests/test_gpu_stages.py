@@ -139,6 +139,58 @@ def test_wfa_roundtrip_property():
         assert ti == len(t) and qi == len(q) and pen == sc[i], i
 
 
+def test_wfa_windowed_tiers_edge_shapes(ora):
+    """the windowed tiers (k_wfa_w.hip: 16 / 32 / 64 / 128 / 192 / 256 diagonals, several problems per wavefront in the narrow ones) are exact only
+    below the bound of their window: single gaps of every length around each half-width (the alignment hugs the window's edge, one base further and
+    the problem must give up and climb), the same with noise, matrices narrower than the window, end diagonals far from 0 (the window is centred
+    between 0 and ql - tl), sequences longer than a tier's LDS staging, scores around 256 (the last windowed score), N bases"""
+    rng = np.random.default_rng(41)
+    T, Q = [], []
+    for L in (12, 30, 60, 70, 72, 100, 111, 112, 128, 129, 167, 168, 192, 193, 255, 256, 257, 343, 344, 384, 385, 512, 513, 700):
+        t = rand_seq(rng, L)
+        for g in (1, 2, 6, 7, 8, 9, 10, 14, 15, 16, 17, 18, 30, 31, 32, 33, 34, 62, 63, 64, 65, 66, 94, 95, 96, 97, 98, 126, 127, 128, 129, 130, 160, 190, 222, 250):
+            if g >= L:
+                continue
+            cut = int(rng.integers(0, L - g + 1))
+            T.append(t); Q.append(t[:cut] + t[cut + g:])
+            T.append(t[:cut] + t[cut + g:]); Q.append(t)
+            m = mutate(rng, t, 0.08)
+            c2 = min(cut, max(0, len(m) - g))
+            T.append(t); Q.append(m[:c2] + m[c2 + g:] if len(m) > g else m)
+        for short in (1, 2, 5, 15, 16, 17, 31, 33):
+            T.append(rand_seq(rng, short)); Q.append(t)
+            T.append(t); Q.append(rand_seq(rng, short))
+            T.append(rand_seq(rng, short)); Q.append(rand_seq(rng, short))
+        for err in (0.02, 0.1, 0.2, 0.3, 0.45):
+            T.append(t); Q.append(mutate(rng, t, err) or b"A")
+        T.append(t.replace(b"A", b"N", 3)); Q.append(mutate(rng, t, 0.1).replace(b"C", b"N", 2) or b"N")
+    sc, cg = mga.wfa_batch(T, Q)
+    for i in range(len(T)):
+        es, ec = ora.wfa(T[i], Q[i])
+        assert es == sc[i], (i, len(T[i]), len(Q[i]), es, sc[i])
+        assert np.array_equal(ec, cg[i]), (i, len(T[i]), len(Q[i]), es)
+
+
+def test_wfa_windowed_tiers_many_problems(ora):
+    """a launch the size of a small chunk with the bench workload's shape (gap lengths 1..400, 10 % errors): every group of every wavefront is refilled
+    many times, the queue runs dry at the end, problems climb from tier to tier"""
+    rng = np.random.default_rng(43)
+    T, Q = [], []
+    for it in range(30000):
+        L = int(min(400, 1 + rng.exponential(70)))
+        t = rand_seq(rng, L)
+        q = mutate(rng, t, 0.1) or b"A"
+        T.append(t); Q.append(q)
+    sc, cg = mga.wfa_batch(T, Q)
+    bad = 0
+    for i in range(len(T)):
+        es, ec = ora.wfa(T[i], Q[i])
+        if es != sc[i] or not np.array_equal(ec, cg[i]):
+            bad += 1
+            assert bad < 5, (i, len(T[i]), len(Q[i]), es, sc[i])
+    assert bad == 0
+
+
 # ---------------------------------------------------------------------------------------------
 # seeds + linear chaining against a real (synthetic) graph
 # ---------------------------------------------------------------------------------------------
