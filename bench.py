@@ -238,6 +238,9 @@ def main():
             mga.get_stats(G, reset=True)
             mga.prof_enable(True)
             mga.prof_get(reset=True)
+            L.mga_wfa_ladder_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+            _z = (ctypes.c_int64 * 32)()
+            L.mga_wfa_ladder_stats(_z, ctypes.byref(_z, 128), 1)
             t0 = time.perf_counter()
             m = mga.map_files_idx(G, [reads_path], n_threads=threads, rank=0, world=world)
             torch.cuda.synchronize()
@@ -246,8 +249,12 @@ def main():
             del os.environ["MGA_PIPE"]
             L.mga_idx_stream_close(G.gi)
             prof, sti = mga.prof_get(), mga.get_stats(G)
+            import numpy as np
+            ln, lu = np.zeros(16, dtype=np.int64), np.zeros(16, dtype=np.int64)
+            L.mga_wfa_ladder_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+            L.mga_wfa_ladder_stats(ln.ctypes.data, lu.ctypes.data, 0)
             mga.prof_enable(False)
-            isolated = dict(ms=dti * 1e3, prof=prof, st=sti)
+            isolated = dict(ms=dti * 1e3, prof=prof, st=sti, ladder=dict(launched=[int(x) for x in ln[:11]], arrived_from_below=[int(x) for x in lu[:11]]))
             R.close()
     if dist is not None:
         dist.barrier()
@@ -321,6 +328,7 @@ def main():
                    roofline=roof if roof else roof_path, roofline_path=roof_path,
                    resident=resident,
                    kernels_ms_isolated=kernels_ms,
+                   wfa_ladder_isolated=(isolated or {}).get("ladder"),
                    per_read=dict(n_mz=agg["n_mz"] / max(1, total_reads * args.steps), n_hit=agg["n_hit"] / max(1, total_reads * args.steps),
                                  n_wfa=st["n_wfa"] / max(1, st["n_reads"]), wfa_cells=st["wfa_cells"] / max(1, st["n_reads"]),
                                  gaf_bytes=agg["gaf_bytes"] / max(1, total_reads * args.steps)),

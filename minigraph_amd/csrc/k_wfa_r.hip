@@ -20,6 +20,7 @@
 #include <type_traits>
 #include "mga_dev.h"
 #include "dev_common.h"
+#include "wfa_window.h"
 
 #define WF_NEG_INF (-0x40000000)
 
@@ -98,10 +99,13 @@ __global__ void __launch_bounds__(64 * NW) k_wfa_r(int n_items, const int32_t *_
 
 		if (tl > SEQCAP || ql > SEQCAP) status = MGA_WFA_RETRY_TIER;
 		else {
-			// window of NV diagonals, centred on 0 unless the matrix is narrower on one side
-			int32_t D0 = -(NV / 2);
-			if (-tl > D0) D0 = -tl;
-			else if (ql < D0 + NV - 1) { D0 = ql - NV + 1; if (D0 < -tl) D0 = -tl; }
+			// Window of NV diagonals, centred between the start diagonal 0 and the end diagonal ql - tl (round 3, k_wfa_w.hip has the argument): the band follows
+			// the reference's [wlo - 1, whi + 1] -- reachable edges, trimming every 256 scores -- but is CLIPPED to the window instead of leaving the tier when
+			// it reaches the window's edge.  Clipped cells read NEG_INF: every value here is <= the reference's and equal on every cell of an optimal path as long
+			// as the score stays below the window's bound BND (no optimal path can touch a diagonal outside); at BND the problem gives up and climbs.  The
+			// round-2 tiers gave up when the BAND (2 s + 1 diagonals at score s) left the window, i.e. at half the score.
+			int32_t D0;
+			const int32_t BND = wfw_window(NV, tl, ql, &D0, 0x3fffffff);
 			const int32_t W0 = D0 + 64 * J * wv; // first diagonal of this wave
 			{ // stage the sequences; 16 bytes of padding so that the 8-byte compares may overrun
 				const char *ts = tseq + pb.t_off, *qs = qseq + pb.q_off;
@@ -186,10 +190,10 @@ __global__ void __launch_bounds__(64 * NW) k_wfa_r(int n_items, const int32_t *_
 				if (NW == 1 && term) return false;
 				// ---- slice s+1 (miniwfa.c:281-325,412-415).  With NW > 1 it is computed speculatively: the terminating
 				// wave cannot tell the others before the barrier.
-				const int32_t nlo = wlo > -tl ? wlo - 1 : -tl;
-				const int32_t nhi = whi < ql ? whi + 1 : ql;
+				const int32_t nlo = max(wlo > -tl ? wlo - 1 : -tl, D0);
+				const int32_t nhi = min(whi < ql ? whi + 1 : ql, D0 + NV - 1);
 				const int32_t width = nhi - nlo + 1;
-				const bool fits = !(nlo < D0 || nhi > D0 + NV - 1 || s + 1 > SMAX || tb_used + width > tbcap);
+				const bool fits = !(s + 1 >= BND || s + 1 > SMAX || tb_used + width > tbcap);
 				if (NW == 1 && !fits) { status = MGA_WFA_RETRY_TIER; return false; }
 				bool reach_lo = false, reach_hi = false; // uniform
 				if (fits) {

@@ -32,8 +32,9 @@ struct wfs_rung_t { int kind, idx, maxlen, next; };
 struct wfs_ladder_t { int n; wfs_rung_t r[MGA_WFA_N_SLOT]; };
 struct wfs_thr_t { int32_t n, t[MGA_WFA_N_SLOT]; };
 static const wfs_ladder_t g_ladder_win = { 11, {
-	{ 0, 0, 71, 1 }, { 0, 1, 111, 2 }, { 0, 2, 167, 3 }, { 0, 3, 255, 4 }, { 0, 4, 343, 5 }, { 0, 5, 512, 7 }, // (W5 stops at score 256: the 512-diagonal band would stop there too)
-	{ 1, 4, 1024, 7 }, { 1, 5, 2048, 8 }, { 1, 6, 4096, 9 }, { 1, 7, 0x7fffffff, 10 }, { 1, 8, 0x7fffffff, -1 } } };
+	{ 0, 0, 71, 1 }, { 0, 1, 111, 2 }, { 0, 2, 167, 3 }, { 0, 3, 255, 4 }, { 0, 4, 343, 5 }, { 0, 5, 420, 6 },
+	// the register tiers are windowed too (their band is the reference's, trimming included, clipped to the window): 512 diagonals decide scores < 542, ...
+	{ 1, 4, 780, 7 }, { 1, 5, 1500, 8 }, { 1, 6, 3000, 9 }, { 1, 7, 0x7fffffff, 10 }, { 1, 8, 0x7fffffff, -1 } } };
 static const wfs_ladder_t g_ladder_old = { 9, {
 	{ 1, 0, 64, 1 }, { 1, 1, 128, 2 }, { 1, 2, 192, 3 }, { 1, 3, 256, 4 }, { 1, 4, 512, 5 }, { 1, 5, 2048, 6 }, { 1, 6, 4096, 7 }, { 1, 7, 0x7fffffff, 8 }, { 1, 8, 0x7fffffff, -1 } } };
 
@@ -285,6 +286,16 @@ done:
 	return ret;
 }
 
+// problems launched / given up per rung since the last reset (bench.py, DESIGN.md: where the gaps are decided)
+static long long g_rung_n[MGA_WFA_MAX_TIER], g_rung_up[MGA_WFA_MAX_TIER];
+extern "C" void mga_wfa_ladder_stats(int64_t *launched, int64_t *given_up, int reset)
+{
+	for (int t = 0; t < MGA_WFA_MAX_TIER; ++t) {
+		launched[t] = __atomic_load_n(&g_rung_n[t], __ATOMIC_RELAXED), given_up[t] = __atomic_load_n(&g_rung_up[t], __ATOMIC_RELAXED);
+		if (reset) __atomic_store_n(&g_rung_n[t], 0, __ATOMIC_RELAXED), __atomic_store_n(&g_rung_up[t], 0, __ATOMIC_RELAXED);
+	}
+}
+
 extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 								 mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int64_t *cells,
 								 void (*bulk_done)(void*), void *bulk_arg)
@@ -370,6 +381,10 @@ extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_
 		}
 		if (herr) { mga_set_error("WFA: %d problems failed (CIGAR pool of %ld ops exhausted, or iteration cap)", herr, (long)pool_cap); return -1; }
 		if (hr[15] > 0) { mga_set_error("%d WFA problems exceed the largest capacity tier", hr[15]); return -1; }
+		if (!sc->wfa_uncapped) for (int t = 0; t < NR; ++t) {
+			if (cnt[t] > 0) __atomic_fetch_add(&g_rung_n[t], (long long)cnt[t], __ATOMIC_RELAXED);
+			if (hr[t] > 0) __atomic_fetch_add(&g_rung_up[t], (long long)hr[t], __ATOMIC_RELAXED); // (arrivals AT rung t)
+		}
 		for (int u = 0; u < NS; ++u) cnt[u] = u < NR ? hr[u] : 0, off[u] = nstart[u], left += cnt[u];
 		if (left == 0) break;
 	}

@@ -33,34 +33,11 @@
 #include <type_traits>
 #include "mga_dev.h"
 #include "dev_common.h"
+#include "wfa_window.h"
 
 #define WF_NEG_INF (-0x40000000)
-#define WFW_SMAX 256 // the windowed tiers decide scores < 256 only (see above)
 
-__host__ __device__ __forceinline__ int32_t wfw_gap(int32_t n) // cheapest way to move n diagonals (penalties 4 / 4,2 / 15,1: miniwfa.c:11-18)
-{
-	if (n < 0) n = -n;
-	if (n == 0) return 0;
-	const int32_t a = 4 + 2 * n, b = 15 + n;
-	return a < b ? a : b;
-}
-
-// window of W diagonals for a tl x ql problem, centred between diagonal 0 and the end diagonal ql - tl, clipped to the matrix's [-tl, ql];
-// returns the bound B (capped at WFW_SMAX): an alignment inside [*lo, *lo + W - 1] that scores < B is THE alignment
-__host__ __device__ __forceinline__ int32_t wfw_window(int32_t W, int32_t tl, int32_t ql, int32_t *lo_)
-{
-	const int32_t e = ql - tl, c = e / 2;
-	int32_t lo = c - W / 2, hi;
-	if (lo < -tl) lo = -tl;
-	hi = lo + W - 1;
-	if (hi > ql) { hi = ql; lo = hi - W + 1; if (lo < -tl) lo = -tl; }
-	*lo_ = lo;
-	const int32_t blo = lo - 1 >= -tl ? wfw_gap(lo - 1) + wfw_gap(e - (lo - 1)) : WFW_SMAX;
-	const int32_t bhi = hi + 1 <= ql ? wfw_gap(hi + 1) + wfw_gap(hi + 1 - e) : WFW_SMAX;
-	const int32_t b = blo < bhi ? blo : bhi;
-	return b < WFW_SMAX ? b : WFW_SMAX;
-}
-extern "C" int32_t mga_wfw_window(int32_t W, int32_t tl, int32_t ql, int32_t *lo) { return wfw_window(W, tl, ql, lo); } // (tests)
+extern "C" int32_t mga_wfw_window(int32_t W, int32_t tl, int32_t ql, int32_t *lo) { return wfw_window(W, tl, ql, lo, WFW_SMAX); } // (tests)
 
 // furthest diagonal any path of score <= s can have reached: max n with wfw_gap(n) <= s
 __device__ __forceinline__ int32_t wfw_reach(int32_t s) { return s < 6 ? 0 : max((s - 4) >> 1, s - 15); }
@@ -88,7 +65,7 @@ template<int G> __device__ __forceinline__ int32_t wfw_from_right(int32_t edge, 
 enum { WFW_IDLE = 0, WFW_RUN = 1, WFW_DONE = 2, WFW_BAIL = 3 };
 
 template<int G, int J, int SEQCAP>
-__global__ void __launch_bounds__(64) k_wfa_fw(int n_items, const int32_t *__restrict__ list, const mga_wfa_prob_t *__restrict__ prob,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 ? 6 : 1, 8))) k_wfa_fw(int n_items, const int32_t *__restrict__ list, const mga_wfa_prob_t *__restrict__ prob,
 											  const char *__restrict__ tseq, const char *__restrict__ qseq, mga_wfa_res_t *__restrict__ res,
 											  char *__restrict__ tb, long long tb_stride, int *__restrict__ counter, mga_wfa_retry_t rt)
 {
@@ -97,6 +74,8 @@ __global__ void __launch_bounds__(64) k_wfa_fw(int n_items, const int32_t *__res
 	constexpr int P = 64 / G;      // problems per wavefront
 	constexpr int W = G * J;       // diagonals of the window = dwords per traceback row
 	constexpr int SEQS = SEQCAP + 16;
+	constexpr int QCH = P == 4 ? 32 : P == 2 ? 16 : J == 1 ? 4 : J == 2 ? 2 : 1; // items drawn from the queue at a time: many where problems are small and millions, one where each is
+	                                                                           // hundreds of steps (a list is sorted longest first: eight in a row to ONE wavefront is a long tail)
 	__shared__ __attribute__((aligned(16))) uint8_t Tb[P][4 * SEQS], Qb[P][4 * SEQS];
 	const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
 	uint8_t *const Tg = Tb[grp], *const Qg = Qb[grp];
@@ -108,10 +87,13 @@ __global__ void __launch_bounds__(64) k_wfa_fw(int n_items, const int32_t *__res
 	int32_t okv[J];               // all ones where this lane's diagonal exists in the matrix (-tl <= d <= ql)
 	uint32_t acc[J];              // traceback bytes of the last (up to) four steps
 	uint32_t *tbp = 0;            // this lane's dword in the current traceback row (slot j: + 64 j)
-	char *region = 0;
+	int32_t it_cur = 0;           // the problem's place in the work list = its traceback region
 	int32_t H[J][18], E1[J][3], F1[J][3], E2[J][2], F2[J][2];
 	int32_t t = 0;                // steps this wavefront has made (all groups advance together)
-	bool q_empty = false;
+	int32_t q_next = 0, q_end = 0, q_base = 0; // the wavefront's reservoir of items; lane l holds the descriptor of item q_base + l
+	__shared__ int32_t dsc_pi[QCH];
+	__shared__ mga_wfa_prob_t dsc_pb[QCH]; // (descriptors of the reservoir's items, in LDS: seven VGPRs fewer than one per lane)
+	bool q_empty = false, q_drained = false;
 #pragma unroll
 	for (int j = 0; j < J; ++j) {
 		okv[j] = 0, acc[j] = 0;
@@ -141,7 +123,7 @@ __global__ void __launch_bounds__(64) k_wfa_fw(int n_items, const int32_t *__res
 					}
 					if (st == WFW_DONE) {
 						mga_wfa_res_t r;
-						r.score = s, r.n_cigar = 0, r.cig_off = (int64_t)(uintptr_t)region, r.status = MGA_WFA_TB, r.pad = lst | ph << 4 | W << 8, r.n_iter = 0;
+						r.score = s, r.n_cigar = 0, r.cig_off = (int64_t)(uintptr_t)(tb + (long long)it_cur * tb_stride), r.status = MGA_WFA_TB, r.pad = lst | ph << 4 | W << 8, r.n_iter = 0;
 						res[pi] = r;
 					}
 				} else if (gl == 0) {
@@ -155,23 +137,39 @@ __global__ void __launch_bounds__(64) k_wfa_fw(int n_items, const int32_t *__res
 			if (!q_empty) {
 				const uint64_t m_idle = __ballot(st == WFW_IDLE && gl == 0);
 				if (m_idle) {
-					int32_t base = 0;
-					if (lane == 0) base = atomicAdd(counter, (int)__popcll(m_idle));
-					base = __builtin_amdgcn_readfirstlane(base);
-					const int32_t item = base + (int32_t)__popcll(m_idle & ((1ULL << (grp * G)) - 1ULL));
-					const bool fill = st == WFW_IDLE && item < n_items;
-					if (__ballot(st == WFW_IDLE && item >= n_items)) q_empty = true;
+					// The wavefront draws QCH items at a time from the launch's queue (ONE atomic: a counter bumped per problem by 7 000 resident waves was the
+					// whole cost of the 16-lane tier, [measured] 13 ns per problem = the rate one address takes atomics at) and reads their descriptors at once,
+					// one per lane; a refill then costs no dependent global round trip but the sequence bytes.
+					if (q_next == q_end && !q_drained) {
+						int32_t b = 0;
+						if (lane == 0) b = atomicAdd(counter, QCH);
+						b = __builtin_amdgcn_readfirstlane(b);
+						q_base = q_next = b, q_end = b + QCH < n_items ? b + QCH : n_items;
+						if (q_end <= q_next) q_end = q_next, q_drained = true;
+						if (lane < q_end - q_next) {
+							const int32_t p_ = list ? list[b + lane] : b + lane;
+							dsc_pi[lane] = p_;
+							dsc_pb[lane] = prob[p_];
+						}
+						WFW_LDS_FENCE();
+					}
+					const int32_t avail = q_end - q_next, n_idle = (int32_t)__popcll(m_idle);
+					const int32_t rank = (int32_t)__popcll(m_idle & ((1ULL << (grp * G)) - 1ULL));
+					const bool fill = st == WFW_IDLE && rank < avail;
+					const int32_t item = q_next + rank, src = fill ? item - q_base : 0;
+					q_next += n_idle < avail ? n_idle : avail;
+					if (q_drained && q_next == q_end) q_empty = true;
 					int32_t ntl = 0, nql = 0;
 					const char *ts = tseq, *qs = qseq;
 					if (fill) {
-						pi = list ? list[item] : item;
-						const mga_wfa_prob_t pb = prob[pi];
+						const mga_wfa_prob_t pb = dsc_pb[src];
+						pi = dsc_pi[src];
 						ntl = pb.tl, nql = pb.ql, ts = tseq + pb.t_off, qs = qseq + pb.q_off;
-						region = tb + (long long)item * tb_stride;
-						tbp = (uint32_t*)region + gl;
+						it_cur = item;
+						tbp = (uint32_t*)(tb + (long long)item * tb_stride) + gl;
 						ph = t & 3, s = 0, lst = 0, e = nql - ntl;
 						if (ntl > SEQCAP || nql > SEQCAP) bnd = 0, ntl = nql = 0; // too long for this tier's LDS: gives up at once
-						else { bnd = wfw_window(W, ntl, nql, &lo); if (bnd > W + 30) bnd = W + 30; } // (W + 30 bounds every window's B; the traceback rows are sized for it)
+						else { bnd = wfw_window(W, ntl, nql, &lo, WFW_SMAX); if (bnd > W + 30) bnd = W + 30; } // (W + 30 bounds every window's B; the traceback rows are sized for it)
 						tl = ntl, ql = nql;
 						st = WFW_RUN;
 					}
@@ -381,7 +379,7 @@ __global__ void __launch_bounds__(256) k_wfa_tb(int n, const mga_wfa_prob_t *__r
 	const char *ts = tseq + pb.t_off, *qs = qseq + pb.q_off;
 	int32_t lo = 0, n_cig = 0;
 	if (mine) {
-		(void)wfw_window(W, pb.tl, pb.ql, &lo);
+		(void)wfw_window(W, pb.tl, pb.ql, &lo, WFW_SMAX);
 		n_cig = wfw_trace<false>(pb.tl, pb.ql, ts, qs, r.score, last, reg, W, ph, lo, 0, 0);
 	}
 	// one reservation per wavefront

@@ -1,0 +1,65 @@
+// valu_rate.hip -- measurement aid: how fast does ONE SIMD of gfx950 issue the integer vector instructions the WFA step is made of?
+// Prints cycles per wave64 instruction for chains of independent v_max_i32 / v_add_u32 / v_cndmask / DPP moves, with 1..8 waves per SIMD.
+// (The answer prices the "valu-issue" roofline of bench.py: DESIGN.md, Measurement notes.)   hipcc --offload-arch=gfx950 -O3 valu_rate.hip -o valu_rate
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+
+template<int KIND>
+__global__ void __launch_bounds__(64) k_rate(int iters, int32_t *out, long long *cyc)
+{
+	int32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+	const int32_t b = out[0];
+	const long long t0 = clock64();
+	for (int i = 0; i < iters; ++i) {
+#pragma unroll
+		for (int u = 0; u < 8; ++u) { // 8 independent chains x 8 = 64 instructions per trip
+			if (KIND == 0) { a0 = max(a0, b); a1 = max(a1, b); a2 = max(a2, b); a3 = max(a3, b); a4 = max(a4, b); a5 = max(a5, b); a6 = max(a6, b); a7 = max(a7, b); asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)); }
+			if (KIND == 1) { a0 += b; a1 += b; a2 += b; a3 += b; a4 += b; a5 += b; a6 += b; a7 += b; asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)); }
+			if (KIND == 2) {
+				a0 = __builtin_amdgcn_update_dpp(a0, a1, 0x138, 0xf, 0xf, false); a1 = __builtin_amdgcn_update_dpp(a1, a2, 0x138, 0xf, 0xf, false);
+				a2 = __builtin_amdgcn_update_dpp(a2, a3, 0x138, 0xf, 0xf, false); a3 = __builtin_amdgcn_update_dpp(a3, a4, 0x138, 0xf, 0xf, false);
+				a4 = __builtin_amdgcn_update_dpp(a4, a5, 0x111, 0xf, 0xf, false); a5 = __builtin_amdgcn_update_dpp(a5, a6, 0x111, 0xf, 0xf, false);
+				a6 = __builtin_amdgcn_update_dpp(a6, a7, 0x111, 0xf, 0xf, false); a7 = __builtin_amdgcn_update_dpp(a7, a0, 0x111, 0xf, 0xf, false);
+			}
+			if (KIND == 3) { // compare + select pairs
+				a0 = a0 < b ? a1 : a0; a1 = a1 < b ? a2 : a1; a2 = a2 < b ? a3 : a2; a3 = a3 < b ? a4 : a3;
+				asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+			}
+		}
+	}
+	const long long t1 = clock64();
+	out[1 + blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+	if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template<int KIND> static void run(const char *name, int per_trip)
+{
+	int32_t *out; long long *cyc;
+	const int iters = 20000;
+	hipMalloc(&out, 4 * (1 + 64 * 8192)); hipMalloc(&cyc, 8 * 8192); hipMemset(out, 0, 4);
+	for (int wps = 1; wps <= 8; wps *= 2) { // waves per SIMD: 256 CUs x 4 SIMDs x wps single-wave workgroups
+		const int nb = 256 * 4 * wps;
+		hipLaunchKernelGGL(k_rate<KIND>, dim3(nb), dim3(64), 0, 0, 1000, out, cyc); hipDeviceSynchronize();
+		hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+		hipEventRecord(e0, 0);
+		hipLaunchKernelGGL(k_rate<KIND>, dim3(nb), dim3(64), 0, 0, iters, out, cyc);
+		hipEventRecord(e1, 0); hipEventSynchronize(e1);
+		float ms; hipEventElapsedTime(&ms, e0, e1);
+		long long h[8192]; hipMemcpy(h, cyc, 8 * nb, hipMemcpyDeviceToHost);
+		double mean = 0; for (int i = 0; i < nb; ++i) mean += h[i]; mean /= nb;
+		const double n_instr = (double)iters * per_trip;
+		printf("%-28s %d waves/SIMD: %.2f clock64 ticks per instruction per wave (%.1f MHz tick), wall %.3f ms -> %.2f ns per instruction per SIMD = %.2f cycles at 2.4 GHz\n",
+			   name, wps, mean / n_instr, mean / (ms * 1e3), ms, ms * 1e6 / (n_instr * wps), ms * 1e6 / (n_instr * wps) * 2.4);
+	}
+	hipFree(out); hipFree(cyc);
+}
+
+int main()
+{
+	run<0>("v_max_i32", 64);
+	run<1>("v_add_u32", 64);
+	run<2>("v_mov_b32 dpp", 64);
+	run<3>("v_cmp + v_cndmask", 64);
+	return 0;
+}
