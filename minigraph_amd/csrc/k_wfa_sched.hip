@@ -392,7 +392,7 @@ extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_
 		int herr = 0;
 		if (mga_dev_wfa_traceback(sc, n, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, ctl + O_ERR) < 0) return -1;
 		if (mga_d2h_s(sc, &herr, ctl + O_ERR, 4) < 0 || mga_ssync(sc) < 0) return -1;
-		if (herr) { mga_set_error("WFA traceback: CIGAR pool of %ld ops exhausted (%d problems)", (long)pool_cap, herr); return -1; }
+		if (herr) { mga_set_error("WFA traceback: %d problems failed (CIGAR pool of %ld ops exhausted, or a walk left its window)", herr, (long)pool_cap); return -1; }
 	}
 	{ // problems the exact pass gave up on (> 1e8 cells): miniwfa's chained fallback (miniwfa.c:829-832)
 		int n_fb = 0;

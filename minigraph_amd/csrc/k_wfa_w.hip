@@ -45,8 +45,6 @@ __device__ __forceinline__ int32_t wfw_reach(int32_t s) { return s < 6 ? 0 : max
 __device__ __forceinline__ int32_t wfw_max(int32_t a, int32_t b) { return a > b ? a : b; }
 __device__ __forceinline__ int32_t wfw_sel(int32_t mask, int32_t a, int32_t b) { return (a & mask) | (b & ~mask); } // v_bfi_b32: a where mask is all ones
 
-struct wfw_u2 { uint32_t x, y; }; // 8 bytes with 4-byte alignment: loads become ds_read2_b32
-
 // neighbour diagonals inside a group of G lanes.  from_left: lane l <- src[l-1], the group's first lane gets NEG_INF (or `edge`: the previous slot's last lane)
 template<int G> __device__ __forceinline__ int32_t wfw_from_left(int32_t edge, int32_t src, int32_t m_first)
 {
@@ -76,7 +74,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 	constexpr int SEQS = SEQCAP + 16;
 	constexpr int QCH = P == 4 ? 32 : P == 2 ? 16 : J == 1 ? 4 : J == 2 ? 2 : 1; // items drawn from the queue at a time: many where problems are small and millions, one where each is
 	                                                                           // hundreds of steps (a list is sorted longest first: eight in a row to ONE wavefront is a long tail)
-	__shared__ __attribute__((aligned(16))) uint8_t Tb[P][4 * SEQS], Qb[P][4 * SEQS];
+	constexpr int MROWS = SEQCAP / 32 + 3; // words of a lane's match mask (+ guard rows that are read, never counted)
+	// T: one copy.  Q: four copies, copy c shifted left by c bytes (position p of copy c, stored at c SEQS + 4 + p, is Q[p + c]), so that the four query bytes
+	// opposite ANY target dword are one aligned dword read.
+	__shared__ __attribute__((aligned(16))) uint8_t Tb[P][SEQS], Qb[P][4 * SEQS];
+	// Match masks: bit b of Mk[w][64 j + lane] says T[32 w + b] == Q[d + 32 w + b] for the diagonal d of (slot j, lane) -- built once per problem (a lane keeps its
+	// diagonal for the problem's life); extending a cell is then a count of trailing ones in a 32-bit window of the mask instead of a loop of byte compares
+	// ([measured] the compare loop was ~60 of ~165 vector instructions of a step).  A row is 64 J dwords: lane l always hits bank l, whatever its word.
+	__shared__ uint32_t Mk[MROWS][64 * J];
 	const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
 	uint8_t *const Tg = Tb[grp], *const Qg = Qb[grp];
 	const int32_t m_first = gl == 0 ? -1 : 0, m_last = gl == G - 1 ? -1 : 0;
@@ -173,26 +178,47 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 						tl = ntl, ql = nql;
 						st = WFW_RUN;
 					}
-					// stage the sequences of the refilled groups; 16 bytes of padding so that the 8-byte compares may overrun
+					// stage the sequences of the refilled groups, a dword per lane and trip (the sequence buffers are padded: reading a few bytes past an end is fine,
+					// and what lies beyond tl / ql never reaches a mask)
 					WFW_LDS_FENCE(); // (the previous problem's reads of these LDS bytes are complete: same wave, in order)
-					for (int32_t i0 = 0; __ballot(fill && i0 < ntl + 16); i0 += G) {
-						const int32_t i = i0 + gl;
-						if (fill && i < ntl + 16) {
-							const uint8_t c = i < ntl ? (uint8_t)ts[i] : (uint8_t)0;
-							Tg[i] = c;
-							if (i >= 1) Tg[SEQS + i - 1] = c;
-							if (i >= 2) Tg[2 * SEQS + i - 2] = c;
-							if (i >= 3) Tg[3 * SEQS + i - 3] = c;
+					for (int32_t m0 = 0; __ballot(fill && 4 * m0 < ntl); m0 += G) {
+						const int32_t m = m0 + gl;
+						if (fill && 4 * m < ntl) { uint32_t v; __builtin_memcpy(&v, ts + 4 * m, 4); *(uint32_t*)(Tg + 4 * m) = v; }
+					}
+					for (int32_t m0 = 0; __ballot(fill && 4 * m0 < nql); m0 += G) {
+						const int32_t m = m0 + gl;
+						if (fill && 4 * m < nql) {
+#pragma unroll
+							for (int c = 0; c < 4; ++c) {
+								uint32_t v;
+								__builtin_memcpy(&v, qs + 4 * m + c, 4);
+								*(uint32_t*)(Qg + c * SEQS + 4 + 4 * m) = v;
+								// position -4..-1 of copy c: the c first bases at its top (a target dword opposite query positions -3..0 sees Q[0] there; what lies before is masked)
+								if (m == 0 && c > 0) { uint32_t v0; __builtin_memcpy(&v0, qs, 4); *(uint32_t*)(Qg + c * SEQS) = v0 << (8 * (4 - c)); }
+							}
 						}
 					}
-					for (int32_t i0 = 0; __ballot(fill && i0 < nql + 16); i0 += G) {
-						const int32_t i = i0 + gl;
-						if (fill && i < nql + 16) {
-							const uint8_t c = i < nql ? (uint8_t)qs[i] : (uint8_t)1;
-							Qg[i] = c;
-							if (i >= 1) Qg[SEQS + i - 1] = c;
-							if (i >= 2) Qg[2 * SEQS + i - 2] = c;
-							if (i >= 3) Qg[3 * SEQS + i - 3] = c;
+					WFW_LDS_FENCE();
+					// match masks of the refilled groups' diagonals, 32 target positions per word, four per compare block (SDWA byte compares, the carry shifts the bit in)
+#pragma unroll
+					for (int j = 0; j < J; ++j) {
+						const int32_t d = lo + gl + 64 * j;
+						const int32_t kmin = d < 0 ? -d : 0, kmax = min(ntl, nql - d); // positions with 0 <= d + k < ql
+						const uint8_t *qc = Qg + (d & 3) * SEQS + 4 + (d & ~3);         // query dword opposite target dword 0 (each copy has a 4-byte front pad; further out: masked below)
+						for (int32_t w = 0; __ballot(fill && w <= (ntl >> 5)); ++w) {  // (one word beyond the last base: bit tl is a built, cleared bit -- a run stops there)
+							uint32_t bits = 0;
+#pragma unroll
+							for (int q8 = 7; q8 >= 0; --q8) {
+								const uint32_t t4 = *(const uint32_t*)(Tg + 32 * w + 4 * q8), q4 = *(const uint32_t*)(qc + 32 * w + 4 * q8);
+								asm volatile("v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_3 src1_sel:BYTE_3\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+											 "v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_2 src1_sel:BYTE_2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+											 "v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_1 src1_sel:BYTE_1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+											 "v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_0 src1_sel:BYTE_0\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+											 : "+v"(bits) : "v"(t4), "v"(q4) : "vcc");
+							}
+							const int32_t b_lo = kmin - 32 * w, b_hi = kmax - 32 * w; // valid bits of this word: [b_lo, b_hi)
+							const uint32_t m_hi = b_hi >= 32 ? ~0u : b_hi <= 0 ? 0u : (1u << b_hi) - 1u, m_lo = b_lo <= 0 ? ~0u : b_lo >= 32 ? 0u : ~0u << b_lo;
+							if (fill && w <= (ntl >> 5)) Mk[w][64 * j + lane] = bits & m_hi & m_lo;
 						}
 					}
 					WFW_LDS_FENCE();
@@ -222,25 +248,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 		for (int j = 0; j < J; ++j) {
 			const int32_t d = lo + gl + 64 * j;
 			if (J > 1) { const int32_t b0 = __builtin_amdgcn_readfirstlane(lo) + 64 * j; if (b0 > rs || b0 + 63 < -rs) continue; } // no diagonal of the slot is reachable yet
-			const int32_t k0 = HA(j, 0), i0 = d + k0;
-			const bool val = st == WFW_RUN && (uint32_t)(k0 + 1) <= (uint32_t)tl && (uint32_t)(i0 + 1) <= (uint32_t)ql; // -1 <= k0 < tl, -1 <= i0 < ql
-			const int32_t tp = val ? k0 + 1 : 0, qp = val ? i0 + 1 : 0;
-			const int32_t room = min(tl - tp, ql - qp);
-			const wfw_u2 *tw = (const wfw_u2*)(Tg + (tp & 3) * SEQS + (tp & ~3)), *qw = (const wfw_u2*)(Qg + (qp & 3) * SEQS + (qp & ~3)); // 4-byte aligned
-			int32_t n = 0, m8 = 0; // m8: matched blocks of 8 bases
-			bool act = val && room > 0;
-			while (__ballot(act)) { // uniform loop, no divergent branch inside: finished lanes reload their last block and add nothing
-				const wfw_u2 a = tw[m8], b = qw[m8];
-				const uint32_t c0 = a.x ^ b.x, c1 = a.y ^ b.y;
-				const int32_t e0 = (int32_t)((c0 ? (uint32_t)__builtin_ctz(c0) : 32u) >> 3), e1 = (int32_t)((c1 ? (uint32_t)__builtin_ctz(c1) : 32u) >> 3);
-				const int32_t adv = e0 < 4 ? e0 : 4 + e1; // equal leading bytes of the block: 0..8
-				n += act ? adv : 0;
-				m8 += (act && adv == 8) ? 1 : 0;
-				act = act && adv == 8 && n < room;
+			const int32_t k0 = HA(j, 0), tp = k0 + 1;
+			const bool val = st == WFW_RUN && (uint32_t)tp <= (uint32_t)tl; // -1 <= k0 < tl (a cell before the query's start or beyond its end has no set bit to count)
+			const int32_t wi = val ? tp >> 5 : 0, sh = tp & 31;
+			const uint32_t *mp = &Mk[wi][64 * j + lane];
+			uint32_t inv = ~__builtin_amdgcn_alignbit(mp[64 * J], mp[0], sh); // ones of the mask from position tp on, as zeros
+			int32_t n = inv ? (int32_t)__builtin_ctz(inv) : 32;
+			bool more = val && inv == 0;
+			for (int32_t wj = wi + 1; __ballot(more); ++wj) { // a run of 32 or more matches (3 % of the steps of a 10 %-error read): next window
+				const uint32_t *mq = &Mk[wj < MROWS - 2 ? wj : MROWS - 2][64 * j + lane];
+				inv = ~__builtin_amdgcn_alignbit(mq[64 * J], mq[0], sh);
+				n += more ? (inv ? (int32_t)__builtin_ctz(inv) : 32) : 0;
+				more = more && inv == 0;
 			}
-			n = min(n, room);
-			const int32_t k = k0 + n;
-			HA(j, 0) = val ? k : k0;
+			const int32_t k = val ? k0 + n : k0;
+			HA(j, 0) = k;
 			if (val && d == e && k == tl - 1) { // the end cell (then d + k == ql - 1)
 				st = WFW_DONE;
 				lst = n == 0 ? (int32_t)(acc[j] & 7u) : 0; // it was entered by a gap state and not extended: the traceback starts in that state (miniwfa.c:406-407)
@@ -345,6 +367,7 @@ run_done:
 			if (run > 0) PUSH(7, run);
 			if (i < 0 || k < 0) break;
 		}
+		if ((uint32_t)((i - k) - lo) >= (uint32_t)W || sc <= 0) return -1; // cannot happen: the walk stays on cells the forward pass computed (fail loudly, never walk out of the region)
 		const uint32_t x = wfw_tb_byte(reg, W, ph, sc, (i - k) - lo);
 		const int32_t state = last == 0 ? (int32_t)(x & 7) : last;
 		const int32_t ext = state > 0 ? (int32_t)(x >> (state + 2) & 1) : 0;
@@ -383,7 +406,7 @@ __global__ void __launch_bounds__(256) k_wfa_tb(int n, const mga_wfa_prob_t *__r
 		n_cig = wfw_trace<false>(pb.tl, pb.ql, ts, qs, r.score, last, reg, W, ph, lo, 0, 0);
 	}
 	// one reservation per wavefront
-	int32_t incl = n_cig;
+	int32_t incl = n_cig > 0 ? n_cig : 0;
 #pragma unroll
 	for (int d = 1; d < 64; d <<= 1) { const int32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
 	const int32_t tot = __shfl(incl, 63);
@@ -391,7 +414,7 @@ __global__ void __launch_bounds__(256) k_wfa_tb(int n, const mga_wfa_prob_t *__r
 	if (lane == 63 && tot > 0) base = atomicAdd(pool_used, (unsigned long long)tot);
 	base = __shfl(base, 63);
 	if (!mine) return;
-	if ((long long)(base + (unsigned long long)tot) > pool_cap) {
+	if (n_cig < 0 || (long long)(base + (unsigned long long)tot) > pool_cap) {
 		r.status = MGA_WFA_POOL_FULL, r.score = -1, r.n_cigar = 0, r.cig_off = 0;
 		res[i] = r;
 		atomicAdd(err, 1);
@@ -442,7 +465,7 @@ extern "C" int mga_dev_wfa_win(mga_sctx_t *sc, int n, const int32_t *d_list, con
 	else if (wt == 1) LAUNCH(32, 1, 192);
 	else if (wt == 2) LAUNCH(64, 1, 256);
 	else if (wt == 3) LAUNCH(64, 2, 384);
-	else if (wt == 4) LAUNCH(64, 3, 512);
+	else if (wt == 4) LAUNCH(64, 3, 384);
 	else LAUNCH(64, 4, 512);
 #undef LAUNCH
 	mga_prof_end(st, MGA_K_WFAW0 + wt);
