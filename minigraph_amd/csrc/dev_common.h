@@ -29,6 +29,9 @@ __device__ __forceinline__ void mga_wave_sync(void)
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// a WFA problem that gives up goes to the next rung's work list (mga_wfa_retry_t); beyond the list's room only the count moves on (the host then sweeps again)
+#define mga_wfa_give_up(rt_, pi_) do { const int k_ = atomicAdd((rt_).cnt, 1); if (k_ < (rt_).cap) (rt_).list[k_] = (pi_); } while (0)
+
 __device__ __forceinline__ int32_t mga_wave_bcast_i32(int32_t v, int src) { return __shfl(v, src); }
 __device__ __forceinline__ int64_t mga_wave_bcast_i64(int64_t v, int src) { return __shfl(v, src); }
 

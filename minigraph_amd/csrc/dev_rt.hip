@@ -101,7 +101,7 @@ extern "C" void mga_sctx_destroy(mga_sctx_t *sc)
 	for (int i = 0; i < 8; ++i) mga_dbuf_free(&sc->wfa_tbuf[i]);
 	mga_dbuf_free(&sc->wfa_cnt);
 	mga_dbuf_free(&sc->scan_tmp); mga_dbuf_free(&sc->txt_cnt); mga_dbuf_free(&sc->txt_off); mga_dbuf_free(&sc->txt_vwb); mga_dbuf_free(&sc->txt_el);
-	mga_dbuf_free(&sc->wfa_list[0]); mga_dbuf_free(&sc->wfa_list[1]); mga_dbuf_free(&sc->wfa_key); mga_dbuf_free(&sc->wfa_ctl);
+	mga_dbuf_free(&sc->wfa_list[0]); mga_dbuf_free(&sc->wfa_list[1]); mga_dbuf_free(&sc->wfa_key); mga_dbuf_free(&sc->wfa_ctl); mga_dbuf_free(&sc->wfa_fb);
 	mga_dbuf_free(&sc->fb_prob); mga_dbuf_free(&sc->fb_res);
 	mga_dbuf_free(&sc->gc_arena[0]); mga_dbuf_free(&sc->gc_arena[1]);
 	for (int i = 0; i < MGA_WFA_MAX_TIER; ++i) { (void)hipStreamDestroy((hipStream_t)sc->tier_stream[i]); (void)hipEventDestroy((hipEvent_t)sc->ev_done[i]); }
@@ -114,7 +114,7 @@ extern "C" void mga_sctx_destroy(mga_sctx_t *sc)
 // The tiers of one chunk run one after another on the context's stream: [measured] 1.95 vs 1.85 Gbp/s against running them
 // concurrently on their own streams -- co-resident tiers halve each other's occupancy, while the tails of the wide tiers are
 // filled by the kernels of the OTHER chunks in the pipeline anyway.  MGA_WFA_CONCURRENT=1 brings the per-tier streams back.
-static int wfa_serial(void) { static int v = -1; if (v < 0) { const char *e = getenv("MGA_WFA_CONCURRENT"); v = !(e && atoi(e) > 0); } return v; }
+static int wfa_serial(void) { return 1; } // (round 3: a sweep of the ladder is one chain of launches -- a rung reads what the rungs before it appended)
 extern "C" int mga_wfa_tiers_serial(void) { return wfa_serial(); }
 extern "C" void *mga_wfa_stream(mga_sctx_t *sc, int slot) { return wfa_serial() ? sc->stream : sc->tier_stream[slot % MGA_WFA_MAX_TIER]; }
 

@@ -75,7 +75,7 @@ __device__ __forceinline__ int32_t wfa_lcp(const char *a, const char *b, int32_t
 	return n < maxlen ? n : maxlen;
 }
 
-__global__ void __launch_bounds__(64) k_wfa(int n_items, const int32_t *__restrict__ list,
+__global__ void __launch_bounds__(64) k_wfa(const int *__restrict__ n_items_p, int cap, const int32_t *__restrict__ list,
 											const mga_wfa_prob_t *__restrict__ prob, const char *__restrict__ tseq, const char *__restrict__ qseq,
 											mga_wfa_res_t *__restrict__ res, uint32_t *__restrict__ pool, long long pool_cap, unsigned long long *pool_used,
 											char *__restrict__ ws_base, int *__restrict__ counter, mga_wfa_retry_t rt, wfa_cfg_t cfg)
@@ -83,6 +83,7 @@ __global__ void __launch_bounds__(64) k_wfa(int n_items, const int32_t *__restri
 	__shared__ int32_t lo_s[WF_NSLOT], hi_s[WF_NSLOT];
 	__shared__ int32_t item_s;
 	const int lane = threadIdx.x;
+	const int n_items = min(*n_items_p, cap);
 	const wfa_ws_t W = wfa_carve(ws_base + (size_t)blockIdx.x * cfg.ws_stride, cfg);
 	const int32_t oe1 = cfg.o1 + cfg.e1, oe2 = cfg.o2 + cfg.e2;
 	const int32_t wmax = cfg.wmax;
@@ -288,7 +289,7 @@ __global__ void __launch_bounds__(64) k_wfa(int n_items, const int32_t *__restri
 			r.n_cigar = status == MGA_WFA_OK ? n_cig : 0;
 			r.cig_off = cig_off, r.status = status, r.pad = 0, r.n_iter = n_iter;
 			res[pi] = r;
-			if (status == MGA_WFA_RETRY_TIER) rt.list[atomicAdd(rt.cnt, 1)] = pi; // next tier's work list
+			if (status == MGA_WFA_RETRY_TIER) mga_wfa_give_up(rt, pi); // next tier's work list
 			else if (status == MGA_WFA_MAX_ITER) rt.fb_list[atomicAdd(rt.fb_cnt, 1)] = pi; // for the chained fallback
 			else if (status != MGA_WFA_OK) atomicAdd(rt.err, 1);
 		}
@@ -309,7 +310,7 @@ static const wfa_cfg_t g_tier[3] = {
 static const int g_tier_waves[3] = { 256, 16, 2 };
 
 
-extern "C" int mga_dev_wfa(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+extern "C" int mga_dev_wfa(mga_sctx_t *sc, const int *d_n, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 						   mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier, mga_wfa_retry_t rt)
 {
 	if (n <= 0) return 0;
@@ -325,7 +326,7 @@ extern "C" int mga_dev_wfa(mga_sctx_t *sc, int n, const int32_t *d_list, const m
 	int *d_counter = (int*)((char*)sc->wfa_cnt.p + 64 * (7 + tier));
 	const int kid = MGA_K_WFA0 + 7 + (tier > 1 ? 1 : tier); // the unbounded tier is accounted with the widest regular one
 	mga_prof_begin(st, kid);
-	hipLaunchKernelGGL(k_wfa, dim3(waves), dim3(64), 0, st, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap,
+	hipLaunchKernelGGL(k_wfa, dim3(waves), dim3(64), 0, st, d_n, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap,
 					   d_pool_used, (char*)sc->wfa_ws[7 + tier].p, d_counter, rt, cfg);
 	mga_prof_end(st, kid);
 	MGA_HIP_CHECK(hipGetLastError());

@@ -66,13 +66,14 @@ extern "C" int mga_wfa_first_tier(int32_t tl, int32_t ql) // (round-2 stage API:
 	return L->n - 1;
 }
 
-__global__ void __launch_bounds__(1024) k_wfa_bin_count(int n, const mga_wfa_prob_t *__restrict__ prob, int32_t *__restrict__ key, int *__restrict__ hist, wfs_thr_t T)
+__global__ void __launch_bounds__(1024) k_wfa_bin_count(int n, const int32_t *__restrict__ ids /* NULL: problems 0..n-1 */, const mga_wfa_prob_t *__restrict__ prob, int32_t *__restrict__ key, int *__restrict__ hist, wfs_thr_t T)
 {
 	__shared__ int h[WFS_NBIN];
 	for (int i = threadIdx.x; i < WFS_NBIN; i += blockDim.x) h[i] = 0;
 	__syncthreads();
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		const int32_t tl = prob[i].tl, ql = prob[i].ql;
+		const int pi = ids ? ids[i] : i;
+		const int32_t tl = prob[pi].tl, ql = prob[pi].ql;
 		int lb = (tl + ql) >> 3;
 		if (lb > 1023) lb = 1023;
 		const int k = wfs_first_rung(tl, ql, T) << 10 | (1023 - lb);
@@ -112,7 +113,8 @@ __global__ void __launch_bounds__(1024) k_wfa_bin_scan(int *__restrict__ hist, i
 
 // tile of 8192 ids per workgroup: LDS histogram of the tile, ONE global atomic per non-empty bin to reserve its slots,
 // then LDS atomics hand out the slots (4.8 M global atomics on ~20 hot bins took 14 ms; this takes <1 ms)
-__global__ void __launch_bounds__(1024) k_wfa_bin_scatter(int n, const int32_t *__restrict__ key, int *__restrict__ cursor, int32_t *__restrict__ list)
+struct wfs_shift_t { int32_t s[MGA_WFA_N_SLOT]; }; // rung r's region of the list starts s[r] slots after where the compact order would put it (room for arrivals from below)
+__global__ void __launch_bounds__(1024) k_wfa_bin_scatter(int n, const int32_t *__restrict__ ids, const int32_t *__restrict__ key, int *__restrict__ cursor, int32_t *__restrict__ list, wfs_shift_t shift)
 {
 	__shared__ int cnt[WFS_NBIN], base[WFS_NBIN];
 	const int t0 = blockIdx.x * 8192;
@@ -130,7 +132,7 @@ __global__ void __launch_bounds__(1024) k_wfa_bin_scatter(int n, const int32_t *
 	__syncthreads();
 #pragma unroll
 	for (int r = 0; r < 8; ++r)
-		if (k[r] >= 0) list[base[k[r]] + atomicSub(&cnt[k[r]], 1) - 1] = t0 + r * 1024 + threadIdx.x;
+		if (k[r] >= 0) list[base[k[r]] + shift.s[k[r] >> 10] + atomicSub(&cnt[k[r]], 1) - 1] = ids ? ids[t0 + r * 1024 + threadIdx.x] : t0 + r * 1024 + threadIdx.x;
 }
 
 __global__ void __launch_bounds__(256) k_wfa_sum_cells(int n, const mga_wfa_res_t *__restrict__ res, unsigned long long *__restrict__ out)
@@ -197,11 +199,29 @@ extern "C" int mga_dev_wfa_gather(mga_sctx_t *sc, int n, const mga_wfa_res_t *d_
 	return 0;
 }
 
-extern "C" int mga_dev_wfa_tier(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+extern "C" int mga_dev_wfa_tier(mga_sctx_t *sc, const int *d_n, int cap, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 								mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier, mga_wfa_retry_t rt)
 {
-	if (tier < 7) return mga_dev_wfa_reg(sc, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier, rt);
-	return mga_dev_wfa(sc, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier - 7, rt); /* HBM tiers with 4096 / 32768 diagonals */
+	if (tier < 7) return mga_dev_wfa_reg(sc, d_n, cap, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier, rt);
+	return mga_dev_wfa(sc, d_n, cap, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier - 7, rt); /* HBM tiers with 4096 / 32768 diagonals */
+}
+
+// problems a sweep left undecided (their rung's list was full): collected for the next sweep
+__global__ void __launch_bounds__(256) k_wfa_collect_open(int n, const mga_wfa_res_t *__restrict__ res, int32_t *__restrict__ list, int *__restrict__ cnt)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool open = i < n && (res[i].status == MGA_WFA_RETRY_TIER || res[i].status == MGA_WFA_PENDING);
+	const uint64_t m = __ballot(open);
+	if (m == 0) return;
+	int base = 0;
+	if ((threadIdx.x & 63) == 0) base = atomicAdd(cnt, (int)__popcll(m));
+	base = __shfl(base, 0);
+	if (open) list[base + (int)__popcll(m & mga_lanemask_lt())] = i;
+}
+__global__ void __launch_bounds__(256) k_wfa_mark_pending(int n, mga_wfa_res_t *__restrict__ res)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) res[i].status = MGA_WFA_PENDING;
 }
 
 
@@ -296,97 +316,138 @@ extern "C" void mga_wfa_ladder_stats(int64_t *launched, int64_t *given_up, int r
 	}
 }
 
-extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
-								 mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int64_t *cells,
-								 void (*bulk_done)(void*), void *bulk_arg)
+// One SWEEP of the ladder (round 3): the rungs run ONCE each, in ascending order, on the context's stream.  A problem that gives up on rung t is appended to
+// the list of a HIGHER rung, which has not started yet and reads its list's length from device memory when it does -- so every retry is served in the same
+// sweep, with no host round trip between the rungs (round 2 ran pass after pass, every rung again for the problems that had climbed to it: seven host
+// synchronisations and ~3 launches per rung and chunk, [measured] 79 ms per 125k reads in the 512-diagonal tier alone, most of it launch tails).
+// A rung's list has room for its own problems + a share of what the rungs below it run; an overflow (never seen on real reads) only moves the count on, and
+// the host then sweeps once more over what is still open.
+static int wfs_sweep(mga_sctx_t *sc, const wfs_ladder_t *LD, int arr_pct, int n_list, const int32_t *d_ids /* NULL: problems 0 .. n_list - 1 */,
+					 const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq, mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap,
+					 unsigned long long *d_pool_used, int *ctl, bool *any_tb, int *n_open)
 {
-	if (cells) *cells = 0;
-	if (n <= 0) return 0;
+	constexpr int NS = MGA_WFA_N_SLOT;
+	constexpr int O_TOFF = WFS_NBIN, O_RC = O_TOFF + 16, O_ERR = O_RC + 32;
+	hipStream_t st = (hipStream_t)sc->stream;
+	const int NR = LD->n;
 	static int dbg = -1;
 	if (dbg < 0) { const char *e = getenv("MGA_DEBUG_WFA"); dbg = e && atoi(e) > 0; }
-	hipStream_t st = (hipStream_t)sc->stream;
-	const wfs_ladder_t *LD = wfs_ladder(sc->wfa_uncapped); // (the fallback's sub-problems: register / HBM tiers only, results in the pool at once)
-	const int NR = LD->n;
-	constexpr int NS = MGA_WFA_N_SLOT;
-	// ctl: hist[NBIN] | tier_off[16] | rc[2][16] | err | fb | cells (8 bytes)
-	constexpr int O_TOFF = WFS_NBIN, O_RC = O_TOFF + 16, O_ERR = O_RC + 32, O_FB = O_ERR + 1, O_CELLS = O_ERR + 2, N_CTL = O_CELLS + 2;
-	if (mga_dbuf_reserve(&sc->wfa_list[0], (size_t)n * 4 + 64) < 0 || mga_dbuf_reserve(&sc->wfa_list[1], (size_t)n * 4 + 64) < 0 ||
-		mga_dbuf_reserve(&sc->wfa_key, (size_t)n * 4 + 64) < 0 || mga_dbuf_reserve(&sc->wfa_ctl, (size_t)N_CTL * 4) < 0 ||
-		mga_dbuf_reserve(&sc->wfa_cnt, 1024) < 0) return -1;
-	int *ctl = (int*)sc->wfa_ctl.p;
-	int32_t *L[2] = { (int32_t*)sc->wfa_list[0].p, (int32_t*)sc->wfa_list[1].p };
-	MGA_HIP_CHECK(hipMemsetAsync(ctl, 0, (size_t)N_CTL * 4, st));
+	*n_open = 0;
+	MGA_HIP_CHECK(hipMemsetAsync(ctl, 0, (size_t)O_ERR * 4, st)); // histogram, offsets, list lengths (the err / fb / cells words behind them are kept)
 	{
-		int nb = (n + 1023) / 1024;
+		int nb = (n_list + 1023) / 1024;
 		if (nb > 1024) nb = 1024;
 		wfs_thr_t T;
 		T.n = NR;
 		for (int k = 0; k < NS; ++k) T.t[k] = k < NR ? LD->r[k].maxlen : 0x7fffffff;
 		mga_prof_begin(st, MGA_K_SCAN);
-		hipLaunchKernelGGL(k_wfa_bin_count, dim3(nb), dim3(1024), 0, st, n, d_prob, (int32_t*)sc->wfa_key.p, ctl, T);
+		hipLaunchKernelGGL(k_wfa_bin_count, dim3(nb), dim3(1024), 0, st, n_list, d_ids, d_prob, (int32_t*)sc->wfa_key.p, ctl, T);
 		hipLaunchKernelGGL(k_wfa_bin_scan, dim3(1), dim3(1024), 0, st, ctl, ctl + O_TOFF);
-		hipLaunchKernelGGL(k_wfa_bin_scatter, dim3((n + 8191) / 8192), dim3(1024), 0, st, n, (const int32_t*)sc->wfa_key.p, ctl, L[0]);
 		mga_prof_end(st, MGA_K_SCAN);
 		MGA_HIP_CHECK(hipGetLastError());
 	}
-	int h[NS + 2], off[NS + 1], cnt[NS + 1];
-	bool any_tb = false;
+	int h[NS + 2], cap[NS], base[NS + 1];
+	int *own = sc->wfa_own; // (lives in the context: the copy engine reads it after this frame's locals could be gone)
 	if (mga_d2h_s(sc, h, ctl + O_TOFF, (NS + 1) * 4) < 0 || mga_ssync(sc) < 0) return -1;
-	for (int t = 0; t < NS; ++t) off[t] = h[t], cnt[t] = t < NR ? h[t + 1] - h[t] : 0;
-	for (int pass = 0, cur = 0;; ++pass, cur ^= 1) {
-		int *rc = ctl + O_RC + 16 * (pass & 1), nstart[NS + 2], incoming[NS + 1];
-		MGA_HIP_CHECK(hipMemsetAsync(rc, 0, 16 * 4, st));
-		MGA_HIP_CHECK(hipMemsetAsync(sc->wfa_cnt.p, 0, 1024, st)); // the rungs' work-queue counters (one 64-byte line each)
-		// region of rung u in the next pass's list: room for everything the rungs that feed it run now
-		for (int u = 0; u <= NS; ++u) incoming[u] = 0;
-		for (int t = 0; t < NR; ++t) if (LD->r[t].next >= 0) incoming[LD->r[t].next] += cnt[t];
-		nstart[0] = 0;
-		for (int u = 0; u < NS; ++u) nstart[u + 1] = nstart[u] + incoming[u];
-		// traceback regions of this pass's windowed rungs
-		int64_t tb_off[NS], tb_bytes = 0;
-		for (int t = 0; t < NR; ++t) { tb_off[t] = tb_bytes; if (LD->r[t].kind == 0 && cnt[t] > 0) tb_bytes += (int64_t)cnt[t] * mga_dev_wfa_win_tb_stride(LD->r[t].idx); }
-		if (tb_bytes > 0) {
-			if (pass >= 8) { mga_set_error("WFA ladder: windowed rung in pass %d", pass); return -1; } // cannot happen: a problem leaves the windowed rungs within six passes
-			if (mga_dbuf_reserve(&sc->wfa_tbuf[pass], (size_t)tb_bytes + 256) < 0) return -1;
-			any_tb = true;
-		}
-		if (mga_wfa_fork(sc) < 0) return -1;
+	int64_t tot_cap = 0;
+	{ // room of every rung's list: its own problems + arr_pct % of what the rungs feeding it may run (+ 4096)
+		int64_t feed[NS];
+		for (int t = 0; t < NS; ++t) own[t] = t < NR ? h[t + 1] - h[t] : 0, feed[t] = 0;
 		for (int t = 0; t < NR; ++t) {
-			if (cnt[t] <= 0) continue;
-			const int nx = LD->r[t].next;
-			// wfa_key is free once the lists are built: it takes the problems that hit the cell cap (only the HBM tiers count cells); rc[15]: problems beyond the last rung
-			mga_wfa_retry_t rt = { L[cur ^ 1] + (nx >= 0 ? nstart[nx] : 0), rc + (nx >= 0 ? nx : 15), ctl + O_ERR, (int32_t*)sc->wfa_key.p, ctl + O_FB };
-			if (LD->r[t].kind == 0) {
-				if (mga_dev_wfa_win(sc, cnt[t], L[cur] + off[t], d_prob, d_tseq, d_qseq, d_res, (char*)sc->wfa_tbuf[pass].p + tb_off[t], LD->r[t].idx, 9 + LD->r[t].idx, rt) < 0) return -1;
-			} else if (mga_dev_wfa_tier(sc, cnt[t], L[cur] + off[t], d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, LD->r[t].idx, rt) < 0) return -1;
+			int64_t c = own[t] + (feed[t] > 0 ? feed[t] * arr_pct / 100 + (arr_pct < 100 ? 4096 : 0) : 0);
+			if (c > n_list) c = n_list;
+			cap[t] = (int)c;
+			if (LD->r[t].next >= 0) feed[LD->r[t].next] += c;
 		}
-		if (mga_wfa_join(sc) < 0) return -1;
-		if (pass == 0 && bulk_done && !mga_wfa_tiers_serial()) { // the narrow rungs carry > 95 % of the work: once they are done the caller may let the next chunk's
-			// WFA phase start; the long tails of the wide ones and the retry passes then overlap with it instead of idling the GPU
-			struct timespec ts = { 0, 50000 };
-			for (int t = 0; t < NR && t < 6; ++t) {
-				const int slot = LD->r[t].kind == 0 ? 9 + LD->r[t].idx : LD->r[t].idx;
-				while (cnt[t] > 0 && hipEventQuery((hipEvent_t)sc->ev_done[slot]) == hipErrorNotReady) nanosleep(&ts, 0);
+		for (int t = NR; t < NS; ++t) cap[t] = 0;
+		base[0] = 0;
+		for (int t = 0; t < NS; ++t) base[t + 1] = base[t] + cap[t], tot_cap = base[t + 1];
+	}
+	if (mga_dbuf_reserve(&sc->wfa_list[0], (size_t)tot_cap * 4 + 64) < 0) return -1;
+	int32_t *L = (int32_t*)sc->wfa_list[0].p;
+	{
+		wfs_shift_t sh;
+		for (int t = 0; t < NS; ++t) sh.s[t] = t < NR ? base[t] - h[t] : 0;
+		mga_prof_begin(st, MGA_K_SCAN);
+		hipLaunchKernelGGL(k_wfa_bin_scatter, dim3((n_list + 8191) / 8192), dim3(1024), 0, st, n_list, d_ids, (const int32_t*)sc->wfa_key.p, ctl, L, sh);
+		mga_prof_end(st, MGA_K_SCAN);
+		MGA_HIP_CHECK(hipGetLastError());
+	}
+	int *rc = ctl + O_RC; // rc[t]: length of rung t's list (own problems, then arrivals); rc[15]: problems beyond the last rung
+	MGA_HIP_CHECK(hipMemcpyAsync(rc, own, NS * 4, hipMemcpyHostToDevice, st));
+	MGA_HIP_CHECK(hipMemsetAsync(sc->wfa_cnt.p, 0, 1024, st)); // the rungs' work-queue counters (one 64-byte line each)
+	int64_t tb_off[NS], tb_bytes = 0;
+	for (int t = 0; t < NR; ++t) { tb_off[t] = tb_bytes; if (LD->r[t].kind == 0 && cap[t] > 0) tb_bytes += (int64_t)cap[t] * mga_dev_wfa_win_tb_stride(LD->r[t].idx); }
+	if (tb_bytes > 0) {
+		if (mga_dbuf_reserve(&sc->wfa_tbuf[0], (size_t)tb_bytes + 256) < 0) return -1;
+		*any_tb = true;
+	}
+	for (int t = 0; t < NR; ++t) {
+		if (cap[t] <= 0) continue;
+		const int nx = LD->r[t].next;
+		// (wfa_fb takes the problems that hit the cell cap: only the HBM tiers count cells)
+		mga_wfa_retry_t rt = { nx >= 0 ? L + base[nx] : L, rc + (nx >= 0 ? nx : 15), ctl + O_ERR, (int32_t*)sc->wfa_fb.p, ctl + O_ERR + 1, nx >= 0 ? cap[nx] : 0 };
+		if (LD->r[t].kind == 0) {
+			if (mga_dev_wfa_win(sc, rc + t, cap[t], L + base[t], d_prob, d_tseq, d_qseq, d_res, (char*)sc->wfa_tbuf[0].p + tb_off[t], LD->r[t].idx, 9 + LD->r[t].idx, rt) < 0) return -1;
+		} else if (mga_dev_wfa_tier(sc, rc + t, cap[t], L + base[t], d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, LD->r[t].idx, rt) < 0) return -1;
+	}
+	int hr[16], herr = 0;
+	if (mga_d2h_s(sc, hr, rc, 16 * 4) < 0 || mga_d2h_s(sc, &herr, ctl + O_ERR, 4) < 0 || mga_ssync(sc) < 0) return -1;
+	if (dbg) {
+		fprintf(stderr, "[wfa] sweep over %d problems:", n_list);
+		for (int t = 0; t < NR; ++t) if (hr[t]) fprintf(stderr, " %s%d: %d (+%d, room %d)", LD->r[t].kind == 0 ? "W" : "R", LD->r[t].idx, own[t], hr[t] - own[t], cap[t]);
+		fprintf(stderr, "\n");
+	}
+	if (herr) { mga_set_error("WFA: %d problems failed (CIGAR pool of %ld ops exhausted, or iteration cap)", herr, (long)pool_cap); return -1; }
+	if (hr[15] > 0) { mga_set_error("%d WFA problems exceed the largest capacity tier", hr[15]); return -1; }
+	if (!sc->wfa_uncapped) for (int t = 0; t < NR; ++t) {
+		__atomic_fetch_add(&g_rung_n[t], (long long)(hr[t] < cap[t] ? hr[t] : cap[t]), __ATOMIC_RELAXED);
+		__atomic_fetch_add(&g_rung_up[t], (long long)(hr[t] - own[t]), __ATOMIC_RELAXED); // (arrivals AT rung t)
+	}
+	for (int t = 0; t < NR; ++t) if (hr[t] > cap[t]) *n_open += hr[t] - cap[t];
+	return 0;
+}
+
+extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+								 mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int64_t *cells,
+								 void (*bulk_done)(void*), void *bulk_arg)
+{
+	(void)bulk_done; (void)bulk_arg; // (round 2: early release of the caller's GPU-phase token between concurrent tiers; a sweep is one chain of launches)
+	if (cells) *cells = 0;
+	if (n <= 0) return 0;
+	hipStream_t st = (hipStream_t)sc->stream;
+	const wfs_ladder_t *LD = wfs_ladder(sc->wfa_uncapped); // (the fallback's sub-problems: register / HBM tiers only, results in the pool at once)
+	// ctl: hist[NBIN] | tier_off[16] | rc[2][16] | err | fb | cells (8 bytes)
+	constexpr int O_TOFF = WFS_NBIN, O_RC = O_TOFF + 16, O_ERR = O_RC + 32, O_FB = O_ERR + 1, O_CELLS = O_ERR + 2, N_CTL = O_CELLS + 2;
+	if (mga_dbuf_reserve(&sc->wfa_key, (size_t)n * 4 + 64) < 0 || mga_dbuf_reserve(&sc->wfa_fb, (size_t)n * 4 + 64) < 0 || mga_dbuf_reserve(&sc->wfa_ctl, (size_t)N_CTL * 4) < 0 ||
+		mga_dbuf_reserve(&sc->wfa_cnt, 1024) < 0) return -1;
+	int *ctl = (int*)sc->wfa_ctl.p;
+	MGA_HIP_CHECK(hipMemsetAsync(ctl, 0, (size_t)N_CTL * 4, st));
+	hipLaunchKernelGGL(k_wfa_mark_pending, dim3((n + 255) / 256), dim3(256), 0, st, n, d_res);
+	MGA_HIP_CHECK(hipGetLastError());
+	bool any_tb = false;
+	int n_open = 0;
+	static int arr_pct = -1;
+	if (arr_pct < 0) { const char *e = getenv("MGA_WFA_ARRIVALS_PCT"); arr_pct = e ? atoi(e) : 25; } // (tests: 0 leaves a rung's list room for 4096 arrivals only)
+	if (wfs_sweep(sc, LD, arr_pct, n, 0, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, ctl, &any_tb, &n_open) < 0) return -1;
+	if (n_open > 0) { // a rung's list overflowed (far more of a chunk's gaps gave up than any read set has shown): what is still open is swept again in slices whose
+		// lists have room for EVERYTHING below them (no second overflow), small enough for the traceback regions that implies
+		const int SLICE = 32768;
+		int *d_cnt = ctl + O_CELLS, k = 0; // (the cells words are free until the end)
+		if (mga_dbuf_reserve(&sc->wfa_list[1], (size_t)n * 4 + 64) < 0) return -1;
+		MGA_HIP_CHECK(hipMemsetAsync(d_cnt, 0, 8, st));
+		hipLaunchKernelGGL(k_wfa_collect_open, dim3((n + 255) / 256), dim3(256), 0, st, n, (const mga_wfa_res_t*)d_res, (int32_t*)sc->wfa_list[1].p, d_cnt);
+		MGA_HIP_CHECK(hipGetLastError());
+		if (mga_d2h_s(sc, &k, d_cnt, 4) < 0 || mga_ssync(sc) < 0) return -1;
+		MGA_HIP_CHECK(hipMemsetAsync(d_cnt, 0, 8, st));
+		for (int o = 0; o < k; o += SLICE) {
+			if (any_tb) { // the windowed rungs' regions are reused by the next sweep: walk them now
+				if (mga_dev_wfa_traceback(sc, n, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, ctl + O_ERR) < 0) return -1;
+				any_tb = false;
 			}
-			bulk_done(bulk_arg);
+			if (wfs_sweep(sc, LD, 100, k - o < SLICE ? k - o : SLICE, (const int32_t*)sc->wfa_list[1].p + o, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, ctl, &any_tb, &n_open) < 0) return -1;
+			if (n_open > 0) { mga_set_error("WFA ladder: %d problems open after a sweep with room for all", n_open); return -1; }
 		}
-		int hr[16], herr = 0, left = 0;
-		if (mga_d2h_s(sc, hr, rc, 16 * 4) < 0 || mga_d2h_s(sc, &herr, ctl + O_ERR, 4) < 0 || mga_ssync(sc) < 0) return -1;
-		if (dbg) {
-			fprintf(stderr, "[wfa] pass %d:", pass);
-			for (int t = 0; t < NR; ++t) if (cnt[t]) fprintf(stderr, " %s%d: %d", LD->r[t].kind == 0 ? "W" : "R", LD->r[t].idx, cnt[t]);
-			fprintf(stderr, " | given up ->");
-			for (int t = 0; t < NR; ++t) if (hr[t]) fprintf(stderr, " rung %d: %d", t, hr[t]);
-			fprintf(stderr, "\n");
-		}
-		if (herr) { mga_set_error("WFA: %d problems failed (CIGAR pool of %ld ops exhausted, or iteration cap)", herr, (long)pool_cap); return -1; }
-		if (hr[15] > 0) { mga_set_error("%d WFA problems exceed the largest capacity tier", hr[15]); return -1; }
-		if (!sc->wfa_uncapped) for (int t = 0; t < NR; ++t) {
-			if (cnt[t] > 0) __atomic_fetch_add(&g_rung_n[t], (long long)cnt[t], __ATOMIC_RELAXED);
-			if (hr[t] > 0) __atomic_fetch_add(&g_rung_up[t], (long long)hr[t], __ATOMIC_RELAXED); // (arrivals AT rung t)
-		}
-		for (int u = 0; u < NS; ++u) cnt[u] = u < NR ? hr[u] : 0, off[u] = nstart[u], left += cnt[u];
-		if (left == 0) break;
 	}
 	if (any_tb) { // the windowed rungs left scores + traceback regions: CIGARs into the pool, one lane per problem
 		int herr = 0;
@@ -397,7 +458,7 @@ extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_
 	{ // problems the exact pass gave up on (> 1e8 cells): miniwfa's chained fallback (miniwfa.c:829-832)
 		int n_fb = 0;
 		if (mga_d2h_s(sc, &n_fb, ctl + O_FB, 4) < 0 || mga_ssync(sc) < 0) return -1;
-		if (n_fb > 0 && wfs_fallback(sc, n_fb, (const int32_t*)sc->wfa_key.p, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used) < 0) return -1;
+		if (n_fb > 0 && wfs_fallback(sc, n_fb, (const int32_t*)sc->wfa_fb.p, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used) < 0) return -1;
 		ctl = (int*)sc->wfa_ctl.p; // the nested ladder may have grown the buffer
 	}
 	if (cells) {

@@ -63,7 +63,7 @@ template<int G> __device__ __forceinline__ int32_t wfw_from_right(int32_t edge, 
 enum { WFW_IDLE = 0, WFW_RUN = 1, WFW_DONE = 2, WFW_BAIL = 3 };
 
 template<int G, int J, int SEQCAP>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 ? 6 : 1, 8))) k_wfa_fw(int n_items, const int32_t *__restrict__ list, const mga_wfa_prob_t *__restrict__ prob,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 ? 6 : 1, 8))) k_wfa_fw(const int *__restrict__ n_items_p, int cap, const int32_t *__restrict__ list, const mga_wfa_prob_t *__restrict__ prob,
 											  const char *__restrict__ tseq, const char *__restrict__ qseq, mga_wfa_res_t *__restrict__ res,
 											  char *__restrict__ tb, long long tb_stride, int *__restrict__ counter, mga_wfa_retry_t rt)
 {
@@ -83,6 +83,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 	// ([measured] the compare loop was ~60 of ~165 vector instructions of a step).  A row is 64 J dwords: lane l always hits bank l, whatever its word.
 	__shared__ uint32_t Mk[MROWS][64 * J];
 	const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
+	const int n_items = min(*n_items_p, cap); // (the list's length is read here: rungs below this one appended to it during the same sweep)
 	uint8_t *const Tg = Tb[grp], *const Qg = Qb[grp];
 	const int32_t m_first = gl == 0 ? -1 : 0, m_last = gl == G - 1 ? -1 : 0;
 	const uint64_t gmask = (G == 64 ? ~0ULL : ((1ULL << G) - 1ULL)) << (grp * G);
@@ -135,7 +136,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 					mga_wfa_res_t r;
 					r.score = -1, r.n_cigar = 0, r.cig_off = 0, r.status = MGA_WFA_RETRY_TIER, r.pad = 0, r.n_iter = 0;
 					res[pi] = r;
-					rt.list[atomicAdd(rt.cnt, 1)] = pi; // next tier's work list
+					mga_wfa_give_up(rt, pi); // next tier's work list
 				}
 				st = WFW_IDLE;
 			}
@@ -446,7 +447,7 @@ static int wfw_rows(int W) { const int smax = W + 30 < WFW_SMAX ? W + 30 : WFW_S
 
 extern "C" int64_t mga_dev_wfa_win_tb_stride(int wt) { return (int64_t)wfw_rows(g_wtier[wt].W) * g_wtier[wt].W * 4; }
 
-extern "C" int mga_dev_wfa_win(mga_sctx_t *sc, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+extern "C" int mga_dev_wfa_win(mga_sctx_t *sc, const int *d_n, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 							   mga_wfa_res_t *d_res, char *d_tb, int wt, int slot, mga_wfa_retry_t rt)
 {
 	if (n <= 0) return 0;
@@ -460,7 +461,7 @@ extern "C" int mga_dev_wfa_win(mga_sctx_t *sc, int n, const int32_t *d_list, con
 	int *d_counter = (int*)((char*)sc->wfa_cnt.p + 64 * slot);
 	const long long stride = (long long)mga_dev_wfa_win_tb_stride(wt);
 	mga_prof_begin(st, MGA_K_WFAW0 + wt);
-#define LAUNCH(GG, JJ, SEQ) hipLaunchKernelGGL((k_wfa_fw<GG, JJ, SEQ>), dim3(wgs), dim3(64), 0, st, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_tb, stride, d_counter, rt)
+#define LAUNCH(GG, JJ, SEQ) hipLaunchKernelGGL((k_wfa_fw<GG, JJ, SEQ>), dim3(wgs), dim3(64), 0, st, d_n, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_tb, stride, d_counter, rt)
 	if (wt == 0) LAUNCH(16, 1, 128);
 	else if (wt == 1) LAUNCH(32, 1, 192);
 	else if (wt == 2) LAUNCH(64, 1, 256);

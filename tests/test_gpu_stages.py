@@ -191,6 +191,16 @@ def test_wfa_windowed_tiers_many_problems(ora):
     assert bad == 0
 
 
+def test_wfa_ladder_list_overflow():
+    """a rung's work list has room for its own problems + a share of what the rungs below it run; with MGA_WFA_ARRIVALS_PCT=0 (4096 arrivals) 12 000 unrelated
+    pairs overflow every list on their way up: the sweep leaves them open and the slices with room for everything finish them -- same answers"""
+    import os, subprocess, sys
+    env = dict(os.environ, MGA_WFA_ARRIVALS_PCT="0", MGA_DEBUG_WFA="1")
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "wfa_overflow_child.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0 and b"OVERFLOW-OK" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
+    assert p.stderr.count(b"[wfa] sweep over") >= 2, p.stderr[-2000:]   # the second sweep happened
+
+
 # ---------------------------------------------------------------------------------------------
 # seeds + linear chaining against a real (synthetic) graph
 # ---------------------------------------------------------------------------------------------
