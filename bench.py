@@ -16,6 +16,10 @@ maps its range against its own replica of the index, and the GAF bytes are gathe
 order inside the timed region.  Extra keys: `resident` (the same reads already in HBM, no parse / upload), `isolated`
 (one pass with ONE chunk in flight, so that per-kernel HIP-event times do not overlap: the per-kernel roofline comes from there).
 
+`python bench.py --gpus N` without a launcher around it starts its own N ranks (torch.distributed.run); a WORLD_SIZE that disagrees with --gpus is refused.
+Graph chaining + the gap list run on the host threads or on the device (the library picks by the host threads a rank has): `value` is the library's choice,
+`device_placement` / `host_placement` is the other one, timed the same way right after it, both compared byte for byte with the reference on every read of the sample.
+
 Rank 0 prints ONE JSON line (metric / roofline / cpu_baseline); everything else goes to stderr.
 """
 import argparse
@@ -102,7 +106,8 @@ def main():
     ap.add_argument("--genome", type=int, default=2350000000, help="backbone bp (2.35 Gbp backbone + 4 alt haplotypes = 3.02 Gbp of graph sequence)")
     ap.add_argument("--chr", type=int, default=24)
     ap.add_argument("--hap", type=int, default=5)
-    ap.add_argument("--cpu-reads", type=int, default=20000)
+    ap.add_argument("--cpu-reads", type=int, default=125000, help="reads of the CPU baseline + parity sample (default: every read of one rank's share -- about 17 s of mapping on 16 cores)")
+    ap.add_argument("--one-placement", action="store_true", help="skip the second placement of graph chaining (the library's own choice only)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: leave every rank's GAF shard where it is (the gather to rank 0 over RCCL is ON by default)")
     ap.add_argument("--resident-steps", type=int, default=2)
@@ -111,11 +116,23 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1: nccl (= RCCL over xGMI, the default) or gloo (host tensors: lets one GPU box run 2 ranks on the same device to test the sharded path)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` launches its own ranks: one process per GPU under torch.distributed.run (the plain command ran ONE rank and said n_gpus 1)
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        log("[bench] launching %d ranks: %s" % (args.gpus, " ".join(cmd)))
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        log("[bench] WORLD_SIZE=%d overrides --gpus %d" % (world, args.gpus))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or run `python bench.py --gpus %d`, which launches its own ranks)" % (args.gpus, world, args.gpus, args.gpus))
     n_gpus = world
     os.environ.setdefault("MGA_DEVICE", str(local_rank))
 
@@ -185,24 +202,53 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    mga.get_stats(G, reset=True)
-    sync()
-    cpu0, thr0 = time.process_time(), cgroup_throttled()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    sync()
-    dt = time.perf_counter() - t0
-    cpu1, thr1 = time.process_time(), cgroup_throttled()
-    st = mga.get_stats(G, reset=True)
+    def timed(n_warm, n_steps):
+        """W untimed + K timed steps, barrier + device sync on both sides, MAX over ranks"""
+        for _ in range(n_warm):
+            step()
+        mga.get_stats(G, reset=True)
+        sync()
+        cpu0, thr0 = time.process_time(), cgroup_throttled()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        torch.cuda.synchronize()
+        sync()
+        dt_ = time.perf_counter() - t0
+        cpu1, thr1 = time.process_time(), cgroup_throttled()
+        st_ = mga.get_stats(G, reset=True)
+        if dist is not None:
+            tt = torch.tensor([dt_], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_ = float(tt.item())
+        return dt_, st_, dict(cpu_s_per_step=round((cpu1 - cpu0) / max(1, n_steps), 3), cfs_throttled_periods=thr1[0] - thr0[0], cfs_throttled_s=round((thr1[1] - thr0[1]) * 1e-6, 3))
+
+    def last_gaf():
+        """rank 0: bytes of the last step's output (enough of it for the CPU sample when it was gathered from N ranks)"""
+        if rank != 0:
+            return None
+        if dist is None:
+            return last["gaf"].bytes()
+        if not args.no_gather:
+            return last["gaf_bytes"][:min(int(last["gaf_bytes"].numel()), 12000 * args.cpu_reads)].cpu().numpy().tobytes()
+        return None
+
+    # Graph chaining + gap list run on the host threads or on the device (k_gchain / k_plan); the library picks by the host threads this rank has (device when <= 12).
+    # The headline is the library's own choice; the OTHER placement is timed right after it (fewer steps), so that both halves of the path are inside a driver-timed,
+    # parity-checked number (VERDICT r2 1a).
+    default_dev = threads <= 12
+    os.environ.pop("MGA_DEV_GCHAIN", None)
+    dt, st, host_main = timed(args.warmup, args.steps)
+    gaf_main = last_gaf()
+    other = None
+    if not args.one_placement:
+        os.environ["MGA_DEV_GCHAIN"] = "0" if default_dev else "1"
+        k_other = max(1, min(args.steps, 3))
+        dt_o, st_o, host_o = timed(1, k_other)
+        other = dict(dt=dt_o, steps=k_other, st=st_o, host=host_o, gaf=last_gaf())
+        os.environ.pop("MGA_DEV_GCHAIN", None)
     n_reads_rank, n_bases_rank = st["n_reads"] // max(1, args.steps), st["n_bases"] // max(1, args.steps)
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
         tb = torch.tensor([n_bases_rank, n_reads_rank] + [st[k] for k in ("n_mz", "n_hit", "wfa_t_bases", "wfa_q_bases", "gaf_bytes")], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(tb)
         total_bases, total_reads = int(tb[0].item()), int(tb[1].item())
@@ -212,14 +258,11 @@ def main():
         agg = {k: st[k] for k in ("n_mz", "n_hit", "wfa_t_bases", "wfa_q_bases", "gaf_bytes")}
 
     # ---- second key: the same reads resident in HBM (no parse, no upload), rank 0 only, untimed extras ----
-    resident = isolated = None
+    resident = isolated = isolated_other = None
     if rank == 0:
-        gaf_first = None
-        if dist is None:
-            gaf_first = last["gaf"].bytes()
+        gaf_first = gaf_main
+        if dist is None and last.get("gaf") is not None:
             last["gaf"].free()
-        elif not args.no_gather:
-            gaf_first = last["gaf_bytes"][:min(int(last["gaf_bytes"].numel()), 12000 * args.cpu_reads)].cpu().numpy().tobytes()   # enough for the CPU sample
         if args.resident_steps > 0:
             R = mga.Reads(reads_path, max_reads=args.reads)
             mga.map_reads(G, R, n_threads=threads, copy=False)
@@ -231,30 +274,36 @@ def main():
             dtr = (time.perf_counter() - t0) / args.resident_steps
             resident = dict(value=R.bases / dtr / 1e9, unit="Gbp/s", ms_per_step=dtr * 1e3, reads=R.n,
                             note="one GPU, reads already in HBM (mga_reads_load), GAF text into the library's buffer: no FASTA parse, no upload")
-            # ---- isolated pass: ONE chunk in flight (MGA_PIPE=1), per-kernel HIP-event times on the launch stream do not overlap ----
-            os.environ["MGA_PIPE"] = "1"
+            # ---- isolated passes: ONE chunk in flight (MGA_PIPE=1), per-kernel HIP-event times on the launch stream do not overlap; one per placement ----
             L.mga_idx_stream_close.argtypes = [ctypes.c_void_p]
-            L.mga_idx_stream_close(G.gi)        # the index's chunk pipeline is rebuilt with one pipeline thread for this pass
-            mga.get_stats(G, reset=True)
-            mga.prof_enable(True)
-            mga.prof_get(reset=True)
             L.mga_wfa_ladder_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
-            _z = (ctypes.c_int64 * 32)()
-            L.mga_wfa_ladder_stats(_z, ctypes.byref(_z, 128), 1)
-            t0 = time.perf_counter()
-            m = mga.map_files_idx(G, [reads_path], n_threads=threads, rank=0, world=world)
-            torch.cuda.synchronize()
-            dti = time.perf_counter() - t0
-            m.free()
-            del os.environ["MGA_PIPE"]
-            L.mga_idx_stream_close(G.gi)
-            prof, sti = mga.prof_get(), mga.get_stats(G)
             import numpy as np
-            ln, lu = np.zeros(16, dtype=np.int64), np.zeros(16, dtype=np.int64)
-            L.mga_wfa_ladder_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
-            L.mga_wfa_ladder_stats(ln.ctypes.data, lu.ctypes.data, 0)
-            mga.prof_enable(False)
-            isolated = dict(ms=dti * 1e3, prof=prof, st=sti, ladder=dict(launched=[int(x) for x in ln[:11]], arrived_from_below=[int(x) for x in lu[:11]]))
+
+            def isolated_pass(dev):
+                os.environ["MGA_PIPE"] = "1"
+                os.environ["MGA_DEV_GCHAIN"] = "1" if dev else "0"
+                L.mga_idx_stream_close(G.gi)        # the index's chunk pipeline is rebuilt with one pipeline thread for this pass
+                mga.get_stats(G, reset=True)
+                mga.prof_enable(True)
+                mga.prof_get(reset=True)
+                _z = (ctypes.c_int64 * 32)()
+                L.mga_wfa_ladder_stats(_z, ctypes.byref(_z, 128), 1)
+                t0_ = time.perf_counter()
+                m = mga.map_files_idx(G, [reads_path], n_threads=threads, rank=0, world=world)
+                torch.cuda.synchronize()
+                dti = time.perf_counter() - t0_
+                m.free()
+                del os.environ["MGA_PIPE"], os.environ["MGA_DEV_GCHAIN"]
+                L.mga_idx_stream_close(G.gi)
+                prof_, sti_ = mga.prof_get(), mga.get_stats(G)
+                ln, lu = np.zeros(16, dtype=np.int64), np.zeros(16, dtype=np.int64)
+                L.mga_wfa_ladder_stats(ln.ctypes.data, lu.ctypes.data, 0)
+                mga.prof_enable(False)
+                return dict(ms=dti * 1e3, prof=prof_, st=sti_, ladder=dict(rungs=["W16x4", "W32x2", "W64", "W128", "W192", "W256", "R512", "R1024", "R2048", "H4096", "H32768"],
+                                                                      run=[int(x) for x in ln[:11]], arrived_from_below=[int(x) for x in lu[:11]]))
+            isolated = isolated_pass(default_dev)
+            if not args.one_placement:
+                isolated_other = isolated_pass(not default_dev)
             R.close()
     if dist is not None:
         dist.barrier()
@@ -290,13 +339,15 @@ def main():
             traffic, traffic_src = None, None
             try:
                 import glob
-                pf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_pmc.json")))[-1]
+                pf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03*_pmc.json")))[-1]
                 pk = json.load(open(pf))["kernels"]
-                sel = [v for k, v in pk.items() if (k == "k_wfa" or k.startswith("k_wfa_r<") if dom == "k_wfa" else k.startswith(dom))]
+                sel = [v for k, v in pk.items() if (k == "k_wfa" or k.startswith("k_wfa_r<") or k.startswith("k_wfa_fw<") or k.startswith("k_wfa_tb") if dom == "k_wfa" else k.startswith(dom))]
                 nl = sum(v.get("launches_fetch", 0) for v in sel)
                 if nl:
                     traffic = sum(v.get("fetch_kb", 0) + v.get("write_kb", 0) for v in sel) * 1024.0 / nl
-                    traffic_src = os.path.relpath(pf, ROOT) + " (committed rocprofv3 --pmc passes of this command, not measured in this run)"
+                    src_m = max(os.path.getmtime(os.path.join(ROOT, "minigraph_amd", "csrc", f)) for f in os.listdir(os.path.join(ROOT, "minigraph_amd", "csrc")) if f.startswith("k_wfa"))
+                    stale = os.path.getmtime(pf) < src_m   # (a profile older than the kernel sources says so: VERDICT r2 item 9)
+                    traffic_src = os.path.relpath(pf, ROOT) + " (committed rocprofv3 --pmc passes of this command, not measured in this run%s)" % ("; STALE: older than the WFA kernel sources" if stale else "")
             except Exception:
                 pass
             ach = alg[dom] / (fam[dom] * 1e-3) / 1e9 if fam[dom] > 0 else 0.0
@@ -304,17 +355,19 @@ def main():
                         launches=launches[dom], avg_launch_ms=fam[dom] / max(1, launches[dom]), alg_bytes_per_launch=alg[dom] / max(1, launches[dom]),
                         family_ms_per_pass=fam[dom], pass_ms=isolated["ms"],
                         note="dominant kernel family by HIP-event time in the ISOLATED pass (one chunk in flight: launch durations do not overlap, sum <= pass_ms); "
-                             "the family is not bound by HBM: a score step is a dependent chain at 4-5 resident waves per SIMD, int_issue prices it against the vector-issue ceiling (DESIGN.md 4, 'Measured and not kept': the ring-layout experiment)",
+                             "the family is bound by vector-instruction ISSUE, not by HBM: int_issue prices it against the measured integer issue rate of a SIMD (profiles/r03_valu_rate.txt)",
                         families={k: dict(ms=round(fam[k], 2), launches=launches[k], alg_GBps=round(alg[k] / max(fam[k], 1e-9) / 1e6, 2)) for k in fam})
-            # integer-issue roofline of the WFA family: wavefront cells per second against what the vector ALUs could issue
+            # integer-issue roofline of the WFA family: wavefront cells (the REFERENCE's band: what miniwfa computes for the same gaps) per second against what the vector
+            # ALUs can issue.  [measured, minigraph_amd/tools/valu_rate.hip -> profiles/r03_valu_rate.txt] a gfx950 SIMD issues one wave64 v_max_i32 / v_add_u32 /
+            # DPP move every 4.15 cycles; a 64-cell slot step of the windowed kernel is ~110 such instructions (ISA count incl. one mask-window extension)
             cells = sti["wfa_cells"]
             if fam["k_wfa"] > 0 and cells > 0:
-                clk, simd = 2.4e9, 256 * 4
-                instr_per_cell_floor = 40.0 / 64.0   # the five recurrences + DPP operands + traceback byte + one extension round: ~40 wave instructions per 64-cell slot step
-                peak_cells = simd * clk / instr_per_cell_floor
-                roof["int_issue"] = dict(bound="valu-issue", achieved=cells / (fam["k_wfa"] * 1e-3), peak=peak_cells, unit="wavefront cells/s",
+                clk, simd, cyc_per_instr, instr_per_slot_step = 2.4e9, 256 * 4, 4.15, 110.0
+                peak_cells = simd * clk / cyc_per_instr * 64.0 / instr_per_slot_step
+                roof["int_issue"] = dict(bound="valu-issue", achieved=cells / (fam["k_wfa"] * 1e-3), peak=peak_cells, unit="reference-band wavefront cells/s",
                                          frac=cells / (fam["k_wfa"] * 1e-3) / peak_cells,
-                                         note="peak = 256 CU x 4 SIMD x 2.4 GHz / (40 wave64 instructions per 64-diagonal slot step)")
+                                         note="peak = 256 CU x 4 SIMD x 2.4 GHz / 4.15 cycles per wave64 integer instruction [measured] x 64 cells / 110 instructions per slot step; achieved counts the cells of "
+                                              "the reference's band (miniwfa.c:421 n_iter) -- the windowed tiers compute about 2.4x fewer to the same alignment, which is why frac is not a utilisation")
         res = dict(metric=METRIC, value=value, unit="Gbp/s",
                    n_gpus=n_gpus, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="u8/int32", data="synthetic",
@@ -329,21 +382,32 @@ def main():
                    resident=resident,
                    kernels_ms_isolated=kernels_ms,
                    wfa_ladder_isolated=(isolated or {}).get("ladder"),
+                   graph_chaining=dict(default=("device (k_gchain + k_plan)" if default_dev else "host threads") + ": %d host threads per rank, device when <= 12" % threads),
                    per_read=dict(n_mz=agg["n_mz"] / max(1, total_reads * args.steps), n_hit=agg["n_hit"] / max(1, total_reads * args.steps),
                                  n_wfa=st["n_wfa"] / max(1, st["n_reads"]), wfa_cells=st["wfa_cells"] / max(1, st["n_reads"]),
                                  gaf_bytes=agg["gaf_bytes"] / max(1, total_reads * args.steps)),
                    index_s=round(t_index, 2),
-                   host=dict(logical_cpus=ncpu, usable_cores=quota, cpu_s_per_step=round((cpu1 - cpu0) / args.steps, 3),
-                             cfs_throttled_periods=thr1[0] - thr0[0], cfs_throttled_s=round((thr1[1] - thr0[1]) * 1e-6, 3)))
+                   host=dict(logical_cpus=ncpu, usable_cores=quota, **host_main))
+        if other is not None:   # the other placement of graph chaining + gap list, timed the same way (fewer steps)
+            key = "host_placement" if default_dev else "device_placement"
+            res[key] = dict(value=total_bases * other["steps"] / other["dt"] / 1e9, unit="Gbp/s", ms_per_step=other["dt"] / other["steps"] * 1e3, steps=other["steps"], warmup=1,
+                            forced_by="MGA_DEV_GCHAIN=%d" % (0 if default_dev else 1), **other["host"])
+            if isolated_other:
+                res[key]["kernels_ms_isolated"] = {k: round(v[0], 3) for k, v in isolated_other["prof"].items() if v[0] > 0}
         ref_bin = os.path.join(ROOT, "oracle", "_ref", "minigraph")
         if not args.no_cpu and os.path.exists(ref_bin):
             try:
                 cb, cpu_gaf, n_cpu = cpu_baseline(ref_bin, graph_path, reads_path, args.cpu_reads, d, min(ncpu, 2 * quota), quota)
                 res["cpu_baseline"] = cb
+                want = open(cpu_gaf, "rb").read()
+
+                def same(got):
+                    return len(got) >= len(want) and got[:len(want)] == want and (len(got) == len(want) or got[len(want) - 1:len(want)] == b"\n")
                 if gaf_first is not None:
-                    want = open(cpu_gaf, "rb").read()
-                    ok = len(gaf_first) >= len(want) and gaf_first[:len(want)] == want and (len(gaf_first) == len(want) or gaf_first[len(want) - 1:len(want)] == b"\n")
-                    res["parity"] = ("GAF byte-identical to the reference on ALL %d reads of the CPU sample (%d bytes)" % (n_cpu, len(want))) if ok else "MISMATCH vs reference GAF"
+                    res["parity"] = ("GAF byte-identical to the reference on ALL %d reads of the CPU sample (%d bytes)" % (n_cpu, len(want))) if same(gaf_first) else "MISMATCH vs reference GAF"
+                if other is not None and other["gaf"] is not None:
+                    res["host_placement" if default_dev else "device_placement"]["parity"] = \
+                        ("GAF byte-identical to the reference on ALL %d reads of the CPU sample (%d bytes)" % (n_cpu, len(want))) if same(other["gaf"]) else "MISMATCH vs reference GAF"
             except Exception as e:  # the baseline is a reported number, never a reason to lose the bench line
                 res["cpu_baseline"] = dict(value=None, unit="Gbp/s", cores=quota, kind="reference", sample="failed: %r" % (e,))
         else:

@@ -390,6 +390,31 @@ def test_long_reads_whose_first_batch_is_one_chunk_vs_reference_binary(monkeypat
     G.close()
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher around it starts two ranks itself (torch.distributed.run), shards ONE read file over them, gathers the
+    GAF to rank 0 and reports n_gpus = 2 with the gathered text byte-identical to the reference (gloo: two ranks share the one GPU of the test box)"""
+    import json
+    import sys
+    need_ref()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--reads", "3000", "--genome", "30000000", "--chr", "2",
+                        "--steps", "1", "--warmup", "1", "--cpu-reads", "6000", "--resident-steps", "0", "--one-placement", "--threads", "4"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert "byte-identical" in d.get("parity", ""), d.get("parity")
+    assert "(6000 in all, ONE file)" in d["config"]["workload"]
+    # the plain launcher contract still holds: a WORLD_SIZE that disagrees with --gpus is refused, not silently overridden
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1"], env=env2, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p2.returncode != 0 and b"n_gpus" not in p2.stdout
+
+
 def test_reads_with_a_gap_beyond_the_exact_wfa_cap_vs_reference_binary():
     """reads whose middle 9-12 kb are 30-40 % diverged: the anchor gap there passes 1e8 WFA cells and the reference falls back to
     mwf_wfa_chain() (miniwfa.c:829-832); same bytes expected, incl. the read whose gap takes the D+I shortcut"""
