@@ -281,6 +281,7 @@ def main():
 
             def isolated_pass(dev):
                 os.environ["MGA_PIPE"] = "1"
+                os.environ["MGA_WFA_SIDE"] = "0"    # (the register tiers' own problems normally start early on a side stream: serialised here, so that launch durations do not overlap)
                 os.environ["MGA_DEV_GCHAIN"] = "1" if dev else "0"
                 L.mga_idx_stream_close(G.gi)        # the index's chunk pipeline is rebuilt with one pipeline thread for this pass
                 mga.get_stats(G, reset=True)
@@ -293,7 +294,7 @@ def main():
                 torch.cuda.synchronize()
                 dti = time.perf_counter() - t0_
                 m.free()
-                del os.environ["MGA_PIPE"], os.environ["MGA_DEV_GCHAIN"]
+                del os.environ["MGA_PIPE"], os.environ["MGA_DEV_GCHAIN"], os.environ["MGA_WFA_SIDE"]
                 L.mga_idx_stream_close(G.gi)
                 prof_, sti_ = mga.prof_get(), mga.get_stats(G)
                 ln, lu = np.zeros(16, dtype=np.int64), np.zeros(16, dtype=np.int64)

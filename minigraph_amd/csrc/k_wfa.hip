@@ -75,7 +75,7 @@ __device__ __forceinline__ int32_t wfa_lcp(const char *a, const char *b, int32_t
 	return n < maxlen ? n : maxlen;
 }
 
-__global__ void __launch_bounds__(64) k_wfa(const int *__restrict__ n_items_p, int cap, const int32_t *__restrict__ list,
+__global__ void __launch_bounds__(64) k_wfa(const int *__restrict__ n_items_p, int cap, int first, const int32_t *__restrict__ list_,
 											const mga_wfa_prob_t *__restrict__ prob, const char *__restrict__ tseq, const char *__restrict__ qseq,
 											mga_wfa_res_t *__restrict__ res, uint32_t *__restrict__ pool, long long pool_cap, unsigned long long *pool_used,
 											char *__restrict__ ws_base, int *__restrict__ counter, mga_wfa_retry_t rt, wfa_cfg_t cfg)
@@ -83,7 +83,8 @@ __global__ void __launch_bounds__(64) k_wfa(const int *__restrict__ n_items_p, i
 	__shared__ int32_t lo_s[WF_NSLOT], hi_s[WF_NSLOT];
 	__shared__ int32_t item_s;
 	const int lane = threadIdx.x;
-	const int n_items = min(*n_items_p, cap);
+	const int n_items = max(0, min(*n_items_p, cap) - first);
+	const int32_t *__restrict__ list = list_ + first;
 	const wfa_ws_t W = wfa_carve(ws_base + (size_t)blockIdx.x * cfg.ws_stride, cfg);
 	const int32_t oe1 = cfg.o1 + cfg.e1, oe2 = cfg.o2 + cfg.e2;
 	const int32_t wmax = cfg.wmax;
@@ -310,7 +311,7 @@ static const wfa_cfg_t g_tier[3] = {
 static const int g_tier_waves[3] = { 256, 16, 2 };
 
 
-extern "C" int mga_dev_wfa(mga_sctx_t *sc, const int *d_n, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+extern "C" int mga_dev_wfa(mga_sctx_t *sc, const int *d_n, int n, int first, int slot, void *stream, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 						   mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier, mga_wfa_retry_t rt)
 {
 	if (n <= 0) return 0;
@@ -320,13 +321,13 @@ extern "C" int mga_dev_wfa(mga_sctx_t *sc, const int *d_n, int n, const int32_t 
 	if (sc->wfa_uncapped) cfg.max_iter = -1;
 	cfg.ws_stride = (int64_t)wfa_ws_bytes(cfg);
 	int waves = g_tier_waves[tier];
-	if (waves > n) waves = n;
+	if (waves > n - first) waves = n - first;
 	if (mga_dbuf_reserve(&sc->wfa_ws[7 + tier], (size_t)cfg.ws_stride * waves) < 0) return -1;
-	hipStream_t st = (hipStream_t)mga_wfa_stream(sc, 7 + tier);
-	int *d_counter = (int*)((char*)sc->wfa_cnt.p + 64 * (7 + tier));
+	hipStream_t st = (hipStream_t)(stream ? stream : sc->stream);
+	int *d_counter = (int*)((char*)sc->wfa_cnt.p + 64 * slot);
 	const int kid = MGA_K_WFA0 + 7 + (tier > 1 ? 1 : tier); // the unbounded tier is accounted with the widest regular one
 	mga_prof_begin(st, kid);
-	hipLaunchKernelGGL(k_wfa, dim3(waves), dim3(64), 0, st, d_n, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap,
+	hipLaunchKernelGGL(k_wfa, dim3(waves), dim3(64), 0, st, d_n, n, first, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap,
 					   d_pool_used, (char*)sc->wfa_ws[7 + tier].p, d_counter, rt, cfg);
 	mga_prof_end(st, kid);
 	MGA_HIP_CHECK(hipGetLastError());

@@ -41,7 +41,7 @@ struct wfr_u2 { uint32_t x, y; }; // 8 bytes with 4-byte alignment: loads become
 __device__ __forceinline__ int32_t wfr_max(int32_t a, int32_t b) { return a > b ? a : b; }
 
 template<int NW, int J, int SEQCAP, int SMAX, int TBLDS, bool TBHBM>
-__global__ void __launch_bounds__(64 * NW) k_wfa_r(const int *__restrict__ n_items_p, int cap, const int32_t *__restrict__ list,
+__global__ void __launch_bounds__(64 * NW) k_wfa_r(const int *__restrict__ n_items_p, int cap, int first, const int32_t *__restrict__ list_,
 												  const mga_wfa_prob_t *__restrict__ prob, const char *__restrict__ tseq, const char *__restrict__ qseq,
 												  mga_wfa_res_t *__restrict__ res, uint32_t *__restrict__ pool, long long pool_cap, unsigned long long *pool_used,
 												  char *__restrict__ ws_base, int *__restrict__ counter, mga_wfa_retry_t rt, wfr_cfg_t cfg)
@@ -63,7 +63,8 @@ __global__ void __launch_bounds__(64 * NW) k_wfa_r(const int *__restrict__ n_ite
 	__shared__ int32_t flags[6]; // [0] score+1 of the terminating slice, [1] its last state, [2+2p],[3+2p] "edge reachable" stamps
 	__shared__ int32_t f_item, f_mn, f_mx;
 	const int tid = threadIdx.x, lane = tid & 63;
-	const int n_items = min(*n_items_p, cap);
+	const int n_items = max(0, min(*n_items_p, cap) - first); // items first .. of the list (a rung's own problems run early, what arrives from below later)
+	const int32_t *__restrict__ list = list_ + first;
 	const int wv = NW > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
 	const int32_t oe1 = cfg.o1 + cfg.e1, oe2 = cfg.o2 + cfg.e2;
 	char *wsb = ws_base + (size_t)blockIdx.x * cfg.ws_stride;
@@ -411,7 +412,7 @@ static const wfr_tier_t g_rtier[7] = {
 	{   64,  16384,  12 << 20 },  // 16 waves x 2 slots: 2048 (a handful of problems per 10^5 reads; keeps them off the slow HBM kernel)
 };
 
-extern "C" int mga_dev_wfa_reg(mga_sctx_t *sc, const int *d_n, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+extern "C" int mga_dev_wfa_reg(mga_sctx_t *sc, const int *d_n, int n, int first, int slot, void *stream, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 							   mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier, mga_wfa_retry_t rt)
 {
 	if (n <= 0) return 0;
@@ -419,13 +420,13 @@ extern "C" int mga_dev_wfa_reg(mga_sctx_t *sc, const int *d_n, int n, const int3
 	const wfr_tier_t &T = g_rtier[tier];
 	wfr_cfg_t cfg = { 4, 4, 2, 15, 1, T.cigcap, T.tbcap, 0 }; // register ages 17/3/2 are tied to these penalties (miniwfa.c:11-18)
 	cfg.ws_stride = (int64_t)(((size_t)T.cigcap * 4 + (size_t)T.tbcap + 255) & ~(size_t)255);
-	int wgs = T.n_wg < (n + 3) / 4 ? T.n_wg : (n + 3) / 4;
+	int wgs = T.n_wg < (n - first + 3) / 4 ? T.n_wg : (n - first + 3) / 4;
 	if (wgs < 1) wgs = 1;
 	if (mga_dbuf_reserve(&sc->wfa_ws[tier], (size_t)cfg.ws_stride * T.n_wg) < 0) return -1;
-	hipStream_t st = (hipStream_t)mga_wfa_stream(sc, tier);
-	int *d_counter = (int*)((char*)sc->wfa_cnt.p + 64 * tier);
+	hipStream_t st = (hipStream_t)(stream ? stream : sc->stream);
+	int *d_counter = (int*)((char*)sc->wfa_cnt.p + 64 * slot);
 	mga_prof_begin(st, MGA_K_WFA0 + tier);
-#define LAUNCH(NW, JJ, SEQ, SM, TBL, HBM) hipLaunchKernelGGL((k_wfa_r<NW, JJ, SEQ, SM, TBL, HBM>), dim3(wgs), dim3(64 * NW), 0, st, d_n, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap, d_pool_used, (char*)sc->wfa_ws[tier].p, d_counter, rt, cfg)
+#define LAUNCH(NW, JJ, SEQ, SM, TBL, HBM) hipLaunchKernelGGL((k_wfa_r<NW, JJ, SEQ, SM, TBL, HBM>), dim3(wgs), dim3(64 * NW), 0, st, d_n, n, first, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap, d_pool_used, (char*)sc->wfa_ws[tier].p, d_counter, rt, cfg)
 	if (tier == 0) LAUNCH(1, 1, 128, 64, 2048, false); // (g_rtier[0].tbcap == 0: traceback in LDS only)
 	else if (tier == 1) LAUNCH(1, 2, 256, 128, 4096, true);
 	else if (tier == 2) LAUNCH(1, 3, 256, 192, 6144, true); // [measured] 60 ns per problem against 87 ns in the two-wave 256-diagonal tier; the centre slot alone holds the first 32 scores

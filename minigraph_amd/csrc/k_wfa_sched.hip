@@ -199,11 +199,12 @@ extern "C" int mga_dev_wfa_gather(mga_sctx_t *sc, int n, const mga_wfa_res_t *d_
 	return 0;
 }
 
-extern "C" int mga_dev_wfa_tier(mga_sctx_t *sc, const int *d_n, int cap, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+extern "C" int mga_dev_wfa_tier(mga_sctx_t *sc, const int *d_n, int cap, int first, int slot, void *stream, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 								mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier, mga_wfa_retry_t rt)
 {
-	if (tier < 7) return mga_dev_wfa_reg(sc, d_n, cap, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier, rt);
-	return mga_dev_wfa(sc, d_n, cap, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier - 7, rt); /* HBM tiers with 4096 / 32768 diagonals */
+	if (cap - first <= 0) return 0;
+	if (tier < 7) return mga_dev_wfa_reg(sc, d_n, cap, first, slot, stream, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier, rt);
+	return mga_dev_wfa(sc, d_n, cap, first, slot, stream, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, tier - 7, rt); /* HBM tiers with 4096 / 32768 diagonals */
 }
 
 // problems a sweep left undecided (their rung's list was full): collected for the next sweep
@@ -375,21 +376,44 @@ static int wfs_sweep(mga_sctx_t *sc, const wfs_ladder_t *LD, int arr_pct, int n_
 	}
 	int *rc = ctl + O_RC; // rc[t]: length of rung t's list (own problems, then arrivals); rc[15]: problems beyond the last rung
 	MGA_HIP_CHECK(hipMemcpyAsync(rc, own, NS * 4, hipMemcpyHostToDevice, st));
-	MGA_HIP_CHECK(hipMemsetAsync(sc->wfa_cnt.p, 0, 1024, st)); // the rungs' work-queue counters (one 64-byte line each)
-	int64_t tb_off[NS], tb_bytes = 0;
-	for (int t = 0; t < NR; ++t) { tb_off[t] = tb_bytes; if (LD->r[t].kind == 0 && cap[t] > 0) tb_bytes += (int64_t)cap[t] * mga_dev_wfa_win_tb_stride(LD->r[t].idx); }
-	if (tb_bytes > 0) {
-		if (mga_dbuf_reserve(&sc->wfa_tbuf[0], (size_t)tb_bytes + 256) < 0) return -1;
-		*any_tb = true;
-	}
-	for (int t = 0; t < NR; ++t) {
-		if (cap[t] <= 0) continue;
+	MGA_HIP_CHECK(hipMemsetAsync(sc->wfa_cnt.p, 0, 4096, st)); // the launches' work-queue counters (one 64-byte line each)
+	int64_t tb_bytes = 0; // traceback regions: ONE buffer, the largest windowed rung's -- every rung's walk (k_wfa_tb) runs right behind its forward pass
+	for (int t = 0; t < NR; ++t) if (LD->r[t].kind == 0 && cap[t] > 0 && (int64_t)cap[t] * mga_dev_wfa_win_tb_stride(LD->r[t].idx) > tb_bytes) tb_bytes = (int64_t)cap[t] * mga_dev_wfa_win_tb_stride(LD->r[t].idx);
+	if (tb_bytes > 0 && mga_dbuf_reserve(&sc->wfa_tbuf[0], (size_t)tb_bytes + 256) < 0) return -1;
+	(void)any_tb;
+	// The register / HBM rungs hold few, long problems (hundreds to thousands of score steps each: a launch is as long as its longest chain of them, with most of
+	// the GPU idle).  Their OWN problems depend on nothing, so they start NOW on a side stream, next to the windowed rungs that fill the machine; what ARRIVES
+	// at them from below is run by a second, short launch at the end of the sweep ([measured] 68 ms of the 225 ms of an isolated WFA phase were these tails).
+	const char *e_side = getenv("MGA_WFA_SIDE");
+	const int use_side = !(e_side && atoi(e_side) == 0); // MGA_WFA_SIDE=0: everything on one stream (bench.py's isolated pass: per-kernel timings that do not overlap)
+	hipStream_t side = use_side ? (hipStream_t)sc->tier_stream[0] : st;
+	bool forked = !use_side;
+	auto rt_of = [&](int t) {
 		const int nx = LD->r[t].next;
 		// (wfa_fb takes the problems that hit the cell cap: only the HBM tiers count cells)
-		mga_wfa_retry_t rt = { nx >= 0 ? L + base[nx] : L, rc + (nx >= 0 ? nx : 15), ctl + O_ERR, (int32_t*)sc->wfa_fb.p, ctl + O_ERR + 1, nx >= 0 ? cap[nx] : 0 };
-		if (LD->r[t].kind == 0) {
-			if (mga_dev_wfa_win(sc, rc + t, cap[t], L + base[t], d_prob, d_tseq, d_qseq, d_res, (char*)sc->wfa_tbuf[0].p + tb_off[t], LD->r[t].idx, 9 + LD->r[t].idx, rt) < 0) return -1;
-		} else if (mga_dev_wfa_tier(sc, rc + t, cap[t], L + base[t], d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, LD->r[t].idx, rt) < 0) return -1;
+		return mga_wfa_retry_t{ nx >= 0 ? L + base[nx] : L, rc + (nx >= 0 ? nx : 15), ctl + O_ERR, (int32_t*)sc->wfa_fb.p, ctl + O_ERR + 1, nx >= 0 ? cap[nx] : 0 };
+	};
+	for (int t = 0; t < NR; ++t) {
+		if (LD->r[t].kind != 1 || own[t] <= 0) continue;
+		if (!forked) {
+			MGA_HIP_CHECK(hipEventRecord((hipEvent_t)sc->ev_ready, st));
+			MGA_HIP_CHECK(hipStreamWaitEvent(side, (hipEvent_t)sc->ev_ready, 0));
+			forked = true;
+		}
+		if (mga_dev_wfa_tier(sc, rc + t, own[t], 0, LD->r[t].idx, side, L + base[t], d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, LD->r[t].idx, rt_of(t)) < 0) return -1;
+	}
+	for (int t = 0; t < NR; ++t) {
+		if (LD->r[t].kind != 0 || cap[t] <= 0) continue;
+		if (mga_dev_wfa_win(sc, rc + t, cap[t], L + base[t], d_prob, d_tseq, d_qseq, d_res, (char*)sc->wfa_tbuf[0].p, LD->r[t].idx, 9 + LD->r[t].idx, rt_of(t)) < 0) return -1;
+		if (mga_dev_wfa_traceback(sc, rc + t, cap[t], L + base[t], d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, ctl + O_ERR) < 0) return -1;
+	}
+	if (forked && use_side) {
+		MGA_HIP_CHECK(hipEventRecord((hipEvent_t)sc->ev_done[0], side));
+		MGA_HIP_CHECK(hipStreamWaitEvent(st, (hipEvent_t)sc->ev_done[0], 0));
+	}
+	for (int t = 0; t < NR; ++t) { // arrivals at the register / HBM rungs, in ascending order (a rung's own launch may itself have sent problems up)
+		if (LD->r[t].kind != 1 || cap[t] - own[t] <= 0) continue;
+		if (mga_dev_wfa_tier(sc, rc + t, cap[t], own[t], 32 + LD->r[t].idx, 0, L + base[t], d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, LD->r[t].idx, rt_of(t)) < 0) return -1;
 	}
 	int hr[16], herr = 0;
 	if (mga_d2h_s(sc, hr, rc, 16 * 4) < 0 || mga_d2h_s(sc, &herr, ctl + O_ERR, 4) < 0 || mga_ssync(sc) < 0) return -1;
@@ -398,7 +422,7 @@ static int wfs_sweep(mga_sctx_t *sc, const wfs_ladder_t *LD, int arr_pct, int n_
 		for (int t = 0; t < NR; ++t) if (hr[t]) fprintf(stderr, " %s%d: %d (+%d, room %d)", LD->r[t].kind == 0 ? "W" : "R", LD->r[t].idx, own[t], hr[t] - own[t], cap[t]);
 		fprintf(stderr, "\n");
 	}
-	if (herr) { mga_set_error("WFA: %d problems failed (CIGAR pool of %ld ops exhausted, or iteration cap)", herr, (long)pool_cap); return -1; }
+	if (herr) { mga_set_error("WFA: %d problems failed (CIGAR pool of %ld ops exhausted, iteration cap, or a traceback walked out of its window)", herr, (long)pool_cap); return -1; }
 	if (hr[15] > 0) { mga_set_error("%d WFA problems exceed the largest capacity tier", hr[15]); return -1; }
 	if (!sc->wfa_uncapped) for (int t = 0; t < NR; ++t) {
 		__atomic_fetch_add(&g_rung_n[t], (long long)(hr[t] < cap[t] ? hr[t] : cap[t]), __ATOMIC_RELAXED);
@@ -420,7 +444,7 @@ extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_
 	// ctl: hist[NBIN] | tier_off[16] | rc[2][16] | err | fb | cells (8 bytes)
 	constexpr int O_TOFF = WFS_NBIN, O_RC = O_TOFF + 16, O_ERR = O_RC + 32, O_FB = O_ERR + 1, O_CELLS = O_ERR + 2, N_CTL = O_CELLS + 2;
 	if (mga_dbuf_reserve(&sc->wfa_key, (size_t)n * 4 + 64) < 0 || mga_dbuf_reserve(&sc->wfa_fb, (size_t)n * 4 + 64) < 0 || mga_dbuf_reserve(&sc->wfa_ctl, (size_t)N_CTL * 4) < 0 ||
-		mga_dbuf_reserve(&sc->wfa_cnt, 1024) < 0) return -1;
+		mga_dbuf_reserve(&sc->wfa_cnt, 4096) < 0) return -1;
 	int *ctl = (int*)sc->wfa_ctl.p;
 	MGA_HIP_CHECK(hipMemsetAsync(ctl, 0, (size_t)N_CTL * 4, st));
 	hipLaunchKernelGGL(k_wfa_mark_pending, dim3((n + 255) / 256), dim3(256), 0, st, n, d_res);
@@ -428,7 +452,7 @@ extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_
 	bool any_tb = false;
 	int n_open = 0;
 	static int arr_pct = -1;
-	if (arr_pct < 0) { const char *e = getenv("MGA_WFA_ARRIVALS_PCT"); arr_pct = e ? atoi(e) : 25; } // (tests: 0 leaves a rung's list room for 4096 arrivals only)
+	if (arr_pct < 0) { const char *e = getenv("MGA_WFA_ARRIVALS_PCT"); arr_pct = e ? atoi(e) : 20; } // (tests: 0 leaves a rung's list room for 4096 arrivals only)
 	if (wfs_sweep(sc, LD, arr_pct, n, 0, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, ctl, &any_tb, &n_open) < 0) return -1;
 	if (n_open > 0) { // a rung's list overflowed (far more of a chunk's gaps gave up than any read set has shown): what is still open is swept again in slices whose
 		// lists have room for EVERYTHING below them (no second overflow), small enough for the traceback regions that implies
@@ -441,19 +465,9 @@ extern "C" int mga_dev_wfa_solve(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_
 		if (mga_d2h_s(sc, &k, d_cnt, 4) < 0 || mga_ssync(sc) < 0) return -1;
 		MGA_HIP_CHECK(hipMemsetAsync(d_cnt, 0, 8, st));
 		for (int o = 0; o < k; o += SLICE) {
-			if (any_tb) { // the windowed rungs' regions are reused by the next sweep: walk them now
-				if (mga_dev_wfa_traceback(sc, n, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, ctl + O_ERR) < 0) return -1;
-				any_tb = false;
-			}
 			if (wfs_sweep(sc, LD, 100, k - o < SLICE ? k - o : SLICE, (const int32_t*)sc->wfa_list[1].p + o, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, ctl, &any_tb, &n_open) < 0) return -1;
 			if (n_open > 0) { mga_set_error("WFA ladder: %d problems open after a sweep with room for all", n_open); return -1; }
 		}
-	}
-	if (any_tb) { // the windowed rungs left scores + traceback regions: CIGARs into the pool, one lane per problem
-		int herr = 0;
-		if (mga_dev_wfa_traceback(sc, n, d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, ctl + O_ERR) < 0) return -1;
-		if (mga_d2h_s(sc, &herr, ctl + O_ERR, 4) < 0 || mga_ssync(sc) < 0) return -1;
-		if (herr) { mga_set_error("WFA traceback: %d problems failed (CIGAR pool of %ld ops exhausted, or a walk left its window)", herr, (long)pool_cap); return -1; }
 	}
 	{ // problems the exact pass gave up on (> 1e8 cells): miniwfa's chained fallback (miniwfa.c:829-832)
 		int n_fb = 0;

@@ -157,26 +157,28 @@ enum { MGA_WFA_OK = 0, MGA_WFA_PENDING = 1, MGA_WFA_RETRY_TIER = 2, MGA_WFA_POOL
  * the problems that hit the reference's 1e8-cell cap (miniwfa.c:827): they are re-done by the chained fallback (k_wfa_sched.hip) */
 typedef struct { int32_t *list; int *cnt; int *err; int32_t *fb_list; int *fb_cnt; int32_t cap; } mga_wfa_retry_t; /* (cap: room of `list`; *cnt runs past it when it overflows) */
 
-/* All tier launchers: the work list is d_list[0 .. min(*d_n, cap)) -- the count is read ON THE DEVICE when the kernel starts, so that a rung can take what
- * the rungs below it appended in the same sweep without a host round trip; cap sizes the launch.
+/* All tier launchers: the work list is d_list[first .. min(*d_n, cap)) -- the count is read ON THE DEVICE when the kernel starts, so that a rung can take what
+ * the rungs below it appended in the same sweep without a host round trip; cap sizes the launch; slot picks the 64-byte work-queue counter of the launch
+ * (zeroed by the caller), stream the HIP stream (NULL: the context's).
  * solves problems of the list in HBM-resident capacity tier 0..1 (4096 / 32768 diagonals); cigars are
  * appended to d_pool (capacity pool_cap ops, *d_pool_used bumped atomically); sequences must be padded by >= 8 readable bytes */
-int mga_dev_wfa(mga_sctx_t *sc, const int *d_n, int cap, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+int mga_dev_wfa(mga_sctx_t *sc, const int *d_n, int cap, int first, int slot, void *stream, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 				mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier, mga_wfa_retry_t rt);
 /* register-resident tiers (k_wfa_r.hip): tier 0-2 one wave per problem (64, 128, 192 diagonals), 3-6 two to sixteen waves (256, 512, 1024, 2048) */
-int mga_dev_wfa_reg(mga_sctx_t *sc, const int *d_n, int cap, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+int mga_dev_wfa_reg(mga_sctx_t *sc, const int *d_n, int cap, int first, int slot, void *stream, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 					mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier, mga_wfa_retry_t rt);
 /* windowed tiers (k_wfa_w.hip): forward pass of tier wt (0..5) over d_list; traceback bytes go to d_tb + item * mga_dev_wfa_win_tb_stride(wt); `slot` picks the
- * work-queue counter / stream.  mga_dev_wfa_traceback() then turns every MGA_WFA_TB result of d_res[0..n) into score + CIGAR in the pool (MGA_WFA_OK). */
+ * work-queue counter.  mga_dev_wfa_traceback() then turns every MGA_WFA_TB result of the SAME list into score + CIGAR in the pool (MGA_WFA_OK); it runs right
+ * behind the rung's forward pass, so that ONE region buffer (the largest rung's) serves the whole sweep. */
 int64_t mga_dev_wfa_win_tb_stride(int wt);
 int mga_dev_wfa_win(mga_sctx_t *sc, const int *d_n, int cap, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 					mga_wfa_res_t *d_res, char *d_tb, int wt, int slot, mga_wfa_retry_t rt);
-int mga_dev_wfa_traceback(mga_sctx_t *sc, int n, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq, mga_wfa_res_t *d_res,
+int mga_dev_wfa_traceback(mga_sctx_t *sc, const int *d_n, int cap, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq, mga_wfa_res_t *d_res,
 						  uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int *d_err);
 int32_t mga_wfw_window(int32_t W, int32_t tl, int32_t ql, int32_t *lo);
 /* tier 0..8: register tiers (one wave, then 2-16 waves per problem), then the HBM-resident tiers */
 int mga_wfa_first_tier(int32_t tl, int32_t ql); /* cheapest tier likely to fit, from the sequence lengths */
-int mga_dev_wfa_tier(mga_sctx_t *sc, const int *d_n, int cap, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
+int mga_dev_wfa_tier(mga_sctx_t *sc, const int *d_n, int cap, int first, int slot, void *stream, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 					 mga_wfa_res_t *d_res, uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int tier, mga_wfa_retry_t rt);
 /* the whole ladder (k_wfa_sched.hip): every problem in its first tier, the ones that outgrow it one tier up, until none is left;
  * d_res[i] / d_pool hold the results; *cells (optional) = total wavefront cells */
