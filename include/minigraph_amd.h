@@ -307,6 +307,13 @@ typedef struct {
 } mga_stats_t;
 void mga_get_stats(const mg_idx_t *gi, mga_stats_t *st, int reset);
 
+/* ---- ADDITIVE: the graph as one binary image (csrc/image.c).  Written once from a gfa_t (after or before mg_index), then MAPPED instead of parsed:
+ * replaces gfa_read (gfa-io.c:294) + gfa_finalize (gfa-base.c:421-430) + gfa_edseq_init (gfa-ed.c:24-42) + the host half of mg_index (index.c:186-230) for
+ * repeated runs and for the N ranks of a node.  The minimizer table is rebuilt on the device from the sequence (k, w stay load-time options).
+ * The loaded index OWNS its graph (gi->g): mg_idx_destroy() releases it; do not gfa_destroy() it. ---- */
+int mga_graph_image_save(const gfa_t *g, const char *path);
+mg_idx_t *mga_index_load_image(const char *path, const mg_idxopt_t *io, int n_threads, mg_mapopt_t *mo);
+
 /* ---- stage-level entry points (host pointers in, host pointers out; device work inside) ----
  * Each replaces the per-read reference routine named in its comment for a whole batch.  Outputs are
  * malloc()'ed by the callee and released with mga_free().  All return 0 on success, <0 on error. */

@@ -93,6 +93,9 @@ def load():
     L.mg_index.argtypes = [C.c_void_p, C.POINTER(idxopt_t), C.c_int, C.POINTER(mapopt_t)]
     L.mg_index.restype = C.c_void_p
     L.mg_idx_destroy.argtypes = [C.c_void_p]
+    L.mga_graph_image_save.argtypes = [C.c_void_p, C.c_char_p]
+    L.mga_index_load_image.argtypes = [C.c_char_p, C.POINTER(idxopt_t), C.c_int, C.POINTER(mapopt_t)]
+    L.mga_index_load_image.restype = C.c_void_p
     L.mga_seed_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, pp, pp, pp, pp, pp]
     L.mga_lchain_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.POINTER(lchain_par_t), pp, pp, pp, pp]
     L.mga_map_files_to_path.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(idxopt_t),
@@ -169,7 +172,8 @@ def wfa_batch(targets, queries):
 class Graph:
     """gfa_read() + mg_index(): the graph and its minimizer index (host + HBM replica)."""
 
-    def __init__(self, path, preset="lr", cigar=True, n_threads=4):
+    def __init__(self, path, preset="lr", cigar=True, n_threads=4, image=False):
+        """image=True: `path` is a graph image written by save_image() (mga_graph_image_save): mapped, not parsed; the index owns the graph"""
         L = load()
         self.io, self.mo, self.go = idxopt_t(), mapopt_t(), ggopt_t()
         L.mg_opt_set(None, C.byref(self.io), C.byref(self.mo), C.byref(self.go))
@@ -177,12 +181,24 @@ class Graph:
             raise ValueError("unknown preset %r" % preset)
         if cigar:
             self.mo.flag |= MG_M_CIGAR
+        if image:
+            self.g = None
+            self.gi = L.mga_index_load_image(path.encode(), C.byref(self.io), n_threads, C.byref(self.mo))
+            if not self.gi:
+                raise RuntimeError("mga_index_load_image(%s) failed: %s" % (path, L.mga_last_error().decode()))
+            return
         self.g = L.gfa_read(path.encode())
         if not self.g:
             raise RuntimeError("gfa_read(%s) failed" % path)
         self.gi = L.mg_index(self.g, C.byref(self.io), n_threads, C.byref(self.mo))
         if not self.gi:
             raise RuntimeError("mg_index failed: %s" % L.mga_last_error().decode())
+
+    def save_image(self, path):
+        """the graph as one binary image (mga_graph_image_save): Graph(path, image=True) maps it instead of parsing GFA text"""
+        if not self.g:
+            raise RuntimeError("this graph was loaded from an image")
+        _check(load().mga_graph_image_save(self.g, path.encode()), "mga_graph_image_save")
 
     def close(self):
         L = load()

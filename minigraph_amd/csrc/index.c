@@ -82,6 +82,77 @@ mg_idx_t *mga_idx_hostpart_mt(gfa_t *g, const mg_idxopt_t *io, int n_threads)
 
 mg_idx_t *mga_idx_hostpart(gfa_t *g, const mg_idxopt_t *io) { return mga_idx_hostpart_mt(g, io, 1); }
 
+/* the same for a graph image: sequences are upper case already, the reverse complements go into ONE block (rc, segment s at off[s]) */
+typedef struct { const gfa_t *g; gfa_edseq_t *es; const int64_t *off; char *rc; } esb_t;
+static void edseq_blob_worker(void *data, int64_t s, int tid)
+{
+	esb_t *w = (esb_t*)data;
+	const gfa_seg_t *p = &w->g->seg[s];
+	char *t = w->rc + w->off[s];
+	int32_t q;
+	(void)tid;
+	for (q = 0; q < p->len; ++q) t[p->len - q - 1] = (char)mga_comp_table[(uint8_t)p->seq[q]];
+	w->es[s<<1].seq = p->seq, w->es[s<<1|1].seq = t;
+	w->es[s<<1].len = w->es[s<<1|1].len = p->len;
+}
+mg_idx_t *mga_idx_hostpart_blob(gfa_t *g, const mg_idxopt_t *io, int n_threads, const int64_t *off, char *rc)
+{
+	mg_idx_t *gi = MGA_CALLOC(mg_idx_t, 1);
+	gfa_edseq_t *es = MGA_MALLOC(gfa_edseq_t, (size_t)g->n_seg * 2 + 1);
+	esb_t w;
+	int k = io->k, wd = io->w, b = io->bucket_bits;
+	mga_tables_init();
+	if (k * 2 < b) b = k * 2;
+	if (wd < 1) wd = 1;
+	w.g = g, w.es = es, w.off = off, w.rc = rc;
+	mga_parallel_for(n_threads, g->n_seg, edseq_blob_worker, &w);
+	gi->g = g, gi->w = wd, gi->k = k, gi->b = b, gi->n_seg = (int32_t)g->n_seg, gi->es = es, gi->B = 0;
+	return gi;
+}
+
+/* the index of a graph whose (upper-cased) forward sequences lie back to back in `cat` (segment s at off[s]): upload, device build of the minimizer table
+ * (k_index.hip), graph replica, host handle.  es_rc != NULL: the reverse-complement images of the segments, same offsets, owned by the caller (graph image). */
+mg_idx_t *mga_idx_from_cat(gfa_t *g, const mg_idxopt_t *io, int n_threads, const char *cat, const int64_t *off, const int32_t *seg_len, int64_t tot, char *es_rc)
+{
+	mga_sctx_t *sc = mga_sctx_default();
+	struct mg_idx_bucket_s *B = MGA_CALLOC(struct mg_idx_bucket_s, 1);
+	mg_idx_t *gi;
+	int k = io->k, w = io->w < 1 ? 1 : io->w;
+	const int dbg = getenv("MGA_DEBUG_INDEX") && atoi(getenv("MGA_DEBUG_INDEX")) > 0; /* phase times of the build to stderr */
+	double t0 = mga_wtime(), t1;
+#define IDX_T(what) do { if (dbg) { mga_dsync(); t1 = mga_wtime(); fprintf(stderr, "[index] %-28s %.3f s\n", what, t1 - t0); t0 = t1; } } while (0)
+	B->dev.n_seg = (int32_t)g->n_seg;
+	B->dev.d_seg_len = (int32_t*)mga_dmalloc((size_t)(g->n_seg + 1) * 4);
+	B->dev.d_gseq = (char*)mga_dmalloc((size_t)tot + 64);
+	B->dev.d_gseq_off = (int64_t*)mga_dmalloc((size_t)(g->n_seg + 1) * 8);
+	IDX_T("device buffers");
+	if (sc == 0 || !B->dev.d_seg_len || !B->dev.d_gseq || !B->dev.d_gseq_off ||
+		mga_h2d(B->dev.d_seg_len, seg_len, (size_t)g->n_seg * 4) < 0 || mga_h2d_big(B->dev.d_gseq, cat, (size_t)tot, n_threads) < 0 || mga_dmemset((char*)B->dev.d_gseq + tot, 0, 64) < 0 ||
+		mga_h2d(B->dev.d_gseq_off, off, (size_t)(g->n_seg + 1) * 8) < 0 || mga_dev_text_tables(mga_comp_table, mga_nt4_table) < 0) {
+		mga_dfree(B->dev.d_seg_len); mga_dfree(B->dev.d_gseq); mga_dfree(B->dev.d_gseq_off);
+		free(B);
+		return 0;
+	}
+	IDX_T("sequence -> HBM");
+	if (mga_dev_index_build(sc, (int)g->n_seg, B->dev.d_gseq, B->dev.d_gseq_off, w, k, &B->dev, &B->n_keys, &B->n_mz, &B->occ_hist, &B->max_occ_seen) < 0) {
+		mga_dfree(B->dev.d_seg_len); mga_dfree(B->dev.d_gseq); mga_dfree(B->dev.d_gseq_off);
+		free(B);
+		return 0;
+	}
+	IDX_T("minimizer table (device)");
+	if (mga_dev_graph_upload(sc, g, mga_comp_table, &B->dev) < 0) { /* arcs + reverse complements: graph chaining runs on the device (k_gchain.hip) */
+		mga_dfree(B->dev.d_seg_len); mga_dfree(B->dev.d_gseq); mga_dfree(B->dev.d_gseq_off); mga_dfree(B->dev.d_tab); mga_dfree(B->dev.d_pos);
+		mga_dfree(B->dev.d_arc); mga_dfree(B->dev.d_arc_idx); mga_dfree(B->dev.d_gseq_rc); free(B->occ_hist); free(B);
+		return 0;
+	}
+	IDX_T("graph replica");
+	gi = es_rc ? mga_idx_hostpart_blob(g, io, n_threads, off, es_rc) : mga_idx_hostpart_mt(g, io, n_threads);
+	gi->B = B;
+	IDX_T("host reverse complements");
+#undef IDX_T
+	return gi;
+}
+
 mg_idx_t *mg_index(gfa_t *g, const mg_idxopt_t *io, int n_threads, mg_mapopt_t *mo)
 {
 	mg_idx_t *gi;
@@ -119,32 +190,12 @@ mg_idx_t *mg_index(gfa_t *g, const mg_idxopt_t *io, int n_threads, mg_mapopt_t *
 	cat = (char*)malloc((size_t)tot + 1);
 	for (s = 0; s < g->n_seg; ++s) if (g->seg[s].seq) memcpy(cat + off[s], g->seg[s].seq, (size_t)g->seg[s].len);
 	if (!(getenv("MGA_HOST_INDEX") && atoi(getenv("MGA_HOST_INDEX")) > 0)) { /* the whole build on the device (k_index.hip); MGA_HOST_INDEX=1 keeps the host build below (A/B) */
-		mga_sctx_t *sc = mga_sctx_default();
 		free(rid);
-		B = MGA_CALLOC(struct mg_idx_bucket_s, 1);
-		B->dev.n_seg = (int32_t)g->n_seg;
-		B->dev.d_seg_len = (int32_t*)mga_dmalloc((size_t)(g->n_seg + 1) * 4);
-		B->dev.d_gseq = (char*)mga_dmalloc((size_t)tot + 64);
-		B->dev.d_gseq_off = (int64_t*)mga_dmalloc((size_t)(g->n_seg + 1) * 8);
-		if (sc == 0 || !B->dev.d_seg_len || !B->dev.d_gseq || !B->dev.d_gseq_off ||
-			mga_h2d(B->dev.d_seg_len, seg_len, (size_t)g->n_seg * 4) < 0 || mga_h2d(B->dev.d_gseq, cat, (size_t)tot) < 0 || mga_dmemset((char*)B->dev.d_gseq + tot, 0, 64) < 0 ||
-			mga_h2d(B->dev.d_gseq_off, off, (size_t)(g->n_seg + 1) * 8) < 0 || mga_dev_text_tables(mga_comp_table, mga_nt4_table) < 0 ||
-			mga_dev_index_build(sc, (int)g->n_seg, B->dev.d_gseq, B->dev.d_gseq_off, w, k, &B->dev, &B->n_keys, &B->n_mz, &B->occ_hist, &B->max_occ_seen) < 0) {
-			mga_dfree(B->dev.d_seg_len); mga_dfree(B->dev.d_gseq); mga_dfree(B->dev.d_gseq_off);
-			free(off); free(seg_len); free(cat); free(B);
-			return 0;
-		}
+		gi = mga_idx_from_cat(g, io, n_threads, cat, off, seg_len, tot, 0);
 		free(off); free(seg_len); free(cat);
-		if (mga_dev_graph_upload(sc, g, mga_comp_table, &B->dev) < 0) { /* arcs + reverse complements: graph chaining runs on the device (k_gchain.hip) */
-			mga_dfree(B->dev.d_seg_len); mga_dfree(B->dev.d_gseq); mga_dfree(B->dev.d_gseq_off); mga_dfree(B->dev.d_tab); mga_dfree(B->dev.d_pos);
-			mga_dfree(B->dev.d_arc); mga_dfree(B->dev.d_arc_idx); mga_dfree(B->dev.d_gseq_rc); free(B->occ_hist); free(B);
-			return 0;
-		}
-		gi = mga_idx_hostpart_mt(g, io, n_threads);
-		gi->B = B;
+		if (gi == 0) return 0;
 		if (mg_verbose >= 3)
-			fprintf(stderr, "[M::%s::%.3f] indexed the graph on the device: %ld minimizers, %ld distinct, table 2^%d slots\n", __func__, mga_wtime() - t0, (long)B->n_mz, (long)B->n_keys, B->dev.bits);
-		(void)n_threads;
+			fprintf(stderr, "[M::%s::%.3f] indexed the graph on the device: %ld minimizers, %ld distinct, table 2^%d slots\n", __func__, mga_wtime() - t0, (long)gi->B->n_mz, (long)gi->B->n_keys, gi->B->dev.bits);
 		if (mo) mg_opt_update(gi, mo, 0);
 		return gi;
 	}
@@ -228,12 +279,13 @@ void mg_idx_destroy(mg_idx_t *gi)
 		mga_dfree(gi->B->dev.d_tab); mga_dfree(gi->B->dev.d_pos); mga_dfree(gi->B->dev.d_seg_len); mga_dfree(gi->B->dev.d_gseq); mga_dfree(gi->B->dev.d_gseq_off);
 		mga_dfree(gi->B->dev.d_arc); mga_dfree(gi->B->dev.d_arc_idx); mga_dfree(gi->B->dev.d_gseq_rc);
 		free(gi->B->occ_hist); free(gi->B->gaf_out);
-		free(gi->B);
 	}
 	if (gi->es) {
-		for (i = 0; i < gi->n_seg; ++i) free((char*)gi->es[i<<1|1].seq);
+		if (!(gi->B && gi->B->img_rc)) for (i = 0; i < gi->n_seg; ++i) free((char*)gi->es[i<<1|1].seq);
 		free(gi->es);
 	}
+	if (gi->B && gi->B->img_g) mga_graph_image_release(gi->B); /* an index loaded from a graph image owns its gfa_t, the mapped file and the reverse-complement block */
+	free(gi->B);
 	free(gi);
 }
 

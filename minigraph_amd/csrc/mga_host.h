@@ -66,7 +66,13 @@ struct mg_idx_bucket_s {
 	int64_t gaf_cap;
 	void *stream;            /* mga_stream_t of the single-batch entry points (mapper.c), created on first use */
 	void *mf_cache;          /* read batches (pinned) and output buffers of mg_map_files jobs on this index (mapfiles.c), reused from job to job */
+	/* an index loaded from a graph image (image.c) owns these: */
+	gfa_t *img_g; void *img_map; size_t img_map_bytes; char *img_rc; int64_t *img_off;
 };
+void mga_graph_image_release(struct mg_idx_bucket_s *B);
+mg_idx_t *mga_idx_from_cat(gfa_t *g, const mg_idxopt_t *io, int n_threads, const char *cat, const int64_t *off, const int32_t *seg_len, int64_t tot, char *es_rc);
+mg_idx_t *mga_idx_hostpart_blob(gfa_t *g, const mg_idxopt_t *io, int n_threads, const int64_t *off, char *rc);
+int mga_h2d_big(void *d, const void *h, size_t bytes, int n_threads); /* pageable host memory -> HBM through pinned staging blocks filled by several threads */
 
 /* ---- the chunk pipeline as a persistent object (mapper.c) ---- */
 typedef struct mga_stream_s mga_stream_t;
