@@ -208,7 +208,7 @@ def main():
             def mapper(r, w):
                 m = mga.map_files_idx(G, [reads_path], n_threads=threads, rank=r, world=w, reuse=last.get("shard"))
                 last["shard"] = m
-                return m.view(), m.seg_len
+                return m.view(), m.seg_len, m.cap   # (the shard's buffer is the library's: page-locked once through its registry, which unregisters before any realloc / free)
             last["gaf_bytes"] = map_sharded(mapper, dst=0, device=coll_dev, as_tensor=True)   # ONE uint8 tensor on rank 0, input order
 
     def sync():

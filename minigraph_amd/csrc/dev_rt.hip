@@ -278,6 +278,36 @@ extern "C" void *mga_hmalloc_pinned(size_t bytes)
 
 extern "C" void mga_hfree_pinned(void *p) { if (p) (void)hipHostFree(p); }
 
+// ---- page-locking of host buffers the LIBRARY owns (the GAF output buffer of mga_map_files_shard, handed back for reuse from step to step): the registry
+// lives here so that every path that frees or reallocates such a buffer -- mga_free(), the writer's realloc, a failed job -- unregisters it first
+// (hipHostRegister from Python on a malloc'ed block the C side later realloc'ed or freed left stale registrations behind) ----
+static struct { void *p; size_t n; } g_pins[64];
+static int g_n_pins = 0;
+static std::mutex g_pin_mtx;
+
+extern "C" void mga_host_unpin(void *p)
+{
+	if (p == 0) return;
+	std::lock_guard<std::mutex> lk(g_pin_mtx);
+	for (int i = 0; i < g_n_pins; ++i)
+		if (g_pins[i].p == p) { (void)hipHostUnregister(p); g_pins[i] = g_pins[--g_n_pins]; return; }
+}
+
+extern "C" int mga_host_pin(void *p, size_t bytes) // 0: registered (or already was, with at least `bytes`); -1: left pageable
+{
+	if (p == 0 || bytes == 0 || mga_dev_init() < 0) return -1;
+	std::lock_guard<std::mutex> lk(g_pin_mtx);
+	for (int i = 0; i < g_n_pins; ++i)
+		if (g_pins[i].p == p) {
+			if (g_pins[i].n >= bytes) return 0;
+			(void)hipHostUnregister(p); g_pins[i] = g_pins[--g_n_pins];
+			break;
+		}
+	if (g_n_pins == 64 || hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return -1; }
+	g_pins[g_n_pins].p = p, g_pins[g_n_pins].n = bytes, ++g_n_pins;
+	return 0;
+}
+
 extern "C" double mga_wtime(void)
 {
 	struct timespec ts;
@@ -303,33 +333,35 @@ extern "C" void mga_dbuf_free(mga_dbuf_t *b)
 	b->p = 0, b->cap = 0;
 }
 
-// ---- exclusive scan int32 -> int64 (single workgroup, 1024 threads; n up to a few million) ----
-__global__ void __launch_bounds__(1024) k_scan_i32_i64(const int32_t *__restrict__ cnt, int64_t n, int64_t *__restrict__ off)
+// ---- exclusive scan int32 -> int64 (single workgroup of 256 threads; n up to a few 10^4: the per-read counts of a chunk) ----
+// 256 threads, not 1024: in the pipeline this kernel is launched while persistent WFA workgroups of other chunks hold most wave slots, and a 16-wave
+// workgroup then waits for a whole CU to drain ([measured] round 2: 1.2-1.7 ms per call, 3.6 % of the stream time, for 20 us of work); four waves fit
+// into the gaps.  Each thread takes 4 consecutive counts per trip, so a trip still covers 1024.
+__global__ void __launch_bounds__(256) k_scan_i32_i64(const int32_t *__restrict__ cnt, int64_t n, int64_t *__restrict__ off)
 {
-	__shared__ int64_t wsum[16];
+	__shared__ int64_t wsum[4];
 	__shared__ int64_t carry;
 	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 	if (threadIdx.x == 0) carry = 0;
 	__syncthreads();
 	for (int64_t base = 0; base < n; base += 1024) {
-		int64_t i = base + threadIdx.x;
-		int64_t v = i < n ? (int64_t)cnt[i] : 0, x = v;
-		for (int d = 1; d < 64; d <<= 1) { // inclusive scan inside the wave
+		const int64_t i0 = base + (int64_t)threadIdx.x * 4;
+		int64_t v[4], s = 0;
+#pragma unroll
+		for (int r = 0; r < 4; ++r) { v[r] = i0 + r < n ? (int64_t)cnt[i0 + r] : 0; s += v[r]; }
+		int64_t x = s;
+		for (int d = 1; d < 64; d <<= 1) { // inclusive scan of the threads' sums inside the wave
 			int64_t y = __shfl_up(x, d);
 			if (lane >= d) x += y;
 		}
 		if (lane == 63) wsum[wid] = x;
 		__syncthreads();
-		if (wid == 0) {
-			int64_t s = lane < 16 ? wsum[lane] : 0, t = s;
-			for (int d = 1; d < 16; d <<= 1) { int64_t y = __shfl_up(t, d); if (lane >= d) t += y; }
-			if (lane < 16) wsum[lane] = t - s; // exclusive prefix of wave sums
-		}
+		int64_t run = carry + x - s;
+		for (int w = 0; w < wid; ++w) run += wsum[w];
+#pragma unroll
+		for (int r = 0; r < 4; ++r) { if (i0 + r < n) off[i0 + r] = run; run += v[r]; }
 		__syncthreads();
-		int64_t c = carry;
-		if (i < n) off[i] = c + wsum[wid] + x - v;
-		__syncthreads();
-		if (threadIdx.x == 1023) carry = c + wsum[wid] + x;
+		if (threadIdx.x == 255) carry = run;
 		__syncthreads();
 	}
 	if (threadIdx.x == 0) off[n] = carry;
@@ -404,7 +436,7 @@ extern "C" int mga_dev_scan_i32_to_i64(mga_sctx_t *sc, const int32_t *d_cnt, int
 {
 	hipStream_t st = (hipStream_t)sc->stream;
 	mga_prof_begin(sc->stream, MGA_K_SCAN);
-	if (n <= 4 * SCAN_TILE) hipLaunchKernelGGL(k_scan_i32_i64, dim3(1), dim3(1024), 0, st, d_cnt, n, d_off);
+	if (n <= 4 * SCAN_TILE) hipLaunchKernelGGL(k_scan_i32_i64, dim3(1), dim3(256), 0, st, d_cnt, n, d_off);
 	else {
 		const int nb = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
 		if (mga_dbuf_reserve(&sc->scan_tmp, (size_t)(nb + 1) * 8) < 0) return -1;

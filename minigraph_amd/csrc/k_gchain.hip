@@ -149,7 +149,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
 	}
 }
 
-extern "C" size_t mga_dev_gchain_arena_bytes(int tier) { return tier == 0 ? (size_t)1 << 20 : (size_t)256 << 20; }
+extern "C" size_t mga_dev_gchain_arena_bytes(int tier)
+{ // MGA_GC_ARENA_KB / MGA_GC_ARENA1_KB: scratch per wavefront of the first launch / of the retry launch (tests: small values push reads through the retry and on to the host)
+	const char *e = getenv(tier == 0 ? "MGA_GC_ARENA_KB" : "MGA_GC_ARENA1_KB");
+	if (e && atoi(e) > 0) return (size_t)atoi(e) << 10;
+	return tier == 0 ? (size_t)1 << 20 : (size_t)256 << 20;
+}
 extern "C" int mga_dev_gchain_waves(int tier) { static int w0 = 0; if (w0 == 0) { const char *e = getenv("MGA_GC_WAVES"); w0 = e && atoi(e) > 0 ? atoi(e) : 2048; } return tier == 0 ? w0 : 24; } /* tier 0: 256 CUs x 4 SIMDs x 2 resident waves (246 VGPRs, no spills: [measured] same kernel time as 4 waves with 513 spills) */
 
 static void gc_par_from_opt(const mg_mapopt_t *opt, int k, float pen_gap, gc_par_t *P)

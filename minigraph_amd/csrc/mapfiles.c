@@ -27,8 +27,9 @@ typedef struct { char *s; size_t l, m; } str_t;
 static inline void str_room(str_t *s, size_t extra) { if (s->l + extra + 2 > s->m) { s->m = (s->l + extra + 2) * 2; if (s->m < 256) s->m = 256; s->s = (char*)realloc(s->s, s->m); } }
 static inline void str_c(str_t *s, int c) { str_room(s, 1); s->s[s->l++] = (char)c; s->s[s->l] = 0; }
 
-/* the rest of the current line: appended to s when s != NULL (a trailing '\r' is dropped, as kseq does), the '\n' is consumed */
-static void rd_line(rd_t *r, str_t *s)
+/* the rest of the current line: appended to s when s != NULL, the '\n' is consumed.  A trailing '\r' is dropped the way kseq does it (kseq.h ks_getuntil2:
+ * "str->l > 1 && last == '\r'", with str->l counted from the start of the record's field: l0) */
+static void rd_line_from(rd_t *r, str_t *s, size_t l0)
 {
 	while (rd_fill(r)) {
 		char *p = r->buf + r->beg, *q = (char*)memchr(p, '\n', (size_t)(r->end - r->beg));
@@ -37,16 +38,17 @@ static void rd_line(rd_t *r, str_t *s)
 		r->beg += (int64_t)n + (q ? 1 : 0);
 		if (q) break;
 	}
-	if (s && s->l > 0 && s->s[s->l - 1] == '\r') s->s[--s->l] = 0;
+	if (s && s->l - l0 > 1 && s->s[s->l - 1] == '\r') s->s[--s->l] = 0;
 }
+static void rd_line(rd_t *r, str_t *s) { rd_line_from(r, s, 0); }
 
 /* one FASTA/FASTQ record (kseq semantics, bseq.c:61-98 via kseq.h); returns 0, or -1 at EOF.  `last` carries a record
  * marker that was read as the first character of a line between calls.  Lines are moved with memchr/memcpy. */
 static int read_record_x(rd_t *r, int *last, str_t *name, str_t *seq, int append) /* append: the bases go behind what seq already holds (the caller's slab) */
 {
 	int c;
-	if (*last == 0) { /* find the next record: a marker at the start of a line */
-		while ((c = rd_getc(r)) >= 0 && c != '>' && c != '@') if (c != '\n') rd_line(r, 0);
+	if (*last == 0) { /* find the next record: the next '>' or '@' WHEREVER it stands, as kseq does (kseq.h:180-184; ADVICE r2: a marker behind garbage on the same line) */
+		while ((c = rd_getc(r)) >= 0 && c != '>' && c != '@') {}
 		if (c < 0) return -1;
 		*last = c;
 	}
@@ -63,21 +65,24 @@ static int read_record_x(rd_t *r, int *last, str_t *name, str_t *seq, int append
 	while ((c = rd_getc(r)) >= 0 && c != '>' && c != '+' && c != '@') {
 		if (c == '\n') continue;
 		str_c(seq, c);
-		rd_line(r, seq);
+		rd_line_from(r, seq, seq0);
 	}
 	if (c == '>' || c == '@') *last = c;
 	else *last = 0;
 	if (c == '+') { /* FASTQ: skip the '+' line and as many quality characters as bases */
 		size_t ql = 0;
+		int tail = 0; /* last character of the current quality line so far (a line may arrive in several buffer fills) */
 		rd_line(r, 0);
 		while (ql < seq->l - seq0 && rd_fill(r)) {
 			char *p = r->buf + r->beg, *q = (char*)memchr(p, '\n', (size_t)(r->end - r->beg));
 			size_t n = q ? (size_t)(q - p) : (size_t)(r->end - r->beg);
 			r->beg += (int64_t)n + (q ? 1 : 0);
-			if (n > 0 && p[n - 1] == '\r') --n;
+			if (n > 0) tail = p[n - 1];
 			ql += n;
+			if (q) { if (ql > 1 && tail == '\r') --ql; tail = 0; } /* (the running length decides about a '\r', as for the bases) */
 		}
 		*last = 0;
+		if (ql != seq->l - seq0) return -1; /* a quality string of another length ends the file: kseq_read returns -2 and bseq.c:66 stops reading */
 	}
 	return 0;
 }
@@ -299,7 +304,7 @@ static void fa_scan_worker1(void *data, int64_t j, int tid)
 			if (c == '+' || c == '@') { L->anomaly = 1; break; }
 			q = (const char*)memchr(p, '\n', (size_t)(end - p));
 			n = q ? q - p : end - p;
-			if (n > 0 && p[n - 1] == '\r') --n;
+			if (n > 0 && p[n - 1] == '\r' && r.nb + n > 1) --n; /* kseq drops a line's trailing CR only once the record holds more than that one character (kseq.h ks_getuntil2) */
 			r.nb += n;
 			p = q ? q + 1 : end;
 		}
@@ -360,7 +365,7 @@ static void fa_fill_worker1(void *data, int64_t i, int tid)
 		const char *q = (const char*)memchr(p, '\n', (size_t)(r->end - p));
 		size_t n = q ? (size_t)(q - p) : (size_t)(r->end - p);
 		const char *nx = q ? q + 1 : r->end;
-		if (n > 0 && p[n - 1] == '\r') --n;
+		if (n > 0 && p[n - 1] == '\r' && (size_t)(dst - d0) + n > 1) --n; /* (the same rule as in pass 1) */
 		seq_copy_normalize(dst, p, n); dst += n;
 		p = nx;
 	}
@@ -584,7 +589,7 @@ static void *writer_main(void *a)
 		if (!W->err && w->len > 0) {
 			if (s->fp) { if (fwrite(w->buf, 1, (size_t)w->len, s->fp) != (size_t)w->len) { fprintf(stderr, "[E::%s] failed to write the results\n", __func__); W->err = 1; } }
 			else {
-				if (s->mem_len + w->len + 1 > s->mem_cap) { s->mem_cap = (s->mem_len + w->len + 1) * 3 / 2; s->mem = (char*)realloc(s->mem, (size_t)s->mem_cap); }
+				if (s->mem_len + w->len + 1 > s->mem_cap) { s->mem_cap = (s->mem_len + w->len + 1) * 3 / 2; mga_host_unpin(s->mem); s->mem = (char*)realloc(s->mem, (size_t)s->mem_cap); }
 				memcpy(s->mem + s->mem_len, w->buf, (size_t)w->len); s->mem_len += w->len;
 			}
 		}
@@ -649,14 +654,18 @@ int mga_map_files_shard(const mg_idx_t *gi, int n_fn, const char **fn, const mg_
 	mga_stream_t *S;
 	const double t0 = mga_wtime();
 	memset(&sink, 0, sizeof sink);
-	if (mem) { sink.mem = *mem, sink.mem_cap = *mem && mem_cap ? *mem_cap : 0; if (sink.mem_cap == 0) sink.mem = 0; *mem = 0, *mem_len = 0; sink.to_mem = 1; }
+	if (mem) { /* a buffer to reuse comes with its capacity; one without is released, not dropped */
+		sink.mem = *mem, sink.mem_cap = *mem && mem_cap ? *mem_cap : 0;
+		if (sink.mem_cap == 0 && sink.mem) { mga_host_unpin(sink.mem); free(sink.mem); sink.mem = 0; }
+		*mem = 0, *mem_len = 0; sink.to_mem = 1;
+	}
 	if (opt->flag & (MG_M_FRAG_MODE | MG_M_CAL_COV)) { /* gmap.c:44-48,119-126,199-214: multi-segment fragments and --cov are not on the accelerated path */
 		if (mg_verbose >= 1) fprintf(stderr, "[E::%s] --frag and --cov are outside the MI355X long-read path (single-segment reads, GAF output)\n", __func__);
-		free(sink.mem);
+		mga_host_unpin(sink.mem); free(sink.mem);
 		return -1;
 	}
 	if (n_threads < 1) n_threads = 1;
-	if ((S = mga_idx_stream_acquire(gi, opt, n_threads)) == 0) { free(sink.mem); return -1; }
+	if ((S = mga_idx_stream_acquire(gi, opt, n_threads)) == 0) { mga_host_unpin(sink.mem); free(sink.mem); return -1; }
 	if (gi->B->mf_cache == 0) { /* (under the stream's job lock) */
 		mc = MGA_CALLOC(mf_cache_t, 1);
 		for (k = 0; k < MF_NB; ++k) mc->fb[k] = MGA_CALLOC(fbatch_t, 1);
@@ -702,7 +711,7 @@ int mga_map_files_shard(const mg_idx_t *gi, int n_fn, const char **fn, const mg_
 	if (R.err || W.err) ret = -1;
 	mga_idx_stream_release(S);
 	if (mem && ret == 0) { if (sink.mem == 0) sink.mem = (char*)calloc(1, 1), sink.mem_cap = 1; sink.mem[sink.mem_len] = 0; *mem = sink.mem, *mem_len = sink.mem_len; if (mem_cap) *mem_cap = sink.mem_cap; }
-	else free(sink.mem);
+	else { mga_host_unpin(sink.mem); free(sink.mem); }
 	if (seg_len && ret == 0) *seg_len = sink.seg_len, *n_seg = sink.n_seg; else free(sink.seg_len);
 	if (t_map) *t_map = mga_wtime() - t0;
 	return ret;

@@ -837,7 +837,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 			rc = mga_dbuf_reserve(&P->hash, (size_t)n * 4 + 4) < 0 || mga_h2d_s(sc, P->hash.p, h_hash, (size_t)n * 4) < 0 || mga_ssync(sc) < 0 ? -1 : 0;
 			free(h_hash);
 			if (rc < 0) goto done;
-			CK(mga_dbuf_reserve(&P->gchdr, (size_t)n * sizeof(mga_gc_hdr_t) + 64)); CK(mga_dbuf_reserve(&P->gcctl, 256)); CK(mga_dbuf_reserve(&P->gcretry, (size_t)n * 4 + 4));
+			CK(mga_dbuf_reserve(&P->gchdr, (size_t)n * sizeof(mga_gc_hdr_t) + 64)); CK(mga_dbuf_reserve(&P->gcctl, 256)); CK(mga_dbuf_reserve(&P->gcretry, (size_t)n * 8 + 8)); /* (two lists: the first launch's retries, the retry launch's own) */
 			CK(mga_hbuf_reserve(&P->h_gchdr, (size_t)n * sizeof(mga_gc_hdr_t) + 64)); /* (large read-backs go to pinned memory) */
 			for (attempt = 0;; ++attempt) {
 				int64_t n_retry;
@@ -863,12 +863,13 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 					CK(mga_dev_gchain(sc, &B->dev, opt, gi->k, par.chn_pen_gap, (int)n_retry, (const int32_t*)P->gcretry.p, 1, (const int64_t*)P->aoff.p, (const int32_t*)P->nu.p, (const int32_t*)P->nb.p,
 									  (const uint64_t*)P->u.p, (const mg128_t*)P->b.p, (const int64_t*)P->minioff.p, (const int32_t*)P->mini.p, (const int64_t*)P->qoff.p, d_seq,
 									  (const uint32_t*)P->hash.p, (const int32_t*)P->rflag.p, (mga_gc_hdr_t*)P->gchdr.p, P->gcpool.p, gc_cap, (mg_llchain_t*)P->lcpool.p, lc_cap,
-									  (mg128_t*)P->apool.p, ga_cap, (unsigned long long*)P->gcctl.p, (int32_t*)P->gcretry.p));
+									  (mg128_t*)P->apool.p, ga_cap, (unsigned long long*)P->gcctl.p, (int32_t*)P->gcretry.p + n)); /* (its own list for what fails again: the input list is still being consumed) */
 					CK(mga_d2h_s(sc, ctl, P->gcctl.p, 64)); CK(mga_ssync(sc));
-					if ((int64_t)ctl[3] > 0 || (int64_t)ctl[1] > gc_cap || (int64_t)ctl[2] > lc_cap || (int64_t)ctl[6] > ga_cap) {
-						mga_set_error("graph chaining: %lld read(s) need more than %zu MiB of scratch each, or the record pools overflowed on the retry", (long long)ctl[3], mga_dev_gchain_arena_bytes(1) >> 20);
-						rc = -1; goto done;
-					}
+					/* A read that fails again -- more scratch than the large arena, or the record pools ran out during the retry -- is left with a non-zero status
+					 * and no records: the host threads chain it, like the reads whose rescue k_lchain deferred (this used to fail the whole job). */
+					if ((int64_t)ctl[1] > gc_cap) ctl[1] = (unsigned long long)gc_cap; /* (the pool counters ran past the pools: only what fits was written) */
+					if ((int64_t)ctl[2] > lc_cap) ctl[2] = (unsigned long long)lc_cap;
+					if ((int64_t)ctl[6] > ga_cap) ctl[6] = (unsigned long long)ga_cap;
 					st->n_gc_retry += n_retry;
 				}
 				break;
@@ -901,7 +902,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 			if (need_a) CK(mga_d2h_s(sc, P->h_apool.p, P->apool.p, (size_t)ctl[6] * 16));
 			CK(mga_ssync(sc)); /* (h_nu / h_nb / h_rflag arrived with the first sync) */
 			for (i = 0; i < n; ++i) /* the few reads whose rescue k_lchain left to the host tree: their chains, anchors and minimizer positions come down for the host path */
-				if (h_gchdr_p[i].status == MGA_GC_HOST) {
+				if (h_gchdr_p[i].status != 0) { /* (MGA_GC_HOST, or a read the device gave up on even in the large arena) */
 					const int64_t ao = h_aoff[i], mo = h_minioff[i];
 					CK(mga_d2h_s(sc, (uint64_t*)P->h_u.p + ao, (const uint64_t*)P->u.p + ao, (size_t)h_nu[i] * 8));
 					CK(mga_d2h_s(sc, (mg128_t*)P->h_b.p + ao, (const mg128_t*)P->b.p + ao, (size_t)h_nb[i] * 16));
@@ -939,6 +940,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	if (dev_plan) {
 		if (ptot[6] != 0 || ptot[2] > 0x7fffffffULL) { mga_set_error("gap list: too many WFA problems or target bases in one chunk (%llu problems); lower MGA_CHUNK", ptot[2]); rc = -1; goto done; }
 		CK(mga_hbuf_reserve(&P->h_plrev, (size_t)ptot[0] * 4 + 16));
+		memset(P->h_plrev.p, 0, (size_t)ptot[0] * 4); /* (reads that chain_worker skips -- max_qlen, empty -- leave their chains' flags unwritten: defined now; their lines are never printed) */
 		mga_batch_set_device_plan(b, h_ploff, (int32_t*)P->h_plrev.p, (int64_t)ptot[0]);
 	}
 	if (dev_gc) mga_batch_set_device_chains(b, h_gchdr_p, P->h_gcpool.p, (const mg_llchain_t*)P->h_lcpool.p, need_a ? (const mg128_t*)P->h_apool.p : 0);

@@ -25,6 +25,8 @@ int  mga_dsync(void);
 void *mga_hmalloc_pinned(size_t bytes);        /* pinned host memory for fast PCIe copies */
 void mga_hfree_pinned(void *p);
 double mga_wtime(void);
+int  mga_host_pin(void *p, size_t bytes);      /* hipHostRegister with a registry: mga_free() and every realloc / free inside the library unregister first */
+void mga_host_unpin(void *p);
 
 /* grow-only device buffer */
 typedef struct { void *p; size_t cap; } mga_dbuf_t;

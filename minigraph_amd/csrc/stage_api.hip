@@ -9,7 +9,8 @@
 #include "dev_common.h"
 
 extern "C" void mga_ksort_128x(int64_t n, mg128_t *a); // ksortx.c: radix_sort_128x with the reference's exact permutation
-extern "C" void mga_free(void *p) { free(p); }
+extern "C" void mga_host_unpin(void *p);
+extern "C" void mga_free(void *p) { mga_host_unpin(p); free(p); } // (a buffer the library handed out may have been page-locked with mga_host_pin)
 
 namespace {
 struct dptr { // RAII for a device allocation

@@ -12,33 +12,23 @@ def shard_range(n_items, rank, world):
     return st, st + base + (1 if rank < rem else 0)
 
 
-_pinned = {}   # base address -> bytes registered with the HIP runtime
-
-
-def _pin_for_dma(arr):
-    """hipHostRegister the memory behind a numpy view (the library's GAF buffer, handed back for reuse from step to step, so its address is
-    stable).  Best effort: any failure leaves the copy on the pageable path."""
+def _pin_for_dma(arr, cap=0):
+    """page-lock the memory behind a numpy view of the LIBRARY's GAF buffer (handed back for reuse from step to step, so its address is stable) through the
+    library's own registry (mga_host_pin): mga_free() and the writer's realloc unregister before the block moves or goes away.  Best effort: a failure leaves
+    the copy on the pageable path."""
     try:
-        ptr, n = arr.ctypes.data, arr.nbytes
-        if n < (1 << 20):
+        import ctypes
+        import minigraph_amd as mga
+        if arr.nbytes < (1 << 20):
             return
-        old = _pinned.get(ptr, 0)
-        if old >= n:
-            return
-        rt = torch.cuda.cudart()
-        if old:
-            rt.cudaHostUnregister(ptr)
-            _pinned.pop(ptr, None)
-        for q in [q for q in _pinned if q != ptr and not (q + _pinned[q] <= ptr or ptr + n <= q)]:   # a buffer that moved: drop stale overlapping registrations
-            rt.cudaHostUnregister(q)
-            _pinned.pop(q, None)
-        if int(rt.cudaHostRegister(ptr, n, 0)) == 0:
-            _pinned[ptr] = n
+        L = mga.load()
+        L.mga_host_pin.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        L.mga_host_pin(arr.ctypes.data, max(int(cap), arr.nbytes))
     except Exception:
         pass
 
 
-def gather_bytes(payload, dst=0, device="cpu", as_tensors=False):
+def gather_bytes(payload, dst=0, device="cpu", as_tensors=False, pin=False):
     """gather one byte string per rank to `dst`; returns the list in rank order on dst, None elsewhere.
     payload: bytes, or any C-contiguous uint8 buffer (e.g. the zero-copy numpy view of the library's GAF buffer).
     One all_gather of the sizes + one gather of byte tensors padded to the largest payload; with as_tensors=True the
@@ -55,8 +45,8 @@ def gather_bytes(payload, dst=0, device="cpu", as_tensors=False):
     if src.size:
         if not src.flags.writeable:
             src = src.copy()  # torch.from_numpy wants a writable array (bytes objects are not)
-        if device != "cpu":
-            _pin_for_dma(src)   # page-lock the (reused) output buffer once: the upload then runs at DMA speed instead of through a bounce buffer
+        if device != "cpu" and pin:
+            _pin_for_dma(src, pin)   # page-lock the library's (reused) output buffer once: the upload then runs at DMA speed instead of through a bounce buffer
         buf[:src.size].copy_(torch.from_numpy(src), non_blocking=False)
     out = [torch.empty(mx, dtype=torch.uint8, device=device) for _ in range(world)] if rank == dst else None
     dist.gather(buf, out, dst=dst)
@@ -84,12 +74,16 @@ def assemble_segments(parts, seg_lens):
 
 def map_sharded(mapper, dst=0, device="cpu", as_tensor=False):
     """one input -> world ranks -> one GAF on `dst` (gmap.c:98-141 fanned out over devices).  mapper(rank, world) maps this rank's shard
-    and returns (payload, seg_len): its GAF bytes (bytes or a uint8 numpy view) and the per-segment byte counts.  One all_gather of the
+    and returns (payload, seg_len[, cap]): its GAF bytes (bytes or a uint8 numpy view) and the per-segment byte counts.  One all_gather of the
     segment tables + one gather of the payloads (RCCL when device == "cuda"); returns the assembled output on dst, None elsewhere:
-    bytes, or with as_tensor=True ONE uint8 tensor on `device` (the parts are put in order by torch.cat, no host round trip)."""
+    bytes, or with as_tensor=True ONE uint8 tensor on `device` (the parts are put in order by torch.cat, no host round trip).
+    A mapper that returns a third value -- the capacity in bytes of the LIBRARY buffer behind its payload view (MappedGaf.cap) -- gets that buffer page-locked
+    once through the library's registry (mga_host_pin) before the upload."""
     import numpy as np
     world, rank = dist.get_world_size(), dist.get_rank()
-    payload, seg_len = mapper(rank, world)
+    res = mapper(rank, world)
+    payload, seg_len = res[0], res[1]
+    pin = int(res[2]) if len(res) > 2 else 0   # capacity of the LIBRARY buffer behind the payload view (MappedGaf.cap), if it is one
     seg_len = [int(x) for x in seg_len]
     n_seg = torch.tensor([len(seg_len)], dtype=torch.int64, device=device)
     dist.all_reduce(n_seg, op=dist.ReduceOp.MAX)
@@ -98,7 +92,7 @@ def map_sharded(mapper, dst=0, device="cpu", as_tensor=False):
         tab[:len(seg_len)] = torch.tensor(seg_len, dtype=torch.int64)
     tabs = [torch.zeros_like(tab) for _ in range(world)]
     dist.all_gather(tabs, tab)
-    parts = gather_bytes(payload, dst=dst, device=device, as_tensors=as_tensor)
+    parts = gather_bytes(payload, dst=dst, device=device, as_tensors=as_tensor, pin=pin)   # pin: capacity of the library buffer behind payload (0: not the library's)
     if rank != dst:
         return None
     tabs = [t.cpu().tolist() for t in tabs]
