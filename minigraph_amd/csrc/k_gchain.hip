@@ -77,6 +77,8 @@ struct gck_out_t {
 	int32_t *retry;
 };
 
+#define GCK_FAST_BYTES 16384 // LDS scratch per wavefront: two waves per SIMD = eight per CU = 128 KB of the CU's 160
+
 __device__ __forceinline__ void gck_copy_words(void *dst, const void *src, int64_t bytes, int lane) // both 4-byte aligned
 {
 	uint32_t *d = (uint32_t*)dst;
@@ -84,8 +86,9 @@ __device__ __forceinline__ void gck_copy_words(void *dst, const void *src, int64
 	for (int64_t i = lane, n = bytes >> 2; i < n; i += 64) d[i] = s[i];
 }
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) k_gchain(gck_in_t in, gck_out_t out, gc_graph_t G, gc_par_t P, char *arena_mem, int64_t arena_bytes)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) k_gchain(gck_in_t in, gck_out_t out, gc_graph_t G, gc_par_t P, char *arena_mem, int64_t arena_bytes, int fast_bytes)
 {
+	extern __shared__ __attribute__((aligned(16))) char fast_lds[]; // fast_bytes of dynamic LDS (0: none)
 	const int lane = threadIdx.x;
 	char *my_arena = arena_mem + (int64_t)blockIdx.x * arena_bytes;
 	for (;;) {
@@ -101,8 +104,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
 		if (n_u <= 0 || n_b <= 0) { if (lane == 0) { H->n_gc = H->n_lc = H->n_a = 0, H->status = 0, H->gc_off = H->lc_off = H->a_off = 0; } continue; }
 		gc_arena_t A;
 		gc_arena_init(&A, my_arena, arena_bytes, 0);
-		// (gc_arena_t::fast_base -- a block of LDS for the scratch of one graph search / GWFA call -- stays unset: flat accesses of the 24-byte
-		// wavefront cells into the LDS aperture raised MEMORY_APERTURE_VIOLATION on gfx950 [measured]; the mechanism is kept for a later look)
+		// MGA_GC_LDS=1: the scratch of ONE graph search / GWFA call at a time in LDS; a call that outgrows the block is run again in the main arena (see the launcher)
+		if (fast_bytes > 0) A.fast_base = (char*)fast_lds, A.fast_cap = fast_bytes;
 		if (out.ctl[15]) A.ticks = out.ctl + 16, A.tick_last = (long long)clock64(); // profiling: ctl[15] != 0 asks for per-stage cycle sums in ctl[16..31]
 		mg128_t *work = (mg128_t*)gc_alloc(&A, (int64_t)n_b * 16); // the chains' anchors: flags and minimizer ranks are written into this copy
 		mg128_t *res_a = (mg128_t*)gc_alloc(&A, (int64_t)n_b * 16); // anchors of the graph chains
@@ -131,6 +134,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
 				a_off = (long long)atomicAdd(&out.ctl[6], (unsigned long long)n_a);
 				if (gc_off + n_gc > out.gc_cap || lc_off + n_lc > out.lc_cap || a_off + n_a > out.a_cap) status = MGA_GC_E_POOL;
 				atomicAdd(&out.ctl[4], (unsigned long long)R.n_gwfa);
+				atomicAdd(&out.ctl[8], (unsigned long long)R.n_fast);
 				atomicAdd(&out.ctl[5], (unsigned long long)R.n_shortk);
 				atomicMax(&out.ctl[7], (unsigned long long)A.peak);
 			}
@@ -194,7 +198,13 @@ extern "C" int mga_dev_gchain(mga_sctx_t *sc, const mga_didx_t *ix, const mg_map
 	G.arc = (const gc_arc_t*)ix->d_arc, G.idx = ix->d_arc_idx, G.seg_len = ix->d_seg_len, G.es = 0, G.seq_fw = ix->d_gseq, G.seq_rc = ix->d_gseq_rc, G.seq_off = ix->d_gseq_off;
 	gc_par_from_opt(opt, k, pen_gap, &P);
 	mga_prof_begin(sc->stream, MGA_K_GCHAIN);
-	hipLaunchKernelGGL(k_gchain, dim3(waves), dim3(64), 0, (hipStream_t)sc->stream, in, out, G, P, (char*)arena->p, (int64_t)ab);
+	// MGA_GC_LDS=1: the scratch of a graph search / of a GWFA call over a short query gap in 16 KB of LDS per wavefront.  OFF by default: [measured, round 3, bench
+	// workload] the shortest-walk searches get 30 % cheaper (10.8 -> 7.6 Gcycles per 16k reads), but only 30 % of the GWFA calls fit, and with the block allocated
+	// EVERY stage of the kernel slows down by 20-30 % (66 -> 92 Gcycles in all; k_gchain 143 -> 153 ms per 125k reads).  The round-2 aperture fault is understood
+	// and gone (gc_diag_t: 32 bytes at 16-byte alignment); what is left to find is why flat accesses into the LDS aperture cost the rest of the kernel so much.
+	const char *e_fast = getenv("MGA_GC_LDS");
+	const int fast_bytes = e_fast && atoi(e_fast) > 0 ? GCK_FAST_BYTES : 0;
+	hipLaunchKernelGGL(k_gchain, dim3(waves), dim3(64), (size_t)fast_bytes, (hipStream_t)sc->stream, in, out, G, P, (char*)arena->p, (int64_t)ab, fast_bytes);
 	mga_prof_end(sc->stream, MGA_K_GCHAIN);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;

@@ -830,7 +830,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 			/* ---- graph chaining: chain records, clean-up, DP + shortest walks, GWFA bridging, ordering, filters -- one wavefront per read ---- */
 			const size_t rec = mga_gc_rec_bytes();
 			uint32_t *h_hash = MGA_MALLOC(uint32_t, n);
-			unsigned long long ctl[8];
+			unsigned long long ctl[9]; /* [8]: GWFA calls / graph searches that ran in the LDS scratch */
 			int attempt;
 			for (i = 0; i < n; ++i) h_hash[i] = mga_read_hash(qnames ? qnames[i] : 0, qlens[i], opt->seed);
 			gc_cap = n_a / (opt->min_lc_cnt > 0 ? opt->min_lc_cnt : 1) + n + 64, lc_cap = gc_cap * 3 + 4096, ga_cap = n_a + 64;
@@ -848,7 +848,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 								  (const mg128_t*)P->b.p, (const int64_t*)P->minioff.p, (const int32_t*)P->mini.p, (const int64_t*)P->qoff.p, d_seq, (const uint32_t*)P->hash.p,
 								  (const int32_t*)P->rflag.p, (mga_gc_hdr_t*)P->gchdr.p, P->gcpool.p, gc_cap, (mg_llchain_t*)P->lcpool.p, lc_cap, (mg128_t*)P->apool.p, ga_cap,
 								  (unsigned long long*)P->gcctl.p, (int32_t*)P->gcretry.p));
-				CK(mga_d2h_s(sc, ctl, P->gcctl.p, 64)); CK(mga_ssync(sc));
+				CK(mga_d2h_s(sc, ctl, P->gcctl.p, 72)); CK(mga_ssync(sc));
 				n_retry = (int64_t)ctl[3];
 				if ((int64_t)ctl[1] > gc_cap || (int64_t)ctl[2] > lc_cap || (int64_t)ctl[6] > ga_cap) { /* a record pool was too small: size it to what the kernel asked for and run the chunk again */
 					if (attempt >= 2) { mga_set_error("graph chaining: record pools keep overflowing (%lld/%lld/%lld)", (long long)ctl[1], (long long)ctl[2], (long long)ctl[6]); rc = -1; goto done; }
@@ -864,7 +864,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 									  (const uint64_t*)P->u.p, (const mg128_t*)P->b.p, (const int64_t*)P->minioff.p, (const int32_t*)P->mini.p, (const int64_t*)P->qoff.p, d_seq,
 									  (const uint32_t*)P->hash.p, (const int32_t*)P->rflag.p, (mga_gc_hdr_t*)P->gchdr.p, P->gcpool.p, gc_cap, (mg_llchain_t*)P->lcpool.p, lc_cap,
 									  (mg128_t*)P->apool.p, ga_cap, (unsigned long long*)P->gcctl.p, (int32_t*)P->gcretry.p + n)); /* (its own list for what fails again: the input list is still being consumed) */
-					CK(mga_d2h_s(sc, ctl, P->gcctl.p, 64)); CK(mga_ssync(sc));
+					CK(mga_d2h_s(sc, ctl, P->gcctl.p, 72)); CK(mga_ssync(sc));
 					/* A read that fails again -- more scratch than the large arena, or the record pools ran out during the retry -- is left with a non-zero status
 					 * and no records: the host threads chain it, like the reads whose rescue k_lchain deferred (this used to fail the whole job). */
 					if ((int64_t)ctl[1] > gc_cap) ctl[1] = (unsigned long long)gc_cap; /* (the pool counters ran past the pools: only what fits was written) */
@@ -880,7 +880,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 				static const char *nm[16] = { "", "records", "cleanup", "index", "dp+shortk", "assemble(rest)", "post", "", "gwfa(rest)", "measure", "order", "gw:clear", "gw:runs", "gw:heads", "gw:dedup", "" };
 				int q_;
 				CK(mga_d2h_s(sc, tk, (char*)P->gcctl.p + 128, 128)); CK(mga_ssync(sc));
-				fprintf(stderr, "[gc-prof] %d reads, Mcycles:", n);
+				fprintf(stderr, "[gc-prof] %d reads, %llu GWFA calls (%llu in the LDS scratch), Mcycles:", n, ctl[4], ctl[8]);
 				for (q_ = 1; q_ < 15; ++q_) if (nm[q_][0]) fprintf(stderr, " %s %.1f", nm[q_], tk[q_] * 1e-6);
 				fprintf(stderr, "\n");
 			}
