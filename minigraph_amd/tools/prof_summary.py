@@ -43,7 +43,31 @@ def main_pmc_json(fetch_db, write_db, source):
     print(json.dumps({"source": source, "kernels": dict(sorted(ker.items()))}, indent=1))
 
 
+def main_sq(paths, title):
+    """per kernel, over one or more --pmc passes of SQ counters: instructions per wave and the shares of the waves' resident cycles"""
+    acc = {}
+    for path in paths:
+        for name, counter, calls, tot in pmc_rows(path):
+            k = acc.setdefault(name.split("(")[0].replace("void ", "").strip()[:46], {})
+            k[counter] = k.get(counter, 0.0) + tot
+            k["_calls_" + counter] = calls
+    print("# rocprofv3 --pmc SQ_* (own passes, no tracing)  %s" % title)
+    print("# per wave: instructions issued; shares: fraction of the waves' resident cycles (SQ_WAVE_CYCLES): valu = SQ_ACTIVE_INST_VALU, wait = SQ_WAIT_ANY (parked on s_waitcnt / barrier),")
+    print("# stall = SQ_WAIT_INST_ANY (issue stalls), vmem / lds / salu = SQ_INST_CYCLES_VMEM / SQ_ACTIVE_INST_LDS / SQ_INST_CYCLES_SALU where collected; busy = SQ_BUSY_CYCLES summed over SEs")
+    print("%-46s %7s %12s %11s %11s %9s %7s %7s %7s %7s %7s %7s" % ("kernel", "calls", "waves", "VALU/wave", "SALU/wave", "LDS/wave", "valu", "wait", "stall", "vmem", "lds", "salu"))
+    def share(k, c):
+        return ("%7.3f" % (k[c] / k["SQ_WAVE_CYCLES"])) if c in k and k.get("SQ_WAVE_CYCLES") else "      -"
+    for name, k in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
+        w = k.get("SQ_WAVES", 0.0)
+        if not w:
+            continue
+        print("%-46s %7d %12d %11.0f %11.0f %9.0f %s %s %s %s %s %s" % (name, k.get("_calls_SQ_WAVES", 0), w, k.get("SQ_INSTS_VALU", 0) / w, k.get("SQ_INSTS_SALU", 0) / w, k.get("SQ_INSTS_LDS", 0) / w,
+              share(k, "SQ_ACTIVE_INST_VALU"), share(k, "SQ_WAIT_ANY"), share(k, "SQ_WAIT_INST_ANY"), share(k, "SQ_INST_CYCLES_VMEM"), share(k, "SQ_ACTIVE_INST_LDS"), share(k, "SQ_INST_CYCLES_SALU")))
+
+
 def main():
+    if sys.argv[1] == "--sq":
+        return main_sq([a for a in sys.argv[2:] if a.endswith(".db")], " ".join(a for a in sys.argv[2:] if not a.endswith(".db")))
     if sys.argv[1] == "--pmc-json":
         return main_pmc_json(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "")
     if sys.argv[1] == "--pmc":
