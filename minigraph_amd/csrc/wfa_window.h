@@ -23,6 +23,7 @@ __host__ __device__ __forceinline__ int32_t wfw_window(int32_t W, int32_t tl, in
 	hi = lo + W - 1;
 	if (hi > ql) { hi = ql; lo = hi - W + 1; if (lo < -tl) lo = -tl; }
 	*lo_ = lo;
+	if (lo > 0 || hi < 0 || e < lo || e > hi) return 0; /* the start diagonal 0 or the end diagonal lies outside: nothing can be decided in this window */
 	const int32_t blo = lo - 1 >= -tl ? wfw_gap(lo - 1) + wfw_gap(e - (lo - 1)) : cap;
 	const int32_t bhi = hi + 1 <= ql ? wfw_gap(hi + 1) + wfw_gap(hi + 1 - e) : cap;
 	const int32_t b = blo < bhi ? blo : bhi;
