@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--hap", type=int, default=5)
     ap.add_argument("--cpu-reads", type=int, default=125000, help="reads of the CPU baseline + parity sample (default: every read of one rank's share -- about 17 s of mapping on 16 cores)")
     ap.add_argument("--one-placement", action="store_true", help="skip the second placement of graph chaining (the library's own choice only)")
+    ap.add_argument("--placement", choices=["auto", "device", "host"], default="auto", help="graph chaining of the headline pass: the library's own choice (auto) or forced (profiling runs)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: leave every rank's GAF shard where it is (the gather to rank 0 over RCCL is ON by default)")
     ap.add_argument("--resident-steps", type=int, default=2)
@@ -250,9 +251,12 @@ def main():
     # Graph chaining + gap list run on the host threads or on the device (k_gchain / k_plan); the library picks by the host threads this rank has (device when <= 12).
     # The headline is the library's own choice; the OTHER placement is timed right after it (fewer steps), so that both halves of the path are inside a driver-timed,
     # parity-checked number.
-    default_dev = threads <= 12
+    default_dev = threads <= 12 if args.placement == "auto" else args.placement == "device"
     os.environ.pop("MGA_DEV_GCHAIN", None)
+    if args.placement != "auto":
+        os.environ["MGA_DEV_GCHAIN"] = "1" if default_dev else "0"
     dt, st, host_main = timed(args.warmup, args.steps)
+    os.environ.pop("MGA_DEV_GCHAIN", None)
     gaf_main = last_gaf()
     other = None
     if not args.one_placement:
@@ -397,7 +401,7 @@ def main():
                    resident=resident,
                    kernels_ms_isolated=kernels_ms,
                    wfa_ladder_isolated=(isolated or {}).get("ladder"),
-                   graph_chaining=dict(default=("device (k_gchain + k_plan)" if default_dev else "host threads") + ": %d host threads per rank, device when <= 12" % threads),
+                   graph_chaining=dict(default=("device (k_gchain + k_plan)" if default_dev else "host threads") + ": %d host threads per rank, device when <= 12" % threads + ("" if args.placement == "auto" else " (FORCED by --placement %s)" % args.placement)),
                    per_read=dict(n_mz=agg["n_mz"] / max(1, total_reads * args.steps), n_hit=agg["n_hit"] / max(1, total_reads * args.steps),
                                  n_wfa=st["n_wfa"] / max(1, st["n_reads"]), wfa_cells=st["wfa_cells"] / max(1, st["n_reads"]),
                                  gaf_bytes=agg["gaf_bytes"] / max(1, total_reads * args.steps)),

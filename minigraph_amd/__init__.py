@@ -12,7 +12,7 @@ import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
-LIB_PATH = os.path.join(PKG, "lib", "libminigraph_amd.so")
+LIB_PATH = os.environ.get("MGA_LIB") or os.path.join(PKG, "lib", "libminigraph_amd.so")  # MGA_LIB: a test build of the same library (tests/test_wave_model.py)
 MGSIM = os.path.join(PKG, "lib", "mgsim")
 
 m128 = np.dtype([("x", "<u8"), ("y", "<u8")])

@@ -125,6 +125,40 @@ GC_HD int32_t gc_sum(int32_t v) { return v; }
 #endif
 #define GC_PAR_FOR(i, n) for (int32_t i = GC_LANE; i < (n); i += GC_NLANE)   /* no allocation, no gc_sync() inside */
 
+/* ---- wave-vector notation: ONE source for the blocks that keep a GWFA wavefront in the registers of the 64 lanes.  On the device a "vector" is a
+ * lane's scalar (arrays of one element) and GC_EACH runs its body once, for this lane; in the host's WAVE MODEL (-DGC_WAVE_MODEL: CPU tests of exactly
+ * this code against the reference, tests/test_wave_model.py) a vector is an array of 64 and GC_EACH loops over the lanes.  Rules that make the two
+ * agree: a GC_EACH body touches its own lane's elements only; values of other lanes are read with GC_UP1 / GC_DN1 / GC_GET / GC_VBALLOT from vectors
+ * completed by an EARLIER GC_EACH; memory another lane has written is read only behind a gc_sync(). */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GC_WAVEPATH 1
+#define GC_WN 1
+#define GC_EACH for (int32_t L_ = GC_LANE, gc_once_ = 1; gc_once_; gc_once_ = 0)
+#define GC_V(x) (x)[0]
+#define GC_UP1(x) __shfl_up((x)[0], 1)          /* lane - 1 (lane 0: its own) */
+#define GC_DN1(x) __shfl_down((x)[0], 1)        /* lane + 1 (lane 63: its own) */
+#define GC_GET(x, src) __shfl((x)[0], (src))    /* src: the same in every lane */
+#define GC_VBALLOT(p) __ballot((p)[0])
+#define GC_PERMUTE32(dst, src, pos) ((dst)[0] = __builtin_amdgcn_ds_permute((pos)[0] << 2, (int)(src)[0])) /* dst[pos[lane]] = src[lane]; pos a permutation of the lanes; dst != src */
+#define GC_PERMUTE64(dst, src, pos) ((dst)[0] = (uint64_t)(uint32_t)__builtin_amdgcn_ds_permute((pos)[0] << 2, (int)(uint32_t)(src)[0]) | (uint64_t)(uint32_t)__builtin_amdgcn_ds_permute((pos)[0] << 2, (int)(uint32_t)((src)[0] >> 32)) << 32)
+#define GC_SHUP(x, d) __shfl_up((x)[0], (d))    /* lane - d (lanes below d: their own) */
+#elif defined(GC_WAVE_MODEL)
+#define GC_WAVEPATH 1
+#define GC_WN 64
+#define GC_EACH for (int32_t L_ = 0; L_ < 64; ++L_)
+#define GC_V(x) (x)[L_]
+#define GC_UP1(x) (x)[L_ > 0 ? L_ - 1 : L_]
+#define GC_DN1(x) (x)[L_ < 63 ? L_ + 1 : L_]
+#define GC_GET(x, src) (x)[(src)]
+static inline uint64_t gc_vballot_(const int *p) { uint64_t m = 0; for (int i = 0; i < 64; ++i) if (p[i]) m |= 1ULL << i; return m; }
+#define GC_VBALLOT(p) gc_vballot_(p)
+#define GC_PERMUTE32(dst, src, pos) do { for (int i_ = 0; i_ < 64; ++i_) (dst)[(pos)[i_]] = (int32_t)(src)[i_]; } while (0)
+#define GC_PERMUTE64(dst, src, pos) do { for (int i_ = 0; i_ < 64; ++i_) (dst)[(pos)[i_]] = (src)[i_]; } while (0)
+#define GC_SHUP(x, d) (x)[L_ >= (d) ? L_ - (d) : L_]
+#endif
+#define GC_VRANK(m) ((int32_t)__builtin_popcountll((m) & ((1ULL << L_) - 1ULL)))   /* set bits below this lane (inside GC_EACH) */
+#define GC_POPC64(m) ((int32_t)__builtin_popcountll(m))
+
 /* non-overlapping copy in 4-byte units by all lanes */
 GC_HD void gc_pcopy(void *dst, const void *src, int64_t bytes)
 {
@@ -1023,6 +1057,32 @@ GC_HD int gc_chain_dp(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, int
 
 /* ------------------------------------------------------------------------------------------------ GWFA */
 
+#if defined(GC_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+#include <stdio.h>
+/* host-only statistics of the GWFA steps (a profiling aid: -DGC_STATS, printed by gc_stats_dump()) */
+typedef struct { long long calls, steps, cells, runs, heads0, heads, out, single_nohead, single, nohead, le64, sum_ql, reached, steps_hist[8], n_hist[8], simple_cells, dedup_steps, long_runs, arena_hist[8], arena_sum, fit16, fit32, fit64, blk_ext, blk_dedup, blk_sorted, blk_fallback, blk_wave, blk_merge, dedup_calls, dd_n[8], dd_done[8], dd_fresh[8], dd_nc[8], dd_sum_n, dd_sum_done, dd_sum_fresh, dd_sum_nc, dd_unsorted, hd_arc, hd_in, hd_other; } gc_stats_t;
+static gc_stats_t gc_stats;
+static inline int gc_stats_bin(long long v) { int b = 0; while (v > 1 && b < 7) v >>= 2, ++b; return b; }
+static void gc_stats_dump(void)
+{
+	const gc_stats_t *S = &gc_stats;
+	fprintf(stderr, "[gc_stats] calls %lld reached %lld mean_ql %.1f steps %lld (%.1f/call) cells %lld (%.1f/step) runs %.2f/step heads0 %.2f/step heads %.2f/step out %.1f/step\n", S->calls, S->reached, (double)S->sum_ql / (S->calls ? S->calls : 1),
+			S->steps, (double)S->steps / (S->calls ? S->calls : 1), S->cells, (double)S->cells / (S->steps ? S->steps : 1), (double)S->runs / (S->steps ? S->steps : 1), (double)S->heads0 / (S->steps ? S->steps : 1), (double)S->heads / (S->steps ? S->steps : 1), (double)S->out / (S->steps ? S->steps : 1));
+	fprintf(stderr, "[gc_stats] steps with one run and no head cell %.3f (cells in them %.3f); one run %.3f; no head %.3f; all runs <= 64 %.3f; dedup %.3f\n", (double)S->single_nohead / S->steps, (double)S->simple_cells / S->cells, (double)S->single / S->steps, (double)S->nohead / S->steps, (double)S->le64 / S->steps, (double)S->dedup_steps / S->steps);
+	fprintf(stderr, "[gc_stats] steps per call (bins 1,4,16,64,256,1k,4k,16k+):"); for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", S->steps_hist[i]); fprintf(stderr, "\n");
+	fprintf(stderr, "[gc_stats] arena bytes per call: mean %.0f; <=16K %.3f <=32K %.3f <=64K %.3f; hist (0.5K,2K,8K,32K,128K,512K,2M,8M+):", (double)S->arena_sum / S->calls, (double)S->fit16 / S->calls, (double)S->fit32 / S->calls, (double)S->fit64 / S->calls); for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", S->arena_hist[i]); fprintf(stderr, "\n");
+	fprintf(stderr, "[gc_stats] wave blocks: extend %lld; dedup calls %lld, as a block %lld (sorted by rank %lld), handed back %lld, in two passes %lld\n", S->blk_ext, S->dedup_calls, S->blk_dedup, S->blk_sorted, S->blk_fallback, S->blk_wave);
+	fprintf(stderr, "[gc_stats] dedup: mean cells %.1f done %.1f fresh %.2f flagged %.1f unsorted %.3f\n", (double)S->dd_sum_n / S->dedup_calls, (double)S->dd_sum_done / S->dedup_calls, (double)S->dd_sum_fresh / S->dedup_calls, (double)S->dd_sum_nc / S->dedup_calls, (double)S->dd_unsorted / S->dedup_calls);
+	fprintf(stderr, "[gc_stats] dedup cells hist (<=1,<8,<32,<128,<512,..):"); for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", S->dd_n[i]); fprintf(stderr, "; done hist:"); for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", S->dd_done[i]);
+	fprintf(stderr, "; fresh hist:"); for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", S->dd_fresh[i]); fprintf(stderr, "; flagged hist:"); for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", S->dd_nc[i]); fprintf(stderr, "\n");
+	fprintf(stderr, "[gc_stats] head cells: inside a vertex %lld, arc fan-out %lld, other %lld\n", S->hd_in, S->hd_arc, S->hd_other);
+	fprintf(stderr, "[gc_stats] cells per step (same bins):"); for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", S->n_hist[i]); fprintf(stderr, "\n");
+}
+#define GC_STAT(...) __VA_ARGS__
+#else
+#define GC_STAT(...)
+#endif
+
 #define GC_DSHIFT 0x40000000
 #define GC_FAST_GAP 400 /* longest query gap whose GWFA call tries the LDS scratch first */
 /* 32 bytes, 16-byte aligned: a cell is moved as two aligned 16-byte words.  (24 bytes at 8-byte alignment let the compiler fuse a copy into a 16-byte access at
@@ -1055,7 +1115,7 @@ GC_HD int gc_u64map_put(gc_arena_t *A, gc_u64map_t *h, uint64_t key, int32_t **v
 	*val = &h->v[i];
 	return GC_OK;
 }
-GC_HD void gc_u64map_clear(gc_u64map_t *h) { GC_PAR_FOR(j, (int32_t)h->cap) h->k[j] = ~0ULL; gc_sync(); h->cnt = 0; }
+GC_HD void gc_u64map_clear(gc_u64map_t *h) { if (h->cnt == 0) return; GC_PAR_FOR(j, (int32_t)h->cap) h->k[j] = ~0ULL; gc_sync(); h->cnt = 0; }
 
 typedef struct {
 	const gc_graph_t *G;
@@ -1066,6 +1126,7 @@ typedef struct {
 	gc_intv_v done, fresh, swap;  /* finished diagonals: merged list, this step's additions, scratch */
 	gc_diag_v ooo, wf[2], head;   /* sort scratch; the two wavefronts; the cells sitting on a vertex or query end */
 	gc_kv_t *sort_kv; gc_diag_t *sort_tmp; int32_t m_sort;
+	gc_diag_t *cl;                /* the flagged cells of a wavefront being sorted (wave path) */
 	GC_VEC(gc_trace_t) tr;
 	int32_t cur, s, end_tb, end_off;
 	uint32_t end_v;
@@ -1245,10 +1306,258 @@ GC_HD int gc_intv_add(gc_arena_t *A, gc_intv_v *L, uint64_t x0, uint64_t x1)
 #define GC_COMPACT_BEGIN(n_) { const int32_t gcn_ = (n_); int32_t gcm_ = 0; for (int32_t gcb_ = 0; gcb_ < gcn_; gcb_ += GC_NLANE) { const int32_t gci_ = gcb_ + GC_LANE; const int gcin_ = gci_ < gcn_;
 #define GC_COMPACT_END(a_, val_, keep_, n_out_) const uint64_t gck_ = gc_ballot(gcin_ && (keep_)); gc_sync(); if (gcin_ && (keep_)) (a_)[gcm_ + gc_rank(gck_)] = (val_); gcm_ += gc_popc(gck_); gc_sync(); } (n_out_) = gcm_; }
 
+#ifdef GC_WAVEPATH
+/* gc_intv_add() of all of this step's finished diagonals at once, for up to 64 ranges in all (the list itself is a handful: adjacent diagonals finish together
+ * and coalesce): a range per lane, ordered by its start (rank by counting), an inclusive prefix maximum of the ends; a range whose start lies beyond every
+ * end in front of it opens an output range, which ends at the prefix maximum in front of the next opening.  The union has one canonical form. */
+GC_HD int gc_intv_add_wave(gc_arena_t *A, gc_intv_v *L, const gc_intv_v *F)
+{
+	const int32_t n_l = L->n, n = L->n + F->n;
+	GC_TRY(gc_vec_reserve(A, *L, n));
+	uint64_t x0[GC_WN], x1[GC_WN], y0[GC_WN], y1[GC_WN], pm[GC_WN], t64[GC_WN];
+	int32_t pos[GC_WN], nxt[GC_WN];
+	int open[GC_WN];
+	GC_EACH {
+		GC_V(x0) = GC_V(x1) = ~0ULL, GC_V(pos) = 0;
+		if (L_ < n) { const gc_intv_t v = L_ < n_l ? L->a[L_] : F->a[L_ - n_l]; GC_V(x0) = v.vd0, GC_V(x1) = v.vd1; }
+	}
+	for (int32_t j = 0; j < n; ++j) {
+		const uint64_t xj = GC_GET(x0, j);
+		GC_EACH GC_V(pos) += (xj < GC_V(x0)) | ((xj == GC_V(x0)) & (j < L_));
+	}
+	GC_EACH { if (L_ >= n) GC_V(pos) = L_; }
+	GC_PERMUTE64(y0, x0, pos);
+	GC_PERMUTE64(y1, x1, pos);
+	GC_EACH GC_V(pm) = L_ < n ? GC_V(y1) : 0;
+	for (int32_t d = 1; d < 64; d <<= 1) {
+		GC_EACH { const uint64_t o = GC_SHUP(pm, d); GC_V(t64) = L_ >= d && o > GC_V(pm) ? o : GC_V(pm); }
+		GC_EACH GC_V(pm) = GC_V(t64);
+	}
+	GC_EACH { const uint64_t before = GC_UP1(pm); GC_V(open) = L_ < n && (L_ == 0 || GC_V(y0) > before); }
+	const uint64_t mo = GC_VBALLOT(open);
+	GC_EACH { const uint64_t above = L_ < 63 ? mo & ~((2ULL << L_) - 1ULL) : 0; GC_V(nxt) = (above ? (int32_t)__builtin_ctzll(above) : n) - 1; }
+	GC_EACH { const uint64_t end = GC_GET(pm, GC_V(nxt)); if (GC_V(open)) { gc_intv_t *o = &L->a[GC_VRANK(mo)]; o->vd0 = GC_V(y0), o->vd1 = end; } }
+	L->n = GC_POPC64(mo);
+	gc_sync();
+	return GC_OK;
+}
+/* gc_gw_dedup() behind the interval merge for a wavefront of up to 64 cells, one lane per cell, the cells in registers: the stable order
+ * (in-order cells keep their place; the flagged ones sorted by the klib insertion sort -- stable up to 64 records -- and merged in behind equal
+ * in-order cells, gfa-ed.c:143-171) is a RANK every lane counts for its own cell; the cells change lanes; a lane looks through its group of equal
+ * (vertex, diagonal) for a cell that beats its own, asks the finished-diagonal list, and the survivors are stored in rank order.  Returns *done = 0
+ * without touching anything when the in-order cells are not in order (never seen; the memory path then does what the reference would). */
+GC_HD int gc_gw_dedup_block(gc_gw_t *z, int32_t *n_a_, gc_diag_t *a, int *done)
+{
+	const int32_t n = *n_a_;
+	int32_t vlo[GC_WN], vhi[GC_WN], k[GC_WN], t[GC_WN], xo[GC_WN];
+	int in[GC_WN], bad[GC_WN], keep[GC_WN];
+	GC_EACH {
+		GC_V(in) = L_ < n;
+		GC_V(vlo) = GC_V(vhi) = -1, GC_V(k) = 0, GC_V(t) = 0, GC_V(xo) = 0; /* (lanes beyond n hold the largest key: they stay where they are) */
+		if (GC_V(in)) { const gc_diag_t me = a[L_]; GC_V(vlo) = (int32_t)(uint32_t)me.vd, GC_V(vhi) = (int32_t)(me.vd >> 32), GC_V(k) = me.k, GC_V(t) = me.t, GC_V(xo) = (int32_t)me.xo; }
+	}
+#define GC_VD_(lo, hi) ((uint64_t)(uint32_t)(hi) << 32 | (uint32_t)(lo))
+	GC_EACH { const uint64_t l = GC_VD_(GC_UP1(vlo), GC_UP1(vhi)); GC_V(bad) = GC_V(in) && L_ > 0 && l > GC_VD_(GC_V(vlo), GC_V(vhi)); }
+	*done = 1;
+	if (GC_VBALLOT(bad)) {
+		int32_t pos[GC_WN], tmp[GC_WN];
+		int inv[GC_WN];
+		GC_EACH { GC_V(pos) = 0, GC_V(inv) = 0; }
+		for (int32_t j = 0; j < n; ++j) {
+			GC_EACH {
+				const uint64_t vj = GC_VD_(GC_GET(vlo, j), GC_GET(vhi, j)), vi = GC_VD_(GC_V(vlo), GC_V(vhi));
+				const int fj = GC_GET(xo, j) & 1, fi = GC_V(xo) & 1;
+				GC_V(pos) += (vj < vi) | ((vj == vi) & ((fj < fi) | ((fj == fi) & (j < L_))));
+				GC_V(inv) |= GC_V(in) & !fi & !fj & (j < L_) & (vj > vi);
+			}
+		}
+		if (GC_VBALLOT(inv)) { GC_STAT(gc_stats.blk_fallback++;) *done = 0; return GC_OK; }
+		GC_STAT(gc_stats.blk_sorted++;)
+		GC_EACH { if (!GC_V(in)) GC_V(pos) = L_; GC_V(xo) &= ~1; } /* the merge leaves every cell unflagged (gfa-ed.c:165) */
+		GC_PERMUTE32(tmp, vlo, pos); GC_EACH GC_V(vlo) = GC_V(tmp);
+		GC_PERMUTE32(tmp, vhi, pos); GC_EACH GC_V(vhi) = GC_V(tmp);
+		GC_PERMUTE32(tmp, k, pos);   GC_EACH GC_V(k) = GC_V(tmp);
+		GC_PERMUTE32(tmp, t, pos);   GC_EACH GC_V(t) = GC_V(tmp);
+		GC_PERMUTE32(tmp, xo, pos);  GC_EACH GC_V(xo) = GC_V(tmp);
+	}
+	GC_STAT(gc_stats.blk_dedup++;)
+	GC_EACH GC_V(keep) = GC_V(in);
+	for (int32_t j = 0; j < n; ++j) { /* keep the furthest cell of every (vertex, diagonal): the first of equals */
+		GC_EACH {
+			const int same = GC_GET(vlo, j) == GC_V(vlo) && GC_GET(vhi, j) == GC_V(vhi);
+			const int32_t kj = GC_GET(k, j);
+			if (same && ((j < L_ && !(kj < GC_V(k))) || (j > L_ && GC_V(k) < kj))) GC_V(keep) = 0;
+		}
+	}
+	if (z->done.n > 0) { /* drop cells on finished diagonals (gfa-ed.c:192-202): the intervals are disjoint and ascending */
+		const int32_t n_b = z->done.n;
+		const gc_intv_t *b = z->done.a;
+		GC_EACH {
+			if (GC_V(keep)) {
+				const uint64_t vd = GC_VD_(GC_V(vlo), GC_V(vhi));
+				int32_t lo = 0, hi = n_b; /* first interval whose end lies beyond the cell */
+				while (lo < hi) { const int32_t m = (lo + hi) >> 1; if (b[m].vd1 <= vd) lo = m + 1; else hi = m; }
+				if (lo < n_b && vd >= b[lo].vd0) GC_V(keep) = 0;
+			}
+		}
+	}
+	const uint64_t mK = GC_VBALLOT(keep);
+	GC_EACH {
+		if (GC_V(keep)) {
+			gc_diag_t c;
+			c.vd = GC_VD_(GC_V(vlo), GC_V(vhi)), c.k = GC_V(k), c.len = 0, c.xo = (uint32_t)GC_V(xo), c.t = GC_V(t), c.pad_[0] = c.pad_[1] = 0;
+			a[GC_VRANK(mK)] = c;
+		}
+	}
+#undef GC_VD_
+	*n_a_ = GC_POPC64(mK);
+	gc_sync();
+	return GC_OK;
+}
+#endif
+#ifdef GC_WAVEPATH
+/* the same for a wavefront of any size with up to 64 flagged cells, in two passes over memory instead of a dozen: (1) every cell is stored at its RANK in
+ * the stable order -- an in-order cell: the in-order cells in front of it (a running ballot count) plus the flagged cells with a smaller key; a flagged cell:
+ * the flagged cells in front of it in (key, position) order plus the in-order cells with a key not larger; the flagged cells sit one per lane meanwhile --
+ * (2) a lane takes its cell from the sorted copy, looks through its group, asks the finished list, and the survivors go back in rank order. */
+GC_HD int gc_gw_dedup_wave(gc_arena_t *A, gc_gw_t *z, int32_t *n_a_, gc_diag_t *a, int *done)
+{
+	const int32_t n = *n_a_;
+	int32_t n_c = 0;
+	int unsorted = 0;
+	*done = 0;
+	for (int32_t base = 0; base < n; base += 64) {
+		int f[GC_WN], u[GC_WN];
+		GC_EACH { const int32_t i = base + L_; GC_V(f) = i < n && (a[i].xo & 1); GC_V(u) = i < n && i > 0 && a[i - 1].vd > a[i].vd; }
+		n_c += GC_POPC64(GC_VBALLOT(f));
+		unsorted |= GC_VBALLOT(u) != 0;
+	}
+	if (n_c > 64) return GC_OK; /* (the klib sort of more than 64 records is not stable: the memory path replays it) */
+	GC_TRY(gc_vec_reserve(A, z->ooo, n));
+	gc_diag_t *tmp = z->ooo.a;
+	if (!unsorted) {
+		for (int32_t base = 0; base < n; base += 64) GC_EACH { const int32_t i = base + L_; if (i < n) tmp[i] = a[i]; }
+	} else {
+		if (z->cl == 0) GC_ALLOC(A, gc_diag_t, z->cl, 64);
+		gc_diag_t *cl = z->cl;
+		for (int32_t base = 0, kc = 0; base < n; base += 64) { /* the flagged cells, in order, with their position (in the len field) */
+			int f[GC_WN];
+			GC_EACH { const int32_t i = base + L_; GC_V(f) = i < n && (a[i].xo & 1); }
+			const uint64_t m = GC_VBALLOT(f);
+			GC_EACH { if (GC_V(f)) { gc_diag_t c = a[base + L_]; c.len = base + L_; cl[kc + GC_VRANK(m)] = c; } }
+			kc += GC_POPC64(m);
+		}
+		gc_sync();
+		uint64_t cvd[GC_WN];
+		int32_t cidx[GC_WN], cnb[GC_WN], ck[GC_WN], ct[GC_WN];
+		uint32_t cxo[GC_WN];
+		GC_EACH {
+			GC_V(cvd) = ~0ULL, GC_V(cidx) = 0x7fffffff, GC_V(cnb) = 0, GC_V(ck) = 0, GC_V(ct) = 0, GC_V(cxo) = 0;
+			if (L_ < n_c) { const gc_diag_t c = cl[L_]; GC_V(cvd) = c.vd, GC_V(cidx) = c.len, GC_V(ck) = c.k, GC_V(ct) = c.t, GC_V(cxo) = c.xo & 0xfffffffeU; }
+		}
+		int32_t n_b = 0;
+		uint64_t last_b = 0; /* key of the last in-order cell so far */
+		int inv_any = 0;
+		for (int32_t base = 0; base < n; base += 64) {
+			uint64_t vd[GC_WN];
+			int32_t pos[GC_WN], src[GC_WN];
+			int isb[GC_WN], inv[GC_WN], le[GC_WN];
+			gc_diag_t me[GC_WN];
+			GC_EACH {
+				const int32_t i = base + L_;
+				GC_V(vd) = 0, GC_V(isb) = 0;
+				if (i < n) { GC_V(me) = a[i]; GC_V(vd) = GC_V(me).vd, GC_V(isb) = !(GC_V(me).xo & 1); }
+			}
+			const uint64_t mb = GC_VBALLOT(isb);
+			GC_EACH { const uint64_t below = mb & ((1ULL << L_) - 1ULL); GC_V(src) = below ? 63 - (int32_t)__builtin_clzll(below) : L_; GC_V(pos) = n_b + GC_POPC64(below); }
+			GC_EACH { /* in-order cells must be in order among themselves */
+				const uint64_t below = mb & ((1ULL << L_) - 1ULL);
+				const uint64_t prev = GC_GET(vd, GC_V(src));
+				GC_V(inv) = GC_V(isb) && (below ? prev > GC_V(vd) : (n_b > 0 && last_b > GC_V(vd)));
+			}
+			inv_any |= GC_VBALLOT(inv) != 0;
+			for (int32_t j = 0; j < n_c; ++j) {
+				const uint64_t cj = GC_GET(cvd, j);
+				GC_EACH { GC_V(pos) += GC_V(isb) & (cj < GC_V(vd)); GC_V(le) = GC_V(isb) & (GC_V(vd) <= cj); }
+				const int32_t cnt = GC_POPC64(GC_VBALLOT(le));
+				GC_EACH { if (L_ == j) GC_V(cnb) += cnt; }
+			}
+			GC_EACH { if (GC_V(isb)) { gc_diag_t c = GC_V(me); c.len = 0; tmp[GC_V(pos)] = c; } }
+			if (mb) { const int32_t hi = 63 - (int32_t)__builtin_clzll(mb); last_b = GC_GET(vd, hi); }
+			n_b += GC_POPC64(mb);
+		}
+		if (inv_any) return GC_OK; /* never seen; nothing but scratch was written */
+		{ /* the flagged cells among themselves: by (key, position) */
+			int32_t pos[GC_WN];
+			GC_EACH GC_V(pos) = GC_V(cnb);
+			for (int32_t j = 0; j < n_c; ++j) {
+				const uint64_t cj = GC_GET(cvd, j);
+				const int32_t ij = GC_GET(cidx, j);
+				GC_EACH GC_V(pos) += (cj < GC_V(cvd)) | ((cj == GC_V(cvd)) & (ij < GC_V(cidx)));
+			}
+			GC_EACH { if (L_ < n_c) { gc_diag_t c; c.vd = GC_V(cvd), c.k = GC_V(ck), c.len = 0, c.xo = GC_V(cxo), c.t = GC_V(ct), c.pad_[0] = c.pad_[1] = 0; tmp[GC_V(pos)] = c; } }
+		}
+	}
+	gc_sync();
+	const int32_t n_d = z->done.n;
+	const gc_intv_t *dn = z->done.a;
+	int32_t n_out = 0;
+	for (int32_t base = 0; base < n; base += 64) {
+		int keep[GC_WN];
+		gc_diag_t me[GC_WN];
+		GC_EACH {
+			const int32_t i = base + L_;
+			GC_V(keep) = 0;
+			if (i < n) {
+				GC_V(me) = tmp[i];
+				const uint64_t vd = GC_V(me).vd;
+				const int32_t k = GC_V(me).k;
+				int kp = 1;
+				for (int32_t j = i - 1; j >= 0 && tmp[j].vd == vd; --j) if (!(tmp[j].k < k)) { kp = 0; break; } /* an earlier cell at least as far */
+				if (kp) for (int32_t j = i + 1; j < n && tmp[j].vd == vd; ++j) if (k < tmp[j].k) { kp = 0; break; } /* a later cell strictly further */
+				if (kp && n_d > 0) { /* on a finished diagonal (gfa-ed.c:192-202)?  the intervals are disjoint and ascending */
+					if (n_d <= 8) { for (int32_t m = 0; m < n_d; ++m) if (vd >= dn[m].vd0 && vd < dn[m].vd1) kp = 0; }
+					else {
+						int32_t lo = 0, hi = n_d;
+						while (lo < hi) { const int32_t m = (lo + hi) >> 1; if (dn[m].vd1 <= vd) lo = m + 1; else hi = m; }
+						if (lo < n_d && vd >= dn[lo].vd0) kp = 0;
+					}
+				}
+				GC_V(keep) = kp;
+			}
+		}
+		const uint64_t mk = GC_VBALLOT(keep);
+		GC_EACH { if (GC_V(keep)) a[n_out + GC_VRANK(mk)] = GC_V(me); }
+		n_out += GC_POPC64(mk);
+	}
+	gc_sync();
+	*n_a_ = n_out;
+	*done = 1;
+	return GC_OK;
+}
+#endif
 GC_HD int gc_gw_dedup(gc_arena_t *A, gc_gw_t *z, int32_t *n_a_, gc_diag_t *a) /* gwf_dedup, gfa-ed.c:258-271 */
 {
 	int32_t n_a = *n_a_;
+#ifdef GC_WAVEPATH
+	if (z->fresh.n > 0 && z->done.n + z->fresh.n <= 64) { GC_STAT(gc_stats.blk_merge++;) GC_TRY(gc_intv_add_wave(A, &z->done, &z->fresh)); } else
+#endif
 	for (int32_t i = 0; i < z->fresh.n; ++i) GC_TRY(gc_intv_add(A, &z->done, z->fresh.a[i].vd0, z->fresh.a[i].vd1)); /* this step's finished diagonals */
+	GC_STAT(gc_stats.dedup_calls++; { int nc_ = 0, uns_ = 0; for (int32_t i = 0; i < n_a; ++i) { nc_ += a[i].xo & 1; if (i && a[i - 1].vd > a[i].vd) uns_ = 1; } gc_stats.dd_sum_n += n_a, gc_stats.dd_sum_fresh += z->fresh.n, gc_stats.dd_sum_nc += nc_, gc_stats.dd_unsorted += uns_;
+		gc_stats.dd_n[gc_stats_bin(n_a)]++, gc_stats.dd_fresh[gc_stats_bin(z->fresh.n)]++, gc_stats.dd_nc[gc_stats_bin(nc_)]++; })
+	GC_STAT(gc_stats.dd_sum_done += z->done.n; gc_stats.dd_done[gc_stats_bin(z->done.n)]++;)
+#ifdef GC_WAVEPATH
+	if (n_a <= 64) {
+		int done;
+		GC_TRY(gc_gw_dedup_block(z, n_a_, a, &done));
+		if (done) return GC_OK;
+	} else {
+		int done;
+		GC_TRY(gc_gw_dedup_wave(A, z, n_a_, a, &done));
+		GC_STAT(gc_stats.blk_wave += done;)
+		if (done) return GC_OK;
+	}
+#endif
 	{
 		int unsorted = 0;
 		GC_PAR_FOR(i, n_a) if (i > 0 && a[i - 1].vd > a[i].vd) unsorted = 1;
@@ -1313,54 +1622,6 @@ GC_HD int gc_gw_extend_run(gc_arena_t *A, gc_gw_t *z, int32_t n, gc_diag_t *a, g
 	GC_TRY(gc_vec_reserve(A, *B, B->n + n + 2));
 	GC_TRY(gc_vec_reserve(A, *H, H->n + n));
 	GC_TRY(gc_vec_reserve(A, z->fresh, z->fresh.n + n + 2));
-#if defined(__HIP_DEVICE_COMPILE__)
-	if (n <= 64) { /* the usual case, a run fits the wavefront: a lane keeps its diagonal in registers from the extension to the compacted output, the
-	                * neighbours' cells come by lane shuffles, places in H / B / the finished list by ballots -- one pass over memory, one fence */
-		const int32_t j = GC_LANE;
-		const int in = j < n;
-		gc_diag_t me;
-		me.vd = 0, me.k = 0, me.len = 0, me.xo = 0, me.t = 0;
-		if (in) {
-			me = a[j];
-			const int32_t k2 = gc_extend1((int32_t)me.vd - GC_DSHIFT, me.k, vl, ts, z->ql, z->q);
-			me.len = k2 - me.k, me.xo += (uint32_t)me.len << 2, me.k = k2;
-		}
-		const int32_t kL = __shfl_up(me.k, 1), tL = __shfl_up(me.t, 1), kR = __shfl_down(me.k, 1), tR = __shfl_down(me.t, 1);
-		const uint32_t xL = __shfl_up(me.xo, 1), xR = __shfl_down(me.xo, 1);
-		/* the cell of my diagonal in the next wavefront */
-		uint32_t mx = me.xo + 4;
-		int32_t mk = me.k + 1, mt = me.t;
-		if (in && j > 0 && kL > me.k + 1) mx = xL + 2, mk = kL, mt = tL;
-		if (in && j + 1 < n && !(mk > kR + 1)) mx = xR + 2, mt = tR, mk = kR + 1;
-		const int32_t d = (int32_t)me.vd - GC_DSHIFT;
-		/* cells at a vertex / query end go to H, flagged, in diagonal order */
-		{
-			const int at_end = in && (me.k == vl - 1 || d + me.k == z->ql - 1);
-			const uint64_t m = gc_ballot(at_end);
-			if (at_end) { gc_diag_t h = me; h.xo |= 1; H->a[H->n + gc_rank(m)] = h; }
-			H->n += gc_popc(m);
-		}
-		/* output order: the cell left of the run (lane 0), the run's cells, the cell right of it (lane n - 1) */
-		const int is0 = in && j == 0, isN = in && j == n - 1;
-		const int32_t k0 = me.k + 1, kN = me.k; /* left edge: vd - 1, xo + 2, k + 1; right edge: vd + 1, xo + 2, k */
-		const int keep0 = is0 && (d - 1) + k0 < z->ql && k0 < vl, fin0 = is0 && !keep0 && k0 == vl;
-		const int keepM = in && d + mk < z->ql && mk < vl, finM = in && !keepM && mk == vl;
-		const int keepN = isN && (d + 1) + kN < z->ql && kN < vl, finN = isN && !keepN && kN == vl;
-		const uint64_t b0 = gc_ballot(keep0), bM = gc_ballot(keepM), bN = gc_ballot(keepN), f0 = gc_ballot(fin0), fM = gc_ballot(finM), fN = gc_ballot(finN);
-		gc_diag_t *b = &B->a[B->n];
-		gc_intv_t *fr = &z->fresh.a[z->fresh.n];
-		if (keep0) { gc_diag_t c; c.vd = me.vd - 1, c.k = k0, c.len = 0, c.xo = me.xo + 2, c.t = me.t; b[0] = c; }
-		if (keepM) { gc_diag_t c; c.vd = me.vd, c.k = mk, c.len = 0, c.xo = mx, c.t = mt; b[gc_popc(b0) + gc_rank(bM)] = c; }
-		if (keepN) { gc_diag_t c; c.vd = me.vd + 1, c.k = kN, c.len = 0, c.xo = me.xo + 2, c.t = me.t; b[gc_popc(b0) + gc_popc(bM)] = c; }
-		if (fin0) { fr[0].vd0 = gc_mk_vd(v, d - 1), fr[0].vd1 = fr[0].vd0 + 1; }
-		if (finM) { gc_intv_t *iv = &fr[gc_popc(f0) + gc_rank(fM)]; iv->vd0 = gc_mk_vd(v, d), iv->vd1 = iv->vd0 + 1; }
-		if (finN) { gc_intv_t *iv = &fr[gc_popc(f0) + gc_popc(fM)]; iv->vd0 = gc_mk_vd(v, d + 1), iv->vd1 = iv->vd0 + 1; }
-		B->n += gc_popc(b0) + gc_popc(bM) + gc_popc(bN);
-		z->fresh.n += gc_popc(f0) + gc_popc(fM) + gc_popc(fN);
-		gc_sync();
-		return GC_OK;
-	}
-#endif
 	GC_PAR_FOR(j, n) {
 		const int32_t k = gc_extend1((int32_t)a[j].vd - GC_DSHIFT, a[j].k, vl, ts, z->ql, z->q);
 		a[j].len = k - a[j].k, a[j].xo += (uint32_t)(k - a[j].k) << 2, a[j].k = k;
@@ -1409,6 +1670,77 @@ GC_HD int gc_gw_extend_run(gc_arena_t *A, gc_gw_t *z, int32_t n, gc_diag_t *a, g
 	B->n += n_keep;
 	return GC_OK;
 }
+#ifdef GC_WAVEPATH
+/* the same for up to 64 cells made of WHOLE runs (the usual wavefront: a few runs of a dozen diagonals), one lane per cell: a lane keeps its cell in
+ * registers from the extension to the output, takes its neighbours' cells by lane exchange where they belong to its run, and finds its places in
+ * H / B / the finished list by ballots -- per run: [cell left of the run] [the run's cells] [cell right of it], runs in order, which is what calling
+ * gc_gw_extend_run() run by run appends.  One pass over memory and one fence for the whole block. */
+GC_HD int gc_gw_extend_block(gc_arena_t *A, gc_gw_t *z, int32_t n, int32_t n_runs, const gc_diag_t *a, gc_diag_v *B, gc_diag_v *H)
+{
+	GC_TRY(gc_vec_reserve(A, *B, B->n + n + 2 * n_runs));
+	GC_TRY(gc_vec_reserve(A, *H, H->n + n));
+	GC_TRY(gc_vec_reserve(A, z->fresh, z->fresh.n + n + 2 * n_runs));
+	GC_STAT(gc_stats.blk_ext++;)
+	uint64_t vd[GC_WN];
+	int32_t k[GC_WN], t[GC_WN], len[GC_WN], vl[GC_WN], mk[GC_WN], mt[GC_WN];
+	uint32_t xo[GC_WN], mx[GC_WN];
+	int in[GC_WN], first[GC_WN], last[GC_WN], at_end[GC_WN], keep0[GC_WN], keepM[GC_WN], keepN[GC_WN], fin0[GC_WN], finM[GC_WN], finN[GC_WN];
+	const int32_t ql = z->ql;
+	GC_EACH {
+		GC_V(in) = L_ < n;
+		GC_V(vd) = 0, GC_V(k) = 0, GC_V(t) = 0, GC_V(len) = 0, GC_V(vl) = 0, GC_V(xo) = 0, GC_V(first) = 0, GC_V(last) = 0;
+		if (GC_V(in)) {
+			const gc_diag_t me = a[L_];
+			GC_V(first) = L_ == 0 || a[L_ - 1].vd + 1 != me.vd;
+			GC_V(last) = L_ == n - 1 || a[L_ + 1].vd != me.vd + 1;
+			const uint32_t v = (uint32_t)(me.vd >> 32);
+			GC_V(vl) = gc_vlen(z->G, v);
+			const int32_t k2 = gc_extend1((int32_t)me.vd - GC_DSHIFT, me.k, GC_V(vl), gc_vseq(z->G, v), ql, z->q);
+			GC_V(vd) = me.vd, GC_V(t) = me.t, GC_V(len) = k2 - me.k, GC_V(xo) = me.xo + ((uint32_t)(k2 - me.k) << 2), GC_V(k) = k2;
+		}
+	}
+	GC_EACH { /* the cell of my diagonal in the next wavefront: the furthest of {insertion from the left, mismatch, deletion from the right} */
+		const int32_t kL = GC_UP1(k), tL = GC_UP1(t), kR = GC_DN1(k), tR = GC_DN1(t);
+		const uint32_t xL = GC_UP1(xo), xR = GC_DN1(xo);
+		uint32_t x = GC_V(xo) + 4;
+		int32_t kk = GC_V(k) + 1, tt = GC_V(t);
+		if (GC_V(in) && !GC_V(first) && kL > GC_V(k) + 1) x = xL + 2, kk = kL, tt = tL;
+		if (GC_V(in) && !GC_V(last) && !(kk > kR + 1)) x = xR + 2, tt = tR, kk = kR + 1;
+		GC_V(mx) = x, GC_V(mk) = kk, GC_V(mt) = tt;
+		const int32_t d = (int32_t)GC_V(vd) - GC_DSHIFT, k0 = GC_V(k) + 1, kN = GC_V(k), l = GC_V(vl);
+		GC_V(at_end) = GC_V(in) && (GC_V(k) == l - 1 || d + GC_V(k) == ql - 1);
+		GC_V(keep0) = GC_V(in) && GC_V(first) && (d - 1) + k0 < ql && k0 < l;
+		GC_V(fin0) = GC_V(in) && GC_V(first) && !GC_V(keep0) && k0 == l;
+		GC_V(keepM) = GC_V(in) && d + kk < ql && kk < l;
+		GC_V(finM) = GC_V(in) && !GC_V(keepM) && kk == l;
+		GC_V(keepN) = GC_V(in) && GC_V(last) && (d + 1) + kN < ql && kN < l;
+		GC_V(finN) = GC_V(in) && GC_V(last) && !GC_V(keepN) && kN == l;
+	}
+	const uint64_t mH = GC_VBALLOT(at_end), b0 = GC_VBALLOT(keep0), bM = GC_VBALLOT(keepM), bN = GC_VBALLOT(keepN), f0 = GC_VBALLOT(fin0), fM = GC_VBALLOT(finM), fN = GC_VBALLOT(finN);
+	GC_EACH {
+		gc_diag_t c;
+		c.len = 0, c.pad_[0] = c.pad_[1] = 0;
+		if (GC_V(at_end)) { /* cells at a vertex / query end go to H, flagged, in diagonal order */
+			c.vd = GC_V(vd), c.k = GC_V(k), c.len = GC_V(len), c.xo = GC_V(xo) | 1, c.t = GC_V(t);
+			H->a[H->n + GC_VRANK(mH)] = c;
+			c.len = 0;
+		}
+		gc_diag_t *b = &B->a[B->n + GC_VRANK(b0) + GC_VRANK(bM) + GC_VRANK(bN)];
+		if (GC_V(keep0)) { c.vd = GC_V(vd) - 1, c.k = GC_V(k) + 1, c.xo = GC_V(xo) + 2, c.t = GC_V(t); *b++ = c; }
+		if (GC_V(keepM)) { c.vd = GC_V(vd), c.k = GC_V(mk), c.xo = GC_V(mx), c.t = GC_V(mt); *b++ = c; }
+		if (GC_V(keepN)) { c.vd = GC_V(vd) + 1, c.k = GC_V(k), c.xo = GC_V(xo) + 2, c.t = GC_V(t); *b++ = c; }
+		gc_intv_t *fr = &z->fresh.a[z->fresh.n + GC_VRANK(f0) + GC_VRANK(fM) + GC_VRANK(fN)]; /* a diagonal that ran off the vertex end is finished */
+		if (GC_V(fin0)) { fr->vd0 = GC_V(vd) - 1, fr->vd1 = fr->vd0 + 1; ++fr; }
+		if (GC_V(finM)) { fr->vd0 = GC_V(vd), fr->vd1 = fr->vd0 + 1; ++fr; }
+		if (GC_V(finN)) { fr->vd0 = GC_V(vd) + 1, fr->vd1 = fr->vd0 + 1; ++fr; }
+	}
+	H->n += GC_POPC64(mH);
+	B->n += GC_POPC64(b0) + GC_POPC64(bM) + GC_POPC64(bN);
+	z->fresh.n += GC_POPC64(f0) + GC_POPC64(fM) + GC_POPC64(fN);
+	gc_sync();
+	return GC_OK;
+}
+#endif
 /* one edit-distance step: consumes wf[cur], builds wf[cur^1]; *reached = 1 when (v1, off1) was hit (gfa-ed.c:405-507) */
 GC_HD int gc_gw_step(gc_arena_t *A, gc_gw_t *z, uint32_t v1, int32_t off1, int *reached)
 {
@@ -1417,6 +1749,7 @@ GC_HD int gc_gw_step(gc_arena_t *A, gc_gw_t *z, uint32_t v1, int32_t off1, int *
 	gc_diag_t *a = Cur->a;
 	int32_t n = Cur->n, head = 0, do_dedup = 1;
 	*reached = 0;
+	GC_STAT(int st_runs = 0; int st_long = 0;)
 	H->n = B->n = 0;
 	z->end_v = (uint32_t)-1, z->end_off = z->end_tb = -1;
 	z->fresh.n = 0;
@@ -1424,6 +1757,25 @@ GC_HD int gc_gw_step(gc_arena_t *A, gc_gw_t *z, uint32_t v1, int32_t off1, int *
 	gc_u64map_clear(&z->seen);
 	GC_TRY(gc_vec_reserve(A, *B, n * 2 + 4));
 	GC_TICK(A, 11);
+#ifdef GC_WAVEPATH
+	for (int32_t x = 0; x < n; ) { /* runs of adjacent diagonals on one vertex, as many WHOLE runs at a time as fit the 64 lanes */
+		int isend[GC_WN];
+		GC_EACH { const int32_t i = x + L_; GC_V(isend) = i < n && (i == n - 1 || a[i + 1].vd != a[i].vd + 1); }
+		const uint64_t m = GC_VBALLOT(isend);
+		if (m) {
+			const int32_t cnt = 64 - (int32_t)__builtin_clzll(m);
+			GC_TRY(gc_gw_extend_block(A, z, cnt, GC_POPC64(m), &a[x], B, H));
+			GC_STAT(st_runs += GC_POPC64(m);)
+			x += cnt;
+		} else { /* a run of more than 64 diagonals */
+			int32_t e = x + 64;
+			while (e < n && a[e].vd == a[e - 1].vd + 1) ++e;
+			GC_TRY(gc_gw_extend_run(A, z, e - x, &a[x], B, H));
+			GC_STAT(++st_runs; st_long = 1;)
+			x = e;
+		}
+	}
+#else
 	{ /* runs of adjacent diagonals on one vertex: the lanes look for the run ends, the runs are then taken in order */
 		int32_t x = 0;
 		for (int32_t base = 0; base < n; base += GC_NLANE) {
@@ -1438,11 +1790,15 @@ GC_HD int gc_gw_step(gc_arena_t *A, gc_gw_t *z, uint32_t v1, int32_t off1, int *
 				const int32_t e = base + bit + 1;
 				m &= m - 1;
 				GC_TRY(gc_gw_extend_run(A, z, e - x, &Cur->a[x], B, H));
+				GC_STAT(++st_runs; if (e - x > 64) st_long = 1;)
 				x = e;
 			}
 		}
 	}
+#endif
 	if (H->n == 0) do_dedup = 0;
+	GC_STAT(gc_stats.steps++; gc_stats.cells += n; gc_stats.runs += st_runs; gc_stats.heads0 += H->n; gc_stats.single += st_runs == 1; gc_stats.nohead += H->n == 0; gc_stats.single_nohead += st_runs == 1 && H->n == 0;
+			if (st_runs == 1 && H->n == 0) gc_stats.simple_cells += n; gc_stats.le64 += !st_long; gc_stats.dedup_steps += do_dedup; gc_stats.n_hist[gc_stats_bin(n)]++;)
 	GC_TICK(A, 12);
 	while (head < H->n) {
 		const gc_diag_t t = H->a[head++];
@@ -1451,6 +1807,7 @@ GC_HD int gc_gw_step(gc_arena_t *A, gc_gw_t *z, uint32_t v1, int32_t off1, int *
 		const int32_t k = gc_extend1(d, t.k, vl, gc_vseq(G, v), z->ql, z->q), qi = k + d;
 		const uint32_t x0 = (t.xo >> 1) + ((uint32_t)(k - t.k) << 1);
 		if (k + 1 < vl && qi + 1 < z->ql) { /* inside a vertex */
+			GC_STAT(gc_stats.hd_in++;)
 			int push1 = 1, push2 = 1;
 			if (B->n >= 2) push1 = gc_diag_update(&B->a[B->n - 2], v, d - 1, k + 1, x0 + 1, ooo, t.t);
 			if (B->n >= 1) push2 = gc_diag_update(&B->a[B->n - 1], v, d, k + 1, x0 + 2, ooo, t.t);
@@ -1458,6 +1815,7 @@ GC_HD int gc_gw_step(gc_arena_t *A, gc_gw_t *z, uint32_t v1, int32_t off1, int *
 			if (push2 || push1) GC_TRY(gc_diag_push(A, B, v, d, k + 1, x0 + 2, 1, t.t));
 			GC_TRY(gc_diag_push(A, B, v, d + 1, k, x0 + 1, ooo, t.t));
 		} else if (qi + 1 < z->ql) { /* end of the vertex, query not finished: fan out over the arcs */
+			GC_STAT(gc_stats.hd_arc++;)
 			const int32_t nv = gc_n_arc(G, v);
 			const gc_arc_t *av = gc_arcs(G, v);
 			int32_t n_ext = 0, tw;
@@ -1500,6 +1858,7 @@ GC_HD int gc_gw_step(gc_arena_t *A, gc_gw_t *z, uint32_t v1, int32_t off1, int *
 		}
 	}
 	GC_TICK(A, 13);
+	GC_STAT(gc_stats.heads += H->n; gc_stats.out += B->n;)
 	if (do_dedup) GC_TRY(gc_gw_dedup(A, z, &B->n, B->a));
 	GC_TICK(A, 14);
 	if (z->max_lag > 0 && B->n > z->max_chk && ((z->s + 1) & 0xf) == 0) B->n = gc_gw_prune(B->n, B->a, (uint32_t)z->max_lag, z->bw_dyn);
@@ -1543,6 +1902,7 @@ GC_HD int gc_gwfa(gc_arena_t *A, const gc_graph_t *G, int32_t ql, const char *q,
 		*path = p, *n_path = n;
 	}
 	*ed = z.end_v != (uint32_t)-1 ? z.s : -1;
+	GC_STAT(gc_stats.calls++; gc_stats.sum_ql += ql; gc_stats.reached += *ed >= 0; gc_stats.steps_hist[gc_stats_bin(z.s + 1)]++;)
 	return GC_OK;
 }
 
@@ -1614,7 +1974,9 @@ GC_HD int gc_bridge(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, gc_as
 			/* (the LDS scratch holds a call over a query gap of a few hundred bases -- [measured] 30 % of the calls of the bench workload fit 16 KB -- and a failed
 			 * attempt is paid twice, so only short gaps try it) */
 			if (A->fast_base && qe - qs <= GC_FAST_GAP) { gc_arena_t F; gc_arena_init(&F, A->fast_base, A->fast_cap, 0); F.ticks = A->ticks, F.tick_last = A->tick_last; rc = gc_gwfa(&F, G, qe - qs, qseq + qs, c0->v, c0->re - span, c1->v, c1->rs + span - 1, P->gdp_max_ed / 2, P->gdp_max_ed, &ed, &path, &n_path); A->tick_last = F.tick_last; if (rc == GC_OK) ++S->n_fast; }
+			GC_STAT(const int64_t st_top0 = A->top; const int64_t st_peak0 = A->peak; A->peak = A->top;)
 			if (rc == GC_E_ARENA) rc = gc_gwfa(A, G, qe - qs, qseq + qs, c0->v, c0->re - span, c1->v, c1->rs + span - 1, P->gdp_max_ed / 2, P->gdp_max_ed, &ed, &path, &n_path);
+			GC_STAT(if (A->base == base) { const int64_t used = A->peak - st_top0; gc_stats.arena_hist[gc_stats_bin(used >> 9)]++; gc_stats.arena_sum += used; if (used <= 16384) gc_stats.fit16++; if (used <= 32768) gc_stats.fit32++; if (used <= 65536) gc_stats.fit64++; } if (A->peak < st_peak0) A->peak = st_peak0;)
 			if (rc != GC_OK) return rc;
 			GC_TICK(A, 8);
 			++S->n_gwfa;

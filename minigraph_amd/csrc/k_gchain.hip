@@ -306,6 +306,14 @@ extern "C" mg_gchains_t *mga_gchain_host_read(const mg_idx_t *gi, const int32_t 
 	return gs;
 }
 
+#if defined(GC_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+extern "C" void mga_gc_stats_dump(void) { gc_stats_dump(); }
+extern "C" void mga_gc_stats_get(long long out[8]) // tests/test_wave_model.py: which wave paths ran
+{
+	out[0] = gc_stats.calls, out[1] = gc_stats.steps, out[2] = gc_stats.blk_ext, out[3] = gc_stats.dedup_calls, out[4] = gc_stats.blk_dedup, out[5] = gc_stats.blk_wave, out[6] = gc_stats.blk_fallback, out[7] = gc_stats.blk_merge;
+}
+#endif
+
 // ---- stage-level host entry points over the same core (CPU parity tests against the reference's mg_shortest_k / gfa_ed_step) ----
 typedef struct { // mg_path_dst_t, mgpriv.h:40-52
 	uint32_t v;
