@@ -32,8 +32,27 @@
 
 #if defined(__HIPCC__)
 #define GC_HD __host__ __device__ inline
+#ifdef GC_AB_NOINLINE   /* (A/B builds, tools/gchain_ab.py: the big routines as functions of their own -- half the code, [measured] 6-13 % slower) */
+#define GC_HDN __host__ __device__ __attribute__((noinline)) inline
+#else
+#define GC_HDN __host__ __device__ inline
+#endif
 #else
 #define GC_HD static inline
+#define GC_HDN static inline
+#endif
+
+/* A routine's bookkeeping state (vector headers, counters, search state).  Every lane of the wavefront holds the SAME values in it (replicated execution, below), so on the
+ * device ONE copy per wavefront in LDS serves all 64 lanes: a private copy per lane lives in scratch memory -- 64 times the footprint, a trip to L2 / HBM per access -- once
+ * its address is taken, which is how the routines here hand state to each other.  (k_gchain runs one wavefront per workgroup; the routines using it are not re-entered.) */
+/* Fields of such state sit on 16-byte boundaries (GC_F): the routines reach the state through plain pointers, the compiler merges neighbouring fields into one access, and a
+ * 16-byte access through a generic pointer into LDS must be 16-byte aligned (8 is enough in HBM: the aperture fault of round 2).  With every field on its own 16-byte slot
+ * there are no neighbours to merge, and whole-struct copies / clears start aligned. */
+#define GC_F __attribute__((aligned(16)))
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GC_AB_NO_LDS_STATE)
+#define GC_STATE(T, name) __shared__ T name##_lds_; T &name = name##_lds_
+#else
+#define GC_STATE(T, name) T name
 #endif
 
 #ifndef GC_PARSORT
@@ -47,14 +66,14 @@
 
 typedef struct gc_block_s { struct gc_block_s *prev; int64_t cap; } gc_block_t;
 typedef struct gc_arena_s {
-	char *base;          /* current block */
-	int64_t top, cap;
-	int32_t ovf;         /* set once an allocation failed (device: fixed capacity) */
-	int32_t growable;    /* host: chain further malloc'ed blocks instead of failing */
-	gc_block_t *blocks;  /* host: extra blocks, newest first */
-	int64_t peak;
-	unsigned long long *ticks; long long tick_last; /* profiling (device): cycles between consecutive GC_TICKs, summed per stage; NULL = off */
-	char *fast_base; int64_t fast_cap; /* device: a small block of LDS for the scratch of ONE graph search / GWFA call at a time (a tenth of the latency
+	GC_F char *base;          /* current block */
+	GC_F int64_t top; GC_F int64_t cap;
+	GC_F int32_t ovf;         /* set once an allocation failed (device: fixed capacity) */
+	GC_F int32_t growable;    /* host: chain further malloc'ed blocks instead of failing */
+	GC_F gc_block_t *blocks;  /* host: extra blocks, newest first */
+	GC_F int64_t peak;
+	GC_F unsigned long long *ticks; GC_F long long tick_last; /* profiling (device): cycles between consecutive GC_TICKs, summed per stage; NULL = off */
+	GC_F char *fast_base; GC_F int64_t fast_cap; /* device: a small block of LDS for the scratch of ONE graph search / GWFA call at a time (a tenth of the latency
 	                          * of HBM); a call that outgrows it is simply run again in the main arena.  NULL: everything in the main arena */
 } gc_arena_t;
 
@@ -125,40 +144,6 @@ GC_HD int32_t gc_sum(int32_t v) { return v; }
 #endif
 #define GC_PAR_FOR(i, n) for (int32_t i = GC_LANE; i < (n); i += GC_NLANE)   /* no allocation, no gc_sync() inside */
 
-/* ---- wave-vector notation: ONE source for the blocks that keep a GWFA wavefront in the registers of the 64 lanes.  On the device a "vector" is a
- * lane's scalar (arrays of one element) and GC_EACH runs its body once, for this lane; in the host's WAVE MODEL (-DGC_WAVE_MODEL: CPU tests of exactly
- * this code against the reference, tests/test_wave_model.py) a vector is an array of 64 and GC_EACH loops over the lanes.  Rules that make the two
- * agree: a GC_EACH body touches its own lane's elements only; values of other lanes are read with GC_UP1 / GC_DN1 / GC_GET / GC_VBALLOT from vectors
- * completed by an EARLIER GC_EACH; memory another lane has written is read only behind a gc_sync(). */
-#if defined(__HIP_DEVICE_COMPILE__)
-#define GC_WAVEPATH 1
-#define GC_WN 1
-#define GC_EACH for (int32_t L_ = GC_LANE, gc_once_ = 1; gc_once_; gc_once_ = 0)
-#define GC_V(x) (x)[0]
-#define GC_UP1(x) __shfl_up((x)[0], 1)          /* lane - 1 (lane 0: its own) */
-#define GC_DN1(x) __shfl_down((x)[0], 1)        /* lane + 1 (lane 63: its own) */
-#define GC_GET(x, src) __shfl((x)[0], (src))    /* src: the same in every lane */
-#define GC_VBALLOT(p) __ballot((p)[0])
-#define GC_PERMUTE32(dst, src, pos) ((dst)[0] = __builtin_amdgcn_ds_permute((pos)[0] << 2, (int)(src)[0])) /* dst[pos[lane]] = src[lane]; pos a permutation of the lanes; dst != src */
-#define GC_PERMUTE64(dst, src, pos) ((dst)[0] = (uint64_t)(uint32_t)__builtin_amdgcn_ds_permute((pos)[0] << 2, (int)(uint32_t)(src)[0]) | (uint64_t)(uint32_t)__builtin_amdgcn_ds_permute((pos)[0] << 2, (int)(uint32_t)((src)[0] >> 32)) << 32)
-#define GC_SHUP(x, d) __shfl_up((x)[0], (d))    /* lane - d (lanes below d: their own) */
-#elif defined(GC_WAVE_MODEL)
-#define GC_WAVEPATH 1
-#define GC_WN 64
-#define GC_EACH for (int32_t L_ = 0; L_ < 64; ++L_)
-#define GC_V(x) (x)[L_]
-#define GC_UP1(x) (x)[L_ > 0 ? L_ - 1 : L_]
-#define GC_DN1(x) (x)[L_ < 63 ? L_ + 1 : L_]
-#define GC_GET(x, src) (x)[(src)]
-static inline uint64_t gc_vballot_(const int *p) { uint64_t m = 0; for (int i = 0; i < 64; ++i) if (p[i]) m |= 1ULL << i; return m; }
-#define GC_VBALLOT(p) gc_vballot_(p)
-#define GC_PERMUTE32(dst, src, pos) do { for (int i_ = 0; i_ < 64; ++i_) (dst)[(pos)[i_]] = (int32_t)(src)[i_]; } while (0)
-#define GC_PERMUTE64(dst, src, pos) do { for (int i_ = 0; i_ < 64; ++i_) (dst)[(pos)[i_]] = (src)[i_]; } while (0)
-#define GC_SHUP(x, d) (x)[L_ >= (d) ? L_ - (d) : L_]
-#endif
-#define GC_VRANK(m) ((int32_t)__builtin_popcountll((m) & ((1ULL << L_) - 1ULL)))   /* set bits below this lane (inside GC_EACH) */
-#define GC_POPC64(m) ((int32_t)__builtin_popcountll(m))
-
 /* non-overlapping copy in 4-byte units by all lanes */
 GC_HD void gc_pcopy(void *dst, const void *src, int64_t bytes)
 {
@@ -200,9 +185,9 @@ GC_HD void gc_pmove_up(void *dst, const void *src, int64_t bytes)
 }
 
 /* growable array in the arena: {a, n, m}; growth re-allocates at the top (in place when the array is the last allocation) */
-#define GC_VEC(T) struct { T *a; int32_t n, m; }
+#define GC_VEC(T) struct { GC_F T *a; GC_F int32_t n; GC_F int32_t m; }
 #define gc_vec_zero(v) ((v).a = 0, (v).n = (v).m = 0)
-GC_HD int gc_vec_grow_(gc_arena_t *A, void **pa, int32_t *pm, int32_t n_used, int32_t need, int32_t esz)
+GC_HDN int gc_vec_grow_(gc_arena_t *A, void **pa, int32_t *pm, int32_t n_used, int32_t need, int32_t esz)
 {
 	if (need <= *pm) return GC_OK;
 	int32_t m = *pm < 8 ? 8 : *pm + (*pm >> 1);
@@ -220,7 +205,7 @@ GC_HD int gc_vec_grow_(gc_arena_t *A, void **pa, int32_t *pm, int32_t n_used, in
 	*pa = p, *pm = m;
 	return GC_OK;
 }
-#define gc_vec_reserve(A, v, need) gc_vec_grow_((A), (void**)&(v).a, &(v).m, (v).n, (need), (int32_t)sizeof(*(v).a))
+#define gc_vec_reserve(A, v, need) ((need) <= (v).m ? GC_OK : gc_vec_grow_((A), (void**)&(v).a, &(v).m, (v).n, (need), (int32_t)sizeof(*(v).a)))
 #define GC_TRY(expr) do { int rc_ = (expr); if (rc_ != GC_OK) return rc_; } while (0)
 #define GC_PUSH(A, v, ptr) do { GC_TRY(gc_vec_reserve((A), (v), (v).n + 1)); (ptr) = &(v).a[(v).n++]; } while (0)
 #define GC_ALLOC(A, T, ptr, count) do { (ptr) = (T*)gc_alloc((A), (int64_t)(count) * (int64_t)sizeof(T)); if ((ptr) == 0) return GC_E_ARENA; } while (0)
@@ -267,7 +252,7 @@ GC_HD void gc_isort(gc_kv_t *a, int32_t n)
 	}
 }
 
-GC_HD int gc_ksort(gc_arena_t *A, gc_kv_t *a, int32_t n, int key_bytes)
+GC_HDN int gc_ksort(gc_arena_t *A, gc_kv_t *a, int32_t n, int key_bytes)
 {
 	if (n <= 64) { gc_isort(a, n); return GC_OK; }
 	const int64_t mark = A->top;
@@ -312,7 +297,7 @@ GC_HD int gc_ksort(gc_arena_t *A, gc_kv_t *a, int32_t n, int key_bytes)
 }
 
 /* plain ascending sort of 64-bit values whose order among equals cannot matter (whole value is the key) */
-GC_HD void gc_sort_u64(uint64_t *a, int32_t n)
+GC_HDN void gc_sort_u64(uint64_t *a, int32_t n)
 {
 	for (int32_t i = n / 2 - 1; i >= 0; --i) { /* heap sort: O(n log n) without scratch */
 		int32_t k = i; uint64_t t = a[k];
@@ -332,30 +317,43 @@ GC_HD void gc_sort_u64(uint64_t *a, int32_t n)
 typedef struct { uint64_t v_lv; uint32_t w; int32_t rank; int32_t ov, ow; uint64_t link_bits; } gc_arc_t; /* byte layout of gfa_arc_t (gfa.h:33-39) */
 
 typedef struct {
-	const gc_arc_t *arc;
-	const uint64_t *idx;          /* per vertex: first arc << 32 | number of arcs (gfa.h:99-101) */
-	const int32_t *seg_len;
+	GC_F const gc_arc_t *arc;
+	GC_F const uint64_t *idx;          /* per vertex: first arc << 32 | number of arcs (gfa.h:99-101) */
+	GC_F const int32_t *seg_len;
 	/* oriented vertex sequences: either one pointer per vertex (host: gfa_edseq_t[]) or two flat copies (device) */
-	const gfa_edseq_t *es;
-	const char *seq_fw, *seq_rc;
-	const int64_t *seq_off;
+	GC_F const gfa_edseq_t *es;
+	GC_F const char *seq_fw; GC_F const char *seq_rc;
+	GC_F const int64_t *seq_off;
 } gc_graph_t;
 
-GC_HD const char *gc_vseq(const gc_graph_t *G, uint32_t v) { return G->es ? G->es[v].seq : ((v & 1) ? G->seq_rc : G->seq_fw) + G->seq_off[v >> 1]; }
-GC_HD int32_t gc_vlen(const gc_graph_t *G, uint32_t v) { return G->seg_len[v >> 1]; }
-GC_HD int32_t gc_n_arc(const gc_graph_t *G, uint32_t v) { return (int32_t)(uint32_t)G->idx[v]; }
-GC_HD const gc_arc_t *gc_arcs(const gc_graph_t *G, uint32_t v) { return G->arc + (G->idx[v] >> 32); }
+/* The graph is read-only while the kernel runs and every caller below asks with the SAME vertex in all 64 lanes: on the device such a load goes through the scalar unit
+ * (a pointer made wave-uniform, into the constant address space: s_load through the scalar cache) instead of a 64-lane vector load of one address. */
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GC_ULOAD)
+template<typename T> __device__ inline T gc_uload(const T *p)
+{
+	const uint64_t u = (uint64_t)p;
+	const uint64_t s = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(u >> 32)) << 32 | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)u);
+	return *(const __attribute__((address_space(4))) T*)s;
+}
+#define GC_UL(expr) gc_uload(&(expr))
+#else
+#define GC_UL(expr) (expr)
+#endif
+GC_HD const char *gc_vseq(const gc_graph_t *G, uint32_t v) { return G->es ? G->es[v].seq : ((v & 1) ? G->seq_rc : G->seq_fw) + GC_UL(G->seq_off[v >> 1]); }
+GC_HD int32_t gc_vlen(const gc_graph_t *G, uint32_t v) { return GC_UL(G->seg_len[v >> 1]); }
+GC_HD int32_t gc_n_arc(const gc_graph_t *G, uint32_t v) { return (int32_t)(uint32_t)GC_UL(G->idx[v]); }
+GC_HD const gc_arc_t *gc_arcs(const gc_graph_t *G, uint32_t v) { return G->arc + (GC_UL(G->idx[v]) >> 32); }
 
 /* ------------------------------------------------------------------------------------------------ parameters, records */
 
 typedef struct {
-	int32_t k;                                  /* minimizer length of the index */
-	int32_t bw, bw_long, max_gap;               /* mg_mapopt_t */
-	int32_t min_lc_cnt, lc_max_occ, lc_max_trim;
-	int32_t max_gc_skip, ref_bonus, min_gc_cnt, min_gc_score, gdp_max_ed;
-	int32_t best_n, sub_diff;
-	float chn_pen_gap;                          /* already scaled by exp(-div * k) (map-algo.c:388-390) */
-	float mask_level, pri_ratio;
+	GC_F int32_t k;                                  /* minimizer length of the index */
+	GC_F int32_t bw; GC_F int32_t bw_long; GC_F int32_t max_gap;               /* mg_mapopt_t */
+	GC_F int32_t min_lc_cnt; GC_F int32_t lc_max_occ; GC_F int32_t lc_max_trim;
+	GC_F int32_t max_gc_skip; GC_F int32_t ref_bonus; GC_F int32_t min_gc_cnt; GC_F int32_t min_gc_score; GC_F int32_t gdp_max_ed;
+	GC_F int32_t best_n; GC_F int32_t sub_diff;
+	GC_F float chn_pen_gap;                          /* already scaled by exp(-div * k) (map-algo.c:388-390) */
+	GC_F float mask_level; GC_F float pri_ratio;
 } gc_par_t;
 
 typedef struct { /* one linear chain (what mg_lchain_t carries, mgpriv/minigraph.h:100-106) */
@@ -374,11 +372,11 @@ typedef struct { /* one graph chain, integer fields only; div and mapq are deriv
 } gc_rec_t;
 
 typedef struct {
-	int32_t n_gc, n_lc, n_a;
-	gc_rec_t *gc;              /* arena */
-	mg_llchain_t *lc;          /* arena */
-	mg128_t *a;                /* caller's buffer (capacity: the read's chained anchors) */
-	int32_t n_gwfa, n_shortk, n_fast;  /* counters (n_fast: GWFA calls + graph searches that ran in the LDS scratch) */
+	GC_F int32_t n_gc; GC_F int32_t n_lc; GC_F int32_t n_a;
+	GC_F gc_rec_t *gc;              /* arena */
+	GC_F mg_llchain_t *lc;          /* arena */
+	GC_F mg128_t *a;                /* caller's buffer (capacity: the read's chained anchors) */
+	GC_F int32_t n_gwfa; GC_F int32_t n_shortk; GC_F int32_t n_fast;  /* counters (n_fast: GWFA calls + graph searches that ran in the LDS scratch) */
 } gc_result_t;
 
 /* ------------------------------------------------------------------------------------------------ chain records + clean-up */
@@ -608,7 +606,7 @@ typedef struct { int32_t k; int32_t p[MG_MAX_SHORT_K]; } gc_sklist_t;           
 typedef struct {
 	GC_VEC(gc_sknode_t) nd;
 	GC_VEC(int32_t) heap;
-	uint32_t *hk; int32_t *hv; uint32_t hcap, hcnt;   /* vertex -> index into tk, open addressing */
+	GC_F uint32_t *hk; GC_F int32_t *hv; GC_F uint32_t hcap; GC_F uint32_t hcnt;   /* vertex -> index into tk, open addressing */
 	GC_VEC(gc_sklist_t) tk;
 } gc_sk_t;
 
@@ -722,7 +720,7 @@ GC_HD int32_t gc_grp_find(int32_t n, const uint64_t *grp, uint32_t v, int32_t *c
 /* Up to max_k shortest walks from src to every destination vertex within max_dist (shortk.c:41-242): a Dijkstra search in which a
  * vertex may be settled max_k times.  The frontier key dist<<32|serial is unique, so the settle order is a function of the arc
  * order alone.  walk != NULL: also return the settled walks needed to backtrack to the destinations (gc_walkv_t[], *n_walk). */
-GC_HD int gc_shortest_k(gc_arena_t *A, const gc_graph_t *G, uint32_t src, int32_t n_dst, gc_dst_t *dst, int32_t max_dist, int32_t max_k,
+GC_HDN int gc_shortest_k(gc_arena_t *A, const gc_graph_t *G, uint32_t src, int32_t n_dst, gc_dst_t *dst, int32_t max_dist, int32_t max_k,
 						gc_walkv_t **walk, int32_t *n_walk)
 {
 	if (walk) *walk = 0, *n_walk = 0;
@@ -733,7 +731,7 @@ GC_HD int gc_shortest_k(gc_arena_t *A, const gc_graph_t *G, uint32_t src, int32_
 		else t->dist = -1, t->n_path = 0, t->path_end = -1;
 	}
 	if (max_k > MG_MAX_SHORT_K) max_k = MG_MAX_SHORT_K;
-	gc_sk_t S;
+	GC_STATE(gc_sk_t, S);
 	memset(&S, 0, sizeof S);
 	int8_t *dst_done;
 	uint64_t *grp;
@@ -797,8 +795,8 @@ GC_HD int gc_shortest_k(gc_arena_t *A, const gc_graph_t *G, uint32_t src, int32_
 		const int32_t nv = gc_n_arc(G, rv);
 		const gc_arc_t *av = gc_arcs(G, rv);
 		for (int32_t i = 0; i < nv; ++i) { /* relax every arc, in arc order (shortk.c:157-188) */
-			const uint32_t w = av[i].w;
-			const int32_t d = rdist + (int32_t)(uint32_t)av[i].v_lv;
+			const uint32_t w = GC_UL(av[i].w);
+			const int32_t d = rdist + (int32_t)(uint32_t)GC_UL(av[i].v_lv);
 			if (d > max_dist) continue;
 			GC_TRY(gc_sk_vertex(A, &S, w, &slot, &absent));
 			gc_sklist_t *q = &S.tk.a[slot];
@@ -1060,7 +1058,7 @@ GC_HD int gc_chain_dp(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, int
 #if defined(GC_STATS) && !defined(__HIP_DEVICE_COMPILE__)
 #include <stdio.h>
 /* host-only statistics of the GWFA steps (a profiling aid: -DGC_STATS, printed by gc_stats_dump()) */
-typedef struct { long long calls, steps, cells, runs, heads0, heads, out, single_nohead, single, nohead, le64, sum_ql, reached, steps_hist[8], n_hist[8], simple_cells, dedup_steps, long_runs, arena_hist[8], arena_sum, fit16, fit32, fit64, blk_ext, blk_dedup, blk_sorted, blk_fallback, blk_wave, blk_merge, dedup_calls, dd_n[8], dd_done[8], dd_fresh[8], dd_nc[8], dd_sum_n, dd_sum_done, dd_sum_fresh, dd_sum_nc, dd_unsorted, hd_arc, hd_in, hd_other; } gc_stats_t;
+typedef struct { long long calls, steps, cells, runs, heads0, heads, out, single_nohead, single, nohead, le64, sum_ql, reached, steps_hist[8], n_hist[8], simple_cells, dedup_steps, long_runs, arena_hist[8], arena_sum, fit16, fit32, fit64, dedup_calls, dd_n[8], dd_done[8], dd_fresh[8], dd_nc[8], dd_sum_n, dd_sum_done, dd_sum_fresh, dd_sum_nc, dd_unsorted, hd_arc, hd_in, hd_other; } gc_stats_t;
 static gc_stats_t gc_stats;
 static inline int gc_stats_bin(long long v) { int b = 0; while (v > 1 && b < 7) v >>= 2, ++b; return b; }
 static void gc_stats_dump(void)
@@ -1071,7 +1069,6 @@ static void gc_stats_dump(void)
 	fprintf(stderr, "[gc_stats] steps with one run and no head cell %.3f (cells in them %.3f); one run %.3f; no head %.3f; all runs <= 64 %.3f; dedup %.3f\n", (double)S->single_nohead / S->steps, (double)S->simple_cells / S->cells, (double)S->single / S->steps, (double)S->nohead / S->steps, (double)S->le64 / S->steps, (double)S->dedup_steps / S->steps);
 	fprintf(stderr, "[gc_stats] steps per call (bins 1,4,16,64,256,1k,4k,16k+):"); for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", S->steps_hist[i]); fprintf(stderr, "\n");
 	fprintf(stderr, "[gc_stats] arena bytes per call: mean %.0f; <=16K %.3f <=32K %.3f <=64K %.3f; hist (0.5K,2K,8K,32K,128K,512K,2M,8M+):", (double)S->arena_sum / S->calls, (double)S->fit16 / S->calls, (double)S->fit32 / S->calls, (double)S->fit64 / S->calls); for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", S->arena_hist[i]); fprintf(stderr, "\n");
-	fprintf(stderr, "[gc_stats] wave blocks: extend %lld; dedup calls %lld, as a block %lld (sorted by rank %lld), handed back %lld, in two passes %lld\n", S->blk_ext, S->dedup_calls, S->blk_dedup, S->blk_sorted, S->blk_fallback, S->blk_wave);
 	fprintf(stderr, "[gc_stats] dedup: mean cells %.1f done %.1f fresh %.2f flagged %.1f unsorted %.3f\n", (double)S->dd_sum_n / S->dedup_calls, (double)S->dd_sum_done / S->dedup_calls, (double)S->dd_sum_fresh / S->dedup_calls, (double)S->dd_sum_nc / S->dedup_calls, (double)S->dd_unsorted / S->dedup_calls);
 	fprintf(stderr, "[gc_stats] dedup cells hist (<=1,<8,<32,<128,<512,..):"); for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", S->dd_n[i]); fprintf(stderr, "; done hist:"); for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", S->dd_done[i]);
 	fprintf(stderr, "; fresh hist:"); for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", S->dd_fresh[i]); fprintf(stderr, "; flagged hist:"); for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", S->dd_nc[i]); fprintf(stderr, "\n");
@@ -1092,11 +1089,11 @@ typedef struct { uint64_t vd0, vd1; } gc_intv_t;
 typedef struct { int32_t v, pre; } gc_trace_t;
 typedef GC_VEC(gc_diag_t) gc_diag_v;
 typedef GC_VEC(gc_intv_t) gc_intv_v;
-typedef struct { uint64_t *k; int32_t *v; uint32_t cap, cnt; } gc_u64map_t;
+typedef struct { GC_F uint64_t *k; GC_F int32_t *v; GC_F uint32_t cap; GC_F uint32_t cnt; } gc_u64map_t;
 
 GC_HD uint64_t gc_mk_vd(uint32_t v, int32_t d) { return (uint64_t)v << 32 | (uint32_t)(GC_DSHIFT + d); }
 GC_HD uint32_t gc_u64slot(uint64_t key, uint32_t cap) { return (uint32_t)((key ^ key >> 29) * 0x9E3779B97F4A7C15ULL >> 40) & (cap - 1); }
-GC_HD int gc_u64map_put(gc_arena_t *A, gc_u64map_t *h, uint64_t key, int32_t **val, int *absent)
+GC_HDN int gc_u64map_put(gc_arena_t *A, gc_u64map_t *h, uint64_t key, int32_t **val, int *absent)
 {
 	if (h->cnt * 2 >= h->cap) {
 		const uint32_t ocap = h->cap, ncap = ocap ? ocap * 2 : 64;
@@ -1118,18 +1115,17 @@ GC_HD int gc_u64map_put(gc_arena_t *A, gc_u64map_t *h, uint64_t key, int32_t **v
 GC_HD void gc_u64map_clear(gc_u64map_t *h) { if (h->cnt == 0) return; GC_PAR_FOR(j, (int32_t)h->cap) h->k[j] = ~0ULL; gc_sync(); h->cnt = 0; }
 
 typedef struct {
-	const gc_graph_t *G;
-	int32_t ql; const char *q;
-	int32_t max_chk, bw_dyn, max_lag;
-	int64_t i_term;
+	GC_F const gc_graph_t *G;
+	GC_F int32_t ql; GC_F const char *q;
+	GC_F int32_t max_chk; GC_F int32_t bw_dyn; GC_F int32_t max_lag;
+	GC_F int64_t i_term;
 	gc_u64map_t seen, tnode;      /* (vertex, query position) entered in the current step; traceback node dedup */
 	gc_intv_v done, fresh, swap;  /* finished diagonals: merged list, this step's additions, scratch */
 	gc_diag_v ooo, wf[2], head;   /* sort scratch; the two wavefronts; the cells sitting on a vertex or query end */
-	gc_kv_t *sort_kv; gc_diag_t *sort_tmp; int32_t m_sort;
-	gc_diag_t *cl;                /* the flagged cells of a wavefront being sorted (wave path) */
+	GC_F gc_kv_t *sort_kv; GC_F gc_diag_t *sort_tmp; GC_F int32_t m_sort;
 	GC_VEC(gc_trace_t) tr;
-	int32_t cur, s, end_tb, end_off;
-	uint32_t end_v;
+	GC_F int32_t cur; GC_F int32_t s; GC_F int32_t end_tb; GC_F int32_t end_off;
+	GC_F uint32_t end_v;
 } gc_gw_t;
 
 GC_HD int gc_trace_push(gc_arena_t *A, gc_gw_t *z, int32_t v, int32_t pre, int32_t *id) /* gfa-ed.c:213-227 */
@@ -1197,7 +1193,7 @@ GC_HD int32_t gc_intv_merge(int32_t n, gc_intv_t *a) /* gfa-ed.c:69-82 */
 /* sort a[] by vd: in-order cells keep their place, the flagged subset goes through the klib sort, stable merge (gfa-ed.c:143-171).
  * The split and the merge are done by rank -- an element's place is its own index plus the number of elements of the OTHER list that go
  * in front of it (ties: the in-order list first), found by binary search -- so every lane moves its own elements. */
-GC_HD int gc_diag_sort(gc_arena_t *A, gc_gw_t *z, int32_t n_a, gc_diag_t *a)
+GC_HDN int gc_diag_sort(gc_arena_t *A, gc_gw_t *z, int32_t n_a, gc_diag_t *a)
 {
 	int32_t n_c = 0;
 	GC_TRY(gc_vec_reserve(A, z->ooo, n_a));
@@ -1279,7 +1275,7 @@ GC_HD int gc_diag_sort(gc_arena_t *A, gc_gw_t *z, int32_t n_a, gc_diag_t *a)
 /* add [x0, x1) to a canonical list of finished-diagonal ranges (ascending, disjoint, not touching): what sorting the new intervals in and
  * coalescing everything that overlaps or touches (gfa-ed.c:69-82,258-264) leaves, without walking the whole list -- a binary search, then
  * the ranges the new one reaches are replaced by their union.  The union of intervals has ONE canonical form, so the list is the reference's. */
-GC_HD int gc_intv_add(gc_arena_t *A, gc_intv_v *L, uint64_t x0, uint64_t x1)
+GC_HDN int gc_intv_add(gc_arena_t *A, gc_intv_v *L, uint64_t x0, uint64_t x1)
 {
 	int32_t lo = 0, hi = L->n;
 	while (lo < hi) { const int32_t m = (lo + hi) >> 1; if (L->a[m].vd1 < x0) lo = m + 1; else hi = m; } /* first range that ends at or behind x0 */
@@ -1306,258 +1302,13 @@ GC_HD int gc_intv_add(gc_arena_t *A, gc_intv_v *L, uint64_t x0, uint64_t x1)
 #define GC_COMPACT_BEGIN(n_) { const int32_t gcn_ = (n_); int32_t gcm_ = 0; for (int32_t gcb_ = 0; gcb_ < gcn_; gcb_ += GC_NLANE) { const int32_t gci_ = gcb_ + GC_LANE; const int gcin_ = gci_ < gcn_;
 #define GC_COMPACT_END(a_, val_, keep_, n_out_) const uint64_t gck_ = gc_ballot(gcin_ && (keep_)); gc_sync(); if (gcin_ && (keep_)) (a_)[gcm_ + gc_rank(gck_)] = (val_); gcm_ += gc_popc(gck_); gc_sync(); } (n_out_) = gcm_; }
 
-#ifdef GC_WAVEPATH
-/* gc_intv_add() of all of this step's finished diagonals at once, for up to 64 ranges in all (the list itself is a handful: adjacent diagonals finish together
- * and coalesce): a range per lane, ordered by its start (rank by counting), an inclusive prefix maximum of the ends; a range whose start lies beyond every
- * end in front of it opens an output range, which ends at the prefix maximum in front of the next opening.  The union has one canonical form. */
-GC_HD int gc_intv_add_wave(gc_arena_t *A, gc_intv_v *L, const gc_intv_v *F)
-{
-	const int32_t n_l = L->n, n = L->n + F->n;
-	GC_TRY(gc_vec_reserve(A, *L, n));
-	uint64_t x0[GC_WN], x1[GC_WN], y0[GC_WN], y1[GC_WN], pm[GC_WN], t64[GC_WN];
-	int32_t pos[GC_WN], nxt[GC_WN];
-	int open[GC_WN];
-	GC_EACH {
-		GC_V(x0) = GC_V(x1) = ~0ULL, GC_V(pos) = 0;
-		if (L_ < n) { const gc_intv_t v = L_ < n_l ? L->a[L_] : F->a[L_ - n_l]; GC_V(x0) = v.vd0, GC_V(x1) = v.vd1; }
-	}
-	for (int32_t j = 0; j < n; ++j) {
-		const uint64_t xj = GC_GET(x0, j);
-		GC_EACH GC_V(pos) += (xj < GC_V(x0)) | ((xj == GC_V(x0)) & (j < L_));
-	}
-	GC_EACH { if (L_ >= n) GC_V(pos) = L_; }
-	GC_PERMUTE64(y0, x0, pos);
-	GC_PERMUTE64(y1, x1, pos);
-	GC_EACH GC_V(pm) = L_ < n ? GC_V(y1) : 0;
-	for (int32_t d = 1; d < 64; d <<= 1) {
-		GC_EACH { const uint64_t o = GC_SHUP(pm, d); GC_V(t64) = L_ >= d && o > GC_V(pm) ? o : GC_V(pm); }
-		GC_EACH GC_V(pm) = GC_V(t64);
-	}
-	GC_EACH { const uint64_t before = GC_UP1(pm); GC_V(open) = L_ < n && (L_ == 0 || GC_V(y0) > before); }
-	const uint64_t mo = GC_VBALLOT(open);
-	GC_EACH { const uint64_t above = L_ < 63 ? mo & ~((2ULL << L_) - 1ULL) : 0; GC_V(nxt) = (above ? (int32_t)__builtin_ctzll(above) : n) - 1; }
-	GC_EACH { const uint64_t end = GC_GET(pm, GC_V(nxt)); if (GC_V(open)) { gc_intv_t *o = &L->a[GC_VRANK(mo)]; o->vd0 = GC_V(y0), o->vd1 = end; } }
-	L->n = GC_POPC64(mo);
-	gc_sync();
-	return GC_OK;
-}
-/* gc_gw_dedup() behind the interval merge for a wavefront of up to 64 cells, one lane per cell, the cells in registers: the stable order
- * (in-order cells keep their place; the flagged ones sorted by the klib insertion sort -- stable up to 64 records -- and merged in behind equal
- * in-order cells, gfa-ed.c:143-171) is a RANK every lane counts for its own cell; the cells change lanes; a lane looks through its group of equal
- * (vertex, diagonal) for a cell that beats its own, asks the finished-diagonal list, and the survivors are stored in rank order.  Returns *done = 0
- * without touching anything when the in-order cells are not in order (never seen; the memory path then does what the reference would). */
-GC_HD int gc_gw_dedup_block(gc_gw_t *z, int32_t *n_a_, gc_diag_t *a, int *done)
-{
-	const int32_t n = *n_a_;
-	int32_t vlo[GC_WN], vhi[GC_WN], k[GC_WN], t[GC_WN], xo[GC_WN];
-	int in[GC_WN], bad[GC_WN], keep[GC_WN];
-	GC_EACH {
-		GC_V(in) = L_ < n;
-		GC_V(vlo) = GC_V(vhi) = -1, GC_V(k) = 0, GC_V(t) = 0, GC_V(xo) = 0; /* (lanes beyond n hold the largest key: they stay where they are) */
-		if (GC_V(in)) { const gc_diag_t me = a[L_]; GC_V(vlo) = (int32_t)(uint32_t)me.vd, GC_V(vhi) = (int32_t)(me.vd >> 32), GC_V(k) = me.k, GC_V(t) = me.t, GC_V(xo) = (int32_t)me.xo; }
-	}
-#define GC_VD_(lo, hi) ((uint64_t)(uint32_t)(hi) << 32 | (uint32_t)(lo))
-	GC_EACH { const uint64_t l = GC_VD_(GC_UP1(vlo), GC_UP1(vhi)); GC_V(bad) = GC_V(in) && L_ > 0 && l > GC_VD_(GC_V(vlo), GC_V(vhi)); }
-	*done = 1;
-	if (GC_VBALLOT(bad)) {
-		int32_t pos[GC_WN], tmp[GC_WN];
-		int inv[GC_WN];
-		GC_EACH { GC_V(pos) = 0, GC_V(inv) = 0; }
-		for (int32_t j = 0; j < n; ++j) {
-			GC_EACH {
-				const uint64_t vj = GC_VD_(GC_GET(vlo, j), GC_GET(vhi, j)), vi = GC_VD_(GC_V(vlo), GC_V(vhi));
-				const int fj = GC_GET(xo, j) & 1, fi = GC_V(xo) & 1;
-				GC_V(pos) += (vj < vi) | ((vj == vi) & ((fj < fi) | ((fj == fi) & (j < L_))));
-				GC_V(inv) |= GC_V(in) & !fi & !fj & (j < L_) & (vj > vi);
-			}
-		}
-		if (GC_VBALLOT(inv)) { GC_STAT(gc_stats.blk_fallback++;) *done = 0; return GC_OK; }
-		GC_STAT(gc_stats.blk_sorted++;)
-		GC_EACH { if (!GC_V(in)) GC_V(pos) = L_; GC_V(xo) &= ~1; } /* the merge leaves every cell unflagged (gfa-ed.c:165) */
-		GC_PERMUTE32(tmp, vlo, pos); GC_EACH GC_V(vlo) = GC_V(tmp);
-		GC_PERMUTE32(tmp, vhi, pos); GC_EACH GC_V(vhi) = GC_V(tmp);
-		GC_PERMUTE32(tmp, k, pos);   GC_EACH GC_V(k) = GC_V(tmp);
-		GC_PERMUTE32(tmp, t, pos);   GC_EACH GC_V(t) = GC_V(tmp);
-		GC_PERMUTE32(tmp, xo, pos);  GC_EACH GC_V(xo) = GC_V(tmp);
-	}
-	GC_STAT(gc_stats.blk_dedup++;)
-	GC_EACH GC_V(keep) = GC_V(in);
-	for (int32_t j = 0; j < n; ++j) { /* keep the furthest cell of every (vertex, diagonal): the first of equals */
-		GC_EACH {
-			const int same = GC_GET(vlo, j) == GC_V(vlo) && GC_GET(vhi, j) == GC_V(vhi);
-			const int32_t kj = GC_GET(k, j);
-			if (same && ((j < L_ && !(kj < GC_V(k))) || (j > L_ && GC_V(k) < kj))) GC_V(keep) = 0;
-		}
-	}
-	if (z->done.n > 0) { /* drop cells on finished diagonals (gfa-ed.c:192-202): the intervals are disjoint and ascending */
-		const int32_t n_b = z->done.n;
-		const gc_intv_t *b = z->done.a;
-		GC_EACH {
-			if (GC_V(keep)) {
-				const uint64_t vd = GC_VD_(GC_V(vlo), GC_V(vhi));
-				int32_t lo = 0, hi = n_b; /* first interval whose end lies beyond the cell */
-				while (lo < hi) { const int32_t m = (lo + hi) >> 1; if (b[m].vd1 <= vd) lo = m + 1; else hi = m; }
-				if (lo < n_b && vd >= b[lo].vd0) GC_V(keep) = 0;
-			}
-		}
-	}
-	const uint64_t mK = GC_VBALLOT(keep);
-	GC_EACH {
-		if (GC_V(keep)) {
-			gc_diag_t c;
-			c.vd = GC_VD_(GC_V(vlo), GC_V(vhi)), c.k = GC_V(k), c.len = 0, c.xo = (uint32_t)GC_V(xo), c.t = GC_V(t), c.pad_[0] = c.pad_[1] = 0;
-			a[GC_VRANK(mK)] = c;
-		}
-	}
-#undef GC_VD_
-	*n_a_ = GC_POPC64(mK);
-	gc_sync();
-	return GC_OK;
-}
-#endif
-#ifdef GC_WAVEPATH
-/* the same for a wavefront of any size with up to 64 flagged cells, in two passes over memory instead of a dozen: (1) every cell is stored at its RANK in
- * the stable order -- an in-order cell: the in-order cells in front of it (a running ballot count) plus the flagged cells with a smaller key; a flagged cell:
- * the flagged cells in front of it in (key, position) order plus the in-order cells with a key not larger; the flagged cells sit one per lane meanwhile --
- * (2) a lane takes its cell from the sorted copy, looks through its group, asks the finished list, and the survivors go back in rank order. */
-GC_HD int gc_gw_dedup_wave(gc_arena_t *A, gc_gw_t *z, int32_t *n_a_, gc_diag_t *a, int *done)
-{
-	const int32_t n = *n_a_;
-	int32_t n_c = 0;
-	int unsorted = 0;
-	*done = 0;
-	for (int32_t base = 0; base < n; base += 64) {
-		int f[GC_WN], u[GC_WN];
-		GC_EACH { const int32_t i = base + L_; GC_V(f) = i < n && (a[i].xo & 1); GC_V(u) = i < n && i > 0 && a[i - 1].vd > a[i].vd; }
-		n_c += GC_POPC64(GC_VBALLOT(f));
-		unsorted |= GC_VBALLOT(u) != 0;
-	}
-	if (n_c > 64) return GC_OK; /* (the klib sort of more than 64 records is not stable: the memory path replays it) */
-	GC_TRY(gc_vec_reserve(A, z->ooo, n));
-	gc_diag_t *tmp = z->ooo.a;
-	if (!unsorted) {
-		for (int32_t base = 0; base < n; base += 64) GC_EACH { const int32_t i = base + L_; if (i < n) tmp[i] = a[i]; }
-	} else {
-		if (z->cl == 0) GC_ALLOC(A, gc_diag_t, z->cl, 64);
-		gc_diag_t *cl = z->cl;
-		for (int32_t base = 0, kc = 0; base < n; base += 64) { /* the flagged cells, in order, with their position (in the len field) */
-			int f[GC_WN];
-			GC_EACH { const int32_t i = base + L_; GC_V(f) = i < n && (a[i].xo & 1); }
-			const uint64_t m = GC_VBALLOT(f);
-			GC_EACH { if (GC_V(f)) { gc_diag_t c = a[base + L_]; c.len = base + L_; cl[kc + GC_VRANK(m)] = c; } }
-			kc += GC_POPC64(m);
-		}
-		gc_sync();
-		uint64_t cvd[GC_WN];
-		int32_t cidx[GC_WN], cnb[GC_WN], ck[GC_WN], ct[GC_WN];
-		uint32_t cxo[GC_WN];
-		GC_EACH {
-			GC_V(cvd) = ~0ULL, GC_V(cidx) = 0x7fffffff, GC_V(cnb) = 0, GC_V(ck) = 0, GC_V(ct) = 0, GC_V(cxo) = 0;
-			if (L_ < n_c) { const gc_diag_t c = cl[L_]; GC_V(cvd) = c.vd, GC_V(cidx) = c.len, GC_V(ck) = c.k, GC_V(ct) = c.t, GC_V(cxo) = c.xo & 0xfffffffeU; }
-		}
-		int32_t n_b = 0;
-		uint64_t last_b = 0; /* key of the last in-order cell so far */
-		int inv_any = 0;
-		for (int32_t base = 0; base < n; base += 64) {
-			uint64_t vd[GC_WN];
-			int32_t pos[GC_WN], src[GC_WN];
-			int isb[GC_WN], inv[GC_WN], le[GC_WN];
-			gc_diag_t me[GC_WN];
-			GC_EACH {
-				const int32_t i = base + L_;
-				GC_V(vd) = 0, GC_V(isb) = 0;
-				if (i < n) { GC_V(me) = a[i]; GC_V(vd) = GC_V(me).vd, GC_V(isb) = !(GC_V(me).xo & 1); }
-			}
-			const uint64_t mb = GC_VBALLOT(isb);
-			GC_EACH { const uint64_t below = mb & ((1ULL << L_) - 1ULL); GC_V(src) = below ? 63 - (int32_t)__builtin_clzll(below) : L_; GC_V(pos) = n_b + GC_POPC64(below); }
-			GC_EACH { /* in-order cells must be in order among themselves */
-				const uint64_t below = mb & ((1ULL << L_) - 1ULL);
-				const uint64_t prev = GC_GET(vd, GC_V(src));
-				GC_V(inv) = GC_V(isb) && (below ? prev > GC_V(vd) : (n_b > 0 && last_b > GC_V(vd)));
-			}
-			inv_any |= GC_VBALLOT(inv) != 0;
-			for (int32_t j = 0; j < n_c; ++j) {
-				const uint64_t cj = GC_GET(cvd, j);
-				GC_EACH { GC_V(pos) += GC_V(isb) & (cj < GC_V(vd)); GC_V(le) = GC_V(isb) & (GC_V(vd) <= cj); }
-				const int32_t cnt = GC_POPC64(GC_VBALLOT(le));
-				GC_EACH { if (L_ == j) GC_V(cnb) += cnt; }
-			}
-			GC_EACH { if (GC_V(isb)) { gc_diag_t c = GC_V(me); c.len = 0; tmp[GC_V(pos)] = c; } }
-			if (mb) { const int32_t hi = 63 - (int32_t)__builtin_clzll(mb); last_b = GC_GET(vd, hi); }
-			n_b += GC_POPC64(mb);
-		}
-		if (inv_any) return GC_OK; /* never seen; nothing but scratch was written */
-		{ /* the flagged cells among themselves: by (key, position) */
-			int32_t pos[GC_WN];
-			GC_EACH GC_V(pos) = GC_V(cnb);
-			for (int32_t j = 0; j < n_c; ++j) {
-				const uint64_t cj = GC_GET(cvd, j);
-				const int32_t ij = GC_GET(cidx, j);
-				GC_EACH GC_V(pos) += (cj < GC_V(cvd)) | ((cj == GC_V(cvd)) & (ij < GC_V(cidx)));
-			}
-			GC_EACH { if (L_ < n_c) { gc_diag_t c; c.vd = GC_V(cvd), c.k = GC_V(ck), c.len = 0, c.xo = GC_V(cxo), c.t = GC_V(ct), c.pad_[0] = c.pad_[1] = 0; tmp[GC_V(pos)] = c; } }
-		}
-	}
-	gc_sync();
-	const int32_t n_d = z->done.n;
-	const gc_intv_t *dn = z->done.a;
-	int32_t n_out = 0;
-	for (int32_t base = 0; base < n; base += 64) {
-		int keep[GC_WN];
-		gc_diag_t me[GC_WN];
-		GC_EACH {
-			const int32_t i = base + L_;
-			GC_V(keep) = 0;
-			if (i < n) {
-				GC_V(me) = tmp[i];
-				const uint64_t vd = GC_V(me).vd;
-				const int32_t k = GC_V(me).k;
-				int kp = 1;
-				for (int32_t j = i - 1; j >= 0 && tmp[j].vd == vd; --j) if (!(tmp[j].k < k)) { kp = 0; break; } /* an earlier cell at least as far */
-				if (kp) for (int32_t j = i + 1; j < n && tmp[j].vd == vd; ++j) if (k < tmp[j].k) { kp = 0; break; } /* a later cell strictly further */
-				if (kp && n_d > 0) { /* on a finished diagonal (gfa-ed.c:192-202)?  the intervals are disjoint and ascending */
-					if (n_d <= 8) { for (int32_t m = 0; m < n_d; ++m) if (vd >= dn[m].vd0 && vd < dn[m].vd1) kp = 0; }
-					else {
-						int32_t lo = 0, hi = n_d;
-						while (lo < hi) { const int32_t m = (lo + hi) >> 1; if (dn[m].vd1 <= vd) lo = m + 1; else hi = m; }
-						if (lo < n_d && vd >= dn[lo].vd0) kp = 0;
-					}
-				}
-				GC_V(keep) = kp;
-			}
-		}
-		const uint64_t mk = GC_VBALLOT(keep);
-		GC_EACH { if (GC_V(keep)) a[n_out + GC_VRANK(mk)] = GC_V(me); }
-		n_out += GC_POPC64(mk);
-	}
-	gc_sync();
-	*n_a_ = n_out;
-	*done = 1;
-	return GC_OK;
-}
-#endif
 GC_HD int gc_gw_dedup(gc_arena_t *A, gc_gw_t *z, int32_t *n_a_, gc_diag_t *a) /* gwf_dedup, gfa-ed.c:258-271 */
 {
 	int32_t n_a = *n_a_;
-#ifdef GC_WAVEPATH
-	if (z->fresh.n > 0 && z->done.n + z->fresh.n <= 64) { GC_STAT(gc_stats.blk_merge++;) GC_TRY(gc_intv_add_wave(A, &z->done, &z->fresh)); } else
-#endif
 	for (int32_t i = 0; i < z->fresh.n; ++i) GC_TRY(gc_intv_add(A, &z->done, z->fresh.a[i].vd0, z->fresh.a[i].vd1)); /* this step's finished diagonals */
 	GC_STAT(gc_stats.dedup_calls++; { int nc_ = 0, uns_ = 0; for (int32_t i = 0; i < n_a; ++i) { nc_ += a[i].xo & 1; if (i && a[i - 1].vd > a[i].vd) uns_ = 1; } gc_stats.dd_sum_n += n_a, gc_stats.dd_sum_fresh += z->fresh.n, gc_stats.dd_sum_nc += nc_, gc_stats.dd_unsorted += uns_;
 		gc_stats.dd_n[gc_stats_bin(n_a)]++, gc_stats.dd_fresh[gc_stats_bin(z->fresh.n)]++, gc_stats.dd_nc[gc_stats_bin(nc_)]++; })
 	GC_STAT(gc_stats.dd_sum_done += z->done.n; gc_stats.dd_done[gc_stats_bin(z->done.n)]++;)
-#ifdef GC_WAVEPATH
-	if (n_a <= 64) {
-		int done;
-		GC_TRY(gc_gw_dedup_block(z, n_a_, a, &done));
-		if (done) return GC_OK;
-	} else {
-		int done;
-		GC_TRY(gc_gw_dedup_wave(A, z, n_a_, a, &done));
-		GC_STAT(gc_stats.blk_wave += done;)
-		if (done) return GC_OK;
-	}
-#endif
 	{
 		int unsorted = 0;
 		GC_PAR_FOR(i, n_a) if (i > 0 && a[i - 1].vd > a[i].vd) unsorted = 1;
@@ -1596,7 +1347,7 @@ GC_HD int gc_gw_dedup(gc_arena_t *A, gc_gw_t *z, int32_t *n_a_, gc_diag_t *a) /*
 	*n_a_ = n_a;
 	return GC_OK;
 }
-GC_HD int32_t gc_gw_prune(int32_t n_a, gc_diag_t *a, uint32_t max_lag, int32_t bw_dyn) /* gfa-ed.c:286-307 */
+GC_HDN int32_t gc_gw_prune(int32_t n_a, gc_diag_t *a, uint32_t max_lag, int32_t bw_dyn) /* gfa-ed.c:286-307 */
 {
 	int32_t max_i = -1, j = 0;
 	uint32_t max_x = 0;
@@ -1614,7 +1365,7 @@ GC_HD int32_t gc_gw_prune(int32_t n_a, gc_diag_t *a, uint32_t max_lag, int32_t b
 /* Landau-Vishkin over a run of n adjacent diagonals on one vertex (gfa-ed.c:331-403): every diagonal is extended along its matches, then
  * the next wavefront takes, per diagonal, the furthest of {insertion from the left neighbour, mismatch, deletion from the right neighbour};
  * cells that reached the end of the vertex or of the query go to H (handled one by one by the caller).  One lane per diagonal. */
-GC_HD int gc_gw_extend_run(gc_arena_t *A, gc_gw_t *z, int32_t n, gc_diag_t *a, gc_diag_v *B, gc_diag_v *H)
+GC_HDN int gc_gw_extend_run(gc_arena_t *A, gc_gw_t *z, int32_t n, gc_diag_t *a, gc_diag_v *B, gc_diag_v *H)
 {
 	const uint32_t v = (uint32_t)(a->vd >> 32);
 	const int32_t vl = gc_vlen(z->G, v);
@@ -1622,6 +1373,54 @@ GC_HD int gc_gw_extend_run(gc_arena_t *A, gc_gw_t *z, int32_t n, gc_diag_t *a, g
 	GC_TRY(gc_vec_reserve(A, *B, B->n + n + 2));
 	GC_TRY(gc_vec_reserve(A, *H, H->n + n));
 	GC_TRY(gc_vec_reserve(A, z->fresh, z->fresh.n + n + 2));
+#if defined(__HIP_DEVICE_COMPILE__)
+	if (n <= 64) { /* the usual case, a run fits the wavefront: a lane keeps its diagonal in registers from the extension to the compacted output, the
+	                * neighbours' cells come by lane shuffles, places in H / B / the finished list by ballots -- one pass over memory, one fence */
+		const int32_t j = GC_LANE;
+		const int in = j < n;
+		gc_diag_t me;
+		me.vd = 0, me.k = 0, me.len = 0, me.xo = 0, me.t = 0, me.pad_[0] = me.pad_[1] = 0;
+		if (in) {
+			me = a[j];
+			const int32_t k2 = gc_extend1((int32_t)me.vd - GC_DSHIFT, me.k, vl, ts, z->ql, z->q);
+			me.len = k2 - me.k, me.xo += (uint32_t)me.len << 2, me.k = k2;
+		}
+		const int32_t kL = __shfl_up(me.k, 1), tL = __shfl_up(me.t, 1), kR = __shfl_down(me.k, 1), tR = __shfl_down(me.t, 1);
+		const uint32_t xL = __shfl_up(me.xo, 1), xR = __shfl_down(me.xo, 1);
+		/* the cell of my diagonal in the next wavefront */
+		uint32_t mx = me.xo + 4;
+		int32_t mk = me.k + 1, mt = me.t;
+		if (in && j > 0 && kL > me.k + 1) mx = xL + 2, mk = kL, mt = tL;
+		if (in && j + 1 < n && !(mk > kR + 1)) mx = xR + 2, mt = tR, mk = kR + 1;
+		const int32_t d = (int32_t)me.vd - GC_DSHIFT;
+		/* cells at a vertex / query end go to H, flagged, in diagonal order */
+		{
+			const int at_end = in && (me.k == vl - 1 || d + me.k == z->ql - 1);
+			const uint64_t m = gc_ballot(at_end);
+			if (at_end) { gc_diag_t h = me; h.xo |= 1; H->a[H->n + gc_rank(m)] = h; }
+			H->n += gc_popc(m);
+		}
+		/* output order: the cell left of the run (lane 0), the run's cells, the cell right of it (lane n - 1) */
+		const int is0 = in && j == 0, isN = in && j == n - 1;
+		const int32_t k0 = me.k + 1, kN = me.k; /* left edge: vd - 1, xo + 2, k + 1; right edge: vd + 1, xo + 2, k */
+		const int keep0 = is0 && (d - 1) + k0 < z->ql && k0 < vl, fin0 = is0 && !keep0 && k0 == vl;
+		const int keepM = in && d + mk < z->ql && mk < vl, finM = in && !keepM && mk == vl;
+		const int keepN = isN && (d + 1) + kN < z->ql && kN < vl, finN = isN && !keepN && kN == vl;
+		const uint64_t b0 = gc_ballot(keep0), bM = gc_ballot(keepM), bN = gc_ballot(keepN), f0 = gc_ballot(fin0), fM = gc_ballot(finM), fN = gc_ballot(finN);
+		gc_diag_t *b = &B->a[B->n];
+		gc_intv_t *fr = &z->fresh.a[z->fresh.n];
+		if (keep0) { gc_diag_t c; c.vd = me.vd - 1, c.k = k0, c.len = 0, c.xo = me.xo + 2, c.t = me.t; b[0] = c; }
+		if (keepM) { gc_diag_t c; c.vd = me.vd, c.k = mk, c.len = 0, c.xo = mx, c.t = mt; b[gc_popc(b0) + gc_rank(bM)] = c; }
+		if (keepN) { gc_diag_t c; c.vd = me.vd + 1, c.k = kN, c.len = 0, c.xo = me.xo + 2, c.t = me.t; b[gc_popc(b0) + gc_popc(bM)] = c; }
+		if (fin0) { fr[0].vd0 = gc_mk_vd(v, d - 1), fr[0].vd1 = fr[0].vd0 + 1; }
+		if (finM) { gc_intv_t *iv = &fr[gc_popc(f0) + gc_rank(fM)]; iv->vd0 = gc_mk_vd(v, d), iv->vd1 = iv->vd0 + 1; }
+		if (finN) { gc_intv_t *iv = &fr[gc_popc(f0) + gc_popc(fM)]; iv->vd0 = gc_mk_vd(v, d + 1), iv->vd1 = iv->vd0 + 1; }
+		B->n += gc_popc(b0) + gc_popc(bM) + gc_popc(bN);
+		z->fresh.n += gc_popc(f0) + gc_popc(fM) + gc_popc(fN);
+		gc_sync();
+		return GC_OK;
+	}
+#endif
 	GC_PAR_FOR(j, n) {
 		const int32_t k = gc_extend1((int32_t)a[j].vd - GC_DSHIFT, a[j].k, vl, ts, z->ql, z->q);
 		a[j].len = k - a[j].k, a[j].xo += (uint32_t)(k - a[j].k) << 2, a[j].k = k;
@@ -1670,77 +1469,6 @@ GC_HD int gc_gw_extend_run(gc_arena_t *A, gc_gw_t *z, int32_t n, gc_diag_t *a, g
 	B->n += n_keep;
 	return GC_OK;
 }
-#ifdef GC_WAVEPATH
-/* the same for up to 64 cells made of WHOLE runs (the usual wavefront: a few runs of a dozen diagonals), one lane per cell: a lane keeps its cell in
- * registers from the extension to the output, takes its neighbours' cells by lane exchange where they belong to its run, and finds its places in
- * H / B / the finished list by ballots -- per run: [cell left of the run] [the run's cells] [cell right of it], runs in order, which is what calling
- * gc_gw_extend_run() run by run appends.  One pass over memory and one fence for the whole block. */
-GC_HD int gc_gw_extend_block(gc_arena_t *A, gc_gw_t *z, int32_t n, int32_t n_runs, const gc_diag_t *a, gc_diag_v *B, gc_diag_v *H)
-{
-	GC_TRY(gc_vec_reserve(A, *B, B->n + n + 2 * n_runs));
-	GC_TRY(gc_vec_reserve(A, *H, H->n + n));
-	GC_TRY(gc_vec_reserve(A, z->fresh, z->fresh.n + n + 2 * n_runs));
-	GC_STAT(gc_stats.blk_ext++;)
-	uint64_t vd[GC_WN];
-	int32_t k[GC_WN], t[GC_WN], len[GC_WN], vl[GC_WN], mk[GC_WN], mt[GC_WN];
-	uint32_t xo[GC_WN], mx[GC_WN];
-	int in[GC_WN], first[GC_WN], last[GC_WN], at_end[GC_WN], keep0[GC_WN], keepM[GC_WN], keepN[GC_WN], fin0[GC_WN], finM[GC_WN], finN[GC_WN];
-	const int32_t ql = z->ql;
-	GC_EACH {
-		GC_V(in) = L_ < n;
-		GC_V(vd) = 0, GC_V(k) = 0, GC_V(t) = 0, GC_V(len) = 0, GC_V(vl) = 0, GC_V(xo) = 0, GC_V(first) = 0, GC_V(last) = 0;
-		if (GC_V(in)) {
-			const gc_diag_t me = a[L_];
-			GC_V(first) = L_ == 0 || a[L_ - 1].vd + 1 != me.vd;
-			GC_V(last) = L_ == n - 1 || a[L_ + 1].vd != me.vd + 1;
-			const uint32_t v = (uint32_t)(me.vd >> 32);
-			GC_V(vl) = gc_vlen(z->G, v);
-			const int32_t k2 = gc_extend1((int32_t)me.vd - GC_DSHIFT, me.k, GC_V(vl), gc_vseq(z->G, v), ql, z->q);
-			GC_V(vd) = me.vd, GC_V(t) = me.t, GC_V(len) = k2 - me.k, GC_V(xo) = me.xo + ((uint32_t)(k2 - me.k) << 2), GC_V(k) = k2;
-		}
-	}
-	GC_EACH { /* the cell of my diagonal in the next wavefront: the furthest of {insertion from the left, mismatch, deletion from the right} */
-		const int32_t kL = GC_UP1(k), tL = GC_UP1(t), kR = GC_DN1(k), tR = GC_DN1(t);
-		const uint32_t xL = GC_UP1(xo), xR = GC_DN1(xo);
-		uint32_t x = GC_V(xo) + 4;
-		int32_t kk = GC_V(k) + 1, tt = GC_V(t);
-		if (GC_V(in) && !GC_V(first) && kL > GC_V(k) + 1) x = xL + 2, kk = kL, tt = tL;
-		if (GC_V(in) && !GC_V(last) && !(kk > kR + 1)) x = xR + 2, tt = tR, kk = kR + 1;
-		GC_V(mx) = x, GC_V(mk) = kk, GC_V(mt) = tt;
-		const int32_t d = (int32_t)GC_V(vd) - GC_DSHIFT, k0 = GC_V(k) + 1, kN = GC_V(k), l = GC_V(vl);
-		GC_V(at_end) = GC_V(in) && (GC_V(k) == l - 1 || d + GC_V(k) == ql - 1);
-		GC_V(keep0) = GC_V(in) && GC_V(first) && (d - 1) + k0 < ql && k0 < l;
-		GC_V(fin0) = GC_V(in) && GC_V(first) && !GC_V(keep0) && k0 == l;
-		GC_V(keepM) = GC_V(in) && d + kk < ql && kk < l;
-		GC_V(finM) = GC_V(in) && !GC_V(keepM) && kk == l;
-		GC_V(keepN) = GC_V(in) && GC_V(last) && (d + 1) + kN < ql && kN < l;
-		GC_V(finN) = GC_V(in) && GC_V(last) && !GC_V(keepN) && kN == l;
-	}
-	const uint64_t mH = GC_VBALLOT(at_end), b0 = GC_VBALLOT(keep0), bM = GC_VBALLOT(keepM), bN = GC_VBALLOT(keepN), f0 = GC_VBALLOT(fin0), fM = GC_VBALLOT(finM), fN = GC_VBALLOT(finN);
-	GC_EACH {
-		gc_diag_t c;
-		c.len = 0, c.pad_[0] = c.pad_[1] = 0;
-		if (GC_V(at_end)) { /* cells at a vertex / query end go to H, flagged, in diagonal order */
-			c.vd = GC_V(vd), c.k = GC_V(k), c.len = GC_V(len), c.xo = GC_V(xo) | 1, c.t = GC_V(t);
-			H->a[H->n + GC_VRANK(mH)] = c;
-			c.len = 0;
-		}
-		gc_diag_t *b = &B->a[B->n + GC_VRANK(b0) + GC_VRANK(bM) + GC_VRANK(bN)];
-		if (GC_V(keep0)) { c.vd = GC_V(vd) - 1, c.k = GC_V(k) + 1, c.xo = GC_V(xo) + 2, c.t = GC_V(t); *b++ = c; }
-		if (GC_V(keepM)) { c.vd = GC_V(vd), c.k = GC_V(mk), c.xo = GC_V(mx), c.t = GC_V(mt); *b++ = c; }
-		if (GC_V(keepN)) { c.vd = GC_V(vd) + 1, c.k = GC_V(k), c.xo = GC_V(xo) + 2, c.t = GC_V(t); *b++ = c; }
-		gc_intv_t *fr = &z->fresh.a[z->fresh.n + GC_VRANK(f0) + GC_VRANK(fM) + GC_VRANK(fN)]; /* a diagonal that ran off the vertex end is finished */
-		if (GC_V(fin0)) { fr->vd0 = GC_V(vd) - 1, fr->vd1 = fr->vd0 + 1; ++fr; }
-		if (GC_V(finM)) { fr->vd0 = GC_V(vd), fr->vd1 = fr->vd0 + 1; ++fr; }
-		if (GC_V(finN)) { fr->vd0 = GC_V(vd) + 1, fr->vd1 = fr->vd0 + 1; ++fr; }
-	}
-	H->n += GC_POPC64(mH);
-	B->n += GC_POPC64(b0) + GC_POPC64(bM) + GC_POPC64(bN);
-	z->fresh.n += GC_POPC64(f0) + GC_POPC64(fM) + GC_POPC64(fN);
-	gc_sync();
-	return GC_OK;
-}
-#endif
 /* one edit-distance step: consumes wf[cur], builds wf[cur^1]; *reached = 1 when (v1, off1) was hit (gfa-ed.c:405-507) */
 GC_HD int gc_gw_step(gc_arena_t *A, gc_gw_t *z, uint32_t v1, int32_t off1, int *reached)
 {
@@ -1757,25 +1485,6 @@ GC_HD int gc_gw_step(gc_arena_t *A, gc_gw_t *z, uint32_t v1, int32_t off1, int *
 	gc_u64map_clear(&z->seen);
 	GC_TRY(gc_vec_reserve(A, *B, n * 2 + 4));
 	GC_TICK(A, 11);
-#ifdef GC_WAVEPATH
-	for (int32_t x = 0; x < n; ) { /* runs of adjacent diagonals on one vertex, as many WHOLE runs at a time as fit the 64 lanes */
-		int isend[GC_WN];
-		GC_EACH { const int32_t i = x + L_; GC_V(isend) = i < n && (i == n - 1 || a[i + 1].vd != a[i].vd + 1); }
-		const uint64_t m = GC_VBALLOT(isend);
-		if (m) {
-			const int32_t cnt = 64 - (int32_t)__builtin_clzll(m);
-			GC_TRY(gc_gw_extend_block(A, z, cnt, GC_POPC64(m), &a[x], B, H));
-			GC_STAT(st_runs += GC_POPC64(m);)
-			x += cnt;
-		} else { /* a run of more than 64 diagonals */
-			int32_t e = x + 64;
-			while (e < n && a[e].vd == a[e - 1].vd + 1) ++e;
-			GC_TRY(gc_gw_extend_run(A, z, e - x, &a[x], B, H));
-			GC_STAT(++st_runs; st_long = 1;)
-			x = e;
-		}
-	}
-#else
 	{ /* runs of adjacent diagonals on one vertex: the lanes look for the run ends, the runs are then taken in order */
 		int32_t x = 0;
 		for (int32_t base = 0; base < n; base += GC_NLANE) {
@@ -1795,7 +1504,6 @@ GC_HD int gc_gw_step(gc_arena_t *A, gc_gw_t *z, uint32_t v1, int32_t off1, int *
 			}
 		}
 	}
-#endif
 	if (H->n == 0) do_dedup = 0;
 	GC_STAT(gc_stats.steps++; gc_stats.cells += n; gc_stats.runs += st_runs; gc_stats.heads0 += H->n; gc_stats.single += st_runs == 1; gc_stats.nohead += H->n == 0; gc_stats.single_nohead += st_runs == 1 && H->n == 0;
 			if (st_runs == 1 && H->n == 0) gc_stats.simple_cells += n; gc_stats.le64 += !st_long; gc_stats.dedup_steps += do_dedup; gc_stats.n_hist[gc_stats_bin(n)]++;)
@@ -1824,8 +1532,8 @@ GC_HD int gc_gw_step(gc_arena_t *A, gc_gw_t *z, uint32_t v1, int32_t off1, int *
 			iv->vd0 = gc_mk_vd(v, d), iv->vd1 = iv->vd0 + 1;
 			GC_TRY(gc_trace_push(A, z, (int32_t)v, t.t, &tw));
 			for (int32_t j = 0; j < nv; ++j) {
-				const uint32_t w = av[j].w;
-				const int32_t ol = av[j].ow;
+				const uint32_t w = GC_UL(av[j].w);
+				const int32_t ol = GC_UL(av[j].ow);
 				int absent;
 				int32_t *dummy;
 				GC_TRY(gc_u64map_put(A, &z->seen, (uint64_t)w << 32 | (uint32_t)(qi + 1), &dummy, &absent));
@@ -1867,10 +1575,10 @@ GC_HD int gc_gw_step(gc_arena_t *A, gc_gw_t *z, uint32_t v1, int32_t off1, int *
 }
 /* unit-cost edit distance of q[0..ql) against the walks from (v0, off0) that end at (v1, off1); *ed = -1 when not reached within
  * s_term edits.  The vertex walk goes to a vector in the arena (gfa_ed_init/step, gfa-ed.c:524-617, as gchain1.c:349-381 calls them). */
-GC_HD int gc_gwfa(gc_arena_t *A, const gc_graph_t *G, int32_t ql, const char *q, uint32_t v0, int32_t off0, uint32_t v1, int32_t off1,
+GC_HDN int gc_gwfa(gc_arena_t *A, const gc_graph_t *G, int32_t ql, const char *q, uint32_t v0, int32_t off0, uint32_t v1, int32_t off1,
 				  int32_t max_lag, int32_t s_term, int32_t *ed, int32_t **path, int32_t *n_path)
 {
-	gc_gw_t z;
+	GC_STATE(gc_gw_t, z);
 	memset(&z, 0, sizeof z);
 	*ed = -1, *path = 0, *n_path = 0;
 	z.G = G, z.ql = ql, z.q = q;
@@ -1910,9 +1618,9 @@ GC_HD int gc_gwfa(gc_arena_t *A, const gc_graph_t *G, int32_t ql, const char *q,
 
 typedef struct {
 	GC_VEC(mg_llchain_t) lc;   /* vertices of all graph chains, in walk order; anchor-free vertices have cnt == 0 */
-	int32_t n_a;               /* anchors copied to the output so far */
-	mg128_t *a_out;
-	int32_t n_gwfa, n_shortk, n_fast;
+	GC_F int32_t n_a;               /* anchors copied to the output so far */
+	GC_F mg128_t *a_out;
+	GC_F int32_t n_gwfa; GC_F int32_t n_shortk; GC_F int32_t n_fast;
 } gc_asm_t;
 
 GC_HD int gc_asm_vertex(gc_arena_t *A, gc_asm_t *S, uint32_t v)
@@ -2106,7 +1814,7 @@ GC_HD int gc_assemble(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, int
 	if (n_gc == 0) return GC_OK;
 	GC_ALLOC(A, gc_rec_t, R->gc, n_gc);
 	memset(R->gc, 0, (size_t)n_gc * sizeof(gc_rec_t));
-	gc_asm_t S;
+	GC_STATE(gc_asm_t, S);
 	memset(&S, 0, sizeof S);
 	S.a_out = R->a;
 	const int32_t span = GC_ASPAN(a[0]);
@@ -2243,11 +1951,11 @@ GC_HD int gc_drop_filtered(gc_arena_t *A, gc_result_t *R)
 /* ------------------------------------------------------------------------------------------------ one read */
 
 typedef struct {
-	int32_t qlen; uint32_t hash;
-	int32_t n_u; const uint64_t *u;      /* linear chains: score<<32 | count */
-	mg128_t *a;                          /* their anchors, chain after chain; MODIFIED in place (flags, minimizer ranks) */
-	int32_t n_mini; const int32_t *mini_pos;
-	const char *qseq;
+	GC_F int32_t qlen; GC_F uint32_t hash;
+	GC_F int32_t n_u; GC_F const uint64_t *u;      /* linear chains: score<<32 | count */
+	GC_F mg128_t *a;                          /* their anchors, chain after chain; MODIFIED in place (flags, minimizer ranks) */
+	GC_F int32_t n_mini; GC_F const int32_t *mini_pos;
+	GC_F const char *qseq;
 } gc_read_t;
 
 /* R->a must point to a buffer for as many anchors as the chains hold.  Returns GC_OK, GC_E_ARENA (nothing usable in R), or GC_E_BUG

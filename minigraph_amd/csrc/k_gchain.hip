@@ -86,13 +86,34 @@ __device__ __forceinline__ void gck_copy_words(void *dst, const void *src, int64
 	for (int64_t i = lane, n = bytes >> 2; i < n; i += 64) d[i] = s[i];
 }
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) k_gchain(gck_in_t in, gck_out_t out, gc_graph_t G, gc_par_t P, char *arena_mem, int64_t arena_bytes, int fast_bytes)
+#ifndef GC_AB_WAVES_PER_EU
+#define GC_AB_WAVES_PER_EU 2
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GC_AB_WAVES_PER_EU, 8))) k_gchain(gck_in_t in, gck_out_t out, gc_graph_t G_arg, gc_par_t P_arg, char *arena_mem, int64_t arena_bytes, int fast_bytes)
 {
 	extern __shared__ __attribute__((aligned(16))) char fast_lds[]; // fast_bytes of dynamic LDS (0: none)
 	const int lane = threadIdx.x;
 	char *my_arena = arena_mem + (int64_t)blockIdx.x * arena_bytes;
+#ifndef GC_AB_NO_LDS_STATE
+	// the routine's top-level state -- arena header, graph view, parameters, read, result -- once per wavefront in LDS (GC_STATE, gc_core.h): handed on by address, a
+	// private copy per lane would live in scratch memory
+	__shared__ gc_graph_t G_lds;
+	__shared__ gc_par_t P_lds;
+	__shared__ gc_arena_t A_lds;
+	__shared__ gc_read_t rd_lds;
+	__shared__ gc_result_t R_lds;
+	G_lds = G_arg, P_lds = P_arg;
+	mga_wave_sync();
+	const gc_graph_t &G = G_lds;
+	const gc_par_t &P = P_lds;
+#else
+	const gc_graph_t &G = G_arg;
+	const gc_par_t &P = P_arg;
+#endif
+	const long long t_wave0 = out.ctl[15] ? (long long)clock64() : 0;
 	for (;;) {
 		int slot = 0;
+		const long long t_read0 = out.ctl[15] ? (long long)clock64() : 0;
 		if (lane == 0) slot = (int)atomicAdd(&out.ctl[0], 1ULL);
 		slot = __shfl(slot, 0);
 		if (slot >= in.n) break;
@@ -102,7 +123,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
 		mga_gc_hdr_t *H = &out.hdr[r];
 		if (in.rflag && in.rflag[r] == 2) { if (lane == 0) { H->n_gc = H->n_lc = H->n_a = 0, H->status = MGA_GC_HOST, H->gc_off = H->lc_off = H->a_off = 0; } continue; }
 		if (n_u <= 0 || n_b <= 0) { if (lane == 0) { H->n_gc = H->n_lc = H->n_a = 0, H->status = 0, H->gc_off = H->lc_off = H->a_off = 0; } continue; }
+#ifndef GC_AB_NO_LDS_STATE
+		gc_arena_t &A = A_lds;
+		gc_read_t &rd = rd_lds;
+		gc_result_t &R = R_lds;
+#else
 		gc_arena_t A;
+		gc_read_t rd;
+		gc_result_t R;
+#endif
 		gc_arena_init(&A, my_arena, arena_bytes, 0);
 		// MGA_GC_LDS=1: the scratch of ONE graph search / GWFA call at a time in LDS; a call that outgrows the block is run again in the main arena (see the launcher)
 		if (fast_bytes > 0) A.fast_base = (char*)fast_lds, A.fast_cap = fast_bytes;
@@ -113,10 +142,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
 		mga_wave_sync();
 		int32_t status = GC_E_ARENA, n_gc = 0, n_lc = 0, n_a = 0;
 		long long gc_off = 0, lc_off = 0, a_off = 0;
-		gc_result_t R;
 		R.gc = 0, R.lc = 0;
 		if (work && res_a) { // every lane runs the routine on the same values (replicated execution, gc_core.h); its hot loops are split over the lanes
-			gc_read_t rd;
 			rd.qlen = (int32_t)(in.q_off[r + 1] - in.q_off[r]), rd.hash = in.hash[r];
 			rd.n_u = n_u, rd.u = in.u + off, rd.a = work;
 			rd.n_mini = (int32_t)(in.mini_off[r + 1] - in.mini_off[r]), rd.mini_pos = in.mini + in.mini_off[r];
@@ -150,7 +177,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
 			gck_copy_words(out.a_pool + a_off, res_a, (int64_t)n_a * 16, lane);
 		}
 		mga_wave_sync();
+		if (out.ctl[15] && lane == 0) atomicMax(&out.ctl[16 + 15], (unsigned long long)((long long)clock64() - t_read0)); // profiling: the longest read ...
 	}
+	if (out.ctl[15] && lane == 0) atomicMax(&out.ctl[16 + 7], (unsigned long long)((long long)clock64() - t_wave0)); // ... and the longest wavefront of the launch
 }
 
 extern "C" size_t mga_dev_gchain_arena_bytes(int tier)
@@ -308,10 +337,6 @@ extern "C" mg_gchains_t *mga_gchain_host_read(const mg_idx_t *gi, const int32_t 
 
 #if defined(GC_STATS) && !defined(__HIP_DEVICE_COMPILE__)
 extern "C" void mga_gc_stats_dump(void) { gc_stats_dump(); }
-extern "C" void mga_gc_stats_get(long long out[8]) // tests/test_wave_model.py: which wave paths ran
-{
-	out[0] = gc_stats.calls, out[1] = gc_stats.steps, out[2] = gc_stats.blk_ext, out[3] = gc_stats.dedup_calls, out[4] = gc_stats.blk_dedup, out[5] = gc_stats.blk_wave, out[6] = gc_stats.blk_fallback, out[7] = gc_stats.blk_merge;
-}
 #endif
 
 // ---- stage-level host entry points over the same core (CPU parity tests against the reference's mg_shortest_k / gfa_ed_step) ----

@@ -877,11 +877,11 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 			st->n_gwfa += (int64_t)ctl[4], st->n_shortk += (int64_t)ctl[5];
 			if (env_int("MGA_GC_PROF", 0)) { /* per-stage cycle sums of this chunk (profiling aid) */
 				unsigned long long tk[16];
-				static const char *nm[16] = { "", "records", "cleanup", "index", "dp+shortk", "assemble(rest)", "post", "", "gwfa(rest)", "measure", "order", "gw:clear", "gw:runs", "gw:heads", "gw:dedup", "" };
+				static const char *nm[16] = { "", "records", "cleanup", "index", "dp+shortk", "assemble(rest)", "post", "MAX-wave", "gwfa(rest)", "measure", "order", "gw:clear", "gw:runs", "gw:heads", "gw:dedup", "MAX-read" };
 				int q_;
 				CK(mga_d2h_s(sc, tk, (char*)P->gcctl.p + 128, 128)); CK(mga_ssync(sc));
 				fprintf(stderr, "[gc-prof] %d reads, %llu GWFA calls (%llu in the LDS scratch), Mcycles:", n, ctl[4], ctl[8]);
-				for (q_ = 1; q_ < 15; ++q_) if (nm[q_][0]) fprintf(stderr, " %s %.1f", nm[q_], tk[q_] * 1e-6);
+				for (q_ = 1; q_ < 16; ++q_) if (nm[q_][0]) fprintf(stderr, " %s %.1f", nm[q_], tk[q_] * 1e-6);
 				fprintf(stderr, "\n");
 			}
 			if ((int64_t)ctl[7] > st->gc_arena_peak) st->gc_arena_peak = (int64_t)ctl[7];

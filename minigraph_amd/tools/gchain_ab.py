@@ -1,0 +1,124 @@
+"""A/B timing of k_gchain builds on one GPU box (a profiling aid).
+
+  python minigraph_amd/tools/gchain_ab.py build   # here: variants of libminigraph_amd.so that differ in k_gchain.hip's -D switches
+  python minigraph_amd/tools/gchain_ab.py run     # on the GPU box: one workload, every variant in its own process, k_gchain ms per variant
+
+Variants live in minigraph_amd/lib/ab/ (git-ignored like every built file; they travel with gpurun)."""
+import glob
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+CSRC = os.path.join(ROOT, "minigraph_amd", "csrc")
+LIB = os.path.join(ROOT, "minigraph_amd", "lib")
+AB = os.path.join(LIB, "ab")
+HIPCC = "/opt/rocm/bin/hipcc"
+VARIANTS = {
+    "base": ["-DGC_AB_NO_LDS_STATE"],   # round-2 placement of the state (private memory)
+    "lds": [],
+    "lds_ul": ["-DGC_ULOAD"],
+    "lds_1k": [],
+    "lds_512": [],
+}
+ENV = {"lds_1k": {"MGA_GC_WAVES": "1024"}, "lds_512": {"MGA_GC_WAVES": "512"}, "lds": {"MGA_GC_PROF": "1"}}
+
+
+def build(names):
+    os.makedirs(AB, exist_ok=True)
+    others = [o for o in sorted(glob.glob(os.path.join(LIB, "obj", "*.o"))) if os.path.basename(o) != "k_gchain.hip.o"]
+    for name in names:
+        obj = os.path.join(AB, name + ".o")
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result", "-w"] + VARIANTS[name] +
+                              ["-c", os.path.join(CSRC, "k_gchain.hip"), "-o", obj])
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic"] + others + [obj, "-o", os.path.join(AB, "lib_%s.so" % name), "-lz", "-lpthread", "-lm"])
+        os.remove(obj)
+        print("built", name, VARIANTS[name])
+
+
+CHILD = r"""
+import os, sys, time, json
+sys.path.insert(0, %(root)r)
+import minigraph_amd as mga
+import torch
+os.environ["MGA_DEV_GCHAIN"] = "1"; os.environ["MGA_PIPE"] = "1"; os.environ["MGA_WFA_SIDE"] = "0"
+G = mga.Graph(sys.argv[1], n_threads=16)
+m = mga.map_files_idx(G, [sys.argv[2]], n_threads=16); ref = bytes(m.bytes()[:1 << 20]); n0 = len(m.bytes()); m.free()
+mga.prof_enable(True); mga.prof_get(reset=True)
+t0 = time.perf_counter()
+for _ in range(2):
+    m = mga.map_files_idx(G, [sys.argv[2]], n_threads=16); m.free()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 2
+pr = mga.prof_get()
+import hashlib
+print("AB", json.dumps(dict(k_gchain_ms=round(pr["k_gchain"][0] / 2, 2), pass_ms=round(dt * 1e3, 1), gaf_bytes=n0, md5=hashlib.md5(ref).hexdigest())))
+"""
+
+
+def run(names, genome, reads):
+    sys.path.insert(0, ROOT)
+    import minigraph_amd as mga
+    d = tempfile.mkdtemp(prefix="mga_ab_")
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "w"), "-G", str(genome), "-c", "8", "-H", "5", "-n", str(reads), "-s", "11"], stderr=subprocess.DEVNULL)
+    for rep in range(2):
+        for name in names:
+            lib = os.path.join(AB, "lib_%s.so" % name)
+            if not os.path.exists(lib):
+                continue
+            env = dict(os.environ, MGA_LIB=lib, **ENV.get(name, {}))
+            p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, os.path.join(d, "w.gfa"), os.path.join(d, "w.reads.fa")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            line = [l for l in p.stdout.decode().splitlines() if l.startswith("AB")]
+            print(name, line[0] if line else ("FAILED " + p.stderr.decode()[-400:]), flush=True)
+            if "MGA_GC_PROF" in env and rep == 0:
+                print("\n".join(l for l in p.stderr.decode().splitlines() if "gc-prof" in l), flush=True)
+
+
+def sq(name, genome, reads):
+    """two SQ counter passes (rocprofv3 --pmc, no tracing) of one variant's child process; the k_gchain / k_plan rows of the summary"""
+    sys.path.insert(0, ROOT)
+    import minigraph_amd as mga
+    d = tempfile.mkdtemp(prefix="mga_ab_")
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "w"), "-G", str(genome), "-c", "8", "-H", "5", "-n", str(reads), "-s", "11"], stderr=subprocess.DEVNULL)
+    child = os.path.join(d, "child.py")
+    open(child, "w").write(CHILD % {"root": ROOT})
+    env = dict(os.environ, MGA_LIB=os.path.join(AB, "lib_%s.so" % name), TMPDIR="/tmp")
+    sets = ["SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY",
+            "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU",
+            "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_IFETCH SQ_WAIT_INST_LDS SQ_INSTS_SMEM"]
+    dbs = []
+    for i, cs in enumerate(sets):
+        out = os.path.join(d, "sq%d" % i)
+        p = subprocess.run(["rocprofv3", "--pmc"] + cs.split() + ["-d", out, "-o", "pmc", "--", sys.executable, child, os.path.join(d, "w.gfa"), os.path.join(d, "w.reads.fa")],
+                           env=env, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        found = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+        print("pass", i, "rc", p.returncode, found[:1], flush=True)
+        if not found:
+            print(p.stderr.decode()[-600:])
+        dbs += found[:1]
+    import sqlite3
+    acc = {}
+    for db in dbs:
+        cur = sqlite3.connect(db).cursor()
+        for kn, cn, calls, tot in cur.execute("select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name"):
+            acc.setdefault(kn.split("(")[0][:28], {})[cn] = (float(tot), int(calls))
+    for kn, k in sorted(acc.items()):
+        if not any(x in kn for x in ("k_gchain", "k_plan", "k_lchain")):
+            continue
+        w, cyc = k.get("SQ_WAVES", (1, 0))[0], k.get("SQ_WAVE_CYCLES", (1, 0))[0]
+        print(kn, "launches", k.get("SQ_WAVES", (0, 0))[1], "waves %.0f" % w, "cycles/wave %.0f" % (cyc / w))
+        for cn, (v, _) in sorted(k.items()):
+            print("    %-24s per wave %14.1f   share of wave cycles %.4f" % (cn, v / w, v / cyc))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "sq":
+        sq(sys.argv[2], int(os.environ.get("AB_GENOME", "800000000")), int(os.environ.get("AB_READS", "49152")))
+        sys.exit(0)
+    names = [a for a in sys.argv[2:] if a in VARIANTS] or list(VARIANTS)
+    if sys.argv[1] == "build":
+        build(names)
+    else:
+        run(names, int(os.environ.get("AB_GENOME", "800000000")), int(os.environ.get("AB_READS", "49152")))
