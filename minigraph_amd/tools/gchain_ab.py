@@ -17,13 +17,12 @@ LIB = os.path.join(ROOT, "minigraph_amd", "lib")
 AB = os.path.join(LIB, "ab")
 HIPCC = "/opt/rocm/bin/hipcc"
 VARIANTS = {
-    "base": ["-DGC_AB_NO_LDS_STATE"],   # round-2 placement of the state (private memory)
-    "lds": [],
-    "lds_ul": ["-DGC_ULOAD"],
-    "lds_1k": [],
-    "lds_512": [],
+    "cur": [],                               # the tree as it is
+    "nolds": ["-DGC_AB_NO_LDS_STATE"],       # round-2 placement of the routines' state (a private copy per lane: scratch memory)
+    "ni": ["-DGC_AB_NOINLINE"],              # the big routines as functions of their own (half the code)
+    "w4": ["-DGC_AB_WAVES_PER_EU=4"],        # 128 VGPRs, four resident wavefronts per SIMD
 }
-ENV = {"lds_1k": {"MGA_GC_WAVES": "1024"}, "lds_512": {"MGA_GC_WAVES": "512"}, "lds": {"MGA_GC_PROF": "1"}}
+ENV = {"w4": {"MGA_GC_WAVES": "4096"}}
 
 
 def build(names):
@@ -63,17 +62,25 @@ def run(names, genome, reads):
     import minigraph_amd as mga
     d = tempfile.mkdtemp(prefix="mga_ab_")
     subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "w"), "-G", str(genome), "-c", "8", "-H", "5", "-n", str(reads), "-s", "11"], stderr=subprocess.DEVNULL)
-    for rep in range(2):
+    import re
+    for rep in range(2):   # first round with per-stage cycle sums (MGA_GC_PROF=1: inflates the kernel, the sums compare builds), second round plain
         for name in names:
             lib = os.path.join(AB, "lib_%s.so" % name)
             if not os.path.exists(lib):
                 continue
             env = dict(os.environ, MGA_LIB=lib, **ENV.get(name, {}))
+            if rep == 0:
+                env["MGA_GC_PROF"] = "1"
             p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, os.path.join(d, "w.gfa"), os.path.join(d, "w.reads.fa")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             line = [l for l in p.stdout.decode().splitlines() if l.startswith("AB")]
-            print(name, line[0] if line else ("FAILED " + p.stderr.decode()[-400:]), flush=True)
-            if "MGA_GC_PROF" in env and rep == 0:
-                print("\n".join(l for l in p.stderr.decode().splitlines() if "gc-prof" in l), flush=True)
+            print(name, "prof" if rep == 0 else "plain", line[0] if line else ("FAILED " + p.stderr.decode()[-400:]), flush=True)
+            if rep == 0:
+                tot = {}
+                for l in p.stderr.decode().splitlines():
+                    if "gc-prof" in l:
+                        for k, v in re.findall(r" ([A-Za-z:+()\-]+) ([0-9.]+)", l.split("Mcycles:")[1]):
+                            tot[k] = max(tot.get(k, 0.0), float(v)) if k.startswith("MAX") else tot.get(k, 0.0) + float(v)
+                print("   Gcycles over the 3 passes:", " ".join("%s %.1f" % (k, v * 1e-3) for k, v in tot.items()), "| SUM %.1f" % (sum(v for k, v in tot.items() if not k.startswith("MAX")) * 1e-3), flush=True)
 
 
 def sq(name, genome, reads):
@@ -85,10 +92,16 @@ def sq(name, genome, reads):
     child = os.path.join(d, "child.py")
     open(child, "w").write(CHILD % {"root": ROOT})
     env = dict(os.environ, MGA_LIB=os.path.join(AB, "lib_%s.so" % name), TMPDIR="/tmp")
+    if os.environ.get("AB_PMC") == "mem":
+        sets_override = ["FETCH_SIZE", "WRITE_SIZE", "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum", "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"]
+    else:
+        sets_override = None
     sets = ["SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY",
             "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU",
             "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_IFETCH SQ_WAIT_INST_LDS SQ_INSTS_SMEM"]
     dbs = []
+    if sets_override:
+        sets = sets_override
     for i, cs in enumerate(sets):
         out = os.path.join(d, "sq%d" % i)
         p = subprocess.run(["rocprofv3", "--pmc"] + cs.split() + ["-d", out, "-o", "pmc", "--", sys.executable, child, os.path.join(d, "w.gfa"), os.path.join(d, "w.reads.fa")],
@@ -106,6 +119,11 @@ def sq(name, genome, reads):
             acc.setdefault(kn.split("(")[0][:28], {})[cn] = (float(tot), int(calls))
     for kn, k in sorted(acc.items()):
         if not any(x in kn for x in ("k_gchain", "k_plan", "k_lchain")):
+            continue
+        if sets_override:
+            print(kn)
+            for cn, (v, nl) in sorted(k.items()):
+                print("    %-32s total %18.0f   per launch %16.1f (%d launches)" % (cn, v, v / max(1, nl), nl))
             continue
         w, cyc = k.get("SQ_WAVES", (1, 0))[0], k.get("SQ_WAVE_CYCLES", (1, 0))[0]
         print(kn, "launches", k.get("SQ_WAVES", (0, 0))[1], "waves %.0f" % w, "cycles/wave %.0f" % (cyc / w))
