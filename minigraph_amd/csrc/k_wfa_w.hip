@@ -27,8 +27,8 @@
 // run in lockstep but on independent problems: a group that finishes (or gives up) is retired and refilled from the work
 // queue while the others carry on.  Traceback bytes never touch LDS: four scores are packed into one dword per lane and stored
 // with one coalesced global_store_dword per four steps into the problem's own region of a scratch pool.
-// Traceback (k_wfa_tb): one LANE per problem walks its region backwards (miniwfa.c:329-377), twice -- count, then write the
-// operators into the CIGAR pool at an offset reserved with one atomic per wavefront -- and leaves the same mga_wfa_res_t the
+// Traceback (k_wfa_tb): one LANE per problem walks its region backwards (miniwfa.c:329-377) ONCE, writing the operators downwards
+// from the end of a slot of the CIGAR pool sized by the score (one reservation per wavefront), and leaves the same mga_wfa_res_t the
 // register tiers of k_wfa_r.hip leave.
 #include <type_traits>
 #include "mga_dev.h"
@@ -347,7 +347,7 @@ __device__ __forceinline__ int32_t wfw_trace(int32_t tl, int32_t ql, const char 
 #define PUSH(op_, len_) do { \
 		if (cur_op == (op_)) cur_len += (len_); \
 		else { \
-			if (cur_op >= 0) { if (WRITE) out[n_total - 1 - n] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; ++n; } \
+			if (cur_op >= 0) { if (WRITE && n < n_total) out[n_total - 1 - n] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; ++n; } \
 			cur_op = (op_), cur_len = (len_); \
 		} \
 	} while (0)
@@ -403,13 +403,12 @@ __global__ void __launch_bounds__(256) k_wfa_tb(const int *__restrict__ n_p, int
 	const int32_t W = r.pad >> 8, ph = r.pad >> 4 & 3, last = r.pad & 7;
 	const uint32_t *reg = (const uint32_t*)(uintptr_t)r.cig_off;
 	const char *ts = tseq + pb.t_off, *qs = qseq + pb.q_off;
+	// ONE walk: the operators come out last to first, so they are written downwards from the end of a slot sized for the most an alignment of this score can have -- an
+	// edit run costs at least 4 (a mismatch), match runs are one more than edit runs, plus the gap that is left when one sequence runs out: <= 2 (S / 4) + 2 -- and the
+	// alignment's CIGAR is the slot's tail.  (A counting walk before the reservation read every traceback sector twice: 51 GB per 125 k reads.)
 	int32_t lo = 0, n_cig = 0;
-	if (mine) {
-		(void)wfw_window(W, pb.tl, pb.ql, &lo, WFW_SMAX);
-		n_cig = wfw_trace<false>(pb.tl, pb.ql, ts, qs, r.score, last, reg, W, ph, lo, 0, 0);
-	}
-	// one reservation per wavefront
-	int32_t incl = n_cig > 0 ? n_cig : 0;
+	const int32_t ub = mine ? (r.score >> 1) + 4 : 0;
+	int32_t incl = ub; // one reservation per wavefront
 #pragma unroll
 	for (int d = 1; d < 64; d <<= 1) { const int32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
 	const int32_t tot = __shfl(incl, 63);
@@ -417,14 +416,18 @@ __global__ void __launch_bounds__(256) k_wfa_tb(const int *__restrict__ n_p, int
 	if (lane == 63 && tot > 0) base = atomicAdd(pool_used, (unsigned long long)tot);
 	base = __shfl(base, 63);
 	if (!mine) return;
-	if (n_cig < 0 || (long long)(base + (unsigned long long)tot) > pool_cap) {
+	const long long slot = (long long)base + (incl - ub);
+	if ((long long)(base + (unsigned long long)tot) <= pool_cap) {
+		(void)wfw_window(W, pb.tl, pb.ql, &lo, WFW_SMAX);
+		n_cig = wfw_trace<true>(pb.tl, pb.ql, ts, qs, r.score, last, reg, W, ph, lo, pool + slot, ub);
+	} else n_cig = -1;
+	if (n_cig < 0 || n_cig > ub) { // (pool full, or -- cannot happen -- a walk that left the window / more operators than the score allows: fail loudly)
 		r.status = MGA_WFA_POOL_FULL, r.score = -1, r.n_cigar = 0, r.cig_off = 0;
 		res[i] = r;
 		atomicAdd(err, 1);
 		return;
 	}
-	const long long off = (long long)base + (incl - n_cig);
-	(void)wfw_trace<true>(pb.tl, pb.ql, ts, qs, r.score, last, reg, W, ph, lo, pool + off, n_cig);
+	const long long off = slot + (ub - n_cig);
 	// the reference's cell count for this alignment (n_iter, miniwfa.c:421): its band at score s is the reachable diagonals +- 1, clipped to the matrix
 	long long cells = 0;
 	for (int32_t s = 0; s < r.score; ++s) { const int32_t w = wfw_reach(s) + 1; cells += min(w, pb.tl) + min(w, pb.ql) + 1; }
