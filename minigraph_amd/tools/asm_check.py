@@ -25,20 +25,25 @@ def main():
     ap.add_argument("--contig", type=int, default=50000000)
     ap.add_argument("--n", type=int, default=2)
     ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--genome", type=int, default=50000000, help="backbone bp of the graph")
+    ap.add_argument("--chr", type=int, default=1)
+    ap.add_argument("--hap", type=int, default=3)
+    ap.add_argument("--cigar-only", action="store_true", help="only the -c run (BASELINE configs[4] is -cx asm)")
     a = ap.parse_args()
     mga.load()
     d = tempfile.mkdtemp(prefix="mga_asm_")
     try:
-        subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "a"), "-G", "50000000", "-H", "3", "-n", str(a.n), "-l", str(a.contig), "-e", "0.001", "-s", "5"],
+        subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "a"), "-G", str(a.genome), "-c", str(a.chr), "-H", str(a.hap), "-n", str(a.n), "-l", str(a.contig), "-e", "0.001", "-s", "5"],
                               stderr=subprocess.DEVNULL)
         g, r = os.path.join(d, "a.gfa"), os.path.join(d, "a.reads.fa")
         ok = True
-        for cigar in (False, True):
+        for cigar in ((True,) if a.cigar_only else (False, True)):
             got, ref = os.path.join(d, "got.gaf"), os.path.join(d, "ref.gaf")
             t0 = time.time()
             mga.map_files(g, [r], got, preset="asm", cigar=cigar, n_threads=a.threads)
             t1 = time.time()
-            out = {"contig_bp": a.contig, "n": a.n, "cigar": cigar, "t_ours_total_s": round(t1 - t0, 2)}
+            out = {"graph_backbone_bp": a.genome, "chr": a.chr, "hap": a.hap, "contig_bp": a.contig, "n": a.n, "query_bp": os.path.getsize(r), "cigar": cigar, "threads": a.threads,
+                   "t_ours_total_s": round(t1 - t0, 2), "gaf_bytes": os.path.getsize(got), "note": "file -> file, graph load + index build included on both sides"}
             if os.path.exists(REF_BIN):
                 with open(ref, "wb") as fo:
                     subprocess.check_call([REF_BIN] + (["-c"] if cigar else []) + ["-x", "asm", "-t", str(a.threads), g, r], stdout=fo, stderr=subprocess.DEVNULL)
