@@ -1664,70 +1664,94 @@ GC_HD void gc_untangle(gc_chain_t *c0, gc_chain_t *c1, const mg128_t *a)
 	if (c0->cnt == 0) c0->qs = c0->qe = c1->qs, c0->rs = c0->re = c1->rs;
 }
 
+/* What a bridge between two chains on different segments comes to: the walk between them, or "no walk of the chosen length" (the reference's "chain skiped").  It depends on the two
+ * chain records, the graph and the query only -- not on the assembly so far -- which is what lets the device compute a read's bridges on several wavefronts (gc_read_p1/p2/p3 below). */
+typedef struct { int32_t failed, ed, n_mid; int32_t *mid; int32_t n_gwfa, n_shortk, n_fast; } gc_bres_t;
+
 /* the vertices between chain c0 and chain c1 (different segments): by aligning the query between them to the graph, or, when that
- * gives up, by the shortest walk of the length the DP chose (gchain1.c:319-407); returns 1 when c1 could not be attached */
+ * gives up, by the shortest walk of the length the DP chose (gchain1.c:319-407).  b->mid lies in A (scratch: the caller resets A when it has used it) */
+GC_HD int gc_bridge_walk(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, int32_t span, const gc_chain_t *c0, const gc_chain_t *c1, const char *qseq, gc_bres_t *b)
+{
+	int32_t ed = -1, *path = 0, n_path = 0, n_mid = 0;
+	const int64_t mark = A->top;
+	const char *base = A->base;
+	b->failed = 0, b->ed = -1, b->n_mid = 0, b->mid = 0, b->n_gwfa = b->n_shortk = b->n_fast = 0;
+	{
+		const int32_t qs = c0->qe - span, qe = c1->qs + span;
+		int rc = GC_E_ARENA;
+		GC_TICK(A, 5);
+		/* (the LDS scratch holds a call over a query gap of a few hundred bases -- [measured] 30 % of the calls of the bench workload fit 16 KB -- and a failed
+		 * attempt is paid twice, so only short gaps try it) */
+		if (A->fast_base && qe - qs <= GC_FAST_GAP) { gc_arena_t F; gc_arena_init(&F, A->fast_base, A->fast_cap, 0); F.ticks = A->ticks, F.tick_last = A->tick_last; rc = gc_gwfa(&F, G, qe - qs, qseq + qs, c0->v, c0->re - span, c1->v, c1->rs + span - 1, P->gdp_max_ed / 2, P->gdp_max_ed, &ed, &path, &n_path); A->tick_last = F.tick_last; if (rc == GC_OK) ++b->n_fast; }
+		GC_STAT(const int64_t st_top0 = A->top; const int64_t st_peak0 = A->peak; A->peak = A->top;)
+		if (rc == GC_E_ARENA) rc = gc_gwfa(A, G, qe - qs, qseq + qs, c0->v, c0->re - span, c1->v, c1->rs + span - 1, P->gdp_max_ed / 2, P->gdp_max_ed, &ed, &path, &n_path);
+		GC_STAT(if (A->base == base) { const int64_t used = A->peak - st_top0; gc_stats.arena_hist[gc_stats_bin(used >> 9)]++; gc_stats.arena_sum += used; if (used <= 16384) gc_stats.fit16++; if (used <= 32768) gc_stats.fit32++; if (used <= 65536) gc_stats.fit64++; } if (A->peak < st_peak0) A->peak = st_peak0;)
+		if (rc != GC_OK) return rc;
+		GC_TICK(A, 8);
+		++b->n_gwfa;
+	}
+	if (ed >= 0) {
+		n_mid = n_path - 2 > 0 ? n_path - 2 : 0;
+		if (n_mid) gc_pmove_down(path, path + 1, (int64_t)n_mid * 4); /* the inner vertices */
+	} else {
+		gc_dst_t dst;
+		gc_walkv_t *w = 0;
+		int32_t n_w = 0;
+		if (A->base == base) A->top = mark;
+		memset(&dst, 0, sizeof dst);
+		dst.v = c0->v ^ 1, dst.target_dist = c1->dist_pre, dst.target_hash = c1->hash_pre, dst.check_hash = 1;
+		int rc = GC_E_ARENA;
+		if (A->fast_base) { gc_arena_t F; gc_arena_init(&F, A->fast_base, A->fast_cap, 0); rc = gc_shortest_k(&F, G, c1->v ^ 1, 1, &dst, dst.target_dist, MG_MAX_SHORT_K, &w, &n_w); }
+		if (rc == GC_E_ARENA) { memset(&dst, 0, sizeof dst); dst.v = c0->v ^ 1, dst.target_dist = c1->dist_pre, dst.target_hash = c1->hash_pre, dst.check_hash = 1; rc = gc_shortest_k(A, G, c1->v ^ 1, 1, &dst, dst.target_dist, MG_MAX_SHORT_K, &w, &n_w); }
+		if (rc == GC_E_ARENA) return rc;
+		++b->n_shortk;
+		if (rc != GC_OK || n_w == 0 || dst.target_hash != dst.hash) { if (A->base == base) A->top = mark; b->failed = 1; return GC_OK; } /* "chain skiped" (gchain1.c:333-338) */
+		n_mid = n_w - 2 > 0 ? n_w - 2 : 0;
+		GC_ALLOC(A, int32_t, path, n_mid > 0 ? n_mid : 1);
+		for (int32_t s = n_w - 2, k = 0; s >= 1; --s) path[k++] = (int32_t)(w[s].v ^ 1); /* found backwards: reverse and flip */
+	}
+	b->ed = ed, b->n_mid = n_mid, b->mid = path;
+	return GC_OK;
+}
+/* the walk's inner vertices, then chain c1, go behind what is assembled; [mark, base]: where the walk's scratch began (released when nothing was allocated on top of it) */
+GC_HD int gc_bridge_append(gc_arena_t *A, gc_asm_t *S, const gc_chain_t *c1, const mg128_t *a, int32_t ed, int32_t n_mid, const int32_t *mid, int64_t mark, const char *base)
+{
+	if (S->lc.n + n_mid + 1 <= S->lc.m) { /* fits the reserved room: nothing is allocated while the vertices are appended */
+		for (int32_t j = 0; j < n_mid; ++j) GC_TRY(gc_asm_vertex(A, S, (uint32_t)mid[j]));
+		if (A->base == base) A->top = mark;
+	} else for (int32_t j = 0; j < n_mid; ++j) GC_TRY(gc_asm_vertex(A, S, (uint32_t)mid[j])); /* long walk: the scratch stays until the read is done */
+	return gc_asm_chain(A, S, c1, a, ed);
+}
+/* c1 lies on the segment of c0: its anchors beyond the end of c0 extend the last vertex */
+GC_HD void gc_bridge_same(gc_asm_t *S, const gc_chain_t *c0, const gc_chain_t *c1, const mg128_t *a)
+{
+	mg_llchain_t *t = &S->lc.a[S->lc.n - 1];
+	int32_t k = 0;
+	while (k < c1->cnt && !(GC_AX(a[c1->off + k]) > c0->re && GC_AY(a[c1->off + k]) > c0->qe)) ++k;
+	if (k < c1->cnt) {
+		t->cnt += c1->cnt - k, t->score += c1->score;
+		gc_pcopy(&S->a_out[S->n_a], &a[c1->off + k], (int64_t)(c1->cnt - k) * (int64_t)sizeof(mg128_t));
+		S->n_a += c1->cnt - k;
+	}
+}
+/* chain c1 behind chain c0 in the assembly; *failed = 1 when c1 could not be attached */
 GC_HD int gc_bridge(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, gc_asm_t *S, int32_t span, const gc_chain_t *c0, const gc_chain_t *c1,
 					const mg128_t *a, const char *qseq, int *failed)
 {
 	*failed = 0;
 	if (c1->v != c0->v) {
-		int32_t ed = -1, *path = 0, n_path = 0, n_mid = 0;
+		gc_bres_t b;
 		GC_TRY(gc_vec_reserve(A, S->lc, S->lc.n + 66)); /* room for the usual walk, so that the search's scratch can be released afterwards */
 		const int64_t mark = A->top;
 		const char *base = A->base;
-		{
-			const int32_t qs = c0->qe - span, qe = c1->qs + span;
-			int rc = GC_E_ARENA;
-			GC_TICK(A, 5);
-			/* (the LDS scratch holds a call over a query gap of a few hundred bases -- [measured] 30 % of the calls of the bench workload fit 16 KB -- and a failed
-			 * attempt is paid twice, so only short gaps try it) */
-			if (A->fast_base && qe - qs <= GC_FAST_GAP) { gc_arena_t F; gc_arena_init(&F, A->fast_base, A->fast_cap, 0); F.ticks = A->ticks, F.tick_last = A->tick_last; rc = gc_gwfa(&F, G, qe - qs, qseq + qs, c0->v, c0->re - span, c1->v, c1->rs + span - 1, P->gdp_max_ed / 2, P->gdp_max_ed, &ed, &path, &n_path); A->tick_last = F.tick_last; if (rc == GC_OK) ++S->n_fast; }
-			GC_STAT(const int64_t st_top0 = A->top; const int64_t st_peak0 = A->peak; A->peak = A->top;)
-			if (rc == GC_E_ARENA) rc = gc_gwfa(A, G, qe - qs, qseq + qs, c0->v, c0->re - span, c1->v, c1->rs + span - 1, P->gdp_max_ed / 2, P->gdp_max_ed, &ed, &path, &n_path);
-			GC_STAT(if (A->base == base) { const int64_t used = A->peak - st_top0; gc_stats.arena_hist[gc_stats_bin(used >> 9)]++; gc_stats.arena_sum += used; if (used <= 16384) gc_stats.fit16++; if (used <= 32768) gc_stats.fit32++; if (used <= 65536) gc_stats.fit64++; } if (A->peak < st_peak0) A->peak = st_peak0;)
-			if (rc != GC_OK) return rc;
-			GC_TICK(A, 8);
-			++S->n_gwfa;
-		}
-		if (ed >= 0) {
-			n_mid = n_path - 2 > 0 ? n_path - 2 : 0;
-			if (n_mid) gc_pmove_down(path, path + 1, (int64_t)n_mid * 4); /* the inner vertices */
-		} else {
-			gc_dst_t dst;
-			gc_walkv_t *w = 0;
-			int32_t n_w = 0;
-			if (A->base == base) A->top = mark;
-			memset(&dst, 0, sizeof dst);
-			dst.v = c0->v ^ 1, dst.target_dist = c1->dist_pre, dst.target_hash = c1->hash_pre, dst.check_hash = 1;
-			int rc = GC_E_ARENA;
-			if (A->fast_base) { gc_arena_t F; gc_arena_init(&F, A->fast_base, A->fast_cap, 0); rc = gc_shortest_k(&F, G, c1->v ^ 1, 1, &dst, dst.target_dist, MG_MAX_SHORT_K, &w, &n_w); }
-			if (rc == GC_E_ARENA) { memset(&dst, 0, sizeof dst); dst.v = c0->v ^ 1, dst.target_dist = c1->dist_pre, dst.target_hash = c1->hash_pre, dst.check_hash = 1; rc = gc_shortest_k(A, G, c1->v ^ 1, 1, &dst, dst.target_dist, MG_MAX_SHORT_K, &w, &n_w); }
-			if (rc == GC_E_ARENA) return rc;
-			++S->n_shortk;
-			if (rc != GC_OK || n_w == 0 || dst.target_hash != dst.hash) { if (A->base == base) A->top = mark; *failed = 1; return GC_OK; } /* "chain skiped" (gchain1.c:333-338) */
-			n_mid = n_w - 2 > 0 ? n_w - 2 : 0;
-			GC_ALLOC(A, int32_t, path, n_mid > 0 ? n_mid : 1);
-			for (int32_t s = n_w - 2, k = 0; s >= 1; --s) path[k++] = (int32_t)(w[s].v ^ 1); /* found backwards: reverse and flip */
-		}
-		if (S->lc.n + n_mid + 1 <= S->lc.m) { /* fits the reserved room: nothing is allocated while the vertices are appended */
-			for (int32_t j = 0; j < n_mid; ++j) GC_TRY(gc_asm_vertex(A, S, (uint32_t)path[j]));
-			if (A->base == base) A->top = mark;
-		} else for (int32_t j = 0; j < n_mid; ++j) GC_TRY(gc_asm_vertex(A, S, (uint32_t)path[j])); /* long walk: the scratch stays until the read is done */
-		GC_TRY(gc_asm_chain(A, S, c1, a, ed));
-	} else { /* same segment: the anchors of c1 beyond the end of c0 extend the last vertex */
-		mg_llchain_t *t = &S->lc.a[S->lc.n - 1];
-		int32_t k = 0;
-		while (k < c1->cnt && !(GC_AX(a[c1->off + k]) > c0->re && GC_AY(a[c1->off + k]) > c0->qe)) ++k;
-		if (k < c1->cnt) {
-			t->cnt += c1->cnt - k, t->score += c1->score;
-			gc_pcopy(&S->a_out[S->n_a], &a[c1->off + k], (int64_t)(c1->cnt - k) * (int64_t)sizeof(mg128_t));
-			S->n_a += c1->cnt - k;
-		}
-	}
+		GC_TRY(gc_bridge_walk(A, G, P, span, c0, c1, qseq, &b));
+		S->n_gwfa += b.n_gwfa, S->n_shortk += b.n_shortk, S->n_fast += b.n_fast;
+		if (b.failed) { *failed = 1; return GC_OK; }
+		GC_TRY(gc_bridge_append(A, S, c1, a, b.ed, b.n_mid, b.mid, mark, base));
+	} else gc_bridge_same(S, c0, c1, a);
 	return GC_OK;
 }
 
-/* coordinates and alignment-length estimates of every graph chain (gchain1.c:242-301), integers only */
 GC_HD void gc_measure(const gc_graph_t *G, gc_result_t *R)
 {
 	for (int32_t i = 0; i < R->n_gc; ++i) {
@@ -1799,42 +1823,111 @@ GC_HD int gc_order_by_score(gc_arena_t *A, gc_result_t *R)
 }
 
 /* from the DP's grouping of the chains (u[], c[]) to graph chains with their vertex walks (gchain1.c:443-520) */
-GC_HD int gc_assemble(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, int32_t n_u, const uint64_t *u, gc_chain_t *c, const mg128_t *a, uint32_t hash,
-					  const char *qseq, gc_result_t *R)
+/* A bridge of a read as a unit of work of its own (device: gc_read_p1 lists them, a wavefront per bridge computes them, gc_read_p3 consumes them in order) */
+#define GC_JOB_OK     0
+#define GC_JOB_FAILED 1   /* no walk of the chosen length ("chain skiped") */
+#define GC_JOB_ARENA  2   /* the scratch arena was too small: the read is run again the monolithic way in a large one */
+typedef struct {
+	const gc_chain_t *c0, *c1;    /* in the read's arena */
+	const char *qseq;
+	int32_t read, span, status;
+	int32_t ed, n_mid, n_gwfa, n_shortk, n_fast;
+	int64_t mid_off;              /* the walk's inner vertices: mid_pool[mid_off .. mid_off + n_mid) */
+} gc_job_t;
+
+GC_HD int gc_asm_kept(const gc_par_t *P, const uint64_t *u, const gc_chain_t *c, int32_t i, int32_t st)
 {
-	int32_t n_gc = 0;
+	const int32_t ni = (int32_t)(uint32_t)u[i];
+	int32_t m = 0;
+	for (int32_t j = 0; j < ni; ++j) m += c[st + j].cnt;
+	return m >= P->min_gc_cnt && (int64_t)(u[i] >> 32) >= P->min_gc_score;
+}
+/* first half of the assembly: the records, the junctions of consecutive chains made monotone (they only touch the chains of their own graph chain), and the number of bridges
+ * between chains on different segments, in the order gc_assemble_run() meets them */
+GC_HD int gc_assemble_begin(gc_arena_t *A, const gc_par_t *P, int32_t n_u, const uint64_t *u, gc_chain_t *c, const mg128_t *a, gc_result_t *R, int32_t *n_jobs)
+{
+	int32_t n_gc = 0, nj = 0;
 	R->n_gc = R->n_lc = R->n_a = 0, R->gc = 0, R->lc = 0;
-	for (int32_t i = 0, st = 0; i < n_u; ++i) {
-		const int32_t ni = (int32_t)(uint32_t)u[i];
-		int32_t m = 0;
-		for (int32_t j = 0; j < ni; ++j) m += c[st + j].cnt;
-		n_gc += m >= P->min_gc_cnt && (int64_t)(u[i] >> 32) >= P->min_gc_score;
-		st += ni;
-	}
+	*n_jobs = 0;
+	for (int32_t i = 0, st = 0; i < n_u; st += (int32_t)(uint32_t)u[i], ++i) n_gc += gc_asm_kept(P, u, c, i, st);
+	R->n_gc = n_gc;
 	if (n_gc == 0) return GC_OK;
 	GC_ALLOC(A, gc_rec_t, R->gc, n_gc);
 	memset(R->gc, 0, (size_t)n_gc * sizeof(gc_rec_t));
+	for (int32_t i = 0, st = 0; i < n_u; st += (int32_t)(uint32_t)u[i], ++i) {
+		const int32_t ni = (int32_t)(uint32_t)u[i];
+		if (!gc_asm_kept(P, u, c, i, st)) continue;
+		for (int32_t j = 1; j < ni; ++j) gc_untangle(&c[st + j - 1], &c[st + j], a);
+		for (int32_t j0 = 0, j = 1; j < ni; ++j) {
+			if (c[st + j].cnt <= 0) continue;
+			nj += c[st + j].v != c[st + j0].v;
+			j0 = j;
+		}
+	}
+	*n_jobs = nj;
+	return GC_OK;
+}
+/* the bridges gc_assemble_begin() counted, in the same order */
+GC_HD void gc_assemble_jobs(const gc_par_t *P, int32_t n_u, const uint64_t *u, const gc_chain_t *c, int32_t read, int32_t span, const char *qseq, gc_job_t *jobs)
+{
+	int32_t nj = 0;
+	for (int32_t i = 0, st = 0; i < n_u; st += (int32_t)(uint32_t)u[i], ++i) {
+		const int32_t ni = (int32_t)(uint32_t)u[i];
+		if (!gc_asm_kept(P, u, c, i, st)) continue;
+		for (int32_t j0 = 0, j = 1; j < ni; ++j) {
+			if (c[st + j].cnt <= 0) continue;
+			if (c[st + j].v != c[st + j0].v) {
+				gc_job_t *q = &jobs[nj++];
+				q->c0 = &c[st + j0], q->c1 = &c[st + j], q->qseq = qseq, q->read = read, q->span = span, q->status = GC_JOB_OK;
+				q->ed = -1, q->n_mid = 0, q->n_gwfa = q->n_shortk = q->n_fast = 0, q->mid_off = 0;
+			}
+			j0 = j;
+		}
+	}
+}
+/* one bridge, on whatever wavefront (or host thread) gets it: scratch in A, the inner vertices of the walk copied to mid_out[0 .. n_mid) by the caller's rule */
+GC_HD int gc_job_run(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, gc_job_t *q, gc_bres_t *b)
+{
+	const int rc = gc_bridge_walk(A, G, P, q->span, q->c0, q->c1, q->qseq, b);
+	if (rc == GC_E_ARENA) { q->status = GC_JOB_ARENA; return GC_OK; }
+	if (rc != GC_OK) return rc;
+	q->status = b->failed ? GC_JOB_FAILED : GC_JOB_OK;
+	q->ed = b->ed, q->n_mid = b->n_mid, q->n_gwfa = b->n_gwfa, q->n_shortk = b->n_shortk, q->n_fast = b->n_fast;
+	return GC_OK;
+}
+/* second half: chains and walks in order (gchain1.c:409-465), measuring, ordering.  jobs == 0: every bridge is computed where it is met; otherwise the bridges between chains on
+ * different segments were computed beforehand (jobs[], inner vertices in mid_pool) and are consumed in order. */
+GC_HD int gc_assemble_run(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, int32_t n_u, const uint64_t *u, gc_chain_t *c, const mg128_t *a, uint32_t hash,
+						  const char *qseq, gc_result_t *R, const gc_job_t *jobs, const int32_t *mid_pool)
+{
+	if (R->n_gc == 0) return GC_OK;
 	GC_STATE(gc_asm_t, S);
 	memset(&S, 0, sizeof S);
 	S.a_out = R->a;
 	const int32_t span = GC_ASPAN(a[0]);
-	int32_t k = 0;
+	int32_t k = 0, jk = 0;
 	for (int32_t i = 0, st = 0; i < n_u; st += (int32_t)(uint32_t)u[i], ++i) {
 		const int32_t ni = (int32_t)(uint32_t)u[i], n_a0 = S.n_a, n_lc0 = S.lc.n;
-		int32_t m = 0;
-		for (int32_t j = 0; j < ni; ++j) m += c[st + j].cnt;
-		if (!(m >= P->min_gc_cnt && (int64_t)(u[i] >> 32) >= P->min_gc_score)) continue;
+		if (!gc_asm_kept(P, u, c, i, st)) continue;
 		gc_rec_t *g = &R->gc[k];
 		uint32_t h = hash;
 		g->score = (int32_t)(u[i] >> 32), g->off = n_lc0;
 		for (int32_t j = 0; j < ni; ++j) h += gc_hash32((uint32_t)c[st + j].qs) + gc_hash32((uint32_t)c[st + j].re) + gc_hash32(c[st + j].v);
 		g->hash = gc_hash32(h);
-		for (int32_t j = 1; j < ni; ++j) gc_untangle(&c[st + j - 1], &c[st + j], a);
 		GC_TRY(gc_asm_chain(A, &S, &c[st], a, -1));
 		for (int32_t j0 = 0, j = 1; j < ni; ++j) {
 			if (c[st + j].cnt <= 0) continue; /* emptied by the untangling: skipped, its neighbours are bridged directly */
-			int failed;
-			GC_TRY(gc_bridge(A, G, P, &S, span, &c[st + j0], &c[st + j], a, qseq, &failed));
+			int failed = 0;
+			if (jobs && c[st + j].v != c[st + j0].v) {
+				const gc_job_t *q = &jobs[jk++];
+				if (q->status == GC_JOB_ARENA) return GC_E_ARENA;
+				S.n_gwfa += q->n_gwfa, S.n_shortk += q->n_shortk, S.n_fast += q->n_fast;
+				if (q->status == GC_JOB_FAILED) failed = 1;
+				else {
+					GC_TRY(gc_vec_reserve(A, S.lc, S.lc.n + 66));
+					GC_TRY(gc_bridge_append(A, &S, &c[st + j], a, q->ed, q->n_mid, mid_pool + q->mid_off, A->top, A->base));
+				}
+			} else GC_TRY(gc_bridge(A, G, P, &S, span, &c[st + j0], &c[st + j], a, qseq, &failed));
 			if (failed) /* no walk of the chosen length between the two: go through the emptied chains in between, pair by pair */
 				for (int32_t t = j0; t < j; ++t) { GC_TRY(gc_bridge(A, G, P, &S, span, &c[st + t], &c[st + t + 1], a, qseq, &failed)); if (failed) return GC_E_BUG; }
 			j0 = j;
@@ -1842,13 +1935,21 @@ GC_HD int gc_assemble(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, int
 		g->cnt = S.lc.n - n_lc0, g->n_anchor = S.n_a - n_a0;
 		++k;
 	}
-	R->n_gc = n_gc, R->n_lc = S.lc.n, R->n_a = S.n_a, R->lc = S.lc.a;
+	R->n_lc = S.lc.n, R->n_a = S.n_a, R->lc = S.lc.a;
 	R->n_gwfa = S.n_gwfa, R->n_shortk += S.n_shortk, R->n_fast = S.n_fast;
 	GC_TICK(A, 5);
 	gc_measure(G, R);
 	GC_TICK(A, 9);
 	{ const int rc_ = gc_order_by_score(A, R); GC_TICK(A, 10); return rc_; }
 }
+GC_HD int gc_assemble(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, int32_t n_u, const uint64_t *u, gc_chain_t *c, const mg128_t *a, uint32_t hash,
+					  const char *qseq, gc_result_t *R)
+{
+	int32_t n_jobs;
+	GC_TRY(gc_assemble_begin(A, P, n_u, u, c, a, R, &n_jobs));
+	return gc_assemble_run(A, G, P, n_u, u, c, a, hash, qseq, R, 0, 0);
+}
+
 
 /* ------------------------------------------------------------------------------------------------ primary / secondary, filters */
 
@@ -1958,14 +2059,22 @@ typedef struct {
 	GC_F const char *qseq;
 } gc_read_t;
 
-/* R->a must point to a buffer for as many anchors as the chains hold.  Returns GC_OK, GC_E_ARENA (nothing usable in R), or GC_E_BUG
+/* What gc_read_p1() leaves for gc_read_p3() (next to A, rd and R, which the caller keeps) */
+typedef struct { GC_F gc_chain_t *c; GC_F uint64_t *u2; GC_F int32_t n_c; GC_F int32_t n_u2; GC_F int32_t n_jobs; GC_F int32_t done; } gc_split_t;
+
+/* One read in three parts, so that the device can give the bridges of a read -- independent GWFA calls / graph searches, most of the cycles, and what makes one read take
+ * fifty times another -- a wavefront each: (1) chain records, clean-up, anchor ranks, DP + reachability, the assembly's first half; sp->n_jobs bridges are then listed with
+ * gc_assemble_jobs() and run with gc_job_run(), in any order, anywhere; (3) assembly, measuring, ordering, parents, filters.  jobs == 0 in part 3: bridges are computed where
+ * they are met (gc_map_read(): the host, the device's large-arena retry).
+ * R->a must point to a buffer for as many anchors as the chains hold.  Returns GC_OK, GC_E_ARENA (nothing usable in R), or GC_E_BUG
  * (R holds zero chains: the reference's own bail-out paths). */
-GC_HD int gc_map_read(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, const gc_read_t *rd, gc_result_t *R)
+GC_HD int gc_read_p1(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, const gc_read_t *rd, gc_result_t *R, gc_split_t *sp)
 {
 	gc_chain_t *c = 0;
 	uint64_t *u2 = 0;
-	int32_t n_c = rd->n_u, n_u2 = 0;
+	int32_t n_c = rd->n_u, n_u2 = 0, n_jobs = 0;
 	R->n_gc = R->n_lc = R->n_a = 0, R->gc = 0, R->lc = 0, R->n_gwfa = R->n_shortk = R->n_fast = 0;
+	sp->c = 0, sp->u2 = 0, sp->n_c = sp->n_u2 = sp->n_jobs = 0, sp->done = 1;
 	if (rd->n_u <= 0) return GC_OK;
 	GC_TICK(A, 0);
 	GC_TRY(gc_make_chains(A, rd->n_u, rd->u, rd->a, &c));
@@ -1977,12 +2086,25 @@ GC_HD int gc_map_read(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, con
 	GC_TRY(gc_chain_dp(A, G, P, rd->qlen, rd->a, c, &n_c, &u2, &n_u2, &R->n_shortk));
 	GC_TICK(A, 4);
 	if (n_u2 == 0) return GC_OK;
-	GC_TRY(gc_assemble(A, G, P, n_u2, u2, c, rd->a, rd->hash, rd->qseq, R));
+	GC_TRY(gc_assemble_begin(A, P, n_u2, u2, c, rd->a, R, &n_jobs));
+	sp->c = c, sp->u2 = u2, sp->n_c = n_c, sp->n_u2 = n_u2, sp->n_jobs = n_jobs, sp->done = 0;
+	return GC_OK;
+}
+GC_HD int gc_read_p3(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, const gc_read_t *rd, gc_result_t *R, const gc_split_t *sp, const gc_job_t *jobs, const int32_t *mid_pool)
+{
+	if (sp->done) return GC_OK;
+	GC_TRY(gc_assemble_run(A, G, P, sp->n_u2, sp->u2, sp->c, rd->a, rd->hash, rd->qseq, R, jobs, mid_pool));
 	GC_TICK(A, 5);
 	for (int32_t i = 0; i < R->n_gc; ++i) R->gc[i].parent = R->gc[i].id = i, R->gc[i].subsc = R->gc[i].n_sub = R->gc[i].flt = 0;
 	GC_TRY(gc_assign_parents(A, P, R->n_gc, R->gc));
 	gc_filter_secondaries(P, R->n_gc, R->gc);
 	{ const int rc_ = gc_drop_filtered(A, R); GC_TICK(A, 6); return rc_; }
+}
+GC_HD int gc_map_read(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, const gc_read_t *rd, gc_result_t *R)
+{
+	gc_split_t sp;
+	GC_TRY(gc_read_p1(A, G, P, rd, R, &sp));
+	return gc_read_p3(A, G, P, rd, R, &sp, 0, 0);
 }
 
 #endif

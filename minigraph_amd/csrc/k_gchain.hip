@@ -86,6 +86,38 @@ __device__ __forceinline__ void gck_copy_words(void *dst, const void *src, int64
 	for (int64_t i = lane, n = bytes >> 2; i < n; i += 64) d[i] = s[i];
 }
 
+// a read's records leave its arena for the chunk's pools: one lane reserves, all 64 copy; a read that did not make it goes to the retry list
+__device__ __forceinline__ void gck_publish(const gck_out_t &out, int r, int lane, int32_t status, const gc_result_t *R, const mg128_t *res_a, long long peak)
+{
+	int32_t n_gc = 0, n_lc = 0, n_a = 0;
+	long long gc_off = 0, lc_off = 0, a_off = 0;
+	mga_gc_hdr_t *H = &out.hdr[r];
+	if (status == GC_OK) n_gc = R->n_gc, n_lc = R->n_lc, n_a = R->n_a;
+	mga_wave_sync();
+	if (lane == 0) { // one lane talks to the chunk's pools and counters
+		if (status == GC_OK) {
+			gc_off = (long long)atomicAdd(&out.ctl[1], (unsigned long long)n_gc);
+			lc_off = (long long)atomicAdd(&out.ctl[2], (unsigned long long)n_lc);
+			a_off = (long long)atomicAdd(&out.ctl[6], (unsigned long long)n_a);
+			if (gc_off + n_gc > out.gc_cap || lc_off + n_lc > out.lc_cap || a_off + n_a > out.a_cap) status = MGA_GC_E_POOL;
+			atomicAdd(&out.ctl[4], (unsigned long long)R->n_gwfa);
+			atomicAdd(&out.ctl[8], (unsigned long long)R->n_fast);
+			atomicAdd(&out.ctl[5], (unsigned long long)R->n_shortk);
+			atomicMax(&out.ctl[7], (unsigned long long)peak);
+		}
+		if (status != GC_OK) out.retry[atomicAdd(&out.ctl[3], 1ULL)] = r, n_gc = n_lc = n_a = 0;
+		H->n_gc = n_gc, H->n_lc = n_lc, H->n_a = n_a, H->status = status, H->gc_off = gc_off, H->lc_off = lc_off, H->a_off = a_off;
+	}
+	// the records leave the arena on all 64 lanes
+	status = __shfl(status, 0), n_gc = __shfl(n_gc, 0), n_lc = __shfl(n_lc, 0), n_a = __shfl(n_a, 0);
+	gc_off = __shfl(gc_off, 0), lc_off = __shfl(lc_off, 0), a_off = __shfl(a_off, 0);
+	if (status == GC_OK) {
+		gck_copy_words(out.gc_pool + gc_off, R->gc, (int64_t)n_gc * (int64_t)sizeof(gc_rec_t), lane);
+		gck_copy_words(out.lc_pool + lc_off, R->lc, (int64_t)n_lc * (int64_t)sizeof(mg_llchain_t), lane);
+		gck_copy_words(out.a_pool + a_off, res_a, (int64_t)n_a * 16, lane);
+	}
+}
+
 #ifndef GC_AB_WAVES_PER_EU
 #define GC_AB_WAVES_PER_EU 2
 #endif
@@ -140,8 +172,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GC_AB_W
 		mg128_t *res_a = (mg128_t*)gc_alloc(&A, (int64_t)n_b * 16); // anchors of the graph chains
 		if (work && res_a) gck_copy_words(work, in.b + off, (int64_t)n_b * 16, lane);
 		mga_wave_sync();
-		int32_t status = GC_E_ARENA, n_gc = 0, n_lc = 0, n_a = 0;
-		long long gc_off = 0, lc_off = 0, a_off = 0;
+		int32_t status = GC_E_ARENA;
 		R.gc = 0, R.lc = 0;
 		if (work && res_a) { // every lane runs the routine on the same values (replicated execution, gc_core.h); its hot loops are split over the lanes
 			rd.qlen = (int32_t)(in.q_off[r + 1] - in.q_off[r]), rd.hash = in.hash[r];
@@ -151,31 +182,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GC_AB_W
 			R.a = res_a;
 			status = gc_map_read(&A, &G, &P, &rd, &R);
 			if (status == GC_E_BUG) status = GC_OK, R.n_gc = R.n_lc = R.n_a = 0; // the reference's own bail-outs: the read gets no chains
-			if (status == GC_OK) n_gc = R.n_gc, n_lc = R.n_lc, n_a = R.n_a;
 		}
-		mga_wave_sync();
-		if (lane == 0) { // one lane talks to the chunk's pools and counters
-			if (status == GC_OK) {
-				gc_off = (long long)atomicAdd(&out.ctl[1], (unsigned long long)n_gc);
-				lc_off = (long long)atomicAdd(&out.ctl[2], (unsigned long long)n_lc);
-				a_off = (long long)atomicAdd(&out.ctl[6], (unsigned long long)n_a);
-				if (gc_off + n_gc > out.gc_cap || lc_off + n_lc > out.lc_cap || a_off + n_a > out.a_cap) status = MGA_GC_E_POOL;
-				atomicAdd(&out.ctl[4], (unsigned long long)R.n_gwfa);
-				atomicAdd(&out.ctl[8], (unsigned long long)R.n_fast);
-				atomicAdd(&out.ctl[5], (unsigned long long)R.n_shortk);
-				atomicMax(&out.ctl[7], (unsigned long long)A.peak);
-			}
-			if (status != GC_OK) out.retry[atomicAdd(&out.ctl[3], 1ULL)] = r, n_gc = n_lc = n_a = 0;
-			H->n_gc = n_gc, H->n_lc = n_lc, H->n_a = n_a, H->status = status, H->gc_off = gc_off, H->lc_off = lc_off, H->a_off = a_off;
-		}
-		// the records leave the arena on all 64 lanes
-		status = __shfl(status, 0), n_gc = __shfl(n_gc, 0), n_lc = __shfl(n_lc, 0), n_a = __shfl(n_a, 0);
-		gc_off = __shfl(gc_off, 0), lc_off = __shfl(lc_off, 0), a_off = __shfl(a_off, 0);
-		if (status == GC_OK) {
-			gck_copy_words(out.gc_pool + gc_off, R.gc, (int64_t)n_gc * (int64_t)sizeof(gc_rec_t), lane);
-			gck_copy_words(out.lc_pool + lc_off, R.lc, (int64_t)n_lc * (int64_t)sizeof(mg_llchain_t), lane);
-			gck_copy_words(out.a_pool + a_off, res_a, (int64_t)n_a * 16, lane);
-		}
+		gck_publish(out, r, lane, status, &R, res_a, (long long)A.peak);
 		mga_wave_sync();
 		if (out.ctl[15] && lane == 0) atomicMax(&out.ctl[16 + 15], (unsigned long long)((long long)clock64() - t_read0)); // profiling: the longest read ...
 	}
@@ -325,7 +333,36 @@ extern "C" mg_gchains_t *mga_gchain_host_read(const mg_idx_t *gi, const int32_t 
 	gc_par_from_opt(opt, gi->k, pen_gap, &P);
 	rd.qlen = qlen, rd.hash = hash, rd.n_u = n_u, rd.u = u, rd.a = a, rd.n_mini = n_mini, rd.mini_pos = mini_pos, rd.qseq = qseq;
 	R.a = (mg128_t*)malloc((size_t)(n_a > 0 ? n_a : 1) * sizeof(mg128_t));
-	int rc = gc_map_read(&A, &G, &P, &rd, &R);
+	int rc;
+	static int split_test = -1; // MGA_GC_SPLIT_TEST=1 (CPU tests): the three-part form the device runs -- part 1, the bridges as jobs in REVERSE order in an arena of their own, part 3
+	if (split_test < 0) { const char *e = getenv("MGA_GC_SPLIT_TEST"); split_test = e && atoi(e) > 0; }
+	if (!split_test) rc = gc_map_read(&A, &G, &P, &rd, &R);
+	else {
+		gc_split_t sp;
+		rc = gc_read_p1(&A, &G, &P, &rd, &R, &sp);
+		if (rc == GC_OK && !sp.done) {
+			gc_job_t *jobs = (gc_job_t*)calloc((size_t)sp.n_jobs + 1, sizeof(gc_job_t));
+			int32_t *pool = 0;
+			int64_t n_pool = 0, m_pool = 0;
+			gc_assemble_jobs(&P, sp.n_u2, sp.u2, sp.c, 0, GC_ASPAN(rd.a[0]), rd.qseq, jobs);
+			for (int32_t k = sp.n_jobs - 1; k >= 0 && rc == GC_OK; --k) {
+				gc_arena_t A2;
+				gc_bres_t b;
+				char *m2 = (char*)malloc(1 << 16);
+				gc_arena_init(&A2, m2, 1 << 16, 1);
+				rc = gc_job_run(&A2, &G, &P, &jobs[k], &b);
+				if (rc == GC_OK && jobs[k].status == GC_JOB_OK) {
+					if (n_pool + b.n_mid > m_pool) { m_pool = (n_pool + b.n_mid) * 2 + 64; pool = (int32_t*)realloc(pool, (size_t)m_pool * 4); }
+					jobs[k].mid_off = n_pool;
+					for (int32_t t = 0; t < b.n_mid; ++t) pool[n_pool++] = b.mid[t];
+				}
+				gc_arena_free_blocks(&A2);
+				free(m2);
+			}
+			if (rc == GC_OK) rc = gc_read_p3(&A, &G, &P, &rd, &R, &sp, jobs, pool);
+			free(jobs); free(pool);
+		}
+	}
 	if (rc != GC_OK) R.n_gc = R.n_lc = R.n_a = 0; // GC_E_BUG: no chains; GC_E_ARENA cannot happen on a growable arena short of malloc failing
 	mg_gchains_t *gs = mga_gchains_from_flat(R.n_gc, R.gc, R.n_lc, R.lc, R.n_a, R.a, rep_len, qlen, n_mz, opt->min_gc_score);
 	if (n_gwfa) *n_gwfa = R.n_gwfa;
