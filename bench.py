@@ -364,9 +364,12 @@ def main():
                 nl = sum(v.get("launches_fetch", 0) for v in sel)
                 if nl:
                     traffic = sum(v.get("fetch_kb", 0) + v.get("write_kb", 0) for v in sel) * 1024.0 / nl
-                    src_m = max(os.path.getmtime(os.path.join(ROOT, "minigraph_amd", "csrc", f)) for f in os.listdir(os.path.join(ROOT, "minigraph_amd", "csrc")) if f.startswith("k_wfa"))
-                    stale = os.path.getmtime(pf) < src_m   # (a profile older than the kernel sources says so: VERDICT r2 item 9)
-                    traffic_src = os.path.relpath(pf, ROOT) + " (committed rocprofv3 --pmc passes of this command, not measured in this run%s)" % ("; STALE: older than the WFA kernel sources" if stale else "")
+                    import hashlib
+                    h = hashlib.sha1()   # the profile names the WFA sources it was taken from (prof_summary.py --pmc-json); a profile of other sources says so
+                    for f in sorted(glob.glob(os.path.join(ROOT, "minigraph_amd", "csrc", "k_wfa*.hip")) + [os.path.join(ROOT, "minigraph_amd", "csrc", "wfa_window.h")]):
+                        h.update(open(f, "rb").read())
+                    stale = json.load(open(pf)).get("wfa_src_sha1") != h.hexdigest()
+                    traffic_src = os.path.relpath(pf, ROOT) + " (committed rocprofv3 --pmc passes of this command, not measured in this run%s)" % ("; STALE: taken from other WFA kernel sources than this tree's" if stale else "")
             except Exception:
                 pass
             ach = alg[dom] / (fam[dom] * 1e-3) / 1e9 if fam[dom] > 0 else 0.0

@@ -40,7 +40,12 @@ def main_pmc_json(fetch_db, write_db, source):
             k = ker.setdefault(name.split("(")[0].replace("void ", "").strip(), {})
             k[key + "_kb"] = round(k.get(key + "_kb", 0.0) + tot, 1)
             k["launches_" + key] = k.get("launches_" + key, 0) + calls
-    print(json.dumps({"source": source, "kernels": dict(sorted(ker.items()))}, indent=1))
+    import glob, hashlib, os
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    h = hashlib.sha1()   # which WFA sources the passes ran (bench.py labels the traffic figure STALE when the tree has others)
+    for f in sorted(glob.glob(os.path.join(root, "minigraph_amd", "csrc", "k_wfa*.hip")) + [os.path.join(root, "minigraph_amd", "csrc", "wfa_window.h")]):
+        h.update(open(f, "rb").read())
+    print(json.dumps({"source": source, "wfa_src_sha1": h.hexdigest(), "kernels": dict(sorted(ker.items()))}, indent=1))
 
 
 def main_sq(paths, title):
