@@ -326,23 +326,10 @@ typedef struct {
 	GC_F const int64_t *seq_off;
 } gc_graph_t;
 
-/* The graph is read-only while the kernel runs and every caller below asks with the SAME vertex in all 64 lanes: on the device such a load goes through the scalar unit
- * (a pointer made wave-uniform, into the constant address space: s_load through the scalar cache) instead of a 64-lane vector load of one address. */
-#if defined(__HIP_DEVICE_COMPILE__) && defined(GC_ULOAD)
-template<typename T> __device__ inline T gc_uload(const T *p)
-{
-	const uint64_t u = (uint64_t)p;
-	const uint64_t s = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(u >> 32)) << 32 | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)u);
-	return *(const __attribute__((address_space(4))) T*)s;
-}
-#define GC_UL(expr) gc_uload(&(expr))
-#else
-#define GC_UL(expr) (expr)
-#endif
-GC_HD const char *gc_vseq(const gc_graph_t *G, uint32_t v) { return G->es ? G->es[v].seq : ((v & 1) ? G->seq_rc : G->seq_fw) + GC_UL(G->seq_off[v >> 1]); }
-GC_HD int32_t gc_vlen(const gc_graph_t *G, uint32_t v) { return GC_UL(G->seg_len[v >> 1]); }
-GC_HD int32_t gc_n_arc(const gc_graph_t *G, uint32_t v) { return (int32_t)(uint32_t)GC_UL(G->idx[v]); }
-GC_HD const gc_arc_t *gc_arcs(const gc_graph_t *G, uint32_t v) { return G->arc + (GC_UL(G->idx[v]) >> 32); }
+GC_HD const char *gc_vseq(const gc_graph_t *G, uint32_t v) { return G->es ? G->es[v].seq : ((v & 1) ? G->seq_rc : G->seq_fw) + G->seq_off[v >> 1]; }
+GC_HD int32_t gc_vlen(const gc_graph_t *G, uint32_t v) { return G->seg_len[v >> 1]; }
+GC_HD int32_t gc_n_arc(const gc_graph_t *G, uint32_t v) { return (int32_t)(uint32_t)G->idx[v]; }
+GC_HD const gc_arc_t *gc_arcs(const gc_graph_t *G, uint32_t v) { return G->arc + (G->idx[v] >> 32); }
 
 /* ------------------------------------------------------------------------------------------------ parameters, records */
 
@@ -795,8 +782,8 @@ GC_HDN int gc_shortest_k(gc_arena_t *A, const gc_graph_t *G, uint32_t src, int32
 		const int32_t nv = gc_n_arc(G, rv);
 		const gc_arc_t *av = gc_arcs(G, rv);
 		for (int32_t i = 0; i < nv; ++i) { /* relax every arc, in arc order (shortk.c:157-188) */
-			const uint32_t w = GC_UL(av[i].w);
-			const int32_t d = rdist + (int32_t)(uint32_t)GC_UL(av[i].v_lv);
+			const uint32_t w = av[i].w;
+			const int32_t d = rdist + (int32_t)(uint32_t)av[i].v_lv;
 			if (d > max_dist) continue;
 			GC_TRY(gc_sk_vertex(A, &S, w, &slot, &absent));
 			gc_sklist_t *q = &S.tk.a[slot];
@@ -1532,8 +1519,8 @@ GC_HD int gc_gw_step(gc_arena_t *A, gc_gw_t *z, uint32_t v1, int32_t off1, int *
 			iv->vd0 = gc_mk_vd(v, d), iv->vd1 = iv->vd0 + 1;
 			GC_TRY(gc_trace_push(A, z, (int32_t)v, t.t, &tw));
 			for (int32_t j = 0; j < nv; ++j) {
-				const uint32_t w = GC_UL(av[j].w);
-				const int32_t ol = GC_UL(av[j].ow);
+				const uint32_t w = av[j].w;
+				const int32_t ol = av[j].ow;
 				int absent;
 				int32_t *dummy;
 				GC_TRY(gc_u64map_put(A, &z->seen, (uint64_t)w << 32 | (uint32_t)(qi + 1), &dummy, &absent));
