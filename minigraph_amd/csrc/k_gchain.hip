@@ -334,8 +334,8 @@ extern "C" mg_gchains_t *mga_gchain_host_read(const mg_idx_t *gi, const int32_t 
 	rd.qlen = qlen, rd.hash = hash, rd.n_u = n_u, rd.u = u, rd.a = a, rd.n_mini = n_mini, rd.mini_pos = mini_pos, rd.qseq = qseq;
 	R.a = (mg128_t*)malloc((size_t)(n_a > 0 ? n_a : 1) * sizeof(mg128_t));
 	int rc;
-	static int split_test = -1; // MGA_GC_SPLIT_TEST=1 (CPU tests): the three-part form the device runs -- part 1, the bridges as jobs in REVERSE order in an arena of their own, part 3
-	if (split_test < 0) { const char *e = getenv("MGA_GC_SPLIT_TEST"); split_test = e && atoi(e) > 0; }
+	static int split_test = -1; // MGA_GC_SPLIT_TEST=1 (CPU tests): the three-part form -- part 1, the bridges as jobs in REVERSE order in an arena of their own, part 3; =3: + the redo path of part 3
+	if (split_test < 0) { const char *e = getenv("MGA_GC_SPLIT_TEST"); split_test = e ? atoi(e) : 0; }
 	if (!split_test) rc = gc_map_read(&A, &G, &P, &rd, &R);
 	else {
 		gc_split_t sp;
@@ -359,6 +359,8 @@ extern "C" mg_gchains_t *mga_gchain_host_read(const mg_idx_t *gi, const int32_t 
 				gc_arena_free_blocks(&A2);
 				free(m2);
 			}
+			if (split_test == 3) // (tests) every bridge between NEIGHBOURING chains is reported as "no walk": part 3 must then redo it where it meets it -- the reference's bytes again
+				for (int32_t k = 0; k < sp.n_jobs; ++k) if (jobs[k].c1 == jobs[k].c0 + 1) jobs[k].status = GC_JOB_FAILED;
 			if (rc == GC_OK) rc = gc_read_p3(&A, &G, &P, &rd, &R, &sp, jobs, pool);
 			free(jobs); free(pool);
 		}

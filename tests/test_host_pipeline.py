@@ -111,17 +111,19 @@ def test_graph_chaining_core_repeats_secondaries():
 
 
 @pytest.mark.skipif(not os.path.exists(rb.REF_BIN), reason="oracle/_ref/minigraph not built")
-def test_three_part_form_of_graph_chaining_bridges_in_reverse_order():
+@pytest.mark.parametrize("level", ["1", "3"])
+def test_three_part_form_of_graph_chaining_bridges_in_reverse_order(level):
     """the device runs a read in three kernels (gc_read_p1 / a wavefront per bridge: gc_job_run / gc_read_p3, gc_core.h) because a read's bridges are independent of each other
     and of the assembly; MGA_GC_SPLIT_TEST=1 makes the HOST instantiation take the same three parts, the bridges last to first in an arena of their own: the same bytes as the
-    reference binary (a child process: the switch is read once)"""
+    reference binary (a child process: the switch is read once).  Level 3 also reports every bridge between neighbouring chains as "no walk of the chosen length", so that part 3
+    takes its redo path (the pairs in between, computed where they are met) for all of them"""
     import sys
     d = tempfile.mkdtemp()
     subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "3000000", "-H", "5", "-n", "500", "-l", "12000", "-s", "43"], stderr=subprocess.DEVNULL)
     child = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\nimport hostpipe as hp\n"
              "g, r = sys.argv[1], sys.argv[2]\nwant, occ, lco = hp.run_reference(g, r, cigar=False)\ngot, _ = hp.map_with_oracle_stages(g, r, occ, lco, cigar=False)\n"
              "print('SAME', int(got == want), len(got))\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, "-c", child, os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")], env=dict(os.environ, MGA_GC_SPLIT_TEST="1"),
+    p = subprocess.run([sys.executable, "-c", child, os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")], env=dict(os.environ, MGA_GC_SPLIT_TEST=level),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     line = [l for l in p.stdout.decode().splitlines() if l.startswith("SAME")][0].split()
