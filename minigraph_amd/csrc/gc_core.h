@@ -79,6 +79,11 @@ typedef struct gc_arena_s {
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define GC_TICK(A, id) do { if ((A)->ticks && (threadIdx.x & 63) == 0) { const long long now_ = (long long)clock64(); atomicAdd(&(A)->ticks[id], (unsigned long long)(now_ - (A)->tick_last)); (A)->tick_last = now_; } } while (0)
+#elif defined(GC_HOST_PROF) /* (host profiling aid: cycles between ticks, summed per stage into gc_host_ticks[]) */
+#include <x86intrin.h>
+static unsigned long long gc_host_ticks[16];
+static __thread unsigned long long gc_host_last;
+#define GC_TICK(A, id) do { const unsigned long long now_ = __rdtsc(); if ((id) != 0) __sync_fetch_and_add(&gc_host_ticks[id], now_ - gc_host_last); gc_host_last = now_; } while (0)
 #else
 #define GC_TICK(A, id) ((void)0)
 #endif
@@ -558,6 +563,25 @@ GC_HD int gc_clean_chains(gc_arena_t *A, const gc_par_t *P, mg128_t *a, gc_chain
 GC_HD int gc_index_anchors(mg128_t *a, int32_t n_a, const int32_t *mini_pos, int32_t n_mini)
 {
 	int bad = 0;
+#if !defined(__HIP_DEVICE_COMPILE__)
+	/* one lane: the walk the reference takes (lchain.c:431-441) -- a chain's anchors ascend on the query, so behind the first one's minimizer the two lists are walked side by
+	 * side.  A chain the walk does not get through is left to the searches below. */
+	if (n_a > 0) {
+		int32_t lo = 0, hi = n_mini - 1, st = -1;
+		const int32_t x0 = GC_AY(a[0]);
+		while (lo <= hi) { const int32_t mid = (int32_t)(((uint32_t)lo + (uint32_t)hi) >> 1), y = mini_pos[mid]; if (y < x0) lo = mid + 1; else if (y > x0) hi = mid - 1; else { st = mid; break; } }
+		if (st >= 0) {
+			int32_t k = 0, j = st; /* (ranks are written as the walk goes: the searches below only read y, and overwrite x for every anchor if the walk does not get through) */
+			while (k < n_a && j < n_mini) {
+				const int32_t y = GC_AY(a[k]), m = mini_pos[j];
+				if (y == m) a[k].x = (uint64_t)j << 32 | (a[k].x & 0xffffffffU), ++k, ++j;
+				else if (y > m) ++j;
+				else break; /* not ascending, or not a minimizer position: the searches decide */
+			}
+			if (k == n_a) return GC_OK;
+		}
+	}
+#endif
 	GC_PAR_FOR(k, n_a) {
 		const int32_t x = GC_AY(a[k]);
 		int32_t lo = 0, hi = n_mini - 1, at = -1;

@@ -374,6 +374,17 @@ extern "C" mg_gchains_t *mga_gchain_host_read(const mg_idx_t *gi, const int32_t 
 	return gs;
 }
 
+#if defined(GC_HOST_PROF) && !defined(__HIP_DEVICE_COMPILE__)
+extern "C" void mga_gc_host_prof_dump(void)
+{
+	static const char *nm[16] = { "", "records", "cleanup", "index", "dp+shortk", "assemble(rest)", "post", "", "gwfa(rest)", "measure", "order", "gw:clear", "gw:runs", "gw:heads", "gw:dedup", "" };
+	unsigned long long tot = 0;
+	for (int q = 1; q < 15; ++q) tot += gc_host_ticks[q];
+	fprintf(stderr, "[gc-host-prof] Mcycles:");
+	for (int q = 1; q < 15; ++q) if (nm[q][0]) fprintf(stderr, " %s %.1f (%.0f%%)", nm[q], gc_host_ticks[q] * 1e-6, 100.0 * gc_host_ticks[q] / (tot ? tot : 1));
+	fprintf(stderr, "\n");
+}
+#endif
 #if defined(GC_STATS) && !defined(__HIP_DEVICE_COMPILE__)
 extern "C" void mga_gc_stats_dump(void) { gc_stats_dump(); }
 #endif
