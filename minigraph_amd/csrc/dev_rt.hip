@@ -32,7 +32,8 @@ extern "C" int mga_device_count(void)
 
 extern "C" int mga_dev_init(void)
 {
-	if (g_dev_ok >= 0) return g_dev_ok ? 0 : -1;
+	if (g_dev_ok > 0) return 0;
+	if (g_dev_ok == 0) { mga_set_error("no HIP device available: the MI355X path cannot run and there is no CPU fallback"); return -1; }
 	int n = 0;
 	hipError_t e = hipGetDeviceCount(&n);
 	if (e != hipSuccess || n <= 0) {

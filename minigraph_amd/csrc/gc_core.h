@@ -1853,21 +1853,28 @@ GC_HD int gc_asm_kept(const gc_par_t *P, const uint64_t *u, const gc_chain_t *c,
 	for (int32_t j = 0; j < ni; ++j) m += c[st + j].cnt;
 	return m >= P->min_gc_cnt && (int64_t)(u[i] >> 32) >= P->min_gc_score;
 }
-/* first half of the assembly: the records, the junctions of consecutive chains made monotone (they only touch the chains of their own graph chain), and the number of bridges
- * between chains on different segments, in the order gc_assemble_run() meets them */
-GC_HD int gc_assemble_begin(gc_arena_t *A, const gc_par_t *P, int32_t n_u, const uint64_t *u, gc_chain_t *c, const mg128_t *a, gc_result_t *R, int32_t *n_jobs)
+/* first half of the assembly: which groups of the DP become graph chains, their records with score and hash -- both decided on the chains AS THE DP LEFT THEM, before any junction
+ * is touched (gchain1.c:452-456,472-484: the anchor count and the hash are taken first, resolve_overlap runs afterwards) --, then the junctions of consecutive chains made
+ * monotone (they only touch the chains of their own graph chain), and the number of bridges between chains on different segments, in the order gc_assemble_run() meets them.
+ * kept[i] != 0: group i is graph chain number kept[i] - 1. */
+GC_HD int gc_assemble_begin(gc_arena_t *A, const gc_par_t *P, int32_t n_u, const uint64_t *u, gc_chain_t *c, const mg128_t *a, uint32_t hash, gc_result_t *R, int32_t **kept_, int32_t *n_jobs)
 {
-	int32_t n_gc = 0, nj = 0;
+	int32_t n_gc = 0, nj = 0, *kept;
 	R->n_gc = R->n_lc = R->n_a = 0, R->gc = 0, R->lc = 0;
-	*n_jobs = 0;
-	for (int32_t i = 0, st = 0; i < n_u; st += (int32_t)(uint32_t)u[i], ++i) n_gc += gc_asm_kept(P, u, c, i, st);
-	R->n_gc = n_gc;
+	*n_jobs = 0, *kept_ = 0;
+	GC_ALLOC(A, int32_t, kept, n_u > 0 ? n_u : 1);
+	for (int32_t i = 0, st = 0; i < n_u; st += (int32_t)(uint32_t)u[i], ++i) kept[i] = gc_asm_kept(P, u, c, i, st) ? ++n_gc : 0;
+	R->n_gc = n_gc, *kept_ = kept;
 	if (n_gc == 0) return GC_OK;
 	GC_ALLOC(A, gc_rec_t, R->gc, n_gc);
 	memset(R->gc, 0, (size_t)n_gc * sizeof(gc_rec_t));
 	for (int32_t i = 0, st = 0; i < n_u; st += (int32_t)(uint32_t)u[i], ++i) {
 		const int32_t ni = (int32_t)(uint32_t)u[i];
-		if (!gc_asm_kept(P, u, c, i, st)) continue;
+		if (!kept[i]) continue;
+		gc_rec_t *g = &R->gc[kept[i] - 1];
+		uint32_t h = hash;
+		for (int32_t j = 0; j < ni; ++j) h += gc_hash32((uint32_t)c[st + j].qs) + gc_hash32((uint32_t)c[st + j].re) + gc_hash32(c[st + j].v);
+		g->hash = gc_hash32(h), g->score = (int32_t)(u[i] >> 32);
 		for (int32_t j = 1; j < ni; ++j) gc_untangle(&c[st + j - 1], &c[st + j], a);
 		for (int32_t j0 = 0, j = 1; j < ni; ++j) {
 			if (c[st + j].cnt <= 0) continue;
@@ -1879,12 +1886,12 @@ GC_HD int gc_assemble_begin(gc_arena_t *A, const gc_par_t *P, int32_t n_u, const
 	return GC_OK;
 }
 /* the bridges gc_assemble_begin() counted, in the same order */
-GC_HD void gc_assemble_jobs(const gc_par_t *P, int32_t n_u, const uint64_t *u, const gc_chain_t *c, int32_t read, int32_t span, const char *qseq, gc_job_t *jobs)
+GC_HD void gc_assemble_jobs(int32_t n_u, const uint64_t *u, const int32_t *kept, const gc_chain_t *c, int32_t read, int32_t span, const char *qseq, gc_job_t *jobs)
 {
 	int32_t nj = 0;
 	for (int32_t i = 0, st = 0; i < n_u; st += (int32_t)(uint32_t)u[i], ++i) {
 		const int32_t ni = (int32_t)(uint32_t)u[i];
-		if (!gc_asm_kept(P, u, c, i, st)) continue;
+		if (!kept[i]) continue;
 		for (int32_t j0 = 0, j = 1; j < ni; ++j) {
 			if (c[st + j].cnt <= 0) continue;
 			if (c[st + j].v != c[st + j0].v) {
@@ -1908,7 +1915,7 @@ GC_HD int gc_job_run(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, gc_j
 }
 /* second half: chains and walks in order (gchain1.c:409-465), measuring, ordering.  jobs == 0: every bridge is computed where it is met; otherwise the bridges between chains on
  * different segments were computed beforehand (jobs[], inner vertices in mid_pool) and are consumed in order. */
-GC_HD int gc_assemble_run(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, int32_t n_u, const uint64_t *u, gc_chain_t *c, const mg128_t *a, uint32_t hash,
+GC_HD int gc_assemble_run(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, int32_t n_u, const uint64_t *u, const int32_t *kept, gc_chain_t *c, const mg128_t *a,
 						  const char *qseq, gc_result_t *R, const gc_job_t *jobs, const int32_t *mid_pool)
 {
 	if (R->n_gc == 0) return GC_OK;
@@ -1916,15 +1923,12 @@ GC_HD int gc_assemble_run(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P,
 	memset(&S, 0, sizeof S);
 	S.a_out = R->a;
 	const int32_t span = GC_ASPAN(a[0]);
-	int32_t k = 0, jk = 0;
+	int32_t jk = 0;
 	for (int32_t i = 0, st = 0; i < n_u; st += (int32_t)(uint32_t)u[i], ++i) {
 		const int32_t ni = (int32_t)(uint32_t)u[i], n_a0 = S.n_a, n_lc0 = S.lc.n;
-		if (!gc_asm_kept(P, u, c, i, st)) continue;
-		gc_rec_t *g = &R->gc[k];
-		uint32_t h = hash;
-		g->score = (int32_t)(u[i] >> 32), g->off = n_lc0;
-		for (int32_t j = 0; j < ni; ++j) h += gc_hash32((uint32_t)c[st + j].qs) + gc_hash32((uint32_t)c[st + j].re) + gc_hash32(c[st + j].v);
-		g->hash = gc_hash32(h);
+		if (!kept[i]) continue;
+		gc_rec_t *g = &R->gc[kept[i] - 1]; /* (score and hash: gc_assemble_begin) */
+		g->off = n_lc0;
 		GC_TRY(gc_asm_chain(A, &S, &c[st], a, -1));
 		for (int32_t j0 = 0, j = 1; j < ni; ++j) {
 			if (c[st + j].cnt <= 0) continue; /* emptied by the untangling: skipped, its neighbours are bridged directly */
@@ -1944,7 +1948,6 @@ GC_HD int gc_assemble_run(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P,
 			j0 = j;
 		}
 		g->cnt = S.lc.n - n_lc0, g->n_anchor = S.n_a - n_a0;
-		++k;
 	}
 	R->n_lc = S.lc.n, R->n_a = S.n_a, R->lc = S.lc.a;
 	R->n_gwfa = S.n_gwfa, R->n_shortk += S.n_shortk, R->n_fast = S.n_fast;
@@ -1956,9 +1959,9 @@ GC_HD int gc_assemble_run(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P,
 GC_HD int gc_assemble(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, int32_t n_u, const uint64_t *u, gc_chain_t *c, const mg128_t *a, uint32_t hash,
 					  const char *qseq, gc_result_t *R)
 {
-	int32_t n_jobs;
-	GC_TRY(gc_assemble_begin(A, P, n_u, u, c, a, R, &n_jobs));
-	return gc_assemble_run(A, G, P, n_u, u, c, a, hash, qseq, R, 0, 0);
+	int32_t n_jobs, *kept;
+	GC_TRY(gc_assemble_begin(A, P, n_u, u, c, a, hash, R, &kept, &n_jobs));
+	return gc_assemble_run(A, G, P, n_u, u, kept, c, a, qseq, R, 0, 0);
 }
 
 
@@ -2071,7 +2074,7 @@ typedef struct {
 } gc_read_t;
 
 /* What gc_read_p1() leaves for gc_read_p3() (next to A, rd and R, which the caller keeps) */
-typedef struct { GC_F gc_chain_t *c; GC_F uint64_t *u2; GC_F int32_t n_c; GC_F int32_t n_u2; GC_F int32_t n_jobs; GC_F int32_t done; } gc_split_t;
+typedef struct { GC_F gc_chain_t *c; GC_F uint64_t *u2; GC_F int32_t *kept; GC_F int32_t n_c; GC_F int32_t n_u2; GC_F int32_t n_jobs; GC_F int32_t done; } gc_split_t;
 
 /* One read in three parts, so that the device can give the bridges of a read -- independent GWFA calls / graph searches, most of the cycles, and what makes one read take
  * fifty times another -- a wavefront each: (1) chain records, clean-up, anchor ranks, DP + reachability, the assembly's first half; sp->n_jobs bridges are then listed with
@@ -2083,9 +2086,9 @@ GC_HD int gc_read_p1(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, cons
 {
 	gc_chain_t *c = 0;
 	uint64_t *u2 = 0;
-	int32_t n_c = rd->n_u, n_u2 = 0, n_jobs = 0;
+	int32_t n_c = rd->n_u, n_u2 = 0, n_jobs = 0, *kept = 0;
 	R->n_gc = R->n_lc = R->n_a = 0, R->gc = 0, R->lc = 0, R->n_gwfa = R->n_shortk = R->n_fast = 0;
-	sp->c = 0, sp->u2 = 0, sp->n_c = sp->n_u2 = sp->n_jobs = 0, sp->done = 1;
+	sp->c = 0, sp->u2 = 0, sp->kept = 0, sp->n_c = sp->n_u2 = sp->n_jobs = 0, sp->done = 1;
 	if (rd->n_u <= 0) return GC_OK;
 	GC_TICK(A, 0);
 	GC_TRY(gc_make_chains(A, rd->n_u, rd->u, rd->a, &c));
@@ -2097,14 +2100,14 @@ GC_HD int gc_read_p1(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, cons
 	GC_TRY(gc_chain_dp(A, G, P, rd->qlen, rd->a, c, &n_c, &u2, &n_u2, &R->n_shortk));
 	GC_TICK(A, 4);
 	if (n_u2 == 0) return GC_OK;
-	GC_TRY(gc_assemble_begin(A, P, n_u2, u2, c, rd->a, R, &n_jobs));
-	sp->c = c, sp->u2 = u2, sp->n_c = n_c, sp->n_u2 = n_u2, sp->n_jobs = n_jobs, sp->done = 0;
+	GC_TRY(gc_assemble_begin(A, P, n_u2, u2, c, rd->a, rd->hash, R, &kept, &n_jobs));
+	sp->c = c, sp->u2 = u2, sp->kept = kept, sp->n_c = n_c, sp->n_u2 = n_u2, sp->n_jobs = n_jobs, sp->done = 0;
 	return GC_OK;
 }
 GC_HD int gc_read_p3(gc_arena_t *A, const gc_graph_t *G, const gc_par_t *P, const gc_read_t *rd, gc_result_t *R, const gc_split_t *sp, const gc_job_t *jobs, const int32_t *mid_pool)
 {
 	if (sp->done) return GC_OK;
-	GC_TRY(gc_assemble_run(A, G, P, sp->n_u2, sp->u2, sp->c, rd->a, rd->hash, rd->qseq, R, jobs, mid_pool));
+	GC_TRY(gc_assemble_run(A, G, P, sp->n_u2, sp->u2, sp->kept, sp->c, rd->a, rd->qseq, R, jobs, mid_pool));
 	GC_TICK(A, 5);
 	for (int32_t i = 0; i < R->n_gc; ++i) R->gc[i].parent = R->gc[i].id = i, R->gc[i].subsc = R->gc[i].n_sub = R->gc[i].flt = 0;
 	GC_TRY(gc_assign_parents(A, P, R->n_gc, R->gc));

@@ -64,13 +64,15 @@ int mga_graph_image_save(const gfa_t *g, const char *path)
 	for (s = 0; s < g->n_seg; ++s) nb += strlen(g->seg[s].name) + 1;
 	for (s = 0; s < g->n_sseq; ++s) sb += strlen(g->sseq[s].name) + 1;
 	names = (char*)malloc(nb + 1), snames = (char*)malloc(sb + 1);
+	if (sr == 0 || qr == 0 || off == 0 || names == 0 || snames == 0) { mga_set_error("graph image: out of memory"); fclose(fp); free(sr); free(qr); free(off); free(names); free(snames); return -1; }
 	for (s = 0, nb = 0; s < g->n_seg; ++s) {
 		const gfa_seg_t *p = &g->seg[s];
 		const size_t l = strlen(p->name) + 1;
 		sr[s].len = p->len, sr[s].snid = p->snid, sr[s].soff = p->soff, sr[s].rank = p->rank, sr[s].del_circ = (uint32_t)p->del | (uint32_t)p->circ << 16, sr[s].name_off = (uint32_t)nb;
 		memcpy(names + nb, p->name, l); nb += l;
 		off[s] = (int64_t)h.tot_seq;
-		if (p->seq) h.tot_seq += (uint64_t)p->len;
+		if (p->seq == 0 && p->len > 0) { mga_set_error("graph image: segment %s has no sequence", p->name); fclose(fp); free(sr); free(qr); free(off); free(names); free(snames); return -1; }
+		h.tot_seq += (uint64_t)p->len;
 	}
 	off[g->n_seg] = (int64_t)h.tot_seq;
 	for (s = 0, sb = 0; s < g->n_sseq; ++s) {
@@ -97,7 +99,7 @@ int mga_graph_image_save(const gfa_t *g, const char *path)
 		const gfa_seg_t *p = &g->seg[s];
 		int32_t q;
 		if (p->seq == 0 || p->len == 0) continue;
-		if ((size_t)p->len > m_buf) { m_buf = (size_t)p->len + ((size_t)p->len >> 1) + 4096; buf = (char*)realloc(buf, m_buf); }
+		if ((size_t)p->len > m_buf) { char *nbuf; m_buf = (size_t)p->len + ((size_t)p->len >> 1) + 4096; nbuf = (char*)realloc(buf, m_buf); if (nbuf == 0) goto done; buf = nbuf; }
 		for (q = 0; q < p->len; ++q) { const unsigned char c = (unsigned char)p->seq[q]; buf[q] = (char)(c - (((c >= 'a') & (c <= 'z')) << 5)); }
 		if (fwrite(buf, 1, (size_t)p->len, fp) != (size_t)p->len) goto done;
 	}
@@ -147,6 +149,43 @@ int mga_h2d_big(void *d, const void *h, size_t bytes, int n_threads)
 }
 
 /* ---- load ---- */
+/* A mapped file is untrusted input: every section must lie inside the file (overflow-safe: count * size is checked by division), the sequence offsets must ascend from 0 to
+ * tot_seq in steps of the segments' lengths, names must start inside their blocks and the blocks must end with a NUL, arcs must name vertices of the graph and the arc index
+ * must stay inside the arc array.  Returns 0 when the image can be used as it is. */
+static int sect_ok(uint64_t off, uint64_t count, uint64_t size, uint64_t file) { return off <= file && (size == 0 || count <= (file - off) / size); }
+static int image_valid(const char *base, uint64_t file)
+{
+	const img_hdr_t *h = (const img_hdr_t*)base;
+	const img_seg_t *sr;
+	const img_sseq_t *qr;
+	const int64_t *off;
+	const gfa_arc_t *arc;
+	const uint64_t *idx;
+	uint64_t s, n_vtx;
+	if (memcmp(h->magic, IMG_MAGIC, 8) != 0 || h->version != 1) return -1;
+	if (h->file_bytes > file) return -2;
+	if (h->n_seg >= 0x7fffffffULL || h->n_sseq > 0xffffffffULL || h->max_rank > 0xffffffffULL) return -2;
+	if (!sect_ok(h->off_seg, h->n_seg, sizeof(img_seg_t), file) || !sect_ok(h->off_names, h->names_bytes, 1, file) || !sect_ok(h->off_sseq, h->n_sseq, sizeof(img_sseq_t), file) ||
+		!sect_ok(h->off_snames, h->snames_bytes, 1, file) || !sect_ok(h->off_arc, h->n_arc, sizeof(gfa_arc_t), file) || !sect_ok(h->off_idx, h->n_seg * 2, 8, file) ||
+		!sect_ok(h->off_seqoff, h->n_seg + 1, 8, file) || !sect_ok(h->off_seq, h->tot_seq, 1, file) || file - h->off_seq - h->tot_seq < 64) return -3; /* (64 readable bytes behind the sequence) */
+	if ((h->off_seg | h->off_sseq | h->off_arc | h->off_idx | h->off_seqoff) & 7) return -4;
+	if (h->n_seg > 0 && (h->names_bytes == 0 || base[h->off_names + h->names_bytes - 1] != 0)) return -5;
+	if (h->n_sseq > 0 && (h->snames_bytes == 0 || base[h->off_snames + h->snames_bytes - 1] != 0)) return -5;
+	sr = (const img_seg_t*)(base + h->off_seg), qr = (const img_sseq_t*)(base + h->off_sseq), off = (const int64_t*)(base + h->off_seqoff);
+	arc = (const gfa_arc_t*)(base + h->off_arc), idx = (const uint64_t*)(base + h->off_idx);
+	if (off[0] != 0 || (uint64_t)off[h->n_seg] != h->tot_seq) return -6;
+	for (s = 0; s < h->n_seg; ++s) {
+		if (sr[s].len < 0 || off[s + 1] < off[s] || off[s + 1] - off[s] != (int64_t)sr[s].len) return -6; /* (a segment without sequence has length 0 in an image: save writes what it has) */
+		if (sr[s].name_off >= h->names_bytes) return -7;
+		if (sr[s].snid >= 0 && (uint64_t)sr[s].snid >= h->n_sseq) return -7;
+	}
+	for (s = 0; s < h->n_sseq; ++s) if (qr[s].name_off >= h->snames_bytes) return -7;
+	n_vtx = h->n_seg * 2;
+	for (s = 0; s < h->n_arc; ++s) if ((arc[s].v_lv >> 32) >= n_vtx || arc[s].w >= n_vtx) return -8;
+	for (s = 0; s < n_vtx; ++s) { const uint64_t st = idx[s] >> 32, n = (uint32_t)idx[s]; if (st > h->n_arc || n > h->n_arc - st) return -9; }
+	return 0;
+}
+
 void mga_graph_image_release(struct mg_idx_bucket_s *B)
 {
 	gfa_t *g = B->img_g;
@@ -181,15 +220,20 @@ mg_idx_t *mga_index_load_image(const char *path, const mg_idxopt_t *io, int n_th
 	double t0 = mga_wtime();
 	if (n_threads < 1) n_threads = 1;
 	mga_tables_init();
-	if (mga_dev_init() < 0) { if (fd >= 0) close(fd); return 0; }
 	if (fd < 0 || fstat(fd, &st) < 0 || (size_t)st.st_size < sizeof(img_hdr_t)) { mga_set_error("graph image: cannot open %s", path); if (fd >= 0) close(fd); return 0; }
 	base = (char*)mmap(0, (size_t)st.st_size, PROT_READ | PROT_WRITE, MAP_PRIVATE, fd, 0); /* private: nothing is written, but gfa_seg_t::seq is a char* */
 	close(fd);
 	if (base == MAP_FAILED) { mga_set_error("graph image: cannot map %s", path); return 0; }
 	h = (const img_hdr_t*)base;
-	if (memcmp(h->magic, IMG_MAGIC, 8) != 0 || h->version != 1 || h->file_bytes > (uint64_t)st.st_size || h->off_seq + h->tot_seq > (uint64_t)st.st_size) {
-		mga_set_error("graph image: %s is not a graph image of this version", path); munmap(base, (size_t)st.st_size); return 0;
+	{
+		const int why = image_valid(base, (uint64_t)st.st_size);
+		if (why != 0) {
+			if (why == -1) mga_set_error("graph image: %s is not a graph image of this version", path);
+			else mga_set_error("graph image: %s is truncated or corrupt (check %d)", path, -why);
+			munmap(base, (size_t)st.st_size); return 0;
+		}
 	}
+	if (mga_dev_init() < 0) { munmap(base, (size_t)st.st_size); return 0; } /* (after the file checks: a corrupt image is reported as such with or without a GPU) */
 	(void)madvise(base, (size_t)st.st_size, MADV_WILLNEED);
 	sr = (const img_seg_t*)(base + h->off_seg), qr = (const img_sseq_t*)(base + h->off_sseq), off = (const int64_t*)(base + h->off_seqoff);
 	g = MGA_CALLOC(gfa_t, 1);

@@ -344,7 +344,7 @@ extern "C" mg_gchains_t *mga_gchain_host_read(const mg_idx_t *gi, const int32_t 
 			gc_job_t *jobs = (gc_job_t*)calloc((size_t)sp.n_jobs + 1, sizeof(gc_job_t));
 			int32_t *pool = 0;
 			int64_t n_pool = 0, m_pool = 0;
-			gc_assemble_jobs(&P, sp.n_u2, sp.u2, sp.c, 0, GC_ASPAN(rd.a[0]), rd.qseq, jobs);
+			gc_assemble_jobs(sp.n_u2, sp.u2, sp.kept, sp.c, 0, GC_ASPAN(rd.a[0]), rd.qseq, jobs);
 			for (int32_t k = sp.n_jobs - 1; k >= 0 && rc == GC_OK; --k) {
 				gc_arena_t A2;
 				gc_bres_t b;
@@ -461,6 +461,38 @@ extern "C" int32_t mga_gwfa_bridge(const gfa_t *g, const gfa_edseq_t *es, int32_
 	gc_arena_free_blocks(&A);
 	free(first); free(seg_len);
 	return ed;
+}
+
+// the assembly alone (mg_gchain_gen, gchain1.c:443-520: records, junctions, bridges, measuring, ordering) from given chain records: CPU parity tests against the reference's function
+extern "C" mg_gchains_t *mga_gchain_gen_host(const gfa_t *g, const gfa_edseq_t *es, int32_t n_u, const uint64_t *u, const mg_lchain_t *lc, const mg128_t *a, int32_t n_a, uint32_t hash,
+											 int32_t min_gc_cnt, int32_t min_gc_score, int32_t gdp_max_ed, const char *qseq, int32_t *rc_out)
+{
+	gc_arena_t A;
+	gc_graph_t G;
+	gc_par_t P;
+	gc_result_t R;
+	int32_t n_c = 0;
+	for (int32_t i = 0; i < n_u; ++i) n_c += (int32_t)(uint32_t)u[i];
+	int32_t *seg_len = gc_host_seg_len(g);
+	gc_arena_init(&A, malloc(1 << 16), 1 << 16, 1);
+	char *first = A.base;
+	memset(&G, 0, sizeof G); memset(&P, 0, sizeof P); memset(&R, 0, sizeof R);
+	G.arc = (const gc_arc_t*)g->arc, G.idx = g->idx, G.seg_len = seg_len, G.es = es;
+	P.min_gc_cnt = min_gc_cnt, P.min_gc_score = min_gc_score, P.gdp_max_ed = gdp_max_ed;
+	gc_chain_t *c = (gc_chain_t*)calloc((size_t)n_c + 1, sizeof(gc_chain_t));
+	for (int32_t i = 0; i < n_c; ++i) {
+		c[i].off = lc[i].off, c[i].cnt = lc[i].cnt, c[i].v = lc[i].v, c[i].rs = lc[i].rs, c[i].re = lc[i].re, c[i].qs = lc[i].qs, c[i].qe = lc[i].qe, c[i].score = lc[i].score;
+		c[i].dist_pre = lc[i].dist_pre, c[i].hash_pre = lc[i].hash_pre, c[i].inner_pre = lc[i].inner_pre;
+	}
+	R.a = (mg128_t*)malloc((size_t)(n_a > 0 ? n_a : 1) * sizeof(mg128_t));
+	int rc = gc_assemble(&A, &G, &P, n_u, u, c, a, hash, qseq, &R);
+	if (rc_out) *rc_out = rc;
+	if (rc != GC_OK) R.n_gc = R.n_lc = R.n_a = 0;
+	mg_gchains_t *gs = mga_gchains_from_flat(R.n_gc, R.gc, R.n_lc, R.lc, R.n_a, R.a, 0, 100, 10, min_gc_score);
+	free(R.a); free(c);
+	gc_arena_free_blocks(&A);
+	free(first); free(seg_len);
+	return gs;
 }
 
 extern "C" void mg_gchain_free(mg_gchains_t *gs) // mgpriv.h:101 / gchain1.c:522-535: everything is malloc-owned (km == NULL)

@@ -43,9 +43,10 @@ def gather_bytes(payload, dst=0, device="cpu", as_tensors=False, pin=False):
     mx = max(max(sizes), 1)
     buf = torch.empty(mx, dtype=torch.uint8, device=device)
     if src.size:
+        copied = False
         if not src.flags.writeable:
-            src = src.copy()  # torch.from_numpy wants a writable array (bytes objects are not)
-        if device != "cpu" and pin:
+            src, copied = src.copy(), True  # torch.from_numpy wants a writable array (bytes objects are not)
+        if device != "cpu" and pin and not copied:   # (never register a numpy-owned temporary: `pin` carries the LIBRARY buffer's capacity and lifetime)
             _pin_for_dma(src, pin)   # page-lock the library's (reused) output buffer once: the upload then runs at DMA speed instead of through a bounce buffer
         buf[:src.size].copy_(torch.from_numpy(src), non_blocking=False)
     out = [torch.empty(mx, dtype=torch.uint8, device=device) for _ in range(world)] if rank == dst else None

@@ -71,3 +71,81 @@ def test_no_gpu_fails_loudly():
         assert "no HIP device" in str(e) or "failed" in str(e)
     else:
         raise AssertionError("sketch_batch succeeded without a GPU")
+
+
+def test_graph_image_loader_rejects_truncated_and_corrupt_files(tmp_path):
+    """the image loader maps a file and used to trust every offset / count in it.  Every section must lie inside the file, the sequence offsets must
+    match the segment lengths, names must be terminated, arcs must name vertices of the graph.  (The checks run before the device is touched: CPU test.)"""
+    import struct
+    import ctypes as C
+    import numpy as np
+    L = mga.load()
+    gfa = tmp_path / "g.gfa"
+    rng = np.random.default_rng(2)
+    with open(gfa, "w") as f:
+        for s in range(3):
+            f.write("S\ts%d\t%s\tSN:Z:chr1\tSO:i:%d\tSR:i:0\n" % (s, "".join(rng.choice(list("ACGT"), 500 + 100 * s)), 1000 * s))
+        f.write("L\ts0\t+\ts1\t+\t0M\nL\ts1\t+\ts2\t+\t0M\n")
+    L.gfa_read.restype = C.c_void_p
+    L.gfa_read.argtypes = [C.c_char_p]
+    g = L.gfa_read(str(gfa).encode())
+    assert g
+    L.mga_graph_image_save.argtypes = [C.c_void_p, C.c_char_p]
+    img = tmp_path / "g.mgi"
+    assert L.mga_graph_image_save(g, str(img).encode()) == 0
+    good = bytearray(open(img, "rb").read())
+    L.mga_index_load_image.restype = C.c_void_p
+    L.mga_index_load_image.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.mga_last_error.restype = C.c_char_p
+    io, mo, go = mga.idxopt_t(), mga.mapopt_t(), mga.ggopt_t()
+    L.mg_opt_set(None, C.byref(io), C.byref(mo), C.byref(go))
+    # header: magic 8, version 4, pad 4, then 5 counts (n_seg n_sseq n_arc max_rank tot_seq) and 11 offsets / sizes, all uint64
+    names = ["n_seg", "n_sseq", "n_arc", "max_rank", "tot_seq", "off_seg", "off_names", "names_bytes", "off_sseq", "off_snames", "snames_bytes", "off_arc", "off_idx",
+             "off_seqoff", "off_seq", "file_bytes"]
+    hdr = dict(zip(names, struct.unpack_from("<16Q", good, 16)))
+
+    def attempt(buf, label):
+        p = tmp_path / ("bad_%s.mgi" % label)
+        open(p, "wb").write(bytes(buf))
+        gi = L.mga_index_load_image(str(p).encode(), C.byref(io), 2, C.byref(mo))
+        msg = L.mga_last_error().decode()
+        assert not gi, label
+        return msg
+
+    def patched(field, value):
+        b = bytearray(good)
+        struct.pack_into("<Q", b, 16 + 8 * names.index(field), value)
+        return b
+
+    assert "not a graph image" in attempt(b"\0" * 4096, "zeros")
+    for label, buf in [
+        ("truncated", good[:len(good) // 2]),
+        ("n_seg_huge", patched("n_seg", 1 << 40)),
+        ("n_arc_wrap", patched("n_arc", (1 << 64) // 32 + 1)),           # count * size wraps in 64 bits
+        ("off_seq_wrap", patched("off_seq", (1 << 64) - 8)),             # off_seq + tot_seq wraps
+        ("off_arc_out", patched("off_arc", len(good) + 64)),
+        ("off_idx_out", patched("off_idx", len(good) - 8)),
+        ("tot_seq_short", patched("tot_seq", hdr["tot_seq"] - 1)),       # offsets no longer end at tot_seq
+        ("names_short", patched("names_bytes", hdr["names_bytes"] - 1)), # last name not terminated
+    ]:
+        msg = attempt(buf, label)
+        assert "truncated or corrupt" in msg, (label, msg)
+    b = bytearray(good)   # a segment record whose length disagrees with the sequence offsets
+    struct.pack_into("<i", b, hdr["off_seg"], 1 << 30)
+    assert "truncated or corrupt" in attempt(b, "seg_len")
+    b = bytearray(good)   # a name offset outside the name block
+    struct.pack_into("<I", b, hdr["off_seg"] + 20, 1 << 20)
+    assert "truncated or corrupt" in attempt(b, "name_off")
+    b = bytearray(good)   # an arc to a vertex the graph does not have
+    struct.pack_into("<I", b, hdr["off_arc"] + 8, 1000)
+    assert "truncated or corrupt" in attempt(b, "arc_w")
+    b = bytearray(good)   # an arc-index entry that runs past the arc array
+    struct.pack_into("<Q", b, hdr["off_idx"], (0 << 32) | 1000)
+    assert "truncated or corrupt" in attempt(b, "idx_cnt")
+    # the untouched image passes the file checks: on a box without a GPU the failure is the device's
+    gi = L.mga_index_load_image(str(img).encode(), C.byref(io), 2, C.byref(mo))
+    if not gi:
+        assert "corrupt" not in L.mga_last_error().decode() and "not a graph image" not in L.mga_last_error().decode()
+    else:
+        L.mg_idx_destroy.argtypes = [C.c_void_p]
+        L.mg_idx_destroy(gi)
