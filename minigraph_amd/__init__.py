@@ -62,7 +62,7 @@ MG_M_CIGAR = 0x4000000
 
 KERNELS = ["k_sketch", "k_seed_count", "k_seed_fill", "k_lchain", "k_wfa_r[64]", "k_wfa_r[128]", "k_wfa_r[192]", "k_wfa_r[256]", "k_wfa_r[512]",
            "k_wfa_r[1024]", "k_wfa_r[2048]", "k_wfa[hbm4096]", "k_wfa[hbm32768]", "k_scan", "k_text", "k_gchain", "k_plan",
-           "k_wfa_w[16x4]", "k_wfa_w[32x2]", "k_wfa_w[64]", "k_wfa_w[128]", "k_wfa_w[192]", "k_wfa_w[256]", "k_wfa_tb"]
+           "k_wfa_w[16x4]", "k_wfa_w[32x2]", "k_wfa_w[64]", "k_wfa_w[128]", "k_wfa_w[192]", "k_wfa_w[256]", "k_wfa_tb", "k_gchain_p2", "k_gchain_p3"]
 
 
 class stats_t(C.Structure):  # mga_stats_t

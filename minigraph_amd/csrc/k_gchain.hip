@@ -12,6 +12,7 @@
 //
 // The same source runs on the host (mga_gchain_host_read below: -x asm where the chainer is host code, and the CPU parity tests).
 #include <stdio.h>
+#include <unistd.h>
 #include <math.h>
 #include "mga_dev.h"
 #include "dev_common.h"
@@ -190,6 +191,275 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GC_AB_W
 	if (out.ctl[15] && lane == 0) atomicMax(&out.ctl[16 + 7], (unsigned long long)((long long)clock64() - t_wave0)); // ... and the longest wavefront of the launch
 }
 
+// ---- the three-kernel form: a read's bridges on wavefronts of their own -------------------------------------------------------------------------
+// k_gchain lasts as long as its longest read, and what makes one read take fifty times another are its bridges: independent GWFA calls / graph searches
+// (gc_job_run) that depend on two chain records, the graph and the query only.  So a chunk goes through three launches on its stream:
+//   k_gchain_p1  a wavefront per read: chain records, clean-up, minimizer ranks, DP + reachability, the assembly's first half (gc_read_p1).  A read that ends up
+//                with graph chains leaves its state -- anchors with flags and ranks, chain records, the DP's grouping, the graph-chain records with score and
+//                hash -- as ONE block in the chunk's state pool, written by a copy at the END of its turn, and lists its bridges in the chunk's job array;
+//   k_gchain_p2  a wavefront per bridge, longest query gaps first: gc_job_run in a scratch arena, the walk's inner vertices into the chunk's vertex pool;
+//   k_gchain_p3  a wavefront per read of the state pool: the assembly's second half consuming the bridges in order, measuring, ordering, parents, filters
+//                (gc_read_p3), records published to the chunk's pools exactly as k_gchain does.
+// Nothing is read across a launch boundary that was not written by a block copy at the end of the previous launch's turn (the pattern k_gchain -> k_plan already
+// relies on); every wavefront works in its own scratch arena, as in the one-kernel form.  A read that runs out of arena / pool room in any part goes to the retry
+// list and is redone by k_gchain in a large arena.
+struct gcs_hdr_t { // a read's state between the parts: 64 bytes, followed by a[n_b] | c[n_c] | u2[n_u2] | kept[n_u2] | gc[n_gc], each padded to 16 bytes
+	int32_t read, n_b, n_c, n_u2, n_gc, n_jobs, n_shortk, span;
+	int64_t job0, bytes;
+	int64_t pad_[2];
+};
+static_assert(sizeof(gcs_hdr_t) == 64, "gcs_hdr_t");
+struct gck_split_t {
+	char *state; int64_t state_cap;            // state pool (bytes)
+	int64_t *p3list;                           // offsets of the states, in the order part 1 finished them
+	gc_job_t *jobs; int64_t jobs_cap;
+	int32_t *mid; int64_t mid_cap;             // inner vertices of the bridges' walks
+	unsigned long long *sctl;                  // [0] state bytes used, [1] jobs listed, [2] vertices used, [3] states listed, [4] next state of part 3, [8..11] next job of part 2 per length class
+};
+#define GCS_A16(x) (((int64_t)(x) + 15) & ~(int64_t)15)
+#define GCS_N_CLASS 3
+struct gcs_view_t { gcs_hdr_t *h; mg128_t *a; gc_chain_t *c; uint64_t *u2; int32_t *kept; gc_rec_t *gc; int64_t bytes; };
+// where the arrays of a block with these counts lie (one definition for the writer, the readers and the host's emulation of the hand-over)
+__host__ __device__ inline void gcs_view(char *blk, int32_t n_b, int32_t n_c, int32_t n_u2, int32_t n_gc, gcs_view_t *v)
+{
+	const int64_t o_a = (int64_t)sizeof(gcs_hdr_t), o_c = o_a + (int64_t)n_b * 16, o_u = o_c + GCS_A16((int64_t)n_c * (int64_t)sizeof(gc_chain_t)), o_k = o_u + GCS_A16((int64_t)n_u2 * 8),
+				  o_g = o_k + GCS_A16((int64_t)n_u2 * 4);
+	v->h = (gcs_hdr_t*)blk, v->a = (mg128_t*)(blk + o_a), v->c = (gc_chain_t*)(blk + o_c), v->u2 = (uint64_t*)(blk + o_u), v->kept = (int32_t*)(blk + o_k), v->gc = (gc_rec_t*)(blk + o_g);
+	v->bytes = o_g + GCS_A16((int64_t)n_gc * (int64_t)sizeof(gc_rec_t));
+}
+__host__ __device__ inline void gcs_copy_words(void *dst, const void *src, int64_t bytes, int lane, int n_lane) // both 4-byte aligned
+{
+	uint32_t *d = (uint32_t*)dst;
+	const uint32_t *s = (const uint32_t*)src;
+	for (int64_t i = lane, n = bytes >> 2; i < n; i += n_lane) d[i] = s[i];
+}
+// part 1's state into the block (arrays by all lanes; the header by the caller's lane 0 once the arrays are visible)
+__host__ __device__ inline void gcs_write_arrays(const gcs_view_t *v, int32_t n_b, const mg128_t *work, const gc_split_t *sp, const gc_result_t *R, int lane, int n_lane)
+{
+	gcs_copy_words(v->a, work, (int64_t)n_b * 16, lane, n_lane);
+	gcs_copy_words(v->c, sp->c, (int64_t)sp->n_c * (int64_t)sizeof(gc_chain_t), lane, n_lane);
+	gcs_copy_words(v->u2, sp->u2, (int64_t)sp->n_u2 * 8, lane, n_lane);
+	gcs_copy_words(v->kept, sp->kept, (int64_t)sp->n_u2 * 4, lane, n_lane);
+	gcs_copy_words(v->gc, R->gc, (int64_t)R->n_gc * (int64_t)sizeof(gc_rec_t), lane, n_lane);
+}
+__host__ __device__ inline void gcs_write_header(const gcs_view_t *v, int32_t read, int32_t n_b, const gc_split_t *sp, const gc_result_t *R, int64_t job0)
+{
+	gcs_hdr_t *h = v->h;
+	h->read = read, h->n_b = n_b, h->n_c = sp->n_c, h->n_u2 = sp->n_u2, h->n_gc = R->n_gc, h->n_jobs = sp->n_jobs, h->n_shortk = R->n_shortk, h->span = GC_ASPAN(v->a[0]);
+	h->job0 = job0, h->bytes = v->bytes, h->pad_[0] = h->pad_[1] = 0;
+}
+// what part 3 starts from: the read's arrays in the block, records to be completed in place, anchors of the graph chains into res_a
+__host__ __device__ inline void gcs_setup_p3(char *blk, mg128_t *res_a, gc_read_t *rd, gc_result_t *R, gc_split_t *sp)
+{
+	gcs_view_t v;
+	const gcs_hdr_t *h = (const gcs_hdr_t*)blk;
+	gcs_view(blk, h->n_b, h->n_c, h->n_u2, h->n_gc, &v);
+	rd->a = v.a; // (part 3 only reads the anchors)
+	R->n_gc = h->n_gc, R->n_lc = R->n_a = 0, R->gc = v.gc, R->lc = 0, R->a = res_a, R->n_gwfa = R->n_fast = 0, R->n_shortk = h->n_shortk;
+	sp->c = v.c, sp->u2 = v.u2, sp->kept = v.kept, sp->n_c = h->n_c, sp->n_u2 = h->n_u2, sp->n_jobs = h->n_jobs, sp->done = 0;
+}
+__device__ __forceinline__ int gcs_job_class(const gc_job_t *q) { const int32_t ql = (q->c1->qs + q->span) - (q->c0->qe - q->span); return ql >= 1200 ? 0 : ql >= 300 ? 1 : 2; } // query gap of the bridge
+
+// A value every lane holds alike, as a SCALAR: branches on it are scalar branches.  The persistent loops below fetch their work with one lane's atomic; when the fetched index
+// stayed a per-lane value (__shfl), the compiler treated every `continue` / `break` of the loop as divergent and restructured it into nested exec-mask loops -- [measured, round 4]
+// in k_gchain_p1 the path of an early `continue` then came back WITHOUT a new fetch (the launch never ended on workloads with chain-less reads).
+__device__ __forceinline__ int32_t gck_uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long gck_uni64(long long v) { const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)((unsigned long long)v >> 32)); return (long long)((unsigned long long)hi << 32 | lo); }
+// The launch parameters (several hundred bytes of pointers and sizes) are copied to LDS at the start and read from there: as kernel arguments they are all loaded into scalar
+// registers up front and stay live across the whole routine -- [measured, round 4] 130-430 spilled SGPRs per kernel, and a part-1 wavefront that took an early `continue`
+// never fetched its next read (workloads with chain-less reads hung the launch).
+#define GCK_ARGS_TO_LDS(has_io, has_split) GCK_ARGS_TO_LDS_##has_io
+#define GCK_ARGS_TO_LDS_1 __shared__ gck_in_t in_lds_; __shared__ gck_out_t out_lds_; __shared__ gck_split_t S_lds_; in_lds_ = in_arg, out_lds_ = out_arg, S_lds_ = S_arg; \
+	const gck_in_t &in = in_lds_; const gck_out_t &out = out_lds_; const gck_split_t &S = S_lds_
+#define GCK_ARGS_TO_LDS_0 __shared__ gck_split_t S_lds_; S_lds_ = S_arg; const gck_split_t &S = S_lds_
+#ifndef GC_AB_P1_WAVES
+#define GC_AB_P1_WAVES 2
+#endif
+#ifndef GC_AB_P2_WAVES
+#define GC_AB_P2_WAVES 2
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GC_AB_P1_WAVES, 8))) k_gchain_p1(gck_in_t in_arg, gck_out_t out_arg, gck_split_t S_arg, gc_graph_t G_arg, gc_par_t P_arg, char *arena_mem, int64_t arena_bytes)
+{
+	GCK_ARGS_TO_LDS(1, 1);
+	const int lane = threadIdx.x;
+	char *my_arena = arena_mem + (int64_t)blockIdx.x * arena_bytes;
+	__shared__ gc_graph_t G_lds;
+	__shared__ gc_par_t P_lds;
+	__shared__ gc_arena_t A_lds;
+	__shared__ gc_read_t rd_lds;
+	__shared__ gc_result_t R_lds;
+	__shared__ gc_split_t sp_lds;
+	G_lds = G_arg, P_lds = P_arg;
+	mga_wave_sync();
+	const gc_graph_t &G = G_lds;
+	const gc_par_t &P = P_lds;
+	gc_arena_t &A = A_lds;
+	gc_read_t &rd = rd_lds;
+	gc_result_t &R = R_lds;
+	gc_split_t &sp = sp_lds;
+	for (;;) { // (one way through the body, no early `continue`: see gck_uni above)
+		int slot = 0;
+		if (lane == 0) slot = (int)atomicAdd(&out.ctl[0], 1ULL);
+		slot = gck_uni(slot);
+		if (slot >= gck_uni(in.n)) break;
+		const int r = gck_uni(in.list ? in.list[slot] : slot);
+		const int64_t off = gck_uni64(in.a_off[r]);
+		const int32_t n_u = gck_uni(in.nu[r]), n_b = gck_uni(in.nb[r]);
+		int32_t none_status = GC_OK, none_shortk = 0; // what the read's header says when it leaves no state behind
+		int save = 0;
+		mg128_t *work = 0;
+		if (gck_uni(in.rflag && in.rflag[r] == 2)) none_status = MGA_GC_HOST; // its chains come from the host tree, not from here
+		else if (n_u > 0 && n_b > 0) {
+			gc_arena_init(&A, my_arena, arena_bytes, 0);
+			if (out.ctl[15]) A.ticks = out.ctl + 16, A.tick_last = (long long)clock64();
+			work = (mg128_t*)gc_alloc(&A, (int64_t)n_b * 16); // the chains' anchors: flags and minimizer ranks are written into this copy
+			if (gck_uni(work == 0)) none_status = GC_E_ARENA;
+			else {
+				gck_copy_words(work, in.b + off, (int64_t)n_b * 16, lane);
+				mga_wave_sync();
+				rd.qlen = (int32_t)(in.q_off[r + 1] - in.q_off[r]), rd.hash = in.hash[r];
+				rd.n_u = n_u, rd.u = in.u + off, rd.a = work;
+				rd.n_mini = (int32_t)(in.mini_off[r + 1] - in.mini_off[r]), rd.mini_pos = in.mini + in.mini_off[r];
+				rd.qseq = in.seq + in.q_off[r];
+				R.gc = 0, R.lc = 0, R.a = 0;
+				const int32_t status = gck_uni(gc_read_p1(&A, &G, &P, &rd, &R, &sp));
+				if (lane == 0) atomicMax(&out.ctl[7], (unsigned long long)A.peak);
+				if (status == GC_E_BUG) none_shortk = gck_uni(R.n_shortk);          // the reference's own bail-outs: the read gets no chains
+				else if (status != GC_OK) none_status = status;                      // out of arena: the retry list
+				else if (gck_uni(sp.done || R.n_gc == 0)) none_shortk = gck_uni(R.n_shortk);
+				else save = 1;
+			}
+		}
+		if (save) { // ---- the state leaves the arena as one block ----
+			const int32_t n_jobs = gck_uni(sp.n_jobs);
+			gcs_view_t v;
+			gcs_view(0, n_b, sp.n_c, sp.n_u2, R.n_gc, &v); // (sizes first)
+			const int64_t bytes = v.bytes;
+			long long s_off = 0, job0 = 0, pos = 0;
+			int ok = 1;
+			if (lane == 0) {
+				s_off = (long long)atomicAdd(&S.sctl[0], (unsigned long long)bytes);
+				job0 = (long long)atomicAdd(&S.sctl[1], (unsigned long long)n_jobs);
+				ok = s_off + bytes <= S.state_cap && job0 + n_jobs <= S.jobs_cap;
+				if (ok) pos = (long long)atomicAdd(&S.sctl[3], 1ULL);
+			}
+			ok = gck_uni(ok), s_off = gck_uni64(s_off), job0 = gck_uni64(job0), pos = gck_uni64(pos);
+			if (!ok) none_status = MGA_GC_E_POOL, save = 0;
+			else {
+				char *blk = S.state + s_off;
+				gcs_view(blk, n_b, sp.n_c, sp.n_u2, R.n_gc, &v);
+				gcs_write_arrays(&v, n_b, work, &sp, &R, lane, 64);
+				mga_wave_sync();
+				if (lane == 0) {
+					gcs_write_header(&v, r, n_b, &sp, &R, job0);
+					S.p3list[pos] = s_off;
+					if (n_jobs > 0) gc_assemble_jobs(sp.n_u2, v.u2, v.kept, v.c, r, v.h->span, rd.qseq, S.jobs + job0); // the bridges, pointing into the block's copy of the chain records
+				}
+			}
+		}
+		if (!save && lane == 0) { // header of a read without graph chains, or of one that goes to the host / to the retry list
+			mga_gc_hdr_t *H = &out.hdr[r];
+			if (none_status != GC_OK && none_status != MGA_GC_HOST) out.retry[atomicAdd(&out.ctl[3], 1ULL)] = r;
+			else if (none_shortk) atomicAdd(&out.ctl[5], (unsigned long long)none_shortk);
+			H->n_gc = H->n_lc = H->n_a = 0, H->status = none_status, H->gc_off = H->lc_off = H->a_off = 0;
+		}
+		mga_wave_sync();
+	}
+}
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GC_AB_P2_WAVES, 8))) k_gchain_p2(gck_split_t S_arg, gc_graph_t G_arg, gc_par_t P_arg, char *arena_mem, int64_t arena_bytes, unsigned long long *ctl)
+{
+	GCK_ARGS_TO_LDS(0, 1);
+	const int lane = threadIdx.x;
+	char *my_arena = arena_mem + (int64_t)blockIdx.x * arena_bytes;
+	__shared__ gc_graph_t G_lds;
+	__shared__ gc_par_t P_lds;
+	__shared__ gc_arena_t A_lds;
+	G_lds = G_arg, P_lds = P_arg;
+	mga_wave_sync();
+	const gc_graph_t &G = G_lds;
+	const gc_par_t &P = P_lds;
+	gc_arena_t &A = A_lds;
+	long long n_jobs = gck_uni64((long long)S.sctl[1]);
+	if (n_jobs > S.jobs_cap) n_jobs = gck_uni64(S.jobs_cap);
+	for (int cls = 0; cls < GCS_N_CLASS; ++cls) { // long query gaps first: the launch ends with the short ones
+		const int quantum = cls == 0 ? 64 : cls == 1 ? 16 : 4; // jobs looked at per reservation (a class's jobs are a fraction of them; the last class must not hand a wavefront a long run)
+		for (;;) {
+			long long base = 0;
+			if (lane == 0) base = (long long)atomicAdd(&S.sctl[8 + cls], (unsigned long long)quantum);
+			base = gck_uni64(base);
+			if (base >= n_jobs) break;
+			uint64_t todo = __ballot(lane < quantum && base + lane < n_jobs && gcs_job_class(&S.jobs[base + lane]) == cls);
+			while (todo) {
+				gc_job_t *q = &S.jobs[base + (__ffsll((long long)todo) - 1)];
+				todo &= todo - 1;
+				gc_bres_t b;
+				gc_arena_init(&A, my_arena, arena_bytes, 0);
+				if (ctl[15]) A.ticks = ctl + 16, A.tick_last = (long long)clock64();
+				gc_job_run(&A, &G, &P, q, &b); // (its status lands in the job)
+				int32_t st = gck_uni(q->status);
+				if (st == GC_JOB_OK && gck_uni(b.n_mid) > 0) {
+					long long mo = 0;
+					if (lane == 0) mo = (long long)atomicAdd(&S.sctl[2], (unsigned long long)b.n_mid);
+					mo = gck_uni64(mo);
+					if (mo + b.n_mid > S.mid_cap) st = GC_JOB_ARENA;
+					else { gck_copy_words(S.mid + mo, b.mid, (int64_t)b.n_mid * 4, lane); if (lane == 0) q->mid_off = mo; }
+				}
+				if (lane == 0) { q->status = st; atomicMax(&ctl[7], (unsigned long long)A.peak); }
+				mga_wave_sync();
+			}
+		}
+	}
+}
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GC_AB_WAVES_PER_EU, 8))) k_gchain_p3(gck_in_t in_arg, gck_out_t out_arg, gck_split_t S_arg, gc_graph_t G_arg, gc_par_t P_arg, char *arena_mem, int64_t arena_bytes)
+{
+	GCK_ARGS_TO_LDS(1, 1);
+	const int lane = threadIdx.x;
+	char *my_arena = arena_mem + (int64_t)blockIdx.x * arena_bytes;
+	__shared__ gc_graph_t G_lds;
+	__shared__ gc_par_t P_lds;
+	__shared__ gc_arena_t A_lds;
+	__shared__ gc_read_t rd_lds;
+	__shared__ gc_result_t R_lds;
+	__shared__ gc_split_t sp_lds;
+	G_lds = G_arg, P_lds = P_arg;
+	mga_wave_sync();
+	const gc_graph_t &G = G_lds;
+	const gc_par_t &P = P_lds;
+	gc_arena_t &A = A_lds;
+	gc_read_t &rd = rd_lds;
+	gc_result_t &R = R_lds;
+	gc_split_t &sp = sp_lds;
+	const long long n_state = gck_uni64((long long)S.sctl[3]);
+	for (;;) {
+		long long k = 0;
+		if (lane == 0) k = (long long)atomicAdd(&S.sctl[4], 1ULL);
+		k = gck_uni64(k);
+		if (k >= n_state) break;
+		char *blk = S.state + gck_uni64(S.p3list[k]);
+		const gcs_hdr_t *h = (const gcs_hdr_t*)blk;
+		const int r = gck_uni(h->read);
+		gc_arena_init(&A, my_arena, arena_bytes, 0);
+		if (out.ctl[15]) A.ticks = out.ctl + 16, A.tick_last = (long long)clock64();
+		mg128_t *res_a = (mg128_t*)gc_alloc(&A, (int64_t)h->n_b * 16); // anchors of the graph chains
+		int32_t status = GC_E_ARENA;
+		R.gc = 0, R.lc = 0;
+		if (res_a) {
+			rd.qlen = (int32_t)(in.q_off[r + 1] - in.q_off[r]), rd.hash = in.hash[r];
+			rd.n_u = in.nu[r], rd.u = in.u + in.a_off[r];
+			rd.n_mini = (int32_t)(in.mini_off[r + 1] - in.mini_off[r]), rd.mini_pos = in.mini + in.mini_off[r];
+			rd.qseq = in.seq + in.q_off[r];
+			gcs_setup_p3(blk, res_a, &rd, &R, &sp);
+			mga_wave_sync();
+			status = gc_read_p3(&A, &G, &P, &rd, &R, &sp, S.jobs + h->job0, S.mid);
+			if (status == GC_E_BUG) status = GC_OK, R.n_gc = R.n_lc = R.n_a = 0;
+		}
+		gck_publish(out, r, lane, status, &R, res_a, (long long)A.peak);
+		mga_wave_sync();
+	}
+}
+
 extern "C" size_t mga_dev_gchain_arena_bytes(int tier)
 { // MGA_GC_ARENA_KB / MGA_GC_ARENA1_KB: scratch per wavefront of the first launch / of the retry launch (tests: small values push reads through the retry and on to the host)
 	const char *e = getenv(tier == 0 ? "MGA_GC_ARENA_KB" : "MGA_GC_ARENA1_KB");
@@ -234,13 +504,50 @@ extern "C" int mga_dev_gchain(mga_sctx_t *sc, const mga_didx_t *ix, const mg_map
 	memset(&G, 0, sizeof G);
 	G.arc = (const gc_arc_t*)ix->d_arc, G.idx = ix->d_arc_idx, G.seg_len = ix->d_seg_len, G.es = 0, G.seq_fw = ix->d_gseq, G.seq_rc = ix->d_gseq_rc, G.seq_off = ix->d_gseq_off;
 	gc_par_from_opt(opt, k, pen_gap, &P);
+	static int split = -1; // MGA_GC_SPLIT=0: the one-kernel form for the first launch as well
+	if (split < 0) { const char *e = getenv("MGA_GC_SPLIT"); split = e ? atoi(e) : 1; }
+	if (tier == 0 && d_list == 0 && split) { // ---- three launches: per read / per bridge / per read (see above) ----
+		static int w2 = 0;
+		if (w2 == 0) { const char *e = getenv("MGA_GC_WAVES2"); w2 = e && atoi(e) > 0 ? atoi(e) : 2048; }
+		const int waves1 = waves, waves2 = w2, waves3 = waves;
+		const int wmax = waves1 > waves2 ? waves1 : waves2;
+		// pools of the chunk: every read's state fits (anchors + records of all its chains), jobs <= linear chains <= graph-chain records; vertices of walks: by count
+		const int64_t jobs_cap = gc_cap, mid_cap = gc_cap * 8 + (1 << 20);
+		const int64_t state_cap = a_cap * 16 + gc_cap * (int64_t)(sizeof(gc_chain_t) + 16 + sizeof(gc_rec_t) + 48) + (int64_t)n * 128 + 4096;
+		const size_t o_list = 256, o_jobs = o_list + (((size_t)n * 8 + 255) & ~(size_t)255), o_mid = o_jobs + (((size_t)jobs_cap * sizeof(gc_job_t) + 255) & ~(size_t)255),
+					 o_state = o_mid + (((size_t)mid_cap * 4 + 255) & ~(size_t)255), total = o_state + (size_t)state_cap;
+		if (mga_dbuf_reserve(arena, ab * (size_t)wmax) < 0 || mga_dbuf_reserve(&sc->gc_split, total) < 0) return -1;
+		gck_split_t S;
+		char *sb = (char*)sc->gc_split.p;
+		S.sctl = (unsigned long long*)sb, S.p3list = (int64_t*)(sb + o_list), S.jobs = (gc_job_t*)(sb + o_jobs), S.jobs_cap = jobs_cap, S.mid = (int32_t*)(sb + o_mid), S.mid_cap = mid_cap;
+		S.state = sb + o_state, S.state_cap = state_cap;
+		static int dbg = -1; // MGA_GC_SPLIT_DEBUG=1: wait behind every part and print the chunk's counters
+		if (dbg < 0) { const char *e = getenv("MGA_GC_SPLIT_DEBUG"); dbg = e ? atoi(e) : 0; }
+#define GCS_DBG(what) do { if (dbg) { unsigned long long c_[12], k_[4] = { 0, 0, 0, 0 }; const double t_ = mga_wtime(); hipError_t e_ = hipErrorNotReady; \
+			while (mga_wtime() - t_ < 4.0 && (e_ = hipStreamQuery((hipStream_t)sc->stream)) == hipErrorNotReady) {} \
+			if (e_ == hipErrorNotReady) { hipStream_t s2_; (void)hipStreamCreateWithFlags(&s2_, hipStreamNonBlocking); (void)hipMemcpyAsync(k_, d_ctl, 32, hipMemcpyDeviceToHost, s2_); (void)hipMemcpyAsync(c_, sb, sizeof c_, hipMemcpyDeviceToHost, s2_); (void)hipStreamSynchronize(s2_); \
+				fprintf(stderr, "[gc-split] %s: STILL RUNNING after 4 s; n %d waves %d/%d ctl[0..3] %llu %llu %llu %llu; state bytes %llu jobs %llu vertices %llu states %llu next3 %llu next2 %llu/%llu/%llu\n", what, n, waves1, waves2, k_[0], k_[1], k_[2], k_[3], c_[0], c_[1], c_[2], c_[3], c_[4], c_[8], c_[9], c_[10]); _exit(3); } \
+			if (e_ == hipSuccess) e_ = hipMemcpy(c_, sb, sizeof c_, hipMemcpyDeviceToHost); \
+			fprintf(stderr, "[gc-split] %s: %s after %.1f ms; n %d state bytes %llu jobs %llu vertices %llu states %llu next3 %llu next2 %llu/%llu/%llu\n", what, hipGetErrorString(e_), (mga_wtime() - t_) * 1e3, n, c_[0], c_[1], c_[2], c_[3], c_[4], c_[8], c_[9], c_[10]); } } while (0)
+		MGA_HIP_CHECK(hipMemsetAsync(sb, 0, 256, (hipStream_t)sc->stream));
+		GCS_DBG("start");
+		mga_prof_begin(sc->stream, MGA_K_GCHAIN);
+		hipLaunchKernelGGL(k_gchain_p1, dim3(waves1), dim3(64), 0, (hipStream_t)sc->stream, in, out, S, G, P, (char*)arena->p, (int64_t)ab);
+		mga_prof_end(sc->stream, MGA_K_GCHAIN);
+		GCS_DBG("part 1");
+		mga_prof_begin(sc->stream, MGA_K_GCHAIN2);
+		hipLaunchKernelGGL(k_gchain_p2, dim3(waves2), dim3(64), 0, (hipStream_t)sc->stream, S, G, P, (char*)arena->p, (int64_t)ab, d_ctl);
+		mga_prof_end(sc->stream, MGA_K_GCHAIN2);
+		GCS_DBG("part 2");
+		mga_prof_begin(sc->stream, MGA_K_GCHAIN3);
+		hipLaunchKernelGGL(k_gchain_p3, dim3(waves3), dim3(64), 0, (hipStream_t)sc->stream, in, out, S, G, P, (char*)arena->p, (int64_t)ab);
+		mga_prof_end(sc->stream, MGA_K_GCHAIN3);
+		GCS_DBG("part 3");
+		MGA_HIP_CHECK(hipGetLastError());
+		return 0;
+	}
 	mga_prof_begin(sc->stream, MGA_K_GCHAIN);
-	// MGA_GC_LDS=1: the scratch of a graph search / of a GWFA call over a short query gap in 16 KB of LDS per wavefront.  OFF by default: [measured, round 3, bench
-	// workload] the shortest-walk searches get 30 % cheaper (10.8 -> 7.6 Gcycles per 16k reads), but only 30 % of the GWFA calls fit, and with the block allocated
-	// EVERY stage of the kernel slows down by 20-30 % (66 -> 92 Gcycles in all; k_gchain 143 -> 153 ms per 125k reads).  The round-2 aperture fault is understood
-	// and gone (gc_diag_t: 32 bytes at 16-byte alignment); what is left to find is why flat accesses into the LDS aperture cost the rest of the kernel so much.
-	const char *e_fast = getenv("MGA_GC_LDS");
-	const int fast_bytes = e_fast && atoi(e_fast) > 0 ? GCK_FAST_BYTES : 0;
+	const int fast_bytes = 0; // (round 3's MGA_GC_LDS experiment -- the scratch of one graph search / GWFA call in 16 KB of LDS -- cost 66 -> 92 Gcycles per 16k reads: removed from the launch; the hook in gc_core.h stays)
 	hipLaunchKernelGGL(k_gchain, dim3(waves), dim3(64), (size_t)fast_bytes, (hipStream_t)sc->stream, in, out, G, P, (char*)arena->p, (int64_t)ab, fast_bytes);
 	mga_prof_end(sc->stream, MGA_K_GCHAIN);
 	MGA_HIP_CHECK(hipGetLastError());
@@ -334,17 +641,31 @@ extern "C" mg_gchains_t *mga_gchain_host_read(const mg_idx_t *gi, const int32_t 
 	rd.qlen = qlen, rd.hash = hash, rd.n_u = n_u, rd.u = u, rd.a = a, rd.n_mini = n_mini, rd.mini_pos = mini_pos, rd.qseq = qseq;
 	R.a = (mg128_t*)malloc((size_t)(n_a > 0 ? n_a : 1) * sizeof(mg128_t));
 	int rc;
-	static int split_test = -1; // MGA_GC_SPLIT_TEST=1 (CPU tests): the three-part form -- part 1, the bridges as jobs in REVERSE order in an arena of their own, part 3; =3: + the redo path of part 3
+	static int split_test = -1; // MGA_GC_SPLIT_TEST (CPU tests) = 1: the three-part form -- part 1, the bridges as jobs in REVERSE order in an arena of their own, part 3; = 3: + the redo path
+	                            // of part 3; = 2: the device's hand-over -- part 1's state leaves through a block (gcs_*), its arena is scrubbed, the jobs and part 3 work from the block
+	char *blk = 0;
 	if (split_test < 0) { const char *e = getenv("MGA_GC_SPLIT_TEST"); split_test = e ? atoi(e) : 0; }
 	if (!split_test) rc = gc_map_read(&A, &G, &P, &rd, &R);
 	else {
 		gc_split_t sp;
 		rc = gc_read_p1(&A, &G, &P, &rd, &R, &sp);
-		if (rc == GC_OK && !sp.done) {
+		if (rc == GC_OK && !sp.done && (split_test != 2 || R.n_gc > 0)) {
 			gc_job_t *jobs = (gc_job_t*)calloc((size_t)sp.n_jobs + 1, sizeof(gc_job_t));
 			int32_t *pool = 0;
 			int64_t n_pool = 0, m_pool = 0;
-			gc_assemble_jobs(sp.n_u2, sp.u2, sp.kept, sp.c, 0, GC_ASPAN(rd.a[0]), rd.qseq, jobs);
+			if (split_test == 2) { // what k_gchain_p1 / p2 / p3 do, with one lane
+				gcs_view_t v;
+				gcs_view(0, n_a, sp.n_c, sp.n_u2, R.n_gc, &v);
+				blk = (char*)malloc((size_t)v.bytes);
+				gcs_view(blk, n_a, sp.n_c, sp.n_u2, R.n_gc, &v);
+				gcs_write_arrays(&v, n_a, rd.a, &sp, &R, 0, 1);
+				gcs_write_header(&v, 0, n_a, &sp, &R, 0);
+				gc_assemble_jobs(sp.n_u2, v.u2, v.kept, v.c, 0, v.h->span, rd.qseq, jobs);
+				memset(A.base, 0xA5, (size_t)A.top); A.top = 0; // part 1's arena is gone (its current block at least)
+				memset(rd.a, 0xA5, (size_t)n_a * 16);           // ... and so is its working copy of the anchors
+				memset(&sp, 0xA5, sizeof sp);
+				gcs_setup_p3(blk, R.a, &rd, &R, &sp);
+			} else gc_assemble_jobs(sp.n_u2, sp.u2, sp.kept, sp.c, 0, GC_ASPAN(rd.a[0]), rd.qseq, jobs);
 			for (int32_t k = sp.n_jobs - 1; k >= 0 && rc == GC_OK; --k) {
 				gc_arena_t A2;
 				gc_bres_t b;
@@ -369,7 +690,7 @@ extern "C" mg_gchains_t *mga_gchain_host_read(const mg_idx_t *gi, const int32_t 
 	mg_gchains_t *gs = mga_gchains_from_flat(R.n_gc, R.gc, R.n_lc, R.lc, R.n_a, R.a, rep_len, qlen, n_mz, opt->min_gc_score);
 	if (n_gwfa) *n_gwfa = R.n_gwfa;
 	if (n_shortk) *n_shortk = R.n_shortk;
-	free(R.a);
+	free(R.a); free(blk);
 	gc_arena_free_blocks(&A);
 	return gs;
 }

@@ -48,6 +48,7 @@ typedef struct mga_sctx_s {
 	void *ev_ready, *ev_done[16];
 	void *ev_sync;             /* event behind mga_ssync() */
 	void *stage;               /* pinned staging for small device-to-host read-backs, delivered by mga_ssync() */
+	mga_dbuf_t gc_split;       /* three-kernel form of graph chaining: counters, state list, jobs, walk vertices, state pool of the chunk in flight */
 	mga_dbuf_t gc_arena[2];    /* per-wave scratch arenas of k_gchain: 1 MiB x resident waves, and the large tier for the reads that outgrow that */
 	int wfa_uncapped;          /* set while the ladder runs the chained fallback's sub-problems: no 1e8-cell cap, unbounded last tier */
 	mga_dbuf_t fb_prob, fb_res; /* sub-problems of the chained fallback and their results */
@@ -71,7 +72,7 @@ void mga_hbuf_free(mga_hbuf_t *b);
 
 /* per-kernel HIP-event timing on the launch stream (bench.py reads it through mga_prof_get) */
 enum { MGA_K_SKETCH = 0, MGA_K_SEED_COUNT, MGA_K_SEED_FILL, MGA_K_LCHAIN, MGA_K_WFA0 /* +tier: 0-2 single-wave register tiers (band 64,128,192), 3-6 multi-wave register tiers (256..2048), 7-8 HBM tiers */, MGA_K_SCAN = MGA_K_WFA0 + 9, MGA_K_TEXT, MGA_K_GCHAIN, MGA_K_PLAN,
-	   MGA_K_WFAW0 /* +0..5: windowed tiers of 16 (4 problems per wave), 32 (2), 64, 128, 192, 256 diagonals (k_wfa_w.hip) */, MGA_K_WFATB = MGA_K_WFAW0 + 6 /* their traceback */, MGA_K_N };
+	   MGA_K_WFAW0 /* +0..5: windowed tiers of 16 (4 problems per wave), 32 (2), 64, 128, 192, 256 diagonals (k_wfa_w.hip) */, MGA_K_WFATB = MGA_K_WFAW0 + 6 /* their traceback */, MGA_K_GCHAIN2 /* graph chaining, three-kernel form: part 2 (a wavefront per bridge) */, MGA_K_GCHAIN3 /* part 3; part 1 counts as MGA_K_GCHAIN */, MGA_K_N };
 #define MGA_WFW_N 6         /* windowed tiers */
 #define MGA_WFA_N_TIER 9    /* register + HBM tiers (k_wfa_r.hip 0-6, k_wfa.hip 7-8) */
 #define MGA_WFA_N_SLOT 11   /* rungs of the ladder: W0-W5, R4-R6, H0-H1 (MGA_WFA_LADDER=old: R0-R6, H0-H1) */

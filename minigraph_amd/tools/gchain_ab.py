@@ -21,14 +21,20 @@ VARIANTS = {
     "nolds": ["-DGC_AB_NO_LDS_STATE"],       # round-2 placement of the routines' state (a private copy per lane: scratch memory)
     "ni": ["-DGC_AB_NOINLINE"],              # the big routines as functions of their own (half the code)
     "w4": ["-DGC_AB_WAVES_PER_EU=4"],        # 128 VGPRs, four resident wavefronts per SIMD
+    "mono": None,                            # (round 4) the tree's own library, one-kernel form (MGA_GC_SPLIT=0)
+    "split": None,                           # the tree's own library, three-kernel form (the default)
+    "p2w4": ["-DGC_AB_P2_WAVES=4"],          # part 2 (a wavefront per bridge) at 128 VGPRs, 4096 wavefronts
+    "p2w3": ["-DGC_AB_P2_WAVES=3"],
 }
-ENV = {"w4": {"MGA_GC_WAVES": "4096"}}
+ENV = {"w4": {"MGA_GC_WAVES": "4096"}, "mono": {"MGA_GC_SPLIT": "0"}, "split": {"MGA_GC_SPLIT": "1"}, "p2w4": {"MGA_GC_WAVES2": "4096"}, "p2w3": {"MGA_GC_WAVES2": "3072"}}
 
 
 def build(names):
     os.makedirs(AB, exist_ok=True)
     others = [o for o in sorted(glob.glob(os.path.join(LIB, "obj", "*.o"))) if os.path.basename(o) != "k_gchain.hip.o"]
     for name in names:
+        if VARIANTS[name] is None:
+            continue
         obj = os.path.join(AB, name + ".o")
         subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result", "-w"] + VARIANTS[name] +
                               ["-c", os.path.join(CSRC, "k_gchain.hip"), "-o", obj])
@@ -53,7 +59,7 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 2
 pr = mga.prof_get()
 import hashlib
-print("AB", json.dumps(dict(k_gchain_ms=round(pr["k_gchain"][0] / 2, 2), pass_ms=round(dt * 1e3, 1), gaf_bytes=n0, md5=hashlib.md5(ref).hexdigest())))
+print("AB", json.dumps(dict(k_gchain_ms=round((pr["k_gchain"][0] + pr["k_gchain_p2"][0] + pr["k_gchain_p3"][0]) / 2, 2), parts_ms=[round(pr[k][0] / 2, 2) for k in ("k_gchain", "k_gchain_p2", "k_gchain_p3")], pass_ms=round(dt * 1e3, 1), gaf_bytes=n0, md5=hashlib.md5(ref).hexdigest())))
 """
 
 
@@ -63,15 +69,19 @@ def run(names, genome, reads):
     d = tempfile.mkdtemp(prefix="mga_ab_")
     subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "w"), "-G", str(genome), "-c", "8", "-H", "5", "-n", str(reads), "-s", "11"], stderr=subprocess.DEVNULL)
     import re
-    for rep in range(2):   # first round with per-stage cycle sums (MGA_GC_PROF=1: inflates the kernel, the sums compare builds), second round plain
+    for rep in ((1,) if os.environ.get("AB_PLAIN_ONLY") else (0, 1)):   # first round with per-stage cycle sums (MGA_GC_PROF=1: inflates the kernel, the sums compare builds), second round plain
         for name in names:
-            lib = os.path.join(AB, "lib_%s.so" % name)
+            lib = os.path.join(AB, "lib_%s.so" % name) if VARIANTS[name] is not None else os.path.join(LIB, "libminigraph_amd.so")
             if not os.path.exists(lib):
                 continue
             env = dict(os.environ, MGA_LIB=lib, **ENV.get(name, {}))
             if rep == 0:
                 env["MGA_GC_PROF"] = "1"
-            p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, os.path.join(d, "w.gfa"), os.path.join(d, "w.reads.fa")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            try:
+                p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, os.path.join(d, "w.gfa"), os.path.join(d, "w.reads.fa")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=int(os.environ.get("AB_TIMEOUT", "150")))
+            except subprocess.TimeoutExpired:
+                print(name, "TIMEOUT", flush=True)
+                continue
             line = [l for l in p.stdout.decode().splitlines() if l.startswith("AB")]
             print(name, "prof" if rep == 0 else "plain", line[0] if line else ("FAILED " + p.stderr.decode()[-400:]), flush=True)
             if rep == 0:

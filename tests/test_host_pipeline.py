@@ -111,12 +111,13 @@ def test_graph_chaining_core_repeats_secondaries():
 
 
 @pytest.mark.skipif(not os.path.exists(rb.REF_BIN), reason="oracle/_ref/minigraph not built")
-@pytest.mark.parametrize("level", ["1", "3"])
+@pytest.mark.parametrize("level", ["1", "2", "3"])
 def test_three_part_form_of_graph_chaining_bridges_in_reverse_order(level):
     """the device runs a read in three kernels (gc_read_p1 / a wavefront per bridge: gc_job_run / gc_read_p3, gc_core.h) because a read's bridges are independent of each other
     and of the assembly; MGA_GC_SPLIT_TEST=1 makes the HOST instantiation take the same three parts, the bridges last to first in an arena of their own: the same bytes as the
     reference binary (a child process: the switch is read once).  Level 3 also reports every bridge between neighbouring chains as "no walk of the chosen length", so that part 3
-    takes its redo path (the pairs in between, computed where they are met) for all of them"""
+    takes its redo path (the pairs in between, computed where they are met) for all of them.  Level 2 is the device's hand-over (k_gchain_p1 -> p2 -> p3): part 1's state leaves
+    through one block (the layout functions the kernels use), its arena and its anchor copy are scrubbed, the jobs and part 3 work from the block"""
     import sys
     d = tempfile.mkdtemp()
     subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "3000000", "-H", "5", "-n", "500", "-l", "12000", "-s", "43"], stderr=subprocess.DEVNULL)
