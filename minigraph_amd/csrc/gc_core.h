@@ -79,6 +79,7 @@ typedef struct gc_arena_s {
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define GC_TICK(A, id) do { if ((A)->ticks && (threadIdx.x & 63) == 0) { const long long now_ = (long long)clock64(); atomicAdd(&(A)->ticks[id], (unsigned long long)(now_ - (A)->tick_last)); (A)->tick_last = now_; } } while (0)
+#define GC_COUNT(A, id, v) do { if ((A)->ticks && (threadIdx.x & 63) == 0) atomicAdd(&(A)->ticks[id], (unsigned long long)(v)); } while (0)
 #elif defined(GC_HOST_PROF) /* (host profiling aid: cycles between ticks, summed per stage into gc_host_ticks[]) */
 #include <x86intrin.h>
 static unsigned long long gc_host_ticks[16];
@@ -86,6 +87,14 @@ static __thread unsigned long long gc_host_last;
 #define GC_TICK(A, id) do { const unsigned long long now_ = __rdtsc(); if ((id) != 0) __sync_fetch_and_add(&gc_host_ticks[id], now_ - gc_host_last); gc_host_last = now_; } while (0)
 #else
 #define GC_TICK(A, id) ((void)0)
+#endif
+#ifdef GC_DD_PROF
+#define GC_DDP(...) __VA_ARGS__   /* (profiling build: the phases of the device's dedup in count slots 1-4) */
+#else
+#define GC_DDP(...)
+#endif
+#ifndef GC_COUNT
+#define GC_COUNT(A, id, v) ((void)0)   /* (device profiling of ONE bridge, k_gchain_p2 with MGA_GC_SPLIT_DEBUG=2: steps, cells, runs, head cells, output cells, sorts in ticks[1,2,3,4,6,10]) */
 #endif
 
 GC_HD void gc_arena_init(gc_arena_t *A, void *mem, int64_t cap, int growable) { A->base = (char*)mem, A->top = 0, A->cap = cap, A->ovf = 0, A->growable = growable, A->blocks = 0, A->peak = 0, A->ticks = 0, A->tick_last = 0, A->fast_base = 0, A->fast_cap = 0; }
@@ -1313,6 +1322,311 @@ GC_HDN int gc_intv_add(gc_arena_t *A, gc_intv_v *L, uint64_t x0, uint64_t x1)
 #define GC_COMPACT_BEGIN(n_) { const int32_t gcn_ = (n_); int32_t gcm_ = 0; for (int32_t gcb_ = 0; gcb_ < gcn_; gcb_ += GC_NLANE) { const int32_t gci_ = gcb_ + GC_LANE; const int gcin_ = gci_ < gcn_;
 #define GC_COMPACT_END(a_, val_, keep_, n_out_) const uint64_t gck_ = gc_ballot(gcin_ && (keep_)); gc_sync(); if (gcin_ && (keep_)) (a_)[gcm_ + gc_rank(gck_)] = (val_); gcm_ += gc_popc(gck_); gc_sync(); } (n_out_) = gcm_; }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+GC_HD uint64_t gc_shfl64(uint64_t v, int src) { const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src); return (uint64_t)hi << 32 | lo; }
+/* this step's finished diagonals join the list: sequentially that is a binary search and a shift per interval ([measured] most of what the dedup of a long bridge cost: ~30 intervals
+ * per step).  The list is the canonical union of everything added so far, so a batch can be merged in one go: the list's ranges and the new ones side by side in the lanes (<= 64
+ * together; more new ones come in several batches), sorted by start through their ranks, a running maximum of the ends tells where a range starts that touches nothing before it. */
+GC_HDN int gc_intv_add_wave(gc_arena_t *A, gc_intv_v *L, int32_t n_f, const gc_intv_t *f)
+{
+	__shared__ __attribute__((aligned(16))) gc_intv_t iv_lds[64];
+	const int32_t lane = GC_LANE;
+	int32_t done_f = 0;
+	while (done_f < n_f) {
+		const int32_t n_d = L->n;
+		if (n_d >= 48) { /* a long list: one by one (the generic way) */
+			for (int32_t i = done_f; i < n_f; ++i) GC_TRY(gc_intv_add(A, L, f[i].vd0, f[i].vd1));
+			return GC_OK;
+		}
+		const int32_t take = n_f - done_f < 64 - n_d ? n_f - done_f : 64 - n_d, T = n_d + take;
+		GC_TRY(gc_vec_reserve(A, *L, T));
+		uint64_t s0 = ~0ULL, e0 = 0;
+		if (lane < n_d) s0 = L->a[lane].vd0, e0 = L->a[lane].vd1;
+		else if (lane < T) s0 = f[done_f + lane - n_d].vd0, e0 = f[done_f + lane - n_d].vd1;
+		int32_t r = 0;
+		for (int32_t j = 0; j < T; ++j) { const uint64_t sj = gc_shfl64(s0, j); r += (sj < s0) | ((sj == s0) & (j < lane)); }
+		if (lane < T) iv_lds[r].vd0 = s0, iv_lds[r].vd1 = e0;
+		gc_sync();
+		uint64_t s1 = ~0ULL, e1 = 0;
+		if (lane < T) s1 = iv_lds[lane].vd0, e1 = iv_lds[lane].vd1;
+		gc_sync();
+		uint64_t pm = e1; /* inclusive running maximum of the ends */
+		for (int32_t d = 1; d < 64; d <<= 1) { const uint64_t o = gc_shfl64(pm, lane >= d ? lane - d : lane); if (lane >= d && o > pm) pm = o; }
+		uint64_t before = gc_shfl64(pm, lane > 0 ? lane - 1 : 0);
+		const int start = lane < T && (lane == 0 || s1 > before); /* touches nothing before it (ranges that touch are one range: gfa-ed.c:69-82) */
+		const uint64_t ms = __ballot(start);
+		const uint64_t above = lane < 63 ? ms & ~((2ULL << lane) - 1ULL) : 0ULL; /* starts behind mine */
+		const int32_t last = above ? (int32_t)__ffsll((long long)above) - 2 : T - 1; /* the last range of my group */
+		const uint64_t en = gc_shfl64(pm, last < 0 ? 0 : last);
+		if (start) { gc_intv_t *o = &L->a[gc_rank(ms)]; o->vd0 = s1, o->vd1 = en; }
+		L->n = gc_popc(ms);
+		gc_sync();
+		done_f += take;
+	}
+	return GC_OK;
+}
+/* gwf_dedup on the device with few dependent trips to memory (round 4: [measured] the generic routine below was 56-66 % of a long bridge's time, ~120 k cycles per call on an otherwise
+ * idle GPU -- a dozen passes, binary searches through HBM / L2 per cell).  Same result, three passes:
+ *   A  every cell once: is the list out of order at all?  in-order cells close ranks in the scratch vector, the flagged ones (a handful: what the head cells pushed) go to LDS;
+ *      the flagged ones are sorted by rank in registers (<= 64: klib's insertion sort is stable, so is a rank), each finds its place among the in-order ones by ONE binary
+ *      search; every in-order cell finds its place by comparing with the sorted flagged keys broadcast lane by lane (no memory);
+ *   B  the merged list in blocks that END AT A GROUP BOUNDARY (a lane also fetches the key behind the block), so that the furthest-cell-of-its-(vertex, diagonal) test sees whole
+ *      groups through lane shuffles; the finished-diagonal test follows for the survivors; the output goes to the scratch vector, which then BECOMES the wavefront (the two vector
+ *      headers are swapped) -- no in-place compaction, no barrier between blocks.
+ * *handled = 0: left to the generic routine (more than 64 flagged cells, in-order cells that are not in order, a group that fills a block): B is valid input for it at that point. */
+GC_HDN int gc_gw_dedup_wave(gc_arena_t *A, gc_gw_t *z, gc_diag_v *B, int *handled)
+{
+	__shared__ __attribute__((aligned(16))) gc_diag_t c_lds[2][64];
+	const int32_t n = B->n, lane = GC_LANE;
+	*handled = 0;
+	GC_TRY(gc_vec_reserve(A, z->ooo, n > 0 ? n : 1));
+	gc_diag_t *a = B->a, *tmp = z->ooo.a;
+	int unsorted = 0, b_unsorted = 0;
+	int32_t n_b = 0, n_c = 0;
+	uint64_t carry_vd = 0, carry_b = 0;
+	for (int32_t base = 0; base < n; base += 64) { /* ---- pass A ---- */
+		const int32_t i = base + lane;
+		const int in = i < n;
+		gc_diag_t me;
+		me.vd = ~0ULL, me.k = 0, me.len = 0, me.xo = 0, me.t = 0, me.pad_[0] = me.pad_[1] = 0;
+		if (in) me = a[i];
+		uint64_t pv = gc_shfl64(me.vd, lane > 0 ? lane - 1 : 0);
+		if (lane == 0) pv = carry_vd;
+		unsorted |= in && pv > me.vd;
+		const int flag = in && (me.xo & 1);
+		const uint64_t mc = __ballot(flag), mb = __ballot(in && !flag);
+		const uint64_t lower = mb & ((1ULL << lane) - 1ULL);
+		uint64_t pb = gc_shfl64(me.vd, lower ? 63 - __clzll((long long)lower) : lane); /* the in-order cell before mine */
+		if (!lower) pb = carry_b;
+		b_unsorted |= in && !flag && pb > me.vd;
+		const int32_t last = n - base > 64 ? 63 : n - base - 1;
+		carry_vd = gc_shfl64(me.vd, last);
+		if (mb) carry_b = gc_shfl64(me.vd, 63 - __clzll((long long)mb));
+		if (flag) { const int32_t ci = n_c + gc_rank(mc); if (ci < 64) c_lds[0][ci] = me; }
+		else if (in) tmp[n_b + gc_rank(mb)] = me;
+		n_b += gc_popc(mb), n_c += gc_popc(mc);
+	}
+	if (__ballot(unsorted)) {
+		if (n_c > 64 || __ballot(b_unsorted)) return GC_OK; /* the generic routine */
+		gc_sync();
+		gc_diag_t c;
+		uint64_t key = ~0ULL;
+		c.vd = ~0ULL, c.k = 0, c.len = 0, c.xo = 0, c.t = 0, c.pad_[0] = c.pad_[1] = 0;
+		if (lane < n_c) c = c_lds[0][lane], key = c.vd;
+		int32_t r = 0;
+		for (int32_t j = 0; j < n_c; ++j) { const uint64_t kj = gc_shfl64(key, j); r += (kj < key) | ((kj == key) & (j < lane)); } /* cells with a smaller key, and equal ones before mine */
+		if (lane < n_c) { c.xo &= 0xfffffffeU; c_lds[1][r] = c; }
+		gc_sync();
+		uint64_t ck = ~0ULL;
+		if (lane < n_c) { /* the sorted flagged cells: mine goes behind the in-order cells that are smaller or equal */
+			c = c_lds[1][lane], ck = c.vd;
+			int32_t lo = 0, hi = n_b;
+			while (lo < hi) { const int32_t m = (lo + hi) >> 1; if (tmp[m].vd <= ck) lo = m + 1; else hi = m; }
+			a[lane + lo] = c;
+		}
+		for (int32_t base = 0; base < n_b; base += 64) { /* an in-order cell goes behind the flagged ones that are strictly smaller */
+			const int32_t i = base + lane;
+			gc_diag_t me;
+			me.vd = 0, me.k = 0, me.len = 0, me.xo = 0, me.t = 0, me.pad_[0] = me.pad_[1] = 0;
+			if (i < n_b) me = tmp[i];
+			int32_t lo = 0;
+			for (int32_t j = 0; j < n_c; ++j) lo += gc_shfl64(ck, j) < me.vd;
+			if (i < n_b) a[i + lo] = me;
+		}
+		gc_sync();
+	}
+	{ /* ---- pass B ---- */
+		const int32_t n_done = z->done.n;
+		const gc_intv_t *dn = z->done.a;
+		int32_t m = 0;
+		for (int32_t base = 0; base < n;) {
+			const int32_t i = base + lane;
+			const int in = i < n;
+			gc_diag_t me;
+			me.vd = ~0ULL, me.k = 0, me.len = 0, me.xo = 0, me.t = 0, me.pad_[0] = me.pad_[1] = 0;
+			if (in) me = a[i];
+			uint64_t nx = ~0ULL;
+			if (lane == 0 && base + 64 < n) nx = a[base + 64].vd;
+			nx = gc_shfl64(nx, 0);
+			uint64_t rv = gc_shfl64(me.vd, lane < 63 ? lane + 1 : 63);
+			if (lane == 63) rv = nx;
+			const uint64_t mbnd = __ballot(in && rv != me.vd); /* a group ends at my cell */
+			if (mbnd == 0) return GC_OK; /* one group fills the block: the generic routine (the list in B is sorted by now, which is all it needs) */
+			const int32_t e = 63 - __clzll((long long)mbnd);
+			const int act = lane <= e;
+			int keep = act;
+			for (int32_t d = 1; d < 64; ++d) { /* the first of the furthest cells of a group stays */
+				const uint64_t lv = gc_shfl64(me.vd, lane >= d ? lane - d : lane), rv2 = gc_shfl64(me.vd, lane + d <= 63 ? lane + d : lane);
+				const int32_t lk = __shfl(me.k, lane >= d ? lane - d : lane), rk = __shfl(me.k, lane + d <= 63 ? lane + d : lane);
+				const int same_l = act && lane >= d && lv == me.vd, same_r = act && lane + d <= e && rv2 == me.vd;
+				if (same_l && !(lk < me.k)) keep = 0;
+				if (same_r && me.k < rk) keep = 0;
+				if (!__ballot(same_l | same_r)) break;
+			}
+			if (keep && n_done > 0) { /* not on a finished diagonal: the intervals are disjoint and ascending */
+				int32_t lo = 0, hi = n_done;
+				while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (dn[mid].vd1 <= me.vd) lo = mid + 1; else hi = mid; }
+				keep = !(lo < n_done && me.vd >= dn[lo].vd0);
+			}
+			const uint64_t mk = __ballot(keep);
+			if (keep) { me.len = 0; tmp[m + gc_rank(mk)] = me; }
+			m += gc_popc(mk);
+			base += e + 1;
+		}
+		gc_sync();
+		gc_diag_t *ta = B->a; const int32_t tm = B->m;
+		B->a = z->ooo.a, B->m = z->ooo.m, B->n = m;
+		z->ooo.a = ta, z->ooo.m = tm;
+	}
+	*handled = 1;
+	return GC_OK;
+}
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+/* The same dedup with the cells' KEYS in LDS (round 4): {vertex|diagonal, offset, where the cell lies in the wavefront} of up to GC_DD_CAP cells -- 16 bytes each -- are fetched
+ * in one sweep (independent loads, several blocks in flight), every pass of the routine above then runs on LDS (stable partition, rank sort of the flagged keys, merge by
+ * shifting the in-order keys up block by block from the top, furthest-of-group by looking at the neighbouring keys, finished-diagonal test against a copy of the list in LDS,
+ * compaction), and the surviving cells are gathered from the wavefront into the scratch vector, which becomes the wavefront.  [measured] a dependent trip to HBM / L2 costs a
+ * lone wavefront 500-1500 cycles, one to LDS ~100: the routine above took ~90 k cycles per call of a long bridge.  *handled = 0: more cells than the LDS block holds, or one of
+ * the cases the routine above leaves to the generic one. */
+#define GC_DD_CAP 640
+typedef struct { uint64_t vd; int32_t k; uint32_t src; } gc_ddkey_t; /* src: index into the wavefront | flagged << 31 */
+GC_HDN int gc_gw_dedup_lds(gc_arena_t *A, gc_gw_t *z, gc_diag_v *B, int *handled)
+{
+	__shared__ __attribute__((aligned(16))) gc_ddkey_t K[GC_DD_CAP];
+	__shared__ __attribute__((aligned(16))) gc_ddkey_t C[2][64];
+	__shared__ __attribute__((aligned(16))) gc_intv_t D[64];
+	const int32_t n = B->n, lane = GC_LANE;
+	*handled = 0;
+	if (n > GC_DD_CAP) return GC_OK;
+	GC_DDP(long long t_0 = clock64());
+	GC_TRY(gc_vec_reserve(A, z->ooo, n > 0 ? n : 1));
+	const gc_diag_t *a = B->a;
+	gc_diag_t *tmp = z->ooo.a;
+	const int32_t n_done = z->done.n;
+	const int done_lds = n_done > 0 && n_done <= 64;
+	if (done_lds && lane < n_done) D[lane] = z->done.a[lane];
+	int unsorted = 0, b_unsorted = 0;
+	int32_t n_c = 0;
+	uint64_t carry_vd = 0, carry_b = 0;
+	for (int32_t base0 = 0; base0 < n; base0 += 256) { /* ---- keys in: four blocks of loads in flight ---- */
+		uint64_t vd[4]; int32_t kk[4]; uint32_t xo[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) { const int32_t i = base0 + u * 64 + lane; vd[u] = ~0ULL, kk[u] = 0, xo[u] = 0; if (i < n) vd[u] = a[i].vd, kk[u] = a[i].k, xo[u] = a[i].xo; }
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const int32_t base = base0 + u * 64, i = base + lane;
+			if (base < n) {
+				const int in = i < n, flag = in && (xo[u] & 1);
+				uint64_t pv = gc_shfl64(vd[u], lane > 0 ? lane - 1 : 0);
+				if (lane == 0) pv = carry_vd;
+				unsorted |= in && pv > vd[u];
+				const uint64_t mc = __ballot(flag), mb = __ballot(in && !flag);
+				const uint64_t lower = mb & ((1ULL << lane) - 1ULL);
+				uint64_t pb = gc_shfl64(vd[u], lower ? 63 - __clzll((long long)lower) : lane); /* the in-order cell before mine */
+				if (!lower) pb = carry_b;
+				b_unsorted |= in && !flag && pb > vd[u];
+				carry_vd = gc_shfl64(vd[u], n - base > 64 ? 63 : n - base - 1);
+				if (mb) carry_b = gc_shfl64(vd[u], 63 - __clzll((long long)mb));
+				if (in) { gc_ddkey_t q; q.vd = vd[u], q.k = kk[u], q.src = (uint32_t)i | (uint32_t)flag << 31; K[i] = q; }
+				n_c += gc_popc(mc);
+			}
+		}
+	}
+	gc_sync();
+	GC_DDP(long long t_1 = clock64());
+	const int sorted_now = __ballot(unsorted) != 0;
+	if (sorted_now) {
+		if (n_c > 64 || __ballot(b_unsorted)) return GC_OK; /* the generic routine */
+		const int32_t n_b = n - n_c;
+		{ /* stable partition in LDS: the in-order keys close ranks (downwards: a block is read completely before it is written, and it is written at or below where it was) */
+			int32_t kb = 0, kc = 0;
+			for (int32_t base = 0; base < n; base += 64) {
+				const int32_t i = base + lane;
+				gc_ddkey_t q;
+				q.vd = 0, q.k = 0, q.src = 0;
+				if (i < n) q = K[i];
+				const int in = i < n, flag = in && (q.src >> 31);
+				const uint64_t mc = __ballot(flag), mb = __ballot(in && !flag);
+				gc_sync();
+				if (flag) C[0][kc + gc_rank(mc)] = q; else if (in) K[kb + gc_rank(mb)] = q;
+				kb += gc_popc(mb), kc += gc_popc(mc);
+				gc_sync();
+			}
+		}
+		gc_ddkey_t c;
+		uint64_t key = ~0ULL;
+		c.vd = ~0ULL, c.k = 0, c.src = 0;
+		if (lane < n_c) c = C[0][lane], key = c.vd;
+		int32_t r = 0;
+		for (int32_t j = 0; j < n_c; ++j) { const uint64_t kj = gc_shfl64(key, j); r += (kj < key) | ((kj == key) & (j < lane)); } /* keys smaller than mine, and equal ones before mine */
+		if (lane < n_c) C[1][r] = c;
+		gc_sync();
+		uint64_t ck = ~0ULL;
+		int32_t c_pos = 0;
+		if (lane < n_c) { /* the sorted flagged keys: mine goes behind the in-order keys that are smaller or equal */
+			c = C[1][lane], ck = c.vd;
+			int32_t lo = 0, hi = n_b;
+			while (lo < hi) { const int32_t m = (lo + hi) >> 1; if (K[m].vd <= ck) lo = m + 1; else hi = m; }
+			c_pos = lane + lo;
+		}
+		for (int32_t base = (n_b - 1) & ~63; base >= 0; base -= 64) { /* an in-order key goes up by the number of flagged keys that are strictly smaller: blocks from the top down */
+			const int32_t i = base + lane;
+			gc_ddkey_t q;
+			q.vd = 0, q.k = 0, q.src = 0;
+			if (i < n_b) q = K[i];
+			int32_t lo = 0;
+			for (int32_t j = 0; j < n_c; ++j) lo += gc_shfl64(ck, j) < q.vd;
+			gc_sync();
+			if (i < n_b) K[i + lo] = q;
+			gc_sync();
+		}
+		if (lane < n_c) K[c_pos] = c;
+		gc_sync();
+	}
+	GC_DDP(long long t_2 = clock64());
+	int32_t m = 0;
+	for (int32_t base = 0; base < n; base += 64) { /* ---- the first of the furthest cells of every (vertex, diagonal) that is not finished; survivors close ranks ---- */
+		const int32_t i = base + lane;
+		gc_ddkey_t q;
+		q.vd = 0, q.k = 0, q.src = 0;
+		int keep = 0;
+		if (i < n) {
+			q = K[i];
+			keep = 1;
+			for (int32_t j = i - 1; j >= 0 && K[j].vd == q.vd; --j) if (!(K[j].k < q.k)) { keep = 0; break; } /* an earlier cell at least as far */
+			if (keep) for (int32_t j = i + 1; j < n && K[j].vd == q.vd; ++j) if (q.k < K[j].k) { keep = 0; break; } /* a later cell strictly further */
+			if (keep && n_done > 0) {
+				int32_t lo = 0, hi = n_done;
+				if (done_lds) { while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (D[mid].vd1 <= q.vd) lo = mid + 1; else hi = mid; } keep = !(lo < n_done && q.vd >= D[lo].vd0); }
+				else { const gc_intv_t *dn = z->done.a; while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (dn[mid].vd1 <= q.vd) lo = mid + 1; else hi = mid; } keep = !(lo < n_done && q.vd >= dn[lo].vd0); }
+			}
+		}
+		const uint64_t mk = __ballot(keep);
+		gc_sync(); /* (every lane has read its neighbours' keys before a block is written: the writes land at or below the block) */
+		if (keep) K[m + gc_rank(mk)] = q;
+		m += gc_popc(mk);
+		gc_sync();
+	}
+	GC_DDP(long long t_3 = clock64());
+	for (int32_t base0 = 0; base0 < m; base0 += 256) { /* ---- the survivors' cells: wavefront -> scratch vector, four blocks in flight ---- */
+		uint4 c0[4], c1[4]; /* a cell as two 16-byte words: {vd, k, len} {xo, t, -, -} */
+#pragma unroll
+		for (int u = 0; u < 4; ++u) { const int32_t p = base0 + u * 64 + lane; c0[u] = make_uint4(0, 0, 0, 0), c1[u] = c0[u]; if (p < m) { const uint4 *src = (const uint4*)&a[K[p].src & 0x7fffffffU]; c0[u] = src[0], c1[u] = src[1]; } }
+#pragma unroll
+		for (int u = 0; u < 4; ++u) { const int32_t p = base0 + u * 64 + lane; if (p < m) { uint4 *dst = (uint4*)&tmp[p]; c0[u].w = 0; if (sorted_now) c1[u].x &= 0xfffffffeU; dst[0] = c0[u], dst[1] = c1[u]; } }
+	}
+	gc_sync();
+	{
+		gc_diag_t *ta = B->a; const int32_t tm = B->m;
+		B->a = z->ooo.a, B->m = z->ooo.m, B->n = m;
+		z->ooo.a = ta, z->ooo.m = tm;
+	}
+	GC_DDP(long long t_4 = clock64(); GC_COUNT(A, 1, t_1 - t_0); GC_COUNT(A, 2, t_2 - t_1); GC_COUNT(A, 3, t_3 - t_2); GC_COUNT(A, 4, t_4 - t_3));
+	*handled = 1;
+	return GC_OK;
+}
+#endif
 GC_HD int gc_gw_dedup(gc_arena_t *A, gc_gw_t *z, int32_t *n_a_, gc_diag_t *a) /* gwf_dedup, gfa-ed.c:258-271 */
 {
 	int32_t n_a = *n_a_;
@@ -1323,7 +1637,7 @@ GC_HD int gc_gw_dedup(gc_arena_t *A, gc_gw_t *z, int32_t *n_a_, gc_diag_t *a) /*
 	{
 		int unsorted = 0;
 		GC_PAR_FOR(i, n_a) if (i > 0 && a[i - 1].vd > a[i].vd) unsorted = 1;
-		if (gc_ballot(unsorted)) GC_TRY(gc_diag_sort(A, z, n_a, a));
+		if (gc_ballot(unsorted)) { GC_COUNT(A, 10, 1); GC_TRY(gc_diag_sort(A, z, n_a, a)); }
 	}
 	/* keep the furthest cell of every (vertex, diagonal): the first of equals.  Groups are a handful of cells: every lane looks left and right
 	 * of its own cell inside the group and leaves its verdict in the cell's (otherwise unused here) len field; then the survivors close ranks */
@@ -1510,12 +1824,14 @@ GC_HD int gc_gw_step(gc_arena_t *A, gc_gw_t *z, uint32_t v1, int32_t off1, int *
 				const int32_t e = base + bit + 1;
 				m &= m - 1;
 				GC_TRY(gc_gw_extend_run(A, z, e - x, &Cur->a[x], B, H));
+				GC_DDP(if (0)) GC_COUNT(A, 3, 1);
 				GC_STAT(++st_runs; if (e - x > 64) st_long = 1;)
 				x = e;
 			}
 		}
 	}
 	if (H->n == 0) do_dedup = 0;
+	GC_DDP(if (0)) { GC_COUNT(A, 1, 1); GC_COUNT(A, 2, n); GC_COUNT(A, 4, H->n); }
 	GC_STAT(gc_stats.steps++; gc_stats.cells += n; gc_stats.runs += st_runs; gc_stats.heads0 += H->n; gc_stats.single += st_runs == 1; gc_stats.nohead += H->n == 0; gc_stats.single_nohead += st_runs == 1 && H->n == 0;
 			if (st_runs == 1 && H->n == 0) gc_stats.simple_cells += n; gc_stats.le64 += !st_long; gc_stats.dedup_steps += do_dedup; gc_stats.n_hist[gc_stats_bin(n)]++;)
 	GC_TICK(A, 12);
@@ -1577,8 +1893,22 @@ GC_HD int gc_gw_step(gc_arena_t *A, gc_gw_t *z, uint32_t v1, int32_t off1, int *
 		}
 	}
 	GC_TICK(A, 13);
+	GC_COUNT(A, 6, B->n); GC_COUNT(A, 9, H->n);
 	GC_STAT(gc_stats.heads += H->n; gc_stats.out += B->n;)
-	if (do_dedup) GC_TRY(gc_gw_dedup(A, z, &B->n, B->a));
+	if (do_dedup) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GC_AB_NO_WAVE_DEDUP)
+		int handled = 0;
+		GC_COUNT(A, 7, z->done.n); GC_COUNT(A, 15, z->fresh.n);
+		GC_TRY(gc_intv_add_wave(A, &z->done, z->fresh.n, z->fresh.a)); /* this step's finished diagonals */
+		z->fresh.n = 0;
+		GC_TICK(A, 0);
+		GC_TRY(gc_gw_dedup_lds(A, z, B, &handled));
+		GC_COUNT(A, 10, handled ? 1 << 20 : 0); /* (profiling: high part of slot 10 = dedups done on LDS) */
+		if (!handled) GC_TRY(gc_gw_dedup_wave(A, z, B, &handled));
+		if (!handled)
+#endif
+		GC_TRY(gc_gw_dedup(A, z, &B->n, B->a));
+	}
 	GC_TICK(A, 14);
 	if (z->max_lag > 0 && B->n > z->max_chk && ((z->s + 1) & 0xf) == 0) B->n = gc_gw_prune(B->n, B->a, (uint32_t)z->max_lag, z->bw_dyn);
 	z->cur ^= 1;

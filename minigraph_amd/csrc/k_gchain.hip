@@ -214,10 +214,10 @@ struct gck_split_t {
 	int64_t *p3list;                           // offsets of the states, in the order part 1 finished them
 	gc_job_t *jobs; int64_t jobs_cap;
 	int32_t *mid; int64_t mid_cap;             // inner vertices of the bridges' walks
-	unsigned long long *sctl;                  // [0] state bytes used, [1] jobs listed, [2] vertices used, [3] states listed, [4] next state of part 3, [8..11] next job of part 2 per length class
+	unsigned long long *sctl;                  // [0] state bytes used, [1] jobs listed, [2] vertices used, [3] states listed, [4] next state of part 3, [8..15] next job of part 2 per length class
 };
 #define GCS_A16(x) (((int64_t)(x) + 15) & ~(int64_t)15)
-#define GCS_N_CLASS 3
+#define GCS_N_CLASS 8
 struct gcs_view_t { gcs_hdr_t *h; mg128_t *a; gc_chain_t *c; uint64_t *u2; int32_t *kept; gc_rec_t *gc; int64_t bytes; };
 // where the arrays of a block with these counts lie (one definition for the writer, the readers and the host's emulation of the hand-over)
 __host__ __device__ inline void gcs_view(char *blk, int32_t n_b, int32_t n_c, int32_t n_u2, int32_t n_gc, gcs_view_t *v)
@@ -258,7 +258,11 @@ __host__ __device__ inline void gcs_setup_p3(char *blk, mg128_t *res_a, gc_read_
 	R->n_gc = h->n_gc, R->n_lc = R->n_a = 0, R->gc = v.gc, R->lc = 0, R->a = res_a, R->n_gwfa = R->n_fast = 0, R->n_shortk = h->n_shortk;
 	sp->c = v.c, sp->u2 = v.u2, sp->kept = v.kept, sp->n_c = h->n_c, sp->n_u2 = h->n_u2, sp->n_jobs = h->n_jobs, sp->done = 0;
 }
-__device__ __forceinline__ int gcs_job_class(const gc_job_t *q) { const int32_t ql = (q->c1->qs + q->span) - (q->c0->qe - q->span); return ql >= 1200 ? 0 : ql >= 300 ? 1 : 2; } // query gap of the bridge
+__device__ __forceinline__ int gcs_job_class(const gc_job_t *q) // by the query gap of the bridge, longest first (the gap is what is known beforehand of a bridge's cost)
+{
+	const int32_t ql = (q->c1->qs + q->span) - (q->c0->qe - q->span);
+	return ql >= 1600 ? 0 : ql >= 1100 ? 1 : ql >= 800 ? 2 : ql >= 600 ? 3 : ql >= 450 ? 4 : ql >= 300 ? 5 : ql >= 150 ? 6 : 7;
+}
 
 // A value every lane holds alike, as a SCALAR: branches on it are scalar branches.  The persistent loops below fetch their work with one lane's atomic; when the fetched index
 // stayed a per-lane value (__shfl), the compiler treated every `continue` / `break` of the loop as divergent and restructured it into nested exec-mask loops -- [measured, round 4]
@@ -367,7 +371,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GC_AB_P
 	}
 }
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GC_AB_P2_WAVES, 8))) k_gchain_p2(gck_split_t S_arg, gc_graph_t G_arg, gc_par_t P_arg, char *arena_mem, int64_t arena_bytes, unsigned long long *ctl)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GC_AB_P2_WAVES, 8))) k_gchain_p2(gck_split_t S_arg, gc_graph_t G_arg, gc_par_t P_arg, char *arena_mem, int64_t arena_bytes, unsigned long long *ctl, long long only_job)
 {
 	GCK_ARGS_TO_LDS(0, 1);
 	const int lane = threadIdx.x;
@@ -383,17 +387,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GC_AB_P
 	long long n_jobs = gck_uni64((long long)S.sctl[1]);
 	if (n_jobs > S.jobs_cap) n_jobs = gck_uni64(S.jobs_cap);
 	for (int cls = 0; cls < GCS_N_CLASS; ++cls) { // long query gaps first: the launch ends with the short ones
-		const int quantum = cls == 0 ? 64 : cls == 1 ? 16 : 4; // jobs looked at per reservation (a class's jobs are a fraction of them; the last class must not hand a wavefront a long run)
+		const int quantum = cls < 4 ? 64 : cls < 6 ? 16 : 4; // jobs looked at per reservation (a class's jobs are a fraction of them; the last classes must not hand a wavefront a long run)
 		for (;;) {
 			long long base = 0;
 			if (lane == 0) base = (long long)atomicAdd(&S.sctl[8 + cls], (unsigned long long)quantum);
 			base = gck_uni64(base);
 			if (base >= n_jobs) break;
-			uint64_t todo = __ballot(lane < quantum && base + lane < n_jobs && gcs_job_class(&S.jobs[base + lane]) == cls);
+			uint64_t todo = __ballot(lane < quantum && base + lane < n_jobs && gcs_job_class(&S.jobs[base + lane]) == cls && (only_job < 0 || base + lane == only_job));
 			while (todo) {
 				gc_job_t *q = &S.jobs[base + (__ffsll((long long)todo) - 1)];
 				todo &= todo - 1;
 				gc_bres_t b;
+				const long long t_job0 = (long long)clock64();
 				gc_arena_init(&A, my_arena, arena_bytes, 0);
 				if (ctl[15]) A.ticks = ctl + 16, A.tick_last = (long long)clock64();
 				gc_job_run(&A, &G, &P, q, &b); // (its status lands in the job)
@@ -405,7 +410,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GC_AB_P
 					if (mo + b.n_mid > S.mid_cap) st = GC_JOB_ARENA;
 					else { gck_copy_words(S.mid + mo, b.mid, (int64_t)b.n_mid * 4, lane); if (lane == 0) q->mid_off = mo; }
 				}
-				if (lane == 0) { q->status = st; atomicMax(&ctl[7], (unsigned long long)A.peak); }
+				if (lane == 0) { q->status = st; q->n_fast = (int32_t)(((long long)clock64() - t_job0) >> 10); atomicMax(&ctl[7], (unsigned long long)A.peak); } // (n_fast: the job's duration in 1024-cycle units, a profiling aid)
 				mga_wave_sync();
 			}
 		}
@@ -523,12 +528,12 @@ extern "C" int mga_dev_gchain(mga_sctx_t *sc, const mga_didx_t *ix, const mg_map
 		S.state = sb + o_state, S.state_cap = state_cap;
 		static int dbg = -1; // MGA_GC_SPLIT_DEBUG=1: wait behind every part and print the chunk's counters
 		if (dbg < 0) { const char *e = getenv("MGA_GC_SPLIT_DEBUG"); dbg = e ? atoi(e) : 0; }
-#define GCS_DBG(what) do { if (dbg) { unsigned long long c_[12], k_[4] = { 0, 0, 0, 0 }; const double t_ = mga_wtime(); hipError_t e_ = hipErrorNotReady; \
+#define GCS_DBG(what) do { if (dbg) { unsigned long long c_[16], k_[4] = { 0, 0, 0, 0 }; const double t_ = mga_wtime(); hipError_t e_ = hipErrorNotReady; \
 			while (mga_wtime() - t_ < 4.0 && (e_ = hipStreamQuery((hipStream_t)sc->stream)) == hipErrorNotReady) {} \
 			if (e_ == hipErrorNotReady) { hipStream_t s2_; (void)hipStreamCreateWithFlags(&s2_, hipStreamNonBlocking); (void)hipMemcpyAsync(k_, d_ctl, 32, hipMemcpyDeviceToHost, s2_); (void)hipMemcpyAsync(c_, sb, sizeof c_, hipMemcpyDeviceToHost, s2_); (void)hipStreamSynchronize(s2_); \
-				fprintf(stderr, "[gc-split] %s: STILL RUNNING after 4 s; n %d waves %d/%d ctl[0..3] %llu %llu %llu %llu; state bytes %llu jobs %llu vertices %llu states %llu next3 %llu next2 %llu/%llu/%llu\n", what, n, waves1, waves2, k_[0], k_[1], k_[2], k_[3], c_[0], c_[1], c_[2], c_[3], c_[4], c_[8], c_[9], c_[10]); _exit(3); } \
+				fprintf(stderr, "[gc-split] %s: STILL RUNNING after 4 s; n %d waves %d/%d ctl[0..3] %llu %llu %llu %llu; state bytes %llu jobs %llu vertices %llu states %llu next3 %llu next2 %llu/%llu/%llu\n", what, n, waves1, waves2, k_[0], k_[1], k_[2], k_[3], c_[0], c_[1], c_[2], c_[3], c_[4], c_[8], c_[9], c_[15]); _exit(3); } \
 			if (e_ == hipSuccess) e_ = hipMemcpy(c_, sb, sizeof c_, hipMemcpyDeviceToHost); \
-			fprintf(stderr, "[gc-split] %s: %s after %.1f ms; n %d state bytes %llu jobs %llu vertices %llu states %llu next3 %llu next2 %llu/%llu/%llu\n", what, hipGetErrorString(e_), (mga_wtime() - t_) * 1e3, n, c_[0], c_[1], c_[2], c_[3], c_[4], c_[8], c_[9], c_[10]); } } while (0)
+			fprintf(stderr, "[gc-split] %s: %s after %.1f ms; n %d state bytes %llu jobs %llu vertices %llu states %llu next3 %llu next2 %llu/%llu/%llu\n", what, hipGetErrorString(e_), (mga_wtime() - t_) * 1e3, n, c_[0], c_[1], c_[2], c_[3], c_[4], c_[8], c_[9], c_[15]); } } while (0)
 		MGA_HIP_CHECK(hipMemsetAsync(sb, 0, 256, (hipStream_t)sc->stream));
 		GCS_DBG("start");
 		mga_prof_begin(sc->stream, MGA_K_GCHAIN);
@@ -536,9 +541,41 @@ extern "C" int mga_dev_gchain(mga_sctx_t *sc, const mga_didx_t *ix, const mg_map
 		mga_prof_end(sc->stream, MGA_K_GCHAIN);
 		GCS_DBG("part 1");
 		mga_prof_begin(sc->stream, MGA_K_GCHAIN2);
-		hipLaunchKernelGGL(k_gchain_p2, dim3(waves2), dim3(64), 0, (hipStream_t)sc->stream, S, G, P, (char*)arena->p, (int64_t)ab, d_ctl);
+		hipLaunchKernelGGL(k_gchain_p2, dim3(waves2), dim3(64), 0, (hipStream_t)sc->stream, S, G, P, (char*)arena->p, (int64_t)ab, d_ctl, -1LL);
 		mga_prof_end(sc->stream, MGA_K_GCHAIN2);
 		GCS_DBG("part 2");
+		if (dbg >= 2) { // where part 2's time goes: the bridges by duration
+			unsigned long long c_[4];
+			if (hipMemcpy(c_, sb, sizeof c_, hipMemcpyDeviceToHost) == hipSuccess && c_[1] > 0) {
+				const size_t nj = (size_t)(c_[1] < (unsigned long long)jobs_cap ? c_[1] : (unsigned long long)jobs_cap);
+				gc_job_t *hj = (gc_job_t*)malloc(nj * sizeof(gc_job_t));
+				gc_chain_t *hc = (gc_chain_t*)malloc(nj * 2 * sizeof(gc_chain_t));
+				if (hipMemcpy(hj, S.jobs, nj * sizeof(gc_job_t), hipMemcpyDeviceToHost) == hipSuccess) {
+					double sum = 0; long long mx = 0; size_t imx = 0, hist[12] = { 0 };
+					for (size_t i_ = 0; i_ < nj; ++i_) { const long long t_ = (long long)hj[i_].n_fast << 10; sum += (double)t_; if (t_ > mx) mx = t_, imx = i_; int b_ = 0; long long x_ = t_ >> 14; while (x_ > 0 && b_ < 11) x_ >>= 1, ++b_; hist[b_]++; }
+					(void)hipMemcpy(&hc[0], hj[imx].c0, sizeof(gc_chain_t), hipMemcpyDeviceToHost); (void)hipMemcpy(&hc[1], hj[imx].c1, sizeof(gc_chain_t), hipMemcpyDeviceToHost);
+					fprintf(stderr, "[gc-split] part 2: %zu bridges, %.1f Mcycles in all (%.0f per wavefront of %d), longest %.2f Mcycles (query gap %d, ed %d, %d inner vertices, %d graph searches); by duration (<16k, <32k, ... cycles):", nj, sum * 1e-6, sum / waves2, waves2,
+							mx * 1e-6, (hc[1].qs + hj[imx].span) - (hc[0].qe - hj[imx].span), hj[imx].ed, hj[imx].n_mid, hj[imx].n_shortk);
+					for (int b_ = 0; b_ < 12; ++b_) fprintf(stderr, " %zu", hist[b_]);
+					fprintf(stderr, "\n");
+					{ // the longest bridge once more, ALONE on the device, with per-stage cycle sums and counts
+						unsigned long long z_[32], one_ = 1, tk_[16];
+						memset(z_, 0, sizeof z_);
+						(void)hipMemcpy(sb + 64, z_, 64, hipMemcpyHostToDevice);          // job counters of the classes
+						(void)hipMemcpy(d_ctl + 16, z_, 128, hipMemcpyHostToDevice); (void)hipMemcpy(d_ctl + 15, &one_, 8, hipMemcpyHostToDevice);
+						const double t1_ = mga_wtime();
+						hipLaunchKernelGGL(k_gchain_p2, dim3(1), dim3(64), 0, (hipStream_t)sc->stream, S, G, P, (char*)arena->p, (int64_t)ab, d_ctl, (long long)imx);
+						(void)hipStreamSynchronize((hipStream_t)sc->stream);
+						const double t2_ = mga_wtime();
+						(void)hipMemcpy(tk_, d_ctl + 16, 128, hipMemcpyDeviceToHost);
+						z_[0] = 0; (void)hipMemcpy(d_ctl + 15, z_, 8, hipMemcpyHostToDevice); (void)hipMemcpy(d_ctl + 16, z_, 128, hipMemcpyHostToDevice);
+						fprintf(stderr, "[gc-split] the longest bridge alone: %.2f ms; steps %llu, cells in %llu, runs %llu, head cells %llu (%llu with those added on the way), cells out %llu, sorts %llu, finished ranges %llu + %llu new, %llu dedups on LDS; Mcycles: clear %.2f runs %.2f heads %.2f ranges %.2f dedup %.2f rest %.2f\n",
+								(t2_ - t1_) * 1e3, tk_[1], tk_[2], tk_[3], tk_[4], tk_[9], tk_[6], tk_[10] & 0xfffffULL, tk_[7], tk_[15], tk_[10] >> 20, tk_[11] * 1e-6, tk_[12] * 1e-6, tk_[13] * 1e-6, tk_[0] * 1e-6, tk_[14] * 1e-6, tk_[8] * 1e-6);
+					}
+				}
+				free(hj); free(hc);
+			}
+		}
 		mga_prof_begin(sc->stream, MGA_K_GCHAIN3);
 		hipLaunchKernelGGL(k_gchain_p3, dim3(waves3), dim3(64), 0, (hipStream_t)sc->stream, in, out, S, G, P, (char*)arena->p, (int64_t)ab);
 		mga_prof_end(sc->stream, MGA_K_GCHAIN3);
