@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--resident-steps", type=int, default=2)
     ap.add_argument("--threads", type=int, default=0, help="host threads per rank (0: min(64, usable cores / ranks))")
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--no-rank-share", action="store_true", help="N=1: skip the `rank_share` block (device placement with the process pinned to 1/8 of the usable cores)")
+    ap.add_argument("--share", type=int, default=8, help="rank_share: the node's ranks the usable cores are divided among")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1: nccl (= RCCL over xGMI, the default) or gloo (host tensors: lets one GPU box run 2 ranks on the same device to test the sharded path)")
     args = ap.parse_args()
 
@@ -200,9 +202,11 @@ def main():
 
     last = {}
 
+    nthr = [threads]   # (the rank_share block runs the same step with a rank's share of the threads)
+
     def step():
         if dist is None:   # (the output buffer of the previous step is handed back for reuse, like a writer thread would recycle its buffers)
-            last["gaf"] = mga.map_files_idx(G, [reads_path], n_threads=threads, reuse=last.get("gaf"))
+            last["gaf"] = mga.map_files_idx(G, [reads_path], n_threads=nthr[0], reuse=last.get("gaf"))
         elif args.no_gather:
             last["gaf"] = mga.map_files_idx(G, [reads_path], n_threads=threads, rank=rank, world=world, reuse=last.get("gaf"))
         else:  # one input -> N GPUs -> one GAF on rank 0: size table all_gather + one RCCL gather of the bytes
@@ -265,6 +269,44 @@ def main():
         dt_o, st_o, host_o = timed(1, k_other)
         other = dict(dt=dt_o, steps=k_other, st=st_o, host=host_o, gaf=last_gaf())
         os.environ.pop("MGA_DEV_GCHAIN", None)
+    # ---- rank_share (N = 1): what ONE rank of an 8-GPU node gets of this box -- the device placement with 1/8 of the usable cores: every thread of the process (the HIP
+    #      runtime's included) pinned to that many CPUs, as many host threads.  Timed by the same function as the headline. ----
+    share = None
+    if dist is None and not args.no_rank_share and not args.one_placement:
+        cores_share = max(1, quota // max(1, args.share))
+        allowed, before = sorted(os.sched_getaffinity(0)), {}
+        try:
+            pin = set(allowed[:cores_share])
+            tids = [int(t) for t in os.listdir("/proc/self/task")]
+            for t in tids:
+                try:
+                    before[t] = os.sched_getaffinity(t)
+                    os.sched_setaffinity(t, pin)
+                except OSError:
+                    pass
+            L.mga_idx_stream_close.argtypes = [ctypes.c_void_p]
+            L.mga_idx_stream_close(G.gi)          # the index's pipeline threads are created anew, inside the pinned set
+            os.environ["MGA_DEV_GCHAIN"] = "1"
+            nthr[0] = max(2, cores_share)
+            k_share = max(1, min(args.steps, 3))
+            dt_s, st_s, host_s = timed(1, k_share)
+            share = dict(value=st_s["n_bases"] / dt_s / 1e9, unit="Gbp/s", ms_per_step=dt_s / k_share * 1e3, steps=k_share, warmup=1, cores_pinned=cores_share, host_threads=nthr[0],
+                         note="device placement of graph chaining + gap list; the whole process pinned to %d of the %d usable cores (1/%d: a rank's share of this box on a node of %d GPUs)"
+                              % (cores_share, quota, args.share, args.share), gaf=last_gaf(), **host_s)
+        finally:
+            nthr[0] = threads
+            os.environ.pop("MGA_DEV_GCHAIN", None)
+            for t, m in before.items():
+                try:
+                    os.sched_setaffinity(t, m)
+                except OSError:
+                    pass
+            for t in os.listdir("/proc/self/task"):   # threads born while pinned
+                try:
+                    os.sched_setaffinity(int(t), set(allowed))
+                except OSError:
+                    pass
+            L.mga_idx_stream_close(G.gi)
     n_reads_rank, n_bases_rank = st["n_reads"] // max(1, args.steps), st["n_bases"] // max(1, args.steps)
     if dist is not None:
         tb = torch.tensor([n_bases_rank, n_reads_rank] + [st[k] for k in ("n_mz", "n_hit", "wfa_t_bases", "wfa_q_bases", "gaf_bytes")], dtype=torch.int64, device=coll_dev)
@@ -417,6 +459,12 @@ def main():
                             forced_by="MGA_DEV_GCHAIN=%d" % (0 if default_dev else 1), **other["host"])
             if isolated_other:
                 res[key]["kernels_ms_isolated"] = {k: round(v[0], 3) for k, v in isolated_other["prof"].items() if v[0] > 0}
+        share_gaf = None
+        if share is not None:
+            share_gaf = share.pop("gaf")
+            dp = res.get("device_placement", {}).get("value") if not default_dev else value
+            share["vs_device_placement"] = round(share["value"] / dp, 3) if dp else None
+            res["rank_share"] = share
         ref_bin = os.path.join(ROOT, "oracle", "_ref", "minigraph")
         if not args.no_cpu and os.path.exists(ref_bin):
             try:
@@ -428,6 +476,8 @@ def main():
                     return len(got) >= len(want) and got[:len(want)] == want and (len(got) == len(want) or got[len(want) - 1:len(want)] == b"\n")
                 if gaf_first is not None:
                     res["parity"] = ("GAF byte-identical to the reference on ALL %d reads of the CPU sample (%d bytes)" % (n_cpu, len(want))) if same(gaf_first) else "MISMATCH vs reference GAF"
+                if share_gaf is not None:
+                    res["rank_share"]["parity"] = ("GAF byte-identical to the reference on ALL %d reads of the CPU sample (%d bytes)" % (n_cpu, len(want))) if same(share_gaf) else "MISMATCH vs reference GAF"
                 if other is not None and other["gaf"] is not None:
                     res["host_placement" if default_dev else "device_placement"]["parity"] = \
                         ("GAF byte-identical to the reference on ALL %d reads of the CPU sample (%d bytes)" % (n_cpu, len(want))) if same(other["gaf"]) else "MISMATCH vs reference GAF"

@@ -304,6 +304,7 @@ typedef struct {
 	int64_t n_rescue_dev, n_rescue_host; /* long-join rescues done by the chaining kernel / deferred to the host tree */
 	int64_t n_gwfa, n_shortk, n_gc_retry, gc_arena_peak; /* graph chaining on the device: GWFA bridges, shortest-walk searches, reads re-run in the large arenas, largest arena use (bytes) */
 	int64_t n_wfa_dev_plan;  /* gaps (of n_wfa) listed by the device itself (k_plan.hip) rather than by host threads */
+	int64_t n_gc_host;       /* reads whose graph chaining the device gave up on even in the large arenas: chained by the host threads */
 } mga_stats_t;
 void mga_get_stats(const mg_idx_t *gi, mga_stats_t *st, int reset);
 

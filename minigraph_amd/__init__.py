@@ -69,7 +69,7 @@ class stats_t(C.Structure):  # mga_stats_t
     _fields_ = [(n, C.c_int64) for n in ("n_reads", "n_bases", "n_mz", "n_probe", "n_hit", "n_anchor_chained", "n_wfa",
                                          "wfa_t_bases", "wfa_q_bases", "wfa_cells", "gaf_bytes")] + \
                [(n, C.c_double) for n in ("t_sketch", "t_seed", "t_lchain", "t_host_chain", "t_wfa", "t_host_post", "t_gaf")] + \
-               [(n, C.c_int64) for n in ("n_rescue_dev", "n_rescue_host", "n_gwfa", "n_shortk", "n_gc_retry", "gc_arena_peak", "n_wfa_dev_plan")]
+               [(n, C.c_int64) for n in ("n_rescue_dev", "n_rescue_host", "n_gwfa", "n_shortk", "n_gc_retry", "gc_arena_peak", "n_wfa_dev_plan", "n_gc_host")]
 
 
 def load():

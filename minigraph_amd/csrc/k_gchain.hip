@@ -80,8 +80,14 @@ struct gck_out_t {
 
 #define GCK_FAST_BYTES 16384 // LDS scratch per wavefront: two waves per SIMD = eight per CU = 128 KB of the CU's 160
 
-__device__ __forceinline__ void gck_copy_words(void *dst, const void *src, int64_t bytes, int lane) // both 4-byte aligned
+__device__ __forceinline__ void gck_copy_words(void *dst, const void *src, int64_t bytes, int lane) // both 4-byte aligned; 16-byte records at 16-byte addresses move as such
 {
+	if ((((uintptr_t)dst | (uintptr_t)src | (uintptr_t)bytes) & 15) == 0) {
+		uint4 *d = (uint4*)dst;
+		const uint4 *s = (const uint4*)src;
+		for (int64_t i = lane, n = bytes >> 4; i < n; i += 64) d[i] = s[i];
+		return;
+	}
 	uint32_t *d = (uint32_t*)dst;
 	const uint32_t *s = (const uint32_t*)src;
 	for (int64_t i = lane, n = bytes >> 2; i < n; i += 64) d[i] = s[i];
@@ -229,6 +235,13 @@ __host__ __device__ inline void gcs_view(char *blk, int32_t n_b, int32_t n_c, in
 }
 __host__ __device__ inline void gcs_copy_words(void *dst, const void *src, int64_t bytes, int lane, int n_lane) // both 4-byte aligned
 {
+	if ((((uintptr_t)dst | (uintptr_t)src | (uintptr_t)bytes) & 15) == 0) {
+		typedef struct __attribute__((aligned(16))) { uint64_t a, b; } w16_t;
+		w16_t *d16 = (w16_t*)dst;
+		const w16_t *s16 = (const w16_t*)src;
+		for (int64_t i = lane, n = bytes >> 4; i < n; i += n_lane) d16[i] = s16[i];
+		return;
+	}
 	uint32_t *d = (uint32_t*)dst;
 	const uint32_t *s = (const uint32_t*)src;
 	for (int64_t i = lane, n = bytes >> 2; i < n; i += n_lane) d[i] = s[i];

@@ -537,7 +537,7 @@ static int batch_finish(mga_batch_t *b)
 	if (!(b->opt.flag & MG_M_CIGAR)) return 0;
 	b->err = 0;
 	mga_parallel_for(b->n_threads, b->n, finish_worker, b);
-	if (b->err == -1) mga_set_error("a gap exceeded miniwfa's max_iter (1e8 cells): the k-mer chaining heuristic of mwf_wfa_chain (miniwfa.c:776-822) is not implemented on this path yet");
+	if (b->err == -1) mga_set_error("a gap came back from the WFA ladder without an alignment (status != OK): the ladder's last tier or its chained fallback (k_wfa_sched.hip: wfs_fallback, miniwfa.c:776-834) gave up on it");
 	else if (b->err < 0) mga_set_error("stitched CIGAR is inconsistent with the chain coordinates");
 	return b->err;
 }
@@ -871,6 +871,14 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 					if ((int64_t)ctl[2] > lc_cap) ctl[2] = (unsigned long long)lc_cap;
 					if ((int64_t)ctl[6] > ga_cap) ctl[6] = (unsigned long long)ga_cap;
 					st->n_gc_retry += n_retry;
+					{ /* reads the retry launch gave up on as well -- beyond the large arena, or the record pools ran out while it ran -- are chained by the host threads: counted, and said once */
+						const long long n_again = (long long)ctl[3];
+						if (n_again > 0) {
+							static int warned = 0;
+							st->n_gc_host += n_again;
+							if (mg_verbose >= 2 && !warned) { warned = 1; fprintf(stderr, "[W::%s] graph chaining on the device: %lld of %lld retried reads go to the host threads (record pools %lld/%lld %lld/%lld %lld/%lld)\n", __func__, n_again, (long long)n_retry, (long long)ctl[1], (long long)gc_cap, (long long)ctl[2], (long long)lc_cap, (long long)ctl[6], (long long)ga_cap); }
+						}
+					}
 				}
 				break;
 			}
@@ -1145,7 +1153,7 @@ static void stats_merge(mga_stats_t *d, const mga_stats_t *s)
 	d->t_sketch += s->t_sketch, d->t_seed += s->t_seed, d->t_lchain += s->t_lchain, d->t_host_chain += s->t_host_chain, d->t_wfa += s->t_wfa, d->t_host_post += s->t_host_post;
 	d->t_gaf += s->t_gaf;
 	d->n_rescue_dev += s->n_rescue_dev, d->n_rescue_host += s->n_rescue_host;
-	d->n_gwfa += s->n_gwfa, d->n_shortk += s->n_shortk, d->n_gc_retry += s->n_gc_retry;
+	d->n_gwfa += s->n_gwfa, d->n_shortk += s->n_shortk, d->n_gc_retry += s->n_gc_retry, d->n_gc_host += s->n_gc_host;
 	if (s->gc_arena_peak > d->gc_arena_peak) d->gc_arena_peak = s->gc_arena_peak;
 	d->n_wfa_dev_plan += s->n_wfa_dev_plan;
 	d->gaf_bytes += s->gaf_bytes;

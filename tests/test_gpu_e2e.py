@@ -841,3 +841,42 @@ def test_text_pool_is_regrown_and_relaunched(monkeypatch):
     R.close()
     G.close()
     assert got == want and want.count(b"\tcg:Z:") >= 490
+
+
+def test_device_placement_is_deterministic_over_repeated_runs(monkeypatch):
+    """the all-device placement (k_gchain_p1 / p2 / p3, k_plan, the windowed WFA ladder with its device-side work lists and atomically
+    reserved pools, k_text) maps ONE workload 20 times: every run gives the same bytes, and they are the reference's.  Atomics only hand out PLACES (pool offsets, list
+    slots, job order); nothing a place decides may reach the output.  A second sweep runs with few resident wavefronts and small job quanta so that the order in which
+    reads / bridges / gaps are picked up differs from the first."""
+    need_ref()
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "12000000", "-c", "2", "-H", "5", "-n", "4000", "-s", "71"], stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    ref_out = os.path.join(d, "ref.gaf")
+    run_ref(["-c", "-x", "lr", "-t", "8", graph, reads], ref_out)
+    want = hashlib.md5(open(ref_out, "rb").read()).hexdigest()
+    monkeypatch.setenv("MGA_DEV_GCHAIN", "1")
+    G = mga.Graph(graph, preset="lr", cigar=True, n_threads=4)
+    seen = set()
+    for it in range(20):
+        m = mga.map_files_idx(G, [reads], n_threads=4)
+        seen.add(hashlib.md5(m.view().tobytes()).hexdigest())
+        m.free()
+    assert seen == {want}, seen
+    st = mga.get_stats(G)
+    assert st["n_gwfa"] > 0 and st["n_wfa_dev_plan"] > 0   # the device did chain and plan
+    G.close()
+    monkeypatch.setenv("MGA_GC_WAVES", "96")     # other pick-up orders: 96 resident wavefronts per part, chunks of 1000 reads, two chunks in flight
+    monkeypatch.setenv("MGA_GC_WAVES2", "160")
+    monkeypatch.setenv("MGA_CHUNK", "1000")
+    code = ("import sys, hashlib; sys.path.insert(0, %r); import minigraph_amd as mga\n"
+            "G = mga.Graph(sys.argv[1], preset='lr', cigar=True, n_threads=4)\n"
+            "s = set()\n"
+            "for it in range(6):\n"
+            "    m = mga.map_files_idx(G, [sys.argv[2]], n_threads=4); s.add(hashlib.md5(m.view().tobytes()).hexdigest()); m.free()\n"
+            "print('SEEN', ' '.join(sorted(s)))\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import sys
+    p = subprocess.run([sys.executable, "-c", code, graph, reads], env=dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)   # (a child: the knobs are read once)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = [l for l in p.stdout.decode().splitlines() if l.startswith("SEEN")][0].split()[1:]
+    assert line == [want], line
