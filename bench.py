@@ -71,6 +71,36 @@ def cpu_baseline(ref_bin, graph, reads_fa, n_reads, out_dir, threads, cores):
                 sample="%d reads (%d bp) of the same workload, minigraph -cx lr -t %d on %d usable cores (affinity capped by the cgroup CPU quota), map phase only (worker_pipeline - mg_opt_update: FASTA parse + mapping + GAF write, as in `value`)" % (n, bases, threads, cores)), gaf, n
 
 
+def asm_block(mga, d, genome, threads, ref_bin):
+    """`-cx asm`: ten contigs of genome/10 bp (0.1 %% divergence from the haplotype walks) against a 3-haplotype bubble graph of `genome` backbone bp in 10 chromosomes;
+    the whole job file -> file (GFA parse, index, mapping, GAF) here and in the unmodified reference on the same cores; the two GAF files must be the same bytes."""
+    pre = os.path.join(d, "asm")
+    contig = genome // 10
+    subprocess.run([mga.MGSIM, "-p", pre, "-G", str(genome), "-c", "10", "-H", "3", "-n", "10", "-l", str(contig), "-e", "0.001", "-s", "5"], stderr=subprocess.DEVNULL, check=True)
+    g, r, got, ref = pre + ".gfa", pre + ".reads.fa", pre + ".got.gaf", pre + ".ref.gaf"
+    t0 = time.time()
+    mga.map_files(g, [r], got, preset="asm", cigar=True, n_threads=threads, verbose=0)
+    t_ours = time.time() - t0
+    out = dict(workload="-cx asm: 10 contigs x %d bp (%.0f Mbp of query, 0.1%% divergence) vs a %.0f Mbp-backbone 3-haplotype bubble graph in 10 chromosomes" % (contig, contig * 10 / 1e6, genome / 1e6),
+               interval="file -> file: GFA parse + index + mapping + GAF, on both sides", seconds=round(t_ours, 2), query_Mbp_per_s=round(contig * 10 / 1e6 / t_ours, 1),
+               gaf_bytes=os.path.getsize(got), host_threads=threads,
+               note="the primary chainer under -x asm (mg_lchain_rmq, lchain.c:252-372) runs on the host threads, split into (segment, strand) runs; sketch, seeds, WFA and text on the device")
+    if ref_bin and os.path.exists(ref_bin):
+        t0 = time.time()
+        with open(ref, "wb") as fo:
+            subprocess.run([ref_bin, "-c", "-x", "asm", "-t", str(threads), g, r], stdout=fo, stderr=subprocess.DEVNULL, check=True)
+        t_ref = time.time() - t0
+        out["reference_seconds"] = round(t_ref, 2)
+        out["vs_reference"] = round(t_ref / t_ours, 2)
+        out["parity"] = "GAF byte-identical to the reference" if subprocess.call(["cmp", "-s", got, ref]) == 0 else "MISMATCH vs reference GAF"
+    for f in (g, r, got, ref, pre + ".lin.fa"):
+        try:
+            os.remove(f)
+        except OSError:
+            pass
+    return out
+
+
 def usable_cores():
     """cores this process may actually burn: the affinity mask capped by the cgroup CPU quota (cpu.max)"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -114,6 +144,8 @@ def main():
     ap.add_argument("--resident-steps", type=int, default=2)
     ap.add_argument("--threads", type=int, default=0, help="host threads per rank (0: min(64, usable cores / ranks))")
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--no-asm", action="store_true", help="N=1: skip the `asm` block (BASELINE configs[4] shape: -cx asm, 10 x 50 Mbp contigs vs a 500 Mbp graph, file -> file next to the reference)")
+    ap.add_argument("--asm-genome", type=int, default=500000000)
     ap.add_argument("--no-rank-share", action="store_true", help="N=1: skip the `rank_share` block (device placement with the process pinned to 1/8 of the usable cores)")
     ap.add_argument("--share", type=int, default=8, help="rank_share: the node's ranks the usable cores are divided among")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1: nccl (= RCCL over xGMI, the default) or gloo (host tensors: lets one GPU box run 2 ranks on the same device to test the sharded path)")
@@ -486,6 +518,11 @@ def main():
         else:
             res["cpu_baseline"] = dict(value=None, unit="Gbp/s", cores=quota, kind="reference",
                                        sample="not run (--no-cpu, or oracle/_ref/minigraph absent)")
+        if dist is None and not args.no_asm:   # ---- BASELINE configs[4] shape on one GPU: -cx asm on chromosome-scale contigs, file -> file, graph load + index on both sides ----
+            try:
+                res["asm"] = asm_block(mga, d, args.asm_genome, threads, None if args.no_cpu else ref_bin)
+            except Exception as e:
+                res["asm"] = dict(error=repr(e))
         print(json.dumps(res), flush=True)
     G.close()
     if dist is not None:

@@ -313,6 +313,13 @@ void mga_get_stats(const mg_idx_t *gi, mga_stats_t *st, int reset);
  * repeated runs and for the N ranks of a node.  The minimizer table is rebuilt on the device from the sequence (k, w stay load-time options).
  * The loaded index OWNS its graph (gi->g): mg_idx_destroy() releases it; do not gfa_destroy() it. ---- */
 int mga_graph_image_save(const gfa_t *g, const char *path);
+
+/* ---- ADDITIVE: mg_gchains_t across ranks (csrc/gcpack.c; SURVEY 8e, BASELINE configs[4]).  Under -x asm the contigs of a query file are sharded over the ranks of a node;
+ * what consumes the mappings -- mg_call_asm (asm-call.c:21), mg_ggsimple (ggsimple.c), mg_cov_asm -- wants all of the file's results, in input order, on one rank (what
+ * ggen_map fills r->gcs[] with, ggen.c:39-71).  pack: n results (NULL entries allowed) -> one malloc'ed, pointer-free buffer (*out, release with mga_free()), returns its
+ * size or -1; unpack: the objects again, each malloc-owned like mg_map()'s (release every one with mg_gchain_free(), the array with mga_free()); NULL on a corrupt buffer. ---- */
+int64_t mga_gchains_pack(int n, mg_gchains_t *const *gcs, void **out);
+mg_gchains_t **mga_gchains_unpack(const void *buf, int64_t bytes, int *n);
 mg_idx_t *mga_index_load_image(const char *path, const mg_idxopt_t *io, int n_threads, mg_mapopt_t *mo);
 
 /* ---- stage-level entry points (host pointers in, host pointers out; device work inside) ----

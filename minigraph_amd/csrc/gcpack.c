@@ -1,0 +1,139 @@
+/*
+ * gcpack.c -- mg_gchains_t across ranks (BASELINE configs[4]): under -x asm the contigs of a query file are sharded over the ranks of a node
+ * (one GPU each), and what consumes the mappings -- mg_call_asm (asm-call.c:21), the graph generation of ggsimple.c, mg_cov_asm -- wants ALL of a file's
+ * mg_gchains_t in input order on one rank (ggen_map, ggen.c:39-71 fills r->gcs[] for exactly that).  mga_gchains_pack() turns a rank's results into one
+ * flat, pointer-free buffer (what a gather moves); mga_gchains_unpack() rebuilds malloc-owned objects the reference's code reads and mg_gchain_free() releases.
+ *
+ * Layout (little endian, 8-byte aligned records):
+ *   uint64 magic, n
+ *   per read: int32 present, n_gc, n_lc, n_a, rep_len, pad[3]
+ *             gc[n_gc] as mg_gchain_t with the three pointers replaced by byte counts of what follows (0: absent)
+ *             lc[n_lc], a[n_a]
+ *             per chain: mg_cigar_t header + cigar[n_cigar] (if p), ds.off[n_off] + ds.ds[len + 1] (if ds.ds)
+ */
+#include "mga_host.h"
+
+#define GCP_MAGIC 0x31504347414d4d47ULL /* "GMMAGCP1" */
+
+typedef struct { int32_t present, n_gc, n_lc, n_a, rep_len, pad[3]; } gcp_read_t;
+typedef struct { char *p; size_t n, m; } gcp_buf_t;
+
+static int gcp_put(gcp_buf_t *b, const void *src, size_t bytes)
+{
+	const size_t pad = (8 - (bytes & 7)) & 7;
+	if (b->n + bytes + pad > b->m) {
+		size_t m = (b->n + bytes + pad) * 2 + 4096;
+		char *q = (char*)realloc(b->p, m);
+		if (q == 0) return -1;
+		b->p = q, b->m = m;
+	}
+	if (bytes) memcpy(b->p + b->n, src, bytes);
+	if (pad) memset(b->p + b->n + bytes, 0, pad);
+	b->n += bytes + pad;
+	return 0;
+}
+
+int64_t mga_gchains_pack(int n, mg_gchains_t *const *gcs, void **out)
+{
+	gcp_buf_t b = { 0, 0, 0 };
+	uint64_t hdr[2] = { GCP_MAGIC, (uint64_t)(n > 0 ? n : 0) };
+	int i, k;
+	*out = 0;
+	if (gcp_put(&b, hdr, sizeof hdr) < 0) goto fail;
+	for (i = 0; i < n; ++i) {
+		const mg_gchains_t *gs = gcs[i];
+		gcp_read_t r;
+		memset(&r, 0, sizeof r);
+		if (gs == 0) { if (gcp_put(&b, &r, sizeof r) < 0) goto fail; continue; } /* map-algo.c:356-360: no object for an empty / over-long read */
+		r.present = 1, r.n_gc = gs->n_gc, r.n_lc = gs->n_lc, r.n_a = gs->n_a, r.rep_len = gs->rep_len;
+		if (gcp_put(&b, &r, sizeof r) < 0) goto fail;
+		for (k = 0; k < gs->n_gc; ++k) { /* records with pointer fields turned into sizes */
+			mg_gchain_t g = gs->gc[k];
+			g.p = (mg_cigar_t*)(uintptr_t)(gs->gc[k].p ? sizeof(mg_cigar_t) + (size_t)gs->gc[k].p->n_cigar * 8 : 0);
+			g.ds.off = (int32_t*)(uintptr_t)(gs->gc[k].ds.ds ? (size_t)gs->gc[k].ds.n_off * 4 : 0);
+			g.ds.ds = (char*)(uintptr_t)(gs->gc[k].ds.ds ? (size_t)gs->gc[k].ds.len + 1 : 0);
+			if (gcp_put(&b, &g, sizeof g) < 0) goto fail;
+		}
+		if (gcp_put(&b, gs->lc, (size_t)gs->n_lc * sizeof(mg_llchain_t)) < 0 || gcp_put(&b, gs->a, (size_t)gs->n_a * sizeof(mg128_t)) < 0) goto fail;
+		for (k = 0; k < gs->n_gc; ++k) {
+			const mg_gchain_t *g = &gs->gc[k];
+			if (g->p && gcp_put(&b, g->p, sizeof(mg_cigar_t) + (size_t)g->p->n_cigar * 8) < 0) goto fail;
+			if (g->ds.ds && (gcp_put(&b, g->ds.off, (size_t)g->ds.n_off * 4) < 0 || gcp_put(&b, g->ds.ds, (size_t)g->ds.len + 1) < 0)) goto fail;
+		}
+	}
+	*out = b.p;
+	return (int64_t)b.n;
+fail:
+	free(b.p);
+	mga_set_error("mga_gchains_pack: out of memory");
+	return -1;
+}
+
+/* cursor over an untrusted buffer: every read is bounds-checked */
+typedef struct { const char *p; size_t n, at; } gcp_cur_t;
+static const void *gcp_get(gcp_cur_t *c, size_t bytes)
+{
+	const size_t pad = (8 - (bytes & 7)) & 7;
+	const void *r;
+	if (bytes > c->n - c->at || pad > c->n - c->at - bytes) return 0;
+	r = c->p + c->at;
+	c->at += bytes + pad;
+	return r;
+}
+
+static void *gcp_dup(const void *src, size_t bytes) { void *p = malloc(bytes ? bytes : 1); if (p && bytes) memcpy(p, src, bytes); return p; }
+
+mg_gchains_t **mga_gchains_unpack(const void *buf, int64_t bytes, int *n_out)
+{
+	gcp_cur_t c = { (const char*)buf, bytes > 0 ? (size_t)bytes : 0, 0 };
+	const uint64_t *hdr = (const uint64_t*)gcp_get(&c, 16);
+	mg_gchains_t **gcs = 0;
+	int64_t n, i;
+	int32_t k;
+	*n_out = 0;
+	if (hdr == 0 || hdr[0] != GCP_MAGIC || hdr[1] > 0x7fffffffULL) { mga_set_error("mga_gchains_unpack: not a packed chain buffer"); return 0; }
+	n = (int64_t)hdr[1];
+	if ((uint64_t)n > c.n / sizeof(gcp_read_t)) { mga_set_error("mga_gchains_unpack: truncated buffer"); return 0; }
+	gcs = MGA_CALLOC(mg_gchains_t*, n > 0 ? n : 1);
+	for (i = 0; i < n; ++i) {
+		const gcp_read_t *r = (const gcp_read_t*)gcp_get(&c, sizeof *r);
+		const mg_gchain_t *g;
+		const void *lc, *a;
+		mg_gchains_t *gs;
+		if (r == 0) goto bad;
+		if (!r->present) continue;
+		if (r->n_gc < 0 || r->n_lc < 0 || r->n_a < 0) goto bad;
+		g = (const mg_gchain_t*)gcp_get(&c, (size_t)r->n_gc * sizeof(mg_gchain_t));
+		lc = gcp_get(&c, (size_t)r->n_lc * sizeof(mg_llchain_t));
+		a = gcp_get(&c, (size_t)r->n_a * sizeof(mg128_t));
+		if (g == 0 || lc == 0 || a == 0) goto bad;
+		gs = gcs[i] = MGA_CALLOC(mg_gchains_t, 1);
+		gs->n_gc = r->n_gc, gs->n_lc = r->n_lc, gs->n_a = r->n_a, gs->rep_len = r->rep_len;
+		if (r->n_gc == 0) continue; /* gchain1.c:460: a valid object without chains owns no arrays */
+		gs->gc = (mg_gchain_t*)gcp_dup(g, (size_t)r->n_gc * sizeof(mg_gchain_t));
+		gs->lc = (mg_llchain_t*)gcp_dup(lc, (size_t)r->n_lc * sizeof(mg_llchain_t));
+		gs->a = (mg128_t*)gcp_dup(a, (size_t)r->n_a * sizeof(mg128_t));
+		for (k = 0; k < r->n_gc; ++k) gs->gc[k].p = 0, gs->gc[k].ds.off = 0, gs->gc[k].ds.ds = 0; /* (sizes so far: owned pointers from here on) */
+		for (k = 0; k < r->n_gc; ++k) {
+			const size_t pb = (size_t)(uintptr_t)g[k].p, ob = (size_t)(uintptr_t)g[k].ds.off, db = (size_t)(uintptr_t)g[k].ds.ds;
+			if (pb) {
+				const mg_cigar_t *p = (const mg_cigar_t*)gcp_get(&c, pb);
+				if (p == 0 || pb < sizeof(mg_cigar_t) || p->n_cigar < 0 || pb != sizeof(mg_cigar_t) + (size_t)p->n_cigar * 8) goto bad;
+				gs->gc[k].p = (mg_cigar_t*)gcp_dup(p, pb);
+			}
+			if (db) {
+				const void *off = gcp_get(&c, ob), *ds = gcp_get(&c, db);
+				if (off == 0 || ds == 0 || ob != (size_t)g[k].ds.n_off * 4 || db != (size_t)g[k].ds.len + 1) goto bad;
+				gs->gc[k].ds.off = (int32_t*)gcp_dup(off, ob);
+				gs->gc[k].ds.ds = (char*)gcp_dup(ds, db);
+			}
+		}
+	}
+	*n_out = (int)n;
+	return gcs;
+bad:
+	for (i = 0; i < n; ++i) mg_gchain_free(gcs[i]);
+	free(gcs);
+	mga_set_error("mga_gchains_unpack: truncated or corrupt buffer");
+	return 0;
+}

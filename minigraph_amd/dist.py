@@ -58,6 +58,39 @@ def gather_bytes(payload, dst=0, device="cpu", as_tensors=False, pin=False):
     return [out[r][:sizes[r]].cpu().numpy().tobytes() for r in range(world)]
 
 
+def gather_chains(gcs, n, dst=0):
+    """-x asm with the contigs of ONE query file sharded over the ranks (BASELINE configs[4]): every rank hands in the mg_gchains_t* of its own contigs
+    (`gcs`: ctypes array of n pointers, input order; contiguous shards, rank order = input order); rank `dst` gets the list of ALL ranks' objects in input order --
+    rebuilt, malloc-owned copies (mga_gchains_unpack), ready for what consumes a file's mappings (mg_call_asm, mg_ggsimple, mg_cov_asm: ggen.c:39-71,100-137) --
+    the other ranks get None.  One pack per rank, one variable-length gather (gather_bytes: RCCL on the GPU box, gloo in the CPU tests)."""
+    import ctypes as C
+    from . import load
+    L = load()
+    L.mga_gchains_pack.restype = C.c_int64
+    L.mga_gchains_pack.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.mga_gchains_unpack.restype = C.POINTER(C.c_void_p)
+    L.mga_gchains_unpack.argtypes = [C.c_char_p, C.c_int64, C.POINTER(C.c_int)]
+    L.mga_free.argtypes = [C.c_void_p]
+    buf = C.c_void_p()
+    nb = L.mga_gchains_pack(n, gcs, C.byref(buf))
+    if nb < 0:
+        raise RuntimeError("mga_gchains_pack failed: %s" % L.mga_last_error().decode())
+    data = C.string_at(buf, nb)
+    L.mga_free(buf)
+    parts = gather_bytes(data, dst=dst)
+    if parts is None:
+        return None
+    out = []
+    for p in parts:
+        k = C.c_int(0)
+        arr = L.mga_gchains_unpack(p, len(p), C.byref(k))
+        if not arr:
+            raise RuntimeError("mga_gchains_unpack failed: %s" % L.mga_last_error().decode())
+        out += [arr[i] for i in range(k.value)]
+        L.mga_free(arr)
+    return out
+
+
 def assemble_segments(parts, seg_lens):
     """rank-order concatenation PER SEGMENT: parts[r] = the bytes rank r produced (its segments back to back), seg_lens[r][s] = how many
     of them belong to output segment s (a memory-mapped FASTA file is one segment cut by byte range; any other input has one segment per

@@ -53,7 +53,7 @@ def run_reference(graph, reads, cigar=True, threads=4, preset="lr"):
     return p.stdout, int(m.group(1)), int(m.group(2))
 
 
-def map_with_oracle_stages(graph, reads, occ_max1, lc_max_occ, cigar=True, n_threads=4, preset="lr", per_read=False):
+def map_with_oracle_stages(graph, reads, occ_max1, lc_max_occ, cigar=True, n_threads=4, preset="lr", per_read=False, return_chains=False):
     """whole -cx lr (or -cx asm) job: oracle for the kernel stages, product C code for everything on the host.  Under asm the RMQ chainer
     is the primary chainer and runs in the product's host phases (mapper.c: rq_chain_all) on the oracle's sorted anchors"""
     L = mga.load()
@@ -141,6 +141,9 @@ def map_with_oracle_stages(graph, reads, occ_max1, lc_max_occ, cigar=True, n_thr
     POOL = np.ascontiguousarray(np.array(pool + [0], dtype=np.uint32))
     assert L.mga_batch_finish(b, res, POOL.ctypes.data) == 0
     gcs = L.mga_batch_take_results(b)
+    if return_chains:   # the mg_gchains_t* themselves (the caller frees them with mg_gchain_free): what ggen_map hands to --call / graph generation
+        L.mga_batch_destroy(b)
+        return dict(gcs=gcs, n=n, names=names, seqs=seqs, flag=mo.flag)
     ks = kstring_t(0, 0, None)
     out = []
     for i in range(n):

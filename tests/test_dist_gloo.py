@@ -109,3 +109,91 @@ def test_one_input_n_ranks_one_gaf(gz, world):
         p.join(60)
         assert p.exitcode == 0
     assert got == want
+
+
+def _call_worker(rank, world, port, q, graph, reads, occ, lco, out_path):
+    """-x asm, contigs sharded over the ranks: every rank maps its contiguous share of the contigs (the product's host pipeline, RMQ chainer included; the oracle stands in for
+    the kernels), the mg_gchains_t travel to rank 0 (mga_gchains_pack -> gather -> mga_gchains_unpack), and rank 0 feeds ALL of them, in input order, to the REFERENCE's own
+    mg_call_asm (asm-call.c:21: what --call runs behind ggen_map, ggen.c:127-137)"""
+    import ctypes as C
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import hostpipe as hp
+    import minigraph_amd as mga
+    import refbind as rb
+    from minigraph_amd.dist import gather_chains
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    names, seqs = hp.read_fa(reads)
+    st, en = shard_range(len(names), rank, world)
+    shard = reads + ".call%d.fa" % rank
+    with open(shard, "wb") as f:
+        for i in range(st, en):
+            f.write(b">" + names[i] + b"\n" + seqs[i] + b"\n")
+    L = mga.load()
+    if en > st:
+        r = hp.map_with_oracle_stages(graph, shard, occ, lco, cigar=True, preset="asm", return_chains=True)
+        got = gather_chains(r["gcs"], r["n"], dst=0)
+        L.mg_gchain_free.argtypes = [C.c_void_p]
+        for i in range(r["n"]):
+            L.mg_gchain_free(r["gcs"][i])
+    else:
+        got = gather_chains(None, 0, dst=0)
+    if rank == 0:
+        assert len(got) == len(names)
+        R = rb.Ref().lib
+
+        class bseq1_t(C.Structure):  # mg_bseq1_t, bseq.h:14-17
+            _fields_ = [("l_seq", C.c_int32), ("rid", C.c_int32), ("name", C.c_char_p), ("seq", C.c_char_p), ("qual", C.c_char_p), ("comment", C.c_char_p)]
+        R.gfa_read.restype = C.c_void_p
+        R.mg_call_asm.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        g = R.gfa_read(graph.encode())
+        sq = (bseq1_t * len(names))()
+        for i in range(len(names)):
+            sq[i].l_seq, sq[i].rid, sq[i].name, sq[i].seq = len(seqs[i]), i, names[i], seqs[i]
+        arr = (C.c_void_p * len(got))(*got)
+        libc = C.CDLL(None)
+        libc.fflush(None)
+        fd = os.open(out_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        keep = os.dup(1)
+        os.dup2(fd, 1)
+        try:
+            R.mg_call_asm(g, len(names), sq, arr, 5, 100000)   # mg_ggopt_t defaults (options.c:52-54)
+            libc.fflush(None)
+        finally:
+            os.dup2(keep, 1)
+            os.close(fd)
+            os.close(keep)
+        q.put(len(got))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_asm_contigs_sharded_over_ranks_chains_gathered_for_call(world):
+    """BASELINE configs[4] / SURVEY 8e: `-cxasm --call` with the contigs sharded over the ranks and the chains gathered: the BED the reference's mg_call_asm prints from the
+    gathered objects is what the reference binary prints for the whole file"""
+    import hostpipe as hp
+    import minigraph_amd as mga
+    import refbind as rb
+    if not (rb.have_oracle() and os.path.exists(rb.REF_BIN)):
+        pytest.skip("oracle/_ref not built")
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "1500000", "-H", "3", "-n", "5", "-l", "400000", "-e", "0.002", "-s", "9"], stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    p = subprocess.run([rb.REF_BIN, "-cxasm", "--call", "-t", "4", graph, reads], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+    want = p.stdout
+    assert want.count(b"\n") > 20   # a BED line per bubble and contig
+    _, occ, lco = hp.run_reference(graph, reads, cigar=True, preset="asm")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    out_path = os.path.join(d, "call.bed")
+    procs = [ctx.Process(target=_call_worker, args=(r, world, port, q, graph, reads, occ, lco, out_path)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    n = q.get(timeout=600)
+    for pr in procs:
+        pr.join(120)
+        assert pr.exitcode == 0
+    assert n == 5
+    assert open(out_path, "rb").read() == want

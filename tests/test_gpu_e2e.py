@@ -880,3 +880,81 @@ def test_device_placement_is_deterministic_over_repeated_runs(monkeypatch):
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     line = [l for l in p.stdout.decode().splitlines() if l.startswith("SEEN")][0].split()[1:]
     assert line == [want], line
+
+
+def test_asm_200Mbp_four_contigs_gaf_and_sharded_call_vs_reference_binary():
+    """BASELINE configs[4] at a scale the test box carries: four 50 Mbp contigs (200 Mbp of query) against a 200 Mbp 3-haplotype graph in 4 chromosomes,
+    `-cx asm`: (1) file -> file GAF = the reference binary's bytes; (2) the contigs as two SHARDS (what two ranks of a node would take), each mapped to mg_gchains_t by
+    mg_map_batch() on the GPU, packed, unpacked on "rank 0" (mga_gchains_pack / _unpack: what dist.gather_chains moves), and fed in input order to the REFERENCE's own
+    mg_call_asm (asm-call.c:21) = the BED of `minigraph -cxasm --call`."""
+    import ctypes as C
+    need_ref()
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "200000000", "-c", "4", "-H", "3", "-n", "4", "-l", "50000000", "-e", "0.001", "-s", "5"], stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    ref_out, got, ref_bed = os.path.join(d, "ref.gaf"), os.path.join(d, "got.gaf"), os.path.join(d, "ref.bed")
+    run_ref(["-c", "-x", "asm", "-t", "16", graph, reads], ref_out)
+    mga.map_files(graph, [reads], got, preset="asm", cigar=True, n_threads=16)
+    if open(ref_out, "rb").read() != open(got, "rb").read():
+        raise AssertionError(first_diff(ref_out, got))
+    assert os.path.getsize(got) > 1000000
+    # ---- (2) ----
+    run_ref(["-c", "-x", "asm", "--call", "-t", "16", graph, reads], ref_bed)
+    import hostpipe as hp
+    names, seqs = hp.read_fa(reads)
+    L = mga.load()
+    G = mga.Graph(graph, preset="asm", cigar=True, n_threads=16)
+    L.mg_map_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(mga.mapopt_t), C.c_int]
+    L.mga_gchains_pack.restype = C.c_int64
+    L.mga_gchains_pack.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.mga_gchains_unpack.restype = C.POINTER(C.c_void_p)
+    L.mga_gchains_unpack.argtypes = [C.c_char_p, C.c_int64, C.POINTER(C.c_int)]
+    L.mg_gchain_free.argtypes = [C.c_void_p]
+    L.mga_free.argtypes = [C.c_void_p]
+    gathered = []
+    for st, en in ((0, 2), (2, 4)):   # two contiguous shards
+        n = en - st
+        gcs = (C.c_void_p * n)()
+        qlens = (C.c_int * n)(*[len(s) for s in seqs[st:en]])
+        sp, npp = (C.c_char_p * n)(*seqs[st:en]), (C.c_char_p * n)(*names[st:en])
+        assert L.mg_map_batch(G.gi, n, qlens, sp, npp, gcs, C.byref(G.mo), 16) == 0, L.mga_last_error()
+        buf = C.c_void_p()
+        nb = L.mga_gchains_pack(n, gcs, C.byref(buf))
+        assert nb > 0
+        data = C.string_at(buf, nb)
+        L.mga_free(buf)
+        for i in range(n):
+            L.mg_gchain_free(gcs[i])
+        k = C.c_int(0)
+        arr = L.mga_gchains_unpack(data, len(data), C.byref(k))
+        assert arr and k.value == n
+        gathered += [arr[i] for i in range(n)]
+        L.mga_free(arr)
+        assert not L.mga_gchains_unpack(data[:len(data) // 2], len(data) // 2, C.byref(k))   # a truncated buffer is refused, not read past
+    G.close()
+    R = rb.Ref().lib
+
+    class bseq1_t(C.Structure):  # mg_bseq1_t, bseq.h:14-17
+        _fields_ = [("l_seq", C.c_int32), ("rid", C.c_int32), ("name", C.c_char_p), ("seq", C.c_char_p), ("qual", C.c_char_p), ("comment", C.c_char_p)]
+    R.gfa_read.restype = C.c_void_p
+    R.mg_call_asm.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+    g = R.gfa_read(graph.encode())
+    sq = (bseq1_t * len(names))()
+    for i in range(len(names)):
+        sq[i].l_seq, sq[i].rid, sq[i].name, sq[i].seq = len(seqs[i]), i, names[i], seqs[i]
+    arr = (C.c_void_p * len(gathered))(*gathered)
+    bed = os.path.join(d, "got.bed")
+    libc = C.CDLL(None)
+    libc.fflush(None)
+    fd, keep = os.open(bed, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644), os.dup(1)
+    os.dup2(fd, 1)
+    try:
+        R.mg_call_asm(g, len(names), sq, arr, 5, 100000)
+        libc.fflush(None)
+    finally:
+        os.dup2(keep, 1)
+        os.close(fd)
+        os.close(keep)
+    want = open(ref_bed, "rb").read()
+    assert want.count(b"\n") > 1000
+    assert open(bed, "rb").read() == want
