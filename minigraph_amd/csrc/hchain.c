@@ -1,6 +1,6 @@
 /*
- * hchain.c -- backtrack + compaction behind the host RMQ chainer (rmq.c; -x asm and the tied long-join rescues).
- * Reference: lchain.c:9-112.  Everything after the linear chains -- chain records, clean-up, graph chaining -- lives in gc_core.h.
+ * hchain.c -- backtrack + compaction behind the host RMQ chainer (rmq.c; -x asm and the tied long-join rescues), and the first chaining pass of ULTRA-LONG -x lr reads.
+ * Reference: lchain.c:9-219.  Everything after the linear chains -- chain records, clean-up, graph chaining -- lives in gc_core.h.
  */
 #include <assert.h>
 #include "hchain.h"
@@ -78,4 +78,68 @@ mg128_t *mga_compact_a(int32_t n_u, uint64_t *u, int32_t n_v, const int32_t *v, 
 	memcpy(u, u2, (size_t)n_u * 8);
 	free(b); free(w); free(u2);
 	return out;
+}
+
+/* ---- first chaining pass of an ultra-long read on a host thread (mg_lchain_dp's forward loop, lchain.c:168-207; single segment, not cDNA) ----
+ * k_lchain gives a read one wavefront: ~10 k cycles per anchor are hidden by the other reads' wavefronts when a chunk holds thousands of 10 kb reads, but a 5 Mbp read
+ * is 3 x 10^5 dependent anchor steps on ONE wavefront ([measured] 1.4 s, round 1-3: slower than the whole reference job).  A host core takes the same steps from its
+ * caches in ~0.1 s, and reads of that length are few, so they are placed here -- like the RMQ chainer of -x asm -- while sketch, seeds, WFA and text stay on the device
+ * (the long-query path of mapper.c).  Fills f, p, v (t: zeroed by the caller); the caller backtracks with mga_chain_backtrack / mga_compact_a. */
+typedef struct { int32_t dist_x, dist_y, bw; float pen_gap, pen_skip; } lcdp_par_t;
+
+static inline int lcdp_pair(const mg128_t *ai, const mg128_t *aj, const lcdp_par_t *P, int32_t *sc_) /* comput_sc (lchain.c:114-139) for one segment: 0 when aj cannot precede ai */
+{
+	const int32_t dq = (int32_t)ai->y - (int32_t)aj->y;
+	int32_t dr, dd, dg, span, sc;
+	if (dq <= 0 || dq > P->dist_x) return 0;
+	dr = (int32_t)(ai->x - aj->x);
+	if (dr == 0 || dq > P->dist_y) return 0;
+	dd = dr > dq ? dr - dq : dq - dr;
+	if (dd > P->bw) return 0;
+	dg = dr < dq ? dr : dq;
+	span = (int32_t)(aj->y >> 32 & 0xff);
+	sc = span < dg ? span : dg;
+	if (dd || dg > span) {
+		const float lin = P->pen_gap * (float)dd + P->pen_skip * (float)dg;
+		const float lg = dd >= 1 ? mga_log2f((float)(dd + 1)) : 0.0f;
+		sc -= (int32_t)(lin + .5f * lg);
+	}
+	*sc_ = sc;
+	return 1;
+}
+
+void mga_lchain_dp_fwd(int max_dist_x, int max_dist_y, int bw, int max_skip, int max_iter, float pen_gap, float pen_skip,
+					   int64_t n, const mg128_t *a, int32_t *f, int64_t *p, int32_t *v, int32_t *t)
+{
+	lcdp_par_t P;
+	int64_t i, lo = 0, best_in_reach = -1; /* lo: first anchor that can still precede anchor i; best_in_reach: the reference's max_ii */
+	P.dist_x = max_dist_x < bw ? bw : max_dist_x, P.dist_y = max_dist_y < bw ? bw : max_dist_y, P.bw = bw, P.pen_gap = pen_gap, P.pen_skip = pen_skip;
+	for (i = 0; i < n; ++i) {
+		const mg128_t *ai = &a[i];
+		int64_t j, from = -1, scan_end;
+		int32_t best = (int32_t)(ai->y >> 32 & 0xff), skipped = 0;
+		while (lo < i && (ai->x >> 32 != a[lo].x >> 32 || ai->x > a[lo].x + (uint64_t)(int64_t)P.dist_x)) ++lo;
+		if (i - lo > max_iter) lo = i - max_iter;
+		for (j = i - 1; j >= lo; --j) { /* nearest first; the order decides which predecessors the skip heuristic still gets to see */
+			int32_t sc;
+			if (!lcdp_pair(ai, &a[j], &P, &sc)) continue;
+			sc += f[j];
+			if (sc > best) { best = sc, from = j; if (skipped > 0) --skipped; }
+			else if (t[j] == (int32_t)i && ++skipped > max_skip) break;
+			if (p[j] >= 0) t[p[j]] = (int32_t)i;
+		}
+		scan_end = j;
+		if (best_in_reach < 0 || ai->x - a[best_in_reach].x > (uint64_t)(int64_t)P.dist_x) { /* the best-scoring anchor in reach fell out of it: look again */
+			int32_t top = INT32_MIN;
+			best_in_reach = -1;
+			for (j = i - 1; j >= lo; --j) if (top < f[j]) top = f[j], best_in_reach = j;
+		}
+		if (best_in_reach >= 0 && best_in_reach < scan_end) { /* the scan was cut before it got there */
+			int32_t sc;
+			if (lcdp_pair(ai, &a[best_in_reach], &P, &sc) && best < sc + f[best_in_reach]) best = sc + f[best_in_reach], from = best_in_reach;
+		}
+		f[i] = best, p[i] = from;
+		v[i] = from >= 0 && v[from] > best ? v[from] : best;
+		if (best_in_reach < 0 || (ai->x - a[best_in_reach].x <= (uint64_t)(int64_t)P.dist_x && f[best_in_reach] < best)) best_in_reach = i;
+	}
 }

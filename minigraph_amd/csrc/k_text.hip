@@ -133,23 +133,52 @@ template<bool WRITE, bool REV> __device__ int32_t txt_ds_run(const txt_walk_t &W
 	return n;
 }
 
-__device__ __forceinline__ int32_t wave_excl_scan(int32_t v, int lane, int32_t *total)
+// ---- workgroup-wide scan / sum (NT = 64: one wavefront, no LDS; NT = 1024: sixteen wavefronts, partial sums through LDS) ----
+template<int NT> __device__ __forceinline__ int32_t blk_excl_scan(int32_t v, int tid, int32_t *total, int32_t *s_w)
 {
+	const int lane = tid & 63;
 	int32_t x = v;
 #pragma unroll
 	for (int d = 1; d < 64; d <<= 1) { const int32_t y = __shfl_up(x, d); if (lane >= d) x += y; }
-	*total = __shfl(x, 63);
-	return x - v;
+	if (NT == 64) { *total = __shfl(x, 63); return x - v; }
+	const int w = tid >> 6;
+	__syncthreads(); // (s_w of the previous call has been read by everybody)
+	if (lane == 63) s_w[w] = x;
+	__syncthreads();
+	int32_t base = 0, tot = 0;
+#pragma unroll
+	for (int k = 0; k < NT / 64; ++k) { const int32_t t = s_w[k]; if (k < w) base += t; tot += t; }
+	*total = tot;
+	return base + x - v;
 }
-__device__ __forceinline__ int32_t wave_sum(int32_t v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d); return v; }
+template<int NT> __device__ __forceinline__ int32_t blk_sum(int32_t v, int tid, int32_t *s_w)
+{
+	for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+	if (NT == 64) return v;
+	__syncthreads();
+	if ((tid & 63) == 0) s_w[tid >> 6] = v;
+	__syncthreads();
+	int32_t tot = 0;
+#pragma unroll
+	for (int k = 0; k < NT / 64; ++k) tot += s_w[k];
+	return tot;
+}
 
-__global__ void __launch_bounds__(64) k_text(int n_chain, const mga_txt_chain_t *__restrict__ chain, const mga_cigitem_t *__restrict__ item, const uint32_t *__restrict__ vert,
+// One WORKGROUP of NT threads per printed chain.  NT = 64 for the chains of ordinary reads (~1600 operators); NT = 1024 when the launch holds chromosome-scale chains
+// (-x asm contigs, ultra-long -x lr reads: 10^5 - 10^6 operators each, a handful of chains per launch -- [measured, round 3] one wavefront per 50 Mbp chain was 1.4 s of a
+// 3.6 s job): the tile loops below stride by NT, the scans run over the workgroup.
+template<int NT>
+__global__ void __launch_bounds__(NT) k_text(int n_chain, const mga_txt_chain_t *__restrict__ chain, const mga_cigitem_t *__restrict__ item, const uint32_t *__restrict__ vert,
 											 const int32_t *__restrict__ vwb, const char *__restrict__ gseq, const int64_t *__restrict__ gseq_off, const int32_t *__restrict__ seg_len,
 											 const char *__restrict__ reads, const int32_t *__restrict__ ncig, const int64_t *__restrict__ cigoff, const uint32_t *__restrict__ ord,
 											 const int64_t *__restrict__ el_off, uint32_t *__restrict__ el, uint32_t *__restrict__ run, int32_t *__restrict__ run_txt,
 											 mga_txt_res_t *__restrict__ res, char *__restrict__ pool, long long pool_cap, unsigned long long *pool_used)
 {
-	const int c = blockIdx.x, lane = threadIdx.x;
+	__shared__ int32_t s_w[NT / 64 + 1];
+	__shared__ int32_t s_o[NT], s_op[NT], s_val[NT];
+	__shared__ int64_t s_src[NT];
+	__shared__ unsigned long long s_res;
+	const int c = blockIdx.x, tid = threadIdx.x;
 	if (c >= n_chain) return;
 	const mga_txt_chain_t C = chain[c];
 	const int64_t eo = el_off[c];
@@ -160,11 +189,11 @@ __global__ void __launch_bounds__(64) k_text(int n_chain, const mga_txt_chain_t 
 	txt_walk_t W;
 	W.vert = vert + C.vert_beg, W.vwb = vwb + C.vert_beg, W.cnt = C.vert_cnt, W.ss = C.ss, W.gseq = gseq, W.gseq_off = gseq_off, W.seg_len = seg_len;
 
-	// ---- S1: concatenated operator list
+	// ---- S1: concatenated operator list: a tile of NT items at a time, every output slot finds its item by a binary search over the tile's offsets (LDS)
 	{
 		int32_t base = 0;
-		for (int64_t tb = C.item_beg; tb < C.item_end; tb += 64) {
-			const int64_t t = tb + lane;
+		for (int64_t tb = C.item_beg; tb < C.item_end; tb += NT) {
+			const int64_t t = tb + tid;
 			mga_cigitem_t it; it.op = 0, it.val = 0;
 			int32_t cnt = 0;
 			int64_t src = 0;
@@ -173,45 +202,39 @@ __global__ void __launch_bounds__(64) k_text(int n_chain, const mga_txt_chain_t 
 				if (it.op >= 0) cnt = 1; else { const int64_t pj = C.prob_base + it.val; cnt = ncig[pj]; src = cigoff[pj]; }
 			}
 			int32_t tot;
-			const int32_t o_l = wave_excl_scan(cnt, lane, &tot);
-			for (int32_t o0 = 0; o0 < tot; o0 += 64) { // uniform trip count: the shuffles need every lane
-				const int32_t o = o0 + lane;
+			const int32_t o_l = blk_excl_scan<NT>(cnt, tid, &tot, s_w);
+			__syncthreads(); // (the previous tile's readers are through)
+			s_o[tid] = o_l, s_op[tid] = it.op, s_val[tid] = it.val, s_src[tid] = src;
+			__syncthreads();
+			for (int32_t o = tid; o < tot; o += NT) {
 				int lo = 0;
 #pragma unroll
-				for (int step = 32; step > 0; step >>= 1) { const int32_t v = __shfl(o_l, lo + step); if (v <= o) lo += step; } // last item whose first slot is <= o (empty items share offsets)
-				const int32_t k = o - __shfl(o_l, lo), op_l = __shfl(it.op, lo), val_l = __shfl(it.val, lo);
-				const int64_t src_l = __shfl(src, lo);
-				if (o < tot) {
-					uint32_t e;
-					if (op_l >= 0) e = (uint32_t)val_l << 5 | 1u << 4 | (uint32_t)op_l;
-					else { const uint32_t cg = ord[src_l + k]; e = (cg >> 4) << 5 | (k == 0 ? 1u << 4 : 0u) | (cg & 0xf); }
-					E[base + o] = e;
-				}
+				for (int step = NT / 2; step > 0; step >>= 1) if (s_o[lo + step] <= o) lo += step; // last item whose first slot is <= o (empty items share offsets)
+				const int32_t k = o - s_o[lo], op_l = s_op[lo];
+				uint32_t e;
+				if (op_l >= 0) e = (uint32_t)s_val[lo] << 5 | 1u << 4 | (uint32_t)op_l;
+				else { const uint32_t cg = ord[s_src[lo] + k]; e = (cg >> 4) << 5 | (k == 0 ? 1u << 4 : 0u) | (cg & 0xf); }
+				E[base + o] = e;
 			}
 			base += tot;
 		}
 	}
-	for (int32_t i = lane; i < n_el; i += 64) R[i] = 0;
+	for (int32_t i = tid; i < n_el; i += NT) R[i] = 0;
 	__threadfence_block();
 	__syncthreads();
 	// ---- S2: runs (append_cigar1 / append_cigar, galign.c:11-37)
 	int32_t n_run = 0;
-	{
-		int32_t carry_op = -1;
-		for (int32_t b0 = 0; b0 < n_el; b0 += 64) {
-			const int32_t i = b0 + lane;
-			const uint32_t e = i < n_el ? E[i] : 0;
-			const int32_t op = (int32_t)(e & 0xf);
-			int32_t prev = __shfl_up(op, 1);
-			if (lane == 0) prev = carry_op;
-			const bool head = i < n_el && !((e >> 4 & 1) && op == prev);
-			const uint64_t hm = __ballot(head);
-			const int32_t ridx = n_run + __popcll(hm & (mga_lanemask_lt() | (1ULL << lane))) - 1;
-			if (i < n_el) atomicAdd(&R[ridx], (e >> 5) << 5 | (head ? (uint32_t)op : 0u)); // lengths add up; the head contributes the operator bits
-			n_run += __popcll(hm);
-			const int last = (n_el - b0 < 64 ? n_el - b0 : 64) - 1;
-			carry_op = __shfl(op, last);
-		}
+	for (int32_t b0 = 0; b0 < n_el; b0 += NT) {
+		const int32_t i = b0 + tid;
+		const uint32_t e = i < n_el ? E[i] : 0;
+		const int32_t op = (int32_t)(e & 0xf);
+		const int32_t prev = i > 0 && i < n_el ? (int32_t)(E[i - 1] & 0xf) : -1;
+		const bool head = i < n_el && !((e >> 4 & 1) && op == prev);
+		int32_t tot;
+		const int32_t before = blk_excl_scan<NT>(head ? 1 : 0, tid, &tot, s_w);
+		const int32_t ridx = n_run + before + (head ? 1 : 0) - 1;
+		if (i < n_el) atomicAdd(&R[ridx], (e >> 5) << 5 | (head ? (uint32_t)op : 0u)); // lengths add up; the head contributes the operator bits
+		n_run += tot;
 	}
 	__threadfence_block();
 	__syncthreads();
@@ -222,25 +245,25 @@ __global__ void __launch_bounds__(64) k_text(int n_chain, const mga_txt_chain_t 
 		int32_t x0 = 0, y0 = C.qs, cg0 = 0, ds0 = 0;
 		char *cg_base = 0, *ds_base = 0;
 		if (pass == 1) {
-			unsigned long long o = 0;
 			const unsigned long long need = (unsigned long long)cg_n + (unsigned long long)ds_n;
-			if (lane == 0) o = atomicAdd(pool_used, need);
-			o = __shfl(o, 0);
+			if (tid == 0) s_res = atomicAdd(pool_used, need);
+			__syncthreads();
+			const unsigned long long o = s_res;
 			mga_txt_res_t r;
 			r.txt_off = (int64_t)o, r.cg_len = cg_n, r.ds_len = ds_n, r.n_cigar = n_run, r.mlen = mlen, r.blen = blen, r.aplen = aplen, r.pad = 0;
 			r.status = (qlen == C.qe - C.qs && aplen == apl) ? 0 : 1; // galign.c:140
 			if (r.status == 0 && (long long)(o + need) > pool_cap) r.status = 2;
-			if (lane == 0) res[c] = r;
+			if (tid == 0) res[c] = r;
 			if (r.status != 0) return;
 			cg_base = pool + o, ds_base = pool + o + cg_n;
 		}
-		for (int32_t b0 = 0; b0 < n_run; b0 += 64) {
-			const int32_t r = b0 + lane;
+		for (int32_t b0 = 0; b0 < n_run; b0 += NT) {
+			const int32_t r = b0 + tid;
 			const uint32_t e = r < n_run ? R[r] : 0;
 			const int32_t op = (int32_t)(e & 0xf), len = (int32_t)(e >> 5);
 			const int32_t dx = r < n_run && op != 1 ? len : 0, dy = r < n_run && op != 2 ? len : 0;
 			int32_t tx, ty;
-			const int32_t x = x0 + wave_excl_scan(dx, lane, &tx), y = y0 + wave_excl_scan(dy, lane, &ty);
+			const int32_t x = x0 + blk_excl_scan<NT>(dx, tid, &tx, s_w), y = y0 + blk_excl_scan<NT>(dy, tid, &ty, s_w);
 			if (pass == 0) {
 				int32_t lc = 0, ld = 0;
 				if (r < n_run) {
@@ -248,12 +271,12 @@ __global__ void __launch_bounds__(64) k_text(int n_chain, const mga_txt_chain_t 
 					ld = txt_ds_run<false, false>(W, q, op, len, x, y, C.qs, C.qe, apl, 0, 0);
 					RT[2 * r] = lc, RT[2 * r + 1] = ld;
 				}
-				mlen += wave_sum(r < n_run && op == 7 ? len : 0), blen += wave_sum(r < n_run ? len : 0);
-				aplen += tx, qlen += ty, cg_n += wave_sum(lc), ds_n += wave_sum(ld);
+				mlen += blk_sum<NT>(r < n_run && op == 7 ? len : 0, tid, s_w), blen += blk_sum<NT>(r < n_run ? len : 0, tid, s_w);
+				aplen += tx, qlen += ty, cg_n += blk_sum<NT>(lc, tid, s_w), ds_n += blk_sum<NT>(ld, tid, s_w);
 			} else {
 				const int32_t lc = r < n_run ? RT[2 * r] : 0, ld = r < n_run ? RT[2 * r + 1] : 0;
 				int32_t tc, td;
-				const int32_t oc = cg0 + wave_excl_scan(lc, lane, &tc), od = ds0 + wave_excl_scan(ld, lane, &td);
+				const int32_t oc = cg0 + blk_excl_scan<NT>(lc, tid, &tc, s_w), od = ds0 + blk_excl_scan<NT>(ld, tid, &td, s_w);
 				if (r < n_run) {
 					char *wc = C.rev_sign ? cg_base + (cg_n - oc - lc) : cg_base + oc; // cg:Z piece: "<len><op>" (format.c:205-215)
 					txt_put_uint(wc, (uint32_t)len, lc - 1);
@@ -295,9 +318,13 @@ extern "C" int mga_dev_text(mga_sctx_t *sc, int n_chain, const mga_txt_chain_t *
 	MGA_HIP_CHECK(hipGetLastError());
 	if (mga_dev_scan_i32_to_i64(sc, (const int32_t*)sc->txt_cnt.p, n_chain, (int64_t*)sc->txt_off.p) < 0) return -1;
 	mga_prof_begin(sc->stream, MGA_K_TEXT);
-	hipLaunchKernelGGL(k_text, dim3(n_chain), dim3(64), 0, st, n_chain, d_chain, d_item, d_vert, (const int32_t*)sc->txt_vwb.p, (const char*)ix->d_gseq,
-					   (const int64_t*)ix->d_gseq_off, (const int32_t*)ix->d_seg_len, d_reads, d_ncig, d_cigoff, d_ord, (const int64_t*)sc->txt_off.p,
-					   el, run, run_txt, d_res, d_pool, (long long)pool_cap, d_pool_used);
+	// chromosome-scale chains (a handful per launch, 10^5+ operators each) get a workgroup of sixteen wavefronts each, ordinary reads' chains one wavefront
+	const bool wide = n_el_max / n_chain >= 32768;
+#define TXT_LAUNCH(NT_) hipLaunchKernelGGL((k_text<NT_>), dim3(n_chain), dim3(NT_), 0, st, n_chain, d_chain, d_item, d_vert, (const int32_t*)sc->txt_vwb.p, (const char*)ix->d_gseq, \
+					   (const int64_t*)ix->d_gseq_off, (const int32_t*)ix->d_seg_len, d_reads, d_ncig, d_cigoff, d_ord, (const int64_t*)sc->txt_off.p, \
+					   el, run, run_txt, d_res, d_pool, (long long)pool_cap, d_pool_used)
+	if (wide) TXT_LAUNCH(1024); else TXT_LAUNCH(64);
+#undef TXT_LAUNCH
 	mga_prof_end(sc->stream, MGA_K_TEXT);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;

@@ -212,8 +212,10 @@ static void rq_prepare_worker(void *data, int64_t i, int tid)
 	if (b->qlens[i] == 0 || (b->opt.max_qlen > 0 && b->qlens[i] > b->opt.max_qlen)) r->n = 0; /* chain_worker returns early for these */
 	if (r->n <= 0) return;
 	r->a = (mg128_t*)(b->a + b->a_off[i]); /* every read owns its slice of the staging buffer */
-	if (b->a_is_raw == 2 && r->n > 1) mga_ksort_128x(r->n, r->a); /* hit order from the device: radix_sort_128x (map-algo.c:189) */
-	rq_cut(r); rq_arrays(r);
+	if ((b->a_is_raw == 2 || b->a_is_raw == 3) && r->n > 1) mga_ksort_128x(r->n, r->a); /* hit order from the device: radix_sort_128x (map-algo.c:189) */
+	if (b->a_is_raw == 3 || b->a_is_raw == 5) { /* (5: already sorted -- the CPU tests' oracle anchors) */ r->cut = MGA_MALLOC(int64_t, 2); r->cut[0] = 0, r->cut[1] = r->n, r->n_cut = 1; } /* an ultra-long -x lr read: its first pass is the DP, one work item */
+	else rq_cut(r);
+	rq_arrays(r);
 	CPU_ADD(C_LCCOPY, tc);
 }
 
@@ -225,6 +227,12 @@ static void rq_fwd_worker(void *data, int64_t j, int tid)
 	const mg_mapopt_t *opt = &b->opt;
 	int64_t tc = cpu_now();
 	(void)tid;
+	if ((b->a_is_raw == 3 || b->a_is_raw == 5) && !r->pass2) { /* mg_lchain_dp (map-algo.c:393-403) on this host thread: hchain.c */
+		mga_lchain_par_t par;
+		mga_batch_lchain_par(b->gi, opt, 0, &par);
+		if (opt->max_gap_ref <= 0 && opt->max_frag_len > 0) { const int g = opt->max_frag_len - b->qlens[task->read]; par.max_dist_x = g > opt->max_gap ? g : opt->max_gap; } /* -F: map-algo.c:383-386 */
+		mga_lchain_dp_fwd(par.max_dist_x, par.max_dist_y, par.bw, par.max_skip, par.max_iter, par.chn_pen_gap, par.chn_pen_skip, r->n, r->a, r->f, r->p, r->v, r->t);
+	} else
 	mga_lchain_rmq_fwd(opt->max_gap, opt->max_gap_pre, r->pass2 ? opt->bw_long : opt->bw, opt->max_lc_skip, opt->rmq_size_cap, b->pen_gap, b->pen_skip,
 					   r->cut[task->k], r->cut[task->k + 1], r->a, r->f, r->p, r->v, r->t);
 	CPU_ADD(r->pass2 ? C_LCRESCUE : C_LCCOPY, tc);
@@ -673,7 +681,9 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	mga_batch_t *b = 0;
 	mga_lchain_par_t par;
 	const int is_rmq = !!(opt->flag & MG_M_RMQ);
-	const int long_q = is_rmq && (gi->k & 1) && !env_int("MGA_NO_LONGQ", 0); /* -x asm: few, very long queries -- intra-query parallel sketch and seed expansion, anchors sorted by the host chainer */
+	int chunk_long = 0; /* -x lr, a chunk of ultra-long reads (batch_cut): the long-query path as well, first chaining pass on host threads (hchain.c: mga_lchain_dp_fwd) */
+	if (!is_rmq && n > 0 && (gi->k & 1) && !env_int("MGA_NO_LONGQ", 0)) { const int lr_long = env_int("MGA_LONG_READ", 262144); chunk_long = lr_long > 0; for (i = 0; i < n && chunk_long; ++i) if (qlens[i] < lr_long) chunk_long = 0; }
+	const int long_q = (is_rmq || chunk_long) && (gi->k & 1) && !env_int("MGA_NO_LONGQ", 0); /* few, very long queries -- intra-query parallel sketch and seed expansion, anchors sorted by the host chainer */
 	const char *d_seq;
 	double t0, t1;
 	gpu_token_t *held = 0; /* GPU phase token currently owned */
@@ -798,7 +808,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	CK(mga_hbuf_reserve(&P->h_mini, (size_t)n_mini * 4 + 16));
 	/* ---- linear chaining ---- */
 	CK(mga_hbuf_reserve(&P->h_b, (size_t)n_a * 16 + 16));
-	if (!is_rmq) {
+	if (!is_rmq && !chunk_long) {
 		size_t wsb = mga_dev_lchain_ws_bytes(n_a);
 		mga_rescue_par_t rs;
 		mga_batch_lchain_par(gi, opt, 0, &par);
@@ -952,7 +962,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 		mga_batch_set_device_plan(b, h_ploff, (int32_t*)P->h_plrev.p, (int64_t)ptot[0]);
 	}
 	if (dev_gc) mga_batch_set_device_chains(b, h_gchdr_p, P->h_gcpool.p, (const mg_llchain_t*)P->h_lcpool.p, need_a ? (const mg128_t*)P->h_apool.p : 0);
-	CK(mga_batch_chain(b, h_nmz, h_rep, (const int32_t*)P->h_mini.p, h_minioff, h_nu, h_nb, (const uint64_t*)P->h_u.p, (const mg128_t*)P->h_b.p, h_aoff, long_q ? 2 : is_rmq, h_rflag));
+	CK(mga_batch_chain(b, h_nmz, h_rep, (const int32_t*)P->h_mini.p, h_minioff, h_nu, h_nb, (const uint64_t*)P->h_u.p, (const mg128_t*)P->h_b.p, h_aoff, chunk_long ? 3 : long_q ? 2 : is_rmq, h_rflag));
 	if (g_dbg_pipe > 1) PIPE_LOG(" hostchain", n, t0);
 	t1 = mga_wtime(); st->t_host_chain += t1 - t0; t0 = t1;
 	/* ---- WFA over all gaps ---- */
@@ -1238,7 +1248,7 @@ mga_stream_t *mga_stream_open(const mg_idx_t *gi, const mg_mapopt_t *opt, int n_
 	g_cpu_on = g_dbg_pipe > 0;
 	S = MGA_CALLOC(mga_stream_t, 1);
 	S->gi = gi, S->opt = *opt, S->n_threads = n_threads > 0 ? n_threads : 1;
-	S->n_pipe = env_int("MGA_PIPE", 4);
+	S->n_pipe = env_int("MGA_PIPE", n_threads <= 4 ? 3 : 4); /* [measured, round 4, a rank pinned to 2 of 16 cores] 3 pipeline threads: 2.31 Gbp/s at 0.70 CPU-s per step, 4: 2.23 at 0.82, 2: 2.07; with 16 threads 4 is the best (3.27 vs 2.96 vs 2.51) */
 	if (S->n_pipe > MGA_MAX_PIPE) S->n_pipe = MGA_MAX_PIPE;
 	if (S->n_pipe < 1) S->n_pipe = 1;
 	S->chunk = env_int("MGA_CHUNK", 16384); /* [measured] larger launches amortise the tails of the WFA tiers: 4096 -> 8192 reads +5 %, -> 16384 another +5 % */
@@ -1285,7 +1295,15 @@ static void batch_cut(mga_stream_t *S, sbatch_t *b)
 		}
 		if (sz < 1) sz = 1;
 		if (sz > left) sz = left;
-		for (k = 0; k < sz; ++k) { bases += b->qlens[pos + k]; if (bases > base_cap && k > 0) break; } /* (a single read longer than the cap is a chunk of its own) */
+		{ /* ultra-long -x lr reads (>= MGA_LONG_READ bases, default 256 k) travel in chunks of their own -- at most 64 Mbp of them -- through the long-query path (map_chunk) */
+			const int lr_long = !(S->opt.flag & MG_M_RMQ) ? env_int("MGA_LONG_READ", 262144) : 0;
+			const int first_long = lr_long > 0 && b->qlens[pos] >= lr_long;
+			for (k = 0; k < sz; ++k) {
+				if (lr_long > 0 && k > 0 && (b->qlens[pos + k] >= lr_long) != first_long) break;
+				bases += b->qlens[pos + k];
+				if ((bases > base_cap || (first_long && bases > (64LL << 20))) && k > 0) break; /* (a single read longer than the cap is a chunk of its own) */
+			}
+		}
 		sz = k;
 		if (m == cap) { cap += cap / 2 + 8; b->cstart = MGA_REALLOC(int, b->cstart, cap + 1); }
 		b->cstart[m++] = pos; pos += sz;

@@ -53,7 +53,7 @@ def run_reference(graph, reads, cigar=True, threads=4, preset="lr"):
     return p.stdout, int(m.group(1)), int(m.group(2))
 
 
-def map_with_oracle_stages(graph, reads, occ_max1, lc_max_occ, cigar=True, n_threads=4, preset="lr", per_read=False, return_chains=False):
+def map_with_oracle_stages(graph, reads, occ_max1, lc_max_occ, cigar=True, n_threads=4, preset="lr", per_read=False, return_chains=False, host_dp=False):
     """whole -cx lr (or -cx asm) job: oracle for the kernel stages, product C code for everything on the host.  Under asm the RMQ chainer
     is the primary chainer and runs in the product's host phases (mapper.c: rq_chain_all) on the oracle's sorted anchors"""
     L = mga.load()
@@ -96,8 +96,8 @@ def map_with_oracle_stages(graph, reads, occ_max1, lc_max_occ, cigar=True, n_thr
     for s in seqs:
         mz = ora.sketch(s, io.w, io.k)
         a, rl, mp = ora.seed_hits(oidx, mz, occ_max1)
-        if is_rmq:
-            u, b = np.zeros(0, dtype=np.uint64), a  # raw x-sorted anchors: the host chains
+        if is_rmq or host_dp:
+            u, b = np.zeros(0, dtype=np.uint64), a  # raw x-sorted anchors: the host chains (host_dp: the placement of ultra-long -x lr reads -- first pass mga_lchain_dp_fwd, rescue by the RMQ tree)
         else:
             u, b = ora.lchain_dp(a, max_dist_x=par.max_dist_x, max_dist_y=par.max_dist_y, bw=par.bw, max_skip=par.max_skip,
                                  max_iter=par.max_iter, min_cnt=par.min_cnt, min_sc=par.min_sc, pen_gap=par.chn_pen_gap, pen_skip=par.chn_pen_skip)
@@ -124,7 +124,7 @@ def map_with_oracle_stages(graph, reads, occ_max1, lc_max_occ, cigar=True, n_thr
     N_MZ, REP, NU, NB = i32(n_mz), i32(rep), i32(nus), i32(nbs)
     b = L.mga_batch_init(gi, C.byref(mo), n, qlens, seqp, namep, q_off.ctypes.data, n_threads)
     assert L.mga_batch_chain(b, N_MZ.ctypes.data, REP.ctypes.data, MINI.ctypes.data, mini_off.ctypes.data, NU.ctypes.data, NB.ctypes.data,
-                             U.ctypes.data, A.ctypes.data, a_off.ctypes.data, is_rmq, None) == 0
+                             U.ctypes.data, A.ctypes.data, a_off.ctypes.data, 5 if (host_dp and not is_rmq) else is_rmq, None) == 0
     n_prob, n_tb = L.mga_batch_n_wfa(b), L.mga_batch_wfa_target_bytes(b)
     probs = (wfa_prob_t * max(n_prob, 1))()
     tbuf = C.create_string_buffer(int(n_tb) + 64)

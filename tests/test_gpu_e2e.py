@@ -138,6 +138,8 @@ def test_error_free_reads_need_no_wfa_problem():
     ("5 haplotypes, 3 chromosomes", ["-G", "6000000", "-H", "5", "-c", "3", "-n", "1500", "-s", "35"], True),
     ("chains only", ["-G", "3000000", "-H", "3", "-n", "1500", "-s", "36"], False),
     ("1.5 Mbp reads (long-join rescue left to the host tree, strays batched in k_lchain)", ["-G", "12000000", "-H", "3", "-n", "4", "-l", "1500000", "-e", "0.05", "-s", "37"], True),
+    ("5 Mbp reads (ultra-long placement: long-query sketch / seeds on the device, first chaining pass on host threads)", ["-G", "16000000", "-H", "3", "-n", "2", "-l", "5000000", "-e", "0.05", "-s", "38"], True),
+    ("300 kb reads next to 10 kb reads (chunks of either kind in one job)", ["-G", "8000000", "-H", "3", "-n", "40", "-l", "300000", "-e", "0.06", "-s", "39", "--mix10k"], True),
 ])
 def test_parity_sweep_vs_reference_binary(tag, simargs, cigar, monkeypatch):
     monkeypatch.setenv("MGA_DEV_GCHAIN", "0" if zlib.crc32(tag.encode()) & 1 else "1")  # both placements of graph chaining over the sweep
@@ -145,8 +147,19 @@ def test_parity_sweep_vs_reference_binary(tag, simargs, cigar, monkeypatch):
     several stable sequences, the chains-only output"""
     need_ref()
     d = tempfile.mkdtemp()
+    mix = "--mix10k" in simargs
+    simargs = [x for x in simargs if x != "--mix10k"]
     subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t")] + simargs, stderr=subprocess.DEVNULL)
     graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    if mix:   # ordinary reads of the same graph interleaved with the long ones: a job whose chunks alternate between the two placements
+        subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "s")] + [("400" if simargs[i - 1] == "-n" else "10000" if simargs[i - 1] == "-l" else x) for i, x in enumerate(simargs)], stderr=subprocess.DEVNULL)
+        long_recs = open(reads, "rb").read().split(b">")[1:]
+        short_recs = [r.replace(b"r", b"s", 1) for r in open(os.path.join(d, "s.reads.fa"), "rb").read().split(b">")[1:]]
+        with open(reads, "wb") as f:
+            for i, r in enumerate(short_recs):
+                f.write(b">" + r)
+                if i % 10 == 9 and i // 10 < len(long_recs):
+                    f.write(b">" + long_recs[i // 10])
     ref_out = os.path.join(d, "ref.gaf")
     run_ref((["-c"] if cigar else []) + ["-x", "lr", "-t", "8", graph, reads], ref_out)
     G = mga.Graph(graph, preset="lr", cigar=cigar, n_threads=8)

@@ -129,3 +129,20 @@ def test_three_part_form_of_graph_chaining_bridges_in_reverse_order(level):
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     line = [l for l in p.stdout.decode().splitlines() if l.startswith("SAME")][0].split()
     assert line[1] == "1" and int(line[2]) > 10000
+
+
+@pytest.mark.skipif(not os.path.exists(rb.REF_BIN), reason="oracle/_ref/minigraph not built")
+def test_ultra_long_read_placement_first_pass_on_host_threads():
+    """-x lr reads beyond MGA_LONG_READ bases are chained on host threads (hchain.c: mga_lchain_dp_fwd restates mg_lchain_dp's forward loop, lchain.c:168-207; the long-join
+    rescue follows through the RMQ tree as for every read the device defers): the same bytes as the reference on reads with many chains, strays and rescues"""
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "2500000", "-H", "4", "-n", "12", "-l", "150000", "-e", "0.08", "-s", "77"], stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    want, occ, lco = hp.run_reference(graph, reads, cigar=False)
+    got, _ = hp.map_with_oracle_stages(graph, reads, occ, lco, cigar=False, host_dp=True)
+    assert got == want
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "u"), "-G", "1500000", "-H", "3", "-n", "300", "-l", "9000", "-s", "78"], stderr=subprocess.DEVNULL)   # ordinary reads through the same code
+    graph, reads = os.path.join(d, "u.gfa"), os.path.join(d, "u.reads.fa")
+    want, occ, lco = hp.run_reference(graph, reads, cigar=False)
+    got, _ = hp.map_with_oracle_stages(graph, reads, occ, lco, cigar=False, host_dp=True)
+    assert got == want
