@@ -155,22 +155,30 @@ __device__ void lc_dp(const mg128_t *__restrict__ a, int32_t n, mga_lchain_par_t
 				continue;
 			}
 		}
+		// Round 4: the loads of an anchor's step that do not depend on each other leave together -- its own record, the window's first anchor and the best-scoring anchor in
+		// reach (known from the previous step) at the top; a predecessor block's anchors with their f, p AND v in one trip (they used to follow the score test) --
+		// [measured] ~10 k cycles per anchor were 6-8 DEPENDENT trips to memory at 4 % VALU utilisation.
 		const uint64_t xi = a[i].x, yi = a[i].y;
+		uint64_t xs0 = st < i ? a[st].x : 0;
+		mg128_t am; am.x = am.y = 0;
+		int32_t fm = 0, vm = 0;
+		if (max_ii >= 0) am = a[max_ii], fm = f[max_ii], vm = v[max_ii];
 		while (st < i) { // lchain.c:171
-			const uint64_t xs = a[st].x;
-			if (xi >> 32 != xs >> 32 || xi > xs + (uint64_t)(int64_t)P.max_dist_x) ++st; else break;
+			if (xi >> 32 != xs0 >> 32 || xi > xs0 + (uint64_t)(int64_t)P.max_dist_x) { ++st; if (st < i) xs0 = a[st].x; } else break;
 		}
 		if (i - st > P.max_iter) st = i - P.max_iter;
-		int32_t max_f = (int32_t)(yi >> 32 & 0xff), max_j = -1, n_skip = 0, end_j = st - 1;
+		int32_t max_f = (int32_t)(yi >> 32 & 0xff), max_j = -1, max_v = 0, n_skip = 0, end_j = st - 1;
 		bool cut = false;
 		for (int32_t j0 = i - 1; j0 >= st && !cut; j0 -= 64) {
 			const int32_t j = j0 - lane;
 			const bool act = j >= st;
-			int32_t sc = LC_NONE, pj = -1;
+			int32_t sc = LC_NONE, pj = -1, vj = 0;
 			if (act) {
 				const mg128_t aj = a[j];
+				const int32_t fj = f[j];
+				pj = p[j], vj = v[j];
 				sc = lc_score(xi, yi, aj.x, aj.y, P);
-				if (sc != LC_NONE) { sc += f[j]; pj = p[j]; }
+				if (sc != LC_NONE) sc += fj; else pj = -1;
 			}
 			const bool valid = sc != LC_NONE;
 			if (valid && pj >= 0) t[pj] = i; // lchain.c:188 (harmless beyond the cut: only compared against this i)
@@ -187,13 +195,13 @@ __device__ void lc_dp(const mg128_t *__restrict__ a, int32_t n, mga_lchain_par_t
 			const uint64_t imp_b = m_imp & before;
 			if (imp_b) {
 				const int bl = 63 - __clzll(imp_b);
-				max_f = __shfl(sc, bl), max_j = j0 - bl;
+				max_f = __shfl(sc, bl), max_v = __shfl(vj, bl), max_j = j0 - bl;
 			}
 			if (cut_lane < 64) { cut = true; end_j = j0 - cut_lane; }
 			__syncthreads();
 		}
 		// lchain.c:191-196: best-scoring anchor within reach, recomputed when it fell out of range
-		if (max_ii < 0 || xi - a[max_ii].x > (uint64_t)(int64_t)P.max_dist_x) {
+		if (max_ii < 0 || xi - am.x > (uint64_t)(int64_t)P.max_dist_x) {
 			int32_t bf = INT32_MIN, bj = -1;
 			for (int32_t j = i - 1 - lane; j >= st; j -= 64) { const int32_t fj = f[j]; if (bf < fj) bf = fj, bj = j; } // descending j per lane: first max kept
 			for (int d = 32; d > 0; d >>= 1) {
@@ -201,16 +209,16 @@ __device__ void lc_dp(const mg128_t *__restrict__ a, int32_t n, mga_lchain_par_t
 				if (of > bf || (of == bf && oj > bj)) bf = of, bj = oj; // ties: the larger j was met first
 			}
 			max_ii = bj;
+			if (max_ii >= 0) am = a[max_ii], fm = f[max_ii], vm = v[max_ii];
 		}
 		if (max_ii >= 0 && max_ii < end_j) { // lchain.c:197-201
-			const mg128_t am = a[max_ii];
 			const int32_t tmp = lc_score(xi, yi, am.x, am.y, P);
-			if (tmp != LC_NONE && max_f < tmp + f[max_ii]) max_f = tmp + f[max_ii], max_j = max_ii;
+			if (tmp != LC_NONE && max_f < tmp + fm) max_f = tmp + fm, max_j = max_ii, max_v = vm;
 		}
 		int32_t vi = max_f;
-		if (max_j >= 0) { const int32_t vj = v[max_j]; if (vj > max_f) vi = vj; }
+		if (max_j >= 0 && max_v > max_f) vi = max_v;
 		if (lane == 0) { f[i] = max_f; p[i] = max_j; v[i] = vi; }
-		if (max_ii < 0 || (xi - a[max_ii].x <= (uint64_t)(int64_t)P.max_dist_x && f[max_ii] < max_f)) max_ii = i;
+		if (max_ii < 0 || (xi - am.x <= (uint64_t)(int64_t)P.max_dist_x && fm < max_f)) max_ii = i;
 		__syncthreads();
 	}
 }
@@ -266,8 +274,8 @@ __device__ bool lc_dp_rmq(const mg128_t *__restrict__ a, int32_t n, const lc_res
 		bool tie = false;
 		for (int32_t j = st + lane; j < i0; j += 64) {
 			const int32_t yj = (int32_t)a[j].y;
+			const double pj = pri[j]; // (with its anchor, not behind the window test: one trip per block instead of two)
 			if ((yj > ylo && yj < yhi) || (j == 0 && yj == yhi)) {
-				const double pj = pri[j];
 				if (bj < 0 || pj < bp) bp = pj, bj = j, tie = false;
 				else if (pj == bp) tie = true;
 			}

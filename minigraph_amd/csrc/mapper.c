@@ -1244,7 +1244,7 @@ mga_stream_t *mga_stream_open(const mg_idx_t *gi, const mg_mapopt_t *opt, int n_
 	int i;
 	if (mga_dev_init() < 0) return 0;
 	if (env_int("MGA_SEGV_TRACE", 0)) signal(SIGSEGV, segv_trace);
-	if (g_dbg_pipe < 0) { g_dbg_pipe = env_int("MGA_DEBUG_PIPE", 0); g_gpu_wfa.avail = env_int("MGA_WFA_SLOTS", 2); /* two chunks may be in their WFA phase: the second one fills the tails of the first */ }
+	if (g_dbg_pipe < 0) { g_dbg_pipe = env_int("MGA_DEBUG_PIPE", 0); g_gpu_wfa.avail = env_int("MGA_WFA_SLOTS", 2); g_gpu_front.avail = env_int("MGA_FRONT_SLOTS", 1); /* two chunks may be in their WFA phase: the second one fills the tails of the first */ }
 	g_cpu_on = g_dbg_pipe > 0;
 	S = MGA_CALLOC(mga_stream_t, 1);
 	S->gi = gi, S->opt = *opt, S->n_threads = n_threads > 0 ? n_threads : 1;
@@ -1512,7 +1512,7 @@ void mg_map_frag(const mg_idx_t *gi, int n_segs, const int *qlens, const char **
 		mga_stats_t cst;
 		int rc;
 		memset(&cst, 0, sizeof cst);
-		if (g_dbg_pipe < 0) { g_dbg_pipe = env_int("MGA_DEBUG_PIPE", 0); g_gpu_wfa.avail = env_int("MGA_WFA_SLOTS", 2); }
+		if (g_dbg_pipe < 0) { g_dbg_pipe = env_int("MGA_DEBUG_PIPE", 0); g_gpu_wfa.avail = env_int("MGA_WFA_SLOTS", 2); g_gpu_front.avail = env_int("MGA_FRONT_SLOTS", 1); }
 		rc = mga_dev_init() < 0 || mga_dev_bind_thread() < 0 || (b->P.sc == 0 && (b->P.sc = mga_sctx_create()) == 0) ? -1 : 0;
 		if (rc == 0) rc = map_chunk(&b->P, gi, 1, qlens, seqs, &qname, gcs, opt, 1, 0, 0, 0, &cst, 0);
 		if (rc < 0) { fprintf(stderr, "[E::%s] %s\n", __func__, mga_last_error()); abort(); /* no CPU fallback */ }
