@@ -4,7 +4,12 @@
  * unique among the threads working on THIS call.  The pool grows on demand and its workers sleep on a condition
  * variable between calls; several pipeline threads may issue calls concurrently.  A call posts T-1 tickets and
  * the caller works as tid 0, so a call never waits for a pool worker to become free before making progress. */
+#define _GNU_SOURCE
 #include <pthread.h>
+#include <stdlib.h>
+#include <unistd.h>
+#include <sys/resource.h>
+#include <sys/syscall.h>
 #include "mga_host.h"
 
 typedef struct pf_job_s {
@@ -35,6 +40,11 @@ static void pf_run(pf_job_t *p, int tid)
 static void *pf_worker(void *a)
 {
 	(void)a;
+	{ /* MGA_POOL_NICE=n: the pool's workers run at nice n -- bulk host work (GAF text, chain records) then yields to the pipeline threads, whose kernel launches and stream waits
+	   * are what keeps the GPU fed when a rank has one or two cores to itself */
+		const char *e = getenv("MGA_POOL_NICE");
+		if (e && atoi(e) > 0) (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), atoi(e));
+	}
 	pthread_mutex_lock(&g_qmtx);
 	for (;;) {
 		pf_ticket_t t;
