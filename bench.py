@@ -432,7 +432,7 @@ def main():
             traffic, traffic_src = None, None
             try:
                 import glob
-                pf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03*_pmc.json")))[-1]
+                pf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]*_pmc.json")))[-1]
                 pk = json.load(open(pf))["kernels"]
                 sel = [v for k, v in pk.items() if (k == "k_wfa" or k.startswith("k_wfa_r<") or k.startswith("k_wfa_fw<") or k.startswith("k_wfa_tb") if dom == "k_wfa" else k.startswith(dom))]
                 nl = sum(v.get("launches_fetch", 0) for v in sel)
@@ -446,13 +446,32 @@ def main():
                     traffic_src = os.path.relpath(pf, ROOT) + " (committed rocprofv3 --pmc passes of this command, not measured in this run%s)" % ("; STALE: taken from other WFA kernel sources than this tree's" if stale else "")
             except Exception:
                 pass
+            # vector-ALU utilisation per rung of the WFA ladder (and the other big kernels), from the committed SQ counter passes of this command (profiles/*_sq_counters.txt,
+            # tools/prof_all.sh): bench.py cannot collect counters around itself, so the figures carry their source
+            valu_busy, valu_src = None, None
+            try:
+                import glob
+                sf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[4-9]*_sq_counters.txt")))[-1]
+                valu_busy = {}
+                for ln in open(sf):
+                    f = ln.split()
+                    if ln.startswith("#") or len(f) < 14 or f[-1] == "-" or not (f[0].startswith("k_wfa") or f[0] in ("k_lchain", "k_text", "k_sketch", "k_seed_fill", "k_gchain_p1", "k_gchain_p2", "k_gchain_p3")):
+                        continue
+                    try:
+                        valu_busy[" ".join(f[:-13])] = dict(valu_busy=float(f[-1]), waves_per_simd=float(f[-2]), valu_share_of_a_wave=float(f[-8]), wait_share_of_a_wave=float(f[-7]))
+                    except ValueError:
+                        pass
+                valu_src = os.path.relpath(sf, ROOT) + " (committed rocprofv3 --pmc SQ_* passes of this command, isolated; valu_busy = SQ_ACTIVE_INST_VALU / (32 x SQ_BUSY_CYCLES))"
+            except Exception:
+                valu_busy = None
             ach = alg[dom] / (fam[dom] * 1e-3) / 1e9 if fam[dom] > 0 else 0.0
             roof = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
                         launches=launches[dom], avg_launch_ms=fam[dom] / max(1, launches[dom]), alg_bytes_per_launch=alg[dom] / max(1, launches[dom]),
                         family_ms_per_pass=fam[dom], pass_ms=isolated["ms"],
                         note="dominant kernel family by HIP-event time in the ISOLATED pass (one chunk in flight: launch durations do not overlap, sum <= pass_ms); "
                              "the family is bound by vector-instruction ISSUE, not by HBM: int_issue prices it against the measured integer issue rate of a SIMD (profiles/r03_valu_rate.txt)",
-                        families={k: dict(ms=round(fam[k], 2), launches=launches[k], alg_GBps=round(alg[k] / max(fam[k], 1e-9) / 1e6, 2)) for k in fam})
+                        families={k: dict(ms=round(fam[k], 2), launches=launches[k], alg_GBps=round(alg[k] / max(fam[k], 1e-9) / 1e6, 2)) for k in fam},
+                        valu_busy=valu_busy, valu_busy_source=valu_src)
             # integer-issue roofline of the WFA family: wavefront cells (the REFERENCE's band: what miniwfa computes for the same gaps) per second against what the vector
             # ALUs can issue.  [measured, minigraph_amd/tools/valu_rate.hip -> profiles/r03_valu_rate.txt] a gfx950 SIMD issues one wave64 v_max_i32 / v_add_u32 /
             # DPP move every 4.15 cycles; a 64-cell slot step of the windowed kernel is ~110 such instructions (ISA count incl. one mask-window extension)

@@ -9,20 +9,20 @@ set -u
 tag=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 ulimit -c 0
-B="python bench.py --steps 1 --warmup 1 --no-cpu --resident-steps 0 --one-placement"
+B="python bench.py --steps 1 --warmup 1 --no-cpu --resident-steps 0 --one-placement --no-asm --no-rank-share"
 out=gpurun_out
 parts=${PROF_PARTS:-iso pipe dev pmc sq}   # PROF_PARTS="iso pmc": a subset (each part is one or two bench runs under rocprofv3, about 70 s each)
 has() { case " $parts " in *" $1 "*) return 0;; esac; return 1; }
 has iso && {
-MGA_PIPE=1 MGA_WFA_SIDE=0 bash minigraph_amd/tools/prof_trace.sh ${tag}_iso MGA_PIPE=1 MGA_WFA_SIDE=0 -- --steps 1 --warmup 1 --no-cpu --resident-steps 0 --one-placement > /dev/null 2>&1
+MGA_PIPE=1 MGA_WFA_SIDE=0 bash minigraph_amd/tools/prof_trace.sh ${tag}_iso MGA_PIPE=1 MGA_WFA_SIDE=0 -- --steps 1 --warmup 1 --no-cpu --resident-steps 0 --one-placement --no-asm --no-rank-share > /dev/null 2>&1
 mv $out/${tag}_iso_kernel_stats.txt $out/${tag}_kernel_stats_isolated.txt
 }
 has pipe && {
-bash minigraph_amd/tools/prof_trace.sh ${tag}_pipe -- --steps 2 --warmup 1 --no-cpu --resident-steps 0 --one-placement > /dev/null 2>&1
+bash minigraph_amd/tools/prof_trace.sh ${tag}_pipe -- --steps 2 --warmup 1 --no-cpu --resident-steps 0 --one-placement --no-asm --no-rank-share > /dev/null 2>&1
 mv $out/${tag}_pipe_kernel_stats.txt $out/${tag}_kernel_stats_pipelined.txt
 }
 has dev && {
-bash minigraph_amd/tools/prof_trace.sh ${tag}_dev MGA_PIPE=1 MGA_WFA_SIDE=0 -- --steps 1 --warmup 1 --no-cpu --resident-steps 0 --one-placement --threads 8 > /dev/null 2>&1
+bash minigraph_amd/tools/prof_trace.sh ${tag}_dev MGA_PIPE=1 MGA_WFA_SIDE=0 -- --steps 1 --warmup 1 --no-cpu --resident-steps 0 --one-placement --no-asm --no-rank-share --threads 8 > /dev/null 2>&1
 mv $out/${tag}_dev_kernel_stats.txt $out/${tag}_kernel_stats_devchain_isolated.txt
 }
 has pmc && {
@@ -39,7 +39,10 @@ has sq && {
 rm -rf $out/prof_${tag}_sq1 $out/prof_${tag}_sq2
 MGA_PIPE=1 MGA_WFA_SIDE=0 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY -d $out/prof_${tag}_sq1 -o pmc -- $B > /dev/null 2> $out/${tag}_sq1.err
 MGA_PIPE=1 MGA_WFA_SIDE=0 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU -d $out/prof_${tag}_sq2 -o pmc -- $B > /dev/null 2> $out/${tag}_sq2.err
-S1=$(find $out/prof_${tag}_sq1 -name "*.db" | head -1); S2=$(find $out/prof_${tag}_sq2 -name "*.db" | head -1)
-python minigraph_amd/tools/prof_summary.py --sq "$S1" "$S2" "MGA_PIPE=1 MGA_WFA_SIDE=0 $B (durations are inflated by the counter collection)" > $out/${tag}_sq_counters.txt 2> $out/${tag}_sq_summary.err
+# (third pass: the same first counter set with graph chaining + gap list on the device -- k_gchain_p1 / p2 / p3, k_plan -- listed behind the others: a kernel's first pass wins)
+rm -rf $out/prof_${tag}_sq3
+MGA_PIPE=1 MGA_WFA_SIDE=0 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY -d $out/prof_${tag}_sq3 -o pmc -- $B --threads 8 > /dev/null 2> $out/${tag}_sq3.err
+S1=$(find $out/prof_${tag}_sq1 -name "*.db" | head -1); S2=$(find $out/prof_${tag}_sq2 -name "*.db" | head -1); S3=$(find $out/prof_${tag}_sq3 -name "*.db" | head -1)
+python minigraph_amd/tools/prof_summary.py --sq "$S1" "$S2" "$S3" "MGA_PIPE=1 MGA_WFA_SIDE=0 $B (durations are inflated by the counter collection)" > $out/${tag}_sq_counters.txt 2> $out/${tag}_sq_summary.err
 }
 ls -la $out/${tag}_*

@@ -49,25 +49,45 @@ def main_pmc_json(fetch_db, write_db, source):
 
 
 def main_sq(paths, title):
-    """per kernel, over one or more --pmc passes of SQ counters: instructions per wave and the shares of the waves' resident cycles"""
+    """per kernel, over one or more --pmc passes of SQ counters: instructions per wave and the shares of the waves' resident cycles.  Every pass is normalised by ITS OWN
+    SQ_WAVES / SQ_WAVE_CYCLES / SQ_BUSY_CYCLES (all passes collect the first two), then the columns of the passes are put side by side."""
     acc = {}
     for path in paths:
+        one = {}
         for name, counter, calls, tot in pmc_rows(path):
-            k = acc.setdefault(name.split("(")[0].replace("void ", "").strip()[:46], {})
+            k = one.setdefault(name.split("(")[0].replace("void ", "").strip()[:46], {})
             k[counter] = k.get(counter, 0.0) + tot
-            k["_calls_" + counter] = calls
+            k["_calls"] = calls
+        for name, k in one.items():
+            w, cyc, busy = k.get("SQ_WAVES", 0.0), k.get("SQ_WAVE_CYCLES", 0.0), k.get("SQ_BUSY_CYCLES", 0.0) * 32.0
+            d = acc.setdefault(name, {})
+            d.setdefault("calls", k.get("_calls", 0)); d.setdefault("waves", w); d.setdefault("cycles", cyc)
+            for c, v in k.items():
+                if c.startswith("_") or c in ("SQ_WAVES", "SQ_WAVE_CYCLES"):
+                    continue
+                if c.startswith("SQ_INSTS_") and w:
+                    d.setdefault(c + "/wave", v / w)
+                elif cyc:
+                    d.setdefault(c + "/cyc", v / cyc)
+            if busy and cyc:
+                d.setdefault("occ", cyc / busy)
+                if "SQ_ACTIVE_INST_VALU" in k:
+                    d.setdefault("valu_busy", k["SQ_ACTIVE_INST_VALU"] / busy)
     print("# rocprofv3 --pmc SQ_* (own passes, no tracing)  %s" % title)
     print("# per wave: instructions issued; shares: fraction of the waves' resident cycles (SQ_WAVE_CYCLES): valu = SQ_ACTIVE_INST_VALU, wait = SQ_WAIT_ANY (parked on s_waitcnt / barrier),")
-    print("# stall = SQ_WAIT_INST_ANY (issue stalls), vmem / lds / salu = SQ_INST_CYCLES_VMEM / SQ_ACTIVE_INST_LDS / SQ_INST_CYCLES_SALU where collected; busy = SQ_BUSY_CYCLES summed over SEs")
-    print("%-46s %7s %12s %11s %11s %9s %7s %7s %7s %7s %7s %7s" % ("kernel", "calls", "waves", "VALU/wave", "SALU/wave", "LDS/wave", "valu", "wait", "stall", "vmem", "lds", "salu"))
-    def share(k, c):
-        return ("%7.3f" % (k[c] / k["SQ_WAVE_CYCLES"])) if c in k and k.get("SQ_WAVE_CYCLES") else "      -"
-    for name, k in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
-        w = k.get("SQ_WAVES", 0.0)
-        if not w:
+    print("# stall = SQ_WAIT_INST_ANY (issue stalls), vmem / lds / salu = SQ_INST_CYCLES_VMEM / SQ_ACTIVE_INST_LDS / SQ_INST_CYCLES_SALU where collected")
+    print("# occ = waves resident per SIMD while the kernel runs = SQ_WAVE_CYCLES / (32 x SQ_BUSY_CYCLES) (SQ_BUSY_CYCLES is summed over the 32 shader engines, each with 32 SIMDs);")
+    print("# valu_busy = SQ_ACTIVE_INST_VALU / (32 x SQ_BUSY_CYCLES): the fraction of a SIMD's cycles in which one of its waves has a vector instruction in the ALU")
+    print("%-46s %7s %12s %11s %11s %9s %7s %7s %7s %7s %7s %7s %6s %9s" % ("kernel", "calls", "waves", "VALU/wave", "SALU/wave", "LDS/wave", "valu", "wait", "stall", "vmem", "lds", "salu", "occ", "valu_busy"))
+
+    def col(d, key, fmt, width):
+        return (fmt % d[key]) if key in d else " " * (width - 1) + "-"
+    for name, d in sorted(acc.items(), key=lambda kv: -kv[1].get("cycles", 0)):
+        if not d.get("waves"):
             continue
-        print("%-46s %7d %12d %11.0f %11.0f %9.0f %s %s %s %s %s %s" % (name, k.get("_calls_SQ_WAVES", 0), w, k.get("SQ_INSTS_VALU", 0) / w, k.get("SQ_INSTS_SALU", 0) / w, k.get("SQ_INSTS_LDS", 0) / w,
-              share(k, "SQ_ACTIVE_INST_VALU"), share(k, "SQ_WAIT_ANY"), share(k, "SQ_WAIT_INST_ANY"), share(k, "SQ_INST_CYCLES_VMEM"), share(k, "SQ_ACTIVE_INST_LDS"), share(k, "SQ_INST_CYCLES_SALU")))
+        print("%-46s %7d %12d %s %s %s %s %s %s %s %s %s %s %s" % (name, d["calls"], d["waves"], col(d, "SQ_INSTS_VALU/wave", "%11.0f", 11), col(d, "SQ_INSTS_SALU/wave", "%11.0f", 11),
+              col(d, "SQ_INSTS_LDS/wave", "%9.0f", 9), col(d, "SQ_ACTIVE_INST_VALU/cyc", "%7.3f", 7), col(d, "SQ_WAIT_ANY/cyc", "%7.3f", 7), col(d, "SQ_WAIT_INST_ANY/cyc", "%7.3f", 7),
+              col(d, "SQ_INST_CYCLES_VMEM/cyc", "%7.3f", 7), col(d, "SQ_ACTIVE_INST_LDS/cyc", "%7.3f", 7), col(d, "SQ_INST_CYCLES_SALU/cyc", "%7.3f", 7), col(d, "occ", "%6.2f", 6), col(d, "valu_busy", "%9.3f", 9)))
 
 
 def main():
