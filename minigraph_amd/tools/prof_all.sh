@@ -45,4 +45,5 @@ MGA_PIPE=1 MGA_WFA_SIDE=0 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU S
 S1=$(find $out/prof_${tag}_sq1 -name "*.db" | head -1); S2=$(find $out/prof_${tag}_sq2 -name "*.db" | head -1); S3=$(find $out/prof_${tag}_sq3 -name "*.db" | head -1)
 python minigraph_amd/tools/prof_summary.py --sq "$S1" "$S2" "$S3" "MGA_PIPE=1 MGA_WFA_SIDE=0 $B (durations are inflated by the counter collection)" > $out/${tag}_sq_counters.txt 2> $out/${tag}_sq_summary.err
 }
+rm -rf $out/prof_${tag}_* $out/prof_${tag}   # the raw rocprofv3 outputs (hundreds of MB) stay on the GPU box: gpurun copies at most 64 MiB back
 ls -la $out/${tag}_*
