@@ -1636,6 +1636,56 @@ GC_HDN int gc_gw_dedup_lds(gc_arena_t *A, gc_gw_t *z, gc_diag_v *B, int *handled
 	return GC_OK;
 }
 #endif
+#if !defined(__HIP_DEVICE_COMPILE__)
+/* gwf_dedup on ONE lane (the host instantiation; round 4): the generic routine below is written for 64 lanes -- partition, rank sort, merge by binary search, two verdict
+ * passes and two compactions, a binary search per cell into the finished ranges -- which a single thread pays as half a dozen sweeps over the wavefront ([measured,
+ * GC_HOST_PROF] 44 % of a bridge's cycles, next to 48 % for the runs).  Same result in two sweeps: the flagged cells (a handful: what the head cells pushed) are pulled out,
+ * insertion-sorted (klib's own method up to 64 records: stable) and merged back from the top (ties: the in-order cell first); then one sweep keeps the first of the furthest
+ * cells of every (vertex, diagonal) while a second cursor walks the finished ranges alongside (both lists ascend).  *handled = 0: more than 64 flagged cells or in-order cells
+ * out of order -- the generic routine, on the untouched list. */
+GC_HD int gc_gw_dedup_lane(gc_arena_t *A, gc_gw_t *z, int32_t *n_a_, gc_diag_t *a, int *handled)
+{
+	const int32_t n = *n_a_;
+	int32_t n_c = 0, unsorted = 0, b_unsorted = 0, have_b = 0;
+	uint64_t last_b = 0;
+	*handled = 0;
+	for (int32_t i = 0; i < n; ++i) {
+		if (i && a[i - 1].vd > a[i].vd) unsorted = 1;
+		if (a[i].xo & 1) ++n_c;
+		else { if (have_b && last_b > a[i].vd) b_unsorted = 1; last_b = a[i].vd, have_b = 1; }
+	}
+	if (unsorted) {
+		if (n_c > 64 || b_unsorted) return GC_OK;
+		GC_TRY(gc_vec_reserve(A, z->ooo, n_c > 0 ? n_c : 1));
+		gc_diag_t *c = z->ooo.a;
+		int32_t nb = 0, nc = 0;
+		for (int32_t i = 0; i < n; ++i) { if (a[i].xo & 1) c[nc++] = a[i]; else { if (nb != i) a[nb] = a[i]; ++nb; } }
+		for (int32_t i = 1; i < nc; ++i) { /* insertion sort: stable */
+			const gc_diag_t t = c[i];
+			int32_t j = i;
+			for (; j > 0 && t.vd < c[j - 1].vd; --j) c[j] = c[j - 1];
+			c[j] = t;
+		}
+		for (int32_t j = 0; j < nc; ++j) c[j].xo &= 0xfffffffeU;
+		for (int32_t i = nb - 1, j = nc - 1, k = n - 1; j >= 0; --k) { /* merge from the top; an in-order cell goes in FRONT of an equal flagged one */
+			if (i >= 0 && a[i].vd > c[j].vd) a[k] = a[i--]; else a[k] = c[j--];
+		}
+	}
+	const gc_intv_t *dn = z->done.a;
+	const int32_t nd = z->done.n;
+	int32_t di = 0, m = 0;
+	for (int32_t i = 0; i < n;) {
+		const uint64_t vd = a[i].vd;
+		int32_t best = i, j = i + 1;
+		for (; j < n && a[j].vd == vd; ++j) if (a[best].k < a[j].k) best = j; /* the FIRST of the furthest */
+		while (di < nd && dn[di].vd1 <= vd) ++di;
+		if (!(di < nd && vd >= dn[di].vd0)) { gc_diag_t t = a[best]; t.len = 0; a[m++] = t; }
+		i = j;
+	}
+	*n_a_ = m, *handled = 1;
+	return GC_OK;
+}
+#endif
 GC_HD int gc_gw_dedup(gc_arena_t *A, gc_gw_t *z, int32_t *n_a_, gc_diag_t *a) /* gwf_dedup, gfa-ed.c:258-271 */
 {
 	int32_t n_a = *n_a_;
@@ -1760,6 +1810,33 @@ GC_HDN int gc_gw_extend_run(gc_arena_t *A, gc_gw_t *z, int32_t n, gc_diag_t *a, 
 		a[j].len = k - a[j].k, a[j].xo += (uint32_t)(k - a[j].k) << 2, a[j].k = k;
 	}
 	gc_sync();
+#if !defined(__HIP_DEVICE_COMPILE__) && !defined(GC_AB_NO_LANE_RUNS)
+	{ /* ONE lane (round 4): what the three lane-parallel passes below leave -- the run's cells at a vertex / query end to H (flagged), the next wavefront's cells of the run and of
+	   * the two diagonals beside it to B, the diagonals that ran off the vertex to the finished list, each in diagonal order -- in one sweep over the extended cells */
+		gc_diag_t *bo = &B->a[B->n], *ho = &H->a[H->n];
+		gc_intv_t *fo = &z->fresh.a[z->fresh.n];
+		int32_t nb = 0, nh = 0, nf = 0;
+		const int32_t ql = z->ql;
+#define GC_RUN_EMIT(vd_, k_, x_, t_) do { const uint64_t evd_ = (vd_); const int32_t ek_ = (k_), ed_ = (int32_t)evd_ - GC_DSHIFT; \
+			if (ed_ + ek_ < ql && ek_ < vl) { gc_diag_t *o_ = &bo[nb++]; o_->vd = evd_, o_->k = ek_, o_->len = 0, o_->xo = (x_), o_->t = (t_), o_->pad_[0] = o_->pad_[1] = 0; } \
+			else if (ek_ == vl) { fo[nf].vd0 = evd_, fo[nf].vd1 = evd_ + 1, ++nf; } } while (0)
+		GC_RUN_EMIT(a[0].vd - 1, a[0].k + 1, a[0].xo + 2, a[0].t);
+		for (int32_t j = 0; j < n; ++j) {
+			uint32_t x;
+			int32_t k, t;
+			if (j > 0 && a[j - 1].k > a[j].k + 1) x = a[j - 1].xo + 2, k = a[j - 1].k, t = a[j - 1].t; /* insertion from the left neighbour ... */
+			else x = a[j].xo + 4, t = a[j].t, k = a[j].k + 1;                                      /* ... unless the mismatch gets at least as far */
+			if (j + 1 < n && !(k > a[j + 1].k + 1)) x = a[j + 1].xo + 2, t = a[j + 1].t, k = a[j + 1].k + 1; /* deletion from the right neighbour, when it gets at least as far */
+			GC_RUN_EMIT(a[j].vd, k, x, t);
+		}
+		GC_RUN_EMIT(a[n - 1].vd + 1, a[n - 1].k, a[n - 1].xo + 2, a[n - 1].t);
+#undef GC_RUN_EMIT
+		for (int32_t j = 0; j < n; ++j) /* (behind the sweep above, which reads the cells' flag bits as they came) */
+			if (a[j].k == vl - 1 || (int32_t)a[j].vd - GC_DSHIFT + a[j].k == ql - 1) { a[j].xo |= 1; ho[nh++] = a[j]; }
+		B->n += nb, H->n += nh, z->fresh.n += nf;
+		return GC_OK;
+	}
+#endif
 	gc_diag_t *b = &B->a[B->n];
 	GC_PAR_FOR(j, n) { /* b[j + 1]: the cell of diagonal a[j].vd in the next wavefront */
 		uint32_t x;
@@ -1914,6 +1991,12 @@ GC_HD int gc_gw_step(gc_arena_t *A, gc_gw_t *z, uint32_t v1, int32_t off1, int *
 		GC_TRY(gc_gw_dedup_lds(A, z, B, &handled));
 		GC_COUNT(A, 10, handled ? 1 << 20 : 0); /* (profiling: high part of slot 10 = dedups done on LDS) */
 		if (!handled) GC_TRY(gc_gw_dedup_wave(A, z, B, &handled));
+		if (!handled)
+#elif !defined(__HIP_DEVICE_COMPILE__) && !defined(GC_AB_NO_LANE_DEDUP)
+		int handled = 0;
+		for (int32_t i = 0; i < z->fresh.n; ++i) GC_TRY(gc_intv_add(A, &z->done, z->fresh.a[i].vd0, z->fresh.a[i].vd1)); /* this step's finished diagonals */
+		z->fresh.n = 0;
+		GC_TRY(gc_gw_dedup_lane(A, z, &B->n, B->a, &handled));
 		if (!handled)
 #endif
 		GC_TRY(gc_gw_dedup(A, z, &B->n, B->a));
