@@ -446,22 +446,45 @@ def main():
                     traffic_src = os.path.relpath(pf, ROOT) + " (committed rocprofv3 --pmc passes of this command, not measured in this run%s)" % ("; STALE: taken from other WFA kernel sources than this tree's" if stale else "")
             except Exception:
                 pass
-            # vector-ALU utilisation per rung of the WFA ladder (and the other big kernels), from the committed SQ counter passes of this command (profiles/*_sq_counters.txt,
-            # tools/prof_all.sh): bench.py cannot collect counters around itself, so the figures carry their source
+            # vector-ALU utilisation per rung of the WFA ladder (and the other big kernels): vector instructions per launch -- SQ_INSTS_VALU of the committed counter passes of this
+            # command (profiles/*_sq_counters.txt, tools/prof_all.sh: bench.py cannot collect counters around itself) -- x 4.15 cycles of a SIMD per wave64 integer instruction
+            # ([measured] profiles/r03_valu_rate.txt) over the SIMD cycles of the launch as timed HERE (HIP events of the isolated pass): the share of the chip's vector issue
+            # slots the kernel uses while it runs
             valu_busy, valu_src = None, None
             try:
                 import glob
                 sf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[4-9]*_sq_counters.txt")))[-1]
-                valu_busy = {}
+                sq = {}
                 for ln in open(sf):
                     f = ln.split()
-                    if ln.startswith("#") or len(f) < 14 or f[-1] == "-" or not (f[0].startswith("k_wfa") or f[0] in ("k_lchain", "k_text", "k_sketch", "k_seed_fill", "k_gchain_p1", "k_gchain_p2", "k_gchain_p3")):
+                    if ln.startswith("#") or len(f) < 14 or f[0] == "kernel":
                         continue
                     try:
-                        valu_busy[" ".join(f[:-13])] = dict(valu_busy=float(f[-1]), waves_per_simd=float(f[-2]), valu_share_of_a_wave=float(f[-8]), wait_share_of_a_wave=float(f[-7]))
+                        sq[" ".join(f[:-13])] = dict(calls=int(f[-13]), waves=float(f[-12]), valu_per_wave=float(f[-11]), valu_share=float(f[-8]) if f[-8] != "-" else None,
+                                                     wait_share=float(f[-7]) if f[-7] != "-" else None)
                     except ValueError:
                         pass
-                valu_src = os.path.relpath(sf, ROOT) + " (committed rocprofv3 --pmc SQ_* passes of this command, isolated; valu_busy = SQ_ACTIVE_INST_VALU / (32 x SQ_BUSY_CYCLES))"
+                names = {"k_wfa_w[16x4]": "k_wfa_fw<16, 1, 128>", "k_wfa_w[32x2]": "k_wfa_fw<32, 1, 192>", "k_wfa_w[64]": "k_wfa_fw<64, 1, 256>", "k_wfa_w[128]": "k_wfa_fw<64, 2, 384>",
+                         "k_wfa_w[192]": "k_wfa_fw<64, 3, 384>", "k_wfa_w[256]": "k_wfa_fw<64, 4, 512>", "k_wfa_r[512]": "k_wfa_r<4, 2, 1024, 1024, 8192, true>", "k_wfa_tb": "k_wfa_tb",
+                         "k_lchain": "k_lchain", "k_sketch": "k_sketch", "k_text": "k_text<64>", "k_seed_fill": "k_seed_fill", "k_seed_count": "k_seed_count"}
+                # the counter passes ran `bench.py --steps S --warmup W --one-placement`: S + W + 1 (the isolated one) passes over the SAME reads as this run's isolated pass, so a
+                # kernel's instructions per pass = its total / (S + W + 1); launches are not compared one to one (the chunking of a pass may differ).  k_sketch is left out: its
+                # counters include the index build's launches over the graph
+                hdr = open(sf).readline()
+                m_s, m_w = re.search(r"--steps (\d+)", hdr), re.search(r"--warmup (\d+)", hdr)
+                n_pass = int(m_s.group(1)) + int(m_w.group(1)) + 1
+                names.pop("k_sketch")
+                valu_busy = {}
+                for kn, sn in names.items():
+                    q, pr_ = sq.get(sn), prof.get(kn)
+                    if not q or not pr_ or pr_[0] <= 0 or pr_[1] <= 0 or q["calls"] <= 0:
+                        continue
+                    inst_per_pass = q["valu_per_wave"] * q["waves"] / n_pass
+                    valu_busy[kn] = dict(valu_busy=round(inst_per_pass * 4.15 / (256 * 4 * pr_[0] * 1e-3 * 2.4e9), 3), valu_instr_per_pass=round(inst_per_pass), ms_per_pass=round(pr_[0], 2),
+                                         share_of_a_waves_cycles=dict(valu=q["valu_share"], waiting=q["wait_share"]))
+                valu_src = ("VALU instructions per pass of 125000 reads: " + os.path.relpath(sf, ROOT) + " (committed rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES passes of this command, %d passes); "
+                            "kernel time per pass: this run's isolated pass; 4.15 SIMD cycles per wave64 integer instruction [measured], 1024 SIMDs at the nominal 2.4 GHz "
+                            "(a lower sustained clock raises the true figure)" % n_pass)
             except Exception:
                 valu_busy = None
             ach = alg[dom] / (fam[dom] * 1e-3) / 1e9 if fam[dom] > 0 else 0.0

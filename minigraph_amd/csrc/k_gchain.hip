@@ -522,8 +522,10 @@ extern "C" int mga_dev_gchain(mga_sctx_t *sc, const mga_didx_t *ix, const mg_map
 	memset(&G, 0, sizeof G);
 	G.arc = (const gc_arc_t*)ix->d_arc, G.idx = ix->d_arc_idx, G.seg_len = ix->d_seg_len, G.es = 0, G.seq_fw = ix->d_gseq, G.seq_rc = ix->d_gseq_rc, G.seq_off = ix->d_gseq_off;
 	gc_par_from_opt(opt, k, pen_gap, &P);
-	static int split = -1; // MGA_GC_SPLIT=0: the one-kernel form for the first launch as well
-	if (split < 0) { const char *e = getenv("MGA_GC_SPLIT"); split = e ? atoi(e) : 1; }
+	// MGA_GC_SPLIT=1: the three-launch form below for a chunk's first launch.  The default is the one-kernel form: in the pipeline (bench.py, 125000 reads per step,
+	// device placement, three interleaved repetitions) it maps 2.94 / 2.99 / 3.03 Gbp/s against 2.67 / 2.64 / 2.76 for the three launches -- each of the three ends in its
+	// own tail (p2's is its longest bridge) and the two per-read kernels run at the occupancy of the one-kernel form, see DESIGN.md "Graph chaining in three launches"
+	const int split = getenv("MGA_GC_SPLIT") ? atoi(getenv("MGA_GC_SPLIT")) : 0; // (read per launch: one launch per chunk)
 	if (tier == 0 && d_list == 0 && split) { // ---- three launches: per read / per bridge / per read (see above) ----
 		static int w2 = 0;
 		if (w2 == 0) { const char *e = getenv("MGA_GC_WAVES2"); w2 = e && atoi(e) > 0 ? atoi(e) : 2048; }

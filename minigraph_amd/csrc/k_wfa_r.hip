@@ -74,7 +74,10 @@ __global__ void __launch_bounds__(64 * NW) k_wfa_r(const int *__restrict__ n_ite
 #define WFR_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory") /* LDS-only barrier: HBM traceback stores keep flying */
 #define WFR_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-	constexpr int POOL_BLK = 512, QCHUNK = NW > 1 ? 4 : 8;
+	constexpr int POOL_BLK = 512, QCHUNK_MAX = NW > 1 ? 4 : 8;
+	// problems taken from the list per atomic: one when the list is shorter than the grid -- a tier above 256 diagonals sees a few hundred to a few thousand problems per launch,
+	// each a millisecond of dependent score steps: handing them out four at a time left three quarters of the workgroups without work and made the launch last four problems
+	const int QCHUNK = __builtin_amdgcn_readfirstlane(max(1, min(QCHUNK_MAX, n_items / (int)gridDim.x)));
 	long long blk_beg = 0, blk_end = 0; // CIGAR pool block owned by wave 0
 	int q_next = 0, q_end = 0;
 
@@ -420,7 +423,7 @@ extern "C" int mga_dev_wfa_reg(mga_sctx_t *sc, const int *d_n, int n, int first,
 	const wfr_tier_t &T = g_rtier[tier];
 	wfr_cfg_t cfg = { 4, 4, 2, 15, 1, T.cigcap, T.tbcap, 0 }; // register ages 17/3/2 are tied to these penalties (miniwfa.c:11-18)
 	cfg.ws_stride = (int64_t)(((size_t)T.cigcap * 4 + (size_t)T.tbcap + 255) & ~(size_t)255);
-	int wgs = T.n_wg < (n - first + 3) / 4 ? T.n_wg : (n - first + 3) / 4;
+	int wgs = T.n_wg < n - first ? T.n_wg : n - first; // (n: the list's capacity; the kernel sizes its queue chunks by the list's real length)
 	if (wgs < 1) wgs = 1;
 	if (mga_dbuf_reserve(&sc->wfa_ws[tier], (size_t)cfg.ws_stride * T.n_wg) < 0) return -1;
 	hipStream_t st = (hipStream_t)(stream ? stream : sc->stream);

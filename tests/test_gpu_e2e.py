@@ -143,6 +143,7 @@ def test_error_free_reads_need_no_wfa_problem():
 ])
 def test_parity_sweep_vs_reference_binary(tag, simargs, cigar, monkeypatch):
     monkeypatch.setenv("MGA_DEV_GCHAIN", "0" if zlib.crc32(tag.encode()) & 1 else "1")  # both placements of graph chaining over the sweep
+    monkeypatch.setenv("MGA_GC_SPLIT", "1" if zlib.crc32(tag.encode()) & 2 else "0")     # ... and, on the device, both its one-kernel and its three-launch form
     """shapes the benchmark workload does not reach: wide WFA tiers (long gaps of long / noisy reads), many short reads,
     several stable sequences, the chains-only output"""
     need_ref()
@@ -822,6 +823,13 @@ def test_graph_chaining_on_device_equals_host_instantiation_and_reference(monkey
         assert st["n_gwfa"] > 500 and st["n_shortk"] > 500, st
     assert st["n_gc_retry"] == 0 and 0 < st["gc_arena_peak"] < (1 << 20), st
     assert st["n_wfa_dev_plan"] > 0.99 * st["n_wfa"] > 0, st   # the gap list was made on the device too (k_plan.hip; all but the reads the host chained)
+    mga.prof_enable(True); mga.prof_get(reset=True)
+    monkeypatch.setenv("MGA_GC_SPLIT", "1")                     # the three-launch form (k_gchain_p1 per read / k_gchain_p2 per bridge / k_gchain_p3 per read): same bytes
+    dev_split = mga.map_reads(G, R, n_threads=8)
+    pr = mga.prof_get(reset=True); mga.prof_enable(False)
+    assert pr["k_gchain_p2"][1] > 0 and pr["k_gchain_p3"][1] > 0, pr   # ... and it did run
+    assert dev_split == dev
+    monkeypatch.delenv("MGA_GC_SPLIT"); mga.get_stats(G, reset=True)
     monkeypatch.setenv("MGA_DEV_PLAN", "0")                     # device chains, gap list by host threads (align.c)
     dev_hostplan = mga.map_reads(G, R, n_threads=8)
     st1 = mga.get_stats(G, reset=True)
@@ -857,7 +865,7 @@ def test_text_pool_is_regrown_and_relaunched(monkeypatch):
 
 
 def test_device_placement_is_deterministic_over_repeated_runs(monkeypatch):
-    """the all-device placement (k_gchain_p1 / p2 / p3, k_plan, the windowed WFA ladder with its device-side work lists and atomically
+    """the all-device placement (k_gchain -- and, in the second sweep, its three-launch form k_gchain_p1 / p2 / p3 --, k_plan, the windowed WFA ladder with its device-side work lists and atomically
     reserved pools, k_text) maps ONE workload 20 times: every run gives the same bytes, and they are the reference's.  Atomics only hand out PLACES (pool offsets, list
     slots, job order); nothing a place decides may reach the output.  A second sweep runs with few resident wavefronts and small job quanta so that the order in which
     reads / bridges / gaps are picked up differs from the first."""
@@ -879,7 +887,8 @@ def test_device_placement_is_deterministic_over_repeated_runs(monkeypatch):
     st = mga.get_stats(G)
     assert st["n_gwfa"] > 0 and st["n_wfa_dev_plan"] > 0   # the device did chain and plan
     G.close()
-    monkeypatch.setenv("MGA_GC_WAVES", "96")     # other pick-up orders: 96 resident wavefronts per part, chunks of 1000 reads, two chunks in flight
+    monkeypatch.setenv("MGA_GC_WAVES", "96")     # other pick-up orders: the three-launch form with 96 resident wavefronts per part, chunks of 1000 reads, two chunks in flight
+    monkeypatch.setenv("MGA_GC_SPLIT", "1")
     monkeypatch.setenv("MGA_GC_WAVES2", "160")
     monkeypatch.setenv("MGA_CHUNK", "1000")
     code = ("import sys, hashlib; sys.path.insert(0, %r); import minigraph_amd as mga\n"
