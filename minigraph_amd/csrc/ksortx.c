@@ -25,12 +25,20 @@ static void kx_sort(kx_t *a, int64_t n, int key_bytes)
 	if (n <= 64) { kx_insertion(a, n); return; }
 	stk = MGA_MALLOC(rng_t, cap);
 	stk[top].b = 0, stk[top].e = n, stk[top].sh = (key_bytes - 1) * 8, ++top;
+	{ /* A pass whose byte is the same in every key of its range moves nothing (every element is "already in its bucket", ksort.h:146) and hands the whole range to the next byte:
+	   * the leading passes over scores (32-bit values in a 64-bit key) or over one strand's anchors are skipped without looking -- the bytes above the highest differing bit */
+		uint64_t d = 0;
+		int64_t i;
+		for (i = 1; i < n; ++i) d |= a[i].key ^ a[0].key;
+		while (stk[0].sh > 0 && (d >> stk[0].sh) == 0) stk[0].sh -= 8;
+	}
 	while (top > 0) {
 		int64_t head[256], tail[256], cnt[256], i, pos;
 		rng_t r = stk[--top];
 		int k;
 		memset(cnt, 0, sizeof cnt);
 		for (i = r.b; i < r.e; ++i) ++cnt[a[i].key >> r.sh & 0xff];
+		if (r.sh > 0 && cnt[a[r.b].key >> r.sh & 0xff] == r.e - r.b) { stk[top].b = r.b, stk[top].e = r.e, stk[top].sh = r.sh > 8 ? r.sh - 8 : 0, ++top; continue; } /* (one bucket: the same, found by counting) */
 		for (k = 0, pos = r.b; k < 256; ++k) head[k] = pos, pos += cnt[k], tail[k] = pos;
 		for (k = 0; k < 256; ++k) { /* displacement cycles, lowest bucket first (ksort.h:141-153) */
 			while (head[k] != tail[k]) {

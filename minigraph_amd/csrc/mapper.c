@@ -287,14 +287,95 @@ static void rq_run_fwd(mga_batch_t *b, int pass2)
 	free(task);
 }
 
+/* The phases as a task graph (round 4).  With barriers between the phases a batch of 8 contigs keeps 8 of 16 threads busy while it sorts and backtracks (one thread per read,
+ * ~1 s per 50 Mbp contig and pass) and every read waits for the slowest: [measured, 10 x 50 Mbp contigs vs a 500 Mbp graph] 65 CPU-s of RMQ chaining in 7.9 s of wall time.
+ * The dependencies are per READ -- sort(i) -> forward runs (i, k) -> backtrack(i) -> forward runs with bw_long (i, k) -> backtrack(i) -- so the threads take tasks from one queue:
+ * finished forward passes hand their read's backtrack to the FRONT of the queue, a read's forward runs are queued as one block behind the others', and read i backtracks while the
+ * forward runs of read i+1 are still being taken.  Same calls on the same data per read: the bytes cannot change.  MGA_RQ_BARRIERS=1: the phases with barriers (A/B). */
+typedef struct {
+	mga_batch_t *b;
+	pthread_mutex_t mtx; pthread_cond_t cv;
+	rq_task_t *lo; int64_t lo_head, lo_tail, lo_cap;  /* forward runs (FIFO) */
+	int32_t *hi; int32_t n_hi;                         /* reads whose sort (>= 0: read, < 0: ~read = backtrack) is due: taken first, last in first out */
+	int32_t *pending;                                  /* forward runs of a read not finished yet */
+	int n_open;                                        /* reads with work left */
+} rq_sched_t;
+
+static void rq_push_fwd(rq_sched_t *S, int read) /* (locked) */
+{
+	const rq_read_t *r = &S->b->rq[read];
+	int k;
+	if (S->lo_tail + r->n_cut > S->lo_cap) { S->lo_cap = (S->lo_tail + r->n_cut) * 2; S->lo = MGA_REALLOC(rq_task_t, S->lo, S->lo_cap); }
+	for (k = 0; k < r->n_cut; ++k) S->lo[S->lo_tail].read = read, S->lo[S->lo_tail++].k = k;
+	S->pending[read] = r->n_cut;
+}
+
+static void rq_sched_worker(void *data, int64_t j_, int tid)
+{
+	rq_sched_t *S = (rq_sched_t*)data;
+	mga_batch_t *b = S->b;
+	(void)j_;
+	pthread_mutex_lock(&S->mtx);
+	for (;;) {
+		while (S->n_hi == 0 && S->lo_head == S->lo_tail && S->n_open > 0) pthread_cond_wait(&S->cv, &S->mtx);
+		if (S->n_hi > 0) {
+			const int32_t h = S->hi[--S->n_hi], read = h >= 0 ? h : ~h;
+			rq_read_t *r = &b->rq[read];
+			pthread_mutex_unlock(&S->mtx);
+			if (h >= 0) rq_prepare_worker(b, read, tid); else rq_finish_worker(b, read, tid);
+			pthread_mutex_lock(&S->mtx);
+			if (r->n > 0 && r->f != 0) rq_push_fwd(S, read); /* sorted and cut, or a second pass with bw_long is due */
+			else --S->n_open;
+			pthread_cond_broadcast(&S->cv);
+		} else if (S->lo_head < S->lo_tail) {
+			const rq_task_t t = S->lo[S->lo_head++];
+			void *arg[2];
+			pthread_mutex_unlock(&S->mtx);
+			arg[0] = b, arg[1] = (void*)&t;
+			rq_fwd_worker(arg, 0, tid);
+			pthread_mutex_lock(&S->mtx);
+			if (--S->pending[t.read] == 0) { S->hi[S->n_hi++] = ~t.read; pthread_cond_broadcast(&S->cv); }
+		} else break; /* n_open == 0 */
+	}
+	pthread_mutex_unlock(&S->mtx);
+}
+
 static void rq_chain_all(mga_batch_t *b)
 {
+	const int prof = getenv("MGA_DEBUG_PIPE") && atoi(getenv("MGA_DEBUG_PIPE")) > 0; /* wall time: where a -x asm job's host time goes (long queries) */
+	const int64_t n_a = b->n > 0 ? b->a_off[b->n] - b->a_off[0] : 0;
+	double t[6];
 	b->rq = MGA_CALLOC(rq_read_t, b->n > 0 ? b->n : 1);
-	mga_parallel_for(b->n_threads, b->n, rq_prepare_worker, b);
-	rq_run_fwd(b, 0);
-	mga_parallel_for(b->n_threads, b->n, rq_finish_worker, b);
-	rq_run_fwd(b, 1);
-	mga_parallel_for(b->n_threads, b->n, rq_finish_worker, b);
+	t[0] = mga_wtime();
+	if (getenv("MGA_RQ_BARRIERS") && atoi(getenv("MGA_RQ_BARRIERS")) > 0) {
+		mga_parallel_for(b->n_threads, b->n, rq_prepare_worker, b);
+		t[1] = mga_wtime();
+		rq_run_fwd(b, 0);
+		t[2] = mga_wtime();
+		mga_parallel_for(b->n_threads, b->n, rq_finish_worker, b);
+		t[3] = mga_wtime();
+		rq_run_fwd(b, 1);
+		t[4] = mga_wtime();
+		mga_parallel_for(b->n_threads, b->n, rq_finish_worker, b);
+		t[5] = mga_wtime();
+		if (prof) fprintf(stderr, "[rq] %d queries, %ld anchors, %d threads: sort %.3f s, forward pass %.3f, backtrack + rescue decision %.3f, forward pass (bw_long) %.3f, backtrack %.3f\n", b->n, (long)n_a,
+						  b->n_threads, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4]);
+		return;
+	}
+	if (b->n > 0) {
+		rq_sched_t S;
+		int i;
+		memset(&S, 0, sizeof S);
+		S.b = b, S.n_open = b->n;
+		pthread_mutex_init(&S.mtx, 0); pthread_cond_init(&S.cv, 0);
+		S.lo_cap = 1024, S.lo = MGA_MALLOC(rq_task_t, S.lo_cap);
+		S.hi = MGA_MALLOC(int32_t, b->n), S.pending = MGA_CALLOC(int32_t, b->n);
+		for (i = b->n - 1; i >= 0; --i) S.hi[S.n_hi++] = i; /* (taken from the top: read 0 first) */
+		mga_parallel_for(b->n_threads, b->n_threads, rq_sched_worker, &S);
+		pthread_mutex_destroy(&S.mtx); pthread_cond_destroy(&S.cv);
+		free(S.lo); free(S.hi); free(S.pending);
+	}
+	if (prof) fprintf(stderr, "[rq] %d queries, %ld anchors, %d threads: sort, forward passes and backtracks of both passes as one task graph: %.3f s\n", b->n, (long)n_a, b->n_threads, mga_wtime() - t[0]);
 }
 
 uint32_t mga_read_hash(const char *qname, int qlen, int seed) /* map-algo.c:362-364 */

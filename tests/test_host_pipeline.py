@@ -51,6 +51,14 @@ def test_asm_preset_host_phases_vs_reference_binary(cigar):
     want, occ, lco = hp.run_reference(graph, reads, cigar=cigar, preset="asm")
     got, _ = hp.map_with_oracle_stages(graph, reads, occ, lco, cigar=cigar, preset="asm")
     assert got == want
+    if not cigar:   # the phases as a task graph over 1 / 3 / 7 threads (a read backtracks while the next one's forward runs are taken) and with barriers between them (MGA_RQ_BARRIERS=1)
+        for nt, barriers in ((1, "0"), (3, "0"), (7, "0"), (5, "1")):
+            os.environ["MGA_RQ_BARRIERS"] = barriers
+            try:
+                got2, _ = hp.map_with_oracle_stages(graph, reads, occ, lco, cigar=False, preset="asm", n_threads=nt)
+            finally:
+                del os.environ["MGA_RQ_BARRIERS"]
+            assert got2 == want, (nt, barriers)
 
 
 def _mutate(rng, s, rate):
