@@ -447,11 +447,13 @@ __device__ void lc_backtrack_compact(const mg128_t *a, int32_t n, int32_t min_sc
 __global__ void __launch_bounds__(64) k_lchain(int n_reads, const mg128_t *__restrict__ a_all, const int64_t *__restrict__ a_off, mga_lchain_par_t P,
 											   lc_rescue_t R, const int64_t *__restrict__ q_off,
 											   uint64_t *__restrict__ u_all, mg128_t *__restrict__ b_all, int32_t *__restrict__ d_nu, int32_t *__restrict__ d_nb,
-											   int32_t *__restrict__ d_flag, int32_t *__restrict__ ws_i32, mg128_t *__restrict__ ws_z, mg128_t *__restrict__ ws_keep)
+											   int32_t *__restrict__ d_flag, int32_t *__restrict__ ws_i32, mg128_t *__restrict__ ws_z, mg128_t *__restrict__ ws_keep,
+											   const int32_t *__restrict__ order)
 {
 	__shared__ klib_lds_t L;
-	const int r = blockIdx.x, lane = threadIdx.x;
-	if (r >= n_reads) return;
+	const int lane = threadIdx.x;
+	if ((int)blockIdx.x >= n_reads) return;
+	const int r = order ? __builtin_amdgcn_readfirstlane(order[blockIdx.x]) : (int)blockIdx.x; // workgroups are dispatched in index order: the reads with the most anchors first (mapper.c)
 	const int64_t off = a_off[r];
 	const int32_t n = (int32_t)(a_off[r + 1] - off);
 	if (lane == 0 && d_flag) d_flag[r] = 0;
@@ -546,7 +548,8 @@ extern "C" int mga_dev_lchain(mga_sctx_t *sc, int n, const mg128_t *d_a, const i
 		}
 	}
 	mga_prof_begin(sc->stream, MGA_K_LCHAIN);
-	hipLaunchKernelGGL(k_lchain, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, R, d_q_off, d_u, d_b, d_nu, d_nb, d_flag, ws_i32, ws_z, ws_keep);
+	hipLaunchKernelGGL(k_lchain, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, R, d_q_off, d_u, d_b, d_nu, d_nb, d_flag, ws_i32, ws_z, ws_keep, sc->lc_order);
+	sc->lc_order = 0;
 	mga_prof_end(sc->stream, MGA_K_LCHAIN);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;

@@ -714,15 +714,16 @@ typedef struct { /* one pipeline context: HIP stream + grow-only device and pinn
 			mga_dbuf_t sk_item, sk_cnt, sk_off, sd_tk, sd_kf, sd_offa, sd_offm, sd_rkey, sd_rmax; /* long-query path (MG_M_RMQ): sketch pieces, per-minimizer scans */
 			mga_dbuf_t hash, gchdr, gcpool, lcpool, apool, gcctl, gcretry; /* graph chaining on the device (k_gchain.hip) */
 			mga_dbuf_t plcnt, ploff, pltot, plsrc, plrev; /* gap list on the device (k_plan.hip) */
+			mga_dbuf_t lcord; /* k_lchain's launch order: reads by anchor count, most first */
 		};
-		mga_dbuf_t dall[55];
+		mga_dbuf_t dall[56];
 	};
 	union {
 		struct { mga_hbuf_t h_b, h_u, h_mini, h_tseq, h_prob, h_pool, h_seq, h_ncig, h_cigoff, h_item, h_chain, h_vert, h_txtres, h_txtpool, h_gchdr, h_gcpool, h_lcpool, h_apool, h_plrev, h_ploff; }; /* pinned staging */
 		mga_hbuf_t hall[20];
 	};
 } pipe_ctx_t;
-_Static_assert(sizeof(((pipe_ctx_t*)0)->dall) == 55 * sizeof(mga_dbuf_t) && sizeof(((pipe_ctx_t*)0)->hall) == 20 * sizeof(mga_hbuf_t), "pipe_ctx_t: buffer lists out of sync");
+_Static_assert(sizeof(((pipe_ctx_t*)0)->dall) == 56 * sizeof(mga_dbuf_t) && sizeof(((pipe_ctx_t*)0)->hall) == 20 * sizeof(mga_hbuf_t), "pipe_ctx_t: buffer lists out of sync");
 
 #define MGA_MAX_PIPE 4
 
@@ -903,6 +904,17 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 		rs.rescue_size = opt->rmq_rescue_size, rs.rescue_ratio = opt->rmq_rescue_ratio;
 		if (opt->max_gap_ref <= 0 && opt->max_frag_len > 0) rs.frag_len = opt->max_frag_len, rs.frag_min_gap = opt->max_gap; /* -F */
 		CK(mga_dbuf_reserve(&P->rflag, (size_t)n * 4 + 4));
+		if (env_int("MGA_LC_ORDER", 1)) { /* the launch lasts as long as its longest read: the reads with the most anchors are launched first (a counting sort of the anchor counts, 16 per bin) */
+			enum { NBIN = 4096 };
+			int32_t *ord = MGA_MALLOC(int32_t, n), *cnt_ = MGA_CALLOC(int32_t, NBIN + 1);
+			for (i = 0; i < n; ++i) { const int64_t na_ = (h_aoff[i + 1] - h_aoff[i]) >> 4; ++cnt_[NBIN - 1 - (na_ < NBIN ? na_ : NBIN - 1) + 1]; }
+			for (i = 0; i < NBIN; ++i) cnt_[i + 1] += cnt_[i];
+			for (i = 0; i < n; ++i) { const int64_t na_ = (h_aoff[i + 1] - h_aoff[i]) >> 4; ord[cnt_[NBIN - 1 - (na_ < NBIN ? na_ : NBIN - 1)]++] = (int32_t)i; }
+			rc = mga_dbuf_reserve(&P->lcord, (size_t)n * 4 + 4) < 0 || mga_h2d_s(sc, P->lcord.p, ord, (size_t)n * 4) < 0 || mga_ssync(sc) < 0 ? -1 : 0;
+			free(ord); free(cnt_);
+			if (rc < 0) goto done;
+			mga_dev_lchain_order(sc, (const int32_t*)P->lcord.p);
+		}
 		CK(mga_dev_lchain(sc, n, (const mg128_t*)P->a.p, (const int64_t*)P->aoff.p, &par, &rs, (const int64_t*)P->qoff.p, (uint64_t*)P->u.p, (mg128_t*)P->b.p,
 						  (int32_t*)P->nu.p, (int32_t*)P->nb.p, (int32_t*)P->rflag.p, P->ws.p, wsb, n_a));
 		h_nu = MGA_MALLOC(int32_t, n); h_nb = MGA_MALLOC(int32_t, n);

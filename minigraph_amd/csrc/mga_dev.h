@@ -52,7 +52,9 @@ typedef struct mga_sctx_s {
 	mga_dbuf_t gc_arena[2];    /* per-wave scratch arenas of k_gchain: 1 MiB x resident waves, and the large tier for the reads that outgrow that */
 	int wfa_uncapped;          /* set while the ladder runs the chained fallback's sub-problems: no 1e8-cell cap, unbounded last tier */
 	mga_dbuf_t fb_prob, fb_res; /* sub-problems of the chained fallback and their results */
+	const int32_t *lc_order;   /* launch order of the NEXT mga_dev_lchain call on this context (device array of n read numbers; consumed by the call) */
 } mga_sctx_t;
+static inline void mga_dev_lchain_order(mga_sctx_t *sc, const int32_t *d_order) { sc->lc_order = d_order; }
 void *mga_wfa_stream(mga_sctx_t *sc, int slot);       /* stream of WFA tier `slot` (the context's own stream unless MGA_WFA_CONCURRENT=1) */
 int mga_wfa_tiers_serial(void);
 int mga_wfa_fork(mga_sctx_t *sc);                     /* tier streams wait for everything queued on sc->stream so far */
