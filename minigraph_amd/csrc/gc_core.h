@@ -589,7 +589,10 @@ GC_HD int gc_index_anchors(mg128_t *a, int32_t n_a, const int32_t *mini_pos, int
 		const int32_t x0 = GC_AY(a[0]);
 		while (lo <= hi) { const int32_t mid = (int32_t)(((uint32_t)lo + (uint32_t)hi) >> 1), y = mini_pos[mid]; if (y < x0) lo = mid + 1; else if (y > x0) hi = mid - 1; else { st = mid; break; } }
 		if (st >= 0) {
-			int32_t k = 0, j = st; /* (ranks are written as the walk goes: the searches below only read y, and overwrite x for every anchor if the walk does not get through) */
+			/* Ranks are written as the walk goes.  When the walk does not get through, the state the searches below leave is the one they would have left alone: the walk
+			 * writes a[k].x only where y == mini_pos[j], mini_pos ascends strictly, so the search of that anchor finds the same j and writes the same value again; an anchor the
+			 * searches do not find (the GC_E_BUG case) was never written by the walk either. */
+			int32_t k = 0, j = st;
 			while (k < n_a && j < n_mini) {
 				const int32_t y = GC_AY(a[k]), m = mini_pos[j];
 				if (y == m) a[k].x = (uint64_t)j << 32 | (a[k].x & 0xffffffffU), ++k, ++j;
