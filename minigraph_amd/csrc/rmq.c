@@ -296,11 +296,17 @@ static inline int32_t score_simple(const mg128_t *ai, const mg128_t *aj, float p
 void mga_lchain_rmq_fwd(int max_dist, int max_dist_inner, int bw, int max_chn_skip, int cap_rmq_size, float pen_gap, float pen_skip,
 						int64_t beg, int64_t end, const mg128_t *a, int32_t *f, int64_t *p, int32_t *v, int32_t *t)
 {
-	int32_t root = -1, root_inner = -1;
+	int32_t root = -1;
 	int64_t i, i0, st = beg, st_inner = beg;
 	rq_pool_t T = {0, 0, 0, -1};
 	if (max_dist < bw) max_dist = bw;
 	if (max_dist_inner <= 0 || max_dist_inner >= max_dist) max_dist_inner = 0;
+	/* ONE tree (round 4).  The reference keeps a second tree for the inner window (lchain.c:286-291,303-312) and only ever asks it ORDER questions -- the largest key below
+	 * (y - 1, n), then its predecessors (lchain.c:326-345) -- whose answers do not depend on a tree's shape.  Its key set is { j : st_inner <= j < i0 } (anchors are inserted
+	 * and erased in index order, and st_inner never passes i0: an anchor of [i0, i) has a[i]'s own x, and at st_inner == i0 the set is empty, so neither the distance nor
+	 * the size clause holds there), a subset of the outer tree's { j : st <= j < i0 } (st <= st_inner: whatever moves st -- distance beyond max_dist, or more than
+	 * cap_rmq_size keys -- moves st_inner too, the inner distance being the smaller one and the two sets being equal when st == st_inner).  So the inner walk runs over the
+	 * OUTER tree and passes over the keys with j < st_inner: the same anchors in the same order, with half the insertions and erasures. */
 	for (i = i0 = beg; i < end; ++i) {
 		int64_t max_j = -1;
 		int32_t q_span = (int32_t)(a[i].y >> 32 & 0xff), max_f = q_span, q;
@@ -311,11 +317,6 @@ void mga_lchain_rmq_fwd(int max_dist, int max_dist_inner, int bw, int max_chn_sk
 				ND(&T, x).y = (int32_t)a[j].y, ND(&T, x).i = j;
 				ND(&T, x).pri = -(f[j] + 0.5 * pen_gap * ((int32_t)a[j].x + (int32_t)a[j].y));
 				rq_insert(&T, &root, x);
-				if (max_dist_inner > 0) {
-					int32_t r = rq_alloc(&T);
-					ND(&T, r).y = ND(&T, x).y, ND(&T, r).i = j, ND(&T, r).pri = ND(&T, x).pri;
-					rq_insert(&T, &root_inner, r);
-				}
 			}
 			i0 = i;
 		}
@@ -327,15 +328,8 @@ void mga_lchain_rmq_fwd(int max_dist, int max_dist_inner, int bw, int max_chn_sk
 			}
 			++st;
 		}
-		if (max_dist_inner > 0) { /* lchain.c:303-312 */
-			while (st_inner < i && (a[i].x >> 32 != a[st_inner].x >> 32 || a[i].x > a[st_inner].x + max_dist_inner || (root_inner >= 0 ? ND(&T, root_inner).size : 0) > cap_rmq_size)) {
-				if (root_inner >= 0) {
-					q = rq_erase(&T, &root_inner, (int32_t)a[st_inner].y, st_inner);
-					if (q >= 0) rq_release(&T, q);
-				}
-				++st_inner;
-			}
-		}
+		if (max_dist_inner > 0) /* lchain.c:303-312: the inner window's set is [st_inner, i0), its size i0 - st_inner */
+			while (st_inner < i && (a[i].x >> 32 != a[st_inner].x >> 32 || a[i].x > a[st_inner].x + max_dist_inner || (st_inner < i0 ? i0 - st_inner : 0) > cap_rmq_size)) ++st_inner;
 		/* RMQ (lchain.c:313-352) */
 		q = rq_rmq(&T, root, (int32_t)a[i].y - max_dist, INT32_MAX, (int32_t)a[i].y - 1, 0);
 		if (q >= 0) {
@@ -343,24 +337,26 @@ void mga_lchain_rmq_fwd(int max_dist, int max_dist_inner, int bw, int max_chn_sk
 			int64_t j = ND(&T, q).i;
 			sc = f[j] + score_simple(&a[i], &a[j], pen_gap, pen_skip, &exact, &width);
 			if (width <= bw && sc > max_f) max_f = sc, max_j = j;
-			if (!exact && root_inner >= 0 && (int32_t)a[i].y > 0) {
-				int32_t lo = rq_lower(&T, root_inner, (int32_t)a[i].y - 1, end); /* (the reference's key index n: above every index in the tree) */
+			if (!exact && max_dist_inner > 0 && st_inner < i0 && (int32_t)a[i].y > 0) {
+				int32_t lo = rq_lower(&T, root, (int32_t)a[i].y - 1, end); /* (the reference's key index n: above every index in the tree) */
 				if (lo >= 0) {
 					rq_itr_t itr;
-					rq_itr_seek(&T, root_inner, lo, &itr);
+					rq_itr_seek(&T, root, lo, &itr);
 					while (itr.top >= 0) {
 						int32_t qq = itr.stack[itr.top];
 						if (ND(&T, qq).y < (int32_t)a[i].y - max_dist_inner) break;
 						j = ND(&T, qq).i;
-						sc = f[j] + score_simple(&a[i], &a[j], pen_gap, pen_skip, 0, &width);
-						if (width <= bw) {
-							if (sc > max_f) {
-								max_f = sc, max_j = j;
-								if (n_skip > 0) --n_skip;
-							} else if (t[j] == (int32_t)i) {
-								if (++n_skip > max_chn_skip) break;
+						if (j >= st_inner) { /* a key of the inner window */
+							sc = f[j] + score_simple(&a[i], &a[j], pen_gap, pen_skip, 0, &width);
+							if (width <= bw) {
+								if (sc > max_f) {
+									max_f = sc, max_j = j;
+									if (n_skip > 0) --n_skip;
+								} else if (t[j] == (int32_t)i) {
+									if (++n_skip > max_chn_skip) break;
+								}
+								if (p[j] >= 0) t[p[j]] = (int32_t)i;
 							}
-							if (p[j] >= 0) t[p[j]] = (int32_t)i;
 						}
 						if (!rq_itr_prev(&T, &itr)) break;
 					}

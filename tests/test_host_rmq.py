@@ -24,6 +24,9 @@ def anchors(rng, n, kind):
         x = np.where(dup, np.roll(x, 1), x)
         x[0] = 17
         x = np.sort(x)
+    elif kind == "dense":        # anchors every few bases, half of them off the diagonal by up to 400: every inner walk visits dozens of keys, many of the outer window only
+        x = np.sort(rng.integers(17, 4 * n, n))
+        y = x + 100 + np.where(rng.random(n) < 0.5, rng.integers(-400, 400, n), 0)
     else:                        # "jumps": long gaps on either axis, several target segments
         y = x + 100 + np.cumsum((rng.random(n) < 0.003) * rng.integers(-8000, 8000, n))
         x = x + np.cumsum((rng.random(n) < 0.002) * rng.integers(0, 30000, n))
@@ -68,10 +71,13 @@ def run_ref(R, a, par):
     return take(r, u, nu.value)
 
 
-@pytest.mark.parametrize("kind", ["colinear", "noisy", "jumps"])
+@pytest.mark.parametrize("kind", ["colinear", "noisy", "jumps", "dense"])
 @pytest.mark.parametrize("par", [(10000, 1000, 2000, 25, 100000, 5, 40),   # -x asm shape
                                  (5000, 1000, 20000, 25, 100000, 5, 40),   # the -x lr rescue (bw_long)
-                                 (3000, 0, 500, 5, 300, 3, 20)])           # no inner tree, a tree cap that bites, few skips
+                                 (3000, 0, 500, 5, 300, 3, 20),            # no inner tree, a tree cap that bites, few skips
+                                 (10000, 1000, 2000, 25, 60, 5, 40),       # a cap that bites BOTH windows (the inner window's size clause, lchain.c:304)
+                                 (4000, 3000, 2000, 3, 200, 5, 40),        # inner window nearly the outer one, cap between them, few skips
+                                 (10000, 150, 2000, 25, 100000, 5, 40)])   # a narrow inner window: its walk passes over many keys of the outer window only (one tree, rmq.c)
 def test_rmq_chainer_matches_reference(kind, par):
     L, R = mga.load(), rb.Ref().lib
     for seed in range(3):
