@@ -59,6 +59,40 @@ __global__ void __launch_bounds__(64) k_text_count(int n_chain, const mga_txt_ch
 	}
 }
 
+// the same for chromosome-scale chains (-x asm: a handful per launch, 10^6 plan items and 10^5 walk vertices each -- [measured, round 4] a lane walked them alone for 1.1 + 1.95 s of a
+// 6.6 s job): a workgroup per chain, items summed by 256 threads, the walk offsets as an exclusive running sum a tile of 256 vertices at a time
+__global__ void __launch_bounds__(256) k_text_count_wg(int n_chain, const mga_txt_chain_t *__restrict__ chain, const mga_cigitem_t *__restrict__ item, const uint32_t *__restrict__ vert,
+													  const int32_t *__restrict__ seg_len, const int32_t *__restrict__ ncig, int32_t *__restrict__ n_el, int32_t *__restrict__ vwb)
+{
+	__shared__ int32_t red[256];
+	const int c = blockIdx.x, tid = threadIdx.x;
+	if (c >= n_chain) return; // (uniform over the workgroup)
+	const mga_txt_chain_t C = chain[c];
+	int32_t n = 0;
+	for (int64_t t = C.item_beg + tid; t < C.item_end; t += 256) { const mga_cigitem_t it = item[t]; n += it.op >= 0 ? 1 : ncig[C.prob_base + it.val]; }
+	red[tid] = n;
+	__syncthreads();
+	for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+	if (tid == 0) n_el[c] = red[0];
+	int32_t carry = 0;
+	for (int32_t k0 = 0; k0 < C.vert_cnt; k0 += 256) {
+		const int32_t k = k0 + tid;
+		int32_t len = 0;
+		if (k < C.vert_cnt) len = (k < C.vert_cnt - 1 ? seg_len[vert[C.vert_beg + k] >> 1] : C.ee) - (k > 0 ? 0 : C.ss);
+		__syncthreads(); // red[] of the previous tile (or of the sum above) has been read by everyone
+		red[tid] = len;
+		__syncthreads();
+		for (int s = 1; s < 256; s <<= 1) { // inclusive scan
+			const int32_t v = tid >= s ? red[tid - s] : 0;
+			__syncthreads();
+			red[tid] += v;
+			__syncthreads();
+		}
+		if (k < C.vert_cnt) vwb[C.vert_beg + k] = carry + red[tid] - len;
+		carry += red[255];
+	}
+}
+
 // ds:Z entries of one run: returns their total length; WRITE: stores them at w (REV: from w + n backwards, each entry transformed)
 template<bool WRITE, bool REV> __device__ int32_t txt_ds_run(const txt_walk_t &W, const char *q, int32_t op, int32_t len, int32_t x, int32_t y, int32_t qs, int32_t qe, int32_t apl,
 															char *w, int32_t n_total)
@@ -311,15 +345,17 @@ extern "C" int mga_dev_text(mga_sctx_t *sc, int n_chain, const mga_txt_chain_t *
 		mga_dbuf_reserve(&sc->txt_vwb, (size_t)(n_vert + 1) * 4) < 0 || mga_dbuf_reserve(&sc->txt_el, (size_t)(n_el_max + 64) * 16) < 0) return -1;
 	uint32_t *el = (uint32_t*)sc->txt_el.p, *run = el + (n_el_max + 64);
 	int32_t *run_txt = (int32_t*)(run + (n_el_max + 64));
+	// chromosome-scale chains (a handful per launch, 10^5+ operators each) get a workgroup each in both passes -- sixteen wavefronts in the writing pass --, ordinary reads' chains a
+	// lane in the counting pass and one wavefront in the writing pass
+	const bool wide = n_el_max / n_chain >= 32768;
 	mga_prof_begin(sc->stream, MGA_K_TEXT);
-	hipLaunchKernelGGL(k_text_count, dim3((n_chain + 63) / 64), dim3(64), 0, st, n_chain, d_chain, d_item, d_vert, (const int32_t*)ix->d_seg_len, d_ncig,
+	if (wide) hipLaunchKernelGGL(k_text_count_wg, dim3(n_chain), dim3(256), 0, st, n_chain, d_chain, d_item, d_vert, (const int32_t*)ix->d_seg_len, d_ncig, (int32_t*)sc->txt_cnt.p, (int32_t*)sc->txt_vwb.p);
+	else hipLaunchKernelGGL(k_text_count, dim3((n_chain + 63) / 64), dim3(64), 0, st, n_chain, d_chain, d_item, d_vert, (const int32_t*)ix->d_seg_len, d_ncig,
 					   (int32_t*)sc->txt_cnt.p, (int32_t*)sc->txt_vwb.p);
 	mga_prof_end(sc->stream, MGA_K_TEXT);
 	MGA_HIP_CHECK(hipGetLastError());
 	if (mga_dev_scan_i32_to_i64(sc, (const int32_t*)sc->txt_cnt.p, n_chain, (int64_t*)sc->txt_off.p) < 0) return -1;
 	mga_prof_begin(sc->stream, MGA_K_TEXT);
-	// chromosome-scale chains (a handful per launch, 10^5+ operators each) get a workgroup of sixteen wavefronts each, ordinary reads' chains one wavefront
-	const bool wide = n_el_max / n_chain >= 32768;
 #define TXT_LAUNCH(NT_) hipLaunchKernelGGL((k_text<NT_>), dim3(n_chain), dim3(NT_), 0, st, n_chain, d_chain, d_item, d_vert, (const int32_t*)sc->txt_vwb.p, (const char*)ix->d_gseq, \
 					   (const int64_t*)ix->d_gseq_off, (const int32_t*)ix->d_seg_len, d_reads, d_ncig, d_cigoff, d_ord, (const int64_t*)sc->txt_off.p, \
 					   el, run, run_txt, d_res, d_pool, (long long)pool_cap, d_pool_used)
