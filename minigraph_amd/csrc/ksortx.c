@@ -80,19 +80,11 @@ void mga_ksort_perm(int64_t n, const uint64_t *key, int key_bytes, int64_t *perm
 	free(a);
 }
 
-void mga_ksort_128x(int64_t n, mg128_t *a)
+void mga_ksort_128x(int64_t n, mg128_t *a) /* radix_sort_128x (ksort.h via map-algo.c:12): in place, the key is x, y travels with it -- the record the sort above moves IS an mg128_t */
 {
-	int64_t i;
-	kx_t *p;
-	mg128_t *b;
+	_Static_assert(sizeof(kx_t) == sizeof(mg128_t), "kx_t / mg128_t");
 	if (n <= 1) return;
-	p = MGA_MALLOC(kx_t, n);
-	b = MGA_MALLOC(mg128_t, n);
-	for (i = 0; i < n; ++i) p[i].key = a[i].x, p[i].src = i;
-	kx_sort(p, n, 8);
-	for (i = 0; i < n; ++i) b[i] = a[p[i].src];
-	memcpy(a, b, (size_t)n * sizeof(mg128_t));
-	free(p); free(b);
+	kx_sort((kx_t*)a, n, 8);
 }
 
 static int cmp_u64(const void *a, const void *b)
