@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--resident-steps", type=int, default=2)
     ap.add_argument("--threads", type=int, default=0, help="host threads per rank (0: min(64, usable cores / ranks))")
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--workdir", default=None, help="keep the synthetic workload (graph, reads, graph image) in this directory and reuse it when it is already there (sweeps of several bench runs in one session)")
     ap.add_argument("--no-asm", action="store_true", help="N=1: skip the `asm` block (BASELINE configs[4] shape: -cx asm, 10 x 50 Mbp contigs vs a 500 Mbp graph, file -> file next to the reference)")
     ap.add_argument("--asm-genome", type=int, default=500000000)
     ap.add_argument("--no-rank-share", action="store_true", help="N=1: skip the `rank_share` block (device placement with the process pinned to 1/8 of the usable cores)")
@@ -193,12 +194,23 @@ def main():
     threads = args.threads or max(2, min(64, quota // world))  # [measured] more threads than usable cores only adds contention + CFS throttling
 
     # ---- synthetic workload (untimed): ONE graph + ONE read file for the whole job, written by rank 0 ----
+    wl_tag = "G%d_c%d_H%d_n%d" % (args.genome, args.chr, args.hap, args.reads * world)
+    reuse_wl = False
     if rank == 0:
-        d = tempfile.mkdtemp(prefix="mga_bench_")
+        if args.workdir:
+            d = os.path.join(os.path.abspath(args.workdir), wl_tag)
+            os.makedirs(d, exist_ok=True)
+            reuse_wl = os.path.exists(os.path.join(d, "w.done"))
+        else:
+            d = tempfile.mkdtemp(prefix="mga_bench_")
         t0 = time.time()
-        p = subprocess.run([mga.MGSIM, "-p", os.path.join(d, "w"), "-G", str(args.genome), "-c", str(args.chr), "-H", str(args.hap),
-                            "-n", str(args.reads * world), "-s", "11"], stderr=subprocess.PIPE, check=True)
-        m = re.search(r"graph=(\d+) bp", p.stderr.decode())
+        if reuse_wl:
+            err_txt = open(os.path.join(d, "w.done")).read()
+        else:
+            p = subprocess.run([mga.MGSIM, "-p", os.path.join(d, "w"), "-G", str(args.genome), "-c", str(args.chr), "-H", str(args.hap),
+                                "-n", str(args.reads * world), "-s", "11"], stderr=subprocess.PIPE, check=True)
+            err_txt = p.stderr.decode()
+        m = re.search(r"graph=(\d+) bp", err_txt)
         graph_bp = int(m.group(1)) if m else int(args.genome * (1 + 0.071 * (args.hap - 1)))
         try:
             os.remove(os.path.join(d, "w.lin.fa"))
@@ -217,7 +229,7 @@ def main():
     # and lets its GPU rebuild the minimizer table (`index_s`: what a run on an existing image pays -- SURVEY 8 f4, csrc/image.c)
     img_path = pre + ".mgi"
     t_build = t_save = 0.0
-    if rank == 0:
+    if rank == 0 and not (reuse_wl and os.path.exists(img_path)):
         t0 = time.time()
         G0 = mga.Graph(graph_path, preset="lr", cigar=True, n_threads=threads)
         t_build = time.time() - t0
@@ -225,6 +237,9 @@ def main():
         G0.save_image(img_path)
         t_save = time.time() - t0
         G0.close()
+        if args.workdir:
+            with open(os.path.join(d, "w.done"), "w") as fo:
+                fo.write(err_txt)
     if dist is not None:
         dist.barrier()
     t0 = time.time()
@@ -569,7 +584,7 @@ def main():
     G.close()
     if dist is not None:
         dist.barrier()
-    if rank == 0 and not args.keep:
+    if rank == 0 and not args.keep and not args.workdir:
         shutil.rmtree(d, ignore_errors=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -94,7 +94,8 @@ mg_gchains_t **mga_gchains_unpack(const void *buf, int64_t bytes, int *n_out)
 	if (hdr == 0 || hdr[0] != GCP_MAGIC || hdr[1] > 0x7fffffffULL) { mga_set_error("mga_gchains_unpack: not a packed chain buffer"); return 0; }
 	n = (int64_t)hdr[1];
 	if ((uint64_t)n > c.n / sizeof(gcp_read_t)) { mga_set_error("mga_gchains_unpack: truncated buffer"); return 0; }
-	gcs = MGA_CALLOC(mg_gchains_t*, n > 0 ? n : 1);
+	gcs = (mg_gchains_t**)calloc(n > 0 ? (size_t)n : 1, sizeof(mg_gchains_t*));
+	if (gcs == 0) { mga_set_error("mga_gchains_unpack: out of memory"); return 0; }
 	for (i = 0; i < n; ++i) {
 		const gcp_read_t *r = (const gcp_read_t*)gcp_get(&c, sizeof *r);
 		const mg_gchain_t *g;
@@ -107,26 +108,37 @@ mg_gchains_t **mga_gchains_unpack(const void *buf, int64_t bytes, int *n_out)
 		lc = gcp_get(&c, (size_t)r->n_lc * sizeof(mg_llchain_t));
 		a = gcp_get(&c, (size_t)r->n_a * sizeof(mg128_t));
 		if (g == 0 || lc == 0 || a == 0) goto bad;
+		/* the consumers (mg_call_asm, the GAF writer) index lc[] through gc[].off/cnt and a[] through lc[].off/cnt, so a peer buffer is only accepted when
+		 * every one of those ranges lies inside its array; an object without chains owns no arrays (gchain1.c:460) and therefore may not claim any records */
+		if (r->n_gc == 0 && (r->n_lc != 0 || r->n_a != 0)) goto bad;
+		for (k = 0; k < r->n_gc; ++k) if (g[k].off < 0 || g[k].cnt < 0 || (int64_t)g[k].off + g[k].cnt > r->n_lc || g[k].n_anchor < 0) goto bad;
+		for (k = 0; k < r->n_lc; ++k) { const mg_llchain_t *l = (const mg_llchain_t*)lc + k; if (l->off < 0 || l->cnt < 0 || (int64_t)l->off + l->cnt > r->n_a) goto bad; }
 		gs = gcs[i] = MGA_CALLOC(mg_gchains_t, 1);
-		gs->n_gc = r->n_gc, gs->n_lc = r->n_lc, gs->n_a = r->n_a, gs->rep_len = r->rep_len;
+		if (gs == 0) goto oom;
+		gs->rep_len = r->rep_len;
 		if (r->n_gc == 0) continue; /* gchain1.c:460: a valid object without chains owns no arrays */
 		gs->gc = (mg_gchain_t*)gcp_dup(g, (size_t)r->n_gc * sizeof(mg_gchain_t));
+		if (gs->gc == 0) goto oom;
+		gs->n_gc = r->n_gc;
+		for (k = 0; k < r->n_gc; ++k) gs->gc[k].p = 0, gs->gc[k].ds.off = 0, gs->gc[k].ds.ds = 0; /* (sizes so far: owned pointers from here on; mg_gchain_free walks gc[0 .. n_gc)) */
 		gs->lc = (mg_llchain_t*)gcp_dup(lc, (size_t)r->n_lc * sizeof(mg_llchain_t));
 		gs->a = (mg128_t*)gcp_dup(a, (size_t)r->n_a * sizeof(mg128_t));
-		for (k = 0; k < r->n_gc; ++k) gs->gc[k].p = 0, gs->gc[k].ds.off = 0, gs->gc[k].ds.ds = 0; /* (sizes so far: owned pointers from here on) */
+		if (gs->lc == 0 || gs->a == 0) goto oom;
+		gs->n_lc = r->n_lc, gs->n_a = r->n_a;
 		for (k = 0; k < r->n_gc; ++k) {
 			const size_t pb = (size_t)(uintptr_t)g[k].p, ob = (size_t)(uintptr_t)g[k].ds.off, db = (size_t)(uintptr_t)g[k].ds.ds;
 			if (pb) {
 				const mg_cigar_t *p = (const mg_cigar_t*)gcp_get(&c, pb);
 				if (p == 0 || pb < sizeof(mg_cigar_t) || p->n_cigar < 0 || pb != sizeof(mg_cigar_t) + (size_t)p->n_cigar * 8) goto bad;
-				gs->gc[k].p = (mg_cigar_t*)gcp_dup(p, pb);
+				if ((gs->gc[k].p = (mg_cigar_t*)gcp_dup(p, pb)) == 0) goto oom;
 			}
 			if (db) {
 				const void *off = gcp_get(&c, ob), *ds = gcp_get(&c, db);
-				if (off == 0 || ds == 0 || ob != (size_t)g[k].ds.n_off * 4 || db != (size_t)g[k].ds.len + 1) goto bad;
+				if (off == 0 || ds == 0 || g[k].ds.n_off < 0 || g[k].ds.len < 0 || ob != (size_t)g[k].ds.n_off * 4 || db != (size_t)g[k].ds.len + 1) goto bad;
 				gs->gc[k].ds.off = (int32_t*)gcp_dup(off, ob);
 				gs->gc[k].ds.ds = (char*)gcp_dup(ds, db);
-			}
+				if (gs->gc[k].ds.off == 0 || gs->gc[k].ds.ds == 0) goto oom;
+			} else if (ob) goto bad;
 		}
 	}
 	*n_out = (int)n;
@@ -135,5 +147,10 @@ bad:
 	for (i = 0; i < n; ++i) mg_gchain_free(gcs[i]);
 	free(gcs);
 	mga_set_error("mga_gchains_unpack: truncated or corrupt buffer");
+	return 0;
+oom:
+	for (i = 0; i < n; ++i) mg_gchain_free(gcs[i]);
+	free(gcs);
+	mga_set_error("mga_gchains_unpack: out of memory");
 	return 0;
 }

@@ -523,6 +523,8 @@ extern "C" size_t mga_dev_lchain_ws_bytes(int64_t total_anchors) { return (size_
 extern "C" int mga_dev_lchain(mga_sctx_t *sc, int n, const mg128_t *d_a, const int64_t *d_a_off, const mga_lchain_par_t *par, const mga_rescue_par_t *resc,
 							  const int64_t *d_q_off, uint64_t *d_u, mg128_t *d_b, int32_t *d_nu, int32_t *d_nb, int32_t *d_flag, void *d_ws, size_t ws_bytes, int64_t total_anchors)
 {
+	const int32_t *d_order = sc->lc_order; // the launch order is consumed by THIS call whatever its outcome (an early return used to leave it for the next call on the context)
+	sc->lc_order = 0;
 	if (n <= 0) return 0;
 	if (par->min_cnt < 2) { mga_set_error("lchain: min_cnt >= 2 required by the workspace layout (got %d)", par->min_cnt); return -1; }
 	if (ws_bytes < mga_dev_lchain_ws_bytes(total_anchors)) { mga_set_error("lchain: workspace too small"); return -1; }
@@ -548,8 +550,7 @@ extern "C" int mga_dev_lchain(mga_sctx_t *sc, int n, const mg128_t *d_a, const i
 		}
 	}
 	mga_prof_begin(sc->stream, MGA_K_LCHAIN);
-	hipLaunchKernelGGL(k_lchain, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, R, d_q_off, d_u, d_b, d_nu, d_nb, d_flag, ws_i32, ws_z, ws_keep, sc->lc_order);
-	sc->lc_order = 0;
+	hipLaunchKernelGGL(k_lchain, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, R, d_q_off, d_u, d_b, d_nu, d_nb, d_flag, ws_i32, ws_z, ws_keep, d_order);
 	mga_prof_end(sc->stream, MGA_K_LCHAIN);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;

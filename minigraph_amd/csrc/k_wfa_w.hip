@@ -31,6 +31,7 @@
 // from the end of a slot of the CIGAR pool sized by the score (one reservation per wavefront), and leaves the same mga_wfa_res_t the
 // register tiers of k_wfa_r.hip leave.
 #include <type_traits>
+#include <stdlib.h>
 #include "mga_dev.h"
 #include "dev_common.h"
 #include "wfa_window.h"
@@ -460,7 +461,12 @@ extern "C" int mga_dev_wfa_win(mga_sctx_t *sc, const int *d_n, int n, const int3
 	const wfw_tier_t &T = g_wtier[wt];
 	const int per = 64 / (T.W < 64 ? T.W : 64);
 	int wgs = (n + per * 4 - 1) / (per * 4);
-	if (wgs > T.n_wg) wgs = T.n_wg;
+	// MGA_WFA_GRID_PCT=<p>: persistent grids of p % of the table's size -- the rest of the wave slots stay free for the kernels of the OTHER chunks in the pipeline
+	// (their launches otherwise only get the chip in this one's tail); a tuning knob, the result does not depend on the grid
+	const char *e_pct = getenv("MGA_WFA_GRID_PCT"); // (read per launch: six launches per chunk)
+	const int grid_pct = e_pct && atoi(e_pct) > 0 ? atoi(e_pct) : 100;
+	const int cap_wg = (int)((long long)T.n_wg * grid_pct / 100) > 64 ? (int)((long long)T.n_wg * grid_pct / 100) : 64;
+	if (wgs > cap_wg) wgs = cap_wg;
 	if (wgs < 1) wgs = 1;
 	hipStream_t st = (hipStream_t)mga_wfa_stream(sc, slot);
 	int *d_counter = (int*)((char*)sc->wfa_cnt.p + 64 * slot);

@@ -719,11 +719,11 @@ typedef struct { /* one pipeline context: HIP stream + grow-only device and pinn
 		mga_dbuf_t dall[56];
 	};
 	union {
-		struct { mga_hbuf_t h_b, h_u, h_mini, h_tseq, h_prob, h_pool, h_seq, h_ncig, h_cigoff, h_item, h_chain, h_vert, h_txtres, h_txtpool, h_gchdr, h_gcpool, h_lcpool, h_apool, h_plrev, h_ploff; }; /* pinned staging */
-		mga_hbuf_t hall[20];
+		struct { mga_hbuf_t h_b, h_u, h_mini, h_tseq, h_prob, h_pool, h_seq, h_ncig, h_cigoff, h_item, h_chain, h_vert, h_txtres, h_txtpool, h_gchdr, h_gcpool, h_lcpool, h_apool, h_plrev, h_ploff, h_lcord; }; /* pinned staging */
+		mga_hbuf_t hall[21];
 	};
 } pipe_ctx_t;
-_Static_assert(sizeof(((pipe_ctx_t*)0)->dall) == 56 * sizeof(mga_dbuf_t) && sizeof(((pipe_ctx_t*)0)->hall) == 20 * sizeof(mga_hbuf_t), "pipe_ctx_t: buffer lists out of sync");
+_Static_assert(sizeof(((pipe_ctx_t*)0)->dall) == 56 * sizeof(mga_dbuf_t) && sizeof(((pipe_ctx_t*)0)->hall) == 21 * sizeof(mga_hbuf_t), "pipe_ctx_t: buffer lists out of sync");
 
 #define MGA_MAX_PIPE 4
 
@@ -740,13 +740,16 @@ static void token_acquire(gpu_token_t *t) { pthread_mutex_lock(&t->m); while (t-
 static void token_release(gpu_token_t *t) { pthread_mutex_lock(&t->m); ++t->avail; pthread_cond_signal(&t->c); pthread_mutex_unlock(&t->m); }
 
 static int env_int(const char *name, int dflt) { const char *s = getenv(name); return s && *s ? atoi(s) : dflt; }
+/* reads of at least this many bases are "ultra-long" -x lr reads (chunks of their own, first chaining pass on host threads): read ONCE per process (the cut and
+ * the chunk's placement must agree, whatever happens to the environment in between) */
+static int lr_long_bases(void) { static int v = -1; if (v < 0) v = env_int("MGA_LONG_READ", 262144); return v; }
 
 #define CK(x) do { if ((x) < 0) { rc = -1; goto done; } } while (0)
 
 static void release_token_cb(void *a) { gpu_token_t **held = (gpu_token_t**)a; if (*held) { token_release(*held); *held = 0; } }
 
 static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs_out,
-					 const mg_mapopt_t *opt, int n_threads, const char *d_seq_res, const int64_t *q_off_res, int seqs_pinned, mga_stats_t *st, kstring_t *gaf_part)
+					 const mg_mapopt_t *opt, int n_threads, const char *d_seq_res, const int64_t *q_off_res, int seqs_pinned, mga_stats_t *st, kstring_t *gaf_part, int lr_long)
 {
 	struct mg_idx_bucket_s *B = gi->B;
 	mga_sctx_t *sc = P->sc;
@@ -764,7 +767,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	mga_lchain_par_t par;
 	const int is_rmq = !!(opt->flag & MG_M_RMQ);
 	int chunk_long = 0; /* -x lr, a chunk of ultra-long reads (batch_cut): the long-query path as well, first chaining pass on host threads (hchain.c: mga_lchain_dp_fwd) */
-	if (!is_rmq && n > 0 && (gi->k & 1) && !env_int("MGA_NO_LONGQ", 0)) { const int lr_long = env_int("MGA_LONG_READ", 262144); chunk_long = lr_long > 0; for (i = 0; i < n && chunk_long; ++i) if (qlens[i] < lr_long) chunk_long = 0; }
+	if (!is_rmq && n > 0 && (gi->k & 1) && !env_int("MGA_NO_LONGQ", 0)) { chunk_long = lr_long > 0; for (i = 0; i < n && chunk_long; ++i) if (qlens[i] < lr_long) chunk_long = 0; }
 	const int long_q = (is_rmq || chunk_long) && (gi->k & 1) && !env_int("MGA_NO_LONGQ", 0); /* few, very long queries -- intra-query parallel sketch and seed expansion, anchors sorted by the host chainer */
 	const char *d_seq;
 	double t0, t1;
@@ -906,13 +909,16 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 		CK(mga_dbuf_reserve(&P->rflag, (size_t)n * 4 + 4));
 		if (env_int("MGA_LC_ORDER", 1)) { /* the launch lasts as long as its longest read: the reads with the most anchors are launched first (a counting sort of the anchor counts, 16 per bin) */
 			enum { NBIN = 4096 };
-			int32_t *ord = MGA_MALLOC(int32_t, n), *cnt_ = MGA_CALLOC(int32_t, NBIN + 1);
+			/* (the order is built in the context's pinned staging and the copy is only ENQUEUED -- the stream puts it before k_lchain; two mallocs, a pageable
+			 * copy and a full synchronisation per chunk stood here while the chunk held the front-phase token.  The buffer is next written by this context's next chunk.) */
+			int32_t *ord, cnt_[NBIN + 1];
+			CK(mga_hbuf_reserve(&P->h_lcord, (size_t)n * 4 + 16)); CK(mga_dbuf_reserve(&P->lcord, (size_t)n * 4 + 4));
+			ord = (int32_t*)P->h_lcord.p;
+			memset(cnt_, 0, sizeof cnt_);
 			for (i = 0; i < n; ++i) { const int64_t na_ = (h_aoff[i + 1] - h_aoff[i]) >> 4; ++cnt_[NBIN - 1 - (na_ < NBIN ? na_ : NBIN - 1) + 1]; }
 			for (i = 0; i < NBIN; ++i) cnt_[i + 1] += cnt_[i];
 			for (i = 0; i < n; ++i) { const int64_t na_ = (h_aoff[i + 1] - h_aoff[i]) >> 4; ord[cnt_[NBIN - 1 - (na_ < NBIN ? na_ : NBIN - 1)]++] = (int32_t)i; }
-			rc = mga_dbuf_reserve(&P->lcord, (size_t)n * 4 + 4) < 0 || mga_h2d_s(sc, P->lcord.p, ord, (size_t)n * 4) < 0 || mga_ssync(sc) < 0 ? -1 : 0;
-			free(ord); free(cnt_);
-			if (rc < 0) goto done;
+			CK(mga_h2d_s(sc, P->lcord.p, ord, (size_t)n * 4));
 			mga_dev_lchain_order(sc, (const int32_t*)P->lcord.p);
 		}
 		CK(mga_dev_lchain(sc, n, (const mg128_t*)P->a.p, (const int64_t*)P->aoff.p, &par, &rs, (const int64_t*)P->qoff.p, (uint64_t*)P->u.p, (mg128_t*)P->b.p,
@@ -1032,7 +1038,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	GPU_RELEASE();
 	if (g_dbg_pipe > 1) PIPE_LOG(" lchain", n, t0);
 	t1 = mga_wtime(); st->t_lchain += t1 - t0; t0 = t1;
-	if (env_int("MGA_CHECK", 0) && !is_rmq && !dev_gc) { /* debugging aid: invariants of what the device stages handed back (host placement) */
+	if (env_int("MGA_CHECK", 0) && !is_rmq && !chunk_long && !dev_gc && h_nu && h_nb) { /* debugging aid: invariants of what the device stages handed back (host placement) */
 		int64_t bad = 0;
 		for (i = 0; i < n && bad < 5; ++i) {
 			const int64_t na_i = h_aoff[i + 1] - h_aoff[i], nm_i = h_minioff[i + 1] - h_minioff[i];
@@ -1211,6 +1217,7 @@ struct mga_stream_s {
 	const mg_idx_t *gi;
 	mg_mapopt_t opt;
 	int n_threads, n_pipe, chunk, max_inflight;
+	int lr_long;                   /* ultra-long -x lr reads: at least this many bases (0: none); fixed when the options are set */
 	pthread_mutex_t m;
 	pthread_cond_t c_work, c_done, c_space;
 	sbatch_t *head, *tail, *cur;   /* submitted and not yet collected (FIFO); cur = first batch that still has chunks to hand out */
@@ -1282,7 +1289,7 @@ static void stream_run_chunk(mga_stream_t *S, pipe_ctx_t *P, sbatch_t *b, int c)
 	int rc;
 	memset(&cst, 0, sizeof cst);
 	rc = b->err ? 0 : map_chunk(P, S->gi, en - st, b->qlens + st, b->seqs + st, b->qnames ? b->qnames + st : 0, b->gcs + st, &S->opt, b->n_threads,
-								b->d_seq, b->q_off ? b->q_off + st : 0, b->seqs_pinned, &cst, b->gaf_part ? b->gaf_part + (size_t)c * b->n_threads : 0);
+								b->d_seq, b->q_off ? b->q_off + st : 0, b->seqs_pinned, &cst, b->gaf_part ? b->gaf_part + (size_t)c * b->n_threads : 0, S->lr_long);
 	PIPE_LOG("map_chunk", c, tc);
 	if (rc == 0 && b->gaf_part && !b->err) { /* the chunk's GAF text was formatted inside map_chunk(); append it to the output in read order */
 		double t0 = mga_wtime();
@@ -1341,6 +1348,7 @@ mga_stream_t *mga_stream_open(const mg_idx_t *gi, const mg_mapopt_t *opt, int n_
 	g_cpu_on = g_dbg_pipe > 0;
 	S = MGA_CALLOC(mga_stream_t, 1);
 	S->gi = gi, S->opt = *opt, S->n_threads = n_threads > 0 ? n_threads : 1;
+	S->lr_long = (opt->flag & MG_M_RMQ) ? 0 : lr_long_bases();
 	S->n_pipe = env_int("MGA_PIPE", n_threads <= 4 ? 3 : 4); /* [measured, round 4, a rank pinned to 2 of 16 cores] 3 pipeline threads: 2.31 Gbp/s at 0.70 CPU-s per step, 4: 2.23 at 0.82, 2: 2.07; with 16 threads 4 is the best (3.27 vs 2.96 vs 2.51) */
 	if (S->n_pipe > MGA_MAX_PIPE) S->n_pipe = MGA_MAX_PIPE;
 	if (S->n_pipe < 1) S->n_pipe = 1;
@@ -1366,10 +1374,73 @@ static void stream_start(mga_stream_t *S) /* worker threads are created with the
 	S->started = 1;
 }
 
-void mga_stream_set_opt(mga_stream_t *S, const mg_mapopt_t *opt, int n_threads) { S->opt = *opt; if (n_threads > 0) S->n_threads = n_threads; } /* only while nothing is in flight */
+void mga_stream_set_opt(mga_stream_t *S, const mg_mapopt_t *opt, int n_threads) { S->opt = *opt; S->lr_long = (opt->flag & MG_M_RMQ) ? 0 : lr_long_bases(); if (n_threads > 0) S->n_threads = n_threads; } /* only while nothing is in flight */
 
-/* chunk boundaries of a batch: MGA_CHUNK reads each; the FIRST batch of a job ramps up from chunk/4 and the LAST one ramps down
- * (fill and drain of the pipeline cost about one chunk time each) */
+/* chunk boundaries of a batch: MGA_CHUNK reads each at most; the FIRST batch of a job ramps up from chunk/4 and the LAST one ramps down
+ * (fill and drain of the pipeline cost about one chunk time each).
+ * MGA_CUT=1 (round 5, default): chunks of EQUAL size inside a batch instead of full chunks + a remainder -- a 50 000-read mini-batch is 4 x 12 500, not 3 x 16 384 + 848:
+ * a chunk of a few hundred reads pays a pass's whole chain of launches and synchronisations for no work ([measured, bench workload] its three -K batches were cut into
+ * 12 chunks, two of them of 848 and 424 reads).  MGA_TAIL=<levels>: the LAST batch ends in chunks of 1/2, 1/4, ... of a chunk (the drain of the pipeline: the last chunk
+ * walks its stages with nothing behind it).  The output never depends on the cut (test_pipeline_knobs_do_not_change_the_output). */
+typedef struct { int even, ramp_first, n_tail, tail_tot, body_sz, tail_sz[8]; } cut_plan_t;
+
+static void cut_plan_init(cut_plan_t *cp, int n, int chunk, int ramp, int flags, int even, int tail_levels)
+{
+	int k, head = 0, body;
+	memset(cp, 0, sizeof *cp);
+	cp->even = even, cp->body_sz = chunk;
+	if (!even) return;
+	if (ramp && (flags & MGA_SB_LAST)) for (k = 0; k < tail_levels && k < 8 && (chunk >> (k + 1)) >= 64; ++k) cp->tail_sz[cp->n_tail++] = chunk >> (k + 1), cp->tail_tot += chunk >> (k + 1);
+	if (ramp && (flags & MGA_SB_FIRST)) head = chunk / 4 + chunk / 2, cp->ramp_first = 1;
+	if (n < head + cp->tail_tot + chunk / 2) { /* too small for both ramps: keep the one that fits, or equal chunks only */
+		if (cp->ramp_first && n >= head + chunk / 2) cp->n_tail = 0, cp->tail_tot = 0;
+		else if (cp->n_tail > 0 && n >= cp->tail_tot + chunk / 2) head = 0, cp->ramp_first = 0;
+		else head = 0, cp->ramp_first = 0, cp->n_tail = 0, cp->tail_tot = 0;
+	}
+	body = n - head - cp->tail_tot;
+	if (body > 0) { const int nc = (body + chunk - 1) / chunk; cp->body_sz = (body + nc - 1) / nc; }
+}
+
+/* size of chunk number m of a batch of which `left` reads are left */
+static int cut_plan_size(const cut_plan_t *cp, int chunk, int ramp, int flags, int m, int left)
+{
+	int sz = chunk, k, suf;
+	if (!cp->even) { /* rounds 1-4: full chunks + what is left */
+		if (ramp) {
+			if (flags & MGA_SB_FIRST) { if (m == 0) sz = chunk / 4; else if (m == 1) sz = chunk / 2; }
+			if ((flags & MGA_SB_LAST) && left <= chunk + chunk / 2) sz = left > chunk / 2 + chunk / 8 ? left - chunk / 2 : left; /* tail: the last chunk is chunk/2 (or what is left) */
+		}
+		return sz;
+	}
+	sz = cp->body_sz;
+	if (cp->ramp_first && m == 0) sz = chunk / 4;
+	else if (cp->ramp_first && m == 1) sz = chunk / 2;
+	if (cp->n_tail > 0) {
+		if (left <= cp->tail_tot) { /* in the tail: the largest run of tail pieces that fits; what a base-capped chunk before left over is absorbed by this piece */
+			for (k = 0, suf = cp->tail_tot; k < cp->n_tail && suf > left; ++k) suf -= cp->tail_sz[k];
+			sz = k < cp->n_tail ? cp->tail_sz[k] + (left - suf) : left;
+		} else if (left - sz < cp->tail_tot) sz = left - cp->tail_tot; /* the body's last chunk ends where the tail pieces begin */
+	}
+	return sz;
+}
+
+/* (tests) the read counts of the chunks a batch of n reads of equal length is cut into; returns their number */
+int mga_debug_cut(int n, int chunk, int flags, int even, int tail_levels, int *sizes, int max_sizes)
+{
+	cut_plan_t cp;
+	int pos = 0, m = 0;
+	const int ramp = n > 6 * chunk || (flags & (MGA_SB_FIRST | MGA_SB_LAST)) != (MGA_SB_FIRST | MGA_SB_LAST);
+	cut_plan_init(&cp, n, chunk, ramp, flags, even, tail_levels);
+	while (pos < n) {
+		int sz = cut_plan_size(&cp, chunk, ramp, flags, m, n - pos);
+		if (sz < 1) sz = 1;
+		if (sz > n - pos) sz = n - pos;
+		if (m < max_sizes) sizes[m] = sz;
+		++m, pos += sz;
+	}
+	return m;
+}
+
 static void batch_cut(mga_stream_t *S, sbatch_t *b)
 {
 	const int n = b->n, chunk = S->chunk;
@@ -1377,19 +1448,17 @@ static void batch_cut(mga_stream_t *S, sbatch_t *b)
 	/* a chunk is also bounded in BASES: its device buffers grow with bases and anchors, not with reads, and a chunk of 16384 reads of 100 kb
 	 * each would be ten times the footprint every measurement was taken at.  MGA_CHUNK reads of 12 kb is the cap (10 kb reads: never reached). */
 	const int64_t base_cap = (S->opt.flag & MG_M_RMQ) ? INT64_MAX : (int64_t)chunk * env_int("MGA_CHUNK_READ_BASES", 12288); /* (-x asm: a batch is a handful of contigs chained in phases over ALL of them) */
-	int pos = 0, m = 0, cap = n / (chunk / 4 > 0 ? chunk / 4 : 1) + 8;
+	int pos = 0, m = 0, cap = n / (chunk / 16 > 0 ? chunk / 16 : 1) + 16;
+	cut_plan_t cp;
+	cut_plan_init(&cp, n, chunk, ramp, b->flags, env_int("MGA_CUT", 1), env_int("MGA_TAIL", 1));
 	b->cstart = MGA_MALLOC(int, cap + 1);
 	while (pos < n) {
-		int sz = chunk, left = n - pos, k;
+		int sz = cut_plan_size(&cp, chunk, ramp, b->flags, m, n - pos), left = n - pos, k;
 		int64_t bases = 0;
-		if (ramp) {
-			if (b->flags & MGA_SB_FIRST) { if (m == 0) sz = chunk / 4; else if (m == 1) sz = chunk / 2; }
-			if ((b->flags & MGA_SB_LAST) && left <= chunk + chunk / 2) sz = left > chunk / 2 + chunk / 8 ? left - chunk / 2 : left; /* tail: the last chunk is chunk/2 (or what is left) */
-		}
 		if (sz < 1) sz = 1;
 		if (sz > left) sz = left;
 		{ /* ultra-long -x lr reads (>= MGA_LONG_READ bases, default 256 k) travel in chunks of their own -- at most 64 Mbp of them -- through the long-query path (map_chunk) */
-			const int lr_long = !(S->opt.flag & MG_M_RMQ) ? env_int("MGA_LONG_READ", 262144) : 0;
+			const int lr_long = S->lr_long;
 			const int first_long = lr_long > 0 && b->qlens[pos] >= lr_long;
 			for (k = 0; k < sz; ++k) {
 				if (lr_long > 0 && k > 0 && (b->qlens[pos + k] >= lr_long) != first_long) break;
@@ -1607,7 +1676,7 @@ void mg_map_frag(const mg_idx_t *gi, int n_segs, const int *qlens, const char **
 		memset(&cst, 0, sizeof cst);
 		if (g_dbg_pipe < 0) { g_dbg_pipe = env_int("MGA_DEBUG_PIPE", 0); g_gpu_wfa.avail = env_int("MGA_WFA_SLOTS", 2); g_gpu_front.avail = env_int("MGA_FRONT_SLOTS", 1); }
 		rc = mga_dev_init() < 0 || mga_dev_bind_thread() < 0 || (b->P.sc == 0 && (b->P.sc = mga_sctx_create()) == 0) ? -1 : 0;
-		if (rc == 0) rc = map_chunk(&b->P, gi, 1, qlens, seqs, &qname, gcs, opt, 1, 0, 0, 0, &cst, 0);
+		if (rc == 0) rc = map_chunk(&b->P, gi, 1, qlens, seqs, &qname, gcs, opt, 1, 0, 0, 0, &cst, 0, (opt->flag & MG_M_RMQ) ? 0 : lr_long_bases());
 		if (rc < 0) { fprintf(stderr, "[E::%s] %s\n", __func__, mga_last_error()); abort(); /* no CPU fallback */ }
 		pthread_mutex_lock(&g_stats_mtx); stats_merge(&gi->B->st, &cst); pthread_mutex_unlock(&g_stats_mtx);
 		return;

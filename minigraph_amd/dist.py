@@ -28,34 +28,53 @@ def _pin_for_dma(arr, cap=0):
         pass
 
 
+def _as_u8(payload):
+    import numpy as np
+    return np.frombuffer(payload, dtype=np.uint8) if not isinstance(payload, np.ndarray) else payload.reshape(-1)
+
+
+def _to_device(src, device, pin=0):
+    """the rank's payload as ONE uint8 tensor of exactly its size on `device` (a zero-copy view for host tensors where the array is writable)"""
+    t = torch.empty(src.size, dtype=torch.uint8, device=device)
+    if src.size:
+        copied = False
+        if not src.flags.writeable:
+            src, copied = src.copy(), True   # torch.from_numpy wants a writable array (bytes objects are not)
+        if device != "cpu" and pin and not copied:   # (never register a numpy-owned temporary: `pin` carries the LIBRARY buffer's capacity and lifetime)
+            _pin_for_dma(src, pin)   # page-lock the library's (reused) output buffer once: the upload then runs at DMA speed instead of through a bounce buffer
+        t.copy_(torch.from_numpy(src), non_blocking=False)
+    return t
+
+
+def _exchange(ops):
+    """run a list of point-to-point operations (dist.P2POp) to completion: one group on RCCL (all links into the destination at once), plain isend / irecv on gloo"""
+    if not ops:
+        return
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+
+
 def gather_bytes(payload, dst=0, device="cpu", as_tensors=False, pin=False):
     """gather one byte string per rank to `dst`; returns the list in rank order on dst, None elsewhere.
     payload: bytes, or any C-contiguous uint8 buffer (e.g. the zero-copy numpy view of the library's GAF buffer).
-    One all_gather of the sizes + one gather of byte tensors padded to the largest payload; with as_tensors=True the
+    One all_gather of the sizes, then SIZE-EXACT point-to-point transfers (round 5): every rank sends exactly its bytes, the destination receives every
+    part into a tensor of exactly that part's size -- nothing is padded to the largest payload and the destination holds every byte once.  With as_tensors=True the
     result stays on `device` (uint8 tensors, no host round trip)."""
-    import numpy as np
     world, rank = dist.get_world_size(), dist.get_rank()
-    src = np.frombuffer(payload, dtype=np.uint8) if not isinstance(payload, np.ndarray) else payload.reshape(-1)
+    src = _as_u8(payload)
     n = torch.tensor([src.size], dtype=torch.int64, device=device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n)
     sizes = [int(s.item()) for s in sizes]
-    mx = max(max(sizes), 1)
-    buf = torch.empty(mx, dtype=torch.uint8, device=device)
-    if src.size:
-        copied = False
-        if not src.flags.writeable:
-            src, copied = src.copy(), True  # torch.from_numpy wants a writable array (bytes objects are not)
-        if device != "cpu" and pin and not copied:   # (never register a numpy-owned temporary: `pin` carries the LIBRARY buffer's capacity and lifetime)
-            _pin_for_dma(src, pin)   # page-lock the library's (reused) output buffer once: the upload then runs at DMA speed instead of through a bounce buffer
-        buf[:src.size].copy_(torch.from_numpy(src), non_blocking=False)
-    out = [torch.empty(mx, dtype=torch.uint8, device=device) for _ in range(world)] if rank == dst else None
-    dist.gather(buf, out, dst=dst)
     if rank != dst:
+        if sizes[rank]:
+            _exchange([dist.P2POp(dist.isend, _to_device(src, device, pin), dst)])
         return None
+    out = [_to_device(src, device, pin) if r == rank else torch.empty(sizes[r], dtype=torch.uint8, device=device) for r in range(world)]
+    _exchange([dist.P2POp(dist.irecv, out[r], r) for r in range(world) if r != rank and sizes[r]])
     if as_tensors:
-        return [out[r][:sizes[r]] for r in range(world)]
-    return [out[r][:sizes[r]].cpu().numpy().tobytes() for r in range(world)]
+        return out
+    return [t.cpu().numpy().tobytes() for t in out]
 
 
 def gather_chains(gcs, n, dst=0):
@@ -109,11 +128,11 @@ def assemble_segments(parts, seg_lens):
 def map_sharded(mapper, dst=0, device="cpu", as_tensor=False):
     """one input -> world ranks -> one GAF on `dst` (gmap.c:98-141 fanned out over devices).  mapper(rank, world) maps this rank's shard
     and returns (payload, seg_len[, cap]): its GAF bytes (bytes or a uint8 numpy view) and the per-segment byte counts.  One all_gather of the
-    segment tables + one gather of the payloads (RCCL when device == "cuda"); returns the assembled output on dst, None elsewhere:
-    bytes, or with as_tensor=True ONE uint8 tensor on `device` (the parts are put in order by torch.cat, no host round trip).
+    segment tables, then every (segment, rank) piece travels point to point STRAIGHT INTO ITS PLACE in one output tensor of exactly the job's size on `dst`
+    (round 5: no padding to the largest shard, no second copy by torch.cat -- the destination holds the output once; on RCCL the seven senders use their own
+    xGMI links into the destination at the same time).  Returns the assembled output on dst, None elsewhere: bytes, or with as_tensor=True ONE uint8 tensor on `device`.
     A mapper that returns a third value -- the capacity in bytes of the LIBRARY buffer behind its payload view (MappedGaf.cap) -- gets that buffer page-locked
     once through the library's registry (mga_host_pin) before the upload."""
-    import numpy as np
     world, rank = dist.get_world_size(), dist.get_rank()
     res = mapper(rank, world)
     payload, seg_len = res[0], res[1]
@@ -126,16 +145,42 @@ def map_sharded(mapper, dst=0, device="cpu", as_tensor=False):
         tab[:len(seg_len)] = torch.tensor(seg_len, dtype=torch.int64)
     tabs = [torch.zeros_like(tab) for _ in range(world)]
     dist.all_gather(tabs, tab)
-    parts = gather_bytes(payload, dst=dst, device=device, as_tensors=as_tensor, pin=pin)   # pin: capacity of the library buffer behind payload (0: not the library's)
-    if rank != dst:
-        return None
     tabs = [t.cpu().tolist() for t in tabs]
-    if not as_tensor:
-        return assemble_segments(parts, tabs)
-    pos, out = [0] * world, []
-    for s in range(len(tabs[0])):
+    src = _as_u8(payload)
+    if sum(tabs[rank]) != src.size:
+        raise RuntimeError("map_sharded: rank %d's segment table sums to %d bytes, its payload has %d" % (rank, sum(tabs[rank]), src.size))
+    if rank != dst:   # this rank's pieces, in segment order (the order the destination posts its receives for this rank in)
+        buf = _to_device(src, device, pin)
+        ops, pos = [], 0
+        for ln in tabs[rank]:
+            if ln:
+                ops.append(dist.P2POp(dist.isend, buf[pos:pos + ln], dst))
+            pos += ln
+        _exchange(ops)
+        return None
+    total = sum(sum(t) for t in tabs)
+    out = torch.empty(total, dtype=torch.uint8, device=device)
+    ops, pos, at = [], [0] * world, 0
+    own = []
+    for s in range(len(tabs[0])):   # output order: segment by segment, ranks in order inside a segment
         for r in range(world):
             ln = int(tabs[r][s])
-            out.append(parts[r][pos[r]:pos[r] + ln])
+            if ln and r == rank:
+                own.append((at, pos[r], ln))
+            elif ln:
+                ops.append((r, s, dist.P2POp(dist.irecv, out[at:at + ln], r)))
             pos[r] += ln
-    return torch.cat(out) if out else torch.empty(0, dtype=torch.uint8, device=device)
+            at += ln
+    ops.sort(key=lambda x: (x[0], x[1]))   # per source rank in ITS sending order (messages of one pair are matched in order)
+    if own:   # the destination's own pieces go from its host buffer straight to their places
+        if not src.flags.writeable:
+            src = src.copy()
+        elif device != "cpu" and pin:
+            _pin_for_dma(src, pin)
+        hs = torch.from_numpy(src)
+        for a_, p_, ln in own:
+            out[a_:a_ + ln].copy_(hs[p_:p_ + ln], non_blocking=False)
+    _exchange([o[2] for o in ops])
+    if as_tensor:
+        return out
+    return out.cpu().numpy().tobytes()

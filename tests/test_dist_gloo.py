@@ -45,6 +45,53 @@ def test_shard_and_gather_world2():
     assert empty == [b"x", b""]
 
 
+def _place_worker(rank, world, port, q, as_tensor):
+    """map_sharded's transport alone: every rank owns `world`-dependent, unequal pieces of several output segments (one rank owns nothing at all, one segment is
+    empty on every rank); the pieces must land, point to point, at their places in ONE output of exactly the job's size on rank 0"""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    from minigraph_amd.dist import map_sharded
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def piece(r, s):
+        if r == 1 or s == 2:
+            return b""
+        return (b"<seg%d rank%d>" % (s, r)) * (1 + 5 * r + 3 * s) + b"\n"
+
+    def mapper(r, w):
+        n_seg = 5 if r != w - 1 else 3   # the last rank has a SHORTER segment table (its input ran out earlier)
+        parts = [piece(r, s) for s in range(n_seg)]
+        return b"".join(parts), [len(x) for x in parts]
+
+    got = map_sharded(mapper, dst=0, as_tensor=as_tensor)
+    if rank == 0:
+        q.put(bytes(got.numpy().tobytes()) if as_tensor else got)
+        want_len = sum(len(piece(r, s)) for r in range(world) for s in range(5 if r != world - 1 else 3))
+        assert (got.numel() if as_tensor else len(got)) == want_len   # the destination holds every byte once: the output is exactly the job's size
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,as_tensor", [(4, True), (4, False), (3, True)])
+def test_pieces_travel_point_to_point_into_place(world, as_tensor):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_place_worker, args=(r, world, port, q, as_tensor)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+
+    def piece(r, s):
+        if r == 1 or s == 2:
+            return b""
+        return (b"<seg%d rank%d>" % (s, r)) * (1 + 5 * r + 3 * s) + b"\n"
+    want = b"".join(piece(r, s) for s in range(5) for r in range(world) if s < (5 if r != world - 1 else 3))
+    assert got == want
+
+
 def test_shard_range_covers_everything():
     for n in (0, 1, 7, 8, 23, 1000):
         for w in (1, 2, 3, 8):

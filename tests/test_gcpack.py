@@ -111,6 +111,34 @@ for at in range(8, 200, 4):             # the words that ARE structure: the coun
     for v in (b"\xff\xff\xff\x7f", b"\xff\xff\xff\xff", b"\x00\x00\x00\x80", b"\x00\x00\x10\x00"):   # (whose pointer fields travel as byte counts)
         b = bytearray(data); b[at:at + 4] = v
         attempt(bytes(b))
+# ---- ADVICE r4: counts that are consistent with the buffer's SIZE but not with each other.  The first read with chains: header at `at`, gc[] behind it (104 bytes each:
+# off @ 8, cnt @ 12, n_anchor @ 16), then lc[] (20 bytes each: off @ 0, cnt @ 4)
+import struct
+at = 16
+while True:
+    present, n_gc, n_lc, n_a = struct.unpack_from("<4i", data, at)
+    if present and n_gc > 0: break
+    at += 32   # (reads without an object / without chains carry a header only)
+gc0, lc0 = at + 32, at + 32 + n_gc * 104
+def refused_with(patch):
+    global refused
+    b = bytearray(data); patch(b)
+    before = refused
+    attempt(bytes(b))
+    return refused == before + 1
+def put(b, off, v): b[off:off + 4] = struct.pack("<i", v)
+assert refused_with(lambda b: put(b, gc0 + 8, n_lc))                      # gc[0].off + cnt beyond lc[]
+assert refused_with(lambda b: put(b, gc0 + 12, n_lc + 1))                 # gc[0].cnt
+assert refused_with(lambda b: put(b, gc0 + 8, -1))
+assert refused_with(lambda b: put(b, lc0 + 0, n_a))                       # lc[0].off + cnt beyond a[]
+assert refused_with(lambda b: put(b, lc0 + 4, n_a + 1))
+assert refused_with(lambda b: put(b, lc0 + 4, -5))
+# an object without chains that still claims records (n_gc = 0, n_lc = 3, n_a = 2: the sizes line up, lc and a would stay NULL behind non-zero counts)
+hdr = struct.pack("<QQ", struct.unpack_from("<Q", data, 0)[0], 1)
+rec = struct.pack("<8i", 1, 0, 3, 2, 0, 0, 0, 0) + b"\0" * (3 * 20 + 4) + b"\0" * (2 * 16)
+before = refused; attempt(hdr + rec); assert refused == before + 1
+rec = struct.pack("<8i", 1, 0, 0, 0, 7, 0, 0, 0)                           # ... and the legal form of the same: accepted, no arrays
+before = accepted; attempt(hdr + rec); assert accepted == before + 1
 print("OK", refused, accepted, refused - r0)
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, "-c", code, os.path.join(d, "packed.bin")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)

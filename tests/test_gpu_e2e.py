@@ -338,11 +338,15 @@ def test_pipeline_knobs_do_not_change_the_output(monkeypatch):
     G = mga.Graph(graph, preset="lr", cigar=True, n_threads=8)
     R = mga.Reads(reads)
     want = mga.map_reads(G, R, n_threads=8)
-    for chunk, pipe, threads, extra in ((1, 4, 2, {}), (3, 2, 1, {}), (64, 1, 8, {}), (100, 3, 16, {"MGA_WFA_CONCURRENT": "1"}), (7, 4, 3, {"MGA_UPLOAD_READS": "1"})):
+    L = mga.load()
+    for chunk, pipe, threads, extra in ((1, 4, 2, {}), (3, 2, 1, {}), (64, 1, 8, {}), (100, 3, 16, {"MGA_WFA_CONCURRENT": "1"}), (7, 4, 3, {"MGA_UPLOAD_READS": "1"}),
+                                        (40, 4, 8, {"MGA_CUT": "0"}), (40, 4, 8, {"MGA_CUT": "1", "MGA_TAIL": "3"}), (64, 3, 8, {"MGA_TAIL": "2", "MGA_WFA_GRID_PCT": "50", "MGA_WFA_SLOTS": "3"}),
+                                        (50, 2, 4, {"MGA_RAMP": "0", "MGA_WFA_GRID_PCT": "1"})):
         monkeypatch.setenv("MGA_CHUNK", str(chunk))
         monkeypatch.setenv("MGA_PIPE", str(pipe))
         for k, v in extra.items():
             monkeypatch.setenv(k, v)
+        L.mga_idx_stream_close(G.gi)   # the index's chunk pipeline is rebuilt with THESE knobs (chunk size, pipeline threads and the cut are fixed when a stream is opened)
         got = mga.map_reads(G, R, n_threads=threads)
         for k in extra:
             monkeypatch.delenv(k)
@@ -460,8 +464,10 @@ def test_graph_image_load_maps_byte_identically_to_build():
             del os.environ["MGA_DEV_GCHAIN"]
 
 
-def test_bench_launches_its_own_ranks():
-    """`python bench.py --gpus 2` without a launcher around it starts two ranks itself (torch.distributed.run), shards ONE read file over them, gathers the
+@pytest.mark.parametrize("ranks,reads", [(2, 3000), (4, 1500)])
+def test_bench_launches_its_own_ranks(ranks, reads):
+    """(4 ranks: round 5 -- the size-exact point-to-point gather with three senders into rank 0)
+    `python bench.py --gpus 2` without a launcher around it starts two ranks itself (torch.distributed.run), shards ONE read file over them, gathers the
     GAF to rank 0 and reports n_gpus = 2 with the gathered text byte-identical to the reference (gloo: two ranks share the one GPU of the test box)"""
     import json
     import sys
@@ -470,15 +476,17 @@ def test_bench_launches_its_own_ranks():
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--reads", "3000", "--genome", "30000000", "--chr", "2",
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--backend", "gloo", "--reads", str(reads), "--genome", "30000000", "--chr", "2",
                         "--steps", "1", "--warmup", "1", "--cpu-reads", "6000", "--resident-steps", "0", "--one-placement", "--threads", "4"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert d["n_gpus"] == ranks and d["value"] > 0
     assert "byte-identical" in d.get("parity", ""), d.get("parity")
     assert "(6000 in all, ONE file)" in d["config"]["workload"]
+    if ranks != 2:
+        return
     # the plain launcher contract still holds: a WORLD_SIZE that disagrees with --gpus is refused, not silently overridden
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     p2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1"], env=env2, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
