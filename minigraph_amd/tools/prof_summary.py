@@ -74,6 +74,12 @@ def main_sq(paths, title):
                 if "SQ_ACTIVE_INST_VALU" in k:
                     d.setdefault("valu_busy", k["SQ_ACTIVE_INST_VALU"] / busy)
     print("# rocprofv3 --pmc SQ_* (own passes, no tracing)  %s" % title)
+    import re
+    m = re.search(r"--reads (\d+)", title)
+    reads = int(m.group(1)) if m else 125000
+    lc = acc.get("k_lchain")
+    if lc and lc.get("waves"):   # k_lchain is one wavefront per read: its waves / the reads of a pass = the passes these counters cover (bench.py divides by it)
+        print("# passes covered: %d (k_lchain: %d waves / %d reads per pass)" % (round(lc["waves"] / reads), lc["waves"], reads))
     print("# per wave: instructions issued; shares: fraction of the waves' resident cycles (SQ_WAVE_CYCLES): valu = SQ_ACTIVE_INST_VALU, wait = SQ_WAIT_ANY (parked on s_waitcnt / barrier),")
     print("# stall = SQ_WAIT_INST_ANY (issue stalls), vmem / lds / salu = SQ_INST_CYCLES_VMEM / SQ_ACTIVE_INST_LDS / SQ_INST_CYCLES_SALU where collected")
     print("# occ = waves resident per SIMD while the kernel runs = SQ_WAVE_CYCLES / (32 x SQ_BUSY_CYCLES) (SQ_BUSY_CYCLES is summed over the 32 shader engines, each with 32 SIMDs);")
@@ -90,7 +96,33 @@ def main_sq(paths, title):
               col(d, "SQ_INST_CYCLES_VMEM/cyc", "%7.3f", 7), col(d, "SQ_ACTIVE_INST_LDS/cyc", "%7.3f", 7), col(d, "SQ_INST_CYCLES_SALU/cyc", "%7.3f", 7), col(d, "occ", "%6.2f", 6), col(d, "valu_busy", "%9.3f", 9)))
 
 
+def main_calib(path):
+    """valu_rate under --pmc (csv): per dispatch of the microbenchmark -- whose instruction count (64 x iters + loop overhead per wave), waves per SIMD and issue rate
+    (an independent stream: ~100 %) are KNOWN -- the raw counters and what prof_summary's formulas make of them: pins the counters' units"""
+    import collections
+    d = collections.OrderedDict()
+    for r in csv.DictReader(open(path)):
+        k = (int(r["Dispatch_Id"]), r["Kernel_Name"].split("(")[0].replace("void ", ""), int(r["Grid_Size"]), int(r.get("Workgroup_Size", 64) or 64))
+        e = d.setdefault(k, {})
+        e[r["Counter_Name"]] = e.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        if r.get("Start_Timestamp") and r.get("End_Timestamp"):
+            e["_ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    print("# valu_rate under rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE: one row per dispatch")
+    print("# expected: VALU/wave = 64 x iters (+ a few), waves/SIMD = grid / 64 / 1024; an independent instruction stream keeps the vector ALU busy ~100 %")
+    print("%-16s %8s %6s %10s %12s %14s %14s %14s %14s %10s | %9s %9s %9s %9s" % ("kernel", "waves", "w/SIMD", "dur_us", "VALU/wave", "ACTIVE_VALU", "WAVE_CYCLES", "BUSY_CYCLES", "GRBM_ACTIVE", "GRBM_MHz",
+                                                                                     "occ(x32)", "busy(x32)", "WC/wave/us", "ACT/INST"))
+    for (did, name, grid, wg), e in d.items():
+        waves = e.get("SQ_WAVES", 0.0) or (grid / 64.0)
+        us = e.get("_ns", 0) / 1e3
+        wc, bc, av, iv, ga = e.get("SQ_WAVE_CYCLES", 0.0), e.get("SQ_BUSY_CYCLES", 0.0), e.get("SQ_ACTIVE_INST_VALU", 0.0), e.get("SQ_INSTS_VALU", 0.0), e.get("GRBM_GUI_ACTIVE", 0.0)
+        print("%-16s %8d %6.2f %10.1f %12.1f %14.0f %14.0f %14.0f %14.0f %10.1f | %9.3f %9.3f %9.1f %9.3f" % (
+            name[:16], waves, grid / 64.0 / 1024.0, us, iv / max(waves, 1), av, wc, bc, ga, ga / us if us else 0.0,
+            wc / (32.0 * bc) if bc else 0.0, av / (32.0 * bc) if bc else 0.0, wc / max(waves, 1) / us if us else 0.0, av / iv if iv else 0.0))
+
+
 def main():
+    if sys.argv[1] == "--calib":
+        return main_calib(sys.argv[2])
     if sys.argv[1] == "--sq":
         return main_sq([a for a in sys.argv[2:] if a.endswith(".db")], " ".join(a for a in sys.argv[2:] if not a.endswith(".db")))
     if sys.argv[1] == "--pmc-json":
