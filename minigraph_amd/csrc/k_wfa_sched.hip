@@ -402,11 +402,28 @@ static int wfs_sweep(mga_sctx_t *sc, const wfs_ladder_t *LD, int arr_pct, int n_
 		}
 		if (mga_dev_wfa_tier(sc, rc + t, own[t], 0, LD->r[t].idx, side, L + base[t], d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, LD->r[t].idx, rt_of(t)) < 0) return -1;
 	}
+	// Round 5: a rung's walk (k_wfa_tb: a lane per problem chasing traceback bytes -- bound by memory latency, 2 % of the vector issue slots) runs on a stream of its own
+	// NEXT TO the following rung's forward pass (bound by vector issue): two traceback buffers used in turn, the forward pass of rung k waits for the walk of rung
+	// k - 2 (the previous user of its buffer), the walk of rung k for its forward pass.  MGA_WFA_TB_SIDE=0 (and the isolated pass, MGA_WFA_SIDE=0): one buffer, one stream.
+	const char *e_tbs = getenv("MGA_WFA_TB_SIDE");
+	const bool tb_side = use_side && !(e_tbs && atoi(e_tbs) == 0);
+	hipStream_t tbs = tb_side ? (hipStream_t)sc->tier_stream[1] : st;
+	if (tb_side && tb_bytes > 0 && mga_dbuf_reserve(&sc->wfa_tbuf[1], (size_t)tb_bytes + 256) < 0) return -1;
+	int n_win = 0;
 	for (int t = 0; t < NR; ++t) {
 		if (LD->r[t].kind != 0 || cap[t] <= 0) continue;
-		if (mga_dev_wfa_win(sc, rc + t, cap[t], L + base[t], d_prob, d_tseq, d_qseq, d_res, (char*)sc->wfa_tbuf[0].p, LD->r[t].idx, 9 + LD->r[t].idx, rt_of(t)) < 0) return -1;
-		if (mga_dev_wfa_traceback(sc, rc + t, cap[t], L + base[t], d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, ctl + O_ERR) < 0) return -1;
+		char *tbuf = (char*)sc->wfa_tbuf[tb_side ? (n_win & 1) : 0].p;
+		if (tb_side && n_win >= 2) MGA_HIP_CHECK(hipStreamWaitEvent(st, (hipEvent_t)sc->ev_done[2 + (n_win & 1)], 0)); // the walk that read this buffer two rungs ago
+		if (mga_dev_wfa_win(sc, rc + t, cap[t], L + base[t], d_prob, d_tseq, d_qseq, d_res, tbuf, LD->r[t].idx, 9 + LD->r[t].idx, rt_of(t)) < 0) return -1;
+		if (tb_side) {
+			MGA_HIP_CHECK(hipEventRecord((hipEvent_t)sc->ev_done[1], st));
+			MGA_HIP_CHECK(hipStreamWaitEvent(tbs, (hipEvent_t)sc->ev_done[1], 0));
+		}
+		if (mga_dev_wfa_traceback(sc, tbs, rc + t, cap[t], L + base[t], d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, ctl + O_ERR) < 0) return -1;
+		if (tb_side) MGA_HIP_CHECK(hipEventRecord((hipEvent_t)sc->ev_done[2 + (n_win & 1)], tbs));
+		++n_win;
 	}
+	if (tb_side) for (int k = 0; k < 2 && k < n_win; ++k) MGA_HIP_CHECK(hipStreamWaitEvent(st, (hipEvent_t)sc->ev_done[2 + k], 0)); // every walk is through before what follows on the main stream
 	if (forked && use_side) {
 		MGA_HIP_CHECK(hipEventRecord((hipEvent_t)sc->ev_done[0], side));
 		MGA_HIP_CHECK(hipStreamWaitEvent(st, (hipEvent_t)sc->ev_done[0], 0));

@@ -454,7 +454,7 @@ static int wfw_rows(int W) { const int smax = W + 30 < WFW_SMAX ? W + 30 : WFW_S
 extern "C" int64_t mga_dev_wfa_win_tb_stride(int wt) { return (int64_t)wfw_rows(g_wtier[wt].W) * g_wtier[wt].W * 4; }
 
 extern "C" int mga_dev_wfa_win(mga_sctx_t *sc, const int *d_n, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
-							   mga_wfa_res_t *d_res, char *d_tb, int wt, int slot, mga_wfa_retry_t rt)
+							   mga_wfa_res_t *d_res, char *d_tb, int wt, int slot, mga_wfa_retry_t rt)  /* (launched on the context's own stream) */
 {
 	if (n <= 0) return 0;
 	if (wt < 0 || wt >= MGA_WFW_N) { mga_set_error("wfa_win: bad tier %d", wt); return -1; }
@@ -485,11 +485,11 @@ extern "C" int mga_dev_wfa_win(mga_sctx_t *sc, const int *d_n, int n, const int3
 	return 0;
 }
 
-extern "C" int mga_dev_wfa_traceback(mga_sctx_t *sc, const int *d_n, int cap, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq, mga_wfa_res_t *d_res,
+extern "C" int mga_dev_wfa_traceback(mga_sctx_t *sc, void *stream, const int *d_n, int cap, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq, mga_wfa_res_t *d_res,
 									 uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int *d_err)
 {
 	if (cap <= 0) return 0;
-	hipStream_t st = (hipStream_t)sc->stream;
+	hipStream_t st = (hipStream_t)(stream ? stream : sc->stream);
 	mga_prof_begin(st, MGA_K_WFATB);
 	hipLaunchKernelGGL(k_wfa_tb, dim3((cap + 255) / 256), dim3(256), 0, st, d_n, cap, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap, d_pool_used, d_err);
 	mga_prof_end(st, MGA_K_WFATB);

@@ -725,7 +725,7 @@ typedef struct { /* one pipeline context: HIP stream + grow-only device and pinn
 } pipe_ctx_t;
 _Static_assert(sizeof(((pipe_ctx_t*)0)->dall) == 56 * sizeof(mga_dbuf_t) && sizeof(((pipe_ctx_t*)0)->hall) == 21 * sizeof(mga_hbuf_t), "pipe_ctx_t: buffer lists out of sync");
 
-#define MGA_MAX_PIPE 4
+#define MGA_MAX_PIPE 8
 
 static double g_job_t0;
 static int g_dbg_pipe = -1;

@@ -288,6 +288,12 @@ static inline int32_t score_simple(const mg128_t *ai, const mg128_t *aj, float p
 	return sc;
 }
 
+/* MGA_RQ_TIE_STATS=1 (measurement aid, round 5): how often is the range-minimum query's answer TIED -- i.e. decided by the AVL tree's shape, which no order-independent
+ * formulation (a device arg-min over the window) can reproduce?  Brute force over the window per query; counters per process. */
+static int g_tie_on = -1;
+static int64_t g_tie[8]; /* runs, runs with a tie, anchors, anchors of runs with a tie, queries with an answer, tied queries, sum of window sizes, longest run */
+void mga_rq_tie_stats(int64_t *out, int reset) { int k; for (k = 0; k < 8; ++k) { out[k] = __atomic_load_n(&g_tie[k], __ATOMIC_RELAXED); if (reset) __atomic_store_n(&g_tie[k], 0, __ATOMIC_RELAXED); } }
+
 /* Forward pass of mg_lchain_rmq (lchain.c:275-353) over anchors [beg,end) of the x-sorted array a[]: fills f, p, v and the skip
  * marks t (zeroed by the caller) with ABSOLUTE indices.  beg must be 0 or the first anchor of a (segment, strand) group: there
  * the sequential run has just erased every node from both trees (the `a[i].x>>32 != a[st].x>>32` clause of lchain.c:294,304), st,
@@ -299,6 +305,8 @@ void mga_lchain_rmq_fwd(int max_dist, int max_dist_inner, int bw, int max_chn_sk
 	int32_t root = -1;
 	int64_t i, i0, st = beg, st_inner = beg;
 	rq_pool_t T = {0, 0, 0, -1};
+	int64_t ts_run_beg = beg, ts_run_ties = 0, ts_q = 0, ts_tq = 0, ts_win = 0;
+	if (g_tie_on < 0) g_tie_on = getenv("MGA_RQ_TIE_STATS") && atoi(getenv("MGA_RQ_TIE_STATS")) > 0;
 	if (max_dist < bw) max_dist = bw;
 	if (max_dist_inner <= 0 || max_dist_inner >= max_dist) max_dist_inner = 0;
 	/* ONE tree (round 4).  The reference keeps a second tree for the inner window (lchain.c:286-291,303-312) and only ever asks it ORDER questions -- the largest key below
@@ -332,6 +340,28 @@ void mga_lchain_rmq_fwd(int max_dist, int max_dist_inner, int bw, int max_chn_sk
 			while (st_inner < i && (a[i].x >> 32 != a[st_inner].x >> 32 || a[i].x > a[st_inner].x + max_dist_inner || (st_inner < i0 ? i0 - st_inner : 0) > cap_rmq_size)) ++st_inner;
 		/* RMQ (lchain.c:313-352) */
 		q = rq_rmq(&T, root, (int32_t)a[i].y - max_dist, INT32_MAX, (int32_t)a[i].y - 1, 0);
+		if (g_tie_on) {
+			if (i > beg && a[i].x >> 32 != a[i - 1].x >> 32) { /* a (segment, strand) run ends: account for it */
+				__atomic_fetch_add(&g_tie[0], 1, __ATOMIC_RELAXED); __atomic_fetch_add(&g_tie[2], i - ts_run_beg, __ATOMIC_RELAXED);
+				if (ts_run_ties) { __atomic_fetch_add(&g_tie[1], 1, __ATOMIC_RELAXED); __atomic_fetch_add(&g_tie[3], i - ts_run_beg, __ATOMIC_RELAXED); }
+				{ int64_t mx = __atomic_load_n(&g_tie[7], __ATOMIC_RELAXED); while (i - ts_run_beg > mx && !__atomic_compare_exchange_n(&g_tie[7], &mx, i - ts_run_beg, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} }
+				ts_run_beg = i, ts_run_ties = 0;
+			}
+			if (q >= 0) {
+				int64_t j, n_eq = 0, n_in = 0;
+				const double pq = ND(&T, q).pri;
+				for (j = st; j < i0; ++j) {
+					const int32_t yj = (int32_t)a[j].y;
+					/* closed key range [(y - max_dist, INT32_MAX), (y - 1, 0)] over keys (y_j, j): y - max_dist < y_j < y - 1, and y_j == y - 1 only for j == 0 */
+					if (yj > (int32_t)a[i].y - max_dist && (yj < (int32_t)a[i].y - 1 || (yj == (int32_t)a[i].y - 1 && j <= 0))) {
+						++n_in;
+						if (-(f[j] + 0.5 * pen_gap * ((int32_t)a[j].x + (int32_t)a[j].y)) == pq) ++n_eq;
+					}
+				}
+				++ts_q, ts_win += n_in;
+				if (n_eq > 1) ++ts_tq, ++ts_run_ties;
+			}
+		}
 		if (q >= 0) {
 			int32_t sc, exact, width, n_skip = 0;
 			int64_t j = ND(&T, q).i;
@@ -365,6 +395,11 @@ void mga_lchain_rmq_fwd(int max_dist, int max_dist_inner, int bw, int max_chn_sk
 		}
 		f[i] = max_f, p[i] = max_j;
 		v[i] = max_j >= 0 && v[max_j] > max_f ? v[max_j] : max_f;
+	}
+	if (g_tie_on && end > beg) {
+		__atomic_fetch_add(&g_tie[0], 1, __ATOMIC_RELAXED); __atomic_fetch_add(&g_tie[2], end - ts_run_beg, __ATOMIC_RELAXED);
+		if (ts_run_ties) { __atomic_fetch_add(&g_tie[1], 1, __ATOMIC_RELAXED); __atomic_fetch_add(&g_tie[3], end - ts_run_beg, __ATOMIC_RELAXED); }
+		__atomic_fetch_add(&g_tie[4], ts_q, __ATOMIC_RELAXED); __atomic_fetch_add(&g_tie[5], ts_tq, __ATOMIC_RELAXED); __atomic_fetch_add(&g_tie[6], ts_win, __ATOMIC_RELAXED);
 	}
 	free(T.a);
 }
