@@ -320,6 +320,18 @@ int mga_graph_image_save(const gfa_t *g, const char *path);
  * size or -1; unpack: the objects again, each malloc-owned like mg_map()'s (release every one with mg_gchain_free(), the array with mga_free()); NULL on a corrupt buffer. ---- */
 int64_t mga_gchains_pack(int n, mg_gchains_t *const *gcs, void **out);
 mg_gchains_t **mga_gchains_unpack(const void *buf, int64_t bytes, int *n);
+/* One rank's part of ggen_map (ggen.c:39-71: the kt_for over a query file's sequences at ggen.c:64) when the file's contigs are sharded over `world` ranks, and the
+ * destination rank's other half.  mga_ggen_map_shard(): the contiguous shard of the n_seq sequences that belongs to `rank` -- cut by BASES, not by count (a file is a few
+ * chromosome-scale contigs of very different lengths); every rank computes the same cut from qlens[] alone: mga_ggen_shard_range() -- is mapped through mg_map_batch() and
+ * comes back packed (*packed, *packed_bytes: mga_gchains_pack's buffer, release with mga_free()); returns 0, or -1 with mga_last_error().  The buffers of all ranks travel to the
+ * rank that runs what consumes a file's mappings (any transport: minigraph_amd.dist.gather_bytes = RCCL point to point on the GPU box, MPI_Gatherv in an MPI build);
+ * mga_ggen_assemble() there turns the `world` buffers, in rank order, into the n_seq objects of the file in INPUT order -- what ggen_map's r->gcs[] holds before
+ * mg_call_asm (asm-call.c:21) / mg_ggsimple / mg_cov_asm run -- each released with mg_gchain_free(), the array with mga_free(); NULL when a part is corrupt or the
+ * parts do not add up to n_seq. */
+void mga_ggen_shard_range(int n_seq, const int *qlens, int rank, int world, int *beg, int *end);
+int mga_ggen_map_shard(const mg_idx_t *gi, int n_seq, const int *qlens, const char **seqs, const char **qnames, const mg_mapopt_t *opt, int n_threads, int rank, int world,
+					   void **packed, int64_t *packed_bytes);
+mg_gchains_t **mga_ggen_assemble(int world, const void *const *parts, const int64_t *part_bytes, int n_seq);
 mg_idx_t *mga_index_load_image(const char *path, const mg_idxopt_t *io, int n_threads, mg_mapopt_t *mo);
 
 /* ---- stage-level entry points (host pointers in, host pointers out; device work inside) ----

@@ -154,3 +154,73 @@ oom:
 	mga_set_error("mga_gchains_unpack: out of memory");
 	return 0;
 }
+
+/* ---- ggen_map (ggen.c:39-71) over ranks: see include/minigraph_amd.h ---- */
+void mga_ggen_shard_range(int n_seq, const int *qlens, int rank, int world, int *beg, int *end)
+{
+	int64_t tot = 0, acc = 0;
+	int i, b = -1, e = -1;
+	if (world < 1) world = 1;
+	if (rank < 0) rank = 0;
+	if (rank >= world) rank = world - 1;
+	for (i = 0; i < n_seq; ++i) tot += qlens[i] > 0 ? qlens[i] : 0;
+	/* sequence i belongs to the rank r with tot * r / world <= (bases before i) < tot * (r + 1) / world: contiguous, order preserving, every sequence exactly once; empty
+	 * sequences go with their predecessor's rank (the comparison below never moves on a zero length) */
+	for (i = 0; i < n_seq; ++i) {
+		int r = tot > 0 ? (int)((__int128)acc * world / tot) : 0;
+		if (r >= world) r = world - 1;
+		if (r >= rank && b < 0) b = i;
+		if (r > rank && e < 0) e = i;
+		acc += qlens[i] > 0 ? qlens[i] : 0;
+	}
+	if (b < 0) b = n_seq;
+	if (e < 0) e = n_seq;
+	if (e < b) e = b;
+	*beg = b, *end = e;
+}
+
+int mga_ggen_map_shard(const mg_idx_t *gi, int n_seq, const int *qlens, const char **seqs, const char **qnames, const mg_mapopt_t *opt, int n_threads, int rank, int world,
+					   void **packed, int64_t *packed_bytes)
+{
+	int beg, end, i, n;
+	mg_gchains_t **gcs;
+	int64_t nb;
+	*packed = 0, *packed_bytes = 0;
+	if (world < 1 || rank < 0 || rank >= world) { mga_set_error("mga_ggen_map_shard: rank %d of %d", rank, world); return -1; }
+	mga_ggen_shard_range(n_seq, qlens, rank, world, &beg, &end);
+	n = end - beg;
+	gcs = (mg_gchains_t**)calloc(n > 0 ? (size_t)n : 1, sizeof *gcs);
+	if (gcs == 0) { mga_set_error("mga_ggen_map_shard: out of memory"); return -1; }
+	if (n > 0 && mg_map_batch(gi, n, qlens + beg, seqs + beg, qnames ? qnames + beg : 0, gcs, opt, n_threads) < 0) { /* (the message is mg_map_batch's) */
+		for (i = 0; i < n; ++i) mg_gchain_free(gcs[i]);
+		free(gcs);
+		return -1;
+	}
+	nb = mga_gchains_pack(n, gcs, packed);
+	for (i = 0; i < n; ++i) mg_gchain_free(gcs[i]);
+	free(gcs);
+	if (nb < 0) return -1;
+	*packed_bytes = nb;
+	return 0;
+}
+
+mg_gchains_t **mga_ggen_assemble(int world, const void *const *parts, const int64_t *part_bytes, int n_seq)
+{
+	mg_gchains_t **all = (mg_gchains_t**)calloc(n_seq > 0 ? (size_t)n_seq : 1, sizeof *all);
+	int r, at = 0, i;
+	if (all == 0) { mga_set_error("mga_ggen_assemble: out of memory"); return 0; }
+	for (r = 0; r < world; ++r) {
+		int k = 0;
+		mg_gchains_t **part = mga_gchains_unpack(parts[r], part_bytes[r], &k);
+		if (part == 0) goto bad; /* (mga_gchains_unpack set the message) */
+		if (at + k > n_seq) { for (i = 0; i < k; ++i) mg_gchain_free(part[i]); free(part); mga_set_error("mga_ggen_assemble: the parts hold more than %d sequences", n_seq); goto bad; }
+		for (i = 0; i < k; ++i) all[at++] = part[i];
+		free(part);
+	}
+	if (at != n_seq) { mga_set_error("mga_ggen_assemble: the parts hold %d sequences, the file has %d", at, n_seq); goto bad; }
+	return all;
+bad:
+	for (i = 0; i < at; ++i) mg_gchain_free(all[i]);
+	free(all);
+	return 0;
+}

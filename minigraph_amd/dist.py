@@ -110,6 +110,48 @@ def gather_chains(gcs, n, dst=0):
     return out
 
 
+def ggen_assemble(parts, n_seq):
+    """rank `dst`: the `world` packed buffers (rank order) -> the file's n_seq mg_gchains_t* in input order (the library's mga_ggen_assemble: what ggen_map's r->gcs[] holds
+    before mg_call_asm runs, ggen.c:39-71)"""
+    import ctypes as C
+    from . import load
+    L = load()
+    L.mga_ggen_assemble.restype = C.POINTER(C.c_void_p)
+    L.mga_ggen_assemble.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.c_int]
+    L.mga_free.argtypes = [C.c_void_p]
+    w = len(parts)
+    ptrs = (C.c_char_p * w)(*parts)
+    lens = (C.c_int64 * w)(*[len(p) for p in parts])
+    arr = L.mga_ggen_assemble(w, ptrs, lens, n_seq)
+    if not arr:
+        raise RuntimeError("mga_ggen_assemble failed: %s" % L.mga_last_error().decode())
+    out = [arr[i] for i in range(n_seq)]
+    L.mga_free(arr)
+    return out
+
+
+def ggen_map_sharded(graph, qlens, seqs, names, n_threads=8, dst=0, device="cpu"):
+    """`ggen_map` (ggen.c:39-71) over the ranks of a node: every rank maps ITS shard of the file's contigs (mga_ggen_map_shard: the cut is by bases, computed by every rank
+    from the lengths alone), the packed chains travel to `dst` size-exact and point to point (RCCL on the GPU box), `dst` gets the file's objects in input order."""
+    import ctypes as C
+    from . import load
+    L = load()
+    n = len(qlens)
+    L.mga_ggen_map_shard.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                     C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.mga_free.argtypes = [C.c_void_p]
+    buf, nb = C.c_void_p(), C.c_int64(0)
+    ql = (C.c_int * n)(*qlens)
+    sq = (C.c_char_p * n)(*seqs)
+    nm = (C.c_char_p * n)(*names)
+    if L.mga_ggen_map_shard(graph.gi, n, ql, sq, nm, C.byref(graph.mo), n_threads, dist.get_rank(), dist.get_world_size(), C.byref(buf), C.byref(nb)) < 0:
+        raise RuntimeError("mga_ggen_map_shard failed: %s" % L.mga_last_error().decode())
+    data = C.string_at(buf, nb.value)
+    L.mga_free(buf)
+    parts = gather_bytes(data, dst=dst, device=device)
+    return None if parts is None else ggen_assemble(parts, n)
+
+
 def assemble_segments(parts, seg_lens):
     """rank-order concatenation PER SEGMENT: parts[r] = the bytes rank r produced (its segments back to back), seg_lens[r][s] = how many
     of them belong to output segment s (a memory-mapped FASTA file is one segment cut by byte range; any other input has one segment per

@@ -171,20 +171,35 @@ def _call_worker(rank, world, port, q, graph, reads, occ, lco, out_path):
     from minigraph_amd.dist import gather_chains
     dist.init_process_group("gloo", rank=rank, world_size=world)
     names, seqs = hp.read_fa(reads)
-    st, en = shard_range(len(names), rank, world)
+    L = mga.load()
+    # the library's own cut of the file's contigs over the ranks (mga_ggen_shard_range: by bases) and its own assembly on rank 0 (mga_ggen_assemble) -- the two halves of
+    # mga_ggen_map_shard that do not need a GPU; the mapping in between is the product's host pipeline with the oracle standing in for the kernels
+    from minigraph_amd.dist import ggen_assemble
+    ql = (C.c_int * len(names))(*[len(x) for x in seqs])
+    b_, e_ = C.c_int(0), C.c_int(0)
+    L.mga_ggen_shard_range(len(names), ql, rank, world, C.byref(b_), C.byref(e_))
+    st, en = b_.value, e_.value
     shard = reads + ".call%d.fa" % rank
     with open(shard, "wb") as f:
         for i in range(st, en):
             f.write(b">" + names[i] + b"\n" + seqs[i] + b"\n")
-    L = mga.load()
+    L.mga_gchains_pack.restype = C.c_int64
+    L.mga_gchains_pack.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.mga_free.argtypes = [C.c_void_p]
+    L.mg_gchain_free.argtypes = [C.c_void_p]
+    buf = C.c_void_p()
     if en > st:
         r = hp.map_with_oracle_stages(graph, shard, occ, lco, cigar=True, preset="asm", return_chains=True)
-        got = gather_chains(r["gcs"], r["n"], dst=0)
-        L.mg_gchain_free.argtypes = [C.c_void_p]
+        nb = L.mga_gchains_pack(r["n"], r["gcs"], C.byref(buf))
         for i in range(r["n"]):
             L.mg_gchain_free(r["gcs"][i])
     else:
-        got = gather_chains(None, 0, dst=0)
+        nb = L.mga_gchains_pack(0, None, C.byref(buf))
+    assert nb > 0
+    data = C.string_at(buf, nb)
+    L.mga_free(buf)
+    parts = gather_bytes(data, dst=0)
+    got = ggen_assemble(parts, len(names)) if rank == 0 else None
     if rank == 0:
         assert len(got) == len(names)
         R = rb.Ref().lib

@@ -145,3 +145,26 @@ print("OK", refused, accepted, refused - r0)
     assert p.returncode == 0 and p.stdout.startswith(b"OK"), (p.returncode, p.stderr.decode()[-1500:])
     n_refused, n_accepted, n_struct = (int(x) for x in p.stdout.split()[1:4])
     assert n_refused > 160 and n_struct >= 20, (n_refused, n_accepted, n_struct)   # every prefix, and hostile counts / sizes; a flipped anchor or score word is data, not structure
+
+
+def test_contigs_are_cut_over_ranks_by_bases():
+    """mga_ggen_shard_range: what every rank of a sharded `ggen_map` (ggen.c:39-71) computes from the contig lengths alone -- contiguous, order preserving, every contig
+    exactly once, balanced in BASES"""
+    import random
+    L = mga.load()
+    rng = random.Random(3)
+    for _ in range(300):
+        n = rng.choice([0, 1, 2, 5, 24, 120])
+        ql = [rng.choice([0, 1, 1000, 50_000_000, 248_000_000]) if rng.random() < 0.3 else rng.randrange(1, 3_000_000) for _ in range(n)]
+        arr = (C.c_int * max(n, 1))(*ql)
+        for world in (1, 2, 3, 8):
+            pos, sizes = 0, []
+            for rank in range(world):
+                b, e = C.c_int(-1), C.c_int(-1)
+                L.mga_ggen_shard_range(n, arr, rank, world, C.byref(b), C.byref(e))
+                assert b.value == pos and e.value >= b.value, (ql, world, rank, b.value, e.value)
+                pos = e.value
+                sizes.append(sum(ql[b.value:e.value]))
+            assert pos == n
+            if n and sum(ql):   # no rank carries more than its share plus one contig
+                assert max(sizes) <= sum(ql) / world + max(ql) + 1

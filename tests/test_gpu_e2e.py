@@ -934,33 +934,26 @@ def test_asm_200Mbp_four_contigs_gaf_and_sharded_call_vs_reference_binary():
     names, seqs = hp.read_fa(reads)
     L = mga.load()
     G = mga.Graph(graph, preset="asm", cigar=True, n_threads=16)
-    L.mg_map_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(mga.mapopt_t), C.c_int]
-    L.mga_gchains_pack.restype = C.c_int64
-    L.mga_gchains_pack.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    # round 5: through the library's own entries -- mga_ggen_map_shard (a rank's part of ggen_map, ggen.c:64: its shard by BASES, mapped and packed) for each of three
+    # "ranks", mga_ggen_assemble on "rank 0" (what dist.ggen_map_sharded does with an RCCL gather in between)
+    from minigraph_amd.dist import ggen_assemble
+    L.mga_ggen_map_shard.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                     C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     L.mga_gchains_unpack.restype = C.POINTER(C.c_void_p)
     L.mga_gchains_unpack.argtypes = [C.c_char_p, C.c_int64, C.POINTER(C.c_int)]
     L.mg_gchain_free.argtypes = [C.c_void_p]
     L.mga_free.argtypes = [C.c_void_p]
-    gathered = []
-    for st, en in ((0, 2), (2, 4)):   # two contiguous shards
-        n = en - st
-        gcs = (C.c_void_p * n)()
-        qlens = (C.c_int * n)(*[len(s) for s in seqs[st:en]])
-        sp, npp = (C.c_char_p * n)(*seqs[st:en]), (C.c_char_p * n)(*names[st:en])
-        assert L.mg_map_batch(G.gi, n, qlens, sp, npp, gcs, C.byref(G.mo), 16) == 0, L.mga_last_error()
-        buf = C.c_void_p()
-        nb = L.mga_gchains_pack(n, gcs, C.byref(buf))
-        assert nb > 0
-        data = C.string_at(buf, nb)
+    n = len(names)
+    qlens, sp, npp = (C.c_int * n)(*[len(x) for x in seqs]), (C.c_char_p * n)(*seqs), (C.c_char_p * n)(*names)
+    parts, world = [], 3
+    for rank in range(world):
+        buf, nb = C.c_void_p(), C.c_int64(0)
+        assert L.mga_ggen_map_shard(G.gi, n, qlens, sp, npp, C.byref(G.mo), 16, rank, world, C.byref(buf), C.byref(nb)) == 0, L.mga_last_error()
+        parts.append(C.string_at(buf, nb.value))
         L.mga_free(buf)
-        for i in range(n):
-            L.mg_gchain_free(gcs[i])
-        k = C.c_int(0)
-        arr = L.mga_gchains_unpack(data, len(data), C.byref(k))
-        assert arr and k.value == n
-        gathered += [arr[i] for i in range(n)]
-        L.mga_free(arr)
-        assert not L.mga_gchains_unpack(data[:len(data) // 2], len(data) // 2, C.byref(k))   # a truncated buffer is refused, not read past
+    k = C.c_int(0)
+    assert not L.mga_gchains_unpack(parts[0][:len(parts[0]) // 2], len(parts[0]) // 2, C.byref(k))   # a truncated buffer is refused, not read past
+    gathered = ggen_assemble(parts, n)
     G.close()
     R = rb.Ref().lib
 
