@@ -419,7 +419,7 @@ static int wfs_sweep(mga_sctx_t *sc, const wfs_ladder_t *LD, int arr_pct, int n_
 			MGA_HIP_CHECK(hipEventRecord((hipEvent_t)sc->ev_done[1], st));
 			MGA_HIP_CHECK(hipStreamWaitEvent(tbs, (hipEvent_t)sc->ev_done[1], 0));
 		}
-		if (mga_dev_wfa_traceback(sc, tbs, rc + t, cap[t], L + base[t], d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, ctl + O_ERR) < 0) return -1;
+		if (mga_dev_wfa_traceback(sc, tbs, rc + t, cap[t], L + base[t], d_prob, d_tseq, d_qseq, d_res, d_pool, pool_cap, d_pool_used, ctl + O_ERR, LD->r[t].idx) < 0) return -1;
 		if (tb_side) MGA_HIP_CHECK(hipEventRecord((hipEvent_t)sc->ev_done[2 + (n_win & 1)], tbs));
 		++n_win;
 	}

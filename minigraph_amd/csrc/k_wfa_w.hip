@@ -388,7 +388,7 @@ run_done:
 }
 
 __global__ void __launch_bounds__(256) k_wfa_tb(const int *__restrict__ n_p, int cap, const int32_t *__restrict__ list, const mga_wfa_prob_t *__restrict__ prob, const char *__restrict__ tseq,
-												const char *__restrict__ qseq, mga_wfa_res_t *__restrict__ res, uint32_t *__restrict__ pool, long long pool_cap, unsigned long long *pool_used, int *__restrict__ err)
+												const char *__restrict__ qseq, mga_wfa_res_t *__restrict__ res, uint32_t *__restrict__ pool, long long pool_cap, unsigned long long *pool_used, int *__restrict__ err, int W_rung)
 {
 	const int n = min(*n_p, cap); // the problems of ONE rung's work list (own + arrivals), right after its forward pass: the regions are reused by the next rung
 	const int it = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
@@ -396,7 +396,9 @@ __global__ void __launch_bounds__(256) k_wfa_tb(const int *__restrict__ n_p, int
 	mga_wfa_res_t r;
 	r.status = MGA_WFA_OK;
 	if (it < n) r = res[i];
-	const bool mine = it < n && r.status == MGA_WFA_TB;
+	// (round 5: the NEXT rung's forward pass may run next to this walk and a problem that gave up here is on both rungs' lists -- its result then belongs to the other
+	// rung's window, says so in `pad` (written with `status` by one 16-byte store), and is left to that rung's walk)
+	const bool mine = it < n && r.status == MGA_WFA_TB && (r.pad >> 8) == W_rung;
 	if (!__ballot(mine)) return;
 	mga_wfa_prob_t pb;
 	pb.tl = pb.ql = 0, pb.t_off = pb.q_off = 0;
@@ -486,12 +488,13 @@ extern "C" int mga_dev_wfa_win(mga_sctx_t *sc, const int *d_n, int n, const int3
 }
 
 extern "C" int mga_dev_wfa_traceback(mga_sctx_t *sc, void *stream, const int *d_n, int cap, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq, mga_wfa_res_t *d_res,
-									 uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int *d_err)
+									 uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int *d_err, int wt)
 {
 	if (cap <= 0) return 0;
+	if (wt < 0 || wt >= MGA_WFW_N) { mga_set_error("wfa_traceback: bad tier %d", wt); return -1; }
 	hipStream_t st = (hipStream_t)(stream ? stream : sc->stream);
 	mga_prof_begin(st, MGA_K_WFATB);
-	hipLaunchKernelGGL(k_wfa_tb, dim3((cap + 255) / 256), dim3(256), 0, st, d_n, cap, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap, d_pool_used, d_err);
+	hipLaunchKernelGGL(k_wfa_tb, dim3((cap + 255) / 256), dim3(256), 0, st, d_n, cap, d_list, d_prob, d_tseq, d_qseq, d_res, d_pool, (long long)pool_cap, d_pool_used, d_err, g_wtier[wt].W);
 	mga_prof_end(st, MGA_K_WFATB);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;

@@ -179,7 +179,7 @@ int64_t mga_dev_wfa_win_tb_stride(int wt);
 int mga_dev_wfa_win(mga_sctx_t *sc, const int *d_n, int cap, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
 					mga_wfa_res_t *d_res, char *d_tb, int wt, int slot, mga_wfa_retry_t rt);
 int mga_dev_wfa_traceback(mga_sctx_t *sc, void *stream /* NULL: the context's */, const int *d_n, int cap, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq, mga_wfa_res_t *d_res,
-						  uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int *d_err);
+						  uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int *d_err, int wt /* the rung's window tier: only results of THAT window are walked */);
 int32_t mga_wfw_window(int32_t W, int32_t tl, int32_t ql, int32_t *lo);
 /* tier 0..8: register tiers (one wave, then 2-16 waves per problem), then the HBM-resident tiers */
 int mga_wfa_first_tier(int32_t tl, int32_t ql); /* cheapest tier likely to fit, from the sequence lengths */
