@@ -16,6 +16,7 @@ mg128_t *mga_lchain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_sk
 void mga_lchain_rmq_fwd(int max_dist, int max_dist_inner, int bw, int max_chn_skip, int cap_rmq_size, float pen_gap, float pen_skip,
 						int64_t beg, int64_t end, const mg128_t *a, int32_t *f, int64_t *p, int32_t *v, int32_t *t);
 mg128_t *mga_lchain_rmq_finish(int bw, int min_cnt, int min_sc, int64_t n, const mg128_t *a, int32_t *f, int64_t *p, int32_t *v, int32_t *t, int *n_u_, uint64_t **u_);
+mg128_t *mga_lchain_rmq_finish2(int bw, int min_cnt, int min_sc, int64_t n, const mg128_t *a, int32_t *f, int64_t *p, int32_t *v, int32_t *t, int *n_u_, uint64_t **u_, int keep_arrays); /* keep_arrays: f, p, v, t belong to the caller (pinned staging of the device pass) */
 
 /* forward pass of mg_lchain_dp (lchain.c:168-207) over the x-sorted anchors of ONE long read on a host thread (single segment, not cDNA); t zeroed by the caller */
 void mga_lchain_dp_fwd(int max_dist_x, int max_dist_y, int bw, int max_skip, int max_iter, float pen_gap, float pen_skip,

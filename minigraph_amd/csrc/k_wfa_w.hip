@@ -125,8 +125,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 			if (g_done || st == WFW_BAIL) { // (a group gives up as a whole: s and bnd are the same in all of its lanes; one lane reaching the end cell in the same step wins)
 				if (g_done) { // the rest of the last traceback row (bytes of steps t & ~3 .. t - 1)
 					if (t & 3) {
+						const int32_t rr = wfw_reach(s + 1), d0 = lo + gl;
 #pragma unroll
-						for (int j = 0; j < J; ++j) tbp[64 * j] = acc[j] << (8 * (4 - (t & 3)));
+						for (int j = 0; j < J; ++j) { const int32_t d = d0 + 64 * j; if ((d < 0 ? -d : d) <= rr) tbp[64 * j] = acc[j] << (8 * (4 - (t & 3))); }
 					}
 					if (st == WFW_DONE) {
 						mga_wfa_res_t r;
@@ -314,8 +315,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 		}
 		if ((t & 3) == 3) { // a row of traceback dwords is full: one coalesced store, next row
 			if (st != WFW_IDLE) { // (lanes of a group that gives up in the very step another lane of it reaches the end cell must store too)
+				// round 5: only the diagonals a path of the row's newest score (s + 1) can have reached are stored -- the cells beyond hold NEG_INF, lie on no path, and the
+				// walk never reads them (it fails loudly if it ever did: uninitialised bytes cannot pass for a path for long).  [measured, round 4] the rungs wrote 48 GB of
+				// traceback per 125 000 reads, a byte per cell of the whole window; the reachable part is about half of it in the rungs of 64 diagonals and more.
+				const int32_t rr = wfw_reach(s + 1), d0 = lo + gl;
 #pragma unroll
-				for (int j = 0; j < J; ++j) tbp[64 * j] = acc[j];
+				for (int j = 0; j < J; ++j) { const int32_t d = d0 + 64 * j; if ((d < 0 ? -d : d) <= rr) tbp[64 * j] = acc[j]; }
 			}
 			tbp += W;
 		}

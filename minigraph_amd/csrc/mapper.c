@@ -112,6 +112,11 @@ struct mga_batch_s {
 	const mg128_t *a;
 	int a_is_raw;
 	struct rq_read_s *rq;   /* a_is_raw: per-read state of the phased RMQ chaining (see rq_* below) */
+	/* round 5: the forward passes of the RMQ chainer on the device (k_rmq.hip), one read at a time on the chunk's stream; rq_harr = pinned arrays p | f | v | t of ALL the
+	 * chunk's anchors (the device writes f, p, v straight into them), rq_tot = their length in anchors */
+	int (*rq_dev_fwd)(void *ctx, const mg128_t *a, int64_t n, int n_cut, const int64_t *cut, int n_order, const int32_t *order, int bw, int32_t *f, int64_t *p, int32_t *v, int32_t *status);
+	void *rq_dev_ctx; char *rq_harr; int64_t rq_tot;
+	pthread_mutex_t rq_dev_mtx;
 	int32_t *seg_len;       /* segment lengths as a flat array (the graph view of gc_core.h on the host) */
 	/* graph chains made on the device (k_gchain.hip): per-read headers + record pools; status != 0 marks the reads the host still chains */
 	const mga_gc_hdr_t *gc_hdr; const char *gc_pool; const mg_llchain_t *gc_lc; const mg128_t *gc_a; size_t gc_rec;
@@ -152,6 +157,12 @@ void mga_batch_set_device_chains(mga_batch_t *b, const mga_gc_hdr_t *hdr, const 
 
 void mga_batch_set_device_plan(mga_batch_t *b, const int64_t *chain_off, int32_t *rev, int64_t n_chain) { b->dp_chain_off = chain_off, b->dp_rev = rev, b->dp_n_chain = n_chain; }
 
+void mga_batch_set_rq_device(mga_batch_t *b, int (*fwd)(void*, const mg128_t*, int64_t, int, const int64_t*, int, const int32_t*, int, int32_t*, int64_t*, int32_t*, int32_t*), void *ctx, char *harr, int64_t tot)
+{
+	b->rq_dev_fwd = fwd, b->rq_dev_ctx = ctx, b->rq_harr = harr, b->rq_tot = tot;
+	pthread_mutex_init(&b->rq_dev_mtx, 0);
+}
+
 void mga_batch_lchain_par(const mg_idx_t *gi, const mg_mapopt_t *opt, int qlen_max, mga_lchain_par_t *par) /* map-algo.c:377-403 for long reads */
 {
 	float tmp = expf(-opt->div * gi->k);
@@ -182,23 +193,30 @@ typedef struct rq_read_s {
 typedef struct { int32_t read, k; } rq_task_t;
 
 #define RQ_RUN_MIN 16384 /* anchors per work item, at least */
+#define RQ_RUN_MIN_DEV 1024 /* ... of the device pass: a wavefront per run, thousands of them */
+#define RQ_RUN_MAX_DEV (1 << 20) /* a run beyond this is the host's: one wavefront walks a run anchor by anchor */
 
-static void rq_cut(rq_read_t *r)
+static void rq_cut(rq_read_t *r, int64_t run_min)
 {
 	int64_t i, last = 0;
 	int32_t m = 16;
 	r->cut = MGA_MALLOC(int64_t, m + 1), r->n_cut = 0;
 	r->cut[0] = 0;
 	for (i = 1; i < r->n; ++i)
-		if (r->a[i].x >> 32 != r->a[i - 1].x >> 32 && i - last >= RQ_RUN_MIN) {
+		if (r->a[i].x >> 32 != r->a[i - 1].x >> 32 && i - last >= run_min) {
 			if (r->n_cut + 1 == m) { m <<= 1; r->cut = MGA_REALLOC(int64_t, r->cut, m + 1); }
 			r->cut[++r->n_cut] = i, last = i;
 		}
 	r->cut[++r->n_cut] = r->n;
 }
 
-static void rq_arrays(rq_read_t *r)
+static void rq_arrays(mga_batch_t *b, rq_read_t *r, int64_t i)
 {
+	if (b->rq_harr) { /* the device pass: slices of the chunk's pinned arrays p | f | v | t (pass 2 has fewer anchors than pass 1: the same slices) */
+		const int64_t T = (b->rq_tot + 1) & ~1LL, o = b->a_off[i] - b->a_off[0];
+		r->p = (int64_t*)b->rq_harr + o, r->f = (int32_t*)(b->rq_harr + 8 * T) + o, r->v = (int32_t*)(b->rq_harr + 12 * T) + o, r->t = (int32_t*)(b->rq_harr + 16 * T) + o;
+		return;
+	}
 	r->p = MGA_MALLOC(int64_t, r->n); r->f = MGA_MALLOC(int32_t, r->n); r->v = MGA_MALLOC(int32_t, r->n); r->t = MGA_CALLOC(int32_t, r->n);
 }
 
@@ -214,8 +232,8 @@ static void rq_prepare_worker(void *data, int64_t i, int tid)
 	r->a = (mg128_t*)(b->a + b->a_off[i]); /* every read owns its slice of the staging buffer */
 	if ((b->a_is_raw == 2 || b->a_is_raw == 3) && r->n > 1) mga_ksort_128x(r->n, r->a); /* hit order from the device: radix_sort_128x (map-algo.c:189) */
 	if (b->a_is_raw == 3 || b->a_is_raw == 5) { /* (5: already sorted -- the CPU tests' oracle anchors) */ r->cut = MGA_MALLOC(int64_t, 2); r->cut[0] = 0, r->cut[1] = r->n, r->n_cut = 1; } /* an ultra-long -x lr read: its first pass is the DP, one work item */
-	else rq_cut(r);
-	rq_arrays(r);
+	else rq_cut(r, b->rq_dev_fwd ? RQ_RUN_MIN_DEV : RQ_RUN_MIN);
+	rq_arrays(b, r, i);
 	CPU_ADD(C_LCCOPY, tc);
 }
 
@@ -238,6 +256,51 @@ static void rq_fwd_worker(void *data, int64_t j, int tid)
 	CPU_ADD(r->pass2 ? C_LCRESCUE : C_LCCOPY, tc);
 }
 
+/* runs of the RMQ chainer's forward pass: [0] taken by the device, [1] redone on the host because two candidates tied on the priority (the AVL shape decides: k_rmq.hip),
+ * [2] ... because the inner window held more candidates than the kernel sorts, [3] kept on the host for their length, [4] device call failed */
+static int64_t g_rq_dev_stat[8];
+void mga_rq_dev_stats(int64_t *out, int reset) { int k; for (k = 0; k < 8; ++k) { out[k] = __atomic_load_n(&g_rq_dev_stat[k], __ATOMIC_RELAXED); if (reset) __atomic_store_n(&g_rq_dev_stat[k], 0, __ATOMIC_RELAXED); } }
+
+typedef struct { int64_t len; int32_t k; } rq_ord_t;
+static int rq_ord_cmp(const void *x, const void *y) { const rq_ord_t *p = (const rq_ord_t*)x, *q = (const rq_ord_t*)y; return p->len > q->len ? -1 : p->len < q->len ? 1 : (p->k > q->k) - (p->k < q->k); }
+
+static int rq_use_dev(const mga_batch_t *b, const rq_read_t *r) { return b->rq_dev_fwd != 0 && !((b->a_is_raw == 3 || b->a_is_raw == 5) && !r->pass2); }
+
+/* the forward pass of ALL runs of one read and pass: on the device, a wavefront per run (k_rmq.hip); what the device gives back -- a run with tied priorities, an
+ * inner window beyond the kernel's sort -- and what is too long for one wavefront goes through the host's exact tree (rmq.c), run by run, on this thread */
+static void rq_dev_worker(mga_batch_t *b, int read)
+{
+	rq_read_t *r = &b->rq[read];
+	const mg_mapopt_t *opt = &b->opt;
+	rq_ord_t *ord = MGA_MALLOC(rq_ord_t, r->n_cut);
+	int32_t *order = MGA_MALLOC(int32_t, r->n_cut), *status = MGA_MALLOC(int32_t, r->n_cut);
+	int32_t k, n_dev = 0;
+	int rc = 0;
+	int64_t tc = cpu_now(), cnt[5] = { 0, 0, 0, 0, 0 };
+	for (k = 0; k < r->n_cut; ++k) {
+		status[k] = 3;
+		if (r->cut[k + 1] - r->cut[k] <= RQ_RUN_MAX_DEV) ord[n_dev].len = r->cut[k + 1] - r->cut[k], ord[n_dev++].k = k;
+	}
+	qsort(ord, (size_t)n_dev, sizeof *ord, rq_ord_cmp); /* longest first: a launch lasts as long as its longest run */
+	for (k = 0; k < n_dev; ++k) order[k] = ord[k].k, status[ord[k].k] = 4;
+	if (n_dev > 0) {
+		pthread_mutex_lock(&b->rq_dev_mtx);
+		rc = b->rq_dev_fwd(b->rq_dev_ctx, r->a, r->n, r->n_cut, r->cut, n_dev, order, r->pass2 ? opt->bw_long : opt->bw, r->f, r->p, r->v, status);
+		pthread_mutex_unlock(&b->rq_dev_mtx);
+		if (rc < 0) for (k = 0; k < n_dev; ++k) status[order[k]] = 4; /* (the message stays in mga_last_error(); the host takes the runs) */
+	}
+	for (k = 0; k < r->n_cut; ++k) {
+		if (status[k] == 0) { ++cnt[0]; continue; }
+		++cnt[status[k] <= 4 ? status[k] : 4];
+		memset(r->t + r->cut[k], 0, (size_t)(r->cut[k + 1] - r->cut[k]) * 4); /* the marks of a run stay inside it */
+		mga_lchain_rmq_fwd(opt->max_gap, opt->max_gap_pre, r->pass2 ? opt->bw_long : opt->bw, opt->max_lc_skip, opt->rmq_size_cap, b->pen_gap, b->pen_skip,
+						   r->cut[k], r->cut[k + 1], r->a, r->f, r->p, r->v, r->t);
+	}
+	for (k = 0; k < 5; ++k) if (cnt[k]) __atomic_fetch_add(&g_rq_dev_stat[k], cnt[k], __ATOMIC_RELAXED);
+	free(ord); free(order); free(status);
+	CPU_ADD(r->pass2 ? C_LCRESCUE : C_LCCOPY, tc);
+}
+
 static void rq_finish_worker(void *data, int64_t i, int tid)
 {
 	mga_batch_t *b = (mga_batch_t*)data;
@@ -247,7 +310,7 @@ static void rq_finish_worker(void *data, int64_t i, int tid)
 	(void)tid;
 	if (r->n <= 0 || r->f == 0) return;
 	if (!r->pass2) {
-		r->out = mga_lchain_rmq_finish(opt->bw, opt->min_lc_cnt, opt->min_lc_score, r->n, r->a, r->f, r->p, r->v, r->t, &r->n_lc, &r->u);
+		r->out = mga_lchain_rmq_finish2(opt->bw, opt->min_lc_cnt, opt->min_lc_score, r->n, r->a, r->f, r->p, r->v, r->t, &r->n_lc, &r->u, b->rq_harr != 0);
 		r->f = r->v = r->t = 0, r->p = 0; free(r->cut); r->cut = 0;
 		if (opt->bw_long > opt->bw && (opt->flag & (MG_M_SPLICE | MG_M_SR)) == 0 && r->n_lc > 1) { /* map-algo.c:407-417 */
 			const int32_t qlen = b->qlens[i], st = (int32_t)r->out[0].y, en = (int32_t)r->out[(int32_t)r->u[0] - 1].y;
@@ -258,12 +321,12 @@ static void rq_finish_worker(void *data, int64_t i, int tid)
 				free(r->u); r->u = 0;
 				mga_ksort_128x(n_a, r->out);
 				r->a = r->out, r->n = n_a, r->pass2 = 1;
-				rq_cut(r); rq_arrays(r);
+				rq_cut(r, b->rq_dev_fwd ? RQ_RUN_MIN_DEV : RQ_RUN_MIN); rq_arrays(b, r, i);
 			}
 		}
 		CPU_ADD(C_LCCOPY, tc);
 	} else {
-		mg128_t *a2 = mga_lchain_rmq_finish(opt->bw_long, opt->min_lc_cnt, opt->min_lc_score, r->n, r->a, r->f, r->p, r->v, r->t, &r->n_lc, &r->u);
+		mg128_t *a2 = mga_lchain_rmq_finish2(opt->bw_long, opt->min_lc_cnt, opt->min_lc_score, r->n, r->a, r->f, r->p, r->v, r->t, &r->n_lc, &r->u, b->rq_harr != 0);
 		r->f = r->v = r->t = 0, r->p = 0; free(r->cut); r->cut = 0;
 		free(r->out); r->out = a2;
 		CPU_ADD(C_LCRESCUE, tc);
@@ -306,6 +369,11 @@ static void rq_push_fwd(rq_sched_t *S, int read) /* (locked) */
 	const rq_read_t *r = &S->b->rq[read];
 	int k;
 	if (S->lo_tail + r->n_cut > S->lo_cap) { S->lo_cap = (S->lo_tail + r->n_cut) * 2; S->lo = MGA_REALLOC(rq_task_t, S->lo, S->lo_cap); }
+	if (rq_use_dev(S->b, r)) { /* ONE task: all runs of the read through the device (k = -1) */
+		S->lo[S->lo_tail].read = read, S->lo[S->lo_tail++].k = -1;
+		S->pending[read] = 1;
+		return;
+	}
 	for (k = 0; k < r->n_cut; ++k) S->lo[S->lo_tail].read = read, S->lo[S->lo_tail++].k = k;
 	S->pending[read] = r->n_cut;
 }
@@ -332,7 +400,7 @@ static void rq_sched_worker(void *data, int64_t j_, int tid)
 			void *arg[2];
 			pthread_mutex_unlock(&S->mtx);
 			arg[0] = b, arg[1] = (void*)&t;
-			rq_fwd_worker(arg, 0, tid);
+			if (t.k < 0) rq_dev_worker(b, t.read); else rq_fwd_worker(arg, 0, tid);
 			pthread_mutex_lock(&S->mtx);
 			if (--S->pending[t.read] == 0) { S->hi[S->n_hi++] = ~t.read; pthread_cond_broadcast(&S->cv); }
 		} else break; /* n_open == 0 */
@@ -348,6 +416,7 @@ static void rq_chain_all(mga_batch_t *b)
 	b->rq = MGA_CALLOC(rq_read_t, b->n > 0 ? b->n : 1);
 	t[0] = mga_wtime();
 	if (getenv("MGA_RQ_BARRIERS") && atoi(getenv("MGA_RQ_BARRIERS")) > 0) {
+		b->rq_dev_fwd = 0; /* (the A/B form with barriers between the phases is the host's) */
 		mga_parallel_for(b->n_threads, b->n, rq_prepare_worker, b);
 		t[1] = mga_wtime();
 		rq_run_fwd(b, 0);
@@ -715,15 +784,16 @@ typedef struct { /* one pipeline context: HIP stream + grow-only device and pinn
 			mga_dbuf_t hash, gchdr, gcpool, lcpool, apool, gcctl, gcretry; /* graph chaining on the device (k_gchain.hip) */
 			mga_dbuf_t plcnt, ploff, pltot, plsrc, plrev; /* gap list on the device (k_plan.hip) */
 			mga_dbuf_t lcord; /* k_lchain's launch order: reads by anchor count, most first */
+			mga_dbuf_t rq_a, rq_f, rq_p, rq_v, rq_t, rq_pri, rq_ys, rq_cut, rq_ord, rq_stat, rq_cnt; /* forward pass of the RMQ chainer on the device (k_rmq.hip), one read at a time */
 		};
-		mga_dbuf_t dall[56];
+		mga_dbuf_t dall[67];
 	};
 	union {
-		struct { mga_hbuf_t h_b, h_u, h_mini, h_tseq, h_prob, h_pool, h_seq, h_ncig, h_cigoff, h_item, h_chain, h_vert, h_txtres, h_txtpool, h_gchdr, h_gcpool, h_lcpool, h_apool, h_plrev, h_ploff, h_lcord; }; /* pinned staging */
-		mga_hbuf_t hall[21];
+		struct { mga_hbuf_t h_b, h_u, h_mini, h_tseq, h_prob, h_pool, h_seq, h_ncig, h_cigoff, h_item, h_chain, h_vert, h_txtres, h_txtpool, h_gchdr, h_gcpool, h_lcpool, h_apool, h_plrev, h_ploff, h_lcord, h_rq, h_rqs; }; /* pinned staging */
+		mga_hbuf_t hall[23];
 	};
 } pipe_ctx_t;
-_Static_assert(sizeof(((pipe_ctx_t*)0)->dall) == 56 * sizeof(mga_dbuf_t) && sizeof(((pipe_ctx_t*)0)->hall) == 21 * sizeof(mga_hbuf_t), "pipe_ctx_t: buffer lists out of sync");
+_Static_assert(sizeof(((pipe_ctx_t*)0)->dall) == 67 * sizeof(mga_dbuf_t) && sizeof(((pipe_ctx_t*)0)->hall) == 23 * sizeof(mga_hbuf_t), "pipe_ctx_t: buffer lists out of sync");
 
 #define MGA_MAX_PIPE 8
 
@@ -745,6 +815,35 @@ static int env_int(const char *name, int dflt) { const char *s = getenv(name); r
 static int lr_long_bases(void) { static int v = -1; if (v < 0) v = env_int("MGA_LONG_READ", 262144); return v; }
 
 #define CK(x) do { if ((x) < 0) { rc = -1; goto done; } } while (0)
+
+/* mga_batch_t's device hook: the forward pass of the RMQ chainer over the runs `order[0 .. n_order)` of one read's x-sorted anchors (k_rmq.hip), on this chunk's stream.
+ * Called by ONE host thread at a time (mga_batch_t::rq_dev_mtx) while the chunk's pipeline thread waits inside mga_batch_chain(); f, p, v arrive in the caller's arrays
+ * (pinned: the chunk's h_rq), status[run] says which runs the host has to redo. */
+typedef struct { pipe_ctx_t *P; const mg_mapopt_t *opt; float pen_gap, pen_skip; } rq_dev_ctx_t;
+static int rq_dev_fwd_hook(void *ctx_, const mg128_t *a, int64_t n, int n_cut, const int64_t *cut, int n_order, const int32_t *order, int bw, int32_t *f, int64_t *p, int32_t *v, int32_t *status)
+{
+	rq_dev_ctx_t *C = (rq_dev_ctx_t*)ctx_;
+	pipe_ctx_t *P = C->P;
+	mga_sctx_t *sc = P->sc;
+	const mg_mapopt_t *opt = C->opt;
+	char *hs;
+	if (mga_dev_bind_thread() < 0) return -1;
+	if (mga_dbuf_reserve(&P->rq_a, (size_t)n * 16 + 64) < 0 || mga_dbuf_reserve(&P->rq_f, (size_t)n * 4 + 64) < 0 || mga_dbuf_reserve(&P->rq_p, (size_t)n * 8 + 64) < 0 ||
+		mga_dbuf_reserve(&P->rq_v, (size_t)n * 4 + 64) < 0 || mga_dbuf_reserve(&P->rq_t, (size_t)n * 4 + 64) < 0 || mga_dbuf_reserve(&P->rq_pri, (size_t)n * 8 + 64) < 0 ||
+		mga_dbuf_reserve(&P->rq_ys, (size_t)n * 4 + 64) < 0 || mga_dbuf_reserve(&P->rq_cut, (size_t)(n_cut + 1) * 8 + 64) < 0 || mga_dbuf_reserve(&P->rq_ord, (size_t)n_cut * 4 + 64) < 0 ||
+		mga_dbuf_reserve(&P->rq_stat, (size_t)n_cut * 4 + 64) < 0 || mga_dbuf_reserve(&P->rq_cnt, 64) < 0 || mga_hbuf_reserve(&P->h_rqs, (size_t)(n_cut + 1) * 16 + 64) < 0) return -1;
+	hs = (char*)P->h_rqs.p; /* cut | order | status through pinned staging: copies from pageable memory wait inside the runtime */
+	memcpy(hs, cut, (size_t)(n_cut + 1) * 8); memcpy(hs + (size_t)(n_cut + 1) * 8, order, (size_t)n_order * 4); memcpy(hs + (size_t)(n_cut + 1) * 12, status, (size_t)n_cut * 4);
+	if (mga_h2d_s(sc, P->rq_a.p, a, (size_t)n * 16) < 0 || mga_h2d_s(sc, P->rq_cut.p, hs, (size_t)(n_cut + 1) * 8) < 0 || mga_h2d_s(sc, P->rq_ord.p, hs + (size_t)(n_cut + 1) * 8, (size_t)n_order * 4) < 0 ||
+		mga_h2d_s(sc, P->rq_stat.p, hs + (size_t)(n_cut + 1) * 12, (size_t)n_cut * 4) < 0) return -1;
+	if (mga_dev_rmq_fwd(sc, n, (const mg128_t*)P->rq_a.p, n_order, (const int64_t*)P->rq_cut.p, (const int32_t*)P->rq_ord.p, opt->max_gap, opt->max_gap_pre, bw, opt->max_lc_skip, opt->rmq_size_cap,
+						C->pen_gap, C->pen_skip, (int32_t*)P->rq_f.p, (int64_t*)P->rq_p.p, (int32_t*)P->rq_v.p, (int32_t*)P->rq_t.p, (double*)P->rq_pri.p, (int32_t*)P->rq_ys.p,
+						(int32_t*)P->rq_stat.p, (int*)P->rq_cnt.p) < 0) return -1;
+	if (mga_d2h_s(sc, f, P->rq_f.p, (size_t)n * 4) < 0 || mga_d2h_s(sc, p, P->rq_p.p, (size_t)n * 8) < 0 || mga_d2h_s(sc, v, P->rq_v.p, (size_t)n * 4) < 0 ||
+		mga_d2h_s(sc, hs + (size_t)(n_cut + 1) * 12, P->rq_stat.p, (size_t)n_cut * 4) < 0 || mga_ssync(sc) < 0) return -1;
+	memcpy(status, hs + (size_t)(n_cut + 1) * 12, (size_t)n_cut * 4);
+	return 0;
+}
 
 static void release_token_cb(void *a) { gpu_token_t **held = (gpu_token_t**)a; if (*held) { token_release(*held); *held = 0; } }
 
@@ -1061,6 +1160,12 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 		mga_batch_set_device_plan(b, h_ploff, (int32_t*)P->h_plrev.p, (int64_t)ptot[0]);
 	}
 	if (dev_gc) mga_batch_set_device_chains(b, h_gchdr_p, P->h_gcpool.p, (const mg_llchain_t*)P->h_lcpool.p, need_a ? (const mg128_t*)P->h_apool.p : 0);
+	rq_dev_ctx_t rq_ctx;
+	if (long_q && n_a > 0 && env_int("MGA_DEV_RMQ", 1)) { /* -x asm (and the rescue pass of ultra-long -x lr reads): the RMQ chainer's forward passes on the device (k_rmq.hip) */
+		rq_ctx.P = P, rq_ctx.opt = opt, rq_ctx.pen_gap = b->pen_gap, rq_ctx.pen_skip = b->pen_skip;
+		CK(mga_hbuf_reserve(&P->h_rq, (size_t)((n_a + 1) & ~1LL) * 20 + 64));
+		mga_batch_set_rq_device(b, rq_dev_fwd_hook, &rq_ctx, (char*)P->h_rq.p, n_a);
+	}
 	CK(mga_batch_chain(b, h_nmz, h_rep, (const int32_t*)P->h_mini.p, h_minioff, h_nu, h_nb, (const uint64_t*)P->h_u.p, (const mg128_t*)P->h_b.p, h_aoff, chunk_long ? 3 : long_q ? 2 : is_rmq, h_rflag));
 	if (g_dbg_pipe > 1) PIPE_LOG(" hostchain", n, t0);
 	t1 = mga_wtime(); st->t_host_chain += t1 - t0; t0 = t1;

@@ -405,18 +405,22 @@ void mga_lchain_rmq_fwd(int max_dist, int max_dist_inner, int bw, int max_chn_sk
 }
 
 /* backtracking + compaction after the forward pass over all of a[0..n) (lchain.c:355-371); frees f, p, v, t */
-mg128_t *mga_lchain_rmq_finish(int bw, int min_cnt, int min_sc, int64_t n, const mg128_t *a, int32_t *f, int64_t *p, int32_t *v, int32_t *t, int *n_u_, uint64_t **u_)
+mg128_t *mga_lchain_rmq_finish2(int bw, int min_cnt, int min_sc, int64_t n, const mg128_t *a, int32_t *f, int64_t *p, int32_t *v, int32_t *t, int *n_u_, uint64_t **u_, int keep_arrays)
 {
 	int32_t n_u, n_v;
 	uint64_t *u;
 	mg128_t *ret;
 	u = mga_chain_backtrack(n, f, p, v, t, min_cnt, min_sc, bw, 0, &n_u, &n_v);
 	*n_u_ = n_u, *u_ = u;
-	free(p); free(f); free(t);
-	if (n_u == 0) { free(v); return 0; }
+	if (!keep_arrays) { free(p); free(f); free(t); }
+	if (n_u == 0) { if (!keep_arrays) free(v); return 0; }
 	ret = mga_compact_a(n_u, u, n_v, v, a);
-	free(v);
+	if (!keep_arrays) free(v);
 	return ret;
+}
+mg128_t *mga_lchain_rmq_finish(int bw, int min_cnt, int min_sc, int64_t n, const mg128_t *a, int32_t *f, int64_t *p, int32_t *v, int32_t *t, int *n_u_, uint64_t **u_)
+{
+	return mga_lchain_rmq_finish2(bw, min_cnt, min_sc, n, a, f, p, v, t, n_u_, u_, 0);
 }
 
 /* in: n x-sorted anchors a[]; out: chains in u[] (malloc'ed, *n_u_ entries) and the compacted anchor array
