@@ -404,9 +404,9 @@ static int wfs_sweep(mga_sctx_t *sc, const wfs_ladder_t *LD, int arr_pct, int n_
 	}
 	// Round 5: a rung's walk (k_wfa_tb: a lane per problem chasing traceback bytes -- bound by memory latency, 2 % of the vector issue slots) runs on a stream of its own
 	// NEXT TO the following rung's forward pass (bound by vector issue): two traceback buffers used in turn, the forward pass of rung k waits for the walk of rung
-	// k - 2 (the previous user of its buffer), the walk of rung k for its forward pass.  MGA_WFA_TB_SIDE=0 (and the isolated pass, MGA_WFA_SIDE=0): one buffer, one stream.
+	// k - 2 (the previous user of its buffer), the walk of rung k for its forward pass.  Opt-in (MGA_WFA_TB_SIDE=1): measured, no gain -- see below; the default and the isolated pass (MGA_WFA_SIDE=0) use one buffer, one stream.
 	const char *e_tbs = getenv("MGA_WFA_TB_SIDE");
-	const bool tb_side = use_side && !(e_tbs && atoi(e_tbs) == 0);
+	const bool tb_side = use_side && e_tbs && atoi(e_tbs) > 0; // [measured, round 5, bench workload, three interleaved repetitions] 3.51 / 3.60 / 3.36 Gbp/s with the walk on its own stream against 3.61 / 3.63 without: kept behind MGA_WFA_TB_SIDE=1, not the default
 	hipStream_t tbs = tb_side ? (hipStream_t)sc->tier_stream[1] : st;
 	if (tb_side && tb_bytes > 0 && mga_dbuf_reserve(&sc->wfa_tbuf[1], (size_t)tb_bytes + 256) < 0) return -1;
 	int n_win = 0;

@@ -1449,12 +1449,16 @@ mga_stream_t *mga_stream_open(const mg_idx_t *gi, const mg_mapopt_t *opt, int n_
 	int i;
 	if (mga_dev_init() < 0) return 0;
 	if (env_int("MGA_SEGV_TRACE", 0)) signal(SIGSEGV, segv_trace);
-	if (g_dbg_pipe < 0) { g_dbg_pipe = env_int("MGA_DEBUG_PIPE", 0); g_gpu_wfa.avail = env_int("MGA_WFA_SLOTS", 2); g_gpu_front.avail = env_int("MGA_FRONT_SLOTS", 1); /* two chunks may be in their WFA phase: the second one fills the tails of the first */ }
+	if (g_dbg_pipe < 0) { g_dbg_pipe = env_int("MGA_DEBUG_PIPE", 0); g_gpu_wfa.avail = env_int("MGA_WFA_SLOTS", 2); g_gpu_front.avail = env_int("MGA_FRONT_SLOTS", n_threads > 4 && n_threads <= 12 ? 2 : 1); /* two chunks may be in their WFA phase: the second one fills the tails of the first */ }
 	g_cpu_on = g_dbg_pipe > 0;
 	S = MGA_CALLOC(mga_stream_t, 1);
 	S->gi = gi, S->opt = *opt, S->n_threads = n_threads > 0 ? n_threads : 1;
 	S->lr_long = (opt->flag & MG_M_RMQ) ? 0 : lr_long_bases();
-	S->n_pipe = env_int("MGA_PIPE", n_threads <= 4 ? 3 : 4); /* [measured, round 4, a rank pinned to 2 of 16 cores] 3 pipeline threads: 2.31 Gbp/s at 0.70 CPU-s per step, 4: 2.23 at 0.82, 2: 2.07; with 16 threads 4 is the best (3.27 vs 2.96 vs 2.51) */
+	/* round 5: a rank with 5 .. 12 host threads chains on the device (k_gchain: long-tailed launches, 117 ms of a 125 000-read step at a quarter of the wave slots): SIX chunks
+	 * in flight, two of them in the front phase, fill those tails with other chunks' kernels -- [measured, bench workload, --placement device, 16 threads] 2.98 / 3.00 Gbp/s
+	 * (4 chunks, one in the front phase) -> 3.24 (6 / 2) -> 3.27-3.30 with the persistent WFA grids at half size; with the chaining on the host threads the same knobs stay
+	 * inside the run-to-run noise (3.51-3.60 vs 3.55-3.65) */
+	S->n_pipe = env_int("MGA_PIPE", n_threads <= 4 ? 3 : n_threads <= 12 ? 6 : 4); /* [measured, round 4, a rank pinned to 2 of 16 cores] 3 pipeline threads: 2.31 Gbp/s at 0.70 CPU-s per step, 4: 2.23 at 0.82, 2: 2.07; with 16 threads 4 is the best (3.27 vs 2.96 vs 2.51) */
 	if (S->n_pipe > MGA_MAX_PIPE) S->n_pipe = MGA_MAX_PIPE;
 	if (S->n_pipe < 1) S->n_pipe = 1;
 	S->chunk = env_int("MGA_CHUNK", 16384); /* [measured] larger launches amortise the tails of the WFA tiers: 4096 -> 8192 reads +5 %, -> 16384 another +5 % */
