@@ -30,7 +30,7 @@ static char *pool_target(mga_tpool_t *tp, int64_t len)
 	return tp->tseq + tp->n_t;
 }
 
-void mga_plan_cigar(const gfa_t *g, const gfa_edseq_t *es, const mg_gchains_t *gt, int32_t gc_idx, int64_t q_base, mga_tpool_t *tp)
+void mga_plan_cigar(const gfa_t *g, const gfa_edseq_t *es, const mg_gchains_t *gt, int32_t gc_idx, int64_t q_base, mga_tpool_t *tp, int64_t vert_beg)
 {
 	const mg_gchain_t *gc = &gt->gc[gc_idx];
 	int32_t l0 = gc->off, off_a0 = gt->lc[l0].off, j, j0 = 0, k, l;
@@ -57,9 +57,14 @@ void mga_plan_cigar(const gfa_t *g, const gfa_edseq_t *es, const mg_gchains_t *g
 		else if (qlen == 0) pool_item(tp, 2, l_seq);
 		else if (l_seq == qlen && qlen <= (int32_t)(q->y >> 32 & 0xff)) pool_item(tp, 7, qlen);
 		else { /* a gap for the WFA kernel: target spliced across vertices, query = read[q.y+1 .. p.y] */
-			char *seq = pool_target(tp, l_seq);
+			char *seq = tp->want_src ? 0 : pool_target(tp, l_seq);
 			mga_wfa_prob_t *pb;
-			if (l == l0) memcpy(seq, &es[gt->lc[l0].v].seq[(int32_t)q->x + 1], (size_t)l_seq);
+			if (tp->want_src) { /* the device splices the target from its own segment images: say where it lies on the chain's walk */
+				mga_plan_src_t *sr;
+				if (tp->n_prob == tp->m_src) { tp->m_src = tp->m_src ? tp->m_src + (tp->m_src >> 1) : 1024; tp->src = (mga_plan_src_t*)realloc(tp->src, (size_t)tp->m_src * sizeof(mga_plan_src_t)); }
+				sr = &tp->src[tp->n_prob];
+				sr->lc0 = vert_beg + (l0 - gc->off), sr->n_lc = l - l0, sr->x0 = (int32_t)q->x, sr->x1 = (int32_t)p->x, sr->pad = 0;
+			} else if (l == l0) memcpy(seq, &es[gt->lc[l0].v].seq[(int32_t)q->x + 1], (size_t)l_seq);
 			else {
 				uint32_t v = gt->lc[l0].v;
 				int32_t n = g->seg[v>>1].len - (int32_t)q->x - 1;

@@ -170,6 +170,37 @@ __global__ void __launch_bounds__(256) k_plan_target(int64_t n_prob, const mga_w
 	}
 }
 
+// the same for gaps listed by the HOST (round 5: host threads chain and list, the device splices): the walk is the flattened vertex array of the text kernel
+__global__ void __launch_bounds__(256) k_plan_target_v(int64_t n_prob, const mga_wfa_prob_t *prob, const mga_plan_src_t *src, const uint32_t *vert,
+													   const int32_t *seg_len, const int64_t *gseq_off, const char *gseq, const char *gseq_rc, char *tseq)
+{
+	const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	if (w >= n_prob) return;
+	const mga_plan_src_t s = src[w];
+	char *dst = tseq + prob[w].t_off;
+	int32_t pos = 0;
+	for (int32_t t = 0; t <= s.n_lc; ++t) {
+		const uint32_t v = vert[s.lc0 + t];
+		const char *base = ((v & 1) ? gseq_rc : gseq) + gseq_off[v >> 1];
+		const int32_t b = t == 0 ? s.x0 + 1 : 0, e = t == s.n_lc ? s.x1 + 1 : seg_len[v >> 1];
+		for (int32_t o = b + lane; o < e; o += 64) dst[pos + (o - b)] = base[o];
+		pos += e - b;
+	}
+}
+
+extern "C" int mga_dev_plan_target_verts(mga_sctx_t *sc, const mga_didx_t *ix, int64_t n_prob, const mga_wfa_prob_t *d_prob, const mga_plan_src_t *d_src, const uint32_t *d_vert, char *d_tseq)
+{
+	if (n_prob <= 0) return 0;
+	hipStream_t st = (hipStream_t)sc->stream;
+	mga_prof_begin(sc->stream, MGA_K_PLAN);
+	hipLaunchKernelGGL(k_plan_target_v, dim3((unsigned)((n_prob + 3) / 4)), dim3(256), 0, st, n_prob, d_prob, d_src, d_vert, (const int32_t*)ix->d_seg_len, (const int64_t*)ix->d_gseq_off,
+					   (const char*)ix->d_gseq, (const char*)ix->d_gseq_rc, d_tseq);
+	mga_prof_end(sc->stream, MGA_K_PLAN);
+	MGA_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+
 static void plan_in_fill(plan_in_t *in, const mga_didx_t *ix, int n, int print_2nd, const mga_gc_hdr_t *d_hdr, const void *d_gc_pool, const mg_llchain_t *d_lc_pool,
 						 const mg128_t *d_a_pool, const int64_t *d_q_off)
 {

@@ -17,9 +17,16 @@ static void kx_insertion(kx_t *a, int64_t n) /* strict '<' : stable (ksort.h:118
 	}
 }
 
+typedef struct { int64_t b, e; int sh; } rng_t;
+
+/* Ranges are independent once their parent has been partitioned -- the order in which they are taken cannot change the result -- so a sort of 10^7 records runs its first
+ * partitioning passes on the calling thread and hands the sub-ranges to the pool (round 5: one 50 Mbp contig's anchor sort and the (score, index) sort of its backtrack were
+ * 0.4 + 0.4 s of ONE thread on the critical path of every contig of a -x asm batch).  stop_at > 0: return to the caller, with the open ranges left in *stk_ / *top_, as soon as
+ * that many ranges are open or the largest open range is below min_par. */
+static void kx_sort_ranges(kx_t *a, rng_t **stk_, int64_t *top_, int64_t *cap_, int64_t stop_at, int64_t min_par);
+
 static void kx_sort(kx_t *a, int64_t n, int key_bytes)
 {
-	typedef struct { int64_t b, e; int sh; } rng_t;
 	rng_t *stk;
 	int64_t top = 0, cap = n / 64 + 8;
 	if (n <= 64) { kx_insertion(a, n); return; }
@@ -32,10 +39,24 @@ static void kx_sort(kx_t *a, int64_t n, int key_bytes)
 		for (i = 1; i < n; ++i) d |= a[i].key ^ a[0].key;
 		while (stk[0].sh > 0 && (d >> stk[0].sh) == 0) stk[0].sh -= 8;
 	}
+	kx_sort_ranges(a, &stk, &top, &cap, 0, 0);
+	free(stk);
+}
+
+static void kx_sort_ranges(kx_t *a, rng_t **stk_, int64_t *top_, int64_t *cap_, int64_t stop_at, int64_t min_par)
+{
+	rng_t *stk = *stk_;
+	int64_t top = *top_, cap = *cap_;
 	while (top > 0) {
 		int64_t head[256], tail[256], cnt[256], i, pos;
-		rng_t r = stk[--top];
+		rng_t r;
 		int k;
+		if (stop_at > 0) { /* the parallel driver: take the LARGEST open range next; stop when there are enough of them or none is worth splitting further */
+			int64_t big = 0, j;
+			for (j = 1; j < top; ++j) if (stk[j].e - stk[j].b > stk[big].e - stk[big].b) big = j;
+			if (top >= stop_at || stk[big].e - stk[big].b < min_par) break;
+			r = stk[big]; stk[big] = stk[--top];
+		} else r = stk[--top];
 		memset(cnt, 0, sizeof cnt);
 		for (i = r.b; i < r.e; ++i) ++cnt[a[i].key >> r.sh & 0xff];
 		if (r.sh > 0 && cnt[a[r.b].key >> r.sh & 0xff] == r.e - r.b) { stk[top].b = r.b, stk[top].e = r.e, stk[top].sh = r.sh > 8 ? r.sh - 8 : 0, ++top; continue; } /* (one bucket: the same, found by counting) */
@@ -48,6 +69,7 @@ static void kx_sort(kx_t *a, int64_t n, int key_bytes)
 				do {
 					kx_t t = a[head[l]];
 					a[head[l]++] = carry;
+					if ((head[l] & 3) == 0) __builtin_prefetch(&a[head[l] + 12], 1, 0); /* every bucket's cursor walks forward: the next lines of the one just written are on their way before the chain of displacements comes back to it ([measured] the pass over 9 M records is a chain of dependent misses otherwise) */
 					carry = t;
 					l = (int)(carry.key >> r.sh & 0xff);
 				} while (l != k);
@@ -65,6 +87,39 @@ static void kx_sort(kx_t *a, int64_t n, int key_bytes)
 			}
 		}
 	}
+	*stk_ = stk, *top_ = top, *cap_ = cap;
+}
+
+typedef struct { kx_t *a; rng_t *r; } kx_par_t;
+static void kx_range_worker(void *data, int64_t i, int tid)
+{
+	kx_par_t *P = (kx_par_t*)data;
+	rng_t *stk;
+	int64_t top = 1, cap = (P->r[i].e - P->r[i].b) / 64 + 8;
+	(void)tid;
+	stk = MGA_MALLOC(rng_t, cap);
+	stk[0] = P->r[i];
+	kx_sort_ranges(P->a, &stk, &top, &cap, 0, 0);
+	free(stk);
+}
+
+int mga_ksort_threads = 1; /* threads a large sort may use (set by the batch that sorts: mapper.c) */
+
+static void kx_sort_mt(kx_t *a, int64_t n, int key_bytes, int n_threads)
+{
+	rng_t *stk;
+	int64_t top = 0, cap = n / 64 + 8, i;
+	kx_par_t P;
+	if (n_threads <= 1 || n < (1 << 18)) { kx_sort(a, n, key_bytes); return; }
+	stk = MGA_MALLOC(rng_t, cap);
+	stk[top].b = 0, stk[top].e = n, stk[top].sh = (key_bytes - 1) * 8, ++top;
+	{ /* (the leading bytes every key shares: as in kx_sort) */
+		uint64_t d = 0;
+		for (i = 1; i < n; ++i) d |= a[i].key ^ a[0].key;
+		while (stk[0].sh > 0 && (d >> stk[0].sh) == 0) stk[0].sh -= 8;
+	}
+	kx_sort_ranges(a, &stk, &top, &cap, (int64_t)n_threads * 8, n / ((int64_t)n_threads * 4) > 4096 ? n / ((int64_t)n_threads * 4) : 4096);
+	if (top > 0) { P.a = a, P.r = stk; mga_parallel_for(n_threads, top, kx_range_worker, &P); }
 	free(stk);
 }
 
@@ -84,7 +139,7 @@ void mga_ksort_128x(int64_t n, mg128_t *a) /* radix_sort_128x (ksort.h via map-a
 {
 	_Static_assert(sizeof(kx_t) == sizeof(mg128_t), "kx_t / mg128_t");
 	if (n <= 1) return;
-	kx_sort((kx_t*)a, n, 8);
+	kx_sort_mt((kx_t*)a, n, 8, mga_ksort_threads);
 }
 
 static int cmp_u64(const void *a, const void *b)

@@ -46,14 +46,14 @@ static void tpool_get(mga_tpool_t *tp)
 	pthread_mutex_lock(&g_cache_mtx);
 	if (g_n_tp_cache > 0) *tp = g_tp_cache[--g_n_tp_cache]; else memset(tp, 0, sizeof *tp);
 	pthread_mutex_unlock(&g_cache_mtx);
-	tp->n_t = tp->n_prob = tp->n_item = tp->n_chain = tp->n_vert = 0, tp->wfa_t_bases = tp->wfa_q_bases = 0;
+	tp->n_t = tp->n_prob = tp->n_item = tp->n_chain = tp->n_vert = 0, tp->wfa_t_bases = tp->wfa_q_bases = 0, tp->want_src = 0;
 }
 static void tpool_put(mga_tpool_t *tp)
 {
 	pthread_mutex_lock(&g_cache_mtx);
 	if (g_n_tp_cache < TP_CACHE_MAX) { g_tp_cache[g_n_tp_cache++] = *tp; pthread_mutex_unlock(&g_cache_mtx); return; }
 	pthread_mutex_unlock(&g_cache_mtx);
-	free(tp->tseq); free(tp->prob); free(tp->item); free(tp->chain); free(tp->vert);
+	free(tp->tseq); free(tp->prob); free(tp->item); free(tp->chain); free(tp->vert); free(tp->src);
 }
 #define STR_CACHE_MAX 512
 static struct { char *s; size_t m; } g_str_cache[STR_CACHE_MAX];
@@ -103,6 +103,7 @@ struct mga_batch_s {
 	mga_tpool_t *tp;
 	int64_t *tp_prob_base, *tp_t_base, *tp_item_base, *tp_chain_base, *tp_vert_base;
 	int want_text;          /* the caller only wants GAF bytes: cg:Z / ds:Z come from the device (k_text.hip) */
+	int want_src;           /* ... and the targets of the gaps are spliced on the device from descriptors (align.h: mga_tpool_t::want_src) */
 	const mga_txt_res_t *txt_res; /* text-mode results, global chain order */
 	const char *txt_pool;
 	/* stage-1 inputs, valid during mga_batch_chain() only */
@@ -149,6 +150,9 @@ mga_batch_t *mga_batch_init(const mg_idx_t *gi, const mg_mapopt_t *opt, int n, c
 	b->tp_vert_base = MGA_CALLOC(int64_t, b->n_threads + 1);
 	return b;
 }
+
+void mga_batch_wfa_export_src(const mga_batch_t *b, mga_wfa_prob_t *prob, char *tseq, mga_plan_src_t *src, int64_t vert_base);
+void mga_batch_set_want_src(mga_batch_t *b, int on) { int t; b->want_src = on; for (t = 0; t < b->n_threads; ++t) b->tp[t].want_src = on; }
 
 void mga_batch_set_device_chains(mga_batch_t *b, const mga_gc_hdr_t *hdr, const void *gc_pool, const mg_llchain_t *lc_pool, const mg128_t *a_pool)
 {
@@ -284,9 +288,12 @@ static void rq_dev_worker(mga_batch_t *b, int read)
 	qsort(ord, (size_t)n_dev, sizeof *ord, rq_ord_cmp); /* longest first: a launch lasts as long as its longest run */
 	for (k = 0; k < n_dev; ++k) order[k] = ord[k].k, status[ord[k].k] = 4;
 	if (n_dev > 0) {
+		const double tw0 = mga_wtime();
 		pthread_mutex_lock(&b->rq_dev_mtx);
+		const double tw1 = mga_wtime();
 		rc = b->rq_dev_fwd(b->rq_dev_ctx, r->a, r->n, r->n_cut, r->cut, n_dev, order, r->pass2 ? opt->bw_long : opt->bw, r->f, r->p, r->v, status);
 		pthread_mutex_unlock(&b->rq_dev_mtx);
+		if (g_cpu_on) fprintf(stderr, "[rq] read %d pass %d: %ld anchors in %d runs (longest %ld) through the device in %.1f ms (+ %.1f ms waiting for it)\n", read, r->pass2 + 1, (long)r->n, n_dev, (long)ord[0].len, (mga_wtime() - tw1) * 1e3, (tw1 - tw0) * 1e3);
 		if (rc < 0) for (k = 0; k < n_dev; ++k) status[order[k]] = 4; /* (the message stays in mga_last_error(); the host takes the runs) */
 	}
 	for (k = 0; k < r->n_cut; ++k) {
@@ -553,24 +560,21 @@ plan:
 				pl->chain_id[k] = -1;
 				if ((gc->id != gc->parent && !(opt->flag & MG_M_PRINT_2ND)) || gc->cnt == 0) continue; /* not printed (format.c:135-136): no alignment needed */
 			}
-			mga_plan_cigar(gi->g, gi->es, gcs, k, b->q_off ? b->q_off[i] : 0, tp);
+			const int64_t vert_beg = tp->n_vert;
+			if (b->want_text) { int32_t j; for (j = 0; j < gc->cnt; ++j) { MGA_GROW(uint32_t, tp->vert, tp->n_vert, tp->m_vert); tp->vert[tp->n_vert++] = gcs->lc[gc->off + j].v; } } /* the chain's walk: what the text kernel prints, and what the device splices the gaps' targets from */
+			mga_plan_cigar(gi->g, gi->es, gcs, k, b->q_off ? b->q_off[i] : 0, tp, vert_beg);
 			if (b->want_text) { /* what the text kernel needs to know about this chain */
 				mga_txt_chain_t *c;
 				const int32_t off_a0 = gcs->lc[gc->off].off;
-				int32_t j;
 				if (mga_gaf_chain_rev(gi->g, gcs, gc, opt->flag)) rev_sign = 1;
 				MGA_GROW(mga_txt_chain_t, tp->chain, tp->n_chain, tp->m_chain);
 				c = &tp->chain[tp->n_chain];
 				c->item_beg = pl->item_off[k], c->item_end = tp->n_item, c->prob_base = 0, c->q_base = b->q_off ? b->q_off[i] : 0;
-				c->vert_beg = tp->n_vert, c->vert_cnt = gc->cnt;
+				c->vert_beg = vert_beg, c->vert_cnt = gc->cnt;
 				c->qs = gc->qs, c->qe = gc->qe, c->ps = gc->ps, c->pe = gc->pe;
 				c->ss = (int32_t)gcs->a[off_a0].x + 1 - (int32_t)(gcs->a[off_a0].y >> 32 & 0xff); /* galign.c:128-129 */
 				c->ee = (int32_t)gcs->a[off_a0 + gc->n_anchor - 1].x + 1;
 				c->rev_sign = rev_sign;
-				for (j = 0; j < gc->cnt; ++j) {
-					MGA_GROW(uint32_t, tp->vert, tp->n_vert, tp->m_vert);
-					tp->vert[tp->n_vert++] = gcs->lc[gc->off + j].v;
-				}
 				pl->chain_id[k] = tp->n_chain++;
 			}
 		}
@@ -587,7 +591,7 @@ int mga_batch_chain(mga_batch_t *b, const int32_t *n_mz, const int32_t *rep_len,
 	b->rescue_flag = rescue_flag;
 	b->n_mz = n_mz, b->rep_len = rep_len, b->mini_pos = mini_pos, b->mini_off = mini_off;
 	b->nu = nu, b->nb = nb, b->u = u, b->a = a, b->a_off = a_off, b->a_is_raw = a_is_raw;
-	if (a_is_raw) rq_chain_all(b);
+	if (a_is_raw) { extern int mga_ksort_threads; if (b->n_threads > mga_ksort_threads) mga_ksort_threads = b->n_threads; /* the big sorts of a contig fan out over the pool (ksortx.c) */ rq_chain_all(b); }
 	mga_parallel_for(b->n_threads, b->n, chain_worker, b);
 	if (b->rq) { free(b->rq); b->rq = 0; }
 	for (t = 0; t < b->n_threads; ++t) {
@@ -603,7 +607,7 @@ int mga_batch_chain(mga_batch_t *b, const int32_t *n_mz, const int32_t *rep_len,
 int64_t mga_batch_n_wfa(const mga_batch_t *b) { return b->tp_prob_base[b->n_threads]; }
 int64_t mga_batch_wfa_target_bytes(const mga_batch_t *b) { return b->tp_t_base[b->n_threads]; }
 
-typedef struct { const mga_batch_t *b; mga_wfa_prob_t *prob; char *tseq; } export_t;
+typedef struct { const mga_batch_t *b; mga_wfa_prob_t *prob; char *tseq; mga_plan_src_t *src; int64_t vert_base; } export_t;
 static void export_worker(void *data, int64_t t, int tid)
 {
 	export_t *e = (export_t*)data;
@@ -612,18 +616,22 @@ static void export_worker(void *data, int64_t t, int tid)
 	int64_t j;
 	int64_t tc = cpu_now();
 	(void)tid;
-	memcpy(e->tseq + b->tp_t_base[t], tp->tseq, (size_t)tp->n_t);
+	if (!tp->want_src) memcpy(e->tseq + b->tp_t_base[t], tp->tseq, (size_t)tp->n_t);
 	for (j = 0; j < tp->n_prob; ++j) {
 		e->prob[b->tp_prob_base[t] + j] = tp->prob[j];
 		e->prob[b->tp_prob_base[t] + j].t_off += b->tp_t_base[t];
+		if (tp->want_src) { e->src[b->tp_prob_base[t] + j] = tp->src[j]; e->src[b->tp_prob_base[t] + j].lc0 += b->tp_vert_base[t] + e->vert_base; }
 	}
 	CPU_ADD(C_EXPORT, tc);
 }
 
-void mga_batch_wfa_export(const mga_batch_t *b, mga_wfa_prob_t *prob, char *tseq)
+void mga_batch_wfa_export(const mga_batch_t *b, mga_wfa_prob_t *prob, char *tseq) { mga_batch_wfa_export_src(b, prob, tseq, 0, 0); }
+
+/* (want_src: src[] receives one descriptor per problem, its first walk vertex as an index into the flattened vertex array + vert_base; tseq is not written) */
+void mga_batch_wfa_export_src(const mga_batch_t *b, mga_wfa_prob_t *prob, char *tseq, mga_plan_src_t *src, int64_t vert_base)
 {
 	export_t e;
-	e.b = b, e.prob = prob, e.tseq = tseq;
+	e.b = b, e.prob = prob, e.tseq = tseq, e.src = src, e.vert_base = vert_base;
 	mga_parallel_for(b->n_threads, b->n_threads, export_worker, &e);
 }
 
@@ -789,11 +797,11 @@ typedef struct { /* one pipeline context: HIP stream + grow-only device and pinn
 		mga_dbuf_t dall[67];
 	};
 	union {
-		struct { mga_hbuf_t h_b, h_u, h_mini, h_tseq, h_prob, h_pool, h_seq, h_ncig, h_cigoff, h_item, h_chain, h_vert, h_txtres, h_txtpool, h_gchdr, h_gcpool, h_lcpool, h_apool, h_plrev, h_ploff, h_lcord, h_rq, h_rqs; }; /* pinned staging */
-		mga_hbuf_t hall[23];
+		struct { mga_hbuf_t h_b, h_u, h_mini, h_tseq, h_prob, h_pool, h_seq, h_ncig, h_cigoff, h_item, h_chain, h_vert, h_txtres, h_txtpool, h_gchdr, h_gcpool, h_lcpool, h_apool, h_plrev, h_ploff, h_lcord, h_rq, h_rqs, h_plsrc; }; /* pinned staging */
+		mga_hbuf_t hall[24];
 	};
 } pipe_ctx_t;
-_Static_assert(sizeof(((pipe_ctx_t*)0)->dall) == 67 * sizeof(mga_dbuf_t) && sizeof(((pipe_ctx_t*)0)->hall) == 23 * sizeof(mga_hbuf_t), "pipe_ctx_t: buffer lists out of sync");
+_Static_assert(sizeof(((pipe_ctx_t*)0)->dall) == 67 * sizeof(mga_dbuf_t) && sizeof(((pipe_ctx_t*)0)->hall) == 24 * sizeof(mga_hbuf_t), "pipe_ctx_t: buffer lists out of sync");
 
 #define MGA_MAX_PIPE 8
 
@@ -1153,6 +1161,8 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	/* ---- host: graph chaining + gap list ---- */
 	b = mga_batch_init(gi, opt, n, qlens, seqs, qnames, q_off, n_threads);
 	b->want_text = want_text;
+	const int dev_splice = want_text && B->dev.d_gseq != 0 && B->dev.d_gseq_rc != 0 && env_int("MGA_DEV_SPLICE", 1); /* the gaps' targets are spliced on the device (align.h: want_src) */
+	if (dev_splice) mga_batch_set_want_src(b, 1);
 	if (dev_plan) {
 		if (ptot[6] != 0 || ptot[2] > 0x7fffffffULL) { mga_set_error("gap list: too many WFA problems or target bases in one chunk (%llu problems); lower MGA_CHUNK", ptot[2]); rc = -1; goto done; }
 		CK(mga_hbuf_reserve(&P->h_plrev, (size_t)ptot[0] * 4 + 16));
@@ -1179,10 +1189,15 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 		int64_t cells = 0;
 		const int64_t n_item = dp_item + (b->want_text ? mga_batch_n_items(b) : 0), n_chain = dp_chain + (b->want_text ? mga_batch_n_chains(b) : 0), n_vert = dp_vert + (b->want_text ? mga_batch_n_verts(b) : 0);
 		if (n_prob > 0x7fffffff) { mga_set_error("too many WFA problems in one chunk (%ld); lower MGA_CHUNK", (long)n_prob); rc = -1; goto done; }
-		CK(mga_hbuf_reserve(&P->h_prob, (size_t)hp_prob * sizeof(mga_wfa_prob_t) + 16)); CK(mga_hbuf_reserve(&P->h_tseq, (size_t)hp_tb + 64));
+		CK(mga_hbuf_reserve(&P->h_prob, (size_t)hp_prob * sizeof(mga_wfa_prob_t) + 16)); CK(mga_hbuf_reserve(&P->h_tseq, dev_splice ? 64 : (size_t)hp_tb + 64));
 		h_prob = (mga_wfa_prob_t*)P->h_prob.p;
-		mga_batch_wfa_export(b, h_prob, (char*)P->h_tseq.p);
-		memset((char*)P->h_tseq.p + hp_tb, 0, 64);
+		if (dev_splice) { /* descriptors instead of bytes: 24 bytes per gap; the vertices they index follow the device-made part (dp_vert) of the walk array */
+			CK(mga_hbuf_reserve(&P->h_plsrc, (size_t)hp_prob * sizeof(mga_plan_src_t) + 16));
+			mga_batch_wfa_export_src(b, h_prob, 0, (mga_plan_src_t*)P->h_plsrc.p, dp_vert);
+		} else {
+			mga_batch_wfa_export(b, h_prob, (char*)P->h_tseq.p);
+			memset((char*)P->h_tseq.p + hp_tb, 0, 64);
+		}
 		for (i = 0; dp_tb > 0 && i < hp_prob; ++i) h_prob[i].t_off += dp_tb;
 		CK(mga_dbuf_reserve(&P->tseq, (size_t)n_tb + 64)); CK(mga_dbuf_reserve(&P->prob, (size_t)n_prob * sizeof(mga_wfa_prob_t) + 16)); CK(mga_dbuf_reserve(&P->res, (size_t)n_prob * sizeof(mga_wfa_res_t) + 16));
 		CK(mga_dbuf_reserve(&P->used, 64));
@@ -1190,15 +1205,33 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 			CK(mga_dbuf_reserve(&P->item, (size_t)n_item * sizeof(mga_cigitem_t) + 16)); CK(mga_dbuf_reserve(&P->chain, (size_t)n_chain * sizeof(mga_txt_chain_t) + 16));
 			CK(mga_dbuf_reserve(&P->vert, (size_t)n_vert * 4 + 16)); CK(mga_dbuf_reserve(&P->txtres, (size_t)n_chain * sizeof(mga_txt_res_t) + 16));
 		}
+		if (dev_plan || dev_splice) CK(mga_dbuf_reserve(&P->plsrc, (size_t)n_prob * sizeof(mga_plan_src_t) + 16));
 		if (dev_plan) { /* pass 2 of k_plan.hip: items, problems + their targets, printed chains and walks, straight from the record pools in HBM */
-			CK(mga_dbuf_reserve(&P->plrev, (size_t)dp_chain * 4 + 16)); CK(mga_dbuf_reserve(&P->plsrc, (size_t)dp_prob * sizeof(mga_plan_src_t) + 16));
+			CK(mga_dbuf_reserve(&P->plrev, (size_t)dp_chain * 4 + 16));
 			CK(mga_h2d_s(sc, P->plrev.p, P->h_plrev.p, (size_t)dp_chain * 4));
 			CK(mga_dev_plan_fill(sc, &B->dev, n, (opt->flag & MG_M_PRINT_2ND) != 0, (const mga_gc_hdr_t*)P->gchdr.p, P->gcpool.p, (const mg_llchain_t*)P->lcpool.p, (const mg128_t*)P->apool.p,
 								 (const int64_t*)P->qoff.p, (const int64_t*)P->ploff.p, (const int32_t*)P->plrev.p, dp_prob, (mga_cigitem_t*)P->item.p, (mga_wfa_prob_t*)P->prob.p,
 								 (mga_plan_src_t*)P->plsrc.p, (mga_txt_chain_t*)P->chain.p, (uint32_t*)P->vert.p, (char*)P->tseq.p));
 		}
 		/* uploads ride the copy engine while another chunk owns the WFA phase */
-		CK(mga_h2d_s(sc, (char*)P->tseq.p + dp_tb, P->h_tseq.p, (size_t)hp_tb + 64)); CK(mga_h2d_s(sc, (mga_wfa_prob_t*)P->prob.p + dp_prob, h_prob, (size_t)hp_prob * sizeof(mga_wfa_prob_t)));
+		CK(mga_h2d_s(sc, (mga_wfa_prob_t*)P->prob.p + dp_prob, h_prob, (size_t)hp_prob * sizeof(mga_wfa_prob_t)));
+		if (dev_splice) { /* walk vertices first (the text kernel's inputs travel now instead of after the ladder), then the targets are spliced where the graph's sequence lies */
+			const int64_t hp_item = n_item - dp_item, hp_chain = n_chain - dp_chain, hp_vert = n_vert - dp_vert;
+			int64_t k;
+			CK(mga_hbuf_reserve(&P->h_item, (size_t)hp_item * sizeof(mga_cigitem_t) + 16)); CK(mga_hbuf_reserve(&P->h_chain, (size_t)hp_chain * sizeof(mga_txt_chain_t) + 16));
+			CK(mga_hbuf_reserve(&P->h_vert, (size_t)hp_vert * 4 + 16));
+			mga_batch_text_export(b, (mga_cigitem_t*)P->h_item.p, (mga_txt_chain_t*)P->h_chain.p, (uint32_t*)P->h_vert.p);
+			for (k = 0; dev_plan && k < hp_chain; ++k) { /* behind the device-made part */
+				mga_txt_chain_t *c = (mga_txt_chain_t*)P->h_chain.p + k;
+				c->item_beg += dp_item, c->item_end += dp_item, c->vert_beg += dp_vert, c->prob_base += dp_prob;
+			}
+			CK(mga_h2d_s(sc, (mga_cigitem_t*)P->item.p + dp_item, P->h_item.p, (size_t)hp_item * sizeof(mga_cigitem_t)));
+			CK(mga_h2d_s(sc, (mga_txt_chain_t*)P->chain.p + dp_chain, P->h_chain.p, (size_t)hp_chain * sizeof(mga_txt_chain_t)));
+			CK(mga_h2d_s(sc, (uint32_t*)P->vert.p + dp_vert, P->h_vert.p, (size_t)hp_vert * 4));
+			CK(mga_h2d_s(sc, (mga_plan_src_t*)P->plsrc.p + dp_prob, P->h_plsrc.p, (size_t)hp_prob * sizeof(mga_plan_src_t)));
+			CK(mga_dmemset_s(sc, (char*)P->tseq.p + n_tb, 0, 64));
+			CK(mga_dev_plan_target_verts(sc, &B->dev, hp_prob, (const mga_wfa_prob_t*)P->prob.p + dp_prob, (const mga_plan_src_t*)P->plsrc.p + dp_prob, (const uint32_t*)P->vert.p, (char*)P->tseq.p));
+		} else CK(mga_h2d_s(sc, (char*)P->tseq.p + dp_tb, P->h_tseq.p, (size_t)hp_tb + 64));
 		GPU_ACQUIRE(&g_gpu_wfa);
 		/* CIGAR pool: a global alignment has at most tl + ql operators, so target bases + query bases bound the chunk; + the abandoned block
 		 * tails (<= 512 ops) of every resident wave.  Sized to the bound, the pool cannot overflow whatever the divergence. */
@@ -1220,6 +1253,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 				unsigned long long txt_used = 0;
 				const int tight = env_int("MGA_TXT_TIGHT", 0); /* (MGA_TXT_TIGHT=1: a deliberately small pool, so that a test sees the second launch) */
 				for (k = 0; k < n; ++k) txt_cap += (tight ? 1 : 3) * (int64_t)qlens[k] / (tight ? 4 : 1) + 1024;
+				if (!dev_splice) { /* (with the targets spliced on the device these went up before the ladder) */
 				CK(mga_hbuf_reserve(&P->h_item, (size_t)hp_item * sizeof(mga_cigitem_t) + 16)); CK(mga_hbuf_reserve(&P->h_chain, (size_t)hp_chain * sizeof(mga_txt_chain_t) + 16));
 				CK(mga_hbuf_reserve(&P->h_vert, (size_t)hp_vert * 4 + 16));
 				mga_batch_text_export(b, (mga_cigitem_t*)P->h_item.p, (mga_txt_chain_t*)P->h_chain.p, (uint32_t*)P->h_vert.p);
@@ -1230,6 +1264,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 				CK(mga_h2d_s(sc, (mga_cigitem_t*)P->item.p + dp_item, P->h_item.p, (size_t)hp_item * sizeof(mga_cigitem_t)));
 				CK(mga_h2d_s(sc, (mga_txt_chain_t*)P->chain.p + dp_chain, P->h_chain.p, (size_t)hp_chain * sizeof(mga_txt_chain_t)));
 				CK(mga_h2d_s(sc, (uint32_t*)P->vert.p + dp_vert, P->h_vert.p, (size_t)hp_vert * 4));
+				}
 				for (k = 0;; ++k) { /* the pool is sized for ordinary reads (~1 byte of cg + ds per base); the kernel counts what it WOULD have written, so a chunk of
 				                     * very divergent reads or many printed secondaries gets a pool of exactly that size and a second launch */
 					CK(mga_dbuf_reserve(&P->txtpool, (size_t)txt_cap)); CK(mga_dmemset_s(sc, P->used.p, 0, 8));

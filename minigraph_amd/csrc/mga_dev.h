@@ -259,6 +259,9 @@ int mga_dev_rmq_fwd(mga_sctx_t *sc, int64_t n, const mg128_t *d_a, int n_runs, c
 					int max_skip, int cap, float pen_gap, float pen_skip, int32_t *d_f, int64_t *d_p, int32_t *d_v, int32_t *d_t, double *d_pri, int32_t *d_ys,
 					int32_t *d_status, int *d_counter);
 
+/* targets of HOST-listed gaps spliced on the device: problem j's target = the walk d_vert[src[j].lc0 .. + n_lc] from base x0 + 1 to base x1, written at d_tseq + prob[j].t_off */
+int mga_dev_plan_target_verts(mga_sctx_t *sc, const mga_didx_t *ix, int64_t n_prob, const mga_wfa_prob_t *d_prob, const mga_plan_src_t *d_src, const uint32_t *d_vert, char *d_tseq);
+
 /* CIGARs of all problems copied into problem order: d_ncig[i] operators at d_ord + d_off[i] (d_off has n+1 entries); *h_total = d_off[n] */
 int mga_dev_wfa_gather(mga_sctx_t *sc, int n, const mga_wfa_res_t *d_res, const uint32_t *d_pool, int32_t *d_ncig, int64_t *d_off, uint32_t *d_ord,
 					   int64_t ord_cap, int64_t *h_total);

@@ -88,3 +88,31 @@ def test_rmq_chainer_matches_reference(kind, par):
         assert np.array_equal(u1, u2), (kind, par, seed)
         assert np.array_equal(b1, b2), (kind, par, seed)
         assert len(u1) > 0
+
+
+def test_host_radix_sort_single_and_pool_equal_the_reference_permutation():
+    """ksortx.c: the product's host twin of klib's in-place MSD radix sort (ksort.h:112-162, radix_sort_128x): same PERMUTATION as the reference's -- equal keys included --
+    on one thread and fanned out over the pool (round 5: the anchor sort and the backtrack's (score, index) sort of a chromosome-scale contig)"""
+    import ctypes as C
+    import numpy as np
+    import minigraph_amd as mga
+    ref = rb.Ref()
+    L = mga.load()
+    L.mga_ksort_128x.argtypes = [C.c_int64, C.c_void_p]
+    thr = C.c_int.in_dll(L, "mga_ksort_threads")
+    rng = np.random.default_rng(5)
+    for n, key_bits in ((300_000, 12), (300_000, 30), (700_000, 52), (1_200_000, 20), (1_200_000, 40), (400_000, 64)):
+        a = np.zeros(n, dtype=rb.m128)
+        a["x"] = rng.integers(0, 2 ** min(key_bits, 63), size=n, dtype=np.uint64)
+        if key_bits == 52:   # anchor-like keys: a few (segment, strand) groups, positions inside them -- heavily skewed first passes
+            a["x"] = (rng.integers(0, 9, size=n, dtype=np.uint64) << np.uint64(33)) | rng.integers(0, 2 ** 22, size=n, dtype=np.uint64)
+        if key_bits == 64:
+            a["x"] |= rng.integers(0, 2, size=n, dtype=np.uint64) << np.uint64(63)
+        a["y"] = np.arange(n, dtype=np.uint64)   # the payload exposes the order of equal keys
+        want = ref.sort128x(a)
+        for t in (1, 3, 16):
+            thr.value = t
+            got = a.copy()
+            L.mga_ksort_128x(n, got.ctypes.data)
+            assert np.array_equal(got, want), (n, key_bits, t)
+    thr.value = 1
