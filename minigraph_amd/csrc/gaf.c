@@ -8,8 +8,12 @@
 #include <assert.h>
 #include "mga_host.h"
 
+/* A kstring_t whose capacity says MGA_KS_WINDOW is a WINDOW into somebody else's buffer (round 5: a chunk's GAF lines written straight to their place in the job's output,
+ * mapper.c): it is never reallocated and never NUL-terminated -- the byte behind a piece belongs to the next piece, which another thread may be writing. */
+#define KS_TERM(s) do { if ((s)->m != MGA_KS_WINDOW) (s)->s[(s)->l] = 0; } while (0)
 static inline void ks_room(kstring_t *s, size_t extra)
 {
+	if (s->m == MGA_KS_WINDOW) return;
 	if (s->l + extra + 1 > s->m) {
 		size_t m = s->l + extra + 1;
 		if (m > 0xfffffff0u) { /* kstring_t (mgpriv.h:31-37) counts in 32 bits: fail loudly instead of wrapping.  A piece is one thread's share of a 16384-read chunk;
@@ -23,8 +27,8 @@ static inline void ks_room(kstring_t *s, size_t extra)
 		s->s = (char*)realloc(s->s, s->m);
 	}
 }
-static inline void ks_c(kstring_t *s, char c) { ks_room(s, 1); s->s[s->l++] = c; s->s[s->l] = 0; }
-static inline void ks_sn(kstring_t *s, const char *p, size_t n) { ks_room(s, n); memcpy(s->s + s->l, p, n); s->l += (unsigned)n; s->s[s->l] = 0; }
+static inline void ks_c(kstring_t *s, char c) { ks_room(s, 1); s->s[s->l++] = c; KS_TERM(s); }
+static inline void ks_sn(kstring_t *s, const char *p, size_t n) { ks_room(s, n); memcpy(s->s + s->l, p, n); s->l += (unsigned)n; KS_TERM(s); }
 static inline void ks_s(kstring_t *s, const char *p) { ks_sn(s, p, strlen(p)); }
 static inline void ks_d(kstring_t *s, int32_t c)
 {
@@ -35,7 +39,7 @@ static inline void ks_d(kstring_t *s, int32_t c)
 	if (c < 0) buf[l++] = '-';
 	ks_room(s, (size_t)l);
 	while (l > 0) s->s[s->l++] = buf[--l];
-	s->s[s->l] = 0;
+	KS_TERM(s);
 }
 /* mgpriv.h:118 / format.c:36-80: the reference's light formatter (%d %u %s %c only), exported because its consumers of mg_gchains_t
  * (asm-call.c:122-137, --call) print with it; appends to s like the original */
@@ -60,7 +64,7 @@ void mg_sprintf_lite(kstring_t *s, const char *fmt, ...)
 		else abort(); /* format.c:68 */
 	}
 	va_end(ap);
-	ks_room(s, 0); s->s[s->l] = 0;
+	ks_room(s, 0); KS_TERM(s);
 }
 
 void mg_write_gaf(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, int32_t n_seg, const int32_t *qlens, const char *qname, uint64_t flag, void *km)
@@ -163,7 +167,7 @@ void mga_write_gaf_append(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, 
 			memcpy(w, qname, qn); w += qn;
 			w = put_tab_d(w, qlen);
 			w = put_s(w, "\t0\t0\t*\t*\t0\t0\t0\t0\t0\t0\n");
-			s->l = (unsigned)(w - s->s), s->s[s->l] = 0;
+			s->l = (unsigned)(w - s->s); KS_TERM(s);
 		}
 		return;
 	}
@@ -282,7 +286,7 @@ void mga_write_gaf_append(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, 
 				*w++ = '\n';
 				s->l = (unsigned)(w - s->s);
 			}
-			s->s[s->l] = 0;
+			KS_TERM(s);
 		}
 	}
 }

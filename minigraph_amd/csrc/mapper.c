@@ -115,7 +115,8 @@ struct mga_batch_s {
 	struct rq_read_s *rq;   /* a_is_raw: per-read state of the phased RMQ chaining (see rq_* below) */
 	/* round 5: the forward passes of the RMQ chainer on the device (k_rmq.hip), one read at a time on the chunk's stream; rq_harr = pinned arrays p | f | v | t of ALL the
 	 * chunk's anchors (the device writes f, p, v straight into them), rq_tot = their length in anchors */
-	int (*rq_dev_fwd)(void *ctx, const mg128_t *a, int64_t n, int n_cut, const int64_t *cut, int n_order, const int32_t *order, int bw, int32_t *f, int64_t *p, int32_t *v, int32_t *status);
+	int (*rq_dev_fwd)(void *ctx, int n_reads, const int64_t *r_abs0, const int64_t *r_n, const mg128_t *const *r_a, int32_t *const *r_f, int64_t *const *r_p, int32_t *const *r_v,
+					  int n_runs, const int64_t *runs /* beg, end, base triples, chunk-level */, int n_order, const int32_t *order, int bw, int32_t *status);
 	void *rq_dev_ctx; char *rq_harr; int64_t rq_tot;
 	pthread_mutex_t rq_dev_mtx;
 	int32_t *seg_len;       /* segment lengths as a flat array (the graph view of gc_core.h on the host) */
@@ -161,7 +162,8 @@ void mga_batch_set_device_chains(mga_batch_t *b, const mga_gc_hdr_t *hdr, const 
 
 void mga_batch_set_device_plan(mga_batch_t *b, const int64_t *chain_off, int32_t *rev, int64_t n_chain) { b->dp_chain_off = chain_off, b->dp_rev = rev, b->dp_n_chain = n_chain; }
 
-void mga_batch_set_rq_device(mga_batch_t *b, int (*fwd)(void*, const mg128_t*, int64_t, int, const int64_t*, int, const int32_t*, int, int32_t*, int64_t*, int32_t*, int32_t*), void *ctx, char *harr, int64_t tot)
+void mga_batch_set_rq_device(mga_batch_t *b, int (*fwd)(void*, int, const int64_t*, const int64_t*, const mg128_t *const*, int32_t *const*, int64_t *const*, int32_t *const*, int, const int64_t*, int, const int32_t*, int, int32_t*),
+							 void *ctx, char *harr, int64_t tot)
 {
 	b->rq_dev_fwd = fwd, b->rq_dev_ctx = ctx, b->rq_harr = harr, b->rq_tot = tot;
 	pthread_mutex_init(&b->rq_dev_mtx, 0);
@@ -270,20 +272,30 @@ static int rq_ord_cmp(const void *x, const void *y) { const rq_ord_t *p = (const
 
 static int rq_use_dev(const mga_batch_t *b, const rq_read_t *r) { return b->rq_dev_fwd != 0 && !((b->a_is_raw == 3 || b->a_is_raw == 5) && !r->pass2); }
 
-/* the forward pass of ALL runs of one read and pass: on the device, a wavefront per run (k_rmq.hip); what the device gives back -- a run with tied priorities, an
- * inner window beyond the kernel's sort -- and what is too long for one wavefront goes through the host's exact tree (rmq.c), run by run, on this thread */
-static void rq_dev_worker(mga_batch_t *b, int read)
+/* the forward pass of ALL runs of some reads' current pass (the same pass for all of them): on the device, a wavefront per run, ONE launch for all the reads (k_rmq.hip:
+ * a launch lasts as long as its longest run, and a read's ~2 000 runs fill a quarter of the wave slots); what the device gives back -- a run with tied priorities, an inner
+ * window beyond the kernel's sort -- and what is too long for one wavefront goes through the host's exact tree (rmq.c), run by run, on this thread */
+static void rq_dev_worker(mga_batch_t *b, int n_reads, const int32_t *reads)
 {
-	rq_read_t *r = &b->rq[read];
 	const mg_mapopt_t *opt = &b->opt;
-	rq_ord_t *ord = MGA_MALLOC(rq_ord_t, r->n_cut);
-	int32_t *order = MGA_MALLOC(int32_t, r->n_cut), *status = MGA_MALLOC(int32_t, r->n_cut);
-	int32_t k, n_dev = 0;
-	int rc = 0;
-	int64_t tc = cpu_now(), cnt[5] = { 0, 0, 0, 0, 0 };
-	for (k = 0; k < r->n_cut; ++k) {
-		status[k] = 3;
-		if (r->cut[k + 1] - r->cut[k] <= RQ_RUN_MAX_DEV) ord[n_dev].len = r->cut[k + 1] - r->cut[k], ord[n_dev++].k = k;
+	const int pass2 = b->rq[reads[0]].pass2;
+	int64_t n_runs = 0, k, q, *runs, *abs0, *rn, cnt[5] = { 0, 0, 0, 0, 0 }, tc = cpu_now();
+	const mg128_t **ra; int32_t **rf, **rv; int64_t **rp;
+	rq_ord_t *ord;
+	int32_t *order, *status, n_dev = 0;
+	int rc = 0, x;
+	for (x = 0; x < n_reads; ++x) n_runs += b->rq[reads[x]].n_cut;
+	runs = MGA_MALLOC(int64_t, 3 * n_runs + 3); ord = MGA_MALLOC(rq_ord_t, n_runs + 1); order = MGA_MALLOC(int32_t, n_runs + 1); status = MGA_MALLOC(int32_t, n_runs + 1);
+	abs0 = MGA_MALLOC(int64_t, n_reads); rn = MGA_MALLOC(int64_t, n_reads); ra = (const mg128_t**)MGA_MALLOC(void*, n_reads); rf = (int32_t**)MGA_MALLOC(void*, n_reads);
+	rv = (int32_t**)MGA_MALLOC(void*, n_reads); rp = (int64_t**)MGA_MALLOC(void*, n_reads);
+	for (x = 0, q = 0; x < n_reads; ++x) {
+		rq_read_t *r = &b->rq[reads[x]];
+		abs0[x] = b->a_off[reads[x]] - b->a_off[0], rn[x] = r->n, ra[x] = r->a, rf[x] = r->f, rv[x] = r->v, rp[x] = r->p;
+		for (k = 0; k < r->n_cut; ++k, ++q) {
+			runs[3 * q] = abs0[x] + r->cut[k], runs[3 * q + 1] = abs0[x] + r->cut[k + 1], runs[3 * q + 2] = abs0[x];
+			status[q] = 3;
+			if (r->cut[k + 1] - r->cut[k] <= RQ_RUN_MAX_DEV) ord[n_dev].len = r->cut[k + 1] - r->cut[k], ord[n_dev++].k = (int32_t)q;
+		}
 	}
 	qsort(ord, (size_t)n_dev, sizeof *ord, rq_ord_cmp); /* longest first: a launch lasts as long as its longest run */
 	for (k = 0; k < n_dev; ++k) order[k] = ord[k].k, status[ord[k].k] = 4;
@@ -291,21 +303,24 @@ static void rq_dev_worker(mga_batch_t *b, int read)
 		const double tw0 = mga_wtime();
 		pthread_mutex_lock(&b->rq_dev_mtx);
 		const double tw1 = mga_wtime();
-		rc = b->rq_dev_fwd(b->rq_dev_ctx, r->a, r->n, r->n_cut, r->cut, n_dev, order, r->pass2 ? opt->bw_long : opt->bw, r->f, r->p, r->v, status);
+		rc = b->rq_dev_fwd(b->rq_dev_ctx, n_reads, abs0, rn, ra, rf, rp, rv, (int)n_runs, runs, n_dev, order, pass2 ? opt->bw_long : opt->bw, status);
 		pthread_mutex_unlock(&b->rq_dev_mtx);
-		if (g_cpu_on) fprintf(stderr, "[rq] read %d pass %d: %ld anchors in %d runs (longest %ld) through the device in %.1f ms (+ %.1f ms waiting for it)\n", read, r->pass2 + 1, (long)r->n, n_dev, (long)ord[0].len, (mga_wtime() - tw1) * 1e3, (tw1 - tw0) * 1e3);
+		if (g_cpu_on) fprintf(stderr, "[rq] pass %d of %d reads: %d runs (longest %ld anchors) through the device in %.1f ms (+ %.1f ms waiting for it)\n", pass2 + 1, n_reads, n_dev, (long)ord[0].len, (mga_wtime() - tw1) * 1e3, (tw1 - tw0) * 1e3);
 		if (rc < 0) for (k = 0; k < n_dev; ++k) status[order[k]] = 4; /* (the message stays in mga_last_error(); the host takes the runs) */
 	}
-	for (k = 0; k < r->n_cut; ++k) {
-		if (status[k] == 0) { ++cnt[0]; continue; }
-		++cnt[status[k] <= 4 ? status[k] : 4];
-		memset(r->t + r->cut[k], 0, (size_t)(r->cut[k + 1] - r->cut[k]) * 4); /* the marks of a run stay inside it */
-		mga_lchain_rmq_fwd(opt->max_gap, opt->max_gap_pre, r->pass2 ? opt->bw_long : opt->bw, opt->max_lc_skip, opt->rmq_size_cap, b->pen_gap, b->pen_skip,
-						   r->cut[k], r->cut[k + 1], r->a, r->f, r->p, r->v, r->t);
+	for (x = 0, q = 0; x < n_reads; ++x) {
+		rq_read_t *r = &b->rq[reads[x]];
+		for (k = 0; k < r->n_cut; ++k, ++q) {
+			if (status[q] == 0) { ++cnt[0]; continue; }
+			++cnt[status[q] <= 4 ? status[q] : 4];
+			memset(r->t + r->cut[k], 0, (size_t)(r->cut[k + 1] - r->cut[k]) * 4); /* the marks of a run stay inside it */
+			mga_lchain_rmq_fwd(opt->max_gap, opt->max_gap_pre, pass2 ? opt->bw_long : opt->bw, opt->max_lc_skip, opt->rmq_size_cap, b->pen_gap, b->pen_skip,
+							   r->cut[k], r->cut[k + 1], r->a, r->f, r->p, r->v, r->t);
+		}
 	}
 	for (k = 0; k < 5; ++k) if (cnt[k]) __atomic_fetch_add(&g_rq_dev_stat[k], cnt[k], __ATOMIC_RELAXED);
-	free(ord); free(order); free(status);
-	CPU_ADD(r->pass2 ? C_LCRESCUE : C_LCCOPY, tc);
+	free(runs); free(ord); free(order); free(status); free(abs0); free(rn); free((void*)ra); free(rf); free(rv); free(rp);
+	CPU_ADD(pass2 ? C_LCRESCUE : C_LCCOPY, tc);
 }
 
 static void rq_finish_worker(void *data, int64_t i, int tid)
@@ -328,6 +343,12 @@ static void rq_finish_worker(void *data, int64_t i, int tid)
 				free(r->u); r->u = 0;
 				mga_ksort_128x(n_a, r->out);
 				r->a = r->out, r->n = n_a, r->pass2 = 1;
+				if (b->rq_dev_fwd && b->a_is_raw == 2) { /* the re-chained anchors go back into the read's slice of the (pinned) staging buffer: the device pass uploads from there, and the
+				                                          * chunk-level positions of the second pass are the first pass's (n_a <= the slice's length) */
+					mg128_t *slice = (mg128_t*)(b->a + b->a_off[i]);
+					memcpy(slice, r->out, (size_t)n_a * sizeof(mg128_t));
+					free(r->out); r->out = 0, r->a = slice;
+				}
 				rq_cut(r, b->rq_dev_fwd ? RQ_RUN_MIN_DEV : RQ_RUN_MIN); rq_arrays(b, r, i);
 			}
 		}
@@ -405,9 +426,27 @@ static void rq_sched_worker(void *data, int64_t j_, int tid)
 		} else if (S->lo_head < S->lo_tail) {
 			const rq_task_t t = S->lo[S->lo_head++];
 			void *arg[2];
+			if (t.k < 0) { /* a device task: every other read whose forward pass of the SAME pass is waiting in the queue goes into the same launch */
+				int32_t *rd = MGA_MALLOC(int32_t, S->lo_tail - S->lo_head + 1), n_rd = 0;
+				int64_t j, w_ = S->lo_head;
+				int x;
+				rd[n_rd++] = t.read;
+				for (j = S->lo_head; j < S->lo_tail; ++j) {
+					if (S->lo[j].k < 0 && b->rq[S->lo[j].read].pass2 == b->rq[t.read].pass2) rd[n_rd++] = S->lo[j].read;
+					else S->lo[w_++] = S->lo[j];
+				}
+				S->lo_tail = w_;
+				pthread_mutex_unlock(&S->mtx);
+				rq_dev_worker(b, n_rd, rd);
+				pthread_mutex_lock(&S->mtx);
+				for (x = 0; x < n_rd; ++x) if (--S->pending[rd[x]] == 0) S->hi[S->n_hi++] = ~rd[x];
+				pthread_cond_broadcast(&S->cv);
+				free(rd);
+				continue;
+			}
 			pthread_mutex_unlock(&S->mtx);
 			arg[0] = b, arg[1] = (void*)&t;
-			if (t.k < 0) rq_dev_worker(b, t.read); else rq_fwd_worker(arg, 0, tid);
+			rq_fwd_worker(arg, 0, tid);
 			pthread_mutex_lock(&S->mtx);
 			if (--S->pending[t.read] == 0) { S->hi[S->n_hi++] = ~t.read; pthread_cond_broadcast(&S->cv); }
 		} else break; /* n_open == 0 */
@@ -729,25 +768,31 @@ void mga_batch_destroy(mga_batch_t *b)
 	free(b);
 }
 
-/* GAF text of one chunk: T pieces in read order; in text mode cg:Z / ds:Z are copied from the device's output */
-typedef struct { mga_batch_t *b; int n, T; kstring_t *part; } gafw_t;
+/* GAF text of one chunk: T pieces in read order; in text mode cg:Z / ds:Z are copied from the device's output.
+ * Round 5: when the chunk is the NEXT one the job's output is waiting for (the usual case: chunks finish nearly in order), its lines are written STRAIGHT to their place in
+ * the output buffer -- a measuring pass (the same formatter with empty payloads + the payload lengths the device reported) gives every piece its offset, the writing pass
+ * formats into windows of the output (gaf.c: MGA_KS_WINDOW).  [measured, round 4] the text went device -> pinned staging -> piece -> output: two host copies of 1.1 GB per
+ * 125 000 reads; now one.  A chunk that finishes ahead of its predecessors takes the old way (pieces, copied when its turn comes). */
+typedef struct { int (*try_reserve)(void *ctx, int64_t bytes, char **dst); void (*commit)(void *ctx, int64_t bytes); void *ctx; } gaf_sink_t;
+typedef struct { mga_batch_t *b; int n, T, mode; kstring_t *part; int64_t *bytes, *off; char *dst; } gafw_t; /* mode 0: into the pieces; 1: measure; 2: into windows of dst */
 
 static void gaf_worker(void *data, int64_t t, int tid)
 {
 	gafw_t *w = (gafw_t*)data;
 	mga_batch_t *bt = w->b;
 	const int n = w->n;
-	int64_t b = (int64_t)n * t / w->T, e = (int64_t)n * (t + 1) / w->T, i;
-	kstring_t *out = &w->part[t];
+	int64_t b = (int64_t)n * t / w->T, e = (int64_t)n * (t + 1) / w->T, i, payload = 0;
+	kstring_t win, *out = &w->part[t];
 	mga_chain_text_t *txt = 0;
 	int32_t m_txt = 0;
 	int64_t tc = cpu_now();
 	(void)tid;
-	{ /* one allocation per piece: a base-aligned read prints about one byte per base (cg + ds), an unaligned one ~120 bytes */
+	if (w->mode == 2) { win.s = w->dst + w->off[t], win.l = 0, win.m = MGA_KS_WINDOW; out = &win; }
+	else if (w->mode == 0) { /* one allocation per piece: a base-aligned read prints about one byte per base (cg + ds), an unaligned one ~120 bytes */
 		size_t est = 4096;
 		for (i = b; i < e; ++i) est += (bt->opt.flag & MG_M_CIGAR) ? (size_t)bt->qlens[i] + 512 : 512;
 		if (est < 0xfffffff0u && est > out->m) { size_t cap; char *p = strbuf_get(est, &cap); if (cap > 0xfffffff0u) cap = 0xfffffff0u; free(out->s); out->s = p, out->m = (unsigned)cap, out->l = 0; }
-	}
+	} else out->l = 0; /* (measure: the piece's own buffer serves as scratch for the lines without their payloads) */
 	for (i = b; i < e; ++i) {
 		int32_t ql = bt->qlens[i], k;
 		const mg_gchains_t *gcs = bt->gcs[i];
@@ -761,12 +806,21 @@ static void gaf_worker(void *data, int64_t t, int tid)
 					const mga_txt_res_t *r = &bt->txt_res[pl->tid < 0 ? pl->chain_id[k] : bt->dp_n_chain + bt->tp_chain_base[pl->tid] + pl->chain_id[k]]; /* device-planned chains first, then the pools' */
 					txt[k].cg = bt->txt_pool + r->txt_off, txt[k].ds = txt[k].cg + r->cg_len;
 					txt[k].cg_len = r->cg_len, txt[k].ds_len = r->ds_len, txt[k].mlen = r->mlen, txt[k].blen = r->blen;
+					if (w->mode == 1) { /* printed or not is the formatter's decision: count what it would copy by letting it copy nothing */
+						if (!((gcs->gc[k].id != gcs->gc[k].parent && !(bt->opt.flag & MG_M_PRINT_2ND)) || gcs->gc[k].cnt == 0)) payload += (int64_t)r->cg_len + r->ds_len;
+						txt[k].cg_len = txt[k].ds_len = 0;
+					}
 				}
 			}
 			tx = txt;
 		}
+		if (w->mode == 1 && out->l > (1u << 20)) { payload += out->l; out->l = 0; } /* (the scratch does not have to hold the whole piece) */
 		mga_write_gaf_append(out, bt->gi->g, gcs, 1, &ql, bt->qnames ? bt->qnames[i] : "*", bt->opt.flag, tx);
-		mg_gchain_free(bt->gcs[i]); bt->gcs[i] = 0;
+		if (w->mode != 1) { mg_gchain_free(bt->gcs[i]); bt->gcs[i] = 0; }
+	}
+	if (w->mode == 1) { w->bytes[t] = payload + out->l; out->l = 0; }
+	else if (w->mode == 2) {
+		if ((int64_t)win.l != w->bytes[t]) { fprintf(stderr, "[E::%s] GAF piece %ld: %u bytes written where %ld were measured\n", __func__, (long)t, win.l, (long)w->bytes[t]); abort(); } /* the two passes run the same formatter: cannot happen, and must not go unnoticed */
 	}
 	free(txt);
 	CPU_ADD(C_GAF, tc);
@@ -827,36 +881,43 @@ static int lr_long_bases(void) { static int v = -1; if (v < 0) v = env_int("MGA_
 /* mga_batch_t's device hook: the forward pass of the RMQ chainer over the runs `order[0 .. n_order)` of one read's x-sorted anchors (k_rmq.hip), on this chunk's stream.
  * Called by ONE host thread at a time (mga_batch_t::rq_dev_mtx) while the chunk's pipeline thread waits inside mga_batch_chain(); f, p, v arrive in the caller's arrays
  * (pinned: the chunk's h_rq), status[run] says which runs the host has to redo. */
-typedef struct { pipe_ctx_t *P; const mg_mapopt_t *opt; float pen_gap, pen_skip; } rq_dev_ctx_t;
-static int rq_dev_fwd_hook(void *ctx_, const mg128_t *a, int64_t n, int n_cut, const int64_t *cut, int n_order, const int32_t *order, int bw, int32_t *f, int64_t *p, int32_t *v, int32_t *status)
+typedef struct { pipe_ctx_t *P; const mg_mapopt_t *opt; float pen_gap, pen_skip; int64_t n_total; } rq_dev_ctx_t;
+static int rq_dev_fwd_hook(void *ctx_, int n_reads, const int64_t *r_abs0, const int64_t *r_n, const mg128_t *const *r_a, int32_t *const *r_f, int64_t *const *r_p, int32_t *const *r_v,
+						   int n_runs, const int64_t *runs, int n_order, const int32_t *order, int bw, int32_t *status)
 {
 	rq_dev_ctx_t *C = (rq_dev_ctx_t*)ctx_;
 	pipe_ctx_t *P = C->P;
 	mga_sctx_t *sc = P->sc;
 	const mg_mapopt_t *opt = C->opt;
+	const int64_t n = C->n_total; /* the chunk's anchors: the device arrays are chunk-level, a read's slice sits at its offset */
 	char *hs;
+	int x;
 	if (mga_dev_bind_thread() < 0) return -1;
 	if (mga_dbuf_reserve(&P->rq_a, (size_t)n * 16 + 64) < 0 || mga_dbuf_reserve(&P->rq_f, (size_t)n * 4 + 64) < 0 || mga_dbuf_reserve(&P->rq_p, (size_t)n * 8 + 64) < 0 ||
 		mga_dbuf_reserve(&P->rq_v, (size_t)n * 4 + 64) < 0 || mga_dbuf_reserve(&P->rq_t, (size_t)n * 4 + 64) < 0 || mga_dbuf_reserve(&P->rq_pri, (size_t)n * 8 + 64) < 0 ||
-		mga_dbuf_reserve(&P->rq_ys, (size_t)n * 4 + 64) < 0 || mga_dbuf_reserve(&P->rq_cut, (size_t)(n_cut + 1) * 8 + 64) < 0 || mga_dbuf_reserve(&P->rq_ord, (size_t)n_cut * 4 + 64) < 0 ||
-		mga_dbuf_reserve(&P->rq_stat, (size_t)n_cut * 4 + 64) < 0 || mga_dbuf_reserve(&P->rq_cnt, 64) < 0 || mga_hbuf_reserve(&P->h_rqs, (size_t)(n_cut + 1) * 16 + 64) < 0) return -1;
-	hs = (char*)P->h_rqs.p; /* cut | order | status through pinned staging: copies from pageable memory wait inside the runtime */
-	memcpy(hs, cut, (size_t)(n_cut + 1) * 8); memcpy(hs + (size_t)(n_cut + 1) * 8, order, (size_t)n_order * 4); memcpy(hs + (size_t)(n_cut + 1) * 12, status, (size_t)n_cut * 4);
-	if (mga_h2d_s(sc, P->rq_a.p, a, (size_t)n * 16) < 0 || mga_h2d_s(sc, P->rq_cut.p, hs, (size_t)(n_cut + 1) * 8) < 0 || mga_h2d_s(sc, P->rq_ord.p, hs + (size_t)(n_cut + 1) * 8, (size_t)n_order * 4) < 0 ||
-		mga_h2d_s(sc, P->rq_stat.p, hs + (size_t)(n_cut + 1) * 12, (size_t)n_cut * 4) < 0) return -1;
-	if (mga_dev_rmq_fwd(sc, n, (const mg128_t*)P->rq_a.p, n_order, (const int64_t*)P->rq_cut.p, (const int32_t*)P->rq_ord.p, opt->max_gap, opt->max_gap_pre, bw, opt->max_lc_skip, opt->rmq_size_cap,
+		mga_dbuf_reserve(&P->rq_ys, (size_t)n * 4 + 64) < 0 || mga_dbuf_reserve(&P->rq_cut, (size_t)n_runs * 24 + 64) < 0 || mga_dbuf_reserve(&P->rq_ord, (size_t)n_runs * 4 + 64) < 0 ||
+		mga_dbuf_reserve(&P->rq_stat, (size_t)n_runs * 4 + 64) < 0 || mga_dbuf_reserve(&P->rq_cnt, 64) < 0 || mga_hbuf_reserve(&P->h_rqs, (size_t)n_runs * 32 + 64) < 0) return -1;
+	hs = (char*)P->h_rqs.p; /* runs | order | status through pinned staging: copies from pageable memory wait inside the runtime */
+	memcpy(hs, runs, (size_t)n_runs * 24); memcpy(hs + (size_t)n_runs * 24, order, (size_t)n_order * 4); memcpy(hs + (size_t)n_runs * 28, status, (size_t)n_runs * 4);
+	for (x = 0; x < n_reads; ++x)
+		if (mga_h2d_s(sc, (mg128_t*)P->rq_a.p + r_abs0[x], r_a[x], (size_t)r_n[x] * 16) < 0 || mga_dmemset_s(sc, (int32_t*)P->rq_t.p + r_abs0[x], 0, (size_t)r_n[x] * 4) < 0) return -1;
+	if (mga_h2d_s(sc, P->rq_cut.p, hs, (size_t)n_runs * 24) < 0 || mga_h2d_s(sc, P->rq_ord.p, hs + (size_t)n_runs * 24, (size_t)n_order * 4) < 0 ||
+		mga_h2d_s(sc, P->rq_stat.p, hs + (size_t)n_runs * 28, (size_t)n_runs * 4) < 0) return -1;
+	if (mga_dev_rmq_fwd(sc, n, (const mg128_t*)P->rq_a.p, n_order, P->rq_cut.p, (const int32_t*)P->rq_ord.p, opt->max_gap, opt->max_gap_pre, bw, opt->max_lc_skip, opt->rmq_size_cap,
 						C->pen_gap, C->pen_skip, (int32_t*)P->rq_f.p, (int64_t*)P->rq_p.p, (int32_t*)P->rq_v.p, (int32_t*)P->rq_t.p, (double*)P->rq_pri.p, (int32_t*)P->rq_ys.p,
 						(int32_t*)P->rq_stat.p, (int*)P->rq_cnt.p) < 0) return -1;
-	if (mga_d2h_s(sc, f, P->rq_f.p, (size_t)n * 4) < 0 || mga_d2h_s(sc, p, P->rq_p.p, (size_t)n * 8) < 0 || mga_d2h_s(sc, v, P->rq_v.p, (size_t)n * 4) < 0 ||
-		mga_d2h_s(sc, hs + (size_t)(n_cut + 1) * 12, P->rq_stat.p, (size_t)n_cut * 4) < 0 || mga_ssync(sc) < 0) return -1;
-	memcpy(status, hs + (size_t)(n_cut + 1) * 12, (size_t)n_cut * 4);
+	for (x = 0; x < n_reads; ++x)
+		if (mga_d2h_s(sc, r_f[x], (int32_t*)P->rq_f.p + r_abs0[x], (size_t)r_n[x] * 4) < 0 || mga_d2h_s(sc, r_p[x], (int64_t*)P->rq_p.p + r_abs0[x], (size_t)r_n[x] * 8) < 0 ||
+			mga_d2h_s(sc, r_v[x], (int32_t*)P->rq_v.p + r_abs0[x], (size_t)r_n[x] * 4) < 0) return -1;
+	if (mga_d2h_s(sc, hs + (size_t)n_runs * 28, P->rq_stat.p, (size_t)n_runs * 4) < 0 || mga_ssync(sc) < 0) return -1;
+	memcpy(status, hs + (size_t)n_runs * 28, (size_t)n_runs * 4);
 	return 0;
 }
 
 static void release_token_cb(void *a) { gpu_token_t **held = (gpu_token_t**)a; if (*held) { token_release(*held); *held = 0; } }
 
 static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs_out,
-					 const mg_mapopt_t *opt, int n_threads, const char *d_seq_res, const int64_t *q_off_res, int seqs_pinned, mga_stats_t *st, kstring_t *gaf_part, int lr_long)
+					 const mg_mapopt_t *opt, int n_threads, const char *d_seq_res, const int64_t *q_off_res, int seqs_pinned, mga_stats_t *st, kstring_t *gaf_part, int lr_long, const gaf_sink_t *sink)
 {
 	struct mg_idx_bucket_s *B = gi->B;
 	mga_sctx_t *sc = P->sc;
@@ -1172,7 +1233,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	if (dev_gc) mga_batch_set_device_chains(b, h_gchdr_p, P->h_gcpool.p, (const mg_llchain_t*)P->h_lcpool.p, need_a ? (const mg128_t*)P->h_apool.p : 0);
 	rq_dev_ctx_t rq_ctx;
 	if (long_q && n_a > 0 && env_int("MGA_DEV_RMQ", 1)) { /* -x asm (and the rescue pass of ultra-long -x lr reads): the RMQ chainer's forward passes on the device (k_rmq.hip) */
-		rq_ctx.P = P, rq_ctx.opt = opt, rq_ctx.pen_gap = b->pen_gap, rq_ctx.pen_skip = b->pen_skip;
+		rq_ctx.P = P, rq_ctx.opt = opt, rq_ctx.pen_gap = b->pen_gap, rq_ctx.pen_skip = b->pen_skip, rq_ctx.n_total = n_a;
 		CK(mga_hbuf_reserve(&P->h_rq, (size_t)((n_a + 1) & ~1LL) * 20 + 64));
 		mga_batch_set_rq_device(b, rq_dev_fwd_hook, &rq_ctx, (char*)P->h_rq.p, n_a);
 	}
@@ -1302,8 +1363,25 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	if (gaf_part) { /* GAF text of this chunk, formatted while other chunks own the GPU; the chains are freed on the way */
 		gafw_t w;
 		double tg = mga_wtime();
-		w.b = b, w.n = n, w.T = n_threads, w.part = gaf_part;
-		mga_parallel_for(n_threads, n_threads, gaf_worker, &w);
+		int direct = 0;
+		w.b = b, w.n = n, w.T = n_threads, w.part = gaf_part, w.mode = 0, w.bytes = w.off = 0, w.dst = 0;
+		if (sink && b->txt_res && env_int("MGA_GAF_DIRECT", 1)) { /* straight to the lines' place in the job's output, if this chunk is what the output waits for */
+			int64_t *bo = MGA_CALLOC(int64_t, 2 * (size_t)n_threads + 2), tot_b = 0;
+			int t_;
+			w.bytes = bo, w.off = bo + n_threads + 1, w.mode = 1;
+			mga_parallel_for(n_threads, n_threads, gaf_worker, &w);
+			for (t_ = 0; t_ < n_threads; ++t_) w.off[t_] = tot_b, tot_b += w.bytes[t_];
+			if (sink->try_reserve(sink->ctx, tot_b, &w.dst)) {
+				w.mode = 2;
+				mga_parallel_for(n_threads, n_threads, gaf_worker, &w);
+				sink->commit(sink->ctx, tot_b);
+				st->gaf_bytes += tot_b;
+				direct = 1;
+			}
+			free(bo);
+			w.mode = 0, w.bytes = w.off = 0;
+		}
+		if (!direct) mga_parallel_for(n_threads, n_threads, gaf_worker, &w);
 		for (i = 0; i < n; ++i) gcs_out[i] = 0;
 		if (g_dbg_pipe > 1) PIPE_LOG(" gaf", n, tg);
 		st->t_gaf += mga_wtime() - tg;
@@ -1419,6 +1497,33 @@ static void pipe_ctx_free(pipe_ctx_t *P)
 	memset(P, 0, sizeof *P);
 }
 
+/* the sink of a chunk's GAF lines (gaf_sink_t): room at the end of the batch's output, if every earlier chunk has been committed */
+typedef struct { sbatch_t *b; int c; } gaf_sink_ctx_t;
+static int sink_try_reserve(void *ctx_, int64_t bytes, char **dst)
+{
+	gaf_sink_ctx_t *x = (gaf_sink_ctx_t*)ctx_;
+	sbatch_t *b = x->b;
+	int ok = 0;
+	pthread_mutex_lock(&b->cmtx);
+	if (b->next_commit == x->c && !b->err) { /* nobody else can append until this chunk is marked done: the room stays where it is while the pieces are written */
+		if (b->out_len + bytes + 1 > b->out_cap) {
+			b->out_cap = (b->out_len + bytes + 1) * 3 / 2 + (1 << 20);
+			b->out = (char*)realloc(b->out, (size_t)b->out_cap);
+		}
+		*dst = b->out + b->out_len;
+		ok = 1;
+	}
+	pthread_mutex_unlock(&b->cmtx);
+	return ok;
+}
+static void sink_commit(void *ctx_, int64_t bytes)
+{
+	gaf_sink_ctx_t *x = (gaf_sink_ctx_t*)ctx_;
+	pthread_mutex_lock(&x->b->cmtx);
+	x->b->out_len += bytes; /* (commit_chunks() then marks the chunk done with empty pieces and lets the chunks behind it follow) */
+	pthread_mutex_unlock(&x->b->cmtx);
+}
+
 /* one chunk of one batch on pipeline context P; the caller holds no lock */
 static void stream_run_chunk(mga_stream_t *S, pipe_ctx_t *P, sbatch_t *b, int c)
 {
@@ -1427,9 +1532,11 @@ static void stream_run_chunk(mga_stream_t *S, pipe_ctx_t *P, sbatch_t *b, int c)
 	double tc = mga_wtime();
 	int64_t tcpu = cpu_now();
 	int rc;
+	gaf_sink_ctx_t sink_ctx = { b, c };
+	gaf_sink_t sink = { sink_try_reserve, sink_commit, &sink_ctx };
 	memset(&cst, 0, sizeof cst);
 	rc = b->err ? 0 : map_chunk(P, S->gi, en - st, b->qlens + st, b->seqs + st, b->qnames ? b->qnames + st : 0, b->gcs + st, &S->opt, b->n_threads,
-								b->d_seq, b->q_off ? b->q_off + st : 0, b->seqs_pinned, &cst, b->gaf_part ? b->gaf_part + (size_t)c * b->n_threads : 0, S->lr_long);
+								b->d_seq, b->q_off ? b->q_off + st : 0, b->seqs_pinned, &cst, b->gaf_part ? b->gaf_part + (size_t)c * b->n_threads : 0, S->lr_long, b->gaf_part ? &sink : 0);
 	PIPE_LOG("map_chunk", c, tc);
 	if (rc == 0 && b->gaf_part && !b->err) { /* the chunk's GAF text was formatted inside map_chunk(); append it to the output in read order */
 		double t0 = mga_wtime();
@@ -1820,7 +1927,7 @@ void mg_map_frag(const mg_idx_t *gi, int n_segs, const int *qlens, const char **
 		memset(&cst, 0, sizeof cst);
 		if (g_dbg_pipe < 0) { g_dbg_pipe = env_int("MGA_DEBUG_PIPE", 0); g_gpu_wfa.avail = env_int("MGA_WFA_SLOTS", 2); g_gpu_front.avail = env_int("MGA_FRONT_SLOTS", 1); }
 		rc = mga_dev_init() < 0 || mga_dev_bind_thread() < 0 || (b->P.sc == 0 && (b->P.sc = mga_sctx_create()) == 0) ? -1 : 0;
-		if (rc == 0) rc = map_chunk(&b->P, gi, 1, qlens, seqs, &qname, gcs, opt, 1, 0, 0, 0, &cst, 0, (opt->flag & MG_M_RMQ) ? 0 : lr_long_bases());
+		if (rc == 0) rc = map_chunk(&b->P, gi, 1, qlens, seqs, &qname, gcs, opt, 1, 0, 0, 0, &cst, 0, (opt->flag & MG_M_RMQ) ? 0 : lr_long_bases(), 0);
 		if (rc < 0) { fprintf(stderr, "[E::%s] %s\n", __func__, mga_last_error()); abort(); /* no CPU fallback */ }
 		pthread_mutex_lock(&g_stats_mtx); stats_merge(&gi->B->st, &cst); pthread_mutex_unlock(&g_stats_mtx);
 		return;

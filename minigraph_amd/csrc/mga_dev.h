@@ -253,9 +253,11 @@ int mga_dev_plan_fill(mga_sctx_t *sc, const mga_didx_t *ix, int n, int print_2nd
 					  const mg128_t *d_a_pool, const int64_t *d_q_off, const int64_t *d_off, const int32_t *d_rev, int64_t n_prob,
 					  mga_cigitem_t *d_item, mga_wfa_prob_t *d_prob, mga_plan_src_t *d_src, mga_txt_chain_t *d_chain, uint32_t *d_vert, char *d_tseq);
 
-/* forward pass of the RMQ chainer (mg_lchain_rmq, lchain.c:252-357) over runs of ONE read's n x-sorted anchors (k_rmq.hip): run r = [d_cut[r], d_cut[r + 1]) for the n_runs run
- * ids in d_order; d_status[r] = 0, or 1 / 2 when the host has to redo the run (tied priorities / inner window beyond the kernel's sort).  Scratch: d_t, d_ys (n int32), d_pri (n doubles) */
-int mga_dev_rmq_fwd(mga_sctx_t *sc, int64_t n, const mg128_t *d_a, int n_runs, const int64_t *d_cut, const int32_t *d_order, int max_dist, int max_dist_inner, int bw,
+/* forward pass of the RMQ chainer (mg_lchain_rmq, lchain.c:252-357) over runs of a CHUNK's x-sorted anchors (k_rmq.hip; each read's slice sorted on its own): d_runs = array of
+ * { int64 beg, end, base } (positions in d_a; base = first anchor of the run's read), taken in the order d_order lists them; d_status[r] = 0, or 1 / 2 when the host has to redo
+ * the run (tied priorities / inner window beyond the kernel's sort); p[] comes out relative to `base`.  Scratch: d_t (zeroed by the caller), d_ys (int32), d_pri (doubles) */
+typedef struct { int64_t beg, end, base; } mga_rq_run_t;
+int mga_dev_rmq_fwd(mga_sctx_t *sc, int64_t n_total, const mg128_t *d_a, int n_order, const void *d_runs, const int32_t *d_order, int max_dist, int max_dist_inner, int bw,
 					int max_skip, int cap, float pen_gap, float pen_skip, int32_t *d_f, int64_t *d_p, int32_t *d_v, int32_t *d_t, double *d_pri, int32_t *d_ys,
 					int32_t *d_status, int *d_counter);
 

@@ -374,7 +374,9 @@ def test_pipeline_knobs_do_not_change_the_output(monkeypatch):
     L = mga.load()
     for chunk, pipe, threads, extra in ((1, 4, 2, {}), (3, 2, 1, {}), (64, 1, 8, {}), (100, 3, 16, {"MGA_WFA_CONCURRENT": "1"}), (7, 4, 3, {"MGA_UPLOAD_READS": "1"}),
                                         (40, 4, 8, {"MGA_CUT": "0"}), (40, 4, 8, {"MGA_CUT": "1", "MGA_TAIL": "3"}), (64, 3, 8, {"MGA_TAIL": "2", "MGA_WFA_GRID_PCT": "50", "MGA_WFA_SLOTS": "3"}),
-                                        (50, 2, 4, {"MGA_RAMP": "0", "MGA_WFA_GRID_PCT": "1"})):
+                                        (50, 2, 4, {"MGA_RAMP": "0", "MGA_WFA_GRID_PCT": "1"}), (40, 4, 8, {"MGA_GAF_DIRECT": "0", "MGA_DEV_SPLICE": "0"}),
+                                        (23, 6, 5, {"MGA_GAF_DIRECT": "1", "MGA_DEV_SPLICE": "1", "MGA_FRONT_SLOTS": "2", "MGA_WFA_TB_SIDE": "1"}), (64, 4, 8, {"MGA_DEV_GCHAIN": "1", "MGA_DEV_SPLICE": "0"}),
+                                        (33, 8, 3, {"MGA_DEV_GCHAIN": "1", "MGA_GAF_DIRECT": "0"})):
         monkeypatch.setenv("MGA_CHUNK", str(chunk))
         monkeypatch.setenv("MGA_PIPE", str(pipe))
         for k, v in extra.items():
