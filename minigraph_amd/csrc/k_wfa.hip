@@ -305,10 +305,13 @@ static const wfa_cfg_t g_tier[3] = {
 	// x o1 e1 o2 e2   wmax   smax   cigcap   tbcap        max_iter   stride
 	{ 4, 4, 2, 15, 1,  4096,   8192,   65536,  1 << 24,    100000000, 0 },
 	{ 4, 4, 2, 15, 1, 32768,  32768, 1 << 20,  104000000,  100000000, 0 }, // tbcap just above max_iter: the cap triggers first
-	// the sub-problems of the chained fallback have no cell cap (miniwfa.c:831): last tier for them, 4 GiB of traceback per wave
-	{ 4, 4, 2, 15, 1, 131072, 131072, 1 << 21, 4LL << 30,  -1,        0 },
+	// the sub-problems of the chained fallback have no cell cap (miniwfa.c:831): last tier for them -- round 5: a million diagonals and 32 GiB of traceback for ONE problem at a
+	// time (allocated when a stretch first gets here: 33 GB of the 288), where rounds 1-4 stopped at 131 072 diagonals / 4 GiB.  The reference bounds the memory of such a stretch
+	// instead (mwf_wfa_seg, miniwfa.c:440-601: checkpoints every 5000 scores, then a second pass whose band restarts at each checkpoint) and arrives at the same CIGAR (DESIGN 4,
+	// chained fallback); a stretch beyond THIS tier -- two unrelated sequences of ~180 kb each without a shared 13-mer chain between them -- still fails loudly.
+	{ 4, 4, 2, 15, 1, 1 << 20, 1 << 20, 1 << 22, 32LL << 30,  -1,        0 },
 };
-static const int g_tier_waves[3] = { 256, 16, 2 };
+static const int g_tier_waves[3] = { 256, 16, 1 };
 
 
 extern "C" int mga_dev_wfa(mga_sctx_t *sc, const int *d_n, int n, int first, int slot, void *stream, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,

@@ -836,8 +836,10 @@ static void gaf_worker(void *data, int64_t t, int tid)
  * ---------------------------------------------------------------------------------------------- */
 #include <pthread.h>
 
+struct gpu_token_s;
 typedef struct { /* one pipeline context: HIP stream + grow-only device and pinned buffers, reused from chunk to chunk */
 	mga_sctx_t *sc;
+	struct gpu_token_s *tok_front, *tok_wfa; /* the GPU phase tokens of the stream this context belongs to (NULL: the process-wide pair -- mg_tbuf_t contexts) */
 	union {
 		struct {
 			mga_dbuf_t seq, qoff, cnt, mzoff, mz, occ, val, na, nmini, rep, aoff, minioff, a, tmp, mini, u, b, nu, nb, ws;
@@ -866,7 +868,7 @@ static int g_dbg_pipe = -1;
 /* Two pipeline threads that start together would run every stage in lockstep (both on the GPU, then both on the host).
  * One token per GPU phase staggers them: while one chunk fills gaps on the GPU, the other one's host stages run, and the
  * cheap front phase (sketch/seed/chain) of one chunk fills the tail of another chunk's WFA launches. */
-typedef struct { pthread_mutex_t m; pthread_cond_t c; int avail; } gpu_token_t;
+typedef struct gpu_token_s { pthread_mutex_t m; pthread_cond_t c; int avail; } gpu_token_t;
 static gpu_token_t g_gpu_front = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, 1 }, g_gpu_wfa = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, 1 };
 static void token_acquire(gpu_token_t *t) { pthread_mutex_lock(&t->m); while (t->avail <= 0) pthread_cond_wait(&t->c, &t->m); --t->avail; pthread_mutex_unlock(&t->m); }
 static void token_release(gpu_token_t *t) { pthread_mutex_lock(&t->m); ++t->avail; pthread_cond_signal(&t->c); pthread_mutex_unlock(&t->m); }
@@ -952,7 +954,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 	if (d_seq_res) {
 		memcpy(q_off, q_off_res, (size_t)(n + 1) * 8);
 		tot = q_off[n] - q_off[0];
-		GPU_ACQUIRE(&g_gpu_front);
+		GPU_ACQUIRE(P->tok_front ? P->tok_front : &g_gpu_front);
 		d_seq = d_seq_res;
 	} else {
 		const char *h_seq;
@@ -967,7 +969,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 			memset(h + tot, 0, 64);
 			h_seq = h;
 		}
-		GPU_ACQUIRE(&g_gpu_front);
+		GPU_ACQUIRE(P->tok_front ? P->tok_front : &g_gpu_front);
 		CK(mga_dbuf_reserve(&P->seq, (size_t)tot + 64));
 		CK(mga_h2d_s(sc, P->seq.p, h_seq, (size_t)tot + 64));
 		d_seq = (const char*)P->seq.p;
@@ -1293,7 +1295,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 			CK(mga_dmemset_s(sc, (char*)P->tseq.p + n_tb, 0, 64));
 			CK(mga_dev_plan_target_verts(sc, &B->dev, hp_prob, (const mga_wfa_prob_t*)P->prob.p + dp_prob, (const mga_plan_src_t*)P->plsrc.p + dp_prob, (const uint32_t*)P->vert.p, (char*)P->tseq.p));
 		} else CK(mga_h2d_s(sc, (char*)P->tseq.p + dp_tb, P->h_tseq.p, (size_t)hp_tb + 64));
-		GPU_ACQUIRE(&g_gpu_wfa);
+		GPU_ACQUIRE(P->tok_wfa ? P->tok_wfa : &g_gpu_wfa);
 		/* CIGAR pool: a global alignment has at most tl + ql operators, so target bases + query bases bound the chunk; + the abandoned block
 		 * tails (<= 512 ops) of every resident wave.  Sized to the bound, the pool cannot overflow whatever the divergence. */
 		pool_cap = n_tb + 4096 + 40000LL * 512 + (int64_t)ptot[5] + 4 * n_prob; /* (+ 4 per problem: k_wfa_tb reserves by an upper bound of the operator count) */
@@ -1436,6 +1438,8 @@ struct mga_stream_s {
 	mg_mapopt_t opt;
 	int n_threads, n_pipe, chunk, max_inflight;
 	int lr_long;                   /* ultra-long -x lr reads: at least this many bases (0: none); fixed when the options are set */
+	gpu_token_t tok_front, tok_wfa; /* chunks of THIS stream in their front (sketch / seeds / chaining) and WFA phase: per stream since round 5 -- a stream opened for a rank's two
+	                                 * threads after one for sixteen used to inherit the first one's counts */
 	pthread_mutex_t m;
 	pthread_cond_t c_work, c_done, c_space;
 	sbatch_t *head, *tail, *cur;   /* submitted and not yet collected (FIFO); cur = first batch that still has chunks to hand out */
@@ -1591,7 +1595,8 @@ mga_stream_t *mga_stream_open(const mg_idx_t *gi, const mg_mapopt_t *opt, int n_
 	int i;
 	if (mga_dev_init() < 0) return 0;
 	if (env_int("MGA_SEGV_TRACE", 0)) signal(SIGSEGV, segv_trace);
-	if (g_dbg_pipe < 0) { g_dbg_pipe = env_int("MGA_DEBUG_PIPE", 0); g_gpu_wfa.avail = env_int("MGA_WFA_SLOTS", 2); g_gpu_front.avail = env_int("MGA_FRONT_SLOTS", n_threads > 4 && n_threads <= 12 ? 2 : 1); /* two chunks may be in their WFA phase: the second one fills the tails of the first */ }
+	if (g_dbg_pipe < 0) { g_dbg_pipe = env_int("MGA_DEBUG_PIPE", 0); g_gpu_wfa.avail = env_int("MGA_WFA_SLOTS", 2); g_gpu_front.avail = env_int("MGA_FRONT_SLOTS", 1); }
+	const int dev_place = env_int("MGA_DEV_GCHAIN", n_threads <= 12) && !env_int("MGA_HOST_GCHAIN", 0); /* (what map_chunk decides per chunk: graph chaining on the device) */
 	g_cpu_on = g_dbg_pipe > 0;
 	S = MGA_CALLOC(mga_stream_t, 1);
 	S->gi = gi, S->opt = *opt, S->n_threads = n_threads > 0 ? n_threads : 1;
@@ -1600,7 +1605,7 @@ mga_stream_t *mga_stream_open(const mg_idx_t *gi, const mg_mapopt_t *opt, int n_
 	 * in flight, two of them in the front phase, fill those tails with other chunks' kernels -- [measured, bench workload, --placement device, 16 threads] 2.98 / 3.00 Gbp/s
 	 * (4 chunks, one in the front phase) -> 3.24 (6 / 2) -> 3.27-3.30 with the persistent WFA grids at half size; with the chaining on the host threads the same knobs stay
 	 * inside the run-to-run noise (3.51-3.60 vs 3.55-3.65) */
-	S->n_pipe = env_int("MGA_PIPE", n_threads <= 4 ? 3 : n_threads <= 12 ? 6 : 4); /* [measured, round 4, a rank pinned to 2 of 16 cores] 3 pipeline threads: 2.31 Gbp/s at 0.70 CPU-s per step, 4: 2.23 at 0.82, 2: 2.07; with 16 threads 4 is the best (3.27 vs 2.96 vs 2.51) */
+	S->n_pipe = env_int("MGA_PIPE", n_threads <= 4 ? 3 : dev_place ? 6 : 4); /* [measured, round 4, a rank pinned to 2 of 16 cores] 3 pipeline threads: 2.31 Gbp/s at 0.70 CPU-s per step, 4: 2.23 at 0.82, 2: 2.07; with 16 threads and the chaining on the host 4 is the best (3.27 vs 2.96 vs 2.51) */
 	if (S->n_pipe > MGA_MAX_PIPE) S->n_pipe = MGA_MAX_PIPE;
 	if (S->n_pipe < 1) S->n_pipe = 1;
 	S->chunk = env_int("MGA_CHUNK", 16384); /* [measured] larger launches amortise the tails of the WFA tiers: 4096 -> 8192 reads +5 %, -> 16384 another +5 % */
@@ -1608,8 +1613,13 @@ mga_stream_t *mga_stream_open(const mg_idx_t *gi, const mg_mapopt_t *opt, int n_
 	S->max_inflight = env_int("MGA_INFLIGHT", 3);
 	pthread_mutex_init(&S->m, 0); pthread_mutex_init(&S->api, 0);
 	pthread_cond_init(&S->c_work, 0); pthread_cond_init(&S->c_done, 0); pthread_cond_init(&S->c_space, 0);
-	for (i = 0; i < S->n_pipe; ++i)
+	pthread_mutex_init(&S->tok_front.m, 0); pthread_cond_init(&S->tok_front.c, 0); pthread_mutex_init(&S->tok_wfa.m, 0); pthread_cond_init(&S->tok_wfa.c, 0);
+	S->tok_wfa.avail = env_int("MGA_WFA_SLOTS", 2);                 /* two chunks may be in their WFA phase: the second one fills the tails of the first */
+	S->tok_front.avail = env_int("MGA_FRONT_SLOTS", dev_place ? 2 : 1); /* ... and with the chaining on the device two in the front phase ([measured] + 8 % at 16 threads, + 7 % at 2) */
+	for (i = 0; i < S->n_pipe; ++i) {
 		if ((S->P[i].sc = mga_sctx_create()) == 0) { while (--i >= 0) pipe_ctx_free(&S->P[i]); free(S); return 0; }
+		S->P[i].tok_front = &S->tok_front, S->P[i].tok_wfa = &S->tok_wfa;
+	}
 	return S;
 }
 

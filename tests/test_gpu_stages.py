@@ -371,6 +371,32 @@ def test_wfa_chained_fallback_matches_mwf_wfa_auto():
         assert rb.Oracle().wfa(T[i], Q[i], max_iter=100000000)[0] < 0
 
 @pytest.mark.gpu
+def test_wfa_chained_fallback_200kb_pair_at_15_percent():
+    """a 200 kb x 200 kb pair at 15 % divergence -- 4 x 10^10 cells for the plain exact pass -- equals mwf_wfa_auto(): its 1e8-cell cap sends it through
+    the chained fallback (13-mer anchors, miniwfa.c:776-822), whose stretches the reference closes in its low-memory mode and the device in its ladder (same CIGARs: DESIGN 4)"""
+    ref = rb.Ref()
+    rng = np.random.default_rng(11)
+    t = rand_seq(rng, 200000)
+    q = bytearray()
+    for c in t:
+        r = rng.random()
+        if r < 0.06:
+            q.append(int(rng.choice([x for x in b"ACGT" if x != c])))
+        elif r < 0.105:
+            continue
+        elif r < 0.15:
+            q.append(c)
+            q.append(int(rng.choice(list(b"ACGT"))))
+        else:
+            q.append(c)
+    q = bytes(q)
+    sc, cg = mga.wfa_batch([t], [q])
+    es, ec = ref.wfa(t, q)
+    assert es == sc[0] and np.array_equal(ec, cg[0])
+    assert rb.Oracle().wfa(t[:60000], q[:60000], max_iter=100000000)[0] < 0   # (already a 60 kb prefix is beyond the exact pass's cap)
+
+
+@pytest.mark.gpu
 def test_wfa_parity_ring_layout_shapes(ora):
     """the register tiers fold their window of diagonals into rings around a centre (k_wfa_r.hip): shapes that push the band to one side (short target,
     long query and the reverse: the centre moves off diagonal 0), to the window's edge (the problem leaves the tier mid-way) and across every ring
