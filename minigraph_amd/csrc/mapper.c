@@ -1438,6 +1438,7 @@ struct mga_stream_s {
 	mg_mapopt_t opt;
 	int n_threads, n_pipe, chunk, max_inflight;
 	int lr_long;                   /* ultra-long -x lr reads: at least this many bases (0: none); fixed when the options are set */
+	int job_chunks;                /* chunks the current job has been cut into so far (the ramp-up of the chunk size belongs to the job) */
 	gpu_token_t tok_front, tok_wfa; /* chunks of THIS stream in their front (sketch / seeds / chaining) and WFA phase: per stream since round 5 -- a stream opened for a rank's two
 	                                 * threads after one for sixteen used to inherit the first one's counts */
 	pthread_mutex_t m;
@@ -1605,7 +1606,7 @@ mga_stream_t *mga_stream_open(const mg_idx_t *gi, const mg_mapopt_t *opt, int n_
 	 * in flight, two of them in the front phase, fill those tails with other chunks' kernels -- [measured, bench workload, --placement device, 16 threads] 2.98 / 3.00 Gbp/s
 	 * (4 chunks, one in the front phase) -> 3.24 (6 / 2) -> 3.27-3.30 with the persistent WFA grids at half size; with the chaining on the host threads the same knobs stay
 	 * inside the run-to-run noise (3.51-3.60 vs 3.55-3.65) */
-	S->n_pipe = env_int("MGA_PIPE", n_threads <= 4 ? 3 : dev_place ? 6 : 4); /* [measured, round 4, a rank pinned to 2 of 16 cores] 3 pipeline threads: 2.31 Gbp/s at 0.70 CPU-s per step, 4: 2.23 at 0.82, 2: 2.07; with 16 threads and the chaining on the host 4 is the best (3.27 vs 2.96 vs 2.51) */
+	S->n_pipe = env_int("MGA_PIPE", dev_place && n_threads > 4 ? 6 : 4); /* round 5, a rank pinned to 2 of 16 cores, two chunks in the front phase: 4 pipeline threads 2.51 Gbp/s, 3: 2.28 (round 4, one chunk in the front phase: 3 was the better one) */ /* [measured, round 4, a rank pinned to 2 of 16 cores] 3 pipeline threads: 2.31 Gbp/s at 0.70 CPU-s per step, 4: 2.23 at 0.82, 2: 2.07; with 16 threads and the chaining on the host 4 is the best (3.27 vs 2.96 vs 2.51) */
 	if (S->n_pipe > MGA_MAX_PIPE) S->n_pipe = MGA_MAX_PIPE;
 	if (S->n_pipe < 1) S->n_pipe = 1;
 	S->chunk = env_int("MGA_CHUNK", 16384); /* [measured] larger launches amortise the tails of the WFA tiers: 4096 -> 8192 reads +5 %, -> 16384 another +5 % */
@@ -1643,22 +1644,25 @@ void mga_stream_set_opt(mga_stream_t *S, const mg_mapopt_t *opt, int n_threads) 
  * a chunk of a few hundred reads pays a pass's whole chain of launches and synchronisations for no work ([measured, bench workload] its three -K batches were cut into
  * 12 chunks, two of them of 848 and 424 reads).  MGA_TAIL=<levels>: the LAST batch ends in chunks of 1/2, 1/4, ... of a chunk (the drain of the pipeline: the last chunk
  * walks its stages with nothing behind it).  The output never depends on the cut (test_pipeline_knobs_do_not_change_the_output). */
-typedef struct { int even, ramp_first, n_tail, tail_tot, body_sz, tail_sz[8]; } cut_plan_t;
+typedef struct { int even, n_head, head_sz[8], n_tail, tail_tot, body_sz, tail_sz[8]; } cut_plan_t;
 
-static void cut_plan_init(cut_plan_t *cp, int n, int chunk, int ramp, int flags, int even, int tail_levels)
+/* job_pos: chunks the JOB has been cut into before this batch; ramp_levels: the job's first chunks are chunk >> levels, ..., chunk >> 1 (round 5: the ramp belongs to the job,
+ * not to its first batch -- the reader's first batch is a short one of 6 400 reads, so that the GPU starts early, and the ramp used to end with it) */
+static void cut_plan_init(cut_plan_t *cp, int n, int chunk, int ramp, int flags, int even, int tail_levels, int job_pos, int ramp_levels)
 {
-	int k, head = 0, body;
+	int k, used = 0, body;
 	memset(cp, 0, sizeof *cp);
 	cp->even = even, cp->body_sz = chunk;
 	if (!even) return;
 	if (ramp && (flags & MGA_SB_LAST)) for (k = 0; k < tail_levels && k < 8 && (chunk >> (k + 1)) >= 64; ++k) cp->tail_sz[cp->n_tail++] = chunk >> (k + 1), cp->tail_tot += chunk >> (k + 1);
-	if (ramp && (flags & MGA_SB_FIRST)) head = chunk / 4 + chunk / 2, cp->ramp_first = 1;
-	if (n < head + cp->tail_tot + chunk / 2) { /* too small for both ramps: keep the one that fits, or equal chunks only */
-		if (cp->ramp_first && n >= head + chunk / 2) cp->n_tail = 0, cp->tail_tot = 0;
-		else if (cp->n_tail > 0 && n >= cp->tail_tot + chunk / 2) head = 0, cp->ramp_first = 0;
-		else head = 0, cp->ramp_first = 0, cp->n_tail = 0, cp->tail_tot = 0;
+	if (n < cp->tail_tot + chunk / 2) cp->n_tail = 0, cp->tail_tot = 0; /* too small for a tapered end */
+	if (ramp_levels > 8) ramp_levels = 8;
+	for (k = job_pos; ramp && k < ramp_levels; ++k) { /* the ramp pieces that are still due, as long as something of the batch is left behind them */
+		const int sz = chunk >> (ramp_levels - k);
+		if (sz < 1 || n - used - cp->tail_tot < sz + sz / 2) break;
+		cp->head_sz[cp->n_head++] = sz, used += sz;
 	}
-	body = n - head - cp->tail_tot;
+	body = n - used - cp->tail_tot;
 	if (body > 0) { const int nc = (body + chunk - 1) / chunk; cp->body_sz = (body + nc - 1) / nc; }
 }
 
@@ -1673,10 +1677,8 @@ static int cut_plan_size(const cut_plan_t *cp, int chunk, int ramp, int flags, i
 		}
 		return sz;
 	}
-	sz = cp->body_sz;
-	if (cp->ramp_first && m == 0) sz = chunk / 4;
-	else if (cp->ramp_first && m == 1) sz = chunk / 2;
-	if (cp->n_tail > 0) {
+	sz = m < cp->n_head ? cp->head_sz[m] : cp->body_sz;
+	if (cp->n_tail > 0 && m >= cp->n_head) {
 		if (left <= cp->tail_tot) { /* in the tail: the largest run of tail pieces that fits; what a base-capped chunk before left over is absorbed by this piece */
 			for (k = 0, suf = cp->tail_tot; k < cp->n_tail && suf > left; ++k) suf -= cp->tail_sz[k];
 			sz = k < cp->n_tail ? cp->tail_sz[k] + (left - suf) : left;
@@ -1686,12 +1688,12 @@ static int cut_plan_size(const cut_plan_t *cp, int chunk, int ramp, int flags, i
 }
 
 /* (tests) the read counts of the chunks a batch of n reads of equal length is cut into; returns their number */
-int mga_debug_cut(int n, int chunk, int flags, int even, int tail_levels, int *sizes, int max_sizes)
+int mga_debug_cut2(int n, int chunk, int flags, int even, int tail_levels, int job_pos, int ramp_levels, int *sizes, int max_sizes)
 {
 	cut_plan_t cp;
 	int pos = 0, m = 0;
 	const int ramp = n > 6 * chunk || (flags & (MGA_SB_FIRST | MGA_SB_LAST)) != (MGA_SB_FIRST | MGA_SB_LAST);
-	cut_plan_init(&cp, n, chunk, ramp, flags, even, tail_levels);
+	cut_plan_init(&cp, n, chunk, ramp, flags, even, tail_levels, job_pos, ramp_levels);
 	while (pos < n) {
 		int sz = cut_plan_size(&cp, chunk, ramp, flags, m, n - pos);
 		if (sz < 1) sz = 1;
@@ -1701,6 +1703,8 @@ int mga_debug_cut(int n, int chunk, int flags, int even, int tail_levels, int *s
 	}
 	return m;
 }
+/* (the round-4 ramp: chunk / 4 and chunk / 2 at the head of the job's first batch) */
+int mga_debug_cut(int n, int chunk, int flags, int even, int tail_levels, int *sizes, int max_sizes) { return mga_debug_cut2(n, chunk, flags, even, tail_levels, (flags & MGA_SB_FIRST) ? 0 : 2, 2, sizes, max_sizes); }
 
 static void batch_cut(mga_stream_t *S, sbatch_t *b)
 {
@@ -1711,7 +1715,10 @@ static void batch_cut(mga_stream_t *S, sbatch_t *b)
 	const int64_t base_cap = (S->opt.flag & MG_M_RMQ) ? INT64_MAX : (int64_t)chunk * env_int("MGA_CHUNK_READ_BASES", 12288); /* (-x asm: a batch is a handful of contigs chained in phases over ALL of them) */
 	int pos = 0, m = 0, cap = n / (chunk / 16 > 0 ? chunk / 16 : 1) + 16;
 	cut_plan_t cp;
-	cut_plan_init(&cp, n, chunk, ramp, b->flags, env_int("MGA_CUT", 1), env_int("MGA_TAIL", 1));
+	{ /* MGA_JOBRAMP=<levels> (default 3): the job's first chunks are chunk/8, chunk/4, chunk/2, whatever batches they fall into; 0: the round-4 rule (chunk/4, chunk/2 in the first batch) */
+		const int lv = env_int("MGA_JOBRAMP", 3);
+		cut_plan_init(&cp, n, chunk, ramp, b->flags, env_int("MGA_CUT", 1), env_int("MGA_TAIL", 1), lv > 0 ? S->job_chunks : ((b->flags & MGA_SB_FIRST) ? 0 : 2), lv > 0 ? lv : 2);
+	}
 	b->cstart = MGA_MALLOC(int, cap + 1);
 	while (pos < n) {
 		int sz = cut_plan_size(&cp, chunk, ramp, b->flags, m, n - pos), left = n - pos, k;
@@ -1733,6 +1740,7 @@ static void batch_cut(mga_stream_t *S, sbatch_t *b)
 	}
 	b->cstart[m] = n;
 	b->n_chunks = m;
+	S->job_chunks += m;
 }
 
 /* Queue a batch.  Everything passed in is BORROWED until the batch has been collected.  gcs != NULL: chain mode (results in gcs[]);
@@ -1748,6 +1756,7 @@ int mga_stream_submit(mga_stream_t *S, int n, const int *qlens, const char **seq
 	b->n_threads = S->n_threads;
 	if (gcs) b->gcs = gcs; else b->gcs = MGA_CALLOC(mg_gchains_t*, n > 0 ? n : 1), b->own_gcs = 1;
 	for (i = 0; i < n; ++i) b->gcs[i] = 0;
+	if (flags & MGA_SB_FIRST) S->job_chunks = 0; /* a new job: its ramp starts over (batches are submitted by one thread) */
 	batch_cut(S, b);
 	if (want_gaf) { b->gaf_part = MGA_CALLOC(kstring_t, (size_t)(b->n_chunks > 0 ? b->n_chunks : 1) * b->n_threads); b->done = MGA_CALLOC(char, b->n_chunks > 0 ? b->n_chunks : 1); }
 	pthread_mutex_init(&b->cmtx, 0);

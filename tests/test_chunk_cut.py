@@ -43,3 +43,25 @@ def test_equal_chunks_and_ramps_at_bench_sizes():
     # a job that is one small batch is not ramped
     assert cut(40000, 16384, FIRST | LAST) == [13334, 13334, 13332]
     assert cut(257, 16384, FIRST | LAST) == [257]
+
+
+def cut2(n, chunk, flags, job_pos, levels, even=1, tail=1):
+    L = mga.load()
+    L.mga_debug_cut2.restype = C.c_int
+    a = (C.c_int * 8192)()
+    m = L.mga_debug_cut2(n, chunk, flags, even, tail, job_pos, levels, a, 8192)
+    return list(a[:m])
+
+
+def test_the_ramp_belongs_to_the_job_not_to_its_first_batch():
+    """round 5: the reader's first batch is a short one (6 400 reads: the GPU starts while the second batch is parsed) -- the ramp of small first chunks continues in the next
+    batch instead of ending with the first"""
+    assert cut2(6400, 16384, FIRST, 0, 3) == [2048, 4352]                 # chunk/8, then what is left (chunk/4 would leave too little behind it)
+    assert cut2(50000, 16384, 0, 2, 3) == [8192, 13936, 13936, 13936]      # two chunks of the job are out: chunk/2 is still due
+    assert cut2(50000, 16384, 0, 3, 3) == [12500] * 4                      # the ramp is over
+    assert cut2(125000, 16384, FIRST | LAST, 0, 3)[:3] == [2048, 4096, 8192]
+    for n in (1, 100, 5000, 6400, 20000, 50000, 1000003):
+        for pos in range(0, 5):
+            for flags in (0, FIRST, LAST, FIRST | LAST):
+                c = cut2(n, 16384, flags, pos, 3, tail=3)
+                assert sum(c) == n and min(c) >= 1 and max(c) <= 16384, (n, pos, flags, c)
