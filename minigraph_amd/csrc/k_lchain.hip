@@ -376,41 +376,174 @@ __device__ void lc_backtrack_compact(const mg128_t *a, int32_t n, int32_t min_sc
 	*n_u_ = n_u, *n_v_ = n_v;
 }
 
-// d_flag[r]: 0 = chains of the first pass; 1 = long-join rescue applied on the device; 2 = rescue due, left to the host
-__global__ void __launch_bounds__(64) k_lchain(int n_reads, const mg128_t *__restrict__ a_all, const int64_t *__restrict__ a_off, mga_lchain_par_t P,
-											   lc_rescue_t R, const int64_t *__restrict__ q_off,
-											   uint64_t *__restrict__ u_all, mg128_t *__restrict__ b_all, int32_t *__restrict__ d_nu, int32_t *__restrict__ d_nb,
-											   int32_t *__restrict__ d_flag, int32_t *__restrict__ ws_i32, mg128_t *__restrict__ ws_z, mg128_t *__restrict__ ws_keep,
-											   const int32_t *__restrict__ order)
+// ---------------- first-pass DP for TWO reads per wavefront (round 5) ----------------
+// lc_dp() gives a read all 64 lanes, but the predecessor scan of an anchor visits 26 predecessors on average before the skip heuristic cuts it ([measured, hchain.c's counters on
+// 600 bench-like reads] 11 % of the anchors visit <= 16, 87 % 17-32, none more) and the kernel is bound by the instructions a wavefront issues per anchor, vector and scalar
+// alike (SQ counters, round 4: 111 k vector + 95 k scalar instructions per read, 72 % of a wave's cycles waiting): half of every vector instruction's lanes and all of the scalar
+// stream serve one read.  Here lanes 0-31 take one read and lanes 32-63 another, SIMT style: the same code, every "scalar" a per-lane value that is uniform inside its group of
+// 32, blocks of 32 predecessors, scans / ballots / shuffles confined to the group (rows of 16 + one row broadcast; masks of 32 bits).  The replay of the sequential heuristics
+// is the one of lc_dp() -- it carries max_f, the skip counter and the cut from block to block, so the block size cannot change a result.
+#define LC_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
+#define LC_SCAN32(name, OP) \
+	__device__ __forceinline__ int32_t name(int32_t v, const int32_t ident) \
+	{ \
+		int32_t t; \
+		t = __builtin_amdgcn_update_dpp(ident, v, 0x111, 0xf, 0xf, false); v = OP(v, t); \
+		t = __builtin_amdgcn_update_dpp(ident, v, 0x112, 0xf, 0xf, false); v = OP(v, t); \
+		t = __builtin_amdgcn_update_dpp(ident, v, 0x114, 0xf, 0xf, false); v = OP(v, t); \
+		t = __builtin_amdgcn_update_dpp(ident, v, 0x118, 0xf, 0xf, false); v = OP(v, t); \
+		t = __builtin_amdgcn_update_dpp(ident, v, 0x142, 0xa, 0xf, false); v = OP(v, t); /* row_bcast:15 into rows 1 and 3: the upper row of either half */ \
+		return v; \
+	}
+LC_SCAN32(lc_scan32_add, LC_OP_ADD)
+LC_SCAN32(lc_scan32_min, LC_OP_MIN)
+LC_SCAN32(lc_scan32_max, LC_OP_MAX)
+__device__ __forceinline__ uint32_t lcg_ballot(bool x, int grp) { return (uint32_t)(__ballot(x) >> (grp * 32)); } // the group's 32 bits (lanes of the other group that are off contribute nothing anyway)
+__device__ __forceinline__ int32_t lcg_prev_lane(int32_t v, int32_t first, int32_t m_first) // lane l <- v[l - 1] inside the group; its first lane <- first (select by mask: a lane that branches around a DPP move is not read by it)
 {
-	__shared__ klib_lds_t L;
-	const int lane = threadIdx.x;
-	if ((int)blockIdx.x >= n_reads) return;
-	const int r = order ? __builtin_amdgcn_readfirstlane(order[blockIdx.x]) : (int)blockIdx.x; // workgroups are dispatched in index order: the reads with the most anchors first (mapper.c)
+	const int32_t t = __builtin_amdgcn_update_dpp(first, v, 0x138, 0xf, 0xf, false);
+	return (m_first & first) | (~m_first & t);
+}
+__device__ __forceinline__ int lcg_skip_replay(bool improve, bool hit, int32_t max_skip, int32_t *n_skip, int grp) // lc_skip_replay() over a group's block of 32; returns the cut's lane in the group (32: none)
+{
+	const int32_t d = improve ? -1 : hit ? 1 : 0;
+	const int32_t S = lc_scan32_add(d, 0) + *n_skip;
+	const int32_t M = lc_scan32_min(S, 0x7fffffff);
+	const int32_t nk = S - (M < 0 ? M : 0);
+	const uint32_t m_cut = lcg_ballot(hit && !improve && nk > max_skip, grp);
+	if (m_cut) return (int)__builtin_ctz(m_cut);
+	*n_skip = __shfl(nk, grp * 32 + 31);
+	return 32;
+}
+
+__device__ void lc_dp2(const mg128_t *__restrict__ a, int32_t n, mga_lchain_par_t P, lc_ws_t W, int lane)
+{
+	int32_t *f = W.f, *p = W.p, *v = W.v, *t = W.t;
+	const int grp = lane >> 5, gl = lane & 31, g0 = grp * 32;
+	const int32_t m_first = gl == 0 ? -1 : 0;
+	for (int32_t i = gl; i < n; i += 32) t[i] = 0;
+	LC_FENCE();
+	int32_t st = 0, max_ii = -1;
+	for (int32_t i = 0; i < n; ++i) {
+		{ // a leading run of anchors without any predecessor in reach (see lc_dp)
+			const int32_t k = i + gl;
+			bool iso = false;
+			uint64_t yk = 0;
+			if (k < n) {
+				const uint64_t xk = a[k].x;
+				yk = a[k].y;
+				if (k == 0) iso = true;
+				else { const uint64_t xp = a[k - 1].x; iso = xk >> 32 != xp >> 32 || xk > xp + (uint64_t)(int64_t)P.max_dist_x; }
+			}
+			const uint32_t m = lcg_ballot(iso, grp);
+			const int r = (~m) ? (int)__builtin_ctz(~m) : 32;
+			if (r > 0) {
+				if (gl < r) { const int32_t sp = (int32_t)(yk >> 32 & 0xff); f[k] = sp, p[k] = -1, v[k] = sp; }
+				max_ii = i + r - 1;
+				if (st < i + r - 1) st = i + r - 1;
+				i += r - 1;
+				LC_FENCE();
+				continue;
+			}
+		}
+		const uint64_t xi = a[i].x, yi = a[i].y;
+		uint64_t xs0 = st < i ? a[st].x : 0;
+		mg128_t am; am.x = am.y = 0;
+		int32_t fm = 0, vm = 0;
+		if (max_ii >= 0) am = a[max_ii], fm = f[max_ii], vm = v[max_ii];
+		while (st < i) { // lchain.c:171
+			if (xi >> 32 != xs0 >> 32 || xi > xs0 + (uint64_t)(int64_t)P.max_dist_x) { ++st; if (st < i) xs0 = a[st].x; } else break;
+		}
+		if (i - st > P.max_iter) st = i - P.max_iter;
+		int32_t max_f = (int32_t)(yi >> 32 & 0xff), max_j = -1, max_v = 0, n_skip = 0, end_j = st - 1;
+		bool cut = false;
+		for (int32_t j0 = i - 1; j0 >= st && !cut; j0 -= 32) {
+			const int32_t j = j0 - gl;
+			const bool act = j >= st;
+			int32_t sc = LC_NONE, pj = -1, vj = 0;
+			if (act) {
+				const mg128_t aj = a[j];
+				const int32_t fj = f[j];
+				pj = p[j], vj = v[j];
+				sc = lc_score(xi, yi, aj.x, aj.y, P);
+				if (sc != LC_NONE) sc += fj; else pj = -1;
+			}
+			const bool valid = sc != LC_NONE;
+			if (valid && pj >= 0) t[pj] = i; // lchain.c:188 (harmless beyond the cut: only compared against this i)
+			LC_FENCE();
+			const bool hit_t = valid && t[j] == i;
+			const int32_t pm = lc_scan32_max(valid ? sc : INT32_MIN, INT32_MIN);
+			int32_t ex = lcg_prev_lane(pm, INT32_MIN, m_first);
+			if (ex < max_f) ex = max_f;
+			const bool improve = valid && sc > ex;
+			const uint32_t m_imp = lcg_ballot(improve, grp);
+			const int cut_lane = lcg_skip_replay(improve, hit_t && !improve, P.max_skip, &n_skip, grp);
+			const uint32_t before = cut_lane == 32 ? ~0u : (1u << cut_lane) - 1u;
+			const uint32_t imp_b = m_imp & before;
+			if (imp_b) {
+				const int bl = 31 - (int)__builtin_clz(imp_b);
+				max_f = __shfl(sc, g0 + bl), max_v = __shfl(vj, g0 + bl), max_j = j0 - bl;
+			}
+			if (cut_lane < 32) { cut = true; end_j = j0 - cut_lane; }
+			LC_FENCE();
+		}
+		// lchain.c:191-196: best-scoring anchor within reach, recomputed when it fell out of range
+		if (max_ii < 0 || xi - am.x > (uint64_t)(int64_t)P.max_dist_x) {
+			int32_t bf = INT32_MIN, bj = -1;
+			for (int32_t j = i - 1 - gl; j >= st; j -= 32) { const int32_t fj = f[j]; if (bf < fj) bf = fj, bj = j; } // descending j per lane: first max kept
+			for (int d = 16; d > 0; d >>= 1) {
+				const int32_t of = __shfl_xor(bf, d), oj = __shfl_xor(bj, d);
+				if (of > bf || (of == bf && oj > bj)) bf = of, bj = oj; // ties: the larger j was met first
+			}
+			max_ii = bj;
+			if (max_ii >= 0) am = a[max_ii], fm = f[max_ii], vm = v[max_ii];
+		}
+		if (max_ii >= 0 && max_ii < end_j) { // lchain.c:197-201
+			const int32_t tmp = lc_score(xi, yi, am.x, am.y, P);
+			if (tmp != LC_NONE && max_f < tmp + fm) max_f = tmp + fm, max_j = max_ii, max_v = vm;
+		}
+		int32_t vi = max_f;
+		if (max_j >= 0 && max_v > max_f) vi = max_v;
+		if (gl == 0) { f[i] = max_f; p[i] = max_j; v[i] = vi; }
+		if (max_ii < 0 || (xi - am.x <= (uint64_t)(int64_t)P.max_dist_x && fm < max_f)) max_ii = i;
+		LC_FENCE();
+	}
+}
+
+// per read: where its anchors and workspace lie, its parameters (map-algo.c:383-386: the reference gap depends on the read's length when -F is given)
+struct lc_read_t { const mg128_t *a; int32_t n; lc_ws_t W; uint64_t *u; mg128_t *b; int64_t off; mga_lchain_par_t P; };
+__device__ __forceinline__ void lc_read_setup(int r, const mg128_t *a_all, const int64_t *a_off, mga_lchain_par_t P, const lc_rescue_t &R, const int64_t *q_off,
+											   uint64_t *u_all, mg128_t *b_all, int32_t *ws_i32, mg128_t *ws_z, lc_read_t *o)
+{
 	const int64_t off = a_off[r];
 	const int32_t n = (int32_t)(a_off[r + 1] - off);
-	if (lane == 0 && d_flag) d_flag[r] = 0;
-	if (n == 0) { if (lane == 0) d_nu[r] = 0, d_nb[r] = 0; return; }
-	const mg128_t *a = a_all + off;
-	lc_ws_t W;
-	W.f = ws_i32 + off * 4, W.p = W.f + n, W.v = W.p + n, W.t = W.v + n; // 4 int32 per anchor
-	W.z = ws_z + off;                                                     // 1 mg128 per anchor
-	uint64_t *u = u_all + off;
-	mg128_t *b = b_all + off;
-	if (R.frag_len > 0 && q_off) { // map-algo.c:383-386: max_chain_gap_ref depends on the read's length when -F is given
+	o->off = off, o->n = n, o->a = a_all + off;
+	o->W.f = ws_i32 + off * 4, o->W.p = o->W.f + n, o->W.v = o->W.p + n, o->W.t = o->W.v + n; // 4 int32 per anchor
+	o->W.z = ws_z + off;                                                                   // 1 mg128 per anchor
+	o->u = u_all + off, o->b = b_all + off;
+	if (R.frag_len > 0 && q_off) {
 		const int32_t g = R.frag_len - (int32_t)(q_off[r + 1] - q_off[r]);
 		P.max_dist_x = g > R.frag_min_gap ? g : R.frag_min_gap;
 	}
 	if (P.max_dist_x < P.bw) P.max_dist_x = P.bw;
 	if (P.max_dist_y < P.bw) P.max_dist_y = P.bw;
+	o->P = P;
+}
 
+// everything behind the first-pass DP of read r: backtrack + compaction, the long-join rescue (map-algo.c:407-417), the read's counts and flag.  The whole wavefront, one read.
+__device__ void lc_read_finish(int r, const lc_read_t &X, const lc_rescue_t &R, const int64_t *__restrict__ q_off, int32_t *__restrict__ d_nu, int32_t *__restrict__ d_nb,
+							   int32_t *__restrict__ d_flag, mg128_t *__restrict__ ws_keep, klib_lds_t *L, int lane, long long &tick_)
+{
+	const mg128_t *a = X.a;
+	const int32_t n = X.n;
+	const lc_ws_t W = X.W;
+	uint64_t *u = X.u;
+	mg128_t *b = X.b;
+	const int64_t off = X.off;
+	const mga_lchain_par_t &P = X.P;
 	int32_t n_u = 0, n_v = 0;
-	long long tick_ = g_lc_prof_on ? (long long)clock64() : 0;
-	lc_dp(a, n, P, W, lane);
-	LC_TICK(0);
-	lc_backtrack_compact(a, n, P.min_sc, P.min_cnt, P.bw, W, u, b, &n_u, &n_v, &L, lane);
+	lc_backtrack_compact(a, n, P.min_sc, P.min_cnt, P.bw, W, u, b, &n_u, &n_v, L, lane);
 	LC_TICK(1);
-
 	// ---- long-join rescue (map-algo.c:407-417) ----
 	if (R.enabled && n_u > 1 && q_off) {
 		const int32_t qlen = (int32_t)(q_off[r + 1] - q_off[r]);
@@ -427,7 +560,7 @@ __global__ void __launch_bounds__(64) k_lchain(int n_reads, const mg128_t *__res
 			for (int32_t i = lane; i < n_v; i += 64) keep[i] = b[i];
 			for (int32_t i = lane; i < n_u; i += 64) keep_u[i] = u[i];
 			__syncthreads();
-			klib_sort128x(b, n_v, W.t, &L); // all chained anchors, by x (n_v = sum of the chain sizes)
+			klib_sort128x(b, n_v, W.t, L); // all chained anchors, by x (n_v = sum of the chain sizes)
 			__syncthreads();
 			LC_TICK(2);
 			int32_t n_u2 = 0, n_v2 = 0;
@@ -436,7 +569,7 @@ __global__ void __launch_bounds__(64) k_lchain(int n_reads, const mg128_t *__res
 			LC_TICK(3);
 			if (rq_ok) {
 				// mg_lchain_rmq backtracks with max_drop = its bw (lchain.c:267,359); the anchors are read from b, the result overwrites b
-				lc_backtrack_compact(b, n_a, R.min_sc, R.min_cnt, R.bw, W, u, b, &n_u2, &n_v2, &L, lane);
+				lc_backtrack_compact(b, n_a, R.min_sc, R.min_cnt, R.bw, W, u, b, &n_u2, &n_v2, L, lane);
 				LC_TICK(4);
 				n_u = n_u2, n_v = n_v2;
 				if (lane == 0 && d_flag) d_flag[r] = 1;
@@ -449,6 +582,63 @@ __global__ void __launch_bounds__(64) k_lchain(int n_reads, const mg128_t *__res
 		}
 	}
 	if (lane == 0) { d_nu[r] = n_u; d_nb[r] = n_v; }
+}
+
+// d_flag[r]: 0 = chains of the first pass; 1 = long-join rescue applied on the device; 2 = rescue due, left to the host
+__global__ void __launch_bounds__(64) k_lchain(int n_reads, const mg128_t *__restrict__ a_all, const int64_t *__restrict__ a_off, mga_lchain_par_t P,
+											   lc_rescue_t R, const int64_t *__restrict__ q_off,
+											   uint64_t *__restrict__ u_all, mg128_t *__restrict__ b_all, int32_t *__restrict__ d_nu, int32_t *__restrict__ d_nb,
+											   int32_t *__restrict__ d_flag, int32_t *__restrict__ ws_i32, mg128_t *__restrict__ ws_z, mg128_t *__restrict__ ws_keep,
+											   const int32_t *__restrict__ order)
+{
+	__shared__ klib_lds_t L;
+	const int lane = threadIdx.x;
+	if ((int)blockIdx.x >= n_reads) return;
+	const int r = order ? __builtin_amdgcn_readfirstlane(order[blockIdx.x]) : (int)blockIdx.x; // workgroups are dispatched in index order: the reads with the most anchors first (mapper.c)
+	if (lane == 0 && d_flag) d_flag[r] = 0;
+	lc_read_t X;
+	lc_read_setup(r, a_all, a_off, P, R, q_off, u_all, b_all, ws_i32, ws_z, &X);
+	if (X.n == 0) { if (lane == 0) d_nu[r] = 0, d_nb[r] = 0; return; }
+	long long tick_ = g_lc_prof_on ? (long long)clock64() : 0;
+	lc_dp(X.a, X.n, X.P, X.W, lane);
+	LC_TICK(0);
+	lc_read_finish(r, X, R, q_off, d_nu, d_nb, d_flag, ws_keep, &L, lane, tick_);
+}
+
+// the same, TWO reads per wavefront in the first-pass DP (lc_dp2), one after the other in everything behind it
+__global__ void __launch_bounds__(64) k_lchain2(int n_reads, const mg128_t *__restrict__ a_all, const int64_t *__restrict__ a_off, mga_lchain_par_t P,
+												lc_rescue_t R, const int64_t *__restrict__ q_off,
+												uint64_t *__restrict__ u_all, mg128_t *__restrict__ b_all, int32_t *__restrict__ d_nu, int32_t *__restrict__ d_nb,
+												int32_t *__restrict__ d_flag, int32_t *__restrict__ ws_i32, mg128_t *__restrict__ ws_z, mg128_t *__restrict__ ws_keep,
+												const int32_t *__restrict__ order)
+{
+	__shared__ klib_lds_t L;
+	const int lane = threadIdx.x, grp = lane >> 5;
+	const int k0 = 2 * (int)blockIdx.x;
+	if (k0 >= n_reads) return;
+	const int ra = order ? __builtin_amdgcn_readfirstlane(order[k0]) : k0;
+	const int rb = k0 + 1 < n_reads ? (order ? __builtin_amdgcn_readfirstlane(order[k0 + 1]) : k0 + 1) : -1; // (neighbours in the launch order: about the same number of anchors)
+	if (lane == 0 && d_flag) { d_flag[ra] = 0; if (rb >= 0) d_flag[rb] = 0; }
+	long long tick_ = g_lc_prof_on ? (long long)clock64() : 0;
+	{ // the two first-pass DPs side by side: each half of the wavefront sets up and runs its own read
+		const int my = grp == 0 ? ra : rb;
+		if (my >= 0) {
+			lc_read_t X;
+			lc_read_setup(my, a_all, a_off, P, R, q_off, u_all, b_all, ws_i32, ws_z, &X);
+			if (X.n > 0) lc_dp2(X.a, X.n, X.P, X.W, lane);
+		}
+	}
+	__syncthreads(); // (both halves are through: what follows is the whole wavefront's, read by read)
+	LC_TICK(0);
+	for (int q = 0; q < 2; ++q) {
+		const int r = q == 0 ? ra : rb;
+		if (r < 0) break;
+		lc_read_t X;
+		lc_read_setup(r, a_all, a_off, P, R, q_off, u_all, b_all, ws_i32, ws_z, &X);
+		if (X.n == 0) { if (lane == 0) d_nu[r] = 0, d_nb[r] = 0; continue; }
+		lc_read_finish(r, X, R, q_off, d_nu, d_nb, d_flag, ws_keep, &L, lane, tick_);
+		__syncthreads();
+	}
 }
 
 extern "C" size_t mga_dev_lchain_ws_bytes(int64_t total_anchors) { return (size_t)(total_anchors + 16) * 56; }
@@ -483,7 +673,11 @@ extern "C" int mga_dev_lchain(mga_sctx_t *sc, int n, const mg128_t *d_a, const i
 		}
 	}
 	mga_prof_begin(sc->stream, MGA_K_LCHAIN);
-	hipLaunchKernelGGL(k_lchain, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, R, d_q_off, d_u, d_b, d_nu, d_nb, d_flag, ws_i32, ws_z, ws_keep, d_order);
+	{
+		const char *e_pair = getenv("MGA_LC_PAIR"); // (read per launch) 0: one read per wavefront in the first-pass DP as well (rounds 1-4)
+		if (e_pair && atoi(e_pair) == 0) hipLaunchKernelGGL(k_lchain, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, R, d_q_off, d_u, d_b, d_nu, d_nb, d_flag, ws_i32, ws_z, ws_keep, d_order);
+		else hipLaunchKernelGGL(k_lchain2, dim3((n + 1) / 2), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, R, d_q_off, d_u, d_b, d_nu, d_nb, d_flag, ws_i32, ws_z, ws_keep, d_order);
+	}
 	mga_prof_end(sc->stream, MGA_K_LCHAIN);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;
