@@ -674,8 +674,12 @@ extern "C" int mga_dev_lchain(mga_sctx_t *sc, int n, const mg128_t *d_a, const i
 	}
 	mga_prof_begin(sc->stream, MGA_K_LCHAIN);
 	{
-		const char *e_pair = getenv("MGA_LC_PAIR"); // (read per launch) 0: one read per wavefront in the first-pass DP as well (rounds 1-4)
-		if (e_pair && atoi(e_pair) == 0) hipLaunchKernelGGL(k_lchain, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, R, d_q_off, d_u, d_b, d_nu, d_nb, d_flag, ws_i32, ws_z, ws_keep, d_order);
+		// [measured, round 5, bench workload, isolated pass / pipelined step, two interleaved repetitions] two reads per wavefront in the first-pass DP: 79.8 ms and 3.59-3.66
+		// Gbp/s against 67.0 ms and 3.74-3.76 with one -- bit-identical (every chaining test and the e2e sweep pass in both forms), but a launch lasts as long as its longest
+		// wavefront, and a wavefront that backtracks and rescues TWO reads one after the other behind a DP that lasts as long as the longer of the two is 1.5 x the longest read.
+		// Kept as MGA_LC_PAIR=1 (the parity tests run it), not the default.
+		const char *e_pair = getenv("MGA_LC_PAIR");
+		if (!(e_pair && atoi(e_pair) > 0)) hipLaunchKernelGGL(k_lchain, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, R, d_q_off, d_u, d_b, d_nu, d_nb, d_flag, ws_i32, ws_z, ws_keep, d_order);
 		else hipLaunchKernelGGL(k_lchain2, dim3((n + 1) / 2), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, R, d_q_off, d_u, d_b, d_nu, d_nb, d_flag, ws_i32, ws_z, ws_keep, d_order);
 	}
 	mga_prof_end(sc->stream, MGA_K_LCHAIN);
