@@ -93,8 +93,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 	int32_t st = WFW_IDLE, pi = -1, tl = 0, ql = 0, lo = 0, e = 0, s = 0, bnd = 0, lst = 0, ph = 0;
 	int32_t okv[J];               // all ones where this lane's diagonal exists in the matrix (-tl <= d <= ql)
 	uint32_t acc[J];              // traceback bytes of the last (up to) four steps
-	uint32_t *tbp = 0;            // this lane's dword in the current traceback row (slot j: + 256 j dwords: 16 tiles of 4 diagonals further)
-	int32_t trow = 0;             // the problem's current traceback row
+	uint32_t *tbp = 0;            // this lane's dword in the current traceback row (slot j: + 64 j)
 	int32_t it_cur = 0;           // the problem's place in the work list = its traceback region
 	int32_t H[J][18], E1[J][3], F1[J][3], E2[J][2], F2[J][2];
 	int32_t t = 0;                // steps this wavefront has made (all groups advance together)
@@ -128,7 +127,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 					if (t & 3) {
 						const int32_t rr = wfw_reach(s + 1), d0 = lo + gl;
 #pragma unroll
-						for (int j = 0; j < J; ++j) { const int32_t d = d0 + 64 * j; if ((d < 0 ? -d : d) <= rr) tbp[256 * j] = acc[j] << (8 * (4 - (t & 3))); }
+						for (int j = 0; j < J; ++j) { const int32_t d = d0 + 64 * j; if ((d < 0 ? -d : d) <= rr) tbp[64 * j] = acc[j] << (8 * (4 - (t & 3))); }
 					}
 					if (st == WFW_DONE) {
 						mga_wfa_res_t r;
@@ -175,7 +174,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 						pi = dsc_pi[src];
 						ntl = pb.tl, nql = pb.ql, ts = tseq + pb.t_off, qs = qseq + pb.q_off;
 						it_cur = item;
-						tbp = (uint32_t*)(tb + (long long)item * tb_stride) + (gl >> 2) * 16 + (gl & 3), trow = 0; // (tiles of 4 diagonals x 4 rows: see wfw_tb_byte)
+						tbp = (uint32_t*)(tb + (long long)item * tb_stride) + gl;
 						ph = t & 3, s = 0, lst = 0, e = nql - ntl;
 						if (ntl > SEQCAP || nql > SEQCAP) bnd = 0, ntl = nql = 0; // too long for this tier's LDS: gives up at once
 						else { bnd = wfw_window(W, ntl, nql, &lo, WFW_SMAX); if (bnd > W + 30) bnd = W + 30; } // (W + 30 bounds every window's B; the traceback rows are sized for it)
@@ -321,10 +320,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 				// traceback per 125 000 reads, a byte per cell of the whole window; the reachable part is about half of it in the rungs of 64 diagonals and more.
 				const int32_t rr = wfw_reach(s + 1), d0 = lo + gl;
 #pragma unroll
-				for (int j = 0; j < J; ++j) { const int32_t d = d0 + 64 * j; if ((d < 0 ? -d : d) <= rr) tbp[256 * j] = acc[j]; }
+				for (int j = 0; j < J; ++j) { const int32_t d = d0 + 64 * j; if ((d < 0 ? -d : d) <= rr) tbp[64 * j] = acc[j]; }
 			}
-			tbp += (trow & 3) == 3 ? 4 * W - 12 : 4; // next row of the tile, or the first row of the next band of tiles
-			++trow;
+			tbp += W;
 		}
 		if (st == WFW_RUN) ++s;
 		++t;
@@ -339,13 +337,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 
 // ---- traceback: one lane per problem (miniwfa.c:329-377) ----------------------------------------------------------------------------
 
-// byte of cell (score sc, window index idx) in a problem's region: four scores per dword (a ROW), the earliest in the top byte.  Round 5: the dwords lie in TILES of 4 diagonals
-// x 4 rows (64 bytes: one sector holds 16 scores of 4 neighbouring diagonals) instead of row after row -- the walk of k_wfa_tb moves a diagonal at a time and used to touch a new
-// sector every four scores ([measured, round 4] 29 GB fetched per 125 000 reads to read a byte per sector); a band of tiles is 4 rows x W diagonals = 4 W dwords.
+// byte of cell (score sc, window index idx) in a problem's region: rows of W dwords, four scores per dword, the earliest in the top byte.
+// [measured and not kept, round 5: the same dwords in TILES of 4 diagonals x 4 rows, so that a 64-byte sector holds 16 scores of 4 neighbouring diagonals instead of 4 scores of
+// 16 -- the walk of k_wfa_tb moves a diagonal at a time.  k_wfa_tb fetched 27.9 GB per 125 000 reads instead of 29.0 and ran 17.8 ms instead of 18.1, the forward kernels 1.6 ms
+// longer (16-byte pieces per wave store): profiles/r05j_pmc_*_tiled_traceback.txt.  What the walk fetches is not mainly traceback: 15 M problems x (descriptor + result + the two
+// sequences + ~4 rows, every one of them a 128-byte line of its own since the lists are sorted by length, not by address) = 1.9 KB per problem.]
 __device__ __forceinline__ uint32_t wfw_tb_byte(const uint32_t *__restrict__ reg, int32_t W, int32_t ph, int32_t sc, int32_t idx)
 {
-	const int32_t p = ph + sc - 1, row = p >> 2;
-	return reg[(size_t)(row >> 2) * (4 * W) + (idx >> 2) * 16 + (row & 3) * 4 + (idx & 3)] >> (8 * (3 - (p & 3))) & 0xffu;
+	const int32_t p = ph + sc - 1;
+	return reg[(size_t)(p >> 2) * W + idx] >> (8 * (3 - (p & 3))) & 0xffu;
 }
 
 // walks the alignment from the end cell to the start; WRITE: operators go to out[n_total - 1 - k] (the walk finds them last to first).  Returns their number.
@@ -460,7 +460,7 @@ static const wfw_tier_t g_wtier[MGA_WFW_N] = {
 	{ 256, 4096 },   // < 256
 };
 // traceback rows per problem: four scores each, scores < min(W + 30, 256), + the phase of the first row (<= 3) and the step after the last score
-static int wfw_rows(int W) { const int smax = W + 30 < WFW_SMAX ? W + 30 : WFW_SMAX; return ((smax + 3) / 4 + 2 + 3) & ~3; } // (whole bands of four rows: the tiled layout)
+static int wfw_rows(int W) { const int smax = W + 30 < WFW_SMAX ? W + 30 : WFW_SMAX; return (smax + 3) / 4 + 2; }
 
 extern "C" int64_t mga_dev_wfa_win_tb_stride(int wt) { return (int64_t)wfw_rows(g_wtier[wt].W) * g_wtier[wt].W * 4; }
 
