@@ -78,13 +78,24 @@ def asm_block(mga, d, genome, threads, ref_bin):
     contig = genome // 10
     subprocess.run([mga.MGSIM, "-p", pre, "-G", str(genome), "-c", "10", "-H", "3", "-n", "10", "-l", str(contig), "-e", "0.001", "-s", "5"], stderr=subprocess.DEVNULL, check=True)
     g, r, got, ref = pre + ".gfa", pre + ".reads.fa", pre + ".got.gaf", pre + ".ref.gaf"
+    try:
+        mga.load().mga_rq_dev_stats((ctypes.c_int64 * 8)(), 1)
+    except Exception:
+        pass
     t0 = time.time()
     mga.map_files(g, [r], got, preset="asm", cigar=True, n_threads=threads, verbose=0)
     t_ours = time.time() - t0
     out = dict(workload="-cx asm: 10 contigs x %d bp (%.0f Mbp of query, 0.1%% divergence) vs a %.0f Mbp-backbone 3-haplotype bubble graph in 10 chromosomes" % (contig, contig * 10 / 1e6, genome / 1e6),
                interval="file -> file: GFA parse + index + mapping + GAF, on both sides", seconds=round(t_ours, 2), query_Mbp_per_s=round(contig * 10 / 1e6 / t_ours, 1),
                gaf_bytes=os.path.getsize(got), host_threads=threads,
-               note="the primary chainer under -x asm (mg_lchain_rmq, lchain.c:252-372) runs on the host threads, split into (segment, strand) runs; sketch, seeds, WFA and text on the device")
+               note="round 5: the forward passes of the primary chainer under -x asm (mg_lchain_rmq, lchain.c:252-357) run on the device, a wavefront per (segment, strand) run (k_rmq.hip); "
+                    "its anchor sort (klib's exact permutation) and backtrack on the host threads; sketch, seeds, WFA and text on the device")
+    try:   # which runs of the RMQ chainer the device took, and which it handed back to the host's exact tree (tied priorities / inner window beyond the kernel's sort / too long)
+        st_rq = (ctypes.c_int64 * 8)()
+        mga.load().mga_rq_dev_stats(st_rq, 1)
+        out["rmq_runs"] = dict(device=int(st_rq[0]), host_tie=int(st_rq[1]), host_inner_window=int(st_rq[2]), host_long=int(st_rq[3]), host_device_failed=int(st_rq[4]))
+    except Exception:
+        pass
     if ref_bin and os.path.exists(ref_bin):
         t0 = time.time()
         with open(ref, "wb") as fo:

@@ -172,113 +172,6 @@ __device__ void lc_dp(const mg128_t *__restrict__ a, int32_t n, mga_lchain_par_t
 	}
 }
 
-// ---------------- first-pass DP, the four per-anchor values as ONE 16-byte record (round 5 experiment, MGA_LC_AOS=1) ----------------
-// The kernel is bound by the vector-memory instructions a CU can take from its 32 wavefronts (an anchor step issued ~14 of them: a[j], f[j], p[j], v[j], the mark's store and
-// re-load, the anchors at i / st / max_ii with their f and v, three stores).  With {f, p, v, t} of an anchor side by side in the (otherwise idle) sort scratch z[], a block of
-// predecessors is two 16-byte loads and an anchor's result one store: ~9 per step.  f, p, v are copied to their arrays for the backtrack when the DP is through.
-__device__ void lc_dp_aos(const mg128_t *__restrict__ a, int32_t n, mga_lchain_par_t P, lc_ws_t W, int lane)
-{
-	int4 *rec = (int4*)W.z; // x = f, y = p, z = v, w = t
-	for (int32_t i = lane; i < n; i += 64) rec[i] = make_int4(0, 0, 0, 0);
-	__syncthreads();
-	int32_t st = 0, max_ii = -1;
-	for (int32_t i = 0; i < n; ++i) {
-		{ // Anchors without any predecessor in reach -- the previous anchor (by x) lies on another (segment, strand) or more than max_dist_x back:
-		  // on a multi-gigabase graph more than half of a read's seed hits are such strays -- leave no trace in the sequential state of the loop:
-		  // f = v = span, p = -1, and the "best anchor in reach" becomes the anchor itself (the recomputation at lchain.c:191-196 finds nothing, the
-		  // update at :203 then takes i).  A run of them is written by the lanes at once instead of costing one trip of the loop each.
-			const int32_t k = i + lane;
-			bool iso = false;
-			uint64_t yk = 0;
-			if (k < n) {
-				const uint64_t xk = a[k].x;
-				yk = a[k].y;
-				if (k == 0) iso = true;
-				else { const uint64_t xp = a[k - 1].x; iso = xk >> 32 != xp >> 32 || xk > xp + (uint64_t)(int64_t)P.max_dist_x; }
-			}
-			const uint64_t m = __ballot(iso);
-			const int r = (~m) ? (int)__builtin_ctzll(~m) : 64; // leading run of strays
-			if (r > 0) {
-				if (lane < r) { const int32_t sp = (int32_t)(yk >> 32 & 0xff); rec[k] = make_int4(sp, -1, sp, 0); }
-				max_ii = i + r - 1;
-				if (st < i + r - 1) st = i + r - 1; // nothing left of the last stray is in reach of what follows (x ascending)
-				i += r - 1;
-				__syncthreads();
-				continue;
-			}
-		}
-		// Round 4: the loads of an anchor's step that do not depend on each other leave together -- its own record, the window's first anchor and the best-scoring anchor in
-		// reach (known from the previous step) at the top; a predecessor block's anchors with their f, p AND v in one trip (they used to follow the score test) --
-		// [measured] ~10 k cycles per anchor were 6-8 DEPENDENT trips to memory at 4 % VALU utilisation.
-		const uint64_t xi = a[i].x, yi = a[i].y;
-		uint64_t xs0 = st < i ? a[st].x : 0;
-		mg128_t am; am.x = am.y = 0;
-		int32_t fm = 0, vm = 0;
-		if (max_ii >= 0) { const int4 rm = rec[max_ii]; am = a[max_ii], fm = rm.x, vm = rm.z; }
-		while (st < i) { // lchain.c:171
-			if (xi >> 32 != xs0 >> 32 || xi > xs0 + (uint64_t)(int64_t)P.max_dist_x) { ++st; if (st < i) xs0 = a[st].x; } else break;
-		}
-		if (i - st > P.max_iter) st = i - P.max_iter;
-		int32_t max_f = (int32_t)(yi >> 32 & 0xff), max_j = -1, max_v = 0, n_skip = 0, end_j = st - 1;
-		bool cut = false;
-		for (int32_t j0 = i - 1; j0 >= st && !cut; j0 -= 64) {
-			const int32_t j = j0 - lane;
-			const bool act = j >= st;
-			int32_t sc = LC_NONE, pj = -1, vj = 0;
-			if (act) {
-				const mg128_t aj = a[j];
-				const int4 rj = rec[j];
-				const int32_t fj = rj.x;
-				pj = rj.y, vj = rj.z;
-				sc = lc_score(xi, yi, aj.x, aj.y, P);
-				if (sc != LC_NONE) sc += fj; else pj = -1;
-			}
-			const bool valid = sc != LC_NONE;
-			if (valid && pj >= 0) rec[pj].w = i; // lchain.c:188 (harmless beyond the cut: only compared against this i)
-			__syncthreads();
-			const bool hit_t = valid && rec[j < 0 ? 0 : j].w == i;
-			// exclusive prefix max of valid scores in visiting order, seeded with the running max_f
-			const int32_t pm = lc_scan_max(valid ? sc : INT32_MIN, INT32_MIN);
-			int32_t ex = lc_prev_lane(pm, INT32_MIN);
-			if (ex < max_f) ex = max_f;
-			const bool improve = valid && sc > ex;
-			const uint64_t m_imp = __ballot(improve);
-			const int cut_lane = lc_skip_replay(improve, hit_t && !improve, P.max_skip, &n_skip);
-			const uint64_t before = cut_lane == 64 ? ~0ULL : (1ULL << cut_lane) - 1ULL;
-			const uint64_t imp_b = m_imp & before;
-			if (imp_b) {
-				const int bl = 63 - __clzll(imp_b);
-				max_f = __shfl(sc, bl), max_v = __shfl(vj, bl), max_j = j0 - bl;
-			}
-			if (cut_lane < 64) { cut = true; end_j = j0 - cut_lane; }
-			__syncthreads();
-		}
-		// lchain.c:191-196: best-scoring anchor within reach, recomputed when it fell out of range
-		if (max_ii < 0 || xi - am.x > (uint64_t)(int64_t)P.max_dist_x) {
-			int32_t bf = INT32_MIN, bj = -1;
-			for (int32_t j = i - 1 - lane; j >= st; j -= 64) { const int32_t fj = rec[j].x; if (bf < fj) bf = fj, bj = j; } // descending j per lane: first max kept
-			for (int d = 32; d > 0; d >>= 1) {
-				const int32_t of = __shfl_xor(bf, d), oj = __shfl_xor(bj, d);
-				if (of > bf || (of == bf && oj > bj)) bf = of, bj = oj; // ties: the larger j was met first
-			}
-			max_ii = bj;
-			if (max_ii >= 0) { const int4 rm = rec[max_ii]; am = a[max_ii], fm = rm.x, vm = rm.z; }
-		}
-		if (max_ii >= 0 && max_ii < end_j) { // lchain.c:197-201
-			const int32_t tmp = lc_score(xi, yi, am.x, am.y, P);
-			if (tmp != LC_NONE && max_f < tmp + fm) max_f = tmp + fm, max_j = max_ii, max_v = vm;
-		}
-		int32_t vi = max_f;
-		if (max_j >= 0 && max_v > max_f) vi = max_v;
-		if (lane == 0) rec[i] = make_int4(max_f, max_j, vi, 0); // (a mark on anchor i can only come from a later step)
-		if (max_ii < 0 || (xi - am.x <= (uint64_t)(int64_t)P.max_dist_x && fm < max_f)) max_ii = i;
-		__syncthreads();
-	}
-	for (int32_t i = lane; i < n; i += 64) { const int4 r = rec[i]; W.f[i] = r.x, W.p[i] = r.y, W.v[i] = r.z; } // the backtrack reads the three arrays (and takes z[] back as its scratch)
-	__syncthreads();
-}
-
-
 // ---------------- RMQ DP of the rescue (lchain.c:275-357); false = this read must be re-chained by the host ----------------
 __device__ bool lc_dp_rmq(const mg128_t *__restrict__ a, int32_t n, const lc_rescue_t &R, lc_ws_t W, int lane)
 {
@@ -696,7 +589,7 @@ __global__ void __launch_bounds__(64) k_lchain(int n_reads, const mg128_t *__res
 											   lc_rescue_t R, const int64_t *__restrict__ q_off,
 											   uint64_t *__restrict__ u_all, mg128_t *__restrict__ b_all, int32_t *__restrict__ d_nu, int32_t *__restrict__ d_nb,
 											   int32_t *__restrict__ d_flag, int32_t *__restrict__ ws_i32, mg128_t *__restrict__ ws_z, mg128_t *__restrict__ ws_keep,
-											   const int32_t *__restrict__ order, int aos)
+											   const int32_t *__restrict__ order)
 {
 	__shared__ klib_lds_t L;
 	const int lane = threadIdx.x;
@@ -707,7 +600,7 @@ __global__ void __launch_bounds__(64) k_lchain(int n_reads, const mg128_t *__res
 	lc_read_setup(r, a_all, a_off, P, R, q_off, u_all, b_all, ws_i32, ws_z, &X);
 	if (X.n == 0) { if (lane == 0) d_nu[r] = 0, d_nb[r] = 0; return; }
 	long long tick_ = g_lc_prof_on ? (long long)clock64() : 0;
-	if (aos) lc_dp_aos(X.a, X.n, X.P, X.W, lane); else lc_dp(X.a, X.n, X.P, X.W, lane);
+	lc_dp(X.a, X.n, X.P, X.W, lane);
 	LC_TICK(0);
 	lc_read_finish(r, X, R, q_off, d_nu, d_nb, d_flag, ws_keep, &L, lane, tick_);
 }
@@ -786,8 +679,9 @@ extern "C" int mga_dev_lchain(mga_sctx_t *sc, int n, const mg128_t *d_a, const i
 		// wavefront, and a wavefront that backtracks and rescues TWO reads one after the other behind a DP that lasts as long as the longer of the two is 1.5 x the longest read.
 		// Kept as MGA_LC_PAIR=1 (the parity tests run it), not the default.
 		const char *e_pair = getenv("MGA_LC_PAIR");
-		const char *e_aos = getenv("MGA_LC_AOS");
-		if (!(e_pair && atoi(e_pair) > 0)) hipLaunchKernelGGL(k_lchain, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, R, d_q_off, d_u, d_b, d_nu, d_nb, d_flag, ws_i32, ws_z, ws_keep, d_order, e_aos && atoi(e_aos) > 0 ? 1 : 0);
+		// (also measured and not kept, `git log -p` has it: the first-pass DP over 16-byte {f, p, v, t} records in z[] -- ~9 vector-memory instructions per anchor step instead of
+		// ~14, bit-identical, 66.5 vs 66.8 ms: the kernel is not bound by the memory instructions a CU takes either.  A launch is its longest read's chain of dependent trips.)
+		if (!(e_pair && atoi(e_pair) > 0)) hipLaunchKernelGGL(k_lchain, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, R, d_q_off, d_u, d_b, d_nu, d_nb, d_flag, ws_i32, ws_z, ws_keep, d_order);
 		else hipLaunchKernelGGL(k_lchain2, dim3((n + 1) / 2), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, R, d_q_off, d_u, d_b, d_nu, d_nb, d_flag, ws_i32, ws_z, ws_keep, d_order);
 	}
 	mga_prof_end(sc->stream, MGA_K_LCHAIN);

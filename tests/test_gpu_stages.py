@@ -291,8 +291,11 @@ def make_anchors(rng, n, n_chain=3, span=17, noise=0.3, tie_frac=0.0):
     return a
 
 
-def test_lchain_synthetic_anchor_sets(ora):
-    """ties in x and in score, tiny / large anchor sets, skip + iteration caps"""
+@pytest.mark.parametrize("pair", ["0", "1"])
+def test_lchain_synthetic_anchor_sets(ora, pair, monkeypatch):
+    """ties in x and in score, tiny / large anchor sets, skip + iteration caps; pair = 1: the first-pass DP of two reads per wavefront in 32-lane groups (k_lchain2, round 5:
+    measured slower than one read per wavefront and not the default, but exact -- the block of predecessors is 32 instead of 64, the replay carries its state across blocks)"""
+    monkeypatch.setenv("MGA_LC_PAIR", pair)
     rng = np.random.default_rng(9)
     sets = []
     for it in range(120):
