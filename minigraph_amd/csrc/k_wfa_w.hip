@@ -335,6 +335,223 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 #undef HA
 }
 
+// ---- PACKED forward pass for the rungs of 128 diagonals and more (round 5) ---------------------------------------------------------------
+// k_wfa_fw gives every diagonal of the window a lane and a 32-bit register per slice; the rungs of 128 / 192 / 256 diagonals therefore run 2 / 3 / 4 "slots" of 64 diagonals,
+// each with its own copy of the ~110 vector instructions of a step, and they are bound by vector-instruction ISSUE (the microbenchmark's rate is reached or passed: DESIGN 4).
+// Offsets inside a window stay below 512 + 1 and the "unreachable" value only has to lose every comparison, so a furthest-reaching offset fits 16 bits: here a lane holds TWO
+// NEIGHBOURING diagonals (2 l, 2 l + 1 of a set of 128) in the halves of one register and the recurrence -- the five maxima, the + 1s, the tie-break bits as sign masks of
+// packed differences, the age shifts, the validity masks -- runs on v_pk_* instructions: once per 128 diagonals.  What stays per diagonal is the extension along the match mask
+// (two bit-field extracts, two mask windows, one repack).  Neighbour exchange: diagonal 2 l - 1 is the high half of lane l - 1, 2 l + 2 the low half of lane l + 1 -- a DPP wave
+// shift and a v_alignbit per operand.  One problem per wavefront, its scalars in SGPRs; traceback rows, result record and the walk (k_wfa_tb) are those of k_wfa_fw.
+typedef short wfp_pk2 __attribute__((ext_vector_type(2)));
+#define WFP_NEG 0xE000E000u   // two 16-bit cells of -8192: below every offset, and no difference of two cells overflows 16 bits (offsets < 600, at most 300 increments on top)
+#define WFP_ONE 0x00010001u
+__device__ __forceinline__ uint32_t wfp_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(wfp_pk2, a), __builtin_bit_cast(wfp_pk2, b))); }
+__device__ __forceinline__ uint32_t wfp_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (wfp_pk2)(__builtin_bit_cast(wfp_pk2, a) + __builtin_bit_cast(wfp_pk2, b))); }
+__device__ __forceinline__ uint32_t wfp_lt(uint32_t a, uint32_t b) // all ones in every half where a < b
+{
+	const wfp_pk2 d = __builtin_bit_cast(wfp_pk2, a) - __builtin_bit_cast(wfp_pk2, b);
+	return __builtin_bit_cast(uint32_t, (wfp_pk2)(d >> (wfp_pk2)(15)));
+}
+__device__ __forceinline__ uint32_t wfp_sel(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+// left neighbours of a lane's two diagonals: (high half of lane l - 1, own low half); lane 0's comes from `edge` (the previous set's lane 63, or WFP_NEG)
+__device__ __forceinline__ uint32_t wfp_from_left(uint32_t edge, uint32_t x) { const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)x, 0x138, 0xf, 0xf, false); return __builtin_amdgcn_alignbit(x, t, 16); }
+// right neighbours: (own high half, low half of lane l + 1); lane 63's comes from `edge` (the next set's lane 0, or WFP_NEG)
+__device__ __forceinline__ uint32_t wfp_from_right(uint32_t edge, uint32_t x) { const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)x, 0x130, 0xf, 0xf, false); return __builtin_amdgcn_alignbit(t, x, 16); }
+
+template<int W, int SEQCAP>
+__global__ void __launch_bounds__(64) k_wfa_fwp(const int *__restrict__ n_items_p, int cap, const int32_t *__restrict__ list, const mga_wfa_prob_t *__restrict__ prob,
+												const char *__restrict__ tseq, const char *__restrict__ qseq, mga_wfa_res_t *__restrict__ res,
+												char *__restrict__ tb, long long tb_stride, int *__restrict__ counter, mga_wfa_retry_t rt)
+{
+	constexpr int JP = (W + 127) / 128; // sets of 128 diagonals (two per lane)
+	constexpr int SEQS = SEQCAP + 16;
+	constexpr int MROWS = SEQCAP / 32 + 3;
+	__shared__ __attribute__((aligned(16))) uint8_t Tg[SEQS], Qg[4 * SEQS];
+	__shared__ uint32_t Mk[MROWS][128 * JP]; // mask of diagonal lo + 128 j + 2 lane + h at [word][64 (2 j + h) + lane]: lane l always hits bank l
+	const int lane = threadIdx.x;
+	const int n_items = min(*n_items_p, cap);
+	for (;;) {
+		int32_t item = 0;
+		if (lane == 0) item = atomicAdd(counter, 1);
+		item = __builtin_amdgcn_readfirstlane(item);
+		if (item >= n_items) break;
+		const int32_t pi = __builtin_amdgcn_readfirstlane(list ? list[item] : item);
+		const mga_wfa_prob_t pb = prob[pi];
+		const int32_t tl = pb.tl, ql = pb.ql, e = ql - tl;
+		const char *ts = tseq + pb.t_off, *qs = qseq + pb.q_off;
+		int32_t lo = 0, bnd = 0;
+		if (tl <= SEQCAP && ql <= SEQCAP) { bnd = wfw_window(W, tl, ql, &lo, WFW_SMAX); if (bnd > W + 30) bnd = W + 30; }
+		bool done = false;
+		int32_t s = 0, lst = 0;
+		uint32_t *tbp = (uint32_t*)(tb + (long long)item * tb_stride) + 2 * lane; // this lane's two dwords in the current row (set j: + 128 j)
+		if (bnd > 0) {
+			// ---- sequences and match masks (as k_wfa_fw)
+			WFW_LDS_FENCE();
+			for (int32_t m = lane; 4 * m < tl; m += 64) { uint32_t v; __builtin_memcpy(&v, ts + 4 * m, 4); *(uint32_t*)(Tg + 4 * m) = v; }
+			for (int32_t m = lane; 4 * m < ql; m += 64) {
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					uint32_t v;
+					__builtin_memcpy(&v, qs + 4 * m + c, 4);
+					*(uint32_t*)(Qg + c * SEQS + 4 + 4 * m) = v;
+					if (m == 0 && c > 0) { uint32_t v0; __builtin_memcpy(&v0, qs, 4); *(uint32_t*)(Qg + c * SEQS) = v0 << (8 * (4 - c)); }
+				}
+			}
+			WFW_LDS_FENCE();
+#pragma unroll
+			for (int q = 0; q < 2 * JP; ++q) {
+				const int32_t d = lo + 128 * (q >> 1) + 2 * lane + (q & 1);
+				const int32_t kmin = d < 0 ? -d : 0, kmax = min(tl, ql - d);
+				const uint8_t *qc = Qg + (d & 3) * SEQS + 4 + (d & ~3);
+				for (int32_t w = 0; w <= (tl >> 5); ++w) {
+					uint32_t bits = 0;
+#pragma unroll
+					for (int q8 = 7; q8 >= 0; --q8) {
+						const uint32_t t4 = *(const uint32_t*)(Tg + 32 * w + 4 * q8), q4 = *(const uint32_t*)(qc + 32 * w + 4 * q8);
+						asm volatile("v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_3 src1_sel:BYTE_3\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+									 "v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_2 src1_sel:BYTE_2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+									 "v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_1 src1_sel:BYTE_1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+									 "v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_0 src1_sel:BYTE_0\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+									 : "+v"(bits) : "v"(t4), "v"(q4) : "vcc");
+					}
+					const int32_t b_lo = kmin - 32 * w, b_hi = kmax - 32 * w;
+					const uint32_t m_hi = b_hi >= 32 ? ~0u : b_hi <= 0 ? 0u : (1u << b_hi) - 1u, m_lo = b_lo <= 0 ? ~0u : b_lo >= 32 ? 0u : ~0u << b_lo;
+					Mk[w][64 * q + lane] = bits & m_hi & m_lo;
+				}
+			}
+			WFW_LDS_FENCE();
+			// ---- state: two diagonals per register
+			uint32_t H[JP][18], E1[JP][3], F1[JP][3], E2[JP][2], F2[JP][2], okv[JP], accA[JP], accB[JP];
+#pragma unroll
+			for (int j = 0; j < JP; ++j) {
+				const int32_t dA = lo + 128 * j + 2 * lane, dB = dA + 1;
+#pragma unroll
+				for (int a = 0; a < 18; ++a) H[j][a] = WFP_NEG;
+#pragma unroll
+				for (int a = 0; a < 3; ++a) E1[j][a] = F1[j][a] = WFP_NEG;
+#pragma unroll
+				for (int a = 0; a < 2; ++a) E2[j][a] = F2[j][a] = WFP_NEG;
+				okv[j] = ((dA >= -tl && dA <= ql && 128 * j + 2 * lane < W) ? 0x0000ffffu : 0u) | ((dB >= -tl && dB <= ql && 128 * j + 2 * lane + 1 < W) ? 0xffff0000u : 0u);
+				accA[j] = accB[j] = 0;
+				if (dA == 0) H[j][2] = (H[j][2] & 0xffff0000u) | 0x0000ffffu; // score 0: H[d = 0] = -1 (miniwfa.c:103-119); age 0 of an even step is H[2]
+				if (dB == 0) H[j][2] = (H[j][2] & 0x0000ffffu) | 0xffff0000u;
+			}
+			bool bail = false;
+#define HP(j_, a_) H[j_][(a_) + 2 - P]
+			auto step = [&](auto Pc) __attribute__((always_inline)) -> bool { // false: the problem is through (done or bail)
+				constexpr int P = decltype(Pc)::value;
+				// ---- extension of slice s (miniwfa.c:399-411)
+				const int32_t rs = wfw_reach(s);
+				bool fin = false;
+				int32_t flst = 0;
+#pragma unroll
+				for (int j = 0; j < JP; ++j) {
+					const int32_t b0 = lo + 128 * j;
+					if (b0 > rs || b0 + 127 < -rs) continue;
+					const uint32_t x = HP(j, 0);
+					int32_t kk[2];
+#pragma unroll
+					for (int h = 0; h < 2; ++h) {
+						const int32_t d = b0 + 2 * lane + h;
+						const int32_t k0 = h ? (int32_t)x >> 16 : (int32_t)(x << 16) >> 16, tp = k0 + 1;
+						const bool val = (uint32_t)tp <= (uint32_t)tl;
+						const int32_t wi = val ? tp >> 5 : 0, sh = tp & 31;
+						const uint32_t *mp = &Mk[wi][64 * (2 * j + h) + lane];
+						uint32_t inv = ~__builtin_amdgcn_alignbit(mp[128 * JP], mp[0], sh);
+						int32_t n = inv ? (int32_t)__builtin_ctz(inv) : 32;
+						bool more = val && inv == 0;
+						for (int32_t wj = wi + 1; __ballot(more); ++wj) {
+							const uint32_t *mq = &Mk[wj < MROWS - 2 ? wj : MROWS - 2][64 * (2 * j + h) + lane];
+							inv = ~__builtin_amdgcn_alignbit(mq[128 * JP], mq[0], sh);
+							n += more ? (inv ? (int32_t)__builtin_ctz(inv) : 32) : 0;
+							more = more && inv == 0;
+						}
+						const int32_t k = val ? k0 + n : k0;
+						kk[h] = k;
+						if (val && d == e && k == tl - 1) { fin = true; flst = n == 0 ? (int32_t)((h ? accB[j] : accA[j]) & 7u) : 0; } // entered by a gap state and not extended: the traceback starts in that state (miniwfa.c:406-407)
+					}
+					HP(j, 0) = ((uint32_t)kk[0] & 0xffffu) | ((uint32_t)kk[1] << 16);
+				}
+				const uint64_t m_fin = __ballot(fin);
+				if (m_fin) { lst = __shfl(flst, (int)__builtin_ctzll(m_fin)); done = true; return false; } // (the end cell lies on ONE diagonal)
+				if (s + 1 >= bnd) { bail = true; return false; }
+				// ---- slice s + 1 (miniwfa.c:281-308), two diagonals per instruction
+				const int32_t rn = wfw_reach(s + 1);
+				uint32_t nH[JP], nE1[JP], nF1[JP], nE2[JP], nF2[JP];
+#pragma unroll
+				for (int j = 0; j < JP; ++j) {
+					const int32_t b0 = lo + 128 * j;
+					if (b0 > rn || b0 + 127 < -rn) { nH[j] = nE1[j] = nF1[j] = nE2[j] = nF2[j] = WFP_NEG; continue; }
+#define WFP_L(R, a) wfp_from_left(j > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)R[j > 0 ? j - 1 : 0][a], 63) : WFP_NEG, R[j][a])
+#define WFP_R(R, a) wfp_from_right(j < JP - 1 ? (uint32_t)__builtin_amdgcn_readlane((int)R[j < JP - 1 ? j + 1 : j][a], 0) : WFP_NEG, R[j][a])
+					const uint32_t ho1l = WFP_L(H, 5 + 2 - P), e1l = WFP_L(E1, 1), ho2l = WFP_L(H, 15 + 2 - P), e2l = WFP_L(E2, 0);
+					const uint32_t ho1r = WFP_R(H, 5 + 2 - P), f1r = WFP_R(F1, 1), ho2r = WFP_R(H, 15 + 2 - P), f2r = WFP_R(F2, 0);
+#undef WFP_L
+#undef WFP_R
+					const uint32_t hx1 = wfp_add(HP(j, 3), WFP_ONE);
+					const uint32_t vE1 = wfp_max(ho1l, e1l), vE2 = wfp_max(ho2l, e2l);
+					const uint32_t vF1 = wfp_add(wfp_max(ho1r, f1r), WFP_ONE), vF2 = wfp_add(wfp_max(ho2r, f2r), WFP_ONE);
+					const uint32_t bits = (wfp_lt(ho1l, e1l) & 0x00080008u) | (wfp_lt(ho2l, e2l) & 0x00200020u) | (wfp_lt(ho1r, f1r) & 0x00100010u) | (wfp_lt(ho2r, f2r) & 0x00400040u);
+					const uint32_t ee = wfp_max(vE1, vE2), ff = wfp_max(vF1, vF2), hh = wfp_max(ee, ff);
+					const uint32_t ze = (wfp_lt(vE1, vE2) & 0x00020002u) | WFP_ONE;              // vE1 >= vE2 ? 1 : 3
+					const uint32_t zf = (wfp_lt(vF1, vF2) & 0x00060006u) ^ 0x00020002u;           // vF1 >= vF2 ? 2 : 4
+					uint32_t z = wfp_sel(wfp_lt(ee, ff), zf, ze);                                  // ee >= ff ? ze : zf
+					z &= wfp_lt(hx1, hh);                                                          // hx1 >= hh ? 0 : z
+					const uint32_t vH = wfp_max(hx1, hh), bz = bits | z;
+					accA[j] = accA[j] << 8 | (bz & 0xffu), accB[j] = accB[j] << 8 | (bz >> 16);
+					nH[j] = wfp_sel(okv[j], vH, WFP_NEG), nE1[j] = wfp_sel(okv[j], vE1, WFP_NEG), nF1[j] = wfp_sel(okv[j], vF1, WFP_NEG);
+					nE2[j] = wfp_sel(okv[j], vE2, WFP_NEG), nF2[j] = wfp_sel(okv[j], vF2, WFP_NEG);
+				}
+#pragma unroll
+				for (int j = 0; j < JP; ++j) { // age shift (H: every second step, by two)
+					HP(j, -1) = nH[j];
+					if (P == 1) {
+#pragma unroll
+						for (int a = 17; a > 1; --a) H[j][a] = H[j][a - 2];
+					}
+					E1[j][2] = E1[j][1]; E1[j][1] = E1[j][0]; E1[j][0] = nE1[j];
+					F1[j][2] = F1[j][1]; F1[j][1] = F1[j][0]; F1[j][0] = nF1[j];
+					E2[j][1] = E2[j][0]; E2[j][0] = nE2[j];
+					F2[j][1] = F2[j][0]; F2[j][0] = nF2[j];
+				}
+				if ((s & 3) == 3) { // a row of traceback dwords is full (one problem per wavefront: the step count IS the score); reachable diagonals only
+					const int32_t rr = wfw_reach(s + 1);
+#pragma unroll
+					for (int j = 0; j < JP; ++j) {
+						const int32_t dA = lo + 128 * j + 2 * lane, dB = dA + 1, ad = min(dA < 0 ? -dA : dA, dB < 0 ? -dB : dB);
+						if (ad <= rr && 128 * j + 2 * lane < W) { tbp[128 * j] = accA[j]; if (128 * j + 2 * lane + 1 < W) tbp[128 * j + 1] = accB[j]; }
+					}
+					tbp += W;
+				}
+				++s;
+				return true;
+			};
+			for (;;) {
+				if (!step(std::integral_constant<int, 0>())) break;
+				if (!step(std::integral_constant<int, 1>())) break;
+			}
+#undef HP
+			if (done) {
+				if (s & 3) { // the rest of the last traceback row (bytes of steps s & ~3 .. s - 1)
+					const int32_t rr = wfw_reach(s + 1);
+#pragma unroll
+					for (int j = 0; j < JP; ++j) {
+						const int32_t dA = lo + 128 * j + 2 * lane, dB = dA + 1, ad = min(dA < 0 ? -dA : dA, dB < 0 ? -dB : dB);
+						if (ad <= rr && 128 * j + 2 * lane < W) { tbp[128 * j] = accA[j] << (8 * (4 - (s & 3))); if (128 * j + 2 * lane + 1 < W) tbp[128 * j + 1] = accB[j] << (8 * (4 - (s & 3))); }
+					}
+				}
+			}
+			(void)bail;
+		}
+		if (lane == 0) {
+			mga_wfa_res_t r;
+			if (done) { r.score = s, r.n_cigar = 0, r.cig_off = (int64_t)(uintptr_t)(tb + (long long)item * tb_stride), r.status = MGA_WFA_TB, r.pad = lst | W << 8, r.n_iter = 0; res[pi] = r; }
+			else { r.score = -1, r.n_cigar = 0, r.cig_off = 0, r.status = MGA_WFA_RETRY_TIER, r.pad = 0, r.n_iter = 0; res[pi] = r; mga_wfa_give_up(rt, pi); }
+		}
+	}
+}
+
 // ---- traceback: one lane per problem (miniwfa.c:329-377) ----------------------------------------------------------------------------
 
 // byte of cell (score sc, window index idx) in a problem's region: rows of W dwords, four scores per dword, the earliest in the top byte.
@@ -484,13 +701,17 @@ extern "C" int mga_dev_wfa_win(mga_sctx_t *sc, const int *d_n, int n, const int3
 	const long long stride = (long long)mga_dev_wfa_win_tb_stride(wt);
 	mga_prof_begin(st, MGA_K_WFAW0 + wt);
 #define LAUNCH(GG, JJ, SEQ) hipLaunchKernelGGL((k_wfa_fw<GG, JJ, SEQ>), dim3(wgs), dim3(64), 0, st, d_n, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_tb, stride, d_counter, rt)
+	const char *e_pk = getenv("MGA_WFA_PACKED"); // (read per launch) 1: the rungs of 128 / 192 / 256 diagonals on the packed kernel (two diagonals per lane, k_wfa_fwp)
+	const bool packed = e_pk && atoi(e_pk) > 0;
+#define LAUNCHP(WW, SEQ) hipLaunchKernelGGL((k_wfa_fwp<WW, SEQ>), dim3(wgs), dim3(64), 0, st, d_n, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_tb, stride, d_counter, rt)
 	if (wt == 0) LAUNCH(16, 1, 128);
 	else if (wt == 1) LAUNCH(32, 1, 192);
 	else if (wt == 2) LAUNCH(64, 1, 256);
-	else if (wt == 3) LAUNCH(64, 2, 384);
-	else if (wt == 4) LAUNCH(64, 3, 384);
-	else LAUNCH(64, 4, 512);
+	else if (wt == 3) { if (packed) LAUNCHP(128, 384); else LAUNCH(64, 2, 384); }
+	else if (wt == 4) { if (packed) LAUNCHP(192, 384); else LAUNCH(64, 3, 384); }
+	else { if (packed) LAUNCHP(256, 512); else LAUNCH(64, 4, 512); }
 #undef LAUNCH
+#undef LAUNCHP
 	mga_prof_end(st, MGA_K_WFAW0 + wt);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;
