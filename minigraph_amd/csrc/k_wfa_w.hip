@@ -371,19 +371,36 @@ __global__ void __launch_bounds__(64) k_wfa_fwp(const int *__restrict__ n_items_
 	__shared__ uint32_t Mk[MROWS][128 * JP]; // mask of diagonal lo + 128 j + 2 lane + h at [word][64 (2 j + h) + lane]: lane l always hits bank l
 	const int lane = threadIdx.x;
 	const int n_items = min(*n_items_p, cap);
+	// ONE lane-0 region per iteration, at the loop's head: it writes the PREVIOUS problem's result and fetches the next work index.  The first version of this kernel had the
+	// result write as an `if (lane == 0)` at the loop's end and the fetch as another at its head; the compiler's structurizer joined the two across the back edge into an inner
+	// loop in which lanes 1..63 -- with nothing to do in either -- went straight back to reading the work index while lane 0 was still parked at the inner loop's exit: they
+	// saw the old index for ever (gpurun's limit, 30 GPU-minutes; a __syncthreads() does not help, for a workgroup of one wavefront it compiles to nothing).
+	bool prev = false, done = false; // (uniform)
+	int32_t s = 0, lst = 0, pi = 0, item = 0;
 	for (;;) {
-		int32_t item = 0;
-		if (lane == 0) item = atomicAdd(counter, 1);
-		item = __builtin_amdgcn_readfirstlane(item);
+		int32_t item_v = 0;
+		if (lane == 0) {
+			if (prev) {
+				mga_wfa_res_t r;
+				if (done) { r.score = s, r.n_cigar = 0, r.cig_off = (int64_t)(uintptr_t)(tb + (long long)item * tb_stride), r.status = MGA_WFA_TB, r.pad = lst | W << 8, r.n_iter = 0; res[pi] = r; }
+				else { r.score = -1, r.n_cigar = 0, r.cig_off = 0, r.status = MGA_WFA_RETRY_TIER, r.pad = 0, r.n_iter = 0; res[pi] = r; mga_wfa_give_up(rt, pi); }
+			}
+			item_v = atomicAdd(counter, 1);
+		}
+		item = __builtin_amdgcn_readfirstlane(item_v);
 		if (item >= n_items) break;
-		const int32_t pi = __builtin_amdgcn_readfirstlane(list ? list[item] : item);
+		prev = true;
+		pi = __builtin_amdgcn_readfirstlane(list ? list[item] : item);
+		// every scalar of the problem goes through readfirstlane: the compiler then keeps the control flow below in scalar branches (a per-lane copy of a uniform value turns
+		// every `if` on it into a divergent one and the loops around them into waterfall / exec-mask loops: the hang of round 4's k_gchain_p1)
 		const mga_wfa_prob_t pb = prob[pi];
-		const int32_t tl = pb.tl, ql = pb.ql, e = ql - tl;
-		const char *ts = tseq + pb.t_off, *qs = qseq + pb.q_off;
+		const int32_t tl = __builtin_amdgcn_readfirstlane(pb.tl), ql = __builtin_amdgcn_readfirstlane(pb.ql), e = ql - tl;
+		const long long t_off = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pb.t_off & 0xffffffffLL)) | (long long)__builtin_amdgcn_readfirstlane((int)(pb.t_off >> 32)) << 32;
+		const long long q_off = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pb.q_off & 0xffffffffLL)) | (long long)__builtin_amdgcn_readfirstlane((int)(pb.q_off >> 32)) << 32;
+		const char *ts = tseq + t_off, *qs = qseq + q_off;
 		int32_t lo = 0, bnd = 0;
 		if (tl <= SEQCAP && ql <= SEQCAP) { bnd = wfw_window(W, tl, ql, &lo, WFW_SMAX); if (bnd > W + 30) bnd = W + 30; }
-		bool done = false;
-		int32_t s = 0, lst = 0;
+		done = false, s = 0, lst = 0;
 		uint32_t *tbp = (uint32_t*)(tb + (long long)item * tb_stride) + 2 * lane; // this lane's two dwords in the current row (set j: + 128 j)
 		if (bnd > 0) {
 			// ---- sequences and match masks (as k_wfa_fw)
@@ -543,11 +560,6 @@ __global__ void __launch_bounds__(64) k_wfa_fwp(const int *__restrict__ n_items_
 				}
 			}
 			(void)bail;
-		}
-		if (lane == 0) {
-			mga_wfa_res_t r;
-			if (done) { r.score = s, r.n_cigar = 0, r.cig_off = (int64_t)(uintptr_t)(tb + (long long)item * tb_stride), r.status = MGA_WFA_TB, r.pad = lst | W << 8, r.n_iter = 0; res[pi] = r; }
-			else { r.score = -1, r.n_cigar = 0, r.cig_off = 0, r.status = MGA_WFA_RETRY_TIER, r.pad = 0, r.n_iter = 0; res[pi] = r; mga_wfa_give_up(rt, pi); }
 		}
 	}
 }
