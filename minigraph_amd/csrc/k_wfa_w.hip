@@ -713,15 +713,18 @@ extern "C" int mga_dev_wfa_win(mga_sctx_t *sc, const int *d_n, int n, const int3
 	const long long stride = (long long)mga_dev_wfa_win_tb_stride(wt);
 	mga_prof_begin(st, MGA_K_WFAW0 + wt);
 #define LAUNCH(GG, JJ, SEQ) hipLaunchKernelGGL((k_wfa_fw<GG, JJ, SEQ>), dim3(wgs), dim3(64), 0, st, d_n, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_tb, stride, d_counter, rt)
-	const char *e_pk = getenv("MGA_WFA_PACKED"); // (read per launch) 1: the rungs of 128 / 192 / 256 diagonals on the packed kernel (two diagonals per lane, k_wfa_fwp)
-	const bool packed = e_pk && atoi(e_pk) > 0;
+	// MGA_WFA_PACKED=<mask> (read per launch): which of the rungs of 128 (bit 0) / 192 (bit 1) / 256 (bit 2) diagonals run the packed kernel (two diagonals per lane, k_wfa_fwp).
+	// Default 5: measured per 125 000 reads (profiles/r05m_packed_sweep.txt) 128: 47.9 -> 32.5 ms, 256: 13.4 -> 10.4 ms, 192: 24.0 -> 25.1 ms (a quarter of its second
+	// set's lanes hold no diagonal, and its registers cost occupancy) -- same results either way (tests/test_gpu_stages.py runs masks 0 and 7)
+	const char *e_pk = getenv("MGA_WFA_PACKED");
+	const int pk_mask = e_pk && *e_pk ? atoi(e_pk) : 5;
 #define LAUNCHP(WW, SEQ) hipLaunchKernelGGL((k_wfa_fwp<WW, SEQ>), dim3(wgs), dim3(64), 0, st, d_n, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_tb, stride, d_counter, rt)
 	if (wt == 0) LAUNCH(16, 1, 128);
 	else if (wt == 1) LAUNCH(32, 1, 192);
 	else if (wt == 2) LAUNCH(64, 1, 256);
-	else if (wt == 3) { if (packed) LAUNCHP(128, 384); else LAUNCH(64, 2, 384); }
-	else if (wt == 4) { if (packed) LAUNCHP(192, 384); else LAUNCH(64, 3, 384); }
-	else { if (packed) LAUNCHP(256, 512); else LAUNCH(64, 4, 512); }
+	else if (wt == 3) { if (pk_mask & 1) LAUNCHP(128, 384); else LAUNCH(64, 2, 384); }
+	else if (wt == 4) { if (pk_mask & 2) LAUNCHP(192, 384); else LAUNCH(64, 3, 384); }
+	else { if (pk_mask & 4) LAUNCHP(256, 512); else LAUNCH(64, 4, 512); }
 #undef LAUNCH
 #undef LAUNCHP
 	mga_prof_end(st, MGA_K_WFAW0 + wt);

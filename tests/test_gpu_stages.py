@@ -139,11 +139,17 @@ def test_wfa_roundtrip_property():
         assert ti == len(t) and qi == len(q) and pen == sc[i], i
 
 
-def test_wfa_windowed_tiers_edge_shapes(ora):
-    """the windowed tiers (k_wfa_w.hip: 16 / 32 / 64 / 128 / 192 / 256 diagonals, several problems per wavefront in the narrow ones) are exact only
+@pytest.mark.parametrize("packed", ["0", "7", None])
+def test_wfa_windowed_tiers_edge_shapes(ora, monkeypatch, packed):
+    """(MGA_WFA_PACKED: the rungs of 128 / 192 / 256 diagonals on the one-diagonal-per-lane kernel, all three on the packed two-per-lane kernel, the default mix)
+    the windowed tiers (k_wfa_w.hip: 16 / 32 / 64 / 128 / 192 / 256 diagonals, several problems per wavefront in the narrow ones) are exact only
     below the bound of their window: single gaps of every length around each half-width (the alignment hugs the window's edge, one base further and
     the problem must give up and climb), the same with noise, matrices narrower than the window, end diagonals far from 0 (the window is centred
     between 0 and ql - tl), sequences longer than a tier's LDS staging, scores around 256 (the last windowed score), N bases"""
+    if packed is None:
+        monkeypatch.delenv("MGA_WFA_PACKED", raising=False)
+    else:
+        monkeypatch.setenv("MGA_WFA_PACKED", packed)
     rng = np.random.default_rng(41)
     T, Q = [], []
     for L in (12, 30, 60, 70, 72, 100, 111, 112, 128, 129, 167, 168, 192, 193, 255, 256, 257, 343, 344, 384, 385, 512, 513, 700):
@@ -171,9 +177,11 @@ def test_wfa_windowed_tiers_edge_shapes(ora):
         assert np.array_equal(ec, cg[i]), (i, len(T[i]), len(Q[i]), es)
 
 
-def test_wfa_windowed_tiers_many_problems(ora):
+@pytest.mark.parametrize("packed", ["0", "7"])
+def test_wfa_windowed_tiers_many_problems(ora, monkeypatch, packed):
     """a launch the size of a small chunk with the bench workload's shape (gap lengths 1..400, 10 % errors): every group of every wavefront is refilled
     many times, the queue runs dry at the end, problems climb from tier to tier"""
+    monkeypatch.setenv("MGA_WFA_PACKED", packed)
     rng = np.random.default_rng(43)
     T, Q = [], []
     for it in range(30000):

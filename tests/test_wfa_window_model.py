@@ -25,3 +25,17 @@ def test_windowed_wfa_equals_the_full_band_below_the_bound():
     p = subprocess.run([exe, "12000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 0, (p.stdout[-500:], p.stderr[-1500:])
     assert b"mismatches 0" in p.stdout, p.stdout
+
+
+def test_packed_two_diagonals_per_lane_kernel_model_equals_the_oracle():
+    """the PACKED forward pass of the 128 / 192 / 256-diagonal rungs (k_wfa_fwp: two neighbouring diagonals in the 16-bit halves of a lane's register, the recurrence on packed
+    16-bit arithmetic with wrap-around differences as tie-break masks, traceback rows holding reachable diagonals only) restated lane by lane in C
+    (tests/cmodels/wfa_packed_model.c) + the walk of k_wfa_tb: score and CIGAR are the oracle's whenever the window decides, the model stops within its bound and the walk
+    never reads a traceback dword the forward pass did not write"""
+    d = tempfile.mkdtemp()
+    exe = os.path.join(d, "model")
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "cmodels", "wfa_packed_model.c"),
+                           os.path.join(ROOT, "oracle", "mgo_wfa.c"), "-o", exe])
+    p = subprocess.run([exe, "4000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, (p.stdout[-500:], p.stderr[-1500:])
+    assert b"mismatches 0" in p.stdout, p.stdout
