@@ -92,6 +92,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 
 	int32_t st = WFW_IDLE, pi = -1, tl = 0, ql = 0, lo = 0, e = 0, s = 0, bnd = 0, lst = 0, ph = 0;
 	int32_t okv[J];               // all ones where this lane's diagonal exists in the matrix (-tl <= d <= ql)
+	int32_t fc[J];                // what the end cell looks like in this lane: tl - 1 on diagonal ql - tl, a value no offset takes elsewhere (and while the group is idle)
 	uint32_t acc[J];              // traceback bytes of the last (up to) four steps
 	uint32_t *tbp = 0;            // this lane's dword in the current traceback row (slot j: + 64 j)
 	int32_t it_cur = 0;           // the problem's place in the work list = its traceback region
@@ -103,7 +104,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 	bool q_empty = false, q_drained = false;
 #pragma unroll
 	for (int j = 0; j < J; ++j) {
-		okv[j] = 0, acc[j] = 0;
+		okv[j] = 0, acc[j] = 0, fc[j] = 0x7fffffff;
 #pragma unroll
 		for (int a = 0; a < 18; ++a) H[j][a] = WF_NEG_INF;
 #pragma unroll
@@ -141,6 +142,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 					mga_wfa_give_up(rt, pi); // next tier's work list
 				}
 				st = WFW_IDLE;
+#pragma unroll
+				for (int j = 0; j < J; ++j) fc[j] = 0x7fffffff; // (the retired problem's cells stay in the registers: they must not look like an end cell)
 			}
 			if (!q_empty) {
 				const uint64_t m_idle = __ballot(st == WFW_IDLE && gl == 0);
@@ -238,6 +241,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 						if (fill) {
 							acc[j] = 0;
 							okv[j] = (d >= -tl && d <= ql) ? -1 : 0;
+							fc[j] = d == e ? tl - 1 : 0x7fffffff;
 							if (d == 0) HA(j, 0) = -1; // score 0: H[d = 0] = -1 (miniwfa.c:103-119)
 						}
 					}
@@ -249,24 +253,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 		const int32_t rs = (J > 1) ? wfw_reach(s) : 0; // (J > 1: one problem per wave, s is uniform)
 #pragma unroll
 		for (int j = 0; j < J; ++j) {
-			const int32_t d = lo + gl + 64 * j;
 			if (J > 1) { const int32_t b0 = __builtin_amdgcn_readfirstlane(lo) + 64 * j; if (b0 > rs || b0 + 63 < -rs) continue; } // no diagonal of the slot is reachable yet
 			const int32_t k0 = HA(j, 0), tp = k0 + 1;
 			const bool val = st == WFW_RUN && (uint32_t)tp <= (uint32_t)tl; // -1 <= k0 < tl (a cell before the query's start or beyond its end has no set bit to count)
-			const int32_t wi = val ? tp >> 5 : 0, sh = tp & 31;
+			const int32_t wi = val ? tp >> 5 : 0;
 			const uint32_t *mp = &Mk[wi][64 * j + lane];
-			uint32_t inv = ~__builtin_amdgcn_alignbit(mp[64 * J], mp[0], sh); // ones of the mask from position tp on, as zeros
+			uint32_t inv = ~__builtin_amdgcn_alignbit(mp[64 * J], mp[0], tp); // ones of the mask from position tp on, as zeros (the shift is taken mod 32)
+			inv = val ? inv : 1u; // (round 5) a cell that cannot be extended sees "no match at once": its run is 0 without a select, and it never asks for another window
 			int32_t n = inv ? (int32_t)__builtin_ctz(inv) : 32;
-			bool more = val && inv == 0;
-			for (int32_t wj = wi + 1; __ballot(more); ++wj) { // a run of 32 or more matches (3 % of the steps of a 10 %-error read): next window
+			for (int32_t wj = wi + 1; __ballot(inv == 0u); ++wj) { // a run of 32 or more matches (3 % of the steps of a 10 %-error read): next window
 				const uint32_t *mq = &Mk[wj < MROWS - 2 ? wj : MROWS - 2][64 * j + lane];
-				inv = ~__builtin_amdgcn_alignbit(mq[64 * J], mq[0], sh);
-				n += more ? (inv ? (int32_t)__builtin_ctz(inv) : 32) : 0;
-				more = more && inv == 0;
+				const uint32_t v = ~__builtin_amdgcn_alignbit(mq[64 * J], mq[0], tp);
+				n += inv == 0u ? (v ? (int32_t)__builtin_ctz(v) : 32) : 0;
+				inv = inv == 0u ? v : inv;
 			}
-			const int32_t k = val ? k0 + n : k0;
+			const int32_t k = k0 + n;
 			HA(j, 0) = k;
-			if (val && d == e && k == tl - 1) { // the end cell (then d + k == ql - 1)
+			if (k == fc[j]) { // the end cell: offset tl - 1 on diagonal e (then d + k == ql - 1; k0 + 1 <= tl holds there, and fc is out of reach in every other lane)
 				st = WFW_DONE;
 				lst = n == 0 ? (int32_t)(acc[j] & 7u) : 0; // it was entered by a gap state and not extended: the traceback starts in that state (miniwfa.c:406-407)
 			}
@@ -344,7 +347,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 // (two bit-field extracts, two mask windows, one repack).  Neighbour exchange: diagonal 2 l - 1 is the high half of lane l - 1, 2 l + 2 the low half of lane l + 1 -- a DPP wave
 // shift and a v_alignbit per operand.  One problem per wavefront, its scalars in SGPRs; traceback rows, result record and the walk (k_wfa_tb) are those of k_wfa_fw.
 typedef short wfp_pk2 __attribute__((ext_vector_type(2)));
-#define WFP_NEG 0xE000E000u   // two 16-bit cells of -8192: below every offset, and no difference of two cells overflows 16 bits (offsets < 600, at most 300 increments on top)
+// Cells are stored BIASED by 0x2000 per half: "unreachable" is 0 -- what a DPP shift with bound_ctrl feeds the lanes at the wave's edge, what a fresh register holds, and what
+// `& okv` leaves of a diagonal outside the matrix -- and loses every comparison against a reached cell (>= 0x1fff = offset -1).  An unreachable cell grows by at most one per
+// step (< 300), a reached one stays below 0x2000 + 513: no half ever carries into its neighbour and every difference of two cells fits 16 bits.
+#define WFP_BIAS 0x2000
 #define WFP_ONE 0x00010001u
 __device__ __forceinline__ uint32_t wfp_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(wfp_pk2, a), __builtin_bit_cast(wfp_pk2, b))); }
 __device__ __forceinline__ uint32_t wfp_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (wfp_pk2)(__builtin_bit_cast(wfp_pk2, a) + __builtin_bit_cast(wfp_pk2, b))); }
@@ -354,10 +360,18 @@ __device__ __forceinline__ uint32_t wfp_lt(uint32_t a, uint32_t b) // all ones i
 	return __builtin_bit_cast(uint32_t, (wfp_pk2)(d >> (wfp_pk2)(15)));
 }
 __device__ __forceinline__ uint32_t wfp_sel(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
-// left neighbours of a lane's two diagonals: (high half of lane l - 1, own low half); lane 0's comes from `edge` (the previous set's lane 63, or WFP_NEG)
-__device__ __forceinline__ uint32_t wfp_from_left(uint32_t edge, uint32_t x) { const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)x, 0x138, 0xf, 0xf, false); return __builtin_amdgcn_alignbit(x, t, 16); }
-// right neighbours: (own high half, low half of lane l + 1); lane 63's comes from `edge` (the next set's lane 0, or WFP_NEG)
-__device__ __forceinline__ uint32_t wfp_from_right(uint32_t edge, uint32_t x) { const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)x, 0x130, 0xf, 0xf, false); return __builtin_amdgcn_alignbit(t, x, 16); }
+// left neighbours of a lane's two diagonals: (high half of lane l - 1, own low half).  EDGE: lane 0's comes from `edge` (the previous set's lane 63); else it is unreachable (0)
+template<bool EDGE> __device__ __forceinline__ uint32_t wfp_from_left(uint32_t edge, uint32_t x)
+{
+	const uint32_t t = EDGE ? (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)x, 0x138, 0xf, 0xf, false) : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, true); // wave_shr:1
+	return __builtin_amdgcn_alignbit(x, t, 16);
+}
+// right neighbours: (own high half, low half of lane l + 1); lane 63's comes from `edge` (the next set's lane 0) or is unreachable
+template<bool EDGE> __device__ __forceinline__ uint32_t wfp_from_right(uint32_t edge, uint32_t x)
+{
+	const uint32_t t = EDGE ? (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)x, 0x130, 0xf, 0xf, false) : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xf, 0xf, true); // wave_shl:1
+	return __builtin_amdgcn_alignbit(t, x, 16);
+}
 
 template<int W, int SEQCAP>
 __global__ void __launch_bounds__(64) k_wfa_fwp(const int *__restrict__ n_items_p, int cap, const int32_t *__restrict__ list, const mga_wfa_prob_t *__restrict__ prob,
@@ -439,59 +453,70 @@ __global__ void __launch_bounds__(64) k_wfa_fwp(const int *__restrict__ n_items_
 			}
 			WFW_LDS_FENCE();
 			// ---- state: two diagonals per register
-			uint32_t H[JP][18], E1[JP][3], F1[JP][3], E2[JP][2], F2[JP][2], okv[JP], accA[JP], accB[JP];
+			uint32_t H[JP][18], E1[JP][3], F1[JP][3], E2[JP][2], F2[JP][2], okv[JP], accA[JP], accB[JP], fc[JP];
 #pragma unroll
 			for (int j = 0; j < JP; ++j) {
 				const int32_t dA = lo + 128 * j + 2 * lane, dB = dA + 1;
 #pragma unroll
-				for (int a = 0; a < 18; ++a) H[j][a] = WFP_NEG;
+				for (int a = 0; a < 18; ++a) H[j][a] = 0;
 #pragma unroll
-				for (int a = 0; a < 3; ++a) E1[j][a] = F1[j][a] = WFP_NEG;
+				for (int a = 0; a < 3; ++a) E1[j][a] = F1[j][a] = 0;
 #pragma unroll
-				for (int a = 0; a < 2; ++a) E2[j][a] = F2[j][a] = WFP_NEG;
+				for (int a = 0; a < 2; ++a) E2[j][a] = F2[j][a] = 0;
 				okv[j] = ((dA >= -tl && dA <= ql && 128 * j + 2 * lane < W) ? 0x0000ffffu : 0u) | ((dB >= -tl && dB <= ql && 128 * j + 2 * lane + 1 < W) ? 0xffff0000u : 0u);
 				accA[j] = accB[j] = 0;
-				if (dA == 0) H[j][2] = (H[j][2] & 0xffff0000u) | 0x0000ffffu; // score 0: H[d = 0] = -1 (miniwfa.c:103-119); age 0 of an even step is H[2]
-				if (dB == 0) H[j][2] = (H[j][2] & 0x0000ffffu) | 0xffff0000u;
+				if (dA == 0) H[j][2] = (uint32_t)(WFP_BIAS - 1);       // score 0: H[d = 0] = -1 (miniwfa.c:103-119); age 0 of an even step is H[2]
+				if (dB == 0) H[j][2] = (uint32_t)(WFP_BIAS - 1) << 16;
+				// what the end cell looks like: offset tl - 1 on diagonal e (one half of one lane); 0xffff in a half never matches
+				fc[j] = (dA == e ? (uint32_t)(tl - 1 + WFP_BIAS) : 0xffffu) | (dB == e ? (uint32_t)(tl - 1 + WFP_BIAS) : 0xffffu) << 16;
 			}
 			bool bail = false;
 #define HP(j_, a_) H[j_][(a_) + 2 - P]
 			auto step = [&](auto Pc) __attribute__((always_inline)) -> bool { // false: the problem is through (done or bail)
 				constexpr int P = decltype(Pc)::value;
-				// ---- extension of slice s (miniwfa.c:399-411)
+				// ---- extension of slice s (miniwfa.c:399-411): the two cells of a lane side by side.  A cell that cannot be extended (unreachable, or at the target's end) gets the
+				// window "no match at once" (inv = 1), so that its run is 0 without a select; a run that fills its 32-bit window (3 % of the steps) goes on in ONE loop for both
 				const int32_t rs = wfw_reach(s);
-				bool fin = false;
-				int32_t flst = 0;
+				uint32_t dfin[JP], nfin[JP]; // a set's cells against the end cell's pattern (a zero half = reached), and the lengths of its two runs
+				bool hit = false;
 #pragma unroll
 				for (int j = 0; j < JP; ++j) {
 					const int32_t b0 = lo + 128 * j;
+					dfin[j] = ~0u, nfin[j] = 0;
 					if (b0 > rs || b0 + 127 < -rs) continue;
 					const uint32_t x = HP(j, 0);
-					int32_t kk[2];
-#pragma unroll
-					for (int h = 0; h < 2; ++h) {
-						const int32_t d = b0 + 2 * lane + h;
-						const int32_t k0 = h ? (int32_t)x >> 16 : (int32_t)(x << 16) >> 16, tp = k0 + 1;
-						const bool val = (uint32_t)tp <= (uint32_t)tl;
-						const int32_t wi = val ? tp >> 5 : 0, sh = tp & 31;
-						const uint32_t *mp = &Mk[wi][64 * (2 * j + h) + lane];
-						uint32_t inv = ~__builtin_amdgcn_alignbit(mp[128 * JP], mp[0], sh);
-						int32_t n = inv ? (int32_t)__builtin_ctz(inv) : 32;
-						bool more = val && inv == 0;
-						for (int32_t wj = wi + 1; __ballot(more); ++wj) {
-							const uint32_t *mq = &Mk[wj < MROWS - 2 ? wj : MROWS - 2][64 * (2 * j + h) + lane];
-							inv = ~__builtin_amdgcn_alignbit(mq[128 * JP], mq[0], sh);
-							n += more ? (inv ? (int32_t)__builtin_ctz(inv) : 32) : 0;
-							more = more && inv == 0;
-						}
-						const int32_t k = val ? k0 + n : k0;
-						kk[h] = k;
-						if (val && d == e && k == tl - 1) { fin = true; flst = n == 0 ? (int32_t)((h ? accB[j] : accA[j]) & 7u) : 0; } // entered by a gap state and not extended: the traceback starts in that state (miniwfa.c:406-407)
+					const int32_t tpA = (int32_t)(x & 0xffffu) + (1 - WFP_BIAS), tpB = (int32_t)(x >> 16) + (1 - WFP_BIAS);
+					const bool valA = (uint32_t)tpA <= (uint32_t)tl, valB = (uint32_t)tpB <= (uint32_t)tl; // -1 <= offset < tl
+					const int32_t wiA = valA ? tpA >> 5 : 0, wiB = valB ? tpB >> 5 : 0;
+					const uint32_t *mA = &Mk[wiA][64 * (2 * j) + lane], *mB = &Mk[wiB][64 * (2 * j + 1) + lane];
+					uint32_t invA = ~__builtin_amdgcn_alignbit(mA[128 * JP], mA[0], tpA), invB = ~__builtin_amdgcn_alignbit(mB[128 * JP], mB[0], tpB); // (the shift is taken mod 32)
+					invA = valA ? invA : 1u, invB = valB ? invB : 1u;
+					uint32_t nA = invA ? (uint32_t)__builtin_ctz(invA) : 32u, nB = invB ? (uint32_t)__builtin_ctz(invB) : 32u;
+					for (int32_t it = 1; __ballot(invA == 0u || invB == 0u); ++it) {
+						const int32_t wa = wiA + it < MROWS - 2 ? wiA + it : MROWS - 2, wb = wiB + it < MROWS - 2 ? wiB + it : MROWS - 2;
+						const uint32_t *qA = &Mk[wa][64 * (2 * j) + lane], *qB = &Mk[wb][64 * (2 * j + 1) + lane];
+						const uint32_t vA = ~__builtin_amdgcn_alignbit(qA[128 * JP], qA[0], tpA), vB = ~__builtin_amdgcn_alignbit(qB[128 * JP], qB[0], tpB);
+						nA += invA == 0u ? (vA ? (uint32_t)__builtin_ctz(vA) : 32u) : 0u, nB += invB == 0u ? (vB ? (uint32_t)__builtin_ctz(vB) : 32u) : 0u;
+						invA = invA == 0u ? vA : invA, invB = invB == 0u ? vB : invB;
 					}
-					HP(j, 0) = ((uint32_t)kk[0] & 0xffffu) | ((uint32_t)kk[1] << 16);
+					nfin[j] = nA | nB << 16;
+					const uint32_t xn = x + nfin[j]; // (no carry between the halves: offsets stay below 0x2000 + tl)
+					HP(j, 0) = xn;
+					dfin[j] = xn ^ fc[j];
+					hit = hit || (dfin[j] & 0xffffu) == 0u || dfin[j] < 0x10000u;
 				}
-				const uint64_t m_fin = __ballot(fin);
-				if (m_fin) { lst = __shfl(flst, (int)__builtin_ctzll(m_fin)); done = true; return false; } // (the end cell lies on ONE diagonal)
+				const uint64_t m_fin = __ballot(hit);
+				if (m_fin) { // the end cell (it lies on ONE diagonal).  Entered by a gap state and not extended: the traceback starts in that state (miniwfa.c:406-407)
+					int32_t flst = 0;
+#pragma unroll
+					for (int j = 0; j < JP; ++j) {
+						if ((dfin[j] & 0xffffu) == 0u) flst = (nfin[j] & 0xffffu) == 0u ? (int32_t)(accA[j] & 7u) : 0;
+						else if (dfin[j] < 0x10000u) flst = (nfin[j] >> 16) == 0u ? (int32_t)(accB[j] & 7u) : 0;
+					}
+					lst = __shfl(flst, (int)__builtin_ctzll(m_fin));
+					done = true;
+					return false;
+				}
 				if (s + 1 >= bnd) { bail = true; return false; }
 				// ---- slice s + 1 (miniwfa.c:281-308), two diagonals per instruction
 				const int32_t rn = wfw_reach(s + 1);
@@ -499,9 +524,9 @@ __global__ void __launch_bounds__(64) k_wfa_fwp(const int *__restrict__ n_items_
 #pragma unroll
 				for (int j = 0; j < JP; ++j) {
 					const int32_t b0 = lo + 128 * j;
-					if (b0 > rn || b0 + 127 < -rn) { nH[j] = nE1[j] = nF1[j] = nE2[j] = nF2[j] = WFP_NEG; continue; }
-#define WFP_L(R, a) wfp_from_left(j > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)R[j > 0 ? j - 1 : 0][a], 63) : WFP_NEG, R[j][a])
-#define WFP_R(R, a) wfp_from_right(j < JP - 1 ? (uint32_t)__builtin_amdgcn_readlane((int)R[j < JP - 1 ? j + 1 : j][a], 0) : WFP_NEG, R[j][a])
+					if (b0 > rn || b0 + 127 < -rn) { nH[j] = nE1[j] = nF1[j] = nE2[j] = nF2[j] = 0u; continue; }
+#define WFP_L(R, a) (j > 0 ? wfp_from_left<true>((uint32_t)__builtin_amdgcn_readlane((int)R[j > 0 ? j - 1 : 0][a], 63), R[j][a]) : wfp_from_left<false>(0u, R[j][a]))
+#define WFP_R(R, a) (j < JP - 1 ? wfp_from_right<true>((uint32_t)__builtin_amdgcn_readlane((int)R[j < JP - 1 ? j + 1 : j][a], 0), R[j][a]) : wfp_from_right<false>(0u, R[j][a]))
 					const uint32_t ho1l = WFP_L(H, 5 + 2 - P), e1l = WFP_L(E1, 1), ho2l = WFP_L(H, 15 + 2 - P), e2l = WFP_L(E2, 0);
 					const uint32_t ho1r = WFP_R(H, 5 + 2 - P), f1r = WFP_R(F1, 1), ho2r = WFP_R(H, 15 + 2 - P), f2r = WFP_R(F2, 0);
 #undef WFP_L
@@ -517,8 +542,7 @@ __global__ void __launch_bounds__(64) k_wfa_fwp(const int *__restrict__ n_items_
 					z &= wfp_lt(hx1, hh);                                                          // hx1 >= hh ? 0 : z
 					const uint32_t vH = wfp_max(hx1, hh), bz = bits | z;
 					accA[j] = accA[j] << 8 | (bz & 0xffu), accB[j] = accB[j] << 8 | (bz >> 16);
-					nH[j] = wfp_sel(okv[j], vH, WFP_NEG), nE1[j] = wfp_sel(okv[j], vE1, WFP_NEG), nF1[j] = wfp_sel(okv[j], vF1, WFP_NEG);
-					nE2[j] = wfp_sel(okv[j], vE2, WFP_NEG), nF2[j] = wfp_sel(okv[j], vF2, WFP_NEG);
+					nH[j] = vH & okv[j], nE1[j] = vE1 & okv[j], nF1[j] = vF1 & okv[j], nE2[j] = vE2 & okv[j], nF2[j] = vF2 & okv[j]; // (a diagonal outside the matrix stays unreachable)
 				}
 #pragma unroll
 				for (int j = 0; j < JP; ++j) { // age shift (H: every second step, by two)
@@ -714,10 +738,10 @@ extern "C" int mga_dev_wfa_win(mga_sctx_t *sc, const int *d_n, int n, const int3
 	mga_prof_begin(st, MGA_K_WFAW0 + wt);
 #define LAUNCH(GG, JJ, SEQ) hipLaunchKernelGGL((k_wfa_fw<GG, JJ, SEQ>), dim3(wgs), dim3(64), 0, st, d_n, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_tb, stride, d_counter, rt)
 	// MGA_WFA_PACKED=<mask> (read per launch): which of the rungs of 128 (bit 0) / 192 (bit 1) / 256 (bit 2) diagonals run the packed kernel (two diagonals per lane, k_wfa_fwp).
-	// Default 5: measured per 125 000 reads (profiles/r05m_packed_sweep.txt) 128: 47.9 -> 32.5 ms, 256: 13.4 -> 10.4 ms, 192: 24.0 -> 25.1 ms (a quarter of its second
-	// set's lanes hold no diagonal, and its registers cost occupancy) -- same results either way (tests/test_gpu_stages.py runs masks 0 and 7)
+	// Default 7: measured per 125 000 reads (profiles/r05n_packed_sweep.txt) 128: 45.9 -> 26.9 ms, 192: 22.8 -> 21.1 ms, 256: 12.5 -> 8.5 ms -- same results either way
+	// (tests/test_gpu_stages.py runs masks 0 and 7)
 	const char *e_pk = getenv("MGA_WFA_PACKED");
-	const int pk_mask = e_pk && *e_pk ? atoi(e_pk) : 5;
+	const int pk_mask = e_pk && *e_pk ? atoi(e_pk) : 7;
 #define LAUNCHP(WW, SEQ) hipLaunchKernelGGL((k_wfa_fwp<WW, SEQ>), dim3(wgs), dim3(64), 0, st, d_n, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_tb, stride, d_counter, rt)
 	if (wt == 0) LAUNCH(16, 1, 128);
 	else if (wt == 1) LAUNCH(32, 1, 192);

@@ -1,7 +1,7 @@
 /* CPU model of the PACKED windowed WFA forward pass (minigraph_amd/csrc/k_wfa_w.hip: k_wfa_fwp) -- two neighbouring diagonals per lane in the 16-bit halves of one
  * register, the recurrence on packed 16-bit arithmetic, the neighbour exchange as a lane shift + a funnel shift, match masks, traceback rows with reachable diagonals only --
  * followed by the walk of k_wfa_tb (wfw_trace), against the oracle's exact WFA (oracle/mgo_wfa.c): whenever the window decides (score below its bound), score and CIGAR must be
- * the oracle's; the model must terminate within the bound's steps; the walk must never read a traceback dword that was not written.  Lanes are loops here, registers arrays
+ * the oracle's; cells are stored biased (unreachable = 0), no half may carry into its neighbour; the model must terminate within the bound's steps; the walk must never read a traceback dword that was not written.  Lanes are loops here, registers arrays
  * indexed by lane; every arithmetic step is the kernel's.  Test infrastructure only. */
 #include <stdio.h>
 #include <stdlib.h>
@@ -9,7 +9,8 @@
 #include <stdint.h>
 #include "mgo.h"
 
-#define NEGPK 0xE000E000u
+#define BIAS 0x2000   /* cells are stored + 0x2000 per half: "unreachable" is 0 */
+#define NEGPK 0u
 #define ONEPK 0x00010001u
 #define SMAX 256
 #define POISON 0xA5A5A5A5u
@@ -51,7 +52,7 @@ static fw_res_t forward(int W, int tl, const char *T, int ql, const char *Q, uin
 {
 	const int JP = (W + 127) / 128, e = ql - tl;
 	static uint32_t Mk[MROWS + 1][128 * MAXJP];
-	uint32_t H[MAXJP][18][64], E1[MAXJP][3][64], F1[MAXJP][3][64], E2[MAXJP][2][64], F2[MAXJP][2][64], okv[MAXJP][64], accA[MAXJP][64], accB[MAXJP][64];
+	uint32_t H[MAXJP][18][64], E1[MAXJP][3][64], F1[MAXJP][3][64], E2[MAXJP][2][64], F2[MAXJP][2][64], okv[MAXJP][64], accA[MAXJP][64], accB[MAXJP][64], fc[MAXJP][64];
 	int lo = 0, bnd, s = 0, j, l, a, h, q, row = 0;
 	fw_res_t R = { 0, -1, 0, 0 };
 	bnd = window(W, tl, ql, &lo, SMAX);
@@ -76,8 +77,9 @@ static fw_res_t forward(int W, int tl, const char *T, int ql, const char *Q, uin
 			for (a = 0; a < 2; ++a) E2[j][a][l] = F2[j][a][l] = NEGPK;
 			okv[j][l] = ((dA >= -tl && dA <= ql && 128 * j + 2 * l < W) ? 0x0000ffffu : 0u) | ((dB >= -tl && dB <= ql && 128 * j + 2 * l + 1 < W) ? 0xffff0000u : 0u);
 			accA[j][l] = accB[j][l] = 0;
-			if (dA == 0) H[j][2][l] = (H[j][2][l] & 0xffff0000u) | 0x0000ffffu;
-			if (dB == 0) H[j][2][l] = (H[j][2][l] & 0x0000ffffu) | 0xffff0000u;
+			if (dA == 0) H[j][2][l] = (uint32_t)(BIAS - 1);
+			if (dB == 0) H[j][2][l] = (uint32_t)(BIAS - 1) << 16;
+			fc[j][l] = (dA == e ? (uint32_t)(tl - 1 + BIAS) : 0xffffu) | (dB == e ? (uint32_t)(tl - 1 + BIAS) : 0xffffu) << 16;
 		}
 	for (;;) {
 		const int P = s & 1, rs = reach(s), rn = reach(s + 1);
@@ -85,28 +87,38 @@ static fw_res_t forward(int W, int tl, const char *T, int ql, const char *Q, uin
 		int fin = 0, flst = 0;
 		uint32_t nH[MAXJP][64], nE1[MAXJP][64], nF1[MAXJP][64], nE2[MAXJP][64], nF2[MAXJP][64];
 		if (++R.steps > bnd + 2) { fprintf(stderr, "model does not terminate (W %d tl %d ql %d)\n", W, tl, ql); exit(2); }
-		for (j = 0; j < JP; ++j) { /* extension of slice s */
+		for (j = 0; j < JP; ++j) { /* extension of slice s: both cells of a lane, one loop for runs that fill their window */
 			const int b0 = lo + 128 * j;
+			uint32_t inv[2][64], n[2][64];
+			int tp[2][64], wi[2][64], it, any;
 			if (b0 > rs || b0 + 127 < -rs) continue;
 			for (l = 0; l < 64; ++l) {
 				const uint32_t x = HP(j, 0)[l];
-				int kk[2];
 				for (h = 0; h < 2; ++h) {
-					const int d = b0 + 2 * l + h, k0 = h ? (int32_t)x >> 16 : (int32_t)(x << 16) >> 16, tp = k0 + 1;
-					const int val = (uint32_t)tp <= (uint32_t)tl, wi = val ? tp >> 5 : 0, sh = tp & 31;
-					uint32_t inv = ~alignbit(Mk[wi + 1][64 * (2 * j + h) + l], Mk[wi][64 * (2 * j + h) + l], sh);
-					int n = inv ? __builtin_ctz(inv) : 32, more = val && inv == 0, wj;
-					for (wj = wi + 1; more; ++wj) {
-						const int wr = wj < MROWS - 2 ? wj : MROWS - 2;
-						inv = ~alignbit(Mk[wr + 1][64 * (2 * j + h) + l], Mk[wr][64 * (2 * j + h) + l], sh);
-						n += inv ? __builtin_ctz(inv) : 32;
-						more = inv == 0;
-						if (wj > MROWS + 4) { fprintf(stderr, "match run does not end (W %d tl %d ql %d d %d)\n", W, tl, ql, d); exit(2); }
-					}
-					kk[h] = val ? k0 + n : k0;
-					if (val && d == e && kk[h] == tl - 1) { fin = 1; flst = n == 0 ? (int)((h ? accB[j][l] : accA[j][l]) & 7u) : 0; }
+					const int val = (tp[h][l] = (int)(h ? x >> 16 : x & 0xffffu) + (1 - BIAS), (uint32_t)tp[h][l] <= (uint32_t)tl);
+					wi[h][l] = val ? tp[h][l] >> 5 : 0;
+					inv[h][l] = ~alignbit(Mk[wi[h][l] + 1][64 * (2 * j + h) + l], Mk[wi[h][l]][64 * (2 * j + h) + l], tp[h][l] & 31);
+					if (!val) inv[h][l] = 1u;
+					n[h][l] = inv[h][l] ? (uint32_t)__builtin_ctz(inv[h][l]) : 32u;
 				}
-				HP(j, 0)[l] = ((uint32_t)kk[0] & 0xffffu) | ((uint32_t)kk[1] << 16);
+			}
+			for (it = 1;; ++it) {
+				for (any = 0, l = 0; l < 64; ++l) any |= inv[0][l] == 0u || inv[1][l] == 0u;
+				if (!any) break;
+				if (it > MROWS + 4) { fprintf(stderr, "match run does not end (W %d tl %d ql %d)\n", W, tl, ql); exit(2); }
+				for (l = 0; l < 64; ++l)
+					for (h = 0; h < 2; ++h) {
+						const int w = wi[h][l] + it < MROWS - 2 ? wi[h][l] + it : MROWS - 2;
+						const uint32_t v = ~alignbit(Mk[w + 1][64 * (2 * j + h) + l], Mk[w][64 * (2 * j + h) + l], tp[h][l] & 31);
+						if (inv[h][l] == 0u) n[h][l] += v ? (uint32_t)__builtin_ctz(v) : 32u, inv[h][l] = v;
+					}
+			}
+			for (l = 0; l < 64; ++l) {
+				const uint32_t nf = n[0][l] | n[1][l] << 16, xn = HP(j, 0)[l] + nf, df = xn ^ fc[j][l];
+				if ((n[0][l] | n[1][l]) >> 15) { fprintf(stderr, "a run overflows its half\n"); exit(2); }
+				HP(j, 0)[l] = xn;
+				if ((df & 0xffffu) == 0u) fin = 1, flst = (nf & 0xffffu) == 0u ? (int)(accA[j][l] & 7u) : 0;
+				else if (df < 0x10000u) fin = 1, flst = (nf >> 16) == 0u ? (int)(accB[j][l] & 7u) : 0;
 			}
 		}
 		if (fin) { R.done = 1, R.score = s, R.lst = flst; break; }
@@ -129,10 +141,12 @@ static fw_res_t forward(int W, int tl, const char *T, int ql, const char *Q, uin
 				z &= pk_lt(hx1, hh);
 				vH = pk_max(hx1, hh), bz = bits | z;
 				accA[j][l] = accA[j][l] << 8 | (bz & 0xffu), accB[j][l] = accB[j][l] << 8 | (bz >> 16);
-				nH[j][l] = sel(okv[j][l], vH, NEGPK), nE1[j][l] = sel(okv[j][l], vE1, NEGPK), nF1[j][l] = sel(okv[j][l], vF1, NEGPK);
-				nE2[j][l] = sel(okv[j][l], vE2, NEGPK), nF2[j][l] = sel(okv[j][l], vF2, NEGPK);
+				nH[j][l] = vH & okv[j][l], nE1[j][l] = vE1 & okv[j][l], nF1[j][l] = vF1 & okv[j][l], nE2[j][l] = vE2 & okv[j][l], nF2[j][l] = vF2 & okv[j][l];
 			}
 		}
+		for (j = 0; j < JP; ++j) /* every cell stays inside its half with room to spare */
+			for (l = 0; l < 64; ++l)
+				if ((nH[j][l] & 0xffffu) > BIAS + 600u || (nH[j][l] >> 16) > BIAS + 600u || (nF1[j][l] & 0xffffu) > BIAS + 600u || (nF2[j][l] >> 16) > BIAS + 600u) { fprintf(stderr, "a cell leaves its range (W %d tl %d ql %d)\n", W, tl, ql); exit(2); }
 		for (j = 0; j < JP; ++j) /* age shift */
 			for (l = 0; l < 64; ++l) {
 				HP(j, -1)[l] = nH[j][l];
