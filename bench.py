@@ -490,8 +490,9 @@ def main():
                                                      wait_share=float(f[-7]) if f[-7] != "-" else None)
                     except ValueError:
                         pass
+                # (round 5: the 128 / 192 / 256 rungs run the packed kernel, MGA_WFA_PACKED=7)
                 names = {"k_wfa_w[16x4]": "k_wfa_fw<16, 1, 128>", "k_wfa_w[32x2]": "k_wfa_fw<32, 1, 192>", "k_wfa_w[64]": "k_wfa_fw<64, 1, 256>", "k_wfa_w[128]": "k_wfa_fwp<128, 384>",
-                         "k_wfa_w[192]": "k_wfa_fwp<192, 384>", "k_wfa_w[256]": "k_wfa_fwp<256, 512>",  # (round 5: the 128 / 192 / 256 rungs run the packed kernel, MGA_WFA_PACKED=7) "k_wfa_r[512]": "k_wfa_r<4, 2, 1024, 1024, 8192, true>", "k_wfa_tb": "k_wfa_tb",
+                         "k_wfa_w[192]": "k_wfa_fwp<192, 384>", "k_wfa_w[256]": "k_wfa_fwp<256, 512>", "k_wfa_r[512]": "k_wfa_r<4, 2, 1024, 1024, 8192, true>", "k_wfa_tb": "k_wfa_tb",
                          "k_lchain": "k_lchain", "k_sketch": "k_sketch", "k_text": "k_text<64>", "k_seed_fill": "k_seed_fill", "k_seed_count": "k_seed_count"}
                 # the counter passes ran `bench.py --steps S --warmup W --one-placement` over the SAME reads as this run's isolated pass, so a kernel's instructions per pass =
                 # its total / the passes the file covers; launches are not compared one to one (the chunking of a pass may differ).  k_sketch is left out: its
