@@ -36,7 +36,10 @@
 #include "dev_common.h"
 #include "wfa_window.h"
 
-#define WF_NEG_INF (-0x40000000)
+// (round 5) Cells are stored BIASED by WFW_BIAS: "unreachable" is 0 -- what a DPP shift with bound_ctrl feeds a group's edge lanes, what a cleared register holds and what `& okv`
+// leaves of a diagonal outside the matrix -- and loses every comparison against a reached cell (>= WFW_BIAS - 1 = offset -1); an unreachable cell grows by at most one per step
+// (< 300 in a window's life).  Before: NEG_INF = -2^30 had to be moved into the destination of every one of the eight neighbour shifts of a step.
+#define WFW_BIAS 0x2000
 
 extern "C" int32_t mga_wfw_window(int32_t W, int32_t tl, int32_t ql, int32_t *lo) { return wfw_window(W, tl, ql, lo, WFW_SMAX); } // (tests)
 
@@ -46,18 +49,20 @@ __device__ __forceinline__ int32_t wfw_reach(int32_t s) { return s < 6 ? 0 : max
 __device__ __forceinline__ int32_t wfw_max(int32_t a, int32_t b) { return a > b ? a : b; }
 __device__ __forceinline__ int32_t wfw_sel(int32_t mask, int32_t a, int32_t b) { return (a & mask) | (b & ~mask); } // v_bfi_b32: a where mask is all ones
 
-// neighbour diagonals inside a group of G lanes.  from_left: lane l <- src[l-1], the group's first lane gets NEG_INF (or `edge`: the previous slot's last lane)
-template<int G> __device__ __forceinline__ int32_t wfw_from_left(int32_t edge, int32_t src, int32_t m_first)
+// neighbour diagonals inside a group of G lanes.  from_left: lane l <- src[l-1]; the group's first lane gets "unreachable" (0), or with EDGE the previous slot's last lane
+template<int G, bool EDGE> __device__ __forceinline__ int32_t wfw_from_left(int32_t edge, int32_t src, int32_t nm_first)
 {
-	if (G == 16) return __builtin_amdgcn_update_dpp(edge, src, 0x111, 0xf, 0xf, false); // row_shr:1 -- lane 0 of every row of 16 keeps `edge`
-	const int32_t v = __builtin_amdgcn_update_dpp(edge, src, 0x138, 0xf, 0xf, false);   // wave_shr:1
-	return G == 32 ? wfw_sel(m_first, edge, v) : v;                                      // (lane 32 must not see lane 31)
+	if (G == 16) return __builtin_amdgcn_update_dpp(0, src, 0x111, 0xf, 0xf, true);       // row_shr:1, bound_ctrl: lane 0 of every row of 16 reads 0
+	if (EDGE) return __builtin_amdgcn_update_dpp(edge, src, 0x138, 0xf, 0xf, false);      // wave_shr:1, lane 0 keeps `edge`
+	const int32_t v = __builtin_amdgcn_update_dpp(0, src, 0x138, 0xf, 0xf, true);         // wave_shr:1, lane 0 reads 0
+	return G == 32 ? v & nm_first : v;                                                     // (lane 32 must not see lane 31)
 }
-template<int G> __device__ __forceinline__ int32_t wfw_from_right(int32_t edge, int32_t src, int32_t m_last)
+template<int G, bool EDGE> __device__ __forceinline__ int32_t wfw_from_right(int32_t edge, int32_t src, int32_t nm_last)
 {
-	if (G == 16) return __builtin_amdgcn_update_dpp(edge, src, 0x101, 0xf, 0xf, false); // row_shl:1
-	const int32_t v = __builtin_amdgcn_update_dpp(edge, src, 0x130, 0xf, 0xf, false);   // wave_shl:1
-	return G == 32 ? wfw_sel(m_last, edge, v) : v;
+	if (G == 16) return __builtin_amdgcn_update_dpp(0, src, 0x101, 0xf, 0xf, true);       // row_shl:1
+	if (EDGE) return __builtin_amdgcn_update_dpp(edge, src, 0x130, 0xf, 0xf, false);      // wave_shl:1
+	const int32_t v = __builtin_amdgcn_update_dpp(0, src, 0x130, 0xf, 0xf, true);
+	return G == 32 ? v & nm_last : v;
 }
 
 // per-lane problem state: 0 idle, 1 running, 2 reached the end cell (this lane holds it), 3 gives up (score bound / lengths)
@@ -86,7 +91,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 	const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
 	const int n_items = min(*n_items_p, cap); // (the list's length is read here: rungs below this one appended to it during the same sweep)
 	uint8_t *const Tg = Tb[grp], *const Qg = Qb[grp];
-	const int32_t m_first = gl == 0 ? -1 : 0, m_last = gl == G - 1 ? -1 : 0;
+	const int32_t nm_first = gl == 0 ? 0 : -1, nm_last = gl == G - 1 ? 0 : -1; // (all ones except in a group's first / last lane)
 	const uint64_t gmask = (G == 64 ? ~0ULL : ((1ULL << G) - 1ULL)) << (grp * G);
 #define WFW_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
@@ -106,11 +111,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 	for (int j = 0; j < J; ++j) {
 		okv[j] = 0, acc[j] = 0, fc[j] = 0x7fffffff;
 #pragma unroll
-		for (int a = 0; a < 18; ++a) H[j][a] = WF_NEG_INF;
+		for (int a = 0; a < 18; ++a) H[j][a] = 0;
 #pragma unroll
-		for (int a = 0; a < 3; ++a) E1[j][a] = F1[j][a] = WF_NEG_INF;
+		for (int a = 0; a < 3; ++a) E1[j][a] = F1[j][a] = 0;
 #pragma unroll
-		for (int a = 0; a < 2; ++a) E2[j][a] = F2[j][a] = WF_NEG_INF;
+		for (int a = 0; a < 2; ++a) E2[j][a] = F2[j][a] = 0;
 	}
 
 	// H of the last 16 scores is shifted by TWO registers every second step (k_wfa_r.hip): the step body exists twice, P = t & 1.
@@ -228,21 +233,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 						}
 					}
 					WFW_LDS_FENCE();
-					const int32_t mf = fill ? -1 : 0;
+					const int32_t nmf = fill ? 0 : -1;
 #pragma unroll
 					for (int j = 0; j < J; ++j) {
 						const int32_t d = lo + gl + 64 * j;
 #pragma unroll
-						for (int a = 0; a < 18; ++a) H[j][a] = wfw_sel(mf, WF_NEG_INF, H[j][a]);
+						for (int a = 0; a < 18; ++a) H[j][a] &= nmf;
 #pragma unroll
-						for (int a = 0; a < 3; ++a) E1[j][a] = wfw_sel(mf, WF_NEG_INF, E1[j][a]), F1[j][a] = wfw_sel(mf, WF_NEG_INF, F1[j][a]);
+						for (int a = 0; a < 3; ++a) E1[j][a] &= nmf, F1[j][a] &= nmf;
 #pragma unroll
-						for (int a = 0; a < 2; ++a) E2[j][a] = wfw_sel(mf, WF_NEG_INF, E2[j][a]), F2[j][a] = wfw_sel(mf, WF_NEG_INF, F2[j][a]);
+						for (int a = 0; a < 2; ++a) E2[j][a] &= nmf, F2[j][a] &= nmf;
 						if (fill) {
 							acc[j] = 0;
 							okv[j] = (d >= -tl && d <= ql) ? -1 : 0;
-							fc[j] = d == e ? tl - 1 : 0x7fffffff;
-							if (d == 0) HA(j, 0) = -1; // score 0: H[d = 0] = -1 (miniwfa.c:103-119)
+							fc[j] = d == e ? tl - 1 + WFW_BIAS : 0x7fffffff;
+							if (d == 0) HA(j, 0) = WFW_BIAS - 1; // score 0: H[d = 0] = -1 (miniwfa.c:103-119)
 						}
 					}
 				}
@@ -254,8 +259,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 #pragma unroll
 		for (int j = 0; j < J; ++j) {
 			if (J > 1) { const int32_t b0 = __builtin_amdgcn_readfirstlane(lo) + 64 * j; if (b0 > rs || b0 + 63 < -rs) continue; } // no diagonal of the slot is reachable yet
-			const int32_t k0 = HA(j, 0), tp = k0 + 1;
-			const bool val = st == WFW_RUN && (uint32_t)tp <= (uint32_t)tl; // -1 <= k0 < tl (a cell before the query's start or beyond its end has no set bit to count)
+			const int32_t k0 = HA(j, 0), tp = k0 + (1 - WFW_BIAS);
+			const bool val = st == WFW_RUN && (uint32_t)tp <= (uint32_t)tl; // -1 <= offset < tl (a cell before the query's start or beyond its end has no set bit to count)
 			const int32_t wi = val ? tp >> 5 : 0;
 			const uint32_t *mp = &Mk[wi][64 * j + lane];
 			uint32_t inv = ~__builtin_amdgcn_alignbit(mp[64 * J], mp[0], tp); // ones of the mask from position tp on, as zeros (the shift is taken mod 32)
@@ -282,11 +287,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 		for (int j = 0; j < J; ++j) {
 			if (J > 1) {
 				const int32_t b0 = __builtin_amdgcn_readfirstlane(lo) + 64 * j;
-				if (b0 > rn || b0 + 63 < -rn) { nH[j] = nE1[j] = nF1[j] = nE2[j] = nF2[j] = WF_NEG_INF; continue; }
+				if (b0 > rn || b0 + 63 < -rn) { nH[j] = nE1[j] = nF1[j] = nE2[j] = nF2[j] = 0; continue; }
 			}
 			// predecessors: score s+1-p is age p-1 now (ages are shifted at the end of the step)
-#define WFW_L(R, a) wfw_from_left<G>(j > 0 ? __builtin_amdgcn_readlane(R[j > 0 ? j - 1 : 0][a], 63) : WF_NEG_INF, R[j][a], m_first)
-#define WFW_R(R, a) wfw_from_right<G>(j < J - 1 ? __builtin_amdgcn_readlane(R[j < J - 1 ? j + 1 : j][a], 0) : WF_NEG_INF, R[j][a], m_last)
+#define WFW_L(R, a) (j > 0 ? wfw_from_left<G, true>(__builtin_amdgcn_readlane(R[j > 0 ? j - 1 : 0][a], 63), R[j][a], nm_first) : wfw_from_left<G, false>(0, R[j][a], nm_first))
+#define WFW_R(R, a) (j < J - 1 ? wfw_from_right<G, true>(__builtin_amdgcn_readlane(R[j < J - 1 ? j + 1 : j][a], 0), R[j][a], nm_last) : wfw_from_right<G, false>(0, R[j][a], nm_last))
 			const int32_t ho1l = WFW_L(H, 5 + 2 - P), e1l = WFW_L(E1, 1), ho2l = WFW_L(H, 15 + 2 - P), e2l = WFW_L(E2, 0);
 			const int32_t ho1r = WFW_R(H, 5 + 2 - P), f1r = WFW_R(F1, 1), ho2r = WFW_R(H, 15 + 2 - P), f2r = WFW_R(F2, 0);
 #undef WFW_L
@@ -301,8 +306,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J == 1 
 			z = hx1 >= hh ? 0u : z;
 			const int32_t vH = wfw_max(hx1, hh);
 			acc[j] = acc[j] << 8 | (bits | z);
-			nH[j] = wfw_sel(okv[j], vH, WF_NEG_INF), nE1[j] = wfw_sel(okv[j], vE1, WF_NEG_INF), nF1[j] = wfw_sel(okv[j], vF1, WF_NEG_INF);
-			nE2[j] = wfw_sel(okv[j], vE2, WF_NEG_INF), nF2[j] = wfw_sel(okv[j], vF2, WF_NEG_INF);
+			nH[j] = vH & okv[j], nE1[j] = vE1 & okv[j], nF1[j] = vF1 & okv[j], nE2[j] = vE2 & okv[j], nF2[j] = vF2 & okv[j]; // (a diagonal outside the matrix stays unreachable)
 		}
 #pragma unroll
 		for (int j = 0; j < J; ++j) { // age shift (H: every second step, by two)
@@ -588,6 +592,240 @@ __global__ void __launch_bounds__(64) k_wfa_fwp(const int *__restrict__ n_items_
 	}
 }
 
+// ---- PACKED forward pass, SEVERAL problems per wavefront (round 5): the rungs of 32 / 64 diagonals as groups of 16 / 32 lanes with two diagonals per lane -- k_wfa_fw's
+// retire / refill machinery (the groups of a wavefront run in lockstep on independent problems) around k_wfa_fwp's step.  Twice the problems per wavefront for a step that
+// costs a quarter more; a refill builds two masks per lane instead of one, which is why the 16-diagonal rung (problems of ~15 steps) is not here.
+template<int G, int SEQCAP>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) k_wfa_fwq(const int *__restrict__ n_items_p, int cap, const int32_t *__restrict__ list, const mga_wfa_prob_t *__restrict__ prob,
+											  const char *__restrict__ tseq, const char *__restrict__ qseq, mga_wfa_res_t *__restrict__ res,
+											  char *__restrict__ tb, long long tb_stride, int *__restrict__ counter, mga_wfa_retry_t rt)
+{
+	static_assert(G == 16 || G == 32, "group size");
+	constexpr int P = 64 / G;      // problems per wavefront
+	constexpr int W = 2 * G;       // diagonals of the window = dwords per traceback row
+	constexpr int SEQS = SEQCAP + 16;
+	constexpr int QCH = P == 4 ? 32 : 16;
+	constexpr int MROWS = SEQCAP / 32 + 3;
+	__shared__ __attribute__((aligned(16))) uint8_t Tb[P][SEQS], Qb[P][4 * SEQS];
+	__shared__ uint32_t Mk[MROWS][128]; // mask of a lane's diagonal h (lo + 2 gl + h) at [word][64 h + lane]
+	const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
+	const int n_items = min(*n_items_p, cap);
+	uint8_t *const Tg = Tb[grp], *const Qg = Qb[grp];
+	const uint32_t nm_first = gl == 0 ? 0u : ~0u, nm_last = gl == G - 1 ? 0u : ~0u;
+	const uint64_t gmask = ((1ULL << G) - 1ULL) << (grp * G);
+
+	int32_t st = WFW_IDLE, pi = -1, tl = 0, ql = 0, lo = 0, e = 0, s = 0, bnd = 0, ph = 0;
+	uint32_t okv = 0, accA = 0, accB = 0, fc = ~0u; // fc: what the end cell looks like in this lane (offset tl - 1 + bias in the half of diagonal ql - tl, 0xffff elsewhere and while idle)
+	uint32_t dfin = ~0u, nfin = 0;                   // the last extension: cells against fc, lengths of the two runs (read when the group retires)
+	uint32_t *tbp = 0;
+	int32_t it_cur = 0;
+	uint32_t H[18], E1[3], F1[3], E2[2], F2[2];
+	int32_t t = 0;
+	int32_t q_next = 0, q_end = 0, q_base = 0;
+	__shared__ int32_t dsc_pi[QCH];
+	__shared__ mga_wfa_prob_t dsc_pb[QCH];
+	bool q_empty = false, q_drained = false;
+#pragma unroll
+	for (int a = 0; a < 18; ++a) H[a] = 0;
+#pragma unroll
+	for (int a = 0; a < 3; ++a) E1[a] = F1[a] = 0;
+#pragma unroll
+	for (int a = 0; a < 2; ++a) E2[a] = F2[a] = 0;
+
+#define HQ(a_) H[(a_) + 2 - P2]
+	auto step = [&](auto Pc) __attribute__((always_inline)) -> bool { // false: the queue is empty and every group is idle
+		constexpr int P2 = decltype(Pc)::value;
+		// ---- retire the groups that are through, refill idle groups from the queue (as k_wfa_fw)
+		if (__ballot(st >= WFW_DONE || (st == WFW_IDLE && !q_empty))) {
+			const uint64_t m_done = __ballot(st == WFW_DONE);
+			const bool g_done = (m_done & gmask) != 0;
+			if (g_done || st == WFW_BAIL) {
+				if (g_done) {
+					if (t & 3) { // the rest of the last traceback row
+						const int32_t rr = wfw_reach(s + 1), dA = lo + 2 * gl, dB = dA + 1;
+						if (min(dA < 0 ? -dA : dA, dB < 0 ? -dB : dB) <= rr) { tbp[0] = accA << (8 * (4 - (t & 3))); tbp[1] = accB << (8 * (4 - (t & 3))); }
+					}
+					if (st == WFW_DONE) {
+						// entered by a gap state and not extended: the traceback starts in that state (miniwfa.c:406-407); the state is the byte BEFORE the one the step's recurrence appended
+						const int32_t lst = (dfin & 0xffffu) == 0u ? ((nfin & 0xffffu) == 0u ? (int32_t)(accA >> 8 & 7u) : 0) : ((nfin >> 16) == 0u ? (int32_t)(accB >> 8 & 7u) : 0);
+						mga_wfa_res_t r;
+						r.score = s, r.n_cigar = 0, r.cig_off = (int64_t)(uintptr_t)(tb + (long long)it_cur * tb_stride), r.status = MGA_WFA_TB, r.pad = lst | ph << 4 | W << 8, r.n_iter = 0;
+						res[pi] = r;
+					}
+				} else if (gl == 0) {
+					mga_wfa_res_t r;
+					r.score = -1, r.n_cigar = 0, r.cig_off = 0, r.status = MGA_WFA_RETRY_TIER, r.pad = 0, r.n_iter = 0;
+					res[pi] = r;
+					mga_wfa_give_up(rt, pi);
+				}
+				st = WFW_IDLE, fc = ~0u;
+			}
+			if (!q_empty) {
+				const uint64_t m_idle = __ballot(st == WFW_IDLE && gl == 0);
+				if (m_idle) {
+					if (q_next == q_end && !q_drained) {
+						int32_t b = 0;
+						if (lane == 0) b = atomicAdd(counter, QCH);
+						b = __builtin_amdgcn_readfirstlane(b);
+						q_base = q_next = b, q_end = b + QCH < n_items ? b + QCH : n_items;
+						if (q_end <= q_next) q_end = q_next, q_drained = true;
+						if (lane < q_end - q_next) {
+							const int32_t p_ = list ? list[b + lane] : b + lane;
+							dsc_pi[lane] = p_;
+							dsc_pb[lane] = prob[p_];
+						}
+						WFW_LDS_FENCE();
+					}
+					const int32_t avail = q_end - q_next, n_idle = (int32_t)__popcll(m_idle);
+					const int32_t rank = (int32_t)__popcll(m_idle & ((1ULL << (grp * G)) - 1ULL));
+					const bool fill = st == WFW_IDLE && rank < avail;
+					const int32_t item = q_next + rank, src = fill ? item - q_base : 0;
+					q_next += n_idle < avail ? n_idle : avail;
+					if (q_drained && q_next == q_end) q_empty = true;
+					int32_t ntl = 0, nql = 0;
+					const char *ts = tseq, *qs = qseq;
+					if (fill) {
+						const mga_wfa_prob_t pb = dsc_pb[src];
+						pi = dsc_pi[src];
+						ntl = pb.tl, nql = pb.ql, ts = tseq + pb.t_off, qs = qseq + pb.q_off;
+						it_cur = item;
+						tbp = (uint32_t*)(tb + (long long)item * tb_stride) + 2 * gl;
+						ph = t & 3, s = 0, e = nql - ntl;
+						if (ntl > SEQCAP || nql > SEQCAP) bnd = 0, ntl = nql = 0;
+						else { bnd = wfw_window(W, ntl, nql, &lo, WFW_SMAX); if (bnd > W + 30) bnd = W + 30; }
+						tl = ntl, ql = nql;
+						st = WFW_RUN;
+					}
+					WFW_LDS_FENCE();
+					for (int32_t m0 = 0; __ballot(fill && 4 * m0 < ntl); m0 += G) {
+						const int32_t m = m0 + gl;
+						if (fill && 4 * m < ntl) { uint32_t v; __builtin_memcpy(&v, ts + 4 * m, 4); *(uint32_t*)(Tg + 4 * m) = v; }
+					}
+					for (int32_t m0 = 0; __ballot(fill && 4 * m0 < nql); m0 += G) {
+						const int32_t m = m0 + gl;
+						if (fill && 4 * m < nql) {
+#pragma unroll
+							for (int c = 0; c < 4; ++c) {
+								uint32_t v;
+								__builtin_memcpy(&v, qs + 4 * m + c, 4);
+								*(uint32_t*)(Qg + c * SEQS + 4 + 4 * m) = v;
+								if (m == 0 && c > 0) { uint32_t v0; __builtin_memcpy(&v0, qs, 4); *(uint32_t*)(Qg + c * SEQS) = v0 << (8 * (4 - c)); }
+							}
+						}
+					}
+					WFW_LDS_FENCE();
+#pragma unroll
+					for (int h = 0; h < 2; ++h) { // match masks of the refilled groups' diagonals (as k_wfa_fw), two per lane
+						const int32_t d = lo + 2 * gl + h;
+						const int32_t kmin = d < 0 ? -d : 0, kmax = min(ntl, nql - d);
+						const uint8_t *qc = Qg + (d & 3) * SEQS + 4 + (d & ~3);
+						for (int32_t w = 0; __ballot(fill && w <= (ntl >> 5)); ++w) {
+							uint32_t bits = 0;
+#pragma unroll
+							for (int q8 = 7; q8 >= 0; --q8) {
+								const uint32_t t4 = *(const uint32_t*)(Tg + 32 * w + 4 * q8), q4 = *(const uint32_t*)(qc + 32 * w + 4 * q8);
+								asm volatile("v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_3 src1_sel:BYTE_3\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+											 "v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_2 src1_sel:BYTE_2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+											 "v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_1 src1_sel:BYTE_1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+											 "v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_0 src1_sel:BYTE_0\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+											 : "+v"(bits) : "v"(t4), "v"(q4) : "vcc");
+							}
+							const int32_t b_lo = kmin - 32 * w, b_hi = kmax - 32 * w;
+							const uint32_t m_hi = b_hi >= 32 ? ~0u : b_hi <= 0 ? 0u : (1u << b_hi) - 1u, m_lo = b_lo <= 0 ? ~0u : b_lo >= 32 ? 0u : ~0u << b_lo;
+							if (fill && w <= (ntl >> 5)) Mk[w][64 * h + lane] = bits & m_hi & m_lo;
+						}
+					}
+					WFW_LDS_FENCE();
+					const uint32_t nmf = fill ? 0u : ~0u;
+#pragma unroll
+					for (int a = 0; a < 18; ++a) H[a] &= nmf;
+#pragma unroll
+					for (int a = 0; a < 3; ++a) E1[a] &= nmf, F1[a] &= nmf;
+#pragma unroll
+					for (int a = 0; a < 2; ++a) E2[a] &= nmf, F2[a] &= nmf;
+					if (fill) {
+						const int32_t dA = lo + 2 * gl, dB = dA + 1;
+						accA = accB = 0;
+						okv = ((dA >= -tl && dA <= ql) ? 0x0000ffffu : 0u) | ((dB >= -tl && dB <= ql) ? 0xffff0000u : 0u);
+						fc = (dA == e ? (uint32_t)(tl - 1 + WFP_BIAS) : 0xffffu) | (dB == e ? (uint32_t)(tl - 1 + WFP_BIAS) : 0xffffu) << 16;
+						if (dA == 0) HQ(0) = (uint32_t)(WFP_BIAS - 1);       // score 0: H[d = 0] = -1 (miniwfa.c:103-119)
+						if (dB == 0) HQ(0) = (uint32_t)(WFP_BIAS - 1) << 16;
+					}
+				}
+			}
+		}
+		if (!__ballot(st == WFW_RUN)) return false;
+		// ---- extension of slice s (miniwfa.c:399-411): the two cells of a lane side by side (k_wfa_fwp)
+		{
+			const uint32_t x = HQ(0);
+			const int32_t tpA = (int32_t)(x & 0xffffu) + (1 - WFP_BIAS), tpB = (int32_t)(x >> 16) + (1 - WFP_BIAS);
+			const bool valA = st == WFW_RUN && (uint32_t)tpA <= (uint32_t)tl, valB = st == WFW_RUN && (uint32_t)tpB <= (uint32_t)tl;
+			const int32_t wiA = valA ? tpA >> 5 : 0, wiB = valB ? tpB >> 5 : 0;
+			const uint32_t *mA = &Mk[wiA][lane], *mB = &Mk[wiB][64 + lane];
+			uint32_t invA = ~__builtin_amdgcn_alignbit(mA[128], mA[0], tpA), invB = ~__builtin_amdgcn_alignbit(mB[128], mB[0], tpB);
+			invA = valA ? invA : 1u, invB = valB ? invB : 1u;
+			uint32_t nA = invA ? (uint32_t)__builtin_ctz(invA) : 32u, nB = invB ? (uint32_t)__builtin_ctz(invB) : 32u;
+			for (int32_t it = 1; __ballot(invA == 0u || invB == 0u); ++it) {
+				const int32_t wa = wiA + it < MROWS - 2 ? wiA + it : MROWS - 2, wb = wiB + it < MROWS - 2 ? wiB + it : MROWS - 2;
+				const uint32_t *qA = &Mk[wa][lane], *qB = &Mk[wb][64 + lane];
+				const uint32_t vA = ~__builtin_amdgcn_alignbit(qA[128], qA[0], tpA), vB = ~__builtin_amdgcn_alignbit(qB[128], qB[0], tpB);
+				nA += invA == 0u ? (vA ? (uint32_t)__builtin_ctz(vA) : 32u) : 0u, nB += invB == 0u ? (vB ? (uint32_t)__builtin_ctz(vB) : 32u) : 0u;
+				invA = invA == 0u ? vA : invA, invB = invB == 0u ? vB : invB;
+			}
+			nfin = nA | nB << 16;
+			const uint32_t xn = x + nfin;
+			HQ(0) = xn;
+			dfin = xn ^ fc;
+			if ((dfin & 0xffffu) == 0u || dfin < 0x10000u) st = WFW_DONE; // the end cell (fc matches nothing in any other lane, nor in an idle group)
+		}
+		if (st == WFW_RUN && s + 1 >= bnd) st = WFW_BAIL;
+		// ---- slice s + 1 (miniwfa.c:281-308), two diagonals per instruction; neighbours stay inside the group
+		{
+#define WFQ_L(x_) __builtin_amdgcn_alignbit((x_), G == 16 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x_), 0x111, 0xf, 0xf, true) : ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x_), 0x138, 0xf, 0xf, true) & nm_first), 16)
+#define WFQ_R(x_) __builtin_amdgcn_alignbit(G == 16 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x_), 0x101, 0xf, 0xf, true) : ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x_), 0x130, 0xf, 0xf, true) & nm_last), (x_), 16)
+			const uint32_t ho1l = WFQ_L(HQ(5)), e1l = WFQ_L(E1[1]), ho2l = WFQ_L(HQ(15)), e2l = WFQ_L(E2[0]);
+			const uint32_t ho1r = WFQ_R(HQ(5)), f1r = WFQ_R(F1[1]), ho2r = WFQ_R(HQ(15)), f2r = WFQ_R(F2[0]);
+#undef WFQ_L
+#undef WFQ_R
+			const uint32_t hx1 = wfp_add(HQ(3), WFP_ONE);
+			const uint32_t vE1 = wfp_max(ho1l, e1l), vE2 = wfp_max(ho2l, e2l);
+			const uint32_t vF1 = wfp_add(wfp_max(ho1r, f1r), WFP_ONE), vF2 = wfp_add(wfp_max(ho2r, f2r), WFP_ONE);
+			const uint32_t bits = (wfp_lt(ho1l, e1l) & 0x00080008u) | (wfp_lt(ho2l, e2l) & 0x00200020u) | (wfp_lt(ho1r, f1r) & 0x00100010u) | (wfp_lt(ho2r, f2r) & 0x00400040u);
+			const uint32_t ee = wfp_max(vE1, vE2), ff = wfp_max(vF1, vF2), hh = wfp_max(ee, ff);
+			const uint32_t ze = (wfp_lt(vE1, vE2) & 0x00020002u) | WFP_ONE;              // vE1 >= vE2 ? 1 : 3
+			const uint32_t zf = (wfp_lt(vF1, vF2) & 0x00060006u) ^ 0x00020002u;           // vF1 >= vF2 ? 2 : 4
+			uint32_t z = wfp_sel(wfp_lt(ee, ff), zf, ze);                                  // ee >= ff ? ze : zf
+			z &= wfp_lt(hx1, hh);                                                          // hx1 >= hh ? 0 : z
+			const uint32_t vH = wfp_max(hx1, hh), bz = bits | z;
+			accA = accA << 8 | (bz & 0xffu), accB = accB << 8 | (bz >> 16);
+			HQ(-1) = vH & okv;
+			if (P2 == 1) {
+#pragma unroll
+				for (int a = 17; a > 1; --a) H[a] = H[a - 2];
+			}
+			E1[2] = E1[1]; E1[1] = E1[0]; E1[0] = vE1 & okv;
+			F1[2] = F1[1]; F1[1] = F1[0]; F1[0] = vF1 & okv;
+			E2[1] = E2[0]; E2[0] = vE2 & okv;
+			F2[1] = F2[0]; F2[0] = vF2 & okv;
+		}
+		if ((t & 3) == 3) { // a row of traceback dwords is full: reachable diagonals only, next row
+			if (st != WFW_IDLE) {
+				const int32_t rr = wfw_reach(s + 1), dA = lo + 2 * gl, dB = dA + 1;
+				if (min(dA < 0 ? -dA : dA, dB < 0 ? -dB : dB) <= rr) { tbp[0] = accA; tbp[1] = accB; }
+			}
+			tbp += W;
+		}
+		if (st == WFW_RUN) ++s;
+		++t;
+		return true;
+	};
+	for (;;) {
+		if (!step(std::integral_constant<int, 0>())) break;
+		if (!step(std::integral_constant<int, 1>())) break;
+	}
+#undef HQ
+}
+
 // ---- traceback: one lane per problem (miniwfa.c:329-377) ----------------------------------------------------------------------------
 
 // byte of cell (score sc, window index idx) in a problem's region: rows of W dwords, four scores per dword, the earliest in the top byte.
@@ -723,7 +961,12 @@ extern "C" int mga_dev_wfa_win(mga_sctx_t *sc, const int *d_n, int n, const int3
 	if (n <= 0) return 0;
 	if (wt < 0 || wt >= MGA_WFW_N) { mga_set_error("wfa_win: bad tier %d", wt); return -1; }
 	const wfw_tier_t &T = g_wtier[wt];
-	const int per = 64 / (T.W < 64 ? T.W : 64);
+	// MGA_WFA_PACKED=<mask> (read per launch): which rungs run a packed kernel (two diagonals per lane): bit 0 / 1 / 2 the rungs of 128 / 192 / 256 diagonals (k_wfa_fwp, one
+	// problem per wavefront), bit 3 / 4 the rungs of 64 / 32 diagonals (k_wfa_fwq, two / four problems per wavefront).  Same results either way (tests/test_gpu_stages.py)
+	const char *e_pk = getenv("MGA_WFA_PACKED");
+	const int pk_mask = e_pk && *e_pk ? atoi(e_pk) : 7;
+	const bool fwq = (wt == 2 && (pk_mask & 8)) || (wt == 1 && (pk_mask & 16));
+	const int per = (fwq ? 2 : 1) * (64 / (T.W < 64 ? T.W : 64)); // problems per wavefront
 	int wgs = (n + per * 4 - 1) / (per * 4);
 	// MGA_WFA_GRID_PCT=<p>: persistent grids of p % of the table's size -- the rest of the wave slots stay free for the kernels of the OTHER chunks in the pipeline
 	// (their launches otherwise only get the chip in this one's tail); a tuning knob, the result does not depend on the grid
@@ -737,20 +980,18 @@ extern "C" int mga_dev_wfa_win(mga_sctx_t *sc, const int *d_n, int n, const int3
 	const long long stride = (long long)mga_dev_wfa_win_tb_stride(wt);
 	mga_prof_begin(st, MGA_K_WFAW0 + wt);
 #define LAUNCH(GG, JJ, SEQ) hipLaunchKernelGGL((k_wfa_fw<GG, JJ, SEQ>), dim3(wgs), dim3(64), 0, st, d_n, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_tb, stride, d_counter, rt)
-	// MGA_WFA_PACKED=<mask> (read per launch): which of the rungs of 128 (bit 0) / 192 (bit 1) / 256 (bit 2) diagonals run the packed kernel (two diagonals per lane, k_wfa_fwp).
-	// Default 7: measured per 125 000 reads (profiles/r05n_packed_sweep.txt) 128: 45.9 -> 26.9 ms, 192: 22.8 -> 21.1 ms, 256: 12.5 -> 8.5 ms -- same results either way
-	// (tests/test_gpu_stages.py runs masks 0 and 7)
-	const char *e_pk = getenv("MGA_WFA_PACKED");
-	const int pk_mask = e_pk && *e_pk ? atoi(e_pk) : 7;
+	// (default mask 7, measured per 125 000 reads, profiles/r05n_packed_sweep.txt: 128: 45.9 -> 26.9 ms, 192: 22.8 -> 21.1 ms, 256: 12.5 -> 8.5 ms)
+#define LAUNCHQ(GG, SEQ) hipLaunchKernelGGL((k_wfa_fwq<GG, SEQ>), dim3(wgs), dim3(64), 0, st, d_n, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_tb, stride, d_counter, rt)
 #define LAUNCHP(WW, SEQ) hipLaunchKernelGGL((k_wfa_fwp<WW, SEQ>), dim3(wgs), dim3(64), 0, st, d_n, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_tb, stride, d_counter, rt)
 	if (wt == 0) LAUNCH(16, 1, 128);
-	else if (wt == 1) LAUNCH(32, 1, 192);
-	else if (wt == 2) LAUNCH(64, 1, 256);
+	else if (wt == 1) { if (pk_mask & 16) LAUNCHQ(16, 192); else LAUNCH(32, 1, 192); }
+	else if (wt == 2) { if (pk_mask & 8) LAUNCHQ(32, 256); else LAUNCH(64, 1, 256); }
 	else if (wt == 3) { if (pk_mask & 1) LAUNCHP(128, 384); else LAUNCH(64, 2, 384); }
 	else if (wt == 4) { if (pk_mask & 2) LAUNCHP(192, 384); else LAUNCH(64, 3, 384); }
 	else { if (pk_mask & 4) LAUNCHP(256, 512); else LAUNCH(64, 4, 512); }
 #undef LAUNCH
 #undef LAUNCHP
+#undef LAUNCHQ
 	mga_prof_end(st, MGA_K_WFAW0 + wt);
 	MGA_HIP_CHECK(hipGetLastError());
 	return 0;

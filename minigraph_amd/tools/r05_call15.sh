@@ -1,0 +1,20 @@
+#!/bin/bash
+# WFA rungs after the biased-cell rewrite of k_wfa_fw + the several-problems-per-wavefront packed kernel (MGA_WFA_PACKED bits 3 / 4): stage tests (streamed to a file: a hang
+# still leaves the names of what passed), e2e subset, sweep
+set -u
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ulimit -c 0
+out=gpurun_out; mkdir -p $out
+t0=$(date +%s)
+timeout 200 python -u -m pytest tests/test_gpu_stages.py -v -x -m gpu -k "wfa" 2>&1 | grep -v "^$" | tee $out/r05o_tests_wfa.txt | tail -30
+rc=${PIPESTATUS[0]}
+echo "[tests] rc $rc $(( $(date +%s) - t0 )) s"
+[ $rc -ne 0 ] && exit 0
+timeout 120 python -m pytest tests/test_gpu_e2e.py -q -x -m gpu -k "mt_known or synthetic_vs_reference" 2>&1 | tail -8 | tee $out/r05o_tests_e2e.txt
+rc=${PIPESTATUS[0]}
+echo "[tests e2e] rc $rc $(( $(date +%s) - t0 )) s"
+[ $rc -ne 0 ] && exit 0
+WD=/tmp/mga_wd
+timeout 60 python bench.py --steps 3 --warmup 1 --workdir $WD --no-cpu --resident-steps 0 --one-placement --no-asm --no-rank-share > /dev/null 2>&1
+STEPS=6 RESIDENT=1 BENCH_ARGS="--workdir $WD --no-asm --no-rank-share" timeout 200 bash minigraph_amd/tools/knob_sweep.sh - "MGA_WFA_PACKED=15" "MGA_WFA_PACKED=31" - 2>&1 | tee $out/r05o_packed_sweep.txt
+echo "[sweep] $(( $(date +%s) - t0 )) s"

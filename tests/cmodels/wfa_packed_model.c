@@ -41,6 +41,7 @@ static uint32_t pk_lt(uint32_t a, uint32_t b) /* sign masks of the packed (wrapp
 static uint32_t sel(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
 static uint32_t alignbit(uint32_t hi, uint32_t lo, int sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh); }
 
+static int NL = 64; /* lanes a problem has: 64 (k_wfa_fwp), or a group of 16 / 32 (k_wfa_fwq: W = 2 NL) */
 #define MAXJP 2
 #define MAXSEQ 512
 #define MROWS (MAXSEQ / 32 + 3)
@@ -51,6 +52,7 @@ typedef struct { int done, score, lst, steps; } fw_res_t;
 static fw_res_t forward(int W, int tl, const char *T, int ql, const char *Q, uint32_t *region, int n_rows)
 {
 	const int JP = (W + 127) / 128, e = ql - tl;
+	NL = W >= 128 ? 64 : W / 2;
 	static uint32_t Mk[MROWS + 1][128 * MAXJP];
 	uint32_t H[MAXJP][18][64], E1[MAXJP][3][64], F1[MAXJP][3][64], E2[MAXJP][2][64], F2[MAXJP][2][64], okv[MAXJP][64], accA[MAXJP][64], accB[MAXJP][64], fc[MAXJP][64];
 	int lo = 0, bnd, s = 0, j, l, a, h, q, row = 0;
@@ -60,7 +62,7 @@ static fw_res_t forward(int W, int tl, const char *T, int ql, const char *Q, uin
 	if (bnd <= 0) return R;
 	memset(Mk, 0, sizeof Mk);
 	for (q = 0; q < 2 * JP; ++q) /* match masks: bit b of word w = T[32 w + b] == Q[d + 32 w + b], valid positions only */
-		for (l = 0; l < 64; ++l) {
+		for (l = 0; l < NL; ++l) {
 			const int d = lo + 128 * (q >> 1) + 2 * l + (q & 1), kmin = d < 0 ? -d : 0, kmax = tl < ql - d ? tl : ql - d;
 			int w, b;
 			for (w = 0; w <= (tl >> 5); ++w) {
@@ -70,7 +72,7 @@ static fw_res_t forward(int W, int tl, const char *T, int ql, const char *Q, uin
 			}
 		}
 	for (j = 0; j < JP; ++j)
-		for (l = 0; l < 64; ++l) {
+		for (l = 0; l < NL; ++l) {
 			const int dA = lo + 128 * j + 2 * l, dB = dA + 1;
 			for (a = 0; a < 18; ++a) H[j][a][l] = NEGPK;
 			for (a = 0; a < 3; ++a) E1[j][a][l] = F1[j][a][l] = NEGPK;
@@ -92,7 +94,7 @@ static fw_res_t forward(int W, int tl, const char *T, int ql, const char *Q, uin
 			uint32_t inv[2][64], n[2][64];
 			int tp[2][64], wi[2][64], it, any;
 			if (b0 > rs || b0 + 127 < -rs) continue;
-			for (l = 0; l < 64; ++l) {
+			for (l = 0; l < NL; ++l) {
 				const uint32_t x = HP(j, 0)[l];
 				for (h = 0; h < 2; ++h) {
 					const int val = (tp[h][l] = (int)(h ? x >> 16 : x & 0xffffu) + (1 - BIAS), (uint32_t)tp[h][l] <= (uint32_t)tl);
@@ -103,17 +105,17 @@ static fw_res_t forward(int W, int tl, const char *T, int ql, const char *Q, uin
 				}
 			}
 			for (it = 1;; ++it) {
-				for (any = 0, l = 0; l < 64; ++l) any |= inv[0][l] == 0u || inv[1][l] == 0u;
+				for (any = 0, l = 0; l < NL; ++l) any |= inv[0][l] == 0u || inv[1][l] == 0u;
 				if (!any) break;
 				if (it > MROWS + 4) { fprintf(stderr, "match run does not end (W %d tl %d ql %d)\n", W, tl, ql); exit(2); }
-				for (l = 0; l < 64; ++l)
+				for (l = 0; l < NL; ++l)
 					for (h = 0; h < 2; ++h) {
 						const int w = wi[h][l] + it < MROWS - 2 ? wi[h][l] + it : MROWS - 2;
 						const uint32_t v = ~alignbit(Mk[w + 1][64 * (2 * j + h) + l], Mk[w][64 * (2 * j + h) + l], tp[h][l] & 31);
 						if (inv[h][l] == 0u) n[h][l] += v ? (uint32_t)__builtin_ctz(v) : 32u, inv[h][l] = v;
 					}
 			}
-			for (l = 0; l < 64; ++l) {
+			for (l = 0; l < NL; ++l) {
 				const uint32_t nf = n[0][l] | n[1][l] << 16, xn = HP(j, 0)[l] + nf, df = xn ^ fc[j][l];
 				if ((n[0][l] | n[1][l]) >> 15) { fprintf(stderr, "a run overflows its half\n"); exit(2); }
 				HP(j, 0)[l] = xn;
@@ -125,10 +127,10 @@ static fw_res_t forward(int W, int tl, const char *T, int ql, const char *Q, uin
 		if (s + 1 >= bnd) break;
 		for (j = 0; j < JP; ++j) { /* slice s + 1 */
 			const int b0 = lo + 128 * j;
-			if (b0 > rn || b0 + 127 < -rn) { for (l = 0; l < 64; ++l) nH[j][l] = nE1[j][l] = nF1[j][l] = nE2[j][l] = nF2[j][l] = NEGPK; continue; }
-			for (l = 0; l < 64; ++l) {
-#define FROM_L(R_, a_) alignbit(R_[j][a_][l], l > 0 ? R_[j][a_][l - 1] : (j > 0 ? R_[j - 1][a_][63] : NEGPK), 16)
-#define FROM_R(R_, a_) alignbit(l < 63 ? R_[j][a_][l + 1] : (j < JP - 1 ? R_[j + 1][a_][0] : NEGPK), R_[j][a_][l], 16)
+			if (b0 > rn || b0 + 127 < -rn) { for (l = 0; l < NL; ++l) nH[j][l] = nE1[j][l] = nF1[j][l] = nE2[j][l] = nF2[j][l] = NEGPK; continue; }
+			for (l = 0; l < NL; ++l) {
+#define FROM_L(R_, a_) alignbit(R_[j][a_][l], l > 0 ? R_[j][a_][l - 1] : (j > 0 ? R_[j - 1][a_][NL - 1] : NEGPK), 16)
+#define FROM_R(R_, a_) alignbit(l < NL - 1 ? R_[j][a_][l + 1] : (j < JP - 1 ? R_[j + 1][a_][0] : NEGPK), R_[j][a_][l], 16)
 				const uint32_t ho1l = FROM_L(H, 5 + 2 - P), e1l = FROM_L(E1, 1), ho2l = FROM_L(H, 15 + 2 - P), e2l = FROM_L(E2, 0);
 				const uint32_t ho1r = FROM_R(H, 5 + 2 - P), f1r = FROM_R(F1, 1), ho2r = FROM_R(H, 15 + 2 - P), f2r = FROM_R(F2, 0);
 				const uint32_t hx1 = pk_add(HP(j, 3)[l], ONEPK);
@@ -145,10 +147,10 @@ static fw_res_t forward(int W, int tl, const char *T, int ql, const char *Q, uin
 			}
 		}
 		for (j = 0; j < JP; ++j) /* every cell stays inside its half with room to spare */
-			for (l = 0; l < 64; ++l)
+			for (l = 0; l < NL; ++l)
 				if ((nH[j][l] & 0xffffu) > BIAS + 600u || (nH[j][l] >> 16) > BIAS + 600u || (nF1[j][l] & 0xffffu) > BIAS + 600u || (nF2[j][l] >> 16) > BIAS + 600u) { fprintf(stderr, "a cell leaves its range (W %d tl %d ql %d)\n", W, tl, ql); exit(2); }
 		for (j = 0; j < JP; ++j) /* age shift */
-			for (l = 0; l < 64; ++l) {
+			for (l = 0; l < NL; ++l) {
 				HP(j, -1)[l] = nH[j][l];
 				if (P == 1) for (a = 17; a > 1; --a) H[j][a][l] = H[j][a - 2][l];
 				E1[j][2][l] = E1[j][1][l]; E1[j][1][l] = E1[j][0][l]; E1[j][0][l] = nE1[j][l];
@@ -160,7 +162,7 @@ static fw_res_t forward(int W, int tl, const char *T, int ql, const char *Q, uin
 			const int rr = reach(s + 1);
 			if (row >= n_rows) { fprintf(stderr, "traceback rows exhausted (W %d)\n", W); exit(2); }
 			for (j = 0; j < JP; ++j)
-				for (l = 0; l < 64; ++l) {
+				for (l = 0; l < NL; ++l) {
 					const int dA = lo + 128 * j + 2 * l, dB = dA + 1, ad = abs(dA) < abs(dB) ? abs(dA) : abs(dB);
 					if (ad <= rr && 128 * j + 2 * l < W) { region[(size_t)row * W + 128 * j + 2 * l] = accA[j][l]; if (128 * j + 2 * l + 1 < W) region[(size_t)row * W + 128 * j + 2 * l + 1] = accB[j][l]; }
 				}
@@ -171,7 +173,7 @@ static fw_res_t forward(int W, int tl, const char *T, int ql, const char *Q, uin
 	if (R.done && (s & 3)) {
 		const int rr = reach(s + 1);
 		for (j = 0; j < JP; ++j)
-			for (l = 0; l < 64; ++l) {
+			for (l = 0; l < NL; ++l) {
 				const int dA = lo + 128 * j + 2 * l, dB = dA + 1, ad = abs(dA) < abs(dB) ? abs(dA) : abs(dB);
 				if (ad <= rr && 128 * j + 2 * l < W) { region[(size_t)row * W + 128 * j + 2 * l] = accA[j][l] << (8 * (4 - (s & 3))); if (128 * j + 2 * l + 1 < W) region[(size_t)row * W + 128 * j + 2 * l + 1] = accB[j][l] << (8 * (4 - (s & 3))); }
 			}
@@ -220,8 +222,8 @@ static uint32_t rnd(void) { rng_s ^= rng_s << 13; rng_s ^= rng_s >> 7; rng_s ^= 
 int main(int argc, char **argv)
 {
 	const int n = argc > 1 ? atoi(argv[1]) : 4000;
-	static const int Ws[3] = { 128, 192, 256 }, caps[3] = { 384, 384, 512 };
-	long solved[3] = { 0 }, gave_up[3] = { 0 }, mism = 0;
+	static const int Ws[5] = { 128, 192, 256, 64, 32 }, caps[5] = { 384, 384, 512, 256, 192 };
+	long solved[5] = { 0 }, gave_up[5] = { 0 }, mism = 0;
 	mgo_wfa_opt_t opt = { 4, 4, 2, 15, 1, 100000000 };
 	int it;
 	for (it = 0; it < n; ++it) {
@@ -244,7 +246,7 @@ int main(int argc, char **argv)
 		if (ql > 2500) ql = 2500;
 		memset(t + tl, 0, 64); memset(q + ql, 0, 64);
 		S = mgo_wfa_exact(&opt, tl, t, ql, q, c0, 8192, &n0, &iter);
-		for (k = 0; k < 3; ++k) {
+		for (k = 0; k < 5; ++k) {
 			const int W = Ws[k], n_rows = SMAX / 4 + 8;
 			int lo, B, m;
 			fw_res_t R;
@@ -266,7 +268,7 @@ int main(int argc, char **argv)
 		}
 	}
 	printf("pairs %d, mismatches %ld; decided / gave up per window:", n, mism);
-	for (it = 0; it < 3; ++it) printf(" %d:%ld/%ld", Ws[it], solved[it], gave_up[it]);
+	for (it = 0; it < 5; ++it) printf(" %d:%ld/%ld", Ws[it], solved[it], gave_up[it]);
 	printf("\n");
 	return mism != 0;
 }

@@ -139,9 +139,10 @@ def test_wfa_roundtrip_property():
         assert ti == len(t) and qi == len(q) and pen == sc[i], i
 
 
-@pytest.mark.parametrize("packed", ["0", "5", None])
+@pytest.mark.parametrize("packed", ["0", "5", None, "31"])
 def test_wfa_windowed_tiers_edge_shapes(ora, monkeypatch, packed):
-    """(MGA_WFA_PACKED: the rungs of 128 / 192 / 256 diagonals on the one-diagonal-per-lane kernel, all three on the packed two-per-lane kernel, the default mix)
+    """(MGA_WFA_PACKED: every rung on the one-diagonal-per-lane kernel, two of the wide rungs packed, the default, and everything that has a packed form -- the rungs of
+    32 and 64 diagonals with four / two problems per wavefront included)
     the windowed tiers (k_wfa_w.hip: 16 / 32 / 64 / 128 / 192 / 256 diagonals, several problems per wavefront in the narrow ones) are exact only
     below the bound of their window: single gaps of every length around each half-width (the alignment hugs the window's edge, one base further and
     the problem must give up and climb), the same with noise, matrices narrower than the window, end diagonals far from 0 (the window is centred
@@ -177,7 +178,7 @@ def test_wfa_windowed_tiers_edge_shapes(ora, monkeypatch, packed):
         assert np.array_equal(ec, cg[i]), (i, len(T[i]), len(Q[i]), es)
 
 
-@pytest.mark.parametrize("packed", ["0", "7"])
+@pytest.mark.parametrize("packed", ["0", "7", "31"])
 def test_wfa_windowed_tiers_many_problems(ora, monkeypatch, packed):
     """a launch the size of a small chunk with the bench workload's shape (gap lengths 1..400, 10 % errors): every group of every wavefront is refilled
     many times, the queue runs dry at the end, problems climb from tier to tier"""
