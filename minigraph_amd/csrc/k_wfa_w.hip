@@ -18,8 +18,8 @@
 //
 // What that buys on a 64-lane wavefront: FOUR problems per wave in 16-lane groups (tier W0), TWO in 32-lane groups (W1), one
 // in 64 lanes (W2) and one in 2-4 slots of 64 lanes (W3-W5) -- no multi-wave tiers, no barrier, no band bookkeeping (the window
-// is computed whole; cells the reference's band has not reached hold NEG_INF + small, which loses every comparison exactly
-// like the NEG_INF of the reference's padding).
+// is computed whole; cells the reference's band has not reached hold "unreachable" + small -- 0 + small under the bias of
+// round 5, WFW_BIAS below -- which loses every comparison exactly like the NEG_INF of the reference's padding).
 //
 // Forward pass (k_wfa_fw): lane l of a group owns diagonal lo + l (+ 64 j for slot j).  H of the last 17 scores, E1/F1 (3),
 // E2/F2 (2) live in VGPRs indexed by age as in k_wfa_r.hip; neighbours come from DPP row / wave shifts that stay inside the
