@@ -596,7 +596,7 @@ __global__ void __launch_bounds__(64) k_wfa_fwp(const int *__restrict__ n_items_
 // retire / refill machinery (the groups of a wavefront run in lockstep on independent problems) around k_wfa_fwp's step.  Twice the problems per wavefront for a step that
 // costs a quarter more; a refill builds two masks per lane instead of one, which is why the 16-diagonal rung (problems of ~15 steps) is not here.
 template<int G, int SEQCAP>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) k_wfa_fwq(const int *__restrict__ n_items_p, int cap, const int32_t *__restrict__ list, const mga_wfa_prob_t *__restrict__ prob,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_wfa_fwq(const int *__restrict__ n_items_p, int cap, const int32_t *__restrict__ list, const mga_wfa_prob_t *__restrict__ prob,
 											  const char *__restrict__ tseq, const char *__restrict__ qseq, mga_wfa_res_t *__restrict__ res,
 											  char *__restrict__ tb, long long tb_stride, int *__restrict__ counter, mga_wfa_retry_t rt)
 {

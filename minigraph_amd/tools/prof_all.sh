@@ -38,11 +38,12 @@ python minigraph_amd/tools/prof_summary.py --pmc-json "$F" "$W" "rocprofv3 --pmc
 has sq && {
 rm -rf $out/prof_${tag}_sq1 $out/prof_${tag}_sq2
 MGA_PIPE=1 MGA_WFA_SIDE=0 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY -d $out/prof_${tag}_sq1 -o pmc -- $B > /dev/null 2> $out/${tag}_sq1.err
-MGA_PIPE=1 MGA_WFA_SIDE=0 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU -d $out/prof_${tag}_sq2 -o pmc -- $B > /dev/null 2> $out/${tag}_sq2.err
+# PROF_SQ_LIGHT=1: the first counter set only (the instruction counts behind roofline.valu_busy); the second set and the device-chaining pass are skipped
+[ "${PROF_SQ_LIGHT:-0}" = 1 ] || MGA_PIPE=1 MGA_WFA_SIDE=0 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU -d $out/prof_${tag}_sq2 -o pmc -- $B > /dev/null 2> $out/${tag}_sq2.err
 # (third pass: the same first counter set with graph chaining + gap list on the device -- k_gchain_p1 / p2 / p3, k_plan -- listed behind the others: a kernel's first pass wins)
 rm -rf $out/prof_${tag}_sq3
-MGA_PIPE=1 MGA_WFA_SIDE=0 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY -d $out/prof_${tag}_sq3 -o pmc -- $B --threads 8 > /dev/null 2> $out/${tag}_sq3.err
-S1=$(find $out/prof_${tag}_sq1 -name "*.db" | head -1); S2=$(find $out/prof_${tag}_sq2 -name "*.db" | head -1); S3=$(find $out/prof_${tag}_sq3 -name "*.db" | head -1)
+[ "${PROF_SQ_LIGHT:-0}" = 1 ] || MGA_PIPE=1 MGA_WFA_SIDE=0 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY -d $out/prof_${tag}_sq3 -o pmc -- $B --threads 8 > /dev/null 2> $out/${tag}_sq3.err
+S1=$(find $out/prof_${tag}_sq1 -name "*.db" | head -1); S2=$(find $out/prof_${tag}_sq2 -name "*.db" 2>/dev/null | head -1); S3=$(find $out/prof_${tag}_sq3 -name "*.db" 2>/dev/null | head -1)
 python minigraph_amd/tools/prof_summary.py --sq "$S1" "$S2" "$S3" "MGA_PIPE=1 MGA_WFA_SIDE=0 $B (durations are inflated by the counter collection)" > $out/${tag}_sq_counters.txt 2> $out/${tag}_sq_summary.err
 }
 rm -rf $out/prof_${tag}_* $out/prof_${tag}   # the raw rocprofv3 outputs (hundreds of MB) stay on the GPU box: gpurun copies at most 64 MiB back

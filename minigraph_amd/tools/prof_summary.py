@@ -83,7 +83,10 @@ def main_sq(paths, title):
     print("# per wave: instructions issued; shares: fraction of the waves' resident cycles (SQ_WAVE_CYCLES): valu = SQ_ACTIVE_INST_VALU, wait = SQ_WAIT_ANY (parked on s_waitcnt / barrier),")
     print("# stall = SQ_WAIT_INST_ANY (issue stalls), vmem / lds / salu = SQ_INST_CYCLES_VMEM / SQ_ACTIVE_INST_LDS / SQ_INST_CYCLES_SALU where collected")
     print("# occ = waves resident per SIMD while the kernel runs = SQ_WAVE_CYCLES / (32 x SQ_BUSY_CYCLES) (SQ_BUSY_CYCLES is summed over the 32 shader engines, each with 32 SIMDs);")
-    print("# valu_busy = SQ_ACTIVE_INST_VALU / (32 x SQ_BUSY_CYCLES): the fraction of a SIMD's cycles in which one of its waves has a vector instruction in the ALU")
+    print("# valu_busy = SQ_ACTIVE_INST_VALU / (32 x SQ_BUSY_CYCLES).  CALIBRATION (profiles/r05a_valu_calibration.txt, a kernel of known instruction count under these counters):")
+    print("#   SQ_INSTS_VALU is exact; SQ_ACTIVE_INST_VALU equals it (it counts issue slots of FOUR cycles, so the `valu` and `valu_busy` columns are a quarter of a cycle share, over")
+    print("#   durations inflated by the counter collection); SQ_WAVE_CYCLES is in the same units and saturates with occupancy.  The utilisation figure that holds is bench.py's")
+    print("#   roofline.valu_busy: VALU/wave x waves / passes here, over 578 M wave-instructions per second per SIMD [measured] and the kernel's time WITHOUT counters")
     print("%-46s %7s %12s %11s %11s %9s %7s %7s %7s %7s %7s %7s %6s %9s" % ("kernel", "calls", "waves", "VALU/wave", "SALU/wave", "LDS/wave", "valu", "wait", "stall", "vmem", "lds", "salu", "occ", "valu_busy"))
 
     def col(d, key, fmt, width):
