@@ -9,20 +9,21 @@ set -u
 tag=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 ulimit -c 0
-B="python bench.py --steps 1 --warmup 1 --no-cpu --resident-steps 0 --one-placement --no-asm --no-rank-share"
+WDA=${PROF_WORKDIR:+--workdir $PROF_WORKDIR}   # PROF_WORKDIR=<dir>: the synthetic workload (graph, reads, graph image) is generated once and reused by every run below
+B="python bench.py --steps 1 --warmup 1 --no-cpu --resident-steps 0 --one-placement --no-asm --no-rank-share $WDA"
 out=gpurun_out
 parts=${PROF_PARTS:-iso pipe dev pmc sq}   # PROF_PARTS="iso pmc": a subset (each part is one or two bench runs under rocprofv3, about 70 s each)
 has() { case " $parts " in *" $1 "*) return 0;; esac; return 1; }
 has iso && {
-MGA_PIPE=1 MGA_WFA_SIDE=0 bash minigraph_amd/tools/prof_trace.sh ${tag}_iso MGA_PIPE=1 MGA_WFA_SIDE=0 -- --steps 1 --warmup 1 --no-cpu --resident-steps 0 --one-placement --no-asm --no-rank-share > /dev/null 2>&1
+MGA_PIPE=1 MGA_WFA_SIDE=0 bash minigraph_amd/tools/prof_trace.sh ${tag}_iso MGA_PIPE=1 MGA_WFA_SIDE=0 -- --steps 1 --warmup 1 --no-cpu --resident-steps 0 --one-placement --no-asm --no-rank-share $WDA > /dev/null 2>&1
 mv $out/${tag}_iso_kernel_stats.txt $out/${tag}_kernel_stats_isolated.txt
 }
 has pipe && {
-bash minigraph_amd/tools/prof_trace.sh ${tag}_pipe -- --steps 2 --warmup 1 --no-cpu --resident-steps 0 --one-placement --no-asm --no-rank-share > /dev/null 2>&1
+bash minigraph_amd/tools/prof_trace.sh ${tag}_pipe -- --steps 2 --warmup 1 --no-cpu --resident-steps 0 --one-placement --no-asm --no-rank-share $WDA > /dev/null 2>&1
 mv $out/${tag}_pipe_kernel_stats.txt $out/${tag}_kernel_stats_pipelined.txt
 }
 has dev && {
-bash minigraph_amd/tools/prof_trace.sh ${tag}_dev MGA_PIPE=1 MGA_WFA_SIDE=0 -- --steps 1 --warmup 1 --no-cpu --resident-steps 0 --one-placement --no-asm --no-rank-share --threads 8 > /dev/null 2>&1
+bash minigraph_amd/tools/prof_trace.sh ${tag}_dev MGA_PIPE=1 MGA_WFA_SIDE=0 -- --steps 1 --warmup 1 --no-cpu --resident-steps 0 --one-placement --no-asm --no-rank-share --threads 8 $WDA > /dev/null 2>&1
 mv $out/${tag}_dev_kernel_stats.txt $out/${tag}_kernel_stats_devchain_isolated.txt
 }
 has pmc && {
@@ -46,5 +47,8 @@ rm -rf $out/prof_${tag}_sq3
 S1=$(find $out/prof_${tag}_sq1 -name "*.db" | head -1); S2=$(find $out/prof_${tag}_sq2 -name "*.db" 2>/dev/null | head -1); S3=$(find $out/prof_${tag}_sq3 -name "*.db" 2>/dev/null | head -1)
 python minigraph_amd/tools/prof_summary.py --sq "$S1" "$S2" "$S3" "MGA_PIPE=1 MGA_WFA_SIDE=0 $B (durations are inflated by the counter collection)" > $out/${tag}_sq_counters.txt 2> $out/${tag}_sq_summary.err
 }
+# the pipelined trace keeps its timestamps: union of kernel intervals against the sum of durations over the second half of the run (the steps after the warm-up)
+T=$(find $out/prof_${tag}_pipe -name "*kernel_trace.csv" 2>/dev/null | head -1)
+[ -n "$T" ] && python minigraph_amd/tools/trace_overlap.py "$T" --window 0.5,1.0 --title "pipelined bench step of $tag, steps after the warm-up" > $out/${tag}_pipe_overlap.txt 2>&1
 rm -rf $out/prof_${tag}_* $out/prof_${tag}   # the raw rocprofv3 outputs (hundreds of MB) stay on the GPU box: gpurun copies at most 64 MiB back
 ls -la $out/${tag}_*
