@@ -119,6 +119,7 @@ struct mga_batch_s {
 					  int n_runs, const int64_t *runs /* beg, end, base triples, chunk-level */, int n_order, const int32_t *order, int bw, int32_t *status);
 	void *rq_dev_ctx; char *rq_harr; int64_t rq_tot;
 	pthread_mutex_t rq_dev_mtx;
+	int rq_dev_err; char rq_dev_errmsg[256]; /* a device call of the hook failed (not: a run handed back): the chunk fails with this message -- no silent host path */
 	int32_t *seg_len;       /* segment lengths as a flat array (the graph view of gc_core.h on the host) */
 	/* graph chains made on the device (k_gchain.hip): per-read headers + record pools; status != 0 marks the reads the host still chains */
 	const mga_gc_hdr_t *gc_hdr; const char *gc_pool; const mg_llchain_t *gc_lc; const mg128_t *gc_a; size_t gc_rec;
@@ -165,7 +166,7 @@ void mga_batch_set_device_plan(mga_batch_t *b, const int64_t *chain_off, int32_t
 void mga_batch_set_rq_device(mga_batch_t *b, int (*fwd)(void*, int, const int64_t*, const int64_t*, const mg128_t *const*, int32_t *const*, int64_t *const*, int32_t *const*, int, const int64_t*, int, const int32_t*, int, int32_t*),
 							 void *ctx, char *harr, int64_t tot)
 {
-	b->rq_dev_fwd = fwd, b->rq_dev_ctx = ctx, b->rq_harr = harr, b->rq_tot = tot;
+	b->rq_dev_fwd = fwd, b->rq_dev_ctx = ctx, b->rq_harr = harr, b->rq_tot = tot, b->rq_dev_err = 0;
 	pthread_mutex_init(&b->rq_dev_mtx, 0);
 }
 
@@ -304,9 +305,10 @@ static void rq_dev_worker(mga_batch_t *b, int n_reads, const int32_t *reads)
 		pthread_mutex_lock(&b->rq_dev_mtx);
 		const double tw1 = mga_wtime();
 		rc = b->rq_dev_fwd(b->rq_dev_ctx, n_reads, abs0, rn, ra, rf, rp, rv, (int)n_runs, runs, n_dev, order, pass2 ? opt->bw_long : opt->bw, status);
+		if (rc < 0 && !b->rq_dev_err) { b->rq_dev_err = 1; snprintf(b->rq_dev_errmsg, sizeof b->rq_dev_errmsg, "%s", mga_last_error()); } /* (the message is this thread's) */
 		pthread_mutex_unlock(&b->rq_dev_mtx);
 		if (g_cpu_on) fprintf(stderr, "[rq] pass %d of %d reads: %d runs (longest %ld anchors) through the device in %.1f ms (+ %.1f ms waiting for it)\n", pass2 + 1, n_reads, n_dev, (long)ord[0].len, (mga_wtime() - tw1) * 1e3, (tw1 - tw0) * 1e3);
-		if (rc < 0) for (k = 0; k < n_dev; ++k) status[order[k]] = 4; /* (the message stays in mga_last_error(); the host takes the runs) */
+		if (rc < 0) for (k = 0; k < n_dev; ++k) status[order[k]] = 4; /* (the task graph runs to its end on the host's tree; mga_batch_chain() then FAILS the chunk with the device's message) */
 	}
 	for (x = 0, q = 0; x < n_reads; ++x) {
 		rq_read_t *r = &b->rq[reads[x]];
@@ -640,6 +642,7 @@ int mga_batch_chain(mga_batch_t *b, const int32_t *n_mz, const int32_t *rep_len,
 		b->tp_chain_base[t + 1] = b->tp_chain_base[t] + b->tp[t].n_chain;
 		b->tp_vert_base[t + 1] = b->tp_vert_base[t] + b->tp[t].n_vert;
 	}
+	if (b->rq_dev_err) { mga_set_error("RMQ forward pass on the device failed: %s", b->rq_dev_errmsg); return -1; } /* fail loudly: a device error must not pass for a slow job */
 	return 0;
 }
 
@@ -1453,6 +1456,18 @@ struct mga_stream_s {
 typedef struct { kstring_t *part; int64_t *off; char *dst; } gcopy_t;
 static void gaf_copy_worker(void *data, int64_t i, int tid) { gcopy_t *g = (gcopy_t*)data; (void)tid; if (g->part[i].l) memcpy(g->dst + g->off[i], g->part[i].s, g->part[i].l); strbuf_put(g->part[i].s, g->part[i].m); g->part[i].s = 0, g->part[i].m = g->part[i].l = 0; }
 
+/* room for `more` bytes (+ 1) at the end of the batch's output; the caller holds cmtx.  -1: out of memory, the buffer is what it was */
+static int out_reserve(sbatch_t *b, int64_t more)
+{
+	if (b->out_len + more + 1 > b->out_cap) {
+		const int64_t cap = (b->out_len + more + 1) * 3 / 2 + (1 << 20);
+		char *p = (char*)realloc(b->out, (size_t)cap);
+		if (p == 0) return -1;
+		b->out = p, b->out_cap = cap;
+	}
+	return 0;
+}
+
 /* chunk c of batch b is formatted: append every chunk that is now complete AND next in read order to the batch's output buffer */
 static void commit_chunks(sbatch_t *b, int c)
 {
@@ -1465,9 +1480,9 @@ static void commit_chunks(sbatch_t *b, int c)
 		int k;
 		g.part = b->gaf_part + (size_t)b->next_commit * T, g.off = off;
 		for (k = 0; k < T; ++k) off[k] = tot, tot += g.part[k].l;
-		if (b->out_len + tot + 1 > b->out_cap) {
-			b->out_cap = (b->out_len + tot + 1) * 3 / 2 + (1 << 20);
-			b->out = (char*)realloc(b->out, (size_t)b->out_cap);
+		if (out_reserve(b, tot) < 0) { /* the job fails loudly (the batch's error is what its caller gets back); the chunks behind this one are marked done and never copied */
+			if (!b->err) { b->err = 1; snprintf(b->errmsg, sizeof b->errmsg, "out of memory: %lld bytes of GAF output", (long long)(b->out_len + tot)); }
+			break;
 		}
 		g.dst = b->out + b->out_len;
 		mga_parallel_for(T < 16 ? T : 16, T, gaf_copy_worker, &g);
@@ -1511,12 +1526,7 @@ static int sink_try_reserve(void *ctx_, int64_t bytes, char **dst)
 	int ok = 0;
 	pthread_mutex_lock(&b->cmtx);
 	if (b->next_commit == x->c && !b->err) { /* nobody else can append until this chunk is marked done: the room stays where it is while the pieces are written */
-		if (b->out_len + bytes + 1 > b->out_cap) {
-			b->out_cap = (b->out_len + bytes + 1) * 3 / 2 + (1 << 20);
-			b->out = (char*)realloc(b->out, (size_t)b->out_cap);
-		}
-		*dst = b->out + b->out_len;
-		ok = 1;
+		if (out_reserve(b, bytes) == 0) { *dst = b->out + b->out_len; ok = 1; } /* (no room: the chunk goes the piece-wise way, whose commit reports the failure) */
 	}
 	pthread_mutex_unlock(&b->cmtx);
 	return ok;
