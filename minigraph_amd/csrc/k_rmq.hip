@@ -173,15 +173,20 @@ __global__ void __launch_bounds__(64) k_rmq_fwd(int n_order, const rq_run_t *__r
 {
 	__shared__ int32_t cand_j[RQ_CAND_MAX], cand_y[RQ_CAND_MAX], sorted_j[RQ_CAND_MAX];
 	const int lane = threadIdx.x;
+	// ONE lane-0 region per iteration, at the loop's head: it writes the previous run's status and fetches the next work index.  (As two regions -- the status at the loop's end,
+	// the fetch at its head -- the compiler's structurizer may join them across the back edge into an inner loop that lanes 1..63 skip: k_wfa_w.hip's k_wfa_fwp hung that way.)
+	int r = -1, rc = 0;
 	for (;;) {
 		int k = 0;
-		if (lane == 0) k = atomicAdd(counter, 1);
+		if (lane == 0) {
+			if (r >= 0) status[r] = rc;
+			k = atomicAdd(counter, 1);
+		}
 		k = __builtin_amdgcn_readfirstlane(k);
 		if (k >= n_order) break;
-		const int r = order ? __builtin_amdgcn_readfirstlane(order[k]) : k;
+		r = order ? __builtin_amdgcn_readfirstlane(order[k]) : k;
 		const rq_run_t run = runs[r];
-		const int rc = rq_run(a, (int32_t)run.beg, (int32_t)run.end, (int32_t)run.base, R, f, p, v, t, pri, ys, cand_j, cand_y, sorted_j, lane);
-		if (lane == 0) status[r] = rc;
+		rc = rq_run(a, (int32_t)run.beg, (int32_t)run.end, (int32_t)run.base, R, f, p, v, t, pri, ys, cand_j, cand_y, sorted_j, lane);
 		__syncthreads();
 	}
 }
