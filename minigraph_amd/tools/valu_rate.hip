@@ -10,6 +10,10 @@ __global__ void __launch_bounds__(64) k_rate(int iters, int32_t *out, long long 
 {
 	int32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
 	const int32_t b = out[0];
+	// KIND 5 / 6 / 7: the v_max_i32 stream with only lanes 0..31 / 0..15 / the even lanes active -- does a wave64 instruction whose EXEC half (quarter) is empty take fewer issue cycles?
+	if (KIND == 5 && threadIdx.x >= 32) return;
+	if (KIND == 6 && threadIdx.x >= 16) return;
+	if (KIND == 7 && (threadIdx.x & 1)) return;
 	const long long t0 = clock64();
 	for (int i = 0; i < iters; ++i) {
 #pragma unroll
@@ -22,6 +26,25 @@ __global__ void __launch_bounds__(64) k_rate(int iters, int32_t *out, long long 
 				a4 = __builtin_amdgcn_update_dpp(a4, a5, 0x111, 0xf, 0xf, false); a5 = __builtin_amdgcn_update_dpp(a5, a6, 0x111, 0xf, 0xf, false);
 				a6 = __builtin_amdgcn_update_dpp(a6, a7, 0x111, 0xf, 0xf, false); a7 = __builtin_amdgcn_update_dpp(a7, a0, 0x111, 0xf, 0xf, false);
 			}
+			if (KIND == 5 || KIND == 6 || KIND == 7) { a0 = max(a0, b); a1 = max(a1, b); a2 = max(a2, b); a3 = max(a3, b); a4 = max(a4, b); a5 = max(a5, b); a6 = max(a6, b); a7 = max(a7, b); asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)); }
+			if (KIND == 4) { // packed 16-bit maxima and sums (the packed WFA step)
+				typedef short pk2 __attribute__((ext_vector_type(2)));
+#define PKMAX(x_) x_ = __builtin_bit_cast(int32_t, __builtin_elementwise_max(__builtin_bit_cast(pk2, x_), __builtin_bit_cast(pk2, b)))
+#define PKADD(x_) x_ = __builtin_bit_cast(int32_t, (pk2)(__builtin_bit_cast(pk2, x_) + __builtin_bit_cast(pk2, b)))
+				PKMAX(a0); PKADD(a1); PKMAX(a2); PKADD(a3); PKMAX(a4); PKADD(a5); PKMAX(a6); PKADD(a7);
+				asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+			}
+			if (KIND == 8) { // v_alignbit_b32 (three operands) and v_and_or_b32
+				a0 = __builtin_amdgcn_alignbit(a0, a1, 16); a1 = (a1 & b) | a2; a2 = __builtin_amdgcn_alignbit(a2, a3, 16); a3 = (a3 & b) | a4;
+				a4 = __builtin_amdgcn_alignbit(a4, a5, 16); a5 = (a5 & b) | a6; a6 = __builtin_amdgcn_alignbit(a6, a7, 16); a7 = (a7 & b) | a0;
+			}
+			if (KIND == 9) { // the match-mask block of the windowed WFA kernels: SDWA byte compares into VCC, the carry shifted into a register (8 instructions)
+				asm volatile("v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_3 src1_sel:BYTE_3\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+							 "v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_2 src1_sel:BYTE_2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+							 "v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_1 src1_sel:BYTE_1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+							 "v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_0 src1_sel:BYTE_0\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+							 : "+v"(a0) : "v"(a1), "v"(b) : "vcc");
+			}
 			if (KIND == 3) { // compare + select pairs
 				a0 = a0 < b ? a1 : a0; a1 = a1 < b ? a2 : a1; a2 = a2 < b ? a3 : a2; a3 = a3 < b ? a4 : a3;
 				asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
@@ -30,7 +53,7 @@ __global__ void __launch_bounds__(64) k_rate(int iters, int32_t *out, long long 
 	}
 	const long long t1 = clock64();
 	out[1 + blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
-	if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+	if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0; // (lane 0 is active in every variant)
 }
 
 template<int KIND> static void run(const char *name, int per_trip)
@@ -61,5 +84,11 @@ int main()
 	run<1>("v_add_u32", 64);
 	run<2>("v_mov_b32 dpp", 64);
 	run<3>("v_cmp + v_cndmask", 64);
+	run<4>("v_pk_max_i16 / v_pk_add_i16", 64);
+	run<8>("v_alignbit / v_and_or", 64);
+	run<9>("v_cmp_sdwa + v_addc (mask)", 64);
+	run<5>("v_max_i32, lanes 0..31", 64);
+	run<6>("v_max_i32, lanes 0..15", 64);
+	run<7>("v_max_i32, even lanes", 64);
 	return 0;
 }
