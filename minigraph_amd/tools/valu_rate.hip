@@ -14,6 +14,7 @@ __global__ void __launch_bounds__(64) k_rate(int iters, int32_t *out, long long 
 	if (KIND == 5 && threadIdx.x >= 32) return;
 	if (KIND == 6 && threadIdx.x >= 16) return;
 	if (KIND == 7 && (threadIdx.x & 1)) return;
+	int32_t sacc = 0;
 	const long long t0 = clock64();
 	for (int i = 0; i < iters; ++i) {
 #pragma unroll
@@ -45,6 +46,21 @@ __global__ void __launch_bounds__(64) k_rate(int iters, int32_t *out, long long 
 							 "v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_0 src1_sel:BYTE_0\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
 							 : "+v"(a0) : "v"(a1), "v"(b) : "vcc");
 			}
+			if (KIND == 10) { // eight v_max_i32 issued with EXEC = 0 (what a skipped per-lane branch leaves in the instruction stream)
+				uint64_t saved;
+				asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 0\n\t"
+							 "v_max_i32 %1, %1, %9\n\tv_max_i32 %2, %2, %9\n\tv_max_i32 %3, %3, %9\n\tv_max_i32 %4, %4, %9\n\t"
+							 "v_max_i32 %5, %5, %9\n\tv_max_i32 %6, %6, %9\n\tv_max_i32 %7, %7, %9\n\tv_max_i32 %8, %8, %9\n\t"
+							 "s_mov_b64 exec, %0"
+							 : "=&s"(saved), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+			}
+			if (KIND == 11) { // v_readfirstlane_b32 (a vector instruction that reads one lane)
+				int32_t s0, s1, s2, s3, s4, s5, s6, s7;
+				asm volatile("v_readfirstlane_b32 %0, %8\n\tv_readfirstlane_b32 %1, %9\n\tv_readfirstlane_b32 %2, %10\n\tv_readfirstlane_b32 %3, %11\n\t"
+							 "v_readfirstlane_b32 %4, %12\n\tv_readfirstlane_b32 %5, %13\n\tv_readfirstlane_b32 %6, %14\n\tv_readfirstlane_b32 %7, %15"
+							 : "=s"(s0), "=s"(s1), "=s"(s2), "=s"(s3), "=s"(s4), "=s"(s5), "=s"(s6), "=s"(s7) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));
+				sacc += s0 ^ s1 ^ s2 ^ s3 ^ s4 ^ s5 ^ s6 ^ s7;
+			}
 			if (KIND == 3) { // compare + select pairs
 				a0 = a0 < b ? a1 : a0; a1 = a1 < b ? a2 : a1; a2 = a2 < b ? a3 : a2; a3 = a3 < b ? a4 : a3;
 				asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
@@ -52,7 +68,7 @@ __global__ void __launch_bounds__(64) k_rate(int iters, int32_t *out, long long 
 		}
 	}
 	const long long t1 = clock64();
-	out[1 + blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+	out[1 + blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + sacc;
 	if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0; // (lane 0 is active in every variant)
 }
 
@@ -87,6 +103,8 @@ int main()
 	run<4>("v_pk_max_i16 / v_pk_add_i16", 64);
 	run<8>("v_alignbit / v_and_or", 64);
 	run<9>("v_cmp_sdwa + v_addc (mask)", 64);
+	run<10>("v_max_i32 with EXEC = 0", 64);
+	run<11>("v_readfirstlane_b32", 64);
 	run<5>("v_max_i32, lanes 0..31", 64);
 	run<6>("v_max_i32, lanes 0..15", 64);
 	run<7>("v_max_i32, even lanes", 64);
