@@ -30,7 +30,7 @@
 // and a gap that gives up has wasted its steps up to the bound, so a gap starts in the narrowest window whose bound most gaps of its length stay under.
 struct wfs_rung_t { int kind, idx, maxlen, next; };
 struct wfs_ladder_t { int n; wfs_rung_t r[MGA_WFA_N_SLOT]; };
-struct wfs_thr_t { int32_t n, t[MGA_WFA_N_SLOT]; };
+struct wfs_thr_t { int32_t n, n_stable, t[MGA_WFA_N_SLOT]; }; // n_stable: the first rungs whose lists are in problem order instead of longest-first (below)
 static const wfs_ladder_t g_ladder_win = { 11, {
 	{ 0, 0, 71, 1 }, { 0, 1, 111, 2 }, { 0, 2, 167, 3 }, { 0, 3, 255, 4 }, { 0, 4, 343, 5 }, { 0, 5, 420, 6 },
 	// the register tiers are windowed too (their band is the reference's, trimming included, clipped to the window): 512 diagonals decide scores < 542, ...
@@ -74,9 +74,11 @@ __global__ void __launch_bounds__(1024) k_wfa_bin_count(int n, const int32_t *__
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const int pi = ids ? ids[i] : i;
 		const int32_t tl = prob[pi].tl, ql = prob[pi].ql;
+		const int rg = wfs_first_rung(tl, ql, T);
 		int lb = (tl + ql) >> 3;
 		if (lb > 1023) lb = 1023;
-		const int k = wfs_first_rung(tl, ql, T) << 10 | (1023 - lb);
+		if (rg < T.n_stable) lb = 0; // one bin: the scatter keeps this rung's problems in index order
+		const int k = rg << 10 | (1023 - lb);
 		key[i] = k;
 		atomicAdd(&h[k], 1);
 	}
@@ -114,25 +116,53 @@ __global__ void __launch_bounds__(1024) k_wfa_bin_scan(int *__restrict__ hist, i
 // tile of 8192 ids per workgroup: LDS histogram of the tile, ONE global atomic per non-empty bin to reserve its slots,
 // then LDS atomics hand out the slots (4.8 M global atomics on ~20 hot bins took 14 ms; this takes <1 ms)
 struct wfs_shift_t { int32_t s[MGA_WFA_N_SLOT]; }; // rung r's region of the list starts s[r] slots after where the compact order would put it (room for arrivals from below)
-__global__ void __launch_bounds__(1024) k_wfa_bin_scatter(int n, const int32_t *__restrict__ ids, const int32_t *__restrict__ key, int *__restrict__ cursor, int32_t *__restrict__ list, wfs_shift_t shift)
+// Round 5: the lists of the first `n_stable` rungs (16 / 32 / 64 diagonals: 97 % of the problems, each a few microseconds of a launch that lasts milliseconds, so longest-first
+// buys them nothing) keep the problems' INDEX order -- runs of ~4 000 ascending ids per block of 8 192.  Neighbouring lanes of the traceback walk (a lane per list entry) and
+// neighbouring refills of the forward kernels then touch neighbouring descriptors, results and sequences: [measured, round 4] the walk fetched 1.9 KB per problem, a 128-byte
+// line of its own for each of descriptor, result, two sequences and ~4 traceback rows.  A rung's rank inside the block comes from ballots and per-wave counts, round by round.
+__global__ void __launch_bounds__(1024) k_wfa_bin_scatter(int n, const int32_t *__restrict__ ids, const int32_t *__restrict__ key, int *__restrict__ cursor, int32_t *__restrict__ list, wfs_shift_t shift, int n_stable)
 {
 	__shared__ int cnt[WFS_NBIN], base[WFS_NBIN];
-	const int t0 = blockIdx.x * 8192;
+	__shared__ int wcnt[3][16];
+	const int t0 = blockIdx.x * 8192, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 	for (int i = threadIdx.x; i < WFS_NBIN; i += 1024) cnt[i] = 0;
 	__syncthreads();
-	int k[8];
+	int k[8], rank[8];
 #pragma unroll
 	for (int r = 0; r < 8; ++r) {
 		const int i = t0 + r * 1024 + threadIdx.x;
 		k[r] = i < n ? key[i] : -1;
+		rank[r] = -1;
 		if (k[r] >= 0) atomicAdd(&cnt[k[r]], 1);
+	}
+	if (n_stable > 0) { // (uniform) rank of an entry among its block's entries of the same rung, in index order: i = t0 + 1024 r + thread
+		int run[3] = { 0, 0, 0 };
+#pragma unroll
+		for (int r = 0; r < 8; ++r) {
+			const int rg = (k[r] >= 0 && (k[r] >> 10) < n_stable) ? k[r] >> 10 : -1;
+			uint64_t b[3];
+#pragma unroll
+			for (int x = 0; x < 3; ++x) { b[x] = __ballot(rg == x); if (lane == 0) wcnt[x][wid] = (int)__popcll(b[x]); }
+			__syncthreads();
+#pragma unroll
+			for (int x = 0; x < 3; ++x) {
+				int pre = 0, tot = 0;
+				for (int w = 0; w < 16; ++w) { const int c = wcnt[x][w]; tot += c; if (w < wid) pre += c; }
+				if (rg == x) rank[r] = run[x] + pre + (int)__popcll(b[x] & mga_lanemask_lt());
+				run[x] += tot;
+			}
+			__syncthreads();
+		}
 	}
 	__syncthreads();
 	for (int i = threadIdx.x; i < WFS_NBIN; i += 1024) if (cnt[i]) base[i] = atomicAdd(&cursor[i], cnt[i]);
 	__syncthreads();
 #pragma unroll
 	for (int r = 0; r < 8; ++r)
-		if (k[r] >= 0) list[base[k[r]] + shift.s[k[r] >> 10] + atomicSub(&cnt[k[r]], 1) - 1] = ids ? ids[t0 + r * 1024 + threadIdx.x] : t0 + r * 1024 + threadIdx.x;
+		if (k[r] >= 0) {
+			const int at = rank[r] >= 0 ? rank[r] : atomicSub(&cnt[k[r]], 1) - 1;
+			list[base[k[r]] + shift.s[k[r] >> 10] + at] = ids ? ids[t0 + r * 1024 + threadIdx.x] : t0 + r * 1024 + threadIdx.x;
+		}
 }
 
 __global__ void __launch_bounds__(256) k_wfa_sum_cells(int n, const mga_wfa_res_t *__restrict__ res, unsigned long long *__restrict__ out)
@@ -334,12 +364,17 @@ static int wfs_sweep(mga_sctx_t *sc, const wfs_ladder_t *LD, int arr_pct, int n_
 	static int dbg = -1;
 	if (dbg < 0) { const char *e = getenv("MGA_DEBUG_WFA"); dbg = e && atoi(e) > 0; }
 	*n_open = 0;
+	// MGA_WFA_LIST_STABLE=<n>: the lists of the first n windowed rungs in problem order (k_wfa_bin_scatter); 0 = every rung longest-first as before round 5.  Only the new ladder's
+	// narrow rungs qualify (the old ladder's rungs are multi-wave kernels whose launches do end in their longest problems)
+	static int n_stable_env = -1;
+	if (n_stable_env < 0) { const char *e = getenv("MGA_WFA_LIST_STABLE"); n_stable_env = e && *e ? atoi(e) : 3; if (n_stable_env > 3) n_stable_env = 3; if (n_stable_env < 0) n_stable_env = 0; }
+	const int n_stable = LD->r[0].kind != 0 ? 0 : n_stable_env; // (kind 1: the round-2 ladder, register tiers from the first rung on)
 	MGA_HIP_CHECK(hipMemsetAsync(ctl, 0, (size_t)O_ERR * 4, st)); // histogram, offsets, list lengths (the err / fb / cells words behind them are kept)
 	{
 		int nb = (n_list + 1023) / 1024;
 		if (nb > 1024) nb = 1024;
 		wfs_thr_t T;
-		T.n = NR;
+		T.n = NR, T.n_stable = n_stable;
 		for (int k = 0; k < NS; ++k) T.t[k] = k < NR ? LD->r[k].maxlen : 0x7fffffff;
 		mga_prof_begin(st, MGA_K_SCAN);
 		hipLaunchKernelGGL(k_wfa_bin_count, dim3(nb), dim3(1024), 0, st, n_list, d_ids, d_prob, (int32_t*)sc->wfa_key.p, ctl, T);
@@ -370,7 +405,7 @@ static int wfs_sweep(mga_sctx_t *sc, const wfs_ladder_t *LD, int arr_pct, int n_
 		wfs_shift_t sh;
 		for (int t = 0; t < NS; ++t) sh.s[t] = t < NR ? base[t] - h[t] : 0;
 		mga_prof_begin(st, MGA_K_SCAN);
-		hipLaunchKernelGGL(k_wfa_bin_scatter, dim3((n_list + 8191) / 8192), dim3(1024), 0, st, n_list, d_ids, (const int32_t*)sc->wfa_key.p, ctl, L, sh);
+		hipLaunchKernelGGL(k_wfa_bin_scatter, dim3((n_list + 8191) / 8192), dim3(1024), 0, st, n_list, d_ids, (const int32_t*)sc->wfa_key.p, ctl, L, sh, n_stable);
 		mga_prof_end(st, MGA_K_SCAN);
 		MGA_HIP_CHECK(hipGetLastError());
 	}
