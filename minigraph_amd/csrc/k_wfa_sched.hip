@@ -364,10 +364,11 @@ static int wfs_sweep(mga_sctx_t *sc, const wfs_ladder_t *LD, int arr_pct, int n_
 	static int dbg = -1;
 	if (dbg < 0) { const char *e = getenv("MGA_DEBUG_WFA"); dbg = e && atoi(e) > 0; }
 	*n_open = 0;
-	// MGA_WFA_LIST_STABLE=<n>: the lists of the first n windowed rungs in problem order (k_wfa_bin_scatter); 0 = every rung longest-first as before round 5.  Only the new ladder's
+	// MGA_WFA_LIST_STABLE=<n>: the lists of the first n windowed rungs in problem order (k_wfa_bin_scatter); 0 (default) = every rung longest-first.  [measured, profiles/r05r_list_sweep.txt]
+	// n = 3: W16 12.7 -> 12.0, W32 15.1 -> 15.5, the traceback walk 18.0 -> 17.8-18.0 ms per 125 000 reads: the walk is a chain of dependent loads per lane, not their volume.  Only the new ladder's
 	// narrow rungs qualify (the old ladder's rungs are multi-wave kernels whose launches do end in their longest problems)
 	static int n_stable_env = -1;
-	if (n_stable_env < 0) { const char *e = getenv("MGA_WFA_LIST_STABLE"); n_stable_env = e && *e ? atoi(e) : 3; if (n_stable_env > 3) n_stable_env = 3; if (n_stable_env < 0) n_stable_env = 0; }
+	if (n_stable_env < 0) { const char *e = getenv("MGA_WFA_LIST_STABLE"); n_stable_env = e && *e ? atoi(e) : 0; if (n_stable_env > 3) n_stable_env = 3; if (n_stable_env < 0) n_stable_env = 0; }
 	const int n_stable = LD->r[0].kind != 0 ? 0 : n_stable_env; // (kind 1: the round-2 ladder, register tiers from the first rung on)
 	MGA_HIP_CHECK(hipMemsetAsync(ctl, 0, (size_t)O_ERR * 4, st)); // histogram, offsets, list lengths (the err / fb / cells words behind them are kept)
 	{
