@@ -25,6 +25,7 @@ static inline void ks_room(kstring_t *s, size_t extra)
 		if (m > 0xfffffff0u) m = 0xfffffff0u;
 		s->m = (unsigned)(m < 64 ? 64 : m);
 		s->s = (char*)realloc(s->s, s->m);
+		if (s->s == 0) { fprintf(stderr, "[E::%s] out of memory (%u bytes of GAF text)\n", __func__, s->m); abort(); }
 	}
 }
 static inline void ks_c(kstring_t *s, char c) { ks_room(s, 1); s->s[s->l++] = c; KS_TERM(s); }
