@@ -72,6 +72,51 @@ __global__ void __launch_bounds__(64) k_rate(int iters, int32_t *out, long long 
 	if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0; // (lane 0 is active in every variant)
 }
 
+// A persistent kernel with a global work queue, as the WFA rungs are: 8 192 workgroups of which a fifth is resident (24 KB of LDS each), n_items items of ITEM_TRIPS x 64
+// v_max_i32 drawn one at a time.  The instruction total is known exactly (items x (ITEM_TRIPS x 64 + a few)); how it spreads over the waves, CUs and XCDs is up to the dispatcher.
+// Question: do the per-dispatch SQ counters report that total, or a scaled sample of part of the chip?
+#define ITEM_TRIPS 100
+__global__ void __launch_bounds__(64) k_queue(int n_items, int *counter, int32_t *out, unsigned long long *done)
+{
+	__shared__ int32_t pad[6144];
+	int32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+	const int32_t b = out[0];
+	pad[threadIdx.x] = b;
+	unsigned long long mine = 0;
+	for (;;) {
+		int item = 0;
+		if (threadIdx.x == 0) item = atomicAdd(counter, 1);
+		item = __builtin_amdgcn_readfirstlane(item);
+		if (item >= n_items) break;
+		for (int i = 0; i < ITEM_TRIPS; ++i) {
+#pragma unroll
+			for (int u = 0; u < 8; ++u) { a0 = max(a0, b); a1 = max(a1, b); a2 = max(a2, b); a3 = max(a3, b); a4 = max(a4, b); a5 = max(a5, b); a6 = max(a6, b); a7 = max(a7, b); asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)); }
+		}
+		++mine;
+	}
+	out[1 + blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + pad[(threadIdx.x * 7) & 63];
+	if (threadIdx.x == 0) atomicAdd(done, mine);
+}
+
+static void run_queue()
+{
+	int32_t *out; int *counter; unsigned long long *done;
+	const int nb = 8192, n_items = 400000;
+	hipMalloc(&out, 4 * (1 + 64 * nb)); hipMalloc(&counter, 4); hipMalloc(&done, 8); hipMemset(out, 0, 4);
+	for (int rep = 0; rep < 2; ++rep) {
+		hipMemset(counter, 0, 4); hipMemset(done, 0, 8);
+		hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+		hipEventRecord(e0, 0);
+		hipLaunchKernelGGL(k_queue, dim3(nb), dim3(64), 0, 0, n_items, counter, out, done);
+		hipEventRecord(e1, 0); hipEventSynchronize(e1);
+		float ms; hipEventElapsedTime(&ms, e0, e1);
+		unsigned long long h = 0; hipMemcpy(&h, done, 8, hipMemcpyDeviceToHost);
+		printf("k_queue: %d workgroups, %d items of %d x 64 v_max_i32: %llu items done, %.3f ms -> %.1f G wave-instructions/s on the chip = %.0f M/s per SIMD (1024 SIMDs); expected VALU per wave (average over %d waves) = %.1f + a few per item\n",
+			   nb, n_items, ITEM_TRIPS, h, ms, (double)h * ITEM_TRIPS * 64 / (ms * 1e6), (double)h * ITEM_TRIPS * 64 / (ms * 1e3) / 1024, nb, (double)h * ITEM_TRIPS * 64 / nb);
+	}
+	hipFree(out); hipFree(counter); hipFree(done);
+}
+
 template<int KIND> static void run(const char *name, int per_trip)
 {
 	int32_t *out; long long *cyc;
@@ -108,5 +153,6 @@ int main()
 	run<5>("v_max_i32, lanes 0..31", 64);
 	run<6>("v_max_i32, lanes 0..15", 64);
 	run<7>("v_max_i32, even lanes", 64);
+	run_queue();
 	return 0;
 }
