@@ -71,6 +71,16 @@ def cpu_baseline(ref_bin, graph, reads_fa, n_reads, out_dir, threads, cores):
                 sample="%d reads (%d bp) of the same workload, minigraph -cx lr -t %d on %d usable cores (affinity capped by the cgroup CPU quota), map phase only (worker_pipeline - mg_opt_update: FASTA parse + mapping + GAF write, as in `value`)" % (n, bases, threads, cores)), gaf, n
 
 
+def kernel_src_sha1():
+    """hash of every device source of this tree -- the same function as minigraph_amd/tools/prof_summary.py's, which stamps it into the counter / PMC summaries"""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "minigraph_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "minigraph_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return h.hexdigest()
+
+
 def asm_block(mga, d, genome, threads, ref_bin):
     """`-cx asm`: ten contigs of genome/10 bp (0.1 %% divergence from the haplotype walks) against a 3-haplotype bubble graph of `genome` backbone bp in 10 chromosomes;
     the whole job file -> file (GFA parse, index, mapping, GAF) here and in the unmodified reference on the same cores; the two GAF files must be the same bytes."""
@@ -470,6 +480,9 @@ def main():
                         h.update(open(f, "rb").read())
                     stale = json.load(open(pf)).get("wfa_src_sha1") != h.hexdigest()
                     traffic_src = os.path.relpath(pf, ROOT) + " (committed rocprofv3 --pmc passes of this command, not measured in this run%s)" % ("; STALE: taken from other WFA kernel sources than this tree's" if stale else "")
+                    all_rec = json.load(open(pf)).get("kernel_src_sha1")   # (round 5) every device source, whichever family is priced
+                    if all_rec is not None and all_rec != kernel_src_sha1():
+                        traffic_src += "; STALE: the tree's device sources differ from the ones the passes ran"
             except Exception:
                 pass
             # vector-ALU utilisation per rung of the WFA ladder (and the other big kernels): vector instructions per launch -- SQ_INSTS_VALU of the committed counter passes of this
@@ -514,7 +527,13 @@ def main():
                     inst_per_pass = q["valu_per_wave"] * q["waves"] / n_pass
                     valu_busy[kn] = dict(valu_busy=round(inst_per_pass * 4.15 / (256 * 4 * pr_[0] * 1e-3 * 2.4e9), 3), valu_instr_per_pass=round(inst_per_pass), ms_per_pass=round(pr_[0], 2),
                                          share_of_a_waves_cycles=dict(valu=q["valu_share"], waiting=q["wait_share"]))
-                valu_src = ("VALU instructions per pass of 125000 reads: " + os.path.relpath(sf, ROOT) + " (committed rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES passes of this command, %d passes); "
+                sq_rec = None
+                for ln in open(sf):
+                    if ln.startswith("# kernel_src_sha1:"):
+                        sq_rec = ln.split(":", 1)[1].strip()
+                        break
+                sq_lbl = "" if sq_rec == kernel_src_sha1() else ("; no source hash recorded in the file" if sq_rec is None else "; STALE: the tree's device sources differ from the ones the passes ran")
+                valu_src = ("VALU instructions per pass of 125000 reads: " + os.path.relpath(sf, ROOT) + sq_lbl + " (committed rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES passes of this command, %d passes); "
                             "kernel time per pass: this run's isolated pass; 4.15 SIMD cycles per wave64 integer instruction [measured], 1024 SIMDs at the nominal 2.4 GHz "
                             "(a lower sustained clock raises the true figure)" % n_pass)
             except Exception:

@@ -45,7 +45,18 @@ def main_pmc_json(fetch_db, write_db, source):
     h = hashlib.sha1()   # which WFA sources the passes ran (bench.py labels the traffic figure STALE when the tree has others)
     for f in sorted(glob.glob(os.path.join(root, "minigraph_amd", "csrc", "k_wfa*.hip")) + [os.path.join(root, "minigraph_amd", "csrc", "wfa_window.h")]):
         h.update(open(f, "rb").read())
-    print(json.dumps({"source": source, "wfa_src_sha1": h.hexdigest(), "kernels": dict(sorted(ker.items()))}, indent=1))
+    print(json.dumps({"source": source, "wfa_src_sha1": h.hexdigest(), "kernel_src_sha1": kernel_src_sha1(), "kernels": dict(sorted(ker.items()))}, indent=1))
+
+
+def kernel_src_sha1():
+    """hash of every device source of the tree (csrc/*.hip and the headers they include): what a counter / PMC file records about the kernels it was taken from, and what
+    bench.py compares with the tree it runs in (a file of other kernels is labelled STALE, whichever family it prices)"""
+    import glob, hashlib, os
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(root, "minigraph_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "minigraph_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return h.hexdigest()
 
 
 def main_sq(paths, title):
@@ -74,6 +85,7 @@ def main_sq(paths, title):
                 if "SQ_ACTIVE_INST_VALU" in k:
                     d.setdefault("valu_busy", k["SQ_ACTIVE_INST_VALU"] / busy)
     print("# rocprofv3 --pmc SQ_* (own passes, no tracing)  %s" % title)
+    print("# kernel_src_sha1: %s" % kernel_src_sha1())
     import re
     m = re.search(r"--reads (\d+)", title)
     reads = int(m.group(1)) if m else 125000
