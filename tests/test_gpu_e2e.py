@@ -173,6 +173,34 @@ def test_parity_sweep_vs_reference_binary(tag, simargs, cigar, monkeypatch):
         raise AssertionError(tag + ": " + first_diff(ref_out, os.path.join(d, "got.gaf")))
 
 
+def test_reads_at_the_long_read_boundary_vs_reference_binary():
+    """reads of exactly MGA_LONG_READ - 2 .. + 1 bases (262 142 .. 262 145): the last two that go through k_lchain and the first two whose first chaining pass runs on host
+    threads (hchain.c), in one job and in both orders -- the same bytes as the reference whichever side of the switch a read falls on"""
+    need_ref()
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "6000000", "-H", "3", "-n", "8", "-l", "300000", "-e", "0.05", "-s", "91"], stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    recs = []
+    for r in open(reads, "rb").read().split(b">")[1:]:
+        name, _, seq = r.partition(b"\n")
+        recs.append((name, seq.replace(b"\n", b"")))
+    assert len(recs) == 8 and min(len(q) for _, q in recs) >= 262145
+    lens = [262143, 262144, 262142, 262145, 262145, 262142, 262144, 262143]
+    with open(reads, "wb") as f:
+        for (name, q), n in zip(recs, lens):
+            f.write(b">" + name + b"\n" + q[:n] + b"\n")
+    ref_out = os.path.join(d, "ref.gaf")
+    run_ref(["-c", "-x", "lr", "-t", "8", graph, reads], ref_out)
+    G = mga.Graph(graph, preset="lr", cigar=True, n_threads=8)
+    R = mga.Reads(reads)
+    got = mga.map_reads(G, R, n_threads=8)
+    R.close()
+    G.close()
+    if open(ref_out, "rb").read() != got:
+        open(os.path.join(d, "got.gaf"), "wb").write(got)
+        raise AssertionError(first_diff(ref_out, os.path.join(d, "got.gaf")))
+
+
 def test_edge_case_reads_vs_reference_binary():
     """the shapes the reference's own callers have to survive: empty and tiny reads, reads without a single
     minimizer hit, runs of N, lower case, U, FASTQ input, duplicated names"""
