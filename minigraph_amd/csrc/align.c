@@ -61,7 +61,8 @@ void mga_plan_cigar(const gfa_t *g, const gfa_edseq_t *es, const mg_gchains_t *g
 			mga_wfa_prob_t *pb;
 			if (tp->want_src) { /* the device splices the target from its own segment images: say where it lies on the chain's walk */
 				mga_plan_src_t *sr;
-				if (tp->n_prob == tp->m_src) { tp->m_src = tp->m_src ? tp->m_src + (tp->m_src >> 1) : 1024; tp->src = (mga_plan_src_t*)realloc(tp->src, (size_t)tp->m_src * sizeof(mga_plan_src_t)); }
+				if (tp->n_prob == tp->m_src) { tp->m_src = tp->m_src ? tp->m_src + (tp->m_src >> 1) : 1024; tp->src = (mga_plan_src_t*)realloc(tp->src, (size_t)tp->m_src * sizeof(mga_plan_src_t));
+					if (tp->src == 0) { fprintf(stderr, "[E::%s] out of memory (%ld gap descriptors)\n", __func__, (long)tp->m_src); abort(); } }
 				sr = &tp->src[tp->n_prob];
 				sr->lc0 = vert_beg + (l0 - gc->off), sr->n_lc = l - l0, sr->x0 = (int32_t)q->x, sr->x1 = (int32_t)p->x, sr->pad = 0;
 			} else if (l == l0) memcpy(seq, &es[gt->lc[l0].v].seq[(int32_t)q->x + 1], (size_t)l_seq);

@@ -11,9 +11,17 @@
 /* A kstring_t whose capacity says MGA_KS_WINDOW is a WINDOW into somebody else's buffer (round 5: a chunk's GAF lines written straight to their place in the job's output,
  * mapper.c): it is never reallocated and never NUL-terminated -- the byte behind a piece belongs to the next piece, which another thread may be writing. */
 #define KS_TERM(s) do { if ((s)->m != MGA_KS_WINDOW) (s)->s[(s)->l] = 0; } while (0)
+static __thread size_t ks_win_limit = 0; /* bytes the calling thread's current window holds (mga_gaf_window_limit): a write past it would land in the next thread's piece */
+void mga_gaf_window_limit(size_t bytes) { ks_win_limit = bytes; }
 static inline void ks_room(kstring_t *s, size_t extra)
 {
-	if (s->m == MGA_KS_WINDOW) return;
+	if (s->m == MGA_KS_WINDOW) {
+		if ((size_t)s->l + extra > ks_win_limit) { /* the measuring pass and the writing pass run the same formatter: cannot happen, and must stop BEFORE the neighbour's bytes are touched */
+			fprintf(stderr, "[E::%s] GAF window of %zu bytes overrun at %u + %zu\n", __func__, ks_win_limit, s->l, extra);
+			abort();
+		}
+		return;
+	}
 	if (s->l + extra + 1 > s->m) {
 		size_t m = s->l + extra + 1;
 		if (m > 0xfffffff0u) { /* kstring_t (mgpriv.h:31-37) counts in 32 bits: fail loudly instead of wrapping.  A piece is one thread's share of a 16384-read chunk;

@@ -164,8 +164,8 @@ void mga_ggen_shard_range(int n_seq, const int *qlens, int rank, int world, int 
 	if (rank < 0) rank = 0;
 	if (rank >= world) rank = world - 1;
 	for (i = 0; i < n_seq; ++i) tot += qlens[i] > 0 ? qlens[i] : 0;
-	/* sequence i belongs to the rank r with tot * r / world <= (bases before i) < tot * (r + 1) / world: contiguous, order preserving, every sequence exactly once; empty
-	 * sequences go with their predecessor's rank (the comparison below never moves on a zero length) */
+	/* sequence i belongs to the rank r with tot * r / world <= (bases before i) < tot * (r + 1) / world: contiguous, order preserving, every sequence exactly once; an empty
+	 * sequence is placed by the bases BEFORE it like any other, i.e. it goes with the sequence that follows it (at a cut: with the successor's rank) */
 	for (i = 0; i < n_seq; ++i) {
 		int r = tot > 0 ? (int)((__int128)acc * world / tot) : 0;
 		if (r >= world) r = world - 1;

@@ -108,7 +108,6 @@ static inline int lcdp_pair(const mg128_t *ai, const mg128_t *aj, const lcdp_par
 	return 1;
 }
 
-int64_t g_lcdp_hist[8]; /* (measurement aid) anchors by the number of predecessors the scan visits: 0, <=16, <=32, <=64, <=128, more; [6] anchors, [7] visited predecessors */
 void mga_lchain_dp_fwd(int max_dist_x, int max_dist_y, int bw, int max_skip, int max_iter, float pen_gap, float pen_skip,
 					   int64_t n, const mg128_t *a, int32_t *f, int64_t *p, int32_t *v, int32_t *t)
 {
@@ -130,7 +129,6 @@ void mga_lchain_dp_fwd(int max_dist_x, int max_dist_y, int bw, int max_skip, int
 			if (p[j] >= 0) t[p[j]] = (int32_t)i;
 		}
 		scan_end = j;
-		{ const int64_t vis = (i - 1) - j; ++g_lcdp_hist[vis == 0 ? 0 : vis <= 16 ? 1 : vis <= 32 ? 2 : vis <= 64 ? 3 : vis <= 128 ? 4 : 5]; ++g_lcdp_hist[6]; g_lcdp_hist[7] += vis; }
 		if (best_in_reach < 0 || ai->x - a[best_in_reach].x > (uint64_t)(int64_t)P.dist_x) { /* the best-scoring anchor in reach fell out of it: look again */
 			int32_t top = INT32_MIN;
 			best_in_reach = -1;

@@ -103,7 +103,7 @@ static void kx_range_worker(void *data, int64_t i, int tid)
 	free(stk);
 }
 
-int mga_ksort_threads = 1; /* threads a large sort may use (set by the batch that sorts: mapper.c) */
+__thread int mga_ksort_threads = 1; /* threads a large sort started on THIS thread may use: set by the worker that sorts for the duration of its task (mapper.c: rq_*_worker), so that one batch's thread count never leaks into another call */
 
 static void kx_sort_mt(kx_t *a, int64_t n, int key_bytes, int n_threads)
 {

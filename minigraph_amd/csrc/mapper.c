@@ -191,6 +191,7 @@ void mga_batch_lchain_par(const mg_idx_t *gi, const mg_mapopt_t *opt, int qlen_m
  * device) and cuts them into such runs, phase 2 runs the forward pass of all runs of all reads on all threads, phase 3 backtracks
  * per read and decides about the long-join rescue (map-algo.c:407-417), phases 4-5 repeat 2-3 with bw_long for the reads that
  * need it.  chain_worker then picks the chains up. */
+extern __thread int mga_ksort_threads;
 typedef struct rq_read_s {
 	mg128_t *a; int64_t n;           /* anchors being chained: the read's slice of the batch (pass 1) or `out` of pass 1 (pass 2) */
 	int32_t *f, *v, *t; int64_t *p;
@@ -222,12 +223,15 @@ static void rq_arrays(mga_batch_t *b, rq_read_t *r, int64_t i)
 	if (b->rq_harr) { /* the device pass: slices of the chunk's pinned arrays p | f | v | t (pass 2 has fewer anchors than pass 1: the same slices) */
 		const int64_t T = (b->rq_tot + 1) & ~1LL, o = b->a_off[i] - b->a_off[0];
 		r->p = (int64_t*)b->rq_harr + o, r->f = (int32_t*)(b->rq_harr + 8 * T) + o, r->v = (int32_t*)(b->rq_harr + 12 * T) + o, r->t = (int32_t*)(b->rq_harr + 16 * T) + o;
+		/* the pinned block is neither zeroed by its allocation nor between chunks (whose p | f | v | t cuts differ), and every HOST forward pass -- the DP of an ultra-long -x lr
+		 * read, the barrier form, a run the device hands back -- wants its skip marks cleared (lchain.c:166, :270): cheap next to any of them, so always */
+		memset(r->t, 0, (size_t)r->n * 4);
 		return;
 	}
 	r->p = MGA_MALLOC(int64_t, r->n); r->f = MGA_MALLOC(int32_t, r->n); r->v = MGA_MALLOC(int32_t, r->n); r->t = MGA_CALLOC(int32_t, r->n);
 }
 
-static void rq_prepare_worker(void *data, int64_t i, int tid)
+static void rq_prepare_worker_(void *data, int64_t i, int tid)
 {
 	mga_batch_t *b = (mga_batch_t*)data;
 	rq_read_t *r = &b->rq[i];
@@ -325,7 +329,7 @@ static void rq_dev_worker(mga_batch_t *b, int n_reads, const int32_t *reads)
 	CPU_ADD(pass2 ? C_LCRESCUE : C_LCCOPY, tc);
 }
 
-static void rq_finish_worker(void *data, int64_t i, int tid)
+static void rq_finish_worker_(void *data, int64_t i, int tid)
 {
 	mga_batch_t *b = (mga_batch_t*)data;
 	rq_read_t *r = &b->rq[i];
@@ -362,6 +366,10 @@ static void rq_finish_worker(void *data, int64_t i, int tid)
 		CPU_ADD(C_LCRESCUE, tc);
 	}
 }
+
+/* the big sorts of a contig fan out over the pool (ksortx.c: mga_ksort_threads is per thread) for the duration of the task that sorts, and never beyond it */
+static void rq_prepare_worker(void *data, int64_t i, int tid) { mga_ksort_threads = ((mga_batch_t*)data)->n_threads; rq_prepare_worker_(data, i, tid); mga_ksort_threads = 1; }
+static void rq_finish_worker(void *data, int64_t i, int tid) { mga_ksort_threads = ((mga_batch_t*)data)->n_threads; rq_finish_worker_(data, i, tid); mga_ksort_threads = 1; }
 
 static void rq_run_fwd(mga_batch_t *b, int pass2)
 {
@@ -632,7 +640,7 @@ int mga_batch_chain(mga_batch_t *b, const int32_t *n_mz, const int32_t *rep_len,
 	b->rescue_flag = rescue_flag;
 	b->n_mz = n_mz, b->rep_len = rep_len, b->mini_pos = mini_pos, b->mini_off = mini_off;
 	b->nu = nu, b->nb = nb, b->u = u, b->a = a, b->a_off = a_off, b->a_is_raw = a_is_raw;
-	if (a_is_raw) { extern int mga_ksort_threads; if (b->n_threads > mga_ksort_threads) mga_ksort_threads = b->n_threads; /* the big sorts of a contig fan out over the pool (ksortx.c) */ rq_chain_all(b); }
+	if (a_is_raw) rq_chain_all(b);
 	mga_parallel_for(b->n_threads, b->n, chain_worker, b);
 	if (b->rq) { free(b->rq); b->rq = 0; }
 	for (t = 0; t < b->n_threads; ++t) {
@@ -790,7 +798,7 @@ static void gaf_worker(void *data, int64_t t, int tid)
 	int32_t m_txt = 0;
 	int64_t tc = cpu_now();
 	(void)tid;
-	if (w->mode == 2) { win.s = w->dst + w->off[t], win.l = 0, win.m = MGA_KS_WINDOW; out = &win; }
+	if (w->mode == 2) { win.s = w->dst + w->off[t], win.l = 0, win.m = MGA_KS_WINDOW; out = &win; mga_gaf_window_limit((size_t)w->bytes[t]); }
 	else if (w->mode == 0) { /* one allocation per piece: a base-aligned read prints about one byte per base (cg + ds), an unaligned one ~120 bytes */
 		size_t est = 4096;
 		for (i = b; i < e; ++i) est += (bt->opt.flag & MG_M_CIGAR) ? (size_t)bt->qlens[i] + 512 : 512;
@@ -1375,8 +1383,9 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 			int t_;
 			w.bytes = bo, w.off = bo + n_threads + 1, w.mode = 1;
 			mga_parallel_for(n_threads, n_threads, gaf_worker, &w);
-			for (t_ = 0; t_ < n_threads; ++t_) w.off[t_] = tot_b, tot_b += w.bytes[t_];
-			if (sink->try_reserve(sink->ctx, tot_b, &w.dst)) {
+			int fits = 1; /* kstring_t::l counts in 32 bits: a piece beyond that (chromosome-scale text on few threads) takes the piece path, which fails loudly at 4 GB (gaf.c: ks_room) */
+			for (t_ = 0; t_ < n_threads; ++t_) { w.off[t_] = tot_b, tot_b += w.bytes[t_]; if (w.bytes[t_] > 0xfffffff0LL) fits = 0; }
+			if (fits && sink->try_reserve(sink->ctx, tot_b, &w.dst)) {
 				w.mode = 2;
 				mga_parallel_for(n_threads, n_threads, gaf_worker, &w);
 				sink->commit(sink->ctx, tot_b);

@@ -90,6 +90,7 @@ void mga_idx_mf_free(mg_idx_t *gi);
 
 typedef struct { const char *cg, *ds; int32_t cg_len, ds_len, mlen, blen; } mga_chain_text_t; /* cg == NULL: format from the chain itself */
 #define MGA_KS_WINDOW 0xffffffffu /* kstring_t::m of a window into another buffer: never reallocated, never NUL-terminated (gaf.c) */
+void mga_gaf_window_limit(size_t bytes); /* the calling thread's next window holds this many bytes: a write past it aborts before it happens (gaf.c) */
 void mga_write_gaf_append(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, int32_t n_seg, const int32_t *qlens, const char *qname, uint64_t flag,
 						  const mga_chain_text_t *txt);
 int mga_gaf_chain_rev(const gfa_t *g, const mg_gchains_t *gs, const mg_gchain_t *p, uint64_t flag);

@@ -54,18 +54,20 @@ def _exchange(ops):
         w.wait()
 
 
-def gather_bytes(payload, dst=0, device="cpu", as_tensors=False, pin=False):
+def gather_bytes(payload, dst=0, device="cpu", as_tensors=False, pin=False, fail_msg=None):
     """gather one byte string per rank to `dst`; returns the list in rank order on dst, None elsewhere.
     payload: bytes, or any C-contiguous uint8 buffer (e.g. the zero-copy numpy view of the library's GAF buffer).
     One all_gather of the sizes, then SIZE-EXACT point-to-point transfers (round 5): every rank sends exactly its bytes, the destination receives every
     part into a tensor of exactly that part's size -- nothing is padded to the largest payload and the destination holds every byte once.  With as_tensors=True the
     result stays on `device` (uint8 tensors, no host round trip)."""
     world, rank = dist.get_world_size(), dist.get_rank()
-    src = _as_u8(payload)
-    n = torch.tensor([src.size], dtype=torch.int64, device=device)
+    src = _as_u8(payload if payload is not None else b"")
+    n = torch.tensor([src.size if payload is not None else -1], dtype=torch.int64, device=device)   # payload None = "this rank failed": said in the one collective every rank is in
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n)
     sizes = [int(s.item()) for s in sizes]
+    if min(sizes) < 0:   # every rank raises, nobody is left waiting in a point-to-point transfer
+        raise RuntimeError("gather_bytes: rank(s) %s have nothing to send%s" % ([r for r in range(world) if sizes[r] < 0], (": " + fail_msg) if (payload is None and fail_msg) else ""))
     if rank != dst:
         if sizes[rank]:
             _exchange([dist.P2POp(dist.isend, _to_device(src, device, pin), dst)])
@@ -92,11 +94,12 @@ def gather_chains(gcs, n, dst=0):
     L.mga_free.argtypes = [C.c_void_p]
     buf = C.c_void_p()
     nb = L.mga_gchains_pack(n, gcs, C.byref(buf))
-    if nb < 0:
-        raise RuntimeError("mga_gchains_pack failed: %s" % L.mga_last_error().decode())
-    data = C.string_at(buf, nb)
-    L.mga_free(buf)
-    parts = gather_bytes(data, dst=dst)
+    if nb < 0:   # (a failure of ONE rank is raised on all of them, inside gather_bytes' size exchange)
+        data, msg = None, "mga_gchains_pack failed: %s" % L.mga_last_error().decode()
+    else:
+        data, msg = C.string_at(buf, nb), None
+        L.mga_free(buf)
+    parts = gather_bytes(data, dst=dst, fail_msg=msg)
     if parts is None:
         return None
     out = []
@@ -145,10 +148,11 @@ def ggen_map_sharded(graph, qlens, seqs, names, n_threads=8, dst=0, device="cpu"
     sq = (C.c_char_p * n)(*seqs)
     nm = (C.c_char_p * n)(*names)
     if L.mga_ggen_map_shard(graph.gi, n, ql, sq, nm, C.byref(graph.mo), n_threads, dist.get_rank(), dist.get_world_size(), C.byref(buf), C.byref(nb)) < 0:
-        raise RuntimeError("mga_ggen_map_shard failed: %s" % L.mga_last_error().decode())
-    data = C.string_at(buf, nb.value)
-    L.mga_free(buf)
-    parts = gather_bytes(data, dst=dst, device=device)
+        data, msg = None, "mga_ggen_map_shard failed: %s" % L.mga_last_error().decode()
+    else:
+        data, msg = C.string_at(buf, nb.value), None
+        L.mga_free(buf)
+    parts = gather_bytes(data, dst=dst, device=device, fail_msg=msg)
     return None if parts is None else ggen_assemble(parts, n)
 
 
@@ -182,15 +186,19 @@ def map_sharded(mapper, dst=0, device="cpu", as_tensor=False):
     seg_len = [int(x) for x in seg_len]
     n_seg = torch.tensor([len(seg_len)], dtype=torch.int64, device=device)
     dist.all_reduce(n_seg, op=dist.ReduceOp.MAX)
-    tab = torch.zeros(max(int(n_seg.item()), 1), dtype=torch.int64, device=device)
+    src = _as_u8(payload)
+    n_tab = max(int(n_seg.item()), 1)
+    tab = torch.zeros(n_tab + 1, dtype=torch.int64, device=device)   # the last word carries the payload's size: every rank can check every table
     if seg_len:
         tab[:len(seg_len)] = torch.tensor(seg_len, dtype=torch.int64)
+    tab[n_tab] = int(src.size)
     tabs = [torch.zeros_like(tab) for _ in range(world)]
     dist.all_gather(tabs, tab)
     tabs = [t.cpu().tolist() for t in tabs]
-    src = _as_u8(payload)
-    if sum(tabs[rank]) != src.size:
-        raise RuntimeError("map_sharded: rank %d's segment table sums to %d bytes, its payload has %d" % (rank, sum(tabs[rank]), src.size))
+    sizes = [int(t.pop()) for t in tabs]
+    bad = [r for r in range(world) if sum(tabs[r]) != sizes[r]]
+    if bad:   # a COLLECTIVE failure: every rank sees the same tables and raises before any point-to-point operation is posted (a lone raise would leave dst waiting in irecv)
+        raise RuntimeError("map_sharded: rank %d's segment table sums to %d bytes, its payload has %d" % (bad[0], sum(tabs[bad[0]]), sizes[bad[0]]))
     if rank != dst:   # this rank's pieces, in segment order (the order the destination posts its receives for this rank in)
         buf = _to_device(src, device, pin)
         ops, pos = [], 0
