@@ -20,6 +20,10 @@ order inside the timed region.  Extra keys: `resident` (the same rea
 Graph chaining + the gap list run on the host threads or on the device (the library picks by the host threads a rank has): `value` is the library's choice,
 `device_placement` / `host_placement` is the other one, timed the same way right after it, both compared byte for byte with the reference on every read of the sample.
 
+N = 1 also runs, after the headline, the other BASELINE configurations at their sizes, each compared byte for byte with the reference on the same box: `file_out` (the headline's step with the
+GAF written to a file, the interval of the CPU leg), `linear` / `bubble50` (configs[1] / configs[2]: 100 000 reads vs the 50 Mbp linear FASTA / 3-haplotype graph) and `asm`
+(configs[4] at one GPU's share: -cx asm, one ~98 Mbp contig per chromosome vs the 3 Gbp graph, then --call through the reference's own caller).
+
 Rank 0 prints ONE JSON line (metric / roofline / cpu_baseline); everything else goes to stderr.
 """
 import argparse
@@ -59,15 +63,9 @@ def cpu_baseline(ref_bin, graph, reads_fa, n_reads, out_dir, threads, cores):
     gaf, err = os.path.join(out_dir, "cpu.gaf"), os.path.join(out_dir, "cpu.log")
     with open(gaf, "wb") as fo, open(err, "w") as fe:
         subprocess.check_call([ref_bin, "-cx", "lr", "-t", str(threads), graph, sample], stdout=fo, stderr=fe)
-    ts = {}
-    for line in open(err):
-        m = re.match(r"\[M::(\w+)::([\d.]+)\*", line)
-        if m:
-            ts[m.group(1)] = float(m.group(2))
-    t_upd, t_map = ts.get("mg_opt_update"), ts.get("worker_pipeline")
+    dt, t_idx = ref_map_phase(err)
     bases = sum(len(l.strip()) for l in open(sample) if not l.startswith(">"))
-    dt = (t_map - t_upd) if (t_upd is not None and t_map is not None) else float("nan")
-    return dict(value=bases / dt / 1e9, unit="Gbp/s", cores=cores, kind="reference", index_s=round(ts.get("mg_index", 0) - ts.get("main", 0), 1),
+    return dict(value=bases / dt / 1e9, unit="Gbp/s", cores=cores, kind="reference", index_s=round(t_idx, 1),
                 sample="%d reads (%d bp) of the same workload, minigraph -cx lr -t %d on %d usable cores (affinity capped by the cgroup CPU quota), map phase only (worker_pipeline - mg_opt_update: FASTA parse + mapping + GAF write, as in `value`)" % (n, bases, threads, cores)), gaf, n
 
 
@@ -81,13 +79,37 @@ def kernel_src_sha1():
     return h.hexdigest()
 
 
-def asm_block(mga, d, genome, threads, ref_bin):
-    """`-cx asm`: ten contigs of genome/10 bp (0.1 %% divergence from the haplotype walks) against a 3-haplotype bubble graph of `genome` backbone bp in 10 chromosomes;
-    the whole job file -> file (GFA parse, index, mapping, GAF) here and in the unmodified reference on the same cores; the two GAF files must be the same bytes."""
+def ref_map_phase(log_path):
+    """seconds of the reference's mapping phase (worker_pipeline - mg_opt_update: SURVEY 8d) and of its graph load + index, from its own log lines"""
+    ts = {}
+    for line in open(log_path):
+        m = re.match(r"\[M::(\w+)::([\d.]+)\*", line)
+        if m:
+            ts[m.group(1)] = float(m.group(2))
+    t_upd, t_map = ts.get("mg_opt_update"), ts.get("worker_pipeline")
+    return ((t_map - t_upd) if (t_upd is not None and t_map is not None) else float("nan")), ts.get("mg_opt_update", float("nan"))
+
+
+def asm_block(mga, d, wl, graph_path, threads, ref_bin, dropin_bin, n_contig=0, small_genome=0):
+    """BASELINE configs[4] at ONE GPU's share: `-cx asm` on chromosome-scale contigs (one per chromosome, 0.1 %% divergence from a haplotype walk) against the SAME 3 Gbp graph the
+    headline maps reads against; the whole job file -> file (GFA parse, index, mapping, GAF) here and in the unmodified reference on the same cores: the two GAF files must be the same
+    bytes.  Then `--call` (ggen.c:128-139 -> mg_call_asm, asm-call.c:21): the reference's own front end linked against THIS library (oracle/_ref/minigraph_dropin: its ggen.c / asm-call.c
+    consuming our mg_gchains_t) against the all-reference binary: the two BED files must be the same bytes.
+    --asm-genome N (N > 0): a smaller self-made graph of N backbone bp in 10 chromosomes with 10 contigs (quick runs)."""
     pre = os.path.join(d, "asm")
-    contig = genome // 10
-    subprocess.run([mga.MGSIM, "-p", pre, "-G", str(genome), "-c", "10", "-H", "3", "-n", "10", "-l", str(contig), "-e", "0.001", "-s", "5"], stderr=subprocess.DEVNULL, check=True)
-    g, r, got, ref = pre + ".gfa", pre + ".reads.fa", pre + ".got.gaf", pre + ".ref.gaf"
+    if small_genome > 0:
+        genome, n_chr, hap, n = small_genome, 10, 3, 10
+        contig = genome // 10
+        subprocess.run([mga.MGSIM, "-p", pre, "-G", str(genome), "-c", "10", "-H", "3", "-n", "10", "-l", str(contig), "-e", "0.001", "-s", "5"], stderr=subprocess.DEVNULL, check=True)
+        g = pre + ".gfa"
+    else:   # the headline's graph (same -G -c -H -s => the same bytes; -R: only the contigs are written), contigs from their own stream
+        genome, n_chr, hap = wl["genome"], wl["chr"], wl["hap"]
+        n = n_contig or n_chr
+        contig = genome // n_chr - 1000
+        subprocess.run([mga.MGSIM, "-R", "-p", pre, "-G", str(genome), "-c", str(n_chr), "-H", str(hap), "-s", "11", "-S", "5", "-n", str(n), "-l", str(contig), "-e", "0.001"], stderr=subprocess.DEVNULL, check=True)
+        g = graph_path
+    r, got, ref, got_bed, ref_bed, log_ = pre + ".reads.fa", pre + ".got.gaf", pre + ".ref.gaf", pre + ".got.bed", pre + ".ref.bed", pre + ".ref.log"
+    q_bp = sum(len(l) - 1 for l in open(r) if not l.startswith(">"))
     try:
         mga.load().mga_rq_dev_stats((ctypes.c_int64 * 8)(), 1)
     except Exception:
@@ -95,10 +117,11 @@ def asm_block(mga, d, genome, threads, ref_bin):
     t0 = time.time()
     mga.map_files(g, [r], got, preset="asm", cigar=True, n_threads=threads, verbose=0)
     t_ours = time.time() - t0
-    out = dict(workload="-cx asm: 10 contigs x %d bp (%.0f Mbp of query, 0.1%% divergence) vs a %.0f Mbp-backbone 3-haplotype bubble graph in 10 chromosomes" % (contig, contig * 10 / 1e6, genome / 1e6),
-               interval="file -> file: GFA parse + index + mapping + GAF, on both sides", seconds=round(t_ours, 2), query_Mbp_per_s=round(contig * 10 / 1e6 / t_ours, 1),
+    out = dict(workload="configs[4] shape at one GPU's share: -cx asm, %d contigs x %.1f Mbp (%.2f Gbp of query, 0.1%% divergence from the haplotype walks) vs the %.2f Gbp-backbone %d-haplotype bubble graph in %d chromosomes%s"
+                        % (n, contig / 1e6, q_bp / 1e9, genome / 1e9, hap, n_chr, "" if small_genome > 0 else " (the headline's graph)"),
+               interval="file -> file: GFA parse + index + mapping + GAF, on both sides", seconds=round(t_ours, 2), query_Mbp_per_s=round(q_bp / 1e6 / t_ours, 1),
                gaf_bytes=os.path.getsize(got), host_threads=threads,
-               note="round 5: the forward passes of the primary chainer under -x asm (mg_lchain_rmq, lchain.c:252-357) run on the device, a wavefront per (segment, strand) run (k_rmq.hip); "
+               note="the forward passes of the primary chainer under -x asm (mg_lchain_rmq, lchain.c:252-357) run on the device, a wavefront per (segment, strand) run (k_rmq.hip); "
                     "its anchor sort (klib's exact permutation) and backtrack on the host threads; sketch, seeds, WFA and text on the device")
     try:   # which runs of the RMQ chainer the device took, and which it handed back to the host's exact tree (tied priorities / inner window beyond the kernel's sort / too long)
         st_rq = (ctypes.c_int64 * 8)()
@@ -114,12 +137,68 @@ def asm_block(mga, d, genome, threads, ref_bin):
         out["reference_seconds"] = round(t_ref, 2)
         out["vs_reference"] = round(t_ref / t_ours, 2)
         out["parity"] = "GAF byte-identical to the reference" if subprocess.call(["cmp", "-s", got, ref]) == 0 else "MISMATCH vs reference GAF"
-    for f in (g, r, got, ref, pre + ".lin.fa"):
+        if dropin_bin and os.path.exists(dropin_bin):   # --call: BED of the reference's own caller on OUR chains vs on its own
+            t0 = time.time()
+            with open(got_bed, "wb") as fo:
+                rc = subprocess.run([dropin_bin, "-cx", "asm", "--call", "-t", str(threads), g, r], stdout=fo, stderr=subprocess.DEVNULL).returncode
+            t_call = time.time() - t0
+            t0 = time.time()
+            with open(ref_bed, "wb") as fo, open(log_, "w") as fe:
+                subprocess.run([ref_bin, "-cx", "asm", "--call", "-t", str(threads), g, r], stdout=fo, stderr=fe, check=True)
+            t_call_ref = time.time() - t0
+            out["call"] = dict(seconds=round(t_call, 2), reference_seconds=round(t_call_ref, 2), vs_reference=round(t_call_ref / max(t_call, 1e-9), 2), bed_bytes=os.path.getsize(ref_bed),
+                               command="minigraph -cx asm --call: main.c / ggen.c / asm-call.c / gfa-bbl.c of the reference linked against libminigraph_amd.so (oracle/_ref/minigraph_dropin, mg_map_batch patch of INTEGRATION.md 1b) vs the unmodified binary")
+            out["call_parity"] = ("BED byte-identical to the reference (%d bytes)" % os.path.getsize(ref_bed)) if (rc == 0 and os.path.getsize(ref_bed) > 0 and subprocess.call(["cmp", "-s", got_bed, ref_bed]) == 0) \
+                else "MISMATCH vs reference BED (dropin exit code %d)" % rc
+        else:
+            out["call_parity"] = "not run: oracle/_ref/minigraph_dropin absent"
+    for f in (r, got, ref, got_bed, ref_bed, log_, pre + ".lin.fa") + ((pre + ".gfa",) if small_genome > 0 else ()):
         try:
             os.remove(f)
         except OSError:
             pass
     return out
+
+
+def small_configs_block(mga, d, threads, ref_bin, n_reads, genome):
+    """BASELINE configs[1] and configs[2] at their sizes on one GPU: the SAME n_reads x 10 kb reads (a) vs the 50 Mbp backbone as a linear FASTA -- ONE segment of 50 Mbp, `-x lr`
+    without base alignment (minimap2-like) -- and (b) vs the 50 Mbp 3-haplotype bubble graph, `-cx lr`.  Graph load + index outside the interval on both sides (our index_s / the
+    reference's up to mg_opt_update), mapping phase file -> GAF FILE on both sides; the GAF files must be the same bytes."""
+    pre = os.path.join(d, "c12")
+    subprocess.run([mga.MGSIM, "-p", pre, "-G", str(genome), "-c", "1", "-H", "3", "-n", str(n_reads), "-s", "11"], stderr=subprocess.DEVNULL, check=True)
+    rd = pre + ".reads.fa"
+    bases = sum(len(l) - 1 for l in open(rd) if not l.startswith(">"))
+    res = {}
+    for key, graph, cigar, what in (("linear", pre + ".lin.fa", False, "configs[1]: %d x 10kb reads vs a %.0f Mbp linear FASTA (one segment), -x lr" % (n_reads, genome / 1e6)),
+                                    ("bubble50", pre + ".gfa", True, "configs[2]: the same reads vs the %.0f Mbp-backbone 3-haplotype bubble graph, -cx lr" % (genome / 1e6))):
+        got, ref, log_ = pre + "." + key + ".got.gaf", pre + "." + key + ".ref.gaf", pre + "." + key + ".ref.log"
+        t0 = time.time()
+        G = mga.Graph(graph, preset="lr", cigar=cigar, n_threads=threads)
+        t_idx = time.time() - t0
+        mga.map_files_idx(G, [rd], n_threads=threads, out_path=got)   # (warm-up: pipeline contexts, buffers)
+        t_map = mga.map_files_idx(G, [rd], n_threads=threads, out_path=got)
+        G.close()
+        o = dict(workload=what, value=bases / t_map / 1e9, unit="Gbp/s", map_seconds=round(t_map, 3), index_s=round(t_idx, 2), gaf_bytes=os.path.getsize(got),
+                 interval="FASTA file -> GAF file, mapping phase (graph load + index outside, on both sides)")
+        if ref_bin and os.path.exists(ref_bin):
+            with open(ref, "wb") as fo, open(log_, "w") as fe:
+                subprocess.run([ref_bin] + (["-c"] if cigar else []) + ["-x", "lr", "-t", str(threads), graph, rd], stdout=fo, stderr=fe, check=True)
+            t_ref, t_ref_idx = ref_map_phase(log_)
+            o["reference"] = dict(value=bases / t_ref / 1e9, unit="Gbp/s", map_seconds=round(t_ref, 2), index_s=round(t_ref_idx, 2))
+            o["vs_reference"] = round(t_ref / t_map, 1)
+            o["parity"] = ("GAF byte-identical to the reference on all %d reads (%d bytes)" % (n_reads, os.path.getsize(ref))) if subprocess.call(["cmp", "-s", got, ref]) == 0 else "MISMATCH vs reference GAF"
+        res[key] = o
+        for f in (got, ref, log_):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+    for f in (rd, pre + ".lin.fa", pre + ".gfa"):
+        try:
+            os.remove(f)
+        except OSError:
+            pass
+    return res
 
 
 def usable_cores():
@@ -166,8 +245,13 @@ def main():
     ap.add_argument("--threads", type=int, default=0, help="host threads per rank (0: min(64, usable cores / ranks))")
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--workdir", default=None, help="keep the synthetic workload (graph, reads, graph image) in this directory and reuse it when it is already there (sweeps of several bench runs in one session)")
-    ap.add_argument("--no-asm", action="store_true", help="N=1: skip the `asm` block (BASELINE configs[4] shape: -cx asm, 10 x 50 Mbp contigs vs a 500 Mbp graph, file -> file next to the reference)")
-    ap.add_argument("--asm-genome", type=int, default=500000000)
+    ap.add_argument("--no-asm", action="store_true", help="N=1: skip the `asm` block (BASELINE configs[4] at one GPU's share: -cx asm, one ~98 Mbp contig per chromosome vs the headline's 3 Gbp graph, file -> file next to the reference, then --call)")
+    ap.add_argument("--asm-genome", type=int, default=0, help="asm block on a self-made graph of this many backbone bp (10 chromosomes, 10 contigs) instead of the headline's graph (quick runs)")
+    ap.add_argument("--asm-contigs", type=int, default=0, help="asm block: contigs (default: one per chromosome)")
+    ap.add_argument("--no-small", action="store_true", help="N=1: skip the `linear` / `bubble50` blocks (BASELINE configs[1] / configs[2]: 100 000 reads vs the 50 Mbp linear FASTA / 3-haplotype graph)")
+    ap.add_argument("--small-reads", type=int, default=100000)
+    ap.add_argument("--small-genome", type=int, default=50000000)
+    ap.add_argument("--no-file-out", action="store_true", help="N=1: skip the `file_out` leg (the headline's step with the GAF written to a FILE by the library's writer thread, as the CPU leg writes it)")
     ap.add_argument("--no-rank-share", action="store_true", help="N=1: skip the `rank_share` block (device placement with the process pinned to 1/8 of the usable cores)")
     ap.add_argument("--share", type=int, default=8, help="rank_share: the node's ranks the usable cores are divided among")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1: nccl (= RCCL over xGMI, the default) or gloo (host tensors: lets one GPU box run 2 ranks on the same device to test the sharded path)")
@@ -272,8 +356,12 @@ def main():
 
     nthr = [threads]   # (the rank_share block runs the same step with a rank's share of the threads)
 
+    fout = [None]      # (the file_out leg: the same step with the GAF going to this file through the library's writer thread)
+
     def step():
-        if dist is None:   # (the output buffer of the previous step is handed back for reuse, like a writer thread would recycle its buffers)
+        if dist is None and fout[0]:
+            mga.map_files_idx(G, [reads_path], n_threads=nthr[0], out_path=fout[0])
+        elif dist is None:   # (the output buffer of the previous step is handed back for reuse, like a writer thread would recycle its buffers)
             last["gaf"] = mga.map_files_idx(G, [reads_path], n_threads=nthr[0], reuse=last.get("gaf"))
         elif args.no_gather:
             last["gaf"] = mga.map_files_idx(G, [reads_path], n_threads=threads, rank=rank, world=world, reuse=last.get("gaf"))
@@ -328,8 +416,16 @@ def main():
     if args.placement != "auto":
         os.environ["MGA_DEV_GCHAIN"] = "1" if default_dev else "0"
     dt, st, host_main = timed(args.warmup, args.steps)
-    os.environ.pop("MGA_DEV_GCHAIN", None)
     gaf_main = last_gaf()
+    file_out = None
+    if dist is None and not args.no_file_out:   # SURVEY 8d asks for the same interval on both sides: the reference's step 2 writes its GAF to a file (gmap.c:119-139), so does this leg
+        fout[0] = os.path.join(d, "gpu.gaf")
+        k_fo = max(1, min(args.steps, 3))
+        dt_f, st_f, host_f = timed(1, k_fo)
+        file_out = dict(value=st_f["n_bases"] / dt_f / 1e9, unit="Gbp/s", ms_per_step=dt_f / k_fo * 1e3, steps=k_fo, warmup=1, path=fout[0], **host_f,
+                        note="the headline's step with the GAF written to a file by the library's writer thread (fwrite per mini-batch, overlapped with the mapping of the next ones), as the CPU leg's stdout goes to a file")
+        fout[0] = None
+    os.environ.pop("MGA_DEV_GCHAIN", None)
     other = None
     if not args.one_placement:
         os.environ["MGA_DEV_GCHAIN"] = "0" if default_dev else "1"
@@ -606,18 +702,53 @@ def main():
                 if other is not None and other["gaf"] is not None:
                     res["host_placement" if default_dev else "device_placement"]["parity"] = \
                         ("GAF byte-identical to the reference on ALL %d reads of the CPU sample (%d bytes)" % (n_cpu, len(want))) if same(other["gaf"]) else "MISMATCH vs reference GAF"
+                if file_out is not None:
+                    fo_path = file_out.pop("path")
+                    if n_cpu >= args.reads:   # whole files, compared as files
+                        file_out["parity"] = ("GAF file byte-identical to the reference's (%d bytes)" % len(want)) if subprocess.call(["cmp", "-s", fo_path, cpu_gaf]) == 0 else "MISMATCH vs reference GAF file"
+                    else:
+                        with open(fo_path, "rb") as fi:
+                            file_out["parity"] = ("GAF file byte-identical to the reference on the %d reads of the CPU sample" % n_cpu) if same(fi.read(len(want) + 1)) else "MISMATCH vs reference GAF file"
+                del want
             except Exception as e:  # the baseline is a reported number, never a reason to lose the bench line
                 res["cpu_baseline"] = dict(value=None, unit="Gbp/s", cores=quota, kind="reference", sample="failed: %r" % (e,))
         else:
             res["cpu_baseline"] = dict(value=None, unit="Gbp/s", cores=quota, kind="reference",
                                        sample="not run (--no-cpu, or oracle/_ref/minigraph absent)")
-        if dist is None and not args.no_asm:   # ---- BASELINE configs[4] shape on one GPU: -cx asm on chromosome-scale contigs, file -> file, graph load + index on both sides ----
+        if file_out is not None:
+            file_out.pop("path", None)
+            res["file_out"] = file_out
+        if dist is None and not (args.no_asm and args.no_small):
+            # the other BASELINE configs, each at its size, each compared with the reference: the headline's index and buffers are released first (host and HBM are free for
+            # the jobs below, which load their own graphs like any file -> file job does)
+            gaf_first = share_gaf = gaf_main = None
+            if other is not None:
+                other["gaf"] = None
+            last.clear()
+            G.close()
+            G = None
+            import gc
+            gc.collect()
+            if not args.workdir and not args.keep:   # the headline's files are not needed any more (the asm block maps against the graph's GFA text only)
+                for f in (reads_path, img_path, os.path.join(d, "cpu.gaf"), os.path.join(d, "gpu.gaf"), os.path.join(d, "cpu_sample.fa")):
+                    try:
+                        os.remove(f)
+                    except OSError:
+                        pass
+        if dist is None and not args.no_small:   # ---- BASELINE configs[1], configs[2] at their sizes ----
             try:
-                res["asm"] = asm_block(mga, d, args.asm_genome, threads, None if args.no_cpu else ref_bin)
+                res.update(small_configs_block(mga, d, threads, None if args.no_cpu else ref_bin, args.small_reads, args.small_genome))
+            except Exception as e:
+                res["linear"] = dict(error=repr(e))
+        if dist is None and not args.no_asm:   # ---- BASELINE configs[4] at one GPU's share: -cx asm on chromosome-scale contigs vs the 3 Gbp graph, file -> file, then --call ----
+            try:
+                res["asm"] = asm_block(mga, d, dict(genome=args.genome, chr=args.chr, hap=args.hap), graph_path, threads, None if args.no_cpu else ref_bin,
+                                       os.path.join(ROOT, "oracle", "_ref", "minigraph_dropin"), n_contig=args.asm_contigs, small_genome=args.asm_genome)
             except Exception as e:
                 res["asm"] = dict(error=repr(e))
         print(json.dumps(res), flush=True)
-    G.close()
+    if G is not None:
+        G.close()
     if dist is not None:
         dist.barrier()
     if rank == 0 and not args.keep and not args.workdir:

@@ -303,14 +303,28 @@ class MappedGaf:
             pass
 
 
-def map_files_idx(graph, read_paths, n_threads=8, rank=0, world=1, reuse=None):
+def map_files_idx(graph, read_paths, n_threads=8, rank=0, world=1, reuse=None, out_path=None):
     """the mapping phase of mg_map_files() against an existing index: FASTA/FASTQ files -> GAF text in memory (MappedGaf).
     world > 1: this process maps shard `rank` (see mga_map_files_shard in include/minigraph_amd.h); .seg_len lists its bytes per
     output segment, .t_map is the wall time of the phase (reader + pipeline + sink) measured inside the library.
-    reuse: a MappedGaf of an earlier call whose buffer may be overwritten (it is consumed)."""
+    reuse: a MappedGaf of an earlier call whose buffer may be overwritten (it is consumed).
+    out_path: the GAF goes to this FILE through the library's writer thread (the reference's step 2, gmap.c:119-139) instead of a buffer; returns the seconds of the phase."""
     L = load()
     fns = (C.c_char_p * len(read_paths))(*[p.encode() for p in read_paths])
     mem, n, cap, seg, nseg, t = C.c_void_p(), C.c_int64(0), C.c_int64(0), C.c_void_p(), C.c_int(0), C.c_double(0.0)
+    if out_path is not None:
+        libc = C.CDLL(None)
+        libc.fopen.restype, libc.fopen.argtypes, libc.fclose.argtypes = C.c_void_p, [C.c_char_p, C.c_char_p], [C.c_void_p]
+        fp = libc.fopen(out_path.encode(), b"wb")
+        if not fp:
+            raise OSError("cannot open %s" % out_path)
+        try:
+            _check(L.mga_map_files_shard(graph.gi, len(read_paths), fns, C.byref(graph.mo), n_threads, rank, world, C.c_void_p(fp),
+                                         None, None, None, C.byref(seg), C.byref(nseg), C.byref(t)), "mga_map_files_shard")
+        finally:
+            libc.fclose(fp)
+        L.mga_free(seg)
+        return t.value
     if reuse is not None and reuse.ptr is not None and reuse.ptr.value and reuse.cap > 0:
         mem, cap = reuse.ptr, C.c_int64(reuse.cap)
         reuse.ptr, reuse.n = None, 0

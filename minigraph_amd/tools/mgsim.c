@@ -2,7 +2,7 @@
  * mgsim -- deterministic synthetic workload generator for the mapping benchmark.
  *
  *   mgsim -p PREFIX [-G backbone_bp] [-c n_chr] [-H n_hap] [-n n_reads] [-l read_len]
- *         [-e err] [-s seed]
+ *         [-e err] [-s seed] [-S read_seed] [-R]
  *
  * writes
  *   PREFIX.lin.fa    backbone "chromosomes" as FASTA (config: linear reference, no graph)
@@ -68,13 +68,14 @@ int main(int argc, char *argv[])
 	int n_chr = 1, H = 3, c, h;
 	double err = 0.10;
 	uint64_t seed = 11, read_seed = 0;
+	int reads_only = 0;
 	const char *prefix = 0;
 	char fn[4096];
 	FILE *fgfa, *flin, *frd;
 	str_t *hap; /* hap[h*n_chr + c] */
 	int64_t seg_id = 0, tot_graph = 0, n_bub = 0;
 
-	while ((c = getopt(argc, argv, "p:G:c:H:n:l:e:s:S:")) >= 0) {
+	while ((c = getopt(argc, argv, "p:G:c:H:n:l:e:s:S:R")) >= 0) {
 		if (c == 'p') prefix = optarg;
 		else if (c == 'G') G = atoll(optarg);
 		else if (c == 'c') n_chr = atoi(optarg);
@@ -84,14 +85,15 @@ int main(int argc, char *argv[])
 		else if (c == 'e') err = atof(optarg);
 		else if (c == 's') seed = strtoull(optarg, 0, 10);
 		else if (c == 'S') read_seed = strtoull(optarg, 0, 10);
+		else if (c == 'R') reads_only = 1; /* the graph of (-G -c -H -s) exists already: write PREFIX.reads.fa only (more reads / other reads, with -S, against one graph) */
 	}
 	if (prefix == 0 || H < 1 || n_chr < 1) {
-		fprintf(stderr, "Usage: mgsim -p PREFIX [-G bp=2000000] [-c n_chr=1] [-H n_hap=3] [-n n_reads=1000] [-l read_len=10000] [-e err=0.1] [-s seed=11] [-S read_seed]\n");
+		fprintf(stderr, "Usage: mgsim -p PREFIX [-G bp=2000000] [-c n_chr=1] [-H n_hap=3] [-n n_reads=1000] [-l read_len=10000] [-e err=0.1] [-s seed=11] [-S read_seed] [-R (reads only)]\n");
 		return 1;
 	}
 	rng_seed(seed);
-	snprintf(fn, sizeof fn, "%s.gfa", prefix);      fgfa = fopen(fn, "w");
-	snprintf(fn, sizeof fn, "%s.lin.fa", prefix);   flin = fopen(fn, "w");
+	snprintf(fn, sizeof fn, "%s.gfa", prefix);      fgfa = fopen(reads_only ? "/dev/null" : fn, "w");
+	snprintf(fn, sizeof fn, "%s.lin.fa", prefix);   flin = fopen(reads_only ? "/dev/null" : fn, "w");
 	snprintf(fn, sizeof fn, "%s.reads.fa", prefix); frd  = fopen(fn, "w");
 	if (!fgfa || !flin || !frd) { perror("fopen"); return 1; }
 	hap = (str_t*)calloc((size_t)H * n_chr, sizeof(str_t));

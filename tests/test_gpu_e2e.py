@@ -62,6 +62,25 @@ def test_synthetic_vs_reference_binary(cigar, target):
         raise AssertionError(first_diff(ref_out, got))
 
 
+@pytest.mark.parametrize("cigar", [False, True])
+def test_single_segment_of_50_Mbp_vs_reference_binary(cigar):
+    """BASELINE configs[1] at its target size: a 50 Mbp linear FASTA is ONE segment of 50 Mbp (gfa-io.c:311-322) -- one k_sketch work list of ~800 pieces for the index build, positions
+    beyond 2^25 in every anchor, a 50 MB row of the segment images; 3 000 reads (a tenth of them from alt alleles the linear reference does not have) with and without base alignment"""
+    need_ref()
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "50000000", "-c", "1", "-H", "3", "-n", "3000", "-s", "11"], stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t.lin.fa"), os.path.join(d, "t.reads.fa")
+    assert sum(1 for l in open(graph) if l.startswith(">")) == 1 and os.path.getsize(graph) > 50000000
+    ref_out, got = os.path.join(d, "ref.gaf"), os.path.join(d, "got.gaf")
+    run_ref((["-c"] if cigar else []) + ["-x", "lr", "-t", "8", graph, reads], ref_out)
+    mga.map_files(graph, [reads], got, cigar=cigar, n_threads=8)
+    if open(ref_out, "rb").read() != open(got, "rb").read():
+        raise AssertionError(first_diff(ref_out, got))
+    assert os.path.getsize(got) > 3000 * (2000 if cigar else 80)
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
+
+
 def test_long_join_rescue_on_device_matches_host_tree_and_reference(monkeypatch):
     """the RMQ rescue (map-algo.c:407-417) runs inside k_lchain; the sequential AVL tree on the host (MGA_HOST_RESCUE=1)
     and the reference binary must give the same bytes, and the device path must actually have been taken"""
