@@ -11,17 +11,20 @@
 /* A kstring_t whose capacity says MGA_KS_WINDOW is a WINDOW into somebody else's buffer (round 5: a chunk's GAF lines written straight to their place in the job's output,
  * mapper.c): it is never reallocated and never NUL-terminated -- the byte behind a piece belongs to the next piece, which another thread may be writing. */
 #define KS_TERM(s) do { if ((s)->m != MGA_KS_WINDOW) (s)->s[(s)->l] = 0; } while (0)
-static __thread size_t ks_win_limit = 0; /* bytes the calling thread's current window holds (mga_gaf_window_limit): a write past it would land in the next thread's piece */
+static __thread size_t ks_win_limit = 0; /* bytes the calling thread's current window holds (mga_gaf_window_limit): a write past it lands in the next thread's piece */
 void mga_gaf_window_limit(size_t bytes) { ks_win_limit = bytes; }
+static void ks_win_overrun(const char *where, size_t at, size_t n)
+{ /* the measuring pass and the writing pass run the same formatter: cannot happen, and must not go unnoticed */
+	fprintf(stderr, "[E::%s] GAF window of %zu bytes overrun at %zu + %zu\n", where, ks_win_limit, at, n);
+	abort();
+}
+/* window mode: the formatter reserves UPPER BOUNDS (ks_room) and then writes raw, so a window is checked where sizes are exact -- before the one large copy of a line (the
+ * device's cg / ds text: KS_FITS) and right after every raw block (KS_WROTE: an overrun is at most one line header old when the process stops) */
+#define KS_FITS(s, n) do { if ((s)->m == MGA_KS_WINDOW && (size_t)(s)->l + (size_t)(n) > ks_win_limit) ks_win_overrun(__func__, (s)->l, (n)); } while (0)
+#define KS_WROTE(s) do { if ((s)->m == MGA_KS_WINDOW && (size_t)(s)->l > ks_win_limit) ks_win_overrun(__func__, (s)->l, 0); } while (0)
 static inline void ks_room(kstring_t *s, size_t extra)
 {
-	if (s->m == MGA_KS_WINDOW) {
-		if ((size_t)s->l + extra > ks_win_limit) { /* the measuring pass and the writing pass run the same formatter: cannot happen, and must stop BEFORE the neighbour's bytes are touched */
-			fprintf(stderr, "[E::%s] GAF window of %zu bytes overrun at %u + %zu\n", __func__, ks_win_limit, s->l, extra);
-			abort();
-		}
-		return;
-	}
+	if (s->m == MGA_KS_WINDOW) return; /* (never grown: see KS_FITS / KS_WROTE) */
 	if (s->l + extra + 1 > s->m) {
 		size_t m = s->l + extra + 1;
 		if (m > 0xfffffff0u) { /* kstring_t (mgpriv.h:31-37) counts in 32 bits: fail loudly instead of wrapping.  A piece is one thread's share of a 16384-read chunk;
@@ -176,7 +179,7 @@ void mga_write_gaf_append(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, 
 			memcpy(w, qname, qn); w += qn;
 			w = put_tab_d(w, qlen);
 			w = put_s(w, "\t0\t0\t*\t*\t0\t0\t0\t0\t0\t0\n");
-			s->l = (unsigned)(w - s->s); KS_TERM(s);
+			s->l = (unsigned)(w - s->s); KS_WROTE(s); KS_TERM(s);
 		}
 		return;
 	}
@@ -223,9 +226,11 @@ void mga_write_gaf_append(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, 
 			for (j = 0; j < n_seg; ++j) { *w++ = ','; w = put_d(w, qlens[j]); }
 		}
 		s->l = (unsigned)(w - s->s);
+		KS_WROTE(s);
 		/* the alignment: text from the device (both strings already in print order), or from the chain's own CIGAR / difference string */
 		if (tx) {
 			ks_room(s, (size_t)tx->cg_len + (size_t)tx->ds_len + 16);
+			KS_FITS(s, (size_t)tx->cg_len + (size_t)tx->ds_len + 12);
 			w = s->s + s->l;
 			w = put_s(w, "\tcg:Z:"); memcpy(w, tx->cg, (size_t)tx->cg_len); w += tx->cg_len;
 			w = put_s(w, "\tds:Z:"); memcpy(w, tx->ds, (size_t)tx->ds_len); w += tx->ds_len;
@@ -262,6 +267,7 @@ void mga_write_gaf_append(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, 
 				s->l = (unsigned)(w - s->s);
 			}
 		}
+		KS_FITS(s, 1);
 		ks_c(s, '\n');
 		if ((mg_dbg_flag & 0x8) || (flag & MG_M_WRITE_LCHAIN)) { /* one line per vertex of the walk, -S / --write-mz (format.c:252-289) */
 			for (j = 0; j < p->cnt; ++j) {
@@ -294,6 +300,7 @@ void mga_write_gaf_append(kstring_t *s, const gfa_t *g, const mg_gchains_t *gs, 
 				}
 				*w++ = '\n';
 				s->l = (unsigned)(w - s->s);
+				KS_WROTE(s);
 			}
 			KS_TERM(s);
 		}

@@ -10,20 +10,20 @@ tag=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 ulimit -c 0
 WDA=${PROF_WORKDIR:+--workdir $PROF_WORKDIR}   # PROF_WORKDIR=<dir>: the synthetic workload (graph, reads, graph image) is generated once and reused by every run below
-B="python bench.py --steps 1 --warmup 1 --no-cpu --resident-steps 0 --one-placement --no-asm --no-rank-share $WDA"
+B="python bench.py --steps 1 --warmup 1 --no-cpu --resident-steps 0 --one-placement --no-asm --no-small --no-file-out --no-rank-share $WDA"
 out=gpurun_out
 parts=${PROF_PARTS:-iso pipe dev pmc sq}   # PROF_PARTS="iso pmc": a subset (each part is one or two bench runs under rocprofv3, about 70 s each)
 has() { case " $parts " in *" $1 "*) return 0;; esac; return 1; }
 has iso && {
-MGA_PIPE=1 MGA_WFA_SIDE=0 bash minigraph_amd/tools/prof_trace.sh ${tag}_iso MGA_PIPE=1 MGA_WFA_SIDE=0 -- --steps 1 --warmup 1 --no-cpu --resident-steps 0 --one-placement --no-asm --no-rank-share $WDA > /dev/null 2>&1
+MGA_PIPE=1 MGA_WFA_SIDE=0 bash minigraph_amd/tools/prof_trace.sh ${tag}_iso MGA_PIPE=1 MGA_WFA_SIDE=0 -- --steps 1 --warmup 1 --no-cpu --resident-steps 0 --one-placement --no-asm --no-small --no-file-out --no-rank-share $WDA > /dev/null 2>&1
 mv $out/${tag}_iso_kernel_stats.txt $out/${tag}_kernel_stats_isolated.txt
 }
 has pipe && {
-bash minigraph_amd/tools/prof_trace.sh ${tag}_pipe -- --steps 2 --warmup 1 --no-cpu --resident-steps 0 --one-placement --no-asm --no-rank-share $WDA > /dev/null 2>&1
+bash minigraph_amd/tools/prof_trace.sh ${tag}_pipe -- --steps 2 --warmup 1 --no-cpu --resident-steps 0 --one-placement --no-asm --no-small --no-file-out --no-rank-share $WDA > /dev/null 2>&1
 mv $out/${tag}_pipe_kernel_stats.txt $out/${tag}_kernel_stats_pipelined.txt
 }
 has dev && {
-bash minigraph_amd/tools/prof_trace.sh ${tag}_dev MGA_PIPE=1 MGA_WFA_SIDE=0 -- --steps 1 --warmup 1 --no-cpu --resident-steps 0 --one-placement --no-asm --no-rank-share --threads 8 $WDA > /dev/null 2>&1
+bash minigraph_amd/tools/prof_trace.sh ${tag}_dev MGA_PIPE=1 MGA_WFA_SIDE=0 -- --steps 1 --warmup 1 --no-cpu --resident-steps 0 --one-placement --no-asm --no-small --no-file-out --no-rank-share --threads 8 $WDA > /dev/null 2>&1
 mv $out/${tag}_dev_kernel_stats.txt $out/${tag}_kernel_stats_devchain_isolated.txt
 }
 has pmc && {
