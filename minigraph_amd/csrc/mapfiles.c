@@ -577,6 +577,46 @@ typedef struct { FILE *fp; int to_mem; char *mem; int64_t mem_len, mem_cap; int6
 typedef struct { char *buf; int64_t len, cap; fbatch_t *fb; int seg; } wbuf_t;
 typedef struct { sink_t *sink; chan_t *in; pthread_mutex_t *pool_m; wbuf_t **pool; int *n_pool; volatile int err; } writer_t;
 
+/* A mini-batch's GAF text (hundreds of MB) into a REGULAR file: slices of it by several threads with pwrite() at their final offsets -- filling fresh page-cache pages is
+ * ~2 GB/s per thread ([measured, round 6] one fwrite per mini-batch made the writer the job's bottleneck: 518 ms per 1.1 GB step against 310 ms of mapping).  Pipes and
+ * terminals take the plain fwrite. */
+typedef struct { int fd; const char *buf; int64_t len, off; int err; } wslice_t;
+static void *wslice_main(void *a)
+{
+	wslice_t *x = (wslice_t*)a;
+	int64_t done = 0;
+	while (done < x->len) {
+		const ssize_t k = pwrite(x->fd, x->buf + done, (size_t)(x->len - done), (off_t)(x->off + done));
+		if (k <= 0) { x->err = 1; break; }
+		done += k;
+	}
+	return 0;
+}
+static int write_parallel(FILE *fp, const char *buf, int64_t len)
+{
+	enum { NW = 4 };
+	struct stat st;
+	const int fd = fileno(fp);
+	off_t at;
+	wslice_t sl[NW];
+	pthread_t th[NW];
+	int k, bad = 0;
+	static int64_t min_len = -1; /* MGA_PWRITE_MIN=<bytes>: the tests push small outputs through this path */
+	if (min_len < 0) { const char *e = getenv("MGA_PWRITE_MIN"); min_len = e && *e ? atoll(e) : (64 << 20); }
+	if (len < min_len || len < NW || fd < 0 || fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) return -1;
+	if (fflush(fp) != 0 || (at = lseek(fd, 0, SEEK_CUR)) < 0) return -1; /* (the stream's buffer is empty now: its position is the descriptor's) */
+	for (k = 0; k < NW; ++k) {
+		const int64_t b = len * k / NW, e = len * (k + 1) / NW;
+		sl[k].fd = fd, sl[k].buf = buf + b, sl[k].len = e - b, sl[k].off = (int64_t)at + b, sl[k].err = 0;
+		if (k > 0) pthread_create(&th[k], 0, wslice_main, &sl[k]);
+	}
+	wslice_main(&sl[0]);
+	for (k = 1; k < NW; ++k) pthread_join(th[k], 0);
+	for (k = 0; k < NW; ++k) bad |= sl[k].err;
+	if (bad || lseek(fd, at + (off_t)len, SEEK_SET) < 0) return -2;
+	return 0;
+}
+
 static void *writer_main(void *a)
 {
 	writer_t *W = (writer_t*)a;
@@ -587,7 +627,10 @@ static void *writer_main(void *a)
 		while (w->seg >= s->n_seg) { MGA_GROW(int64_t, s->seg_len, s->n_seg, s->m_seg); s->seg_len[s->n_seg++] = 0; }
 		s->seg_len[w->seg] += w->len;
 		if (!W->err && w->len > 0) {
-			if (s->fp) { if (fwrite(w->buf, 1, (size_t)w->len, s->fp) != (size_t)w->len) { fprintf(stderr, "[E::%s] failed to write the results\n", __func__); W->err = 1; } }
+			if (s->fp) {
+				const int pw = write_parallel(s->fp, w->buf, w->len); /* -1: not a large write to a regular file */
+				if (pw == -2 || (pw == -1 && fwrite(w->buf, 1, (size_t)w->len, s->fp) != (size_t)w->len)) { fprintf(stderr, "[E::%s] failed to write the results\n", __func__); W->err = 1; }
+			}
 			else {
 				if (s->mem_len + w->len + 1 > s->mem_cap) { s->mem_cap = (s->mem_len + w->len + 1) * 3 / 2; mga_host_unpin(s->mem); s->mem = (char*)realloc(s->mem, (size_t)s->mem_cap); }
 				memcpy(s->mem + s->mem_len, w->buf, (size_t)w->len); s->mem_len += w->len;

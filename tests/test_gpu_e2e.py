@@ -81,6 +81,21 @@ def test_single_segment_of_50_Mbp_vs_reference_binary(cigar):
     shutil.rmtree(d, ignore_errors=True)
 
 
+def test_file_sink_written_in_parallel_slices(monkeypatch):
+    """a job whose GAF goes to a regular FILE writes every mini-batch in four slices by pwrite() at their final offsets (mapfiles.c: write_parallel; large outputs only, unless
+    MGA_PWRITE_MIN says otherwise): three mini-batches here, the file must be the reference's bytes and end where the last slice ends"""
+    need_ref()
+    monkeypatch.setenv("MGA_PWRITE_MIN", "1000")
+    d = tempfile.mkdtemp()
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "3000000", "-H", "3", "-n", "900", "-s", "15"], stderr=subprocess.DEVNULL)
+    graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
+    ref_out, got = os.path.join(d, "ref.gaf"), os.path.join(d, "got.gaf")
+    run_ref(["-c", "-x", "lr", "-t", "4", "-K", "3500000", graph, reads], ref_out)
+    mga.map_files(graph, [reads], got, cigar=True, map_opt=dict(mini_batch_size=3500000))
+    if open(ref_out, "rb").read() != open(got, "rb").read():
+        raise AssertionError(first_diff(ref_out, got))
+
+
 def test_long_join_rescue_on_device_matches_host_tree_and_reference(monkeypatch):
     """the RMQ rescue (map-algo.c:407-417) runs inside k_lchain; the sequential AVL tree on the host (MGA_HOST_RESCUE=1)
     and the reference binary must give the same bytes, and the device path must actually have been taken"""
