@@ -172,6 +172,201 @@ __device__ void lc_dp(const mg128_t *__restrict__ a, int32_t n, mga_lchain_par_t
 	}
 }
 
+// ---------------- first-pass DP, round 6: the last 64 anchors in REGISTERS ----------------
+// [measured, round 6, profiles/r06d_lchain_occupancy.txt] the kernel is bound by the LATENCY of its dependent global round trips, not by instruction issue: forced to 4 / 2
+// resident waves per SIMD instead of 7 it takes 82.7 / 128 ms instead of 69.3 while the cycles a wave spends in each phase fall by only 10 / 22 % -- a wave waits, whoever
+// shares its SIMD.  lc_dp() pays ~6 such trips per anchor: the anchor, the window's first anchor (one trip per anchor it moves by), the best anchor in reach, a block of 64
+// predecessors' a / f / p / v, the t[] mark store -> load, and the f / p / v store the next anchor reads back.  Here the window of the last 64 anchors IS a set of registers --
+// lane l holds anchor i - 1 - l: x, y, span, f, p, v -- shifted by one lane per anchor (DPP wave_shr:1, the new anchor enters at lane 0):
+//   * the first block of predecessors (26 are visited on average, [measured] round 5) needs no load at all; marks t[p[j]] = i whose target is inside the window go through an
+//     LDS ring, the others to global memory as before;
+//   * the window's start moves by a ballot over the lanes (anchors are x-sorted: the in-reach lanes are a prefix), the best anchor in reach is read from a lane;
+//   * the anchors themselves arrive 64 at a time (one coalesced load per 64 steps), with their "no predecessor in reach" flags as one ballot mask per block;
+//   * f / p / v are still stored per anchor (the backtrack and blocks beyond the window read them) but nothing waits for the store.
+// Anything further back than 64 anchors -- windows in repeats, max_iter-long scans -- takes lc_dp()'s global-memory block loop unchanged, behind a wait for the stores.
+// Same replay of the reference's heuristics, same values (tests/test_gpu_stages.py: test_lchain_*, run in both forms).
+struct lcw_win_t { int32_t xl, xh, yl, sp, f, p, v; };
+#define LCW_NOSEG ((int32_t)0xffffffff) /* x >> 32 of an empty window slot: no anchor has it (it would be segment 2^31 - 1, reverse strand) */
+
+__device__ __forceinline__ int32_t lcw_score(int32_t xil, int32_t yil, int32_t xjl, int32_t yjl, int32_t span, const mga_lchain_par_t &P) // lc_score() on the low words (same segment and strand)
+{
+	const int32_t dq = yil - yjl;
+	if (dq <= 0 || dq > P.max_dist_x) return LC_NONE;
+	const int32_t dr = xil - xjl;
+	if (dr == 0 || dq > P.max_dist_y) return LC_NONE;
+	const int32_t dd = dr > dq ? dr - dq : dq - dr;
+	if (dd > P.bw) return LC_NONE;
+	const int32_t dg = dr < dq ? dr : dq;
+	int32_t sc = span < dg ? span : dg;
+	if (dd || dg > span) {
+		const float lin = P.chn_pen_gap * (float)dd + P.chn_pen_skip * (float)dg;
+		const float lg = dd >= 1 ? lc_log2((float)(dd + 1)) : 0.0f;
+		sc -= (int32_t)(lin + .5f * lg);
+	}
+	return sc;
+}
+
+__device__ void lc_dp_w(const mg128_t *__restrict__ a, int32_t n, mga_lchain_par_t P, lc_ws_t W, int lane)
+{
+	__shared__ int32_t tm[128]; // marks of the window's anchors: tm[j & 127] == i <=> t[j] == i
+	int32_t *f = W.f, *p = W.p, *v = W.v, *t = W.t;
+	for (int32_t i = lane; i < n; i += 64) t[i] = 0;
+	tm[lane] = -1, tm[64 + lane] = -1;
+	lcw_win_t w; w.xl = 0, w.xh = LCW_NOSEG, w.yl = 0, w.sp = 0, w.f = 0, w.p = -1, w.v = 0;
+	int32_t nfill = 0;                 // anchors in the window: [i - nfill, i)
+	int32_t ib = -64;                  // the block of anchors in (bxl, bxh, byl, bsp): lane l holds anchor ib + l
+	int32_t bxl = 0, bxh = 0, byl = 0, bsp = 0, carry_xl = 0, carry_xh = LCW_NOSEG;
+	uint64_t m_iso = 0;
+	int32_t st = 0, max_ii = -1;
+	uint64_t am_x = 0; int32_t am_yl = 0, am_sp = 0, fm = 0, vm = 0; // the best-scoring anchor in reach (lchain.c: max_ii), kept with the values memory would give
+	__syncthreads();
+	for (int32_t i = 0; i < n; ++i) {
+		if (i >= ib + 64) { // next block of anchors + its stray flags
+			ib = i;
+			const int32_t k = ib + lane;
+			mg128_t ak; ak.x = ak.y = 0;
+			if (k < n) ak = a[k];
+			bxl = (int32_t)ak.x, bxh = (int32_t)(ak.x >> 32), byl = (int32_t)ak.y, bsp = (int32_t)(ak.y >> 32 & 0xff);
+			const int32_t pxl = lc_prev_lane(bxl, carry_xl), pxh = lc_prev_lane(bxh, carry_xh); // anchor k - 1
+			const bool iso = k < n && (k == 0 || bxh != pxh || (uint32_t)(bxl - pxl) > (uint32_t)P.max_dist_x);
+			m_iso = __ballot(iso);
+			carry_xl = __builtin_amdgcn_readlane(bxl, 63), carry_xh = __builtin_amdgcn_readlane(bxh, 63);
+		}
+		const int o = i - ib;
+		{ // a run of anchors without any predecessor in reach (see lc_dp): f = v = span, p = -1, written by the lanes at once; only the last of them can precede what follows
+			const uint64_t rest = ~(m_iso >> o);
+			const int r = rest ? (int)__builtin_ctzll(rest) : 64;
+			if (r > 0) {
+				if (lane >= o && lane < o + r) { const int32_t k = ib + lane; f[k] = bsp, p[k] = -1, v[k] = bsp; }
+				const int ls = o + r - 1;
+				const int32_t sxl = __builtin_amdgcn_readlane(bxl, ls), sxh = __builtin_amdgcn_readlane(bxh, ls), syl = __builtin_amdgcn_readlane(byl, ls), ssp = __builtin_amdgcn_readlane(bsp, ls);
+				w.xl = sxl, w.yl = syl, w.sp = ssp, w.f = ssp, w.p = -1, w.v = ssp;
+				w.xh = lane == 0 ? sxh : LCW_NOSEG;
+				nfill = 1;
+				max_ii = i + r - 1;
+				am_x = (uint64_t)(uint32_t)sxh << 32 | (uint32_t)sxl, am_yl = syl, am_sp = ssp, fm = ssp, vm = ssp;
+				if (st < i + r - 1) st = i + r - 1;
+				i += r - 1;
+				continue;
+			}
+		}
+		const int32_t xil = __builtin_amdgcn_readlane(bxl, o), xih = __builtin_amdgcn_readlane(bxh, o), yil = __builtin_amdgcn_readlane(byl, o), spi = __builtin_amdgcn_readlane(bsp, o);
+		const uint64_t xi = (uint64_t)(uint32_t)xih << 32 | (uint32_t)xil;
+		// lchain.c:171: the window's start.  In reach: same segment and strand, not more than max_dist_x back; anchors are x-sorted, so the lanes in reach are a prefix
+		bool deep = false; // predecessors beyond the register window
+		{
+			const bool in = w.xh == xih && (uint32_t)(xil - w.xl) <= (uint32_t)P.max_dist_x;
+			const uint64_t m_out = ~__ballot(in);
+			const int r = m_out ? (int)__builtin_ctzll(m_out) : 64;
+			if (r < 64 || i - 64 <= st) { if (st < i - r) st = i - r; }
+			else { // the whole window is in reach and the start lies before it: the reference's loop over memory, up to the window's first anchor
+				__syncthreads();
+				while (st < i - 64) { const uint64_t xs = a[st].x; if (xi >> 32 != xs >> 32 || xi > xs + (uint64_t)(int64_t)P.max_dist_x) ++st; else break; }
+			}
+			if (i - st > P.max_iter) st = i - P.max_iter;
+			deep = i - st > 64;
+		}
+		int32_t max_f = spi, max_j = -1, max_v = 0, n_skip = 0, end_j = st - 1;
+		bool cut = false;
+		{ // the first block of predecessors: lane l <-> anchor i - 1 - l, from the registers
+			const int32_t j = i - 1 - lane;
+			const bool act = j >= st;
+			int32_t sc = LC_NONE, pj = -1;
+			if (act) {
+				sc = lcw_score(xil, yil, w.xl, w.yl, w.sp, P);
+				if (sc != LC_NONE) sc += w.f, pj = w.p;
+			}
+			const bool valid = sc != LC_NONE;
+			if (valid && pj >= 0) { if (i - 1 - pj < 64) tm[pj & 127] = i; else t[pj] = i; } // lchain.c:188
+			mga_wave_sync();
+			const bool hit_t = valid && tm[j & 127] == i;
+			const int32_t pm = lc_scan_max(valid ? sc : INT32_MIN, INT32_MIN);
+			int32_t ex = lc_prev_lane(pm, INT32_MIN);
+			if (ex < max_f) ex = max_f;
+			const bool improve = valid && sc > ex;
+			const uint64_t m_imp = __ballot(improve);
+			const int cut_lane = lc_skip_replay(improve, hit_t && !improve, P.max_skip, &n_skip);
+			const uint64_t before = cut_lane == 64 ? ~0ULL : (1ULL << cut_lane) - 1ULL;
+			const uint64_t imp_b = m_imp & before;
+			if (imp_b) {
+				const int bl = 63 - __clzll(imp_b);
+				max_f = __builtin_amdgcn_readlane(sc, bl), max_v = __builtin_amdgcn_readlane(w.v, bl), max_j = i - 1 - bl;
+			}
+			if (cut_lane < 64) { cut = true; end_j = i - 1 - cut_lane; }
+		}
+		if (deep && !cut) { // further back than the window: lc_dp()'s block loop over memory (the stores of f / p / v and of the marks are waited for first)
+			__syncthreads();
+			for (int32_t j0 = i - 65; j0 >= st && !cut; j0 -= 64) {
+				const int32_t j = j0 - lane;
+				const bool act = j >= st;
+				int32_t sc = LC_NONE, pj = -1, vj = 0;
+				if (act) {
+					const mg128_t aj = a[j];
+					const int32_t fj = f[j];
+					pj = p[j], vj = v[j];
+					sc = lc_score(xi, (uint64_t)(uint32_t)yil | (uint64_t)spi << 32, aj.x, aj.y, P);
+					if (sc != LC_NONE) sc += fj; else pj = -1;
+				}
+				const bool valid = sc != LC_NONE;
+				if (valid && pj >= 0) t[pj] = i;
+				__syncthreads();
+				const bool hit_t = valid && t[j] == i;
+				const int32_t pm = lc_scan_max(valid ? sc : INT32_MIN, INT32_MIN);
+				int32_t ex = lc_prev_lane(pm, INT32_MIN);
+				if (ex < max_f) ex = max_f;
+				const bool improve = valid && sc > ex;
+				const uint64_t m_imp = __ballot(improve);
+				const int cut_lane = lc_skip_replay(improve, hit_t && !improve, P.max_skip, &n_skip);
+				const uint64_t before = cut_lane == 64 ? ~0ULL : (1ULL << cut_lane) - 1ULL;
+				const uint64_t imp_b = m_imp & before;
+				if (imp_b) {
+					const int bl = 63 - __clzll(imp_b);
+					max_f = __shfl(sc, bl), max_v = __shfl(vj, bl), max_j = j0 - bl;
+				}
+				if (cut_lane < 64) { cut = true; end_j = j0 - cut_lane; }
+				__syncthreads();
+			}
+		}
+		// lchain.c:191-196: best-scoring anchor within reach, recomputed when it fell out of range
+		if (max_ii < 0 || xi - am_x > (uint64_t)(int64_t)P.max_dist_x) {
+			if (!deep) { // the candidates are the window's lanes [0, i - st): largest f, ties to the larger j = the smaller lane
+				const bool act = i - 1 - lane >= st;
+				const int32_t top = __builtin_amdgcn_readlane(lc_scan_max(act ? w.f : INT32_MIN, INT32_MIN), 63);
+				const uint64_t m_top = __ballot(act && w.f == top);
+				if (m_top) {
+					const int lm = (int)__builtin_ctzll(m_top);
+					max_ii = i - 1 - lm;
+					am_x = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(w.xh, lm) << 32 | (uint32_t)__builtin_amdgcn_readlane(w.xl, lm);
+					am_yl = __builtin_amdgcn_readlane(w.yl, lm), am_sp = __builtin_amdgcn_readlane(w.sp, lm), fm = top, vm = __builtin_amdgcn_readlane(w.v, lm);
+				} else max_ii = -1;
+			} else {
+				__syncthreads();
+				int32_t bf = INT32_MIN, bj = -1;
+				for (int32_t j = i - 1 - lane; j >= st; j -= 64) { const int32_t fj = f[j]; if (bf < fj) bf = fj, bj = j; } // descending j per lane: first max kept
+				for (int d = 32; d > 0; d >>= 1) {
+					const int32_t of = __shfl_xor(bf, d), oj = __shfl_xor(bj, d);
+					if (of > bf || (of == bf && oj > bj)) bf = of, bj = oj; // ties: the larger j was met first
+				}
+				max_ii = bj;
+				if (max_ii >= 0) { const mg128_t am = a[max_ii]; am_x = am.x, am_yl = (int32_t)am.y, am_sp = (int32_t)(am.y >> 32 & 0xff), fm = f[max_ii], vm = v[max_ii]; }
+			}
+		}
+		if (max_ii >= 0 && max_ii < end_j) { // lchain.c:197-201
+			const int32_t tmp = lc_score(xi, (uint64_t)(uint32_t)yil | (uint64_t)spi << 32, am_x, (uint64_t)(uint32_t)am_yl | (uint64_t)am_sp << 32, P);
+			if (tmp != LC_NONE && max_f < tmp + fm) max_f = tmp + fm, max_j = max_ii, max_v = vm;
+		}
+		int32_t vi = max_f;
+		if (max_j >= 0 && max_v > max_f) vi = max_v;
+		if (lane == 0) { f[i] = max_f; p[i] = max_j; v[i] = vi; }
+		if (max_ii < 0 || (xi - am_x <= (uint64_t)(int64_t)P.max_dist_x && fm < max_f)) max_ii = i, am_x = xi, am_yl = yil, am_sp = spi, fm = max_f, vm = vi;
+		// the anchor enters the window at lane 0, everything else moves up a lane
+		w.xl = lc_prev_lane(w.xl, xil), w.xh = lc_prev_lane(w.xh, xih), w.yl = lc_prev_lane(w.yl, yil), w.sp = lc_prev_lane(w.sp, spi);
+		w.f = lc_prev_lane(w.f, max_f), w.p = lc_prev_lane(w.p, max_j), w.v = lc_prev_lane(w.v, vi);
+		if (nfill < 64) ++nfill;
+	}
+	__syncthreads(); // (every store has landed before the backtrack reads f / p / v)
+}
+
 // ---------------- RMQ DP of the rescue (lchain.c:275-357); false = this read must be re-chained by the host ----------------
 __device__ bool lc_dp_rmq(const mg128_t *__restrict__ a, int32_t n, const lc_rescue_t &R, lc_ws_t W, int lane)
 {
@@ -589,7 +784,7 @@ __global__ void __launch_bounds__(64) k_lchain(int n_reads, const mg128_t *__res
 											   lc_rescue_t R, const int64_t *__restrict__ q_off,
 											   uint64_t *__restrict__ u_all, mg128_t *__restrict__ b_all, int32_t *__restrict__ d_nu, int32_t *__restrict__ d_nb,
 											   int32_t *__restrict__ d_flag, int32_t *__restrict__ ws_i32, mg128_t *__restrict__ ws_z, mg128_t *__restrict__ ws_keep,
-											   const int32_t *__restrict__ order)
+											   const int32_t *__restrict__ order, int dp_win)
 {
 	__shared__ klib_lds_t L;
 	const int lane = threadIdx.x;
@@ -600,7 +795,7 @@ __global__ void __launch_bounds__(64) k_lchain(int n_reads, const mg128_t *__res
 	lc_read_setup(r, a_all, a_off, P, R, q_off, u_all, b_all, ws_i32, ws_z, &X);
 	if (X.n == 0) { if (lane == 0) d_nu[r] = 0, d_nb[r] = 0; return; }
 	long long tick_ = g_lc_prof_on ? (long long)clock64() : 0;
-	lc_dp(X.a, X.n, X.P, X.W, lane);
+	if (dp_win) lc_dp_w(X.a, X.n, X.P, X.W, lane); else lc_dp(X.a, X.n, X.P, X.W, lane);
 	LC_TICK(0);
 	lc_read_finish(r, X, R, q_off, d_nu, d_nb, d_flag, ws_keep, &L, lane, tick_);
 }
@@ -681,7 +876,9 @@ extern "C" int mga_dev_lchain(mga_sctx_t *sc, int n, const mg128_t *d_a, const i
 		const char *e_pair = getenv("MGA_LC_PAIR");
 		// (also measured and not kept, `git log -p` has it: the first-pass DP over 16-byte {f, p, v, t} records in z[] -- ~9 vector-memory instructions per anchor step instead of
 		// ~14, bit-identical, 66.5 vs 66.8 ms: the kernel is not bound by the memory instructions a CU takes either.  A launch is its longest read's chain of dependent trips.)
-		if (!(e_pair && atoi(e_pair) > 0)) hipLaunchKernelGGL(k_lchain, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, R, d_q_off, d_u, d_b, d_nu, d_nb, d_flag, ws_i32, ws_z, ws_keep, d_order);
+		const char *e_win = getenv("MGA_LC_WIN"); // 0: the first-pass DP over global memory (lc_dp), the form of rounds 1-5; default: the last 64 anchors in registers (lc_dp_w)
+		const int dp_win = !(e_win && *e_win && atoi(e_win) == 0);
+		if (!(e_pair && atoi(e_pair) > 0)) hipLaunchKernelGGL(k_lchain, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, R, d_q_off, d_u, d_b, d_nu, d_nb, d_flag, ws_i32, ws_z, ws_keep, d_order, dp_win);
 		else hipLaunchKernelGGL(k_lchain2, dim3((n + 1) / 2), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, R, d_q_off, d_u, d_b, d_nu, d_nb, d_flag, ws_i32, ws_z, ws_keep, d_order);
 	}
 	mga_prof_end(sc->stream, MGA_K_LCHAIN);

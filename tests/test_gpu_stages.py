@@ -251,6 +251,7 @@ def test_seed_and_lchain_parity(ora, sim, long_path, monkeypatch):
     rep_len from a running maximum), here on ordinary reads against the same oracle"""
     if long_path:
         monkeypatch.setenv("MGA_SEED_LONG", "1")
+    monkeypatch.setenv("MGA_LC_WIN", "0" if long_path else "1")   # (the first-pass DP over memory / with the last 64 anchors in registers)
     gfa, reads = os.path.join(sim, "t.gfa"), read_fa(os.path.join(sim, "t.reads.fa"))
     G = mga.Graph(gfa)
     try:
@@ -300,11 +301,14 @@ def make_anchors(rng, n, n_chain=3, span=17, noise=0.3, tie_frac=0.0):
     return a
 
 
-@pytest.mark.parametrize("pair", ["0", "1"])
-def test_lchain_synthetic_anchor_sets(ora, pair, monkeypatch):
+@pytest.mark.parametrize("pair,win", [("0", "1"), ("0", "0"), ("1", "0")])
+def test_lchain_synthetic_anchor_sets(ora, pair, win, monkeypatch):
     """ties in x and in score, tiny / large anchor sets, skip + iteration caps; pair = 1: the first-pass DP of two reads per wavefront in 32-lane groups (k_lchain2, round 5:
-    measured slower than one read per wavefront and not the default, but exact -- the block of predecessors is 32 instead of 64, the replay carries its state across blocks)"""
+    measured slower than one read per wavefront and not the default, but exact -- the block of predecessors is 32 instead of 64, the replay carries its state across blocks);
+    win = 1 (round 6, the default): the last 64 anchors in registers (lc_dp_w: first block of predecessors from the lanes, marks through an LDS ring, blocks further back and
+    windows of hundreds of anchors -- these sets have them -- from memory), win = 0: every block from memory (lc_dp)"""
     monkeypatch.setenv("MGA_LC_PAIR", pair)
+    monkeypatch.setenv("MGA_LC_WIN", win)
     rng = np.random.default_rng(9)
     sets = []
     for it in range(120):
