@@ -247,6 +247,18 @@ def lchain_batch(anchor_list, **kw):
     return [(uu[uoff[i]:uoff[i + 1]], bb[boff[i]:boff[i + 1]]) for i in range(n)]
 
 
+def sort128x_batch(arrays):
+    """radix_sort_128x on the device, one wavefront per array (the chaining kernels' sort: LDS form up to 1024 elements) -> list of sorted copies"""
+    L = load()
+    n = len(arrays)
+    off = np.zeros(n + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(a) for a in arrays])
+    flat = np.ascontiguousarray(np.concatenate(arrays)) if n else np.zeros(0, dtype=m128)
+    L.mga_sort128x_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    _check(L.mga_sort128x_batch(n, flat.ctypes.data, off.ctypes.data), "mga_sort128x_batch")
+    return [flat[off[i]:off[i + 1]] for i in range(n)]
+
+
 def map_files(graph_path, read_paths, out_path, preset="lr", cigar=True, n_threads=8, verbose=1, idx_opt=None, map_opt=None, flags=0):
     """gfa_read + mg_map_files: the whole `minigraph -cx lr graph reads > out` job through the C ABI.
     idx_opt / map_opt: {field: value} written into mg_idxopt_t / mg_mapopt_t after the preset, the way main.c:131-191 applies

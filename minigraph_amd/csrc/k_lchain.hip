@@ -38,9 +38,12 @@
 //       exactly like the first pass; more than 64 candidates also defers the read to the host.
 // [measured] the rescue fires on ~48 % of 10 kb reads and cost 46 us/read of host CPU, a third of the host budget.
 // profiling aid (MGA_LC_PROF=1): cycles per phase summed over reads: [0] first-pass DP, [1] its backtrack + compaction, [2] rescue sort, [3] rescue DP, [4] rescue backtrack
-__device__ unsigned long long g_lc_prof[8];
+__device__ unsigned long long g_lc_prof[16]; // [8..12] counts: anchors, chain ends, walks, walk steps, backtracks
 __device__ int g_lc_prof_on;
-#define LC_TICK(id) do { if (g_lc_prof_on && lane == 0) { const long long now_ = (long long)clock64(); atomicAdd(&g_lc_prof[id], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
+// (a read's cycles are summed in LDS and added to the global counters once, when the read is done: [measured, round 6] one atomicAdd per tick from every wavefront on ONE
+// address made the ticks inside the walk -- 15 per read -- cost more than the kernel: every barrier waits for the wave's outstanding atomics too)
+#define LC_TICK(id) do { if (g_lc_prof_on && lane == 0) { const long long now_ = (long long)clock64(); LP->prof[id] += (unsigned long long)(now_ - tick_); tick_ = now_; } } while (0)
+#define LC_COUNT(id, val) do { if (g_lc_prof_on && lane == 0) LP->prof[id] += (unsigned long long)(val); } while (0)
 #define LC_RESCUE_DEV_MAX 16384 // chained anchors of a read beyond which the long-join rescue is left to the host tree (~0.5 Mbp of read)
 struct lc_rescue_t {
 	int32_t enabled;          // bw_long > bw, long-read mode
@@ -71,9 +74,20 @@ __device__ __forceinline__ int32_t lc_score(uint64_t xi, uint64_t yi, uint64_t x
 }
 
 struct lc_ws_t { int32_t *f, *p, *v, *t; mg128_t *z; };
+// the LDS of a read's wavefront, one phase after the other: the marks of the DP's register window, the two forms of the klib sort, the candidate lists of the rescue's DP.
+// 5 344 bytes: 28 single-wave workgroups (7 per SIMD, what the registers allow) fit a CU's 160 KB.
+struct lc_lds_t {
+	union { int32_t tm[128]; klib_lds_t big; klib_small_lds_t small; struct { int32_t cand_j[64], cand_y[64], sorted_j[64]; } rq; };
+	unsigned long long prof[16]; // MGA_LC_PROF: this read's cycles per phase
+};
+__device__ __forceinline__ void lc_sort(mg128_t *a, int32_t n, mg128_t *tmp, int32_t *stk, lc_lds_t *L) // klib's radix_sort_128x, permutation and all; tmp: n elements of scratch
+{
+	if (n <= KLIB_SMALL_CAP) klib_sort128x_small(a, n, tmp, &L->small);
+	else klib_sort128x(a, n, stk, &L->big);
+}
 
 // ---------------- first-pass DP (lchain.c:168-207) ----------------
-__device__ void lc_dp(const mg128_t *__restrict__ a, int32_t n, mga_lchain_par_t P, lc_ws_t W, int lane)
+__device__ __forceinline__ void lc_dp(const mg128_t *__restrict__ a, int32_t n, mga_lchain_par_t P, lc_ws_t W, int lane)
 {
 	int32_t *f = W.f, *p = W.p, *v = W.v, *t = W.t;
 	for (int32_t i = lane; i < n; i += 64) t[i] = 0;
@@ -206,9 +220,9 @@ __device__ __forceinline__ int32_t lcw_score(int32_t xil, int32_t yil, int32_t x
 	return sc;
 }
 
-__device__ void lc_dp_w(const mg128_t *__restrict__ a, int32_t n, mga_lchain_par_t P, lc_ws_t W, int lane)
+__device__ __forceinline__ void lc_dp_w(const mg128_t *__restrict__ a, int32_t n, mga_lchain_par_t P, lc_ws_t W, lc_lds_t *L, int lane)
 {
-	__shared__ int32_t tm[128]; // marks of the window's anchors: tm[j & 127] == i <=> t[j] == i
+	int32_t *tm = L->tm; // marks of the window's anchors: tm[j & 127] == i <=> t[j] == i
 	int32_t *f = W.f, *p = W.p, *v = W.v, *t = W.t;
 	for (int32_t i = lane; i < n; i += 64) t[i] = 0;
 	tm[lane] = -1, tm[64 + lane] = -1;
@@ -368,9 +382,9 @@ __device__ void lc_dp_w(const mg128_t *__restrict__ a, int32_t n, mga_lchain_par
 }
 
 // ---------------- RMQ DP of the rescue (lchain.c:275-357); false = this read must be re-chained by the host ----------------
-__device__ bool lc_dp_rmq(const mg128_t *__restrict__ a, int32_t n, const lc_rescue_t &R, lc_ws_t W, int lane)
+__device__ __forceinline__ bool lc_dp_rmq(const mg128_t *__restrict__ a, int32_t n, const lc_rescue_t &R, lc_ws_t W, lc_lds_t *L, int lane)
 {
-	__shared__ int32_t cand_j[64], cand_y[64], sorted_j[64];
+	int32_t *cand_j = L->rq.cand_j, *cand_y = L->rq.cand_y, *sorted_j = L->rq.sorted_j;
 	int32_t *f = W.f, *p = W.p, *v = W.v, *t = W.t;
 	double *pri = (double*)W.z; // z is free until the backtrack
 	int32_t max_dist = R.max_dist, max_dist_inner = R.max_dist_inner;
@@ -491,13 +505,14 @@ __device__ bool lc_dp_rmq(const mg128_t *__restrict__ a, int32_t n, const lc_res
 }
 
 // ---------------- backtrack (lchain.c:27-77) + compact_a (lchain.c:79-112): chains of a[] -> (u, b) ----------------
-__device__ void lc_backtrack_compact(const mg128_t *a, int32_t n, int32_t min_sc, int32_t min_cnt, int32_t max_drop, lc_ws_t W,
-									 uint64_t *u, mg128_t *b, /* a may alias b: a is fully read into z before b is written */ int32_t *n_u_, int32_t *n_v_, klib_lds_t *L, int lane)
+// In two parts with the klib sort of the chain ends between them, so that a read's two backtracks (first pass, long-join rescue) and its sorts each have ONE call site:
+// [measured, round 6] inlined per call the kernel was 59 KB of code and every phase ran 2-5 x slower -- the waves of a CU are spread over all phases and the
+// instruction cache did not hold them.
+// part 1: z = chain ends with f >= min_sc, in index order; returns their number
+__device__ __forceinline__ int32_t lc_chain_ends(int32_t n, int32_t min_sc, lc_ws_t W, int lane)
 {
-	int32_t *f = W.f, *p = W.p, *v = W.v, *t = W.t;
+	const int32_t *f = W.f;
 	mg128_t *z = W.z;
-	*n_u_ = 0, *n_v_ = 0;
-	// z = chain ends with f >= min_sc, in index order, then the klib sort by score
 	int32_t n_z = 0;
 	for (int32_t c0 = 0; c0 < n; c0 += 64) {
 		const int32_t i = c0 + lane;
@@ -507,34 +522,74 @@ __device__ void lc_backtrack_compact(const mg128_t *a, int32_t n, int32_t min_sc
 		n_z += __popcll(m);
 	}
 	__syncthreads();
+	return n_z;
+}
+
+// part 2, behind the klib sort of z by score: the walks from the best end down, then the compaction
+__device__ __forceinline__ void lc_walk_compact(const mg128_t *a, int32_t n, int32_t n_z, int32_t min_sc, int32_t min_cnt, int32_t max_drop, lc_ws_t W,
+												uint64_t *u, mg128_t *b, /* a may alias b: a is fully read into z before b is written */ int32_t *n_u_, int32_t *n_v_, lc_lds_t *L, int lane, long long &tick_)
+{
+	lc_lds_t *LP = L;
+	int32_t *f = W.f, *p = W.p, *v = W.v, *t = W.t;
+	mg128_t *z = W.z;
+	*n_u_ = 0, *n_v_ = 0;
 	if (n_z == 0) return;
-	klib_sort128x(z, n_z, t, L); // t[] is free here (re-zeroed below) and large enough for the range stack
 	for (int32_t i = lane; i < n; i += 64) t[i] = 0;
 	__syncthreads();
 	int32_t n_u = 0, n_v = 0;
-	if (lane == 0) { // the walk is a chain of dependent loads: one lane
-		for (int32_t k = n_z - 1; k >= 0; --k) {
-			const int32_t e = (int32_t)z[k].y, zs = (int32_t)z[k].x;
-			if (t[e] != 0) continue;
-			// mg_chain_bk_end (lchain.c:9-25)
-			int32_t i = e, stop = -1, best_i = e, best = 0;
-			do {
-				t[i] = 2;
-				stop = i = p[i];
-				const int32_t s = i < 0 ? zs : zs - f[i];
-				if (s > best) best = s, best_i = i;
-				else if (best - s > max_drop) break;
-			} while (i >= 0 && t[i] == 0);
-			for (i = e; i >= 0 && i != stop; i = p[i]) t[i] = 0;
-			const int32_t cutp = best_i, n_v0 = n_v;
-			for (i = e; i != cutp; i = p[i]) v[n_v++] = i, t[i] = 1;
-			const int32_t sc = i < 0 ? zs : zs - f[i];
-			if (sc >= min_sc && n_v > n_v0 && n_v - n_v0 >= min_cnt) u[n_u++] = (uint64_t)sc << 32 | (uint64_t)(n_v - n_v0);
-			else n_v = n_v0;
+	// The walk (lchain.c:9-25, 41-60).  Rounds 1-5 gave it to one lane: a chain of dependent loads -- z[k] -> t[e] per chain end, p[i] -> f[i], t[i] per step, three times over
+	// the same path (mg_chain_bk_end, the reset of t[], the collection) -- [measured, round 6, profiles/r06f_lchain_phases.txt] 1.6 M cycles per backtrack for 250 chain ends
+	// and 256 steps, a third of the kernel.  Now the wavefront keeps a BLOCK of 64 anchors' p / f / t in registers (lane l <-> anchor top - l): a step reads its successor
+	// from a lane (p[i] < i: the path only descends, so the block slides down and is reloaded when the path leaves it -- one trip per 64 anchors instead of three per step);
+	// the path goes to v[] as it is walked (the collection IS the path's head up to the best cut), the marks t[] = 1 of the kept part are set afterwards by all lanes.
+	// t[] = 2 is never materialised: a path cannot meet itself, and every anchor the reference marks 2 is 0 or 1 again when its walk ends.
+	// Chain ends are taken 64 at a time: the ones already marked are skipped by a ballot, the marks re-read after every walk that set any.
+	unsigned long long c_walk = 0, c_step = 0;
+	for (int32_t k0 = n_z - 1; k0 >= 0; k0 -= 64) {
+		const int32_t k = k0 - lane;
+		int32_t ze = 0, zsc = 0, te = 1;
+		if (k >= 0) { const mg128_t zk = z[k]; ze = (int32_t)zk.y, zsc = (int32_t)zk.x; te = t[ze]; }
+		uint64_t m_free = __ballot(te == 0);
+		LC_TICK(13);
+		while (m_free) {
+			const int lw = (int)__builtin_ctzll(m_free);
+			const int32_t e = __builtin_amdgcn_readlane(ze, lw), zs = __builtin_amdgcn_readlane(zsc, lw);
+			++c_walk;
+			int32_t top = e, pb = -1, fb = 0, tb = 0;
+			{ const int32_t j = top - lane; if (j >= 0) pb = p[j], fb = f[j], tb = t[j]; }
+			int32_t i = e, cnt = 0, best = 0, best_cnt = 0;
+			for (;;) {
+				if (lane == 0) v[n_v + cnt] = i;
+				++cnt;
+				const int32_t ni = __builtin_amdgcn_readlane(pb, top - i);
+				if (ni < 0) { if (zs > best) best = zs, best_cnt = cnt; break; } // (a drop at the chain's start ends the loop like its end does)
+				if (top - ni > 63) { top = ni; const int32_t j = top - lane; pb = -1, fb = 0, tb = 0; if (j >= 0) pb = p[j], fb = f[j], tb = t[j]; }
+				const int32_t sc = zs - __builtin_amdgcn_readlane(fb, top - ni);
+				if (sc > best) best = sc, best_cnt = cnt;
+				else if (best - sc > max_drop) break;
+				i = ni;
+				if (__builtin_amdgcn_readlane(tb, top - i) != 0) break;
+			}
+			c_step += cnt;
+			LC_TICK(14);
+			const uint64_t m_rest = lw == 63 ? 0 : m_free & (~0ULL << (lw + 1));
+			if (best_cnt > 0) {
+				__syncthreads(); // the path is in v[]
+				for (int32_t q = lane; q < best_cnt; q += 64) t[v[n_v + q]] = 1;
+				if (best >= min_sc && best_cnt >= min_cnt) { if (lane == 0) u[n_u] = (uint64_t)best << 32 | (uint64_t)best_cnt; ++n_u; n_v += best_cnt; }
+				if (m_rest) {
+					__syncthreads(); // the marks are set
+					if (k >= 0) te = t[ze];
+					m_free = __ballot(te == 0) & m_rest;
+				} else m_free = 0;
+			} else m_free = m_rest;
+			LC_TICK(15);
 		}
+		__syncthreads();
 	}
-	n_u = __shfl(n_u, 0), n_v = __shfl(n_v, 0);
+	LC_COUNT(8, n); LC_COUNT(9, n_z); LC_COUNT(10, c_walk); LC_COUNT(11, c_step); LC_COUNT(12, 1);
 	__syncthreads();
+	LC_TICK(7);
 	if (n_u == 0) return;
 	// NB: v[] was overwritten from index 0 by the walk (n_v <= anchors visited), as in the reference
 	{
@@ -553,7 +608,7 @@ __device__ void lc_backtrack_compact(const mg128_t *a, int32_t n, int32_t min_sc
 		for (int32_t c = 0; c < n_u; ++c) { w[c].x = z[k0].x; w[c].y = (uint64_t)k0 << 32 | (uint64_t)c; k0 += (int32_t)u[c]; }
 	}
 	__syncthreads();
-	klib_sort128x(w, n_u, t, L);
+	if (n_u <= 64) klib_rank_sort64(w, n_u); else klib_sort128x(w, n_u, t, &L->big); // (t[] is free by now and large enough for the range stack)
 	uint64_t *u2 = (uint64_t*)v; // n_u * 8 bytes <= n * 4 bytes when min_cnt >= 2; guarded by the host wrapper
 	if (lane == 0) for (int32_t c = 0; c < n_u; ++c) u2[c] = u[(int32_t)w[c].y];
 	__syncthreads();
@@ -611,7 +666,7 @@ __device__ __forceinline__ int lcg_skip_replay(bool improve, bool hit, int32_t m
 	return 32;
 }
 
-__device__ void lc_dp2(const mg128_t *__restrict__ a, int32_t n, mga_lchain_par_t P, lc_ws_t W, int lane)
+__device__ __forceinline__ void lc_dp2(const mg128_t *__restrict__ a, int32_t n, mga_lchain_par_t P, lc_ws_t W, int lane)
 {
 	int32_t *f = W.f, *p = W.p, *v = W.v, *t = W.t;
 	const int grp = lane >> 5, gl = lane & 31, g0 = grp * 32;
@@ -726,9 +781,10 @@ __device__ __forceinline__ void lc_read_setup(int r, const mg128_t *a_all, const
 }
 
 // everything behind the first-pass DP of read r: backtrack + compaction, the long-join rescue (map-algo.c:407-417), the read's counts and flag.  The whole wavefront, one read.
-__device__ void lc_read_finish(int r, const lc_read_t &X, const lc_rescue_t &R, const int64_t *__restrict__ q_off, int32_t *__restrict__ d_nu, int32_t *__restrict__ d_nb,
-							   int32_t *__restrict__ d_flag, mg128_t *__restrict__ ws_keep, klib_lds_t *L, int lane, long long &tick_)
+__device__ __forceinline__ void lc_read_finish(int r, const lc_read_t &X, const lc_rescue_t &R, const int64_t *__restrict__ q_off, int32_t *__restrict__ d_nu, int32_t *__restrict__ d_nb,
+							   int32_t *__restrict__ d_flag, mg128_t *__restrict__ ws_keep, lc_lds_t *L, int lane, long long &tick_)
 {
+	lc_lds_t *LP = L;
 	const mg128_t *a = X.a;
 	const int32_t n = X.n;
 	const lc_ws_t W = X.W;
@@ -737,56 +793,70 @@ __device__ void lc_read_finish(int r, const lc_read_t &X, const lc_rescue_t &R, 
 	const int64_t off = X.off;
 	const mga_lchain_par_t &P = X.P;
 	int32_t n_u = 0, n_v = 0;
-	lc_backtrack_compact(a, n, P.min_sc, P.min_cnt, P.bw, W, u, b, &n_u, &n_v, L, lane);
-	LC_TICK(1);
-	// ---- long-join rescue (map-algo.c:407-417) ----
-	if (R.enabled && n_u > 1 && q_off) {
-		const int32_t qlen = (int32_t)(q_off[r + 1] - q_off[r]);
-		const int32_t st = (int32_t)b[0].y, en = (int32_t)b[(int32_t)u[0] - 1].y;
-		const int32_t unc = qlen - (en - st);
-		if ((unc > R.rescue_size || (float)unc > (float)qlen * R.rescue_ratio) && n_v > LC_RESCUE_DEV_MAX) {
-			// an ultra-long read (hundreds of kb and up): the rescue's per-anchor window searches on ONE wavefront would take longer than the host's
-			// tree over the same anchors ([measured] round 1: 2 x 5 Mbp reads 2.2 s in here against 0.9 s for the whole reference job), so the read
-			// goes the way of the tied ones -- first-pass chains out, flag 2, the host re-chains it with the RMQ tree (and chains it through the graph)
-			if (lane == 0 && d_flag) d_flag[r] = 2;
-		} else if (unc > R.rescue_size || (float)unc > (float)qlen * R.rescue_ratio) {
-			mg128_t *keep = (mg128_t*)((char*)ws_keep + off * 24); // the first-pass result (16 B/anchor + 8 B/chain), should the host have to take over
-			uint64_t *keep_u = (uint64_t*)(keep + n_v);
-			for (int32_t i = lane; i < n_v; i += 64) keep[i] = b[i];
-			for (int32_t i = lane; i < n_u; i += 64) keep_u[i] = u[i];
-			__syncthreads();
-			klib_sort128x(b, n_v, W.t, L); // all chained anchors, by x (n_v = sum of the chain sizes)
+	mg128_t *keep = (mg128_t*)((char*)ws_keep + off * 24); // the first-pass result (16 B/anchor + 8 B/chain), should the host have to take over; scratch of the sorts while it holds nothing
+	uint64_t *keep_u = 0;
+	const mg128_t *src = a;
+	int32_t n_src = n, min_sc = P.min_sc, min_cnt = P.min_cnt, max_drop = P.bw;
+	// step 0: the first pass's backtrack; 1: the long-join rescue's sort + DP (map-algo.c:407-417); 2: the rescue's backtrack.  One sort, one walk, whatever the step.
+	for (int step = 0;;) {
+		mg128_t *sa, *stmp;
+		int32_t sn;
+		if (step == 1) sa = b, sn = n_v, stmp = W.z; // all chained anchors, by x (n_v = sum of the chain sizes); z is free between the backtracks
+		else { sa = W.z, sn = __builtin_amdgcn_readfirstlane(lc_chain_ends(n_src, min_sc, W, lane)), stmp = keep; LC_TICK(5); }
+		lc_sort(sa, sn, stmp, W.t, L); // (t[] is free here -- re-zeroed by the walk -- and large enough for the range stack)
+		if (step == 1) {
 			__syncthreads();
 			LC_TICK(2);
-			int32_t n_u2 = 0, n_v2 = 0;
-			const int32_t n_a = n_v;
-			const bool rq_ok = lc_dp_rmq(b, n_a, R, W, lane);
+			const bool rq_ok = lc_dp_rmq(b, n_v, R, W, L, lane);
 			LC_TICK(3);
-			if (rq_ok) {
-				// mg_lchain_rmq backtracks with max_drop = its bw (lchain.c:267,359); the anchors are read from b, the result overwrites b
-				lc_backtrack_compact(b, n_a, R.min_sc, R.min_cnt, R.bw, W, u, b, &n_u2, &n_v2, L, lane);
-				LC_TICK(4);
-				n_u = n_u2, n_v = n_v2;
-				if (lane == 0 && d_flag) d_flag[r] = 1;
-			} else {
+			if (!rq_ok) {
 				__syncthreads();
 				for (int32_t i = lane; i < n_v; i += 64) b[i] = keep[i];
 				for (int32_t i = lane; i < n_u; i += 64) u[i] = keep_u[i];
 				if (lane == 0 && d_flag) d_flag[r] = 2;
+				break;
 			}
+			// mg_lchain_rmq backtracks with max_drop = its bw (lchain.c:267,359); the anchors are read from b, the result overwrites b; keep is no longer needed: the rescue's chains stand
+			step = 2, src = b, n_src = n_v, min_sc = R.min_sc, min_cnt = R.min_cnt, max_drop = R.bw;
+			continue;
 		}
+		LC_TICK(6);
+		lc_walk_compact(src, n_src, sn, min_sc, min_cnt, max_drop, W, u, b, &n_u, &n_v, L, lane, tick_);
+		n_u = __builtin_amdgcn_readfirstlane(n_u), n_v = __builtin_amdgcn_readfirstlane(n_v);
+		if (step == 2) { LC_TICK(4); if (lane == 0 && d_flag) d_flag[r] = 1; break; }
+		LC_TICK(1);
+		if (!(R.enabled && n_u > 1 && q_off)) break;
+		const int32_t qlen = (int32_t)(q_off[r + 1] - q_off[r]);
+		const int32_t st = (int32_t)b[0].y, en = (int32_t)b[(int32_t)u[0] - 1].y;
+		const int32_t unc = qlen - (en - st);
+		if (!(unc > R.rescue_size || (float)unc > (float)qlen * R.rescue_ratio)) break;
+		if (n_v > LC_RESCUE_DEV_MAX) {
+			// an ultra-long read (hundreds of kb and up): the rescue's per-anchor window searches on ONE wavefront would take longer than the host's
+			// tree over the same anchors ([measured] round 1: 2 x 5 Mbp reads 2.2 s in here against 0.9 s for the whole reference job), so the read
+			// goes the way of the tied ones -- first-pass chains out, flag 2, the host re-chains it with the RMQ tree (and chains it through the graph)
+			if (lane == 0 && d_flag) d_flag[r] = 2;
+			break;
+		}
+		keep_u = (uint64_t*)(keep + n_v);
+		for (int32_t i = lane; i < n_v; i += 64) keep[i] = b[i];
+		for (int32_t i = lane; i < n_u; i += 64) keep_u[i] = u[i];
+		__syncthreads();
+		step = 1;
 	}
 	if (lane == 0) { d_nu[r] = n_u; d_nb[r] = n_v; }
 }
 
 // d_flag[r]: 0 = chains of the first pass; 1 = long-join rescue applied on the device; 2 = rescue due, left to the host
-__global__ void __launch_bounds__(64) k_lchain(int n_reads, const mg128_t *__restrict__ a_all, const int64_t *__restrict__ a_off, mga_lchain_par_t P,
+template<int WPE> // resident waves per SIMD the register allocation is held to (measurement knob MGA_LC_WPE; see mga_dev_lchain)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) k_lchain(int n_reads, const mg128_t *__restrict__ a_all, const int64_t *__restrict__ a_off, mga_lchain_par_t P,
 											   lc_rescue_t R, const int64_t *__restrict__ q_off,
 											   uint64_t *__restrict__ u_all, mg128_t *__restrict__ b_all, int32_t *__restrict__ d_nu, int32_t *__restrict__ d_nb,
 											   int32_t *__restrict__ d_flag, int32_t *__restrict__ ws_i32, mg128_t *__restrict__ ws_z, mg128_t *__restrict__ ws_keep,
 											   const int32_t *__restrict__ order, int dp_win)
 {
-	__shared__ klib_lds_t L;
+	__shared__ lc_lds_t L;
+	lc_lds_t *LP = &L;
+	if (threadIdx.x < 16) L.prof[threadIdx.x] = 0;
 	const int lane = threadIdx.x;
 	if ((int)blockIdx.x >= n_reads) return;
 	const int r = order ? __builtin_amdgcn_readfirstlane(order[blockIdx.x]) : (int)blockIdx.x; // workgroups are dispatched in index order: the reads with the most anchors first (mapper.c)
@@ -795,9 +865,10 @@ __global__ void __launch_bounds__(64) k_lchain(int n_reads, const mg128_t *__res
 	lc_read_setup(r, a_all, a_off, P, R, q_off, u_all, b_all, ws_i32, ws_z, &X);
 	if (X.n == 0) { if (lane == 0) d_nu[r] = 0, d_nb[r] = 0; return; }
 	long long tick_ = g_lc_prof_on ? (long long)clock64() : 0;
-	if (dp_win) lc_dp_w(X.a, X.n, X.P, X.W, lane); else lc_dp(X.a, X.n, X.P, X.W, lane);
+	if (dp_win) lc_dp_w(X.a, X.n, X.P, X.W, &L, lane); else lc_dp(X.a, X.n, X.P, X.W, lane);
 	LC_TICK(0);
 	lc_read_finish(r, X, R, q_off, d_nu, d_nb, d_flag, ws_keep, &L, lane, tick_);
+	if (g_lc_prof_on) { mga_wave_sync(); if (lane < 16 && L.prof[lane]) atomicAdd(&g_lc_prof[lane], L.prof[lane]); }
 }
 
 // the same, TWO reads per wavefront in the first-pass DP (lc_dp2), one after the other in everything behind it
@@ -807,7 +878,9 @@ __global__ void __launch_bounds__(64) k_lchain2(int n_reads, const mg128_t *__re
 												int32_t *__restrict__ d_flag, int32_t *__restrict__ ws_i32, mg128_t *__restrict__ ws_z, mg128_t *__restrict__ ws_keep,
 												const int32_t *__restrict__ order)
 {
-	__shared__ klib_lds_t L;
+	__shared__ lc_lds_t L;
+	lc_lds_t *LP = &L;
+	if (threadIdx.x < 16) L.prof[threadIdx.x] = 0;
 	const int lane = threadIdx.x, grp = lane >> 5;
 	const int k0 = 2 * (int)blockIdx.x;
 	if (k0 >= n_reads) return;
@@ -834,6 +907,25 @@ __global__ void __launch_bounds__(64) k_lchain2(int n_reads, const mg128_t *__re
 		lc_read_finish(r, X, R, q_off, d_nu, d_nb, d_flag, ws_keep, &L, lane, tick_);
 		__syncthreads();
 	}
+	if (g_lc_prof_on) { mga_wave_sync(); if (lane < 16 && L.prof[lane]) atomicAdd(&g_lc_prof[lane], L.prof[lane]); }
+}
+
+// stage test: the sorts of this file on their own (tests/test_gpu_stages.py: test_device_klib_sort)
+__global__ void __launch_bounds__(64) k_sort128x(int n, mg128_t *a_all, const int64_t *__restrict__ a_off, mg128_t *tmp_all, int32_t *stk_all)
+{
+	__shared__ lc_lds_t L;
+	if ((int)blockIdx.x >= n) return;
+	const int64_t off = a_off[blockIdx.x];
+	const int64_t m = a_off[blockIdx.x + 1] - off;
+	if (m > 0x7fffffff) return;
+	lc_sort(a_all + off, (int32_t)m, tmp_all + off, stk_all + 3 * off + 8 * (int64_t)blockIdx.x, &L);
+}
+extern "C" int mga_dev_sort128x(mga_sctx_t *sc, int n, mg128_t *d_a, const int64_t *d_a_off, mg128_t *d_tmp, int32_t *d_stk)
+{
+	if (n <= 0) return 0;
+	hipLaunchKernelGGL(k_sort128x, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, d_tmp, d_stk);
+	MGA_HIP_CHECK(hipGetLastError());
+	return 0;
 }
 
 extern "C" size_t mga_dev_lchain_ws_bytes(int64_t total_anchors) { return (size_t)(total_anchors + 16) * 56; }
@@ -862,9 +954,9 @@ extern "C" int mga_dev_lchain(mga_sctx_t *sc, int n, const mg128_t *d_a, const i
 		static int prof_on = -1;
 		if (prof_on < 0) { const char *e = getenv("MGA_LC_PROF"); prof_on = e && atoi(e) > 0; if (prof_on) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lc_prof_on), &prof_on, sizeof(int)); }
 		if (prof_on) { // print what the previous launches accumulated
-			unsigned long long h[8];
+			unsigned long long h[16];
 			if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lc_prof), sizeof h) == hipSuccess)
-				fprintf(stderr, "[lc-prof] Mcycles so far: dp %.1f backtrack %.1f rescue-sort %.1f rescue-dp %.1f rescue-backtrack %.1f\n", h[0] * 1e-6, h[1] * 1e-6, h[2] * 1e-6, h[3] * 1e-6, h[4] * 1e-6);
+				fprintf(stderr, "[lc-prof] Mcycles so far: dp %.1f backtrack %.1f rescue-sort %.1f rescue-dp %.1f rescue-backtrack %.1f | inside both backtracks: ends %.1f sort %.1f walk %.1f (their rest = compaction); %llu backtracks: anchors %llu ends %llu walks %llu steps %llu; walk = ends' marks %.1f + steps %.1f + marks %.1f\n", h[0] * 1e-6, h[1] * 1e-6, h[2] * 1e-6, h[3] * 1e-6, h[4] * 1e-6, h[5] * 1e-6, h[6] * 1e-6, h[7] * 1e-6, h[12], h[8], h[9], h[10], h[11], h[13] * 1e-6, h[14] * 1e-6, h[15] * 1e-6);
 		}
 	}
 	mga_prof_begin(sc->stream, MGA_K_LCHAIN);
@@ -878,7 +970,10 @@ extern "C" int mga_dev_lchain(mga_sctx_t *sc, int n, const mg128_t *d_a, const i
 		// ~14, bit-identical, 66.5 vs 66.8 ms: the kernel is not bound by the memory instructions a CU takes either.  A launch is its longest read's chain of dependent trips.)
 		const char *e_win = getenv("MGA_LC_WIN"); // 0: the first-pass DP over global memory (lc_dp), the form of rounds 1-5; default: the last 64 anchors in registers (lc_dp_w)
 		const int dp_win = !(e_win && *e_win && atoi(e_win) == 0);
-		if (!(e_pair && atoi(e_pair) > 0)) hipLaunchKernelGGL(k_lchain, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, R, d_q_off, d_u, d_b, d_nu, d_nb, d_flag, ws_i32, ws_z, ws_keep, d_order, dp_win);
+		const char *e_wpe = getenv("MGA_LC_WPE");
+		const int wpe = e_wpe && *e_wpe ? atoi(e_wpe) : 7;
+#define LC_LAUNCH(W_) hipLaunchKernelGGL(k_lchain<W_>, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, R, d_q_off, d_u, d_b, d_nu, d_nb, d_flag, ws_i32, ws_z, ws_keep, d_order, dp_win)
+		if (!(e_pair && atoi(e_pair) > 0)) { if (wpe <= 5) LC_LAUNCH(5); else if (wpe == 6) LC_LAUNCH(6); else LC_LAUNCH(7); }
 		else hipLaunchKernelGGL(k_lchain2, dim3((n + 1) / 2), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, R, d_q_off, d_u, d_b, d_nu, d_nb, d_flag, ws_i32, ws_z, ws_keep, d_order);
 	}
 	mga_prof_end(sc->stream, MGA_K_LCHAIN);

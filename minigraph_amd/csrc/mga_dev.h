@@ -152,6 +152,7 @@ typedef struct {
 int mga_dev_lchain(mga_sctx_t *sc, int n, const mg128_t *d_a, const int64_t *d_a_off, const mga_lchain_par_t *par, const mga_rescue_par_t *resc,
 				   const int64_t *d_q_off, uint64_t *d_u, mg128_t *d_b, int32_t *d_nu, int32_t *d_nb, int32_t *d_flag, void *d_ws, size_t ws_bytes, int64_t total_anchors);
 size_t mga_dev_lchain_ws_bytes(int64_t total_anchors);
+int mga_dev_sort128x(mga_sctx_t *sc, int n, mg128_t *d_a, const int64_t *d_a_off, mg128_t *d_tmp, int32_t *d_stk); /* (stage test of the kernels' klib sort; d_tmp: as many elements as d_a, d_stk: 3 int32 per element + 8 per array) */
 
 /* ---- WFA (k_wfa.hip) ---- */
 typedef struct { int64_t t_off, q_off; int32_t tl, ql; } mga_wfa_prob_t;

@@ -168,6 +168,21 @@ extern "C" int mga_seed_batch(const mg_idx_t *gi, int n, const mg128_t *mz, cons
 	return 0;
 }
 
+extern "C" int mga_sort128x_batch(int n, mg128_t *a, const int64_t *a_off)
+{
+	if (mga_dev_init() < 0) return -1;
+	mga_sctx_t *SC = mga_sctx_default();
+	if (SC == 0) return -1;
+	if (n <= 0) return 0;
+	const int64_t tot = a_off[n];
+	dptr d_a, d_aoff, d_tmp, d_stk;
+	if (!d_a.alloc((size_t)tot * 16 + 16) || !d_aoff.alloc((n + 1) * 8) || !d_tmp.alloc((size_t)tot * 16 + 16) || !d_stk.alloc((size_t)tot * 12 + (size_t)n * 32 + 64)) return -1;
+	if (mga_h2d(d_a.p, a, (size_t)tot * 16) < 0 || mga_h2d(d_aoff.p, a_off, (n + 1) * 8) < 0) return -1;
+	if (mga_dev_sort128x(SC, n, d_a.as<mg128_t>(), d_aoff.as<int64_t>(), d_tmp.as<mg128_t>(), d_stk.as<int32_t>()) < 0) return -1;
+	if (mga_ssync(SC) < 0 || mga_d2h(a, d_a.p, (size_t)tot * 16) < 0) return -1;
+	return 0;
+}
+
 extern "C" int mga_lchain_batch(int n, const mg128_t *a, const int64_t *a_off, const mga_lchain_par_t *par,
 								uint64_t **u, int64_t **u_off, mg128_t **b, int64_t **b_off)
 {

@@ -324,6 +324,43 @@ def test_lchain_synthetic_anchor_sets(ora, pair, win, monkeypatch):
             assert np.array_equal(lc[i][1], ea), ("a", i, kw)
 
 
+@pytest.mark.gpu
+def test_device_klib_sort(ora):
+    """the kernels' radix_sort_128x (dev_klibsort.h) against the restatement pinned to the reference's: the order it leaves EQUAL keys in is observable (chain ends of equal
+    score, anchors of equal x), so y carries each element's original place and must come out where klib puts it.  Sizes around the insertion-sort limit (64), the LDS form's
+    limit (1024: klib_sort128x_small, round 6) and beyond (the in-memory form); keys that differ in one byte only, in every byte, scores (small integers with many ties),
+    anchors (segment in the high word), all equal"""
+    rng = np.random.default_rng(17)
+    arrays = []
+    for n in [0, 1, 2, 63, 64, 65, 66, 127, 128, 129, 200, 255, 256, 257, 511, 640, 1000, 1023, 1024, 1025, 1500, 3000, 9000]:
+        for kind in range(9):
+            a = np.zeros(n, dtype=mga.m128)
+            if kind == 0:
+                x = rng.integers(0, 1 << 62, size=n, dtype=np.uint64) * np.uint64(4)           # every byte differs
+            elif kind == 1:
+                x = rng.integers(40, 400, size=n).astype(np.uint64)                            # scores: one byte, many ties
+            elif kind == 2:
+                x = rng.integers(40, 12000, size=n).astype(np.uint64)                          # scores: two bytes
+            elif kind == 3:
+                x = (rng.integers(0, 6, size=n).astype(np.uint64) << np.uint64(33)) | rng.integers(0, 50000, size=n).astype(np.uint64)  # anchors: (segment, strand) | position
+            elif kind == 4:
+                x = np.full(n, 0x1234567890, dtype=np.uint64)                                  # all equal
+            elif kind == 5:
+                x = rng.integers(0, 3, size=n).astype(np.uint64) << np.uint64(56)              # the top byte only: three buckets, everything else ties
+            elif kind == 6:
+                x = (rng.integers(0, 256, size=n).astype(np.uint64) << np.uint64(24)) | rng.integers(0, 2, size=n).astype(np.uint64)  # a middle byte, then a byte five levels down
+            elif kind == 7:
+                x = np.sort(rng.integers(0, 1 << 40, size=n).astype(np.uint64))[::-1].copy()   # descending
+            else:
+                x = (rng.integers(0, 2, size=n).astype(np.uint64) << np.uint64(8)) | np.where(rng.random(n) < 0.9, 7, rng.integers(0, 256, size=n)).astype(np.uint64)  # one bucket of > 64 among small ones
+            a["x"], a["y"] = x, np.arange(n, dtype=np.uint64)
+            arrays.append(a)
+    got = mga.sort128x_batch(arrays)
+    for i, a in enumerate(arrays):
+        want = ora.sort128x(a.copy())
+        assert np.array_equal(got[i]["x"], want["x"]) and np.array_equal(got[i]["y"], want["y"]), (i, len(a), i % 9)
+
+
 @pytest.mark.parametrize("w,k", [(11, 17), (10, 19), (5, 15), (200, 27)])
 def test_sketch_long_sequences_in_pieces(ora, w, k):
     """sequences above 64 kb are sketched in pieces that warm up on the preceding w+k+64 bases (k odd); piece boundaries,
