@@ -362,6 +362,8 @@ int mga_lchain_batch(int n, const mg128_t *a, const int64_t *a_off, const mga_lc
 /* radix_sort_128x (ksort.h:112-162 through misc.c:9) as the chaining kernels run it: array i = a[a_off[i]..a_off[i+1]) is sorted in place by x with the
  * reference's exact permutation of equal keys -- one wavefront per array, the LDS form up to 1024 elements, the in-memory form beyond (tests). */
 int mga_sort128x_batch(int n, mg128_t *a, const int64_t *a_off);
+/* the dv:f: field of a GAF line as the device prints it (k_gaf.hip; format.c:200-203: "%.4f", "0" for zero): out = n x 8 bytes, NUL-padded (tests) */
+int mga_gaf_div_batch(int n, const float *div, char *out);
 
 /* mwf_wfa_auto's exact mode (miniwfa.c:380-435,603-615,824-828) for n independent problems:
  * target i = tseq[t_off[i]..t_off[i+1]), query i = qseq[q_off[i]..q_off[i+1]) (raw ASCII compare).

@@ -62,7 +62,7 @@ MG_M_CIGAR = 0x4000000
 
 KERNELS = ["k_sketch", "k_seed_count", "k_seed_fill", "k_lchain", "k_wfa_r[64]", "k_wfa_r[128]", "k_wfa_r[192]", "k_wfa_r[256]", "k_wfa_r[512]",
            "k_wfa_r[1024]", "k_wfa_r[2048]", "k_wfa[hbm4096]", "k_wfa[hbm32768]", "k_scan", "k_text", "k_gchain", "k_plan",
-           "k_wfa_w[16x4]", "k_wfa_w[32x2]", "k_wfa_w[64]", "k_wfa_w[128]", "k_wfa_w[192]", "k_wfa_w[256]", "k_wfa_tb", "k_gchain_p2", "k_gchain_p3"]
+           "k_wfa_w[16x4]", "k_wfa_w[32x2]", "k_wfa_w[64]", "k_wfa_w[128]", "k_wfa_w[192]", "k_wfa_w[256]", "k_wfa_tb", "k_gchain_p2", "k_gchain_p3", "k_gaf"]
 
 
 class stats_t(C.Structure):  # mga_stats_t
@@ -245,6 +245,16 @@ def lchain_batch(anchor_list, **kw):
     uu = _take(u, int(uoff[-1]), np.uint64)
     bb = _take(b, int(boff[-1]), m128)
     return [(uu[uoff[i]:uoff[i + 1]], bb[boff[i]:boff[i + 1]]) for i in range(n)]
+
+
+def gaf_div_batch(div):
+    """dv:f: text of each float as the device's GAF writer prints it -> list of bytes"""
+    L = load()
+    div = np.ascontiguousarray(div, dtype=np.float32)
+    out = np.zeros(len(div) * 8, dtype=np.uint8)
+    L.mga_gaf_div_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    _check(L.mga_gaf_div_batch(len(div), div.ctypes.data, out.ctypes.data), "mga_gaf_div_batch")
+    return [bytes(out[8 * i:8 * i + 8]).rstrip(b"\0") for i in range(len(div))]
 
 
 def sort128x_batch(arrays):

@@ -142,7 +142,7 @@ mg_idx_t *mga_idx_from_cat(gfa_t *g, const mg_idxopt_t *io, int n_threads, const
 	IDX_T("minimizer table (device)");
 	if (mga_dev_graph_upload(sc, g, mga_comp_table, &B->dev) < 0) { /* arcs + reverse complements: graph chaining runs on the device (k_gchain.hip) */
 		mga_dfree(B->dev.d_seg_len); mga_dfree(B->dev.d_gseq); mga_dfree(B->dev.d_gseq_off); mga_dfree(B->dev.d_tab); mga_dfree(B->dev.d_pos);
-		mga_dfree(B->dev.d_arc); mga_dfree(B->dev.d_arc_idx); mga_dfree(B->dev.d_gseq_rc); free(B->occ_hist); free(B);
+		mga_dfree(B->dev.d_arc); mga_dfree(B->dev.d_arc_idx); mga_dfree(B->dev.d_gseq_rc); mga_dfree(B->dev.d_gaf_seg); mga_dfree(B->dev.d_gaf_sseq); mga_dfree(B->dev.d_gaf_names); free(B->occ_hist); free(B);
 		return 0;
 	}
 	IDX_T("graph replica");
@@ -278,6 +278,7 @@ void mg_idx_destroy(mg_idx_t *gi)
 		mga_idx_stream_close(gi); /* pipeline threads, HIP streams and buffers of the single-batch entry points */
 		mga_dfree(gi->B->dev.d_tab); mga_dfree(gi->B->dev.d_pos); mga_dfree(gi->B->dev.d_seg_len); mga_dfree(gi->B->dev.d_gseq); mga_dfree(gi->B->dev.d_gseq_off);
 		mga_dfree(gi->B->dev.d_arc); mga_dfree(gi->B->dev.d_arc_idx); mga_dfree(gi->B->dev.d_gseq_rc);
+		mga_dfree(gi->B->dev.d_gaf_seg); mga_dfree(gi->B->dev.d_gaf_sseq); mga_dfree(gi->B->dev.d_gaf_names);
 		free(gi->B->occ_hist); free(gi->B->gaf_out);
 	}
 	if (gi->es) {

@@ -53,6 +53,7 @@ extern "C" int mga_dev_graph_upload(mga_sctx_t *sc, const gfa_t *g, const unsign
 		MGA_HIP_CHECK(hipGetLastError());
 		if (mga_ssync(sc) < 0) return -1;
 	}
+	if (mga_dev_gaf_names_upload(g, ix) < 0) return -1; // (GAF lines on the device, k_gaf.hip)
 	return 0;
 }
 

@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(64) k_seed_fill(mga_didx_t ix, int n, const mg
 												  const int64_t *__restrict__ a_off, mg128_t *__restrict__ a_all,
 												  const int64_t *__restrict__ mini_off, int32_t *__restrict__ mini_all, mg128_t *__restrict__ tmp_all)
 {
-	__shared__ klib_lds_t L;
+	__shared__ union { klib_lds_t big; klib_small_lds_t small; } L;
 	const int r = blockIdx.x, lane = threadIdx.x;
 	if (r >= n) return;
 	const int64_t base = mz_off[r];
@@ -123,7 +123,9 @@ __global__ void __launch_bounds__(64) k_seed_fill(mga_didx_t ix, int n, const mg
 		nmini += __popcll(m_kept);
 	}
 	__syncthreads();
-	klib_sort128x(a, n_a, (int32_t*)(tmp_all + a_off[r]), &L);
+	// radix_sort_128x (map-algo.c:189).  Round 6: up to 1024 anchors -- most 10 kb reads -- the sort runs its sequential part in LDS (dev_klibsort.h: klib_sort128x_small)
+	if (n_a <= KLIB_SMALL_CAP) klib_sort128x_small(a, (int32_t)n_a, tmp_all + a_off[r], &L.small);
+	else klib_sort128x(a, n_a, (int32_t*)(tmp_all + a_off[r]), &L.big);
 }
 
 extern "C" int mga_dev_seed_count(mga_sctx_t *sc, const mga_didx_t *ix, int n, const mg128_t *d_mz, const int64_t *d_mz_off, const int32_t *d_mz_cnt, int max_occ,

@@ -106,6 +106,7 @@ struct mga_batch_s {
 	int want_src;           /* ... and the targets of the gaps are spliced on the device from descriptors (align.h: mga_tpool_t::want_src) */
 	const mga_txt_res_t *txt_res; /* text-mode results, global chain order */
 	const char *txt_pool;
+	const char *gaf_dev; int64_t gaf_dev_len; /* the chunk's GAF lines as the device wrote them (k_gaf.hip), read order, back to back; NULL: the host formats */
 	/* stage-1 inputs, valid during mga_batch_chain() only */
 	const int32_t *n_mz, *rep_len, *mini_pos, *nu, *nb;
 	const int64_t *mini_off, *a_off;
@@ -860,15 +861,16 @@ typedef struct { /* one pipeline context: HIP stream + grow-only device and pinn
 			mga_dbuf_t plcnt, ploff, pltot, plsrc, plrev; /* gap list on the device (k_plan.hip) */
 			mga_dbuf_t lcord; /* k_lchain's launch order: reads by anchor count, most first */
 			mga_dbuf_t rq_a, rq_f, rq_p, rq_v, rq_t, rq_pri, rq_ys, rq_cut, rq_ord, rq_stat, rq_cnt; /* forward pass of the RMQ chainer on the device (k_rmq.hip), one read at a time */
+			mga_dbuf_t g_line, g_qn, g_qoff, g_len, g_off, g_out; /* whole GAF lines on the device (k_gaf.hip): line records, read names, line lengths / offsets, the text */
 		};
-		mga_dbuf_t dall[67];
+		mga_dbuf_t dall[73];
 	};
 	union {
-		struct { mga_hbuf_t h_b, h_u, h_mini, h_tseq, h_prob, h_pool, h_seq, h_ncig, h_cigoff, h_item, h_chain, h_vert, h_txtres, h_txtpool, h_gchdr, h_gcpool, h_lcpool, h_apool, h_plrev, h_ploff, h_lcord, h_rq, h_rqs, h_plsrc; }; /* pinned staging */
-		mga_hbuf_t hall[24];
+		struct { mga_hbuf_t h_b, h_u, h_mini, h_tseq, h_prob, h_pool, h_seq, h_ncig, h_cigoff, h_item, h_chain, h_vert, h_txtres, h_txtpool, h_gchdr, h_gcpool, h_lcpool, h_apool, h_plrev, h_ploff, h_lcord, h_rq, h_rqs, h_plsrc, h_gline, h_gqn, h_gout; }; /* pinned staging */
+		mga_hbuf_t hall[27];
 	};
 } pipe_ctx_t;
-_Static_assert(sizeof(((pipe_ctx_t*)0)->dall) == 67 * sizeof(mga_dbuf_t) && sizeof(((pipe_ctx_t*)0)->hall) == 24 * sizeof(mga_hbuf_t), "pipe_ctx_t: buffer lists out of sync");
+_Static_assert(sizeof(((pipe_ctx_t*)0)->dall) == 73 * sizeof(mga_dbuf_t) && sizeof(((pipe_ctx_t*)0)->hall) == 27 * sizeof(mga_hbuf_t), "pipe_ctx_t: buffer lists out of sync");
 
 #define MGA_MAX_PIPE 8
 
@@ -928,6 +930,40 @@ static int rq_dev_fwd_hook(void *ctx_, int n_reads, const int64_t *r_abs0, const
 }
 
 static void release_token_cb(void *a) { gpu_token_t **held = (gpu_token_t**)a; if (*held) { token_release(*held); *held = 0; } }
+
+/* ---- GAF lines on the device (k_gaf.hip) ----
+ * One record per line the reference's writer prints for the chunk (format.c:121-250), in print order: the printed chains of every read (in text mode exactly the chains with a
+ * text-kernel chain: chain_id >= 0), or the one line of an unmapped read under MG_M_SHOW_UNMAP.  Returns the number of lines; -1: a read of the chunk has chains but no plan
+ * (it was not chained here) -- the host then formats the chunk as before. */
+static int64_t gaf_lines_build(const mga_batch_t *b, int n, mga_gaf_line_t *line)
+{
+	int64_t nl = 0;
+	int i, k;
+	for (i = 0; i < n; ++i) {
+		const mg_gchains_t *gcs = b->gcs[i];
+		const read_plan_t *pl = &b->plan[i];
+		if (gcs == 0 || gcs->n_gc == 0) {
+			if (b->opt.flag & MG_M_SHOW_UNMAP) { mga_gaf_line_t *l = &line[nl++]; memset(l, 0, sizeof *l); l->read = i, l->chain = -1, l->qlen = b->qlens[i]; }
+			continue;
+		}
+		if (pl->chain_id == 0) return -1;
+		for (k = 0; k < gcs->n_gc; ++k) {
+			const mg_gchain_t *p = &gcs->gc[k];
+			mga_gaf_line_t *l;
+			if (pl->chain_id[k] < 0) continue; /* not printed (format.c:135-136) */
+			l = &line[nl++];
+			l->read = i, l->qlen = b->qlens[i];
+			l->chain = (int32_t)(pl->tid < 0 ? pl->chain_id[k] : b->dp_n_chain + b->tp_chain_base[pl->tid] + pl->chain_id[k]); /* device-planned chains first, then the pools' */
+			l->qs = p->qs, l->qe = p->qe, l->plen = p->plen, l->ps = p->ps, l->pe = p->pe;
+			l->mapq = (int32_t)p->mapq, l->n_anchor = p->n_anchor, l->score = p->score, l->subsc = p->subsc;
+			l->primary = p->id == p->parent, l->div = p->div;
+		}
+	}
+	return nl;
+}
+
+typedef struct { char *dst; const char *src; int64_t bytes; int T; } pcopy_t;
+static void pcopy_worker(void *data, int64_t t, int tid) { pcopy_t *c = (pcopy_t*)data; const int64_t b = c->bytes * t / c->T, e = c->bytes * (t + 1) / c->T; (void)tid; if (e > b) memcpy(c->dst + b, c->src + b, (size_t)(e - b)); }
 
 static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens, const char **seqs, const char **qnames, mg_gchains_t **gcs_out,
 					 const mg_mapopt_t *opt, int n_threads, const char *d_seq_res, const int64_t *q_off_res, int seqs_pinned, mga_stats_t *st, kstring_t *gaf_part, int lr_long, const gaf_sink_t *sink)
@@ -1350,12 +1386,43 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 					if (k >= 2) { mga_set_error("text kernel: output of %lld bytes exceeds the pool of %lld", (long long)txt_used, (long long)txt_cap); rc = -1; goto done; }
 					txt_cap = (int64_t)txt_used + ((int64_t)txt_used >> 4) + 4096;
 				}
-				CK(mga_hbuf_reserve(&P->h_txtres, (size_t)n_chain * sizeof(mga_txt_res_t) + 16)); CK(mga_hbuf_reserve(&P->h_txtpool, (size_t)txt_used + 16));
-				CK(mga_d2h_s(sc, P->h_txtres.p, P->txtres.p, (size_t)n_chain * sizeof(mga_txt_res_t))); CK(mga_d2h_s(sc, P->h_txtpool.p, P->txtpool.p, (size_t)txt_used));
+				CK(mga_hbuf_reserve(&P->h_txtres, (size_t)n_chain * sizeof(mga_txt_res_t) + 16));
+				CK(mga_d2h_s(sc, P->h_txtres.p, P->txtres.p, (size_t)n_chain * sizeof(mga_txt_res_t)));
+				/* Round 6: the whole LINES are written on the device (k_gaf.hip) -- name, coordinates, path column, tags in front of the two strings, every line at its place in
+				 * the chunk's text -- unless the job asks for what only the host's writer prints (per-vertex lines of -S / --write-mz) or the chains are chromosome-scale
+				 * (their walks have 10^5 vertices: one wavefront per line would fold them alone).  MGA_DEV_GAF=0: the host formats as in rounds 1-5 (A/B, tests). */
+				int64_t n_lines = -1;
+				if (gaf_part && B->dev.d_gaf_seg != 0 && !(opt->flag & (MG_M_WRITE_LCHAIN | MG_M_WRITE_MZ | MG_M_FRAG_MERGE)) && !(mg_dbg_flag & 0x8) && n_chain > 0 &&
+					(n_item + n_ops) / n_chain < 32768 && n_chain < 0x7fffffffLL && env_int("MGA_DEV_GAF", 1)) {
+					CK(mga_hbuf_reserve(&P->h_gline, (size_t)(n_chain + n) * sizeof(mga_gaf_line_t) + 64));
+					n_lines = gaf_lines_build(b, n, (mga_gaf_line_t*)P->h_gline.p);
+				}
+				if (n_lines > 0) {
+					int64_t qn_bytes = 0, tot_b = 0, *qo;
+					char *qn;
+					for (i = 0; i < n; ++i) qn_bytes += qnames ? (int64_t)strlen(qnames[i]) : 1;
+					CK(mga_hbuf_reserve(&P->h_gqn, (size_t)(n + 1) * 8 + (size_t)qn_bytes + 64));
+					qo = (int64_t*)P->h_gqn.p, qn = (char*)(qo + n + 1);
+					for (i = 0, qn_bytes = 0; i < n; ++i) { const char *nm = qnames ? qnames[i] : "*"; const size_t l = strlen(nm); qo[i] = qn_bytes; memcpy(qn + qn_bytes, nm, l); qn_bytes += (int64_t)l; }
+					qo[n] = qn_bytes;
+					CK(mga_dbuf_reserve(&P->g_line, (size_t)n_lines * sizeof(mga_gaf_line_t) + 64)); CK(mga_dbuf_reserve(&P->g_qoff, (size_t)(n + 1) * 8)); CK(mga_dbuf_reserve(&P->g_qn, (size_t)qn_bytes + 64));
+					CK(mga_dbuf_reserve(&P->g_len, (size_t)(n_lines + 1) * 4)); CK(mga_dbuf_reserve(&P->g_off, (size_t)(n_lines + 2) * 8));
+					CK(mga_h2d_s(sc, P->g_line.p, P->h_gline.p, (size_t)n_lines * sizeof(mga_gaf_line_t))); CK(mga_h2d_s(sc, P->g_qoff.p, qo, (size_t)(n + 1) * 8)); CK(mga_h2d_s(sc, P->g_qn.p, qn, (size_t)qn_bytes + 1));
+					CK(mga_dev_gaf(sc, &B->dev, (int)n_lines, (const mga_gaf_line_t*)P->g_line.p, (const char*)P->g_qn.p, (const int64_t*)P->g_qoff.p, opt->flag, (const mga_txt_chain_t*)P->chain.p,
+								   (const uint32_t*)P->vert.p, (const mga_txt_res_t*)P->txtres.p, (const char*)P->txtpool.p, (int32_t*)P->g_len.p, 0, 0));
+					CK(mga_dev_scan_i32_to_i64(sc, (const int32_t*)P->g_len.p, n_lines, (int64_t*)P->g_off.p));
+					CK(mga_d2h_s(sc, &tot_b, (int64_t*)P->g_off.p + n_lines, 8)); CK(mga_ssync(sc));
+					CK(mga_dbuf_reserve(&P->g_out, (size_t)tot_b + 64)); CK(mga_hbuf_reserve(&P->h_gout, (size_t)tot_b + 64));
+					CK(mga_dev_gaf(sc, &B->dev, (int)n_lines, (const mga_gaf_line_t*)P->g_line.p, (const char*)P->g_qn.p, (const int64_t*)P->g_qoff.p, opt->flag, (const mga_txt_chain_t*)P->chain.p,
+								   (const uint32_t*)P->vert.p, (const mga_txt_res_t*)P->txtres.p, (const char*)P->txtpool.p, (int32_t*)P->g_len.p, (const int64_t*)P->g_off.p, (char*)P->g_out.p));
+					if (tot_b > 0) CK(mga_d2h_s(sc, P->h_gout.p, P->g_out.p, (size_t)tot_b));
+					b->gaf_dev = (const char*)P->h_gout.p, b->gaf_dev_len = tot_b;
+				} else if (n_lines == 0) b->gaf_dev = "", b->gaf_dev_len = 0; /* (nothing of this chunk is printed) */
+				else { CK(mga_hbuf_reserve(&P->h_txtpool, (size_t)txt_used + 16)); CK(mga_d2h_s(sc, P->h_txtpool.p, P->txtpool.p, (size_t)txt_used)); }
 				CK(mga_ssync(sc));
 				for (k = 0; k < n_chain; ++k)
 					if (((const mga_txt_res_t*)P->h_txtres.p)[k].status != 0) { mga_set_error("text kernel: stitched CIGAR inconsistent with the chain coordinates (galign.c:140), chain %ld", (long)k); rc = -1; goto done; }
-				b->txt_res = (const mga_txt_res_t*)P->h_txtres.p, b->txt_pool = (const char*)P->h_txtpool.p;
+				b->txt_res = (const mga_txt_res_t*)P->h_txtres.p, b->txt_pool = b->gaf_dev ? 0 : (const char*)P->h_txtpool.p;
 			} else {
 				CK(mga_hbuf_reserve(&P->h_ncig, (size_t)n_prob * 4 + 16)); CK(mga_hbuf_reserve(&P->h_cigoff, (size_t)(n_prob + 1) * 8)); CK(mga_hbuf_reserve(&P->h_pool, (size_t)n_ops * 4 + 16));
 				CK(mga_d2h_s(sc, P->h_ncig.p, P->ncig.p, (size_t)n_prob * 4)); CK(mga_d2h_s(sc, P->h_cigoff.p, P->cigoff.p, (size_t)(n_prob + 1) * 8));
@@ -1378,6 +1445,27 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 		double tg = mga_wtime();
 		int direct = 0;
 		w.b = b, w.n = n, w.T = n_threads, w.part = gaf_part, w.mode = 0, w.bytes = w.off = 0, w.dst = 0;
+		if (b->gaf_dev) { /* the lines came from the device: straight to their place in the job's output if this chunk is the one the output waits for, else into the chunk's pieces */
+			pcopy_t pc;
+			pc.src = b->gaf_dev, pc.bytes = b->gaf_dev_len, pc.T = n_threads, pc.dst = 0;
+			if (sink && env_int("MGA_GAF_DIRECT", 1) && sink->try_reserve(sink->ctx, pc.bytes, &pc.dst)) {
+				mga_parallel_for(n_threads, n_threads, pcopy_worker, &pc);
+				sink->commit(sink->ctx, pc.bytes);
+				st->gaf_bytes += pc.bytes;
+			} else { /* piece t takes the bytes [bytes t / T, bytes (t + 1) / T): the pieces are concatenated in order, wherever a line is cut */
+				int t_;
+				for (t_ = 0; t_ < n_threads; ++t_) {
+					const int64_t pb = pc.bytes * t_ / n_threads, pe = pc.bytes * (t_ + 1) / n_threads;
+					kstring_t *out = &gaf_part[t_];
+					if (pe - pb > 0xfffffff0LL) { mga_set_error("more than 4 GB of GAF text in one output piece: use a smaller -K or more threads"); rc = -1; goto done; }
+					if ((size_t)(pe - pb) + 1 > out->m) { size_t cap; char *p = strbuf_get((size_t)(pe - pb) + 1, &cap); if (cap > 0xfffffff0u) cap = 0xfffffff0u; free(out->s); out->s = p, out->m = (unsigned)cap; }
+					memcpy(out->s, pc.src + pb, (size_t)(pe - pb));
+					out->l = (unsigned)(pe - pb), out->s[out->l] = 0;
+				}
+			}
+			for (i = 0; i < n; ++i) { mg_gchain_free(b->gcs[i]); b->gcs[i] = 0; gcs_out[i] = 0; }
+			direct = 1;
+		} else
 		if (sink && b->txt_res && env_int("MGA_GAF_DIRECT", 1)) { /* straight to the lines' place in the job's output, if this chunk is what the output waits for */
 			int64_t *bo = MGA_CALLOC(int64_t, 2 * (size_t)n_threads + 2), tot_b = 0;
 			int t_;

@@ -74,7 +74,7 @@ void mga_hbuf_free(mga_hbuf_t *b);
 
 /* per-kernel HIP-event timing on the launch stream (bench.py reads it through mga_prof_get) */
 enum { MGA_K_SKETCH = 0, MGA_K_SEED_COUNT, MGA_K_SEED_FILL, MGA_K_LCHAIN, MGA_K_WFA0 /* +tier: 0-2 single-wave register tiers (band 64,128,192), 3-6 multi-wave register tiers (256..2048), 7-8 HBM tiers */, MGA_K_SCAN = MGA_K_WFA0 + 9, MGA_K_TEXT, MGA_K_GCHAIN, MGA_K_PLAN,
-	   MGA_K_WFAW0 /* +0..5: windowed tiers of 16 (4 problems per wave), 32 (2), 64, 128, 192, 256 diagonals (k_wfa_w.hip) */, MGA_K_WFATB = MGA_K_WFAW0 + 6 /* their traceback */, MGA_K_GCHAIN2 /* graph chaining, three-kernel form: part 2 (a wavefront per bridge) */, MGA_K_GCHAIN3 /* part 3; part 1 counts as MGA_K_GCHAIN */, MGA_K_N };
+	   MGA_K_WFAW0 /* +0..5: windowed tiers of 16 (4 problems per wave), 32 (2), 64, 128, 192, 256 diagonals (k_wfa_w.hip) */, MGA_K_WFATB = MGA_K_WFAW0 + 6 /* their traceback */, MGA_K_GCHAIN2 /* graph chaining, three-kernel form: part 2 (a wavefront per bridge) */, MGA_K_GCHAIN3 /* part 3; part 1 counts as MGA_K_GCHAIN */, MGA_K_GAF /* whole GAF lines (k_gaf.hip) */, MGA_K_N };
 #define MGA_WFW_N 6         /* windowed tiers */
 #define MGA_WFA_N_TIER 9    /* register + HBM tiers (k_wfa_r.hip 0-6, k_wfa.hip 7-8) */
 #define MGA_WFA_N_SLOT 11   /* rungs of the ladder: W0-W5, R4-R6, H0-H1 (MGA_WFA_LADDER=old: R0-R6, H0-H1) */
@@ -113,6 +113,9 @@ typedef struct {
 	void *d_arc;
 	uint64_t *d_arc_idx;
 	char *d_gseq_rc;         /* reverse complement of every segment at the same offsets as d_gseq */
+	/* names and stable-sequence coordinates for the GAF lines written on the device (k_gaf.hip) */
+	void *d_gaf_seg, *d_gaf_sseq;
+	char *d_gaf_names;
 } mga_didx_t;
 
 /* collect_matches (map-algo.c:58-91), pass 1: probe every minimizer.  Flat per-minimizer outputs
@@ -214,6 +217,21 @@ int mga_dev_text_tables(const unsigned char *comp, const unsigned char *nt4); /*
 int mga_dev_text(mga_sctx_t *sc, int n_chain, const mga_txt_chain_t *d_chain, const mga_cigitem_t *d_item, int64_t n_vert, const uint32_t *d_vert,
 				 const mga_didx_t *ix, const char *d_reads, int64_t n_el_max, const int32_t *d_ncig, const int64_t *d_cigoff, const uint32_t *d_ord,
 				 mga_txt_res_t *d_res, char *d_pool, int64_t pool_cap, unsigned long long *d_pool_used);
+
+/* ---- whole GAF lines on the device (k_gaf.hip): mg_write_gaf, format.c:121-250 ---- */
+typedef struct {
+	int32_t read;             /* read of the chunk: its name (d_qnames + d_qname_off[read]) */
+	int32_t chain;            /* the text kernel's chain: walk, cg:Z / ds:Z, mlen / blen; -1: the line of an unmapped read (MG_M_SHOW_UNMAP) */
+	int32_t qlen, qs, qe, plen, ps, pe;
+	int32_t mapq, n_anchor, score, subsc;
+	int32_t primary;          /* tp:A:P (id == parent) or tp:A:S */
+	float div;                /* dv:f:, printed when 0 <= div <= 1 */
+} mga_gaf_line_t;
+int mga_dev_gaf_names_upload(const gfa_t *g, mga_didx_t *ix);
+int mga_dev_gaf_div(mga_sctx_t *sc, int n, const float *d_div, char *d_out); /* (stage test) dv:f: text of n values, 8 bytes each */
+/* d_out == NULL: d_len[i] = bytes of line i; else: line i at d_out + d_off[i].  Lines are the caller's: printed chains of the chunk in read order */
+int mga_dev_gaf(mga_sctx_t *sc, const mga_didx_t *ix, int n_lines, const mga_gaf_line_t *d_line, const char *d_qnames, const int64_t *d_qname_off, uint64_t flag,
+				const mga_txt_chain_t *d_chain, const uint32_t *d_vert, const mga_txt_res_t *d_tres, const char *d_tpool, int32_t *d_len, const int64_t *d_off, char *d_out);
 
 /* ---- graph chaining on the device (k_gchain.hip, gc_core.h): from the chains of k_lchain to filtered graph chains ---- */
 typedef struct { int32_t n_gc, n_lc, n_a, status; int64_t gc_off, lc_off, a_off; } mga_gc_hdr_t; /* per read: records at gc_pool + gc_off, lc_pool + lc_off, anchors at a_pool + a_off */

@@ -168,6 +168,19 @@ extern "C" int mga_seed_batch(const mg_idx_t *gi, int n, const mg128_t *mz, cons
 	return 0;
 }
 
+extern "C" int mga_gaf_div_batch(int n, const float *div, char *out)
+{
+	if (mga_dev_init() < 0) return -1;
+	mga_sctx_t *SC = mga_sctx_default();
+	if (SC == 0) return -1;
+	if (n <= 0) return 0;
+	dptr d_div, d_out;
+	if (!d_div.alloc((size_t)n * 4 + 16) || !d_out.alloc((size_t)n * 8 + 16)) return -1;
+	if (mga_h2d(d_div.p, div, (size_t)n * 4) < 0 || mga_dev_gaf_div(SC, n, d_div.as<float>(), d_out.as<char>()) < 0) return -1;
+	if (mga_ssync(SC) < 0 || mga_d2h(out, d_out.p, (size_t)n * 8) < 0) return -1;
+	return 0;
+}
+
 extern "C" int mga_sort128x_batch(int n, mg128_t *a, const int64_t *a_off)
 {
 	if (mga_dev_init() < 0) return -1;

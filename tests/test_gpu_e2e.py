@@ -132,12 +132,16 @@ def test_device_text_equals_host_text_and_reference(monkeypatch, target):
     G = mga.Graph(graph, preset="lr", cigar=True, n_threads=8)
     R = mga.Reads(reads)
     dev = mga.map_reads(G, R, n_threads=8)
+    monkeypatch.setenv("MGA_DEV_GAF", "0")   # round 6: the whole lines come from the device (k_gaf.hip); 0 = the host formats the columns and copies cg / ds behind them
+    dev_hostlines = mga.map_reads(G, R, n_threads=8)
+    monkeypatch.delenv("MGA_DEV_GAF")
     monkeypatch.setenv("MGA_HOST_TEXT", "1")
     host = mga.map_reads(G, R, n_threads=8)
     R.close()
     G.close()
     assert dev.count(b"\n") > 1000 and b"\tds:Z:" in dev
     assert sum(1 for l in dev.split(b"\n") if l and l.split(b"\t")[4] == b"-") > 100   # reverse-strand lines are exercised
+    assert dev == dev_hostlines
     assert dev == host
     if need_ref() is None:   # (asserts: a GPU box without the reference binary FAILS these tests)
         ref_out = os.path.join(d, "ref.gaf")
@@ -692,7 +696,12 @@ OPTION_SETS = [
      None, dict(chn_pen_gap=0.5, max_lc_skip=10, max_lc_iter=1000, gdp_max_ed=2000, max_gc_skip=10, max_gap_pre=500, ref_bonus=5), 0),
     ("rmq_primary", ["--rmq=yes"], None, None, 0x8000),
     ("write_mz", ["--write-mz"], None, None, 0x1000000 | 0x800000),
-    ("frag_len", ["-F", "40000"], None, dict(max_frag_len=40000), 0),     # per-read reference gap max(F - qlen, max_gap) in the DP (map-algo.c:383-386)
+    ("frag_len", ["-F", "40000"], None, dict(max_frag_len=40000), 0),
+    # the forms of the path column on the device's GAF writer (k_gaf.hip; the sets with -S / --write-mz above take the host's writer): vertices by name, no compact
+    # form, secondary chains + the lines of unmapped reads with the stable-sequence intervals
+    ("vc", ["--vc"], None, None, 0x800),
+    ("no_comp_path", ["--no-comp-path"], None, None, 0x200000),
+    ("2nd_unmap", ["--secondary=yes", "--show-unmap=yes", "-p", "0.5", "-N", "3"], None, dict(pri_ratio=0.5, best_n=3), 0x2000 | 0x100000),     # per-read reference gap max(F - qlen, max_gap) in the DP (map-algo.c:383-386)
 ]
 
 

@@ -325,6 +325,23 @@ def test_lchain_synthetic_anchor_sets(ora, pair, win, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_gaf_div_text():
+    """dv:f: as the device's GAF writer prints it (k_gaf.hip: a float times 10^4 is exact in a double, rounded half-to-even) against "%.4f" of the same float -- random
+    values, the decimal ties a float can hit exactly (odd multiples of 1/32 ... 1/4096: x.xxxx5 with nothing behind it), values next to them, the ends of [0, 1]"""
+    rng = np.random.default_rng(5)
+    vals = [0.0, 1.0, 0.5, 0.25, 1e-7, 4.9e-5, 5.1e-5, 0.99995, 0.999949, 0.99996, 1.0 - 2.0 ** -24]
+    for sh in range(5, 13):
+        vals += [m / 2.0 ** sh for m in range(1, 2 ** sh, 2) if m < 600]
+    ties = np.array(vals, dtype=np.float32)
+    near = np.concatenate([np.nextafter(ties, np.float32(0)), np.nextafter(ties, np.float32(2))])
+    allv = np.concatenate([ties, near[(near >= 0) & (near <= 1)], rng.random(20000).astype(np.float32), (rng.random(5000) * 0.2).astype(np.float32)])
+    got = mga.gaf_div_batch(allv)
+    for v, g in zip(allv.tolist(), got):
+        want = b"0" if v == 0.0 else ("%.4f" % v).encode()
+        assert g == want, (v, g, want)
+
+
+@pytest.mark.gpu
 def test_device_klib_sort(ora):
     """the kernels' radix_sort_128x (dev_klibsort.h) against the restatement pinned to the reference's: the order it leaves EQUAL keys in is observable (chain ends of equal
     score, anchors of equal x), so y carries each element's original place and must come out where klib puts it.  Sizes around the insertion-sort limit (64), the LDS form's
