@@ -225,7 +225,6 @@ __device__ __forceinline__ void klib_sort128x_small(mg128_t *a, int32_t n, mg128
 					const int32_t st = be - c;
 					const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
 					int32_t rank = 0;
-					#pragma unroll 2
 					for (int j = 0; j < np; ++j) {
 						const uint64_t kj = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(khi, j) << 32 | (uint32_t)__builtin_amdgcn_readlane(klo, j);
 						const int32_t sj = __builtin_amdgcn_readlane(st, j);

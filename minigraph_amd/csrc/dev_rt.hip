@@ -103,7 +103,7 @@ extern "C" void mga_sctx_destroy(mga_sctx_t *sc)
 	mga_dbuf_free(&sc->wfa_cnt);
 	mga_dbuf_free(&sc->scan_tmp); mga_dbuf_free(&sc->txt_cnt); mga_dbuf_free(&sc->txt_off); mga_dbuf_free(&sc->txt_vwb); mga_dbuf_free(&sc->txt_el);
 	mga_dbuf_free(&sc->wfa_list[0]); mga_dbuf_free(&sc->wfa_list[1]); mga_dbuf_free(&sc->wfa_key); mga_dbuf_free(&sc->wfa_ctl); mga_dbuf_free(&sc->wfa_fb);
-	mga_dbuf_free(&sc->fb_prob); mga_dbuf_free(&sc->fb_res);
+	mga_dbuf_free(&sc->fb_prob); mga_dbuf_free(&sc->fb_res); mga_dbuf_free(&sc->sk_planes);
 	mga_dbuf_free(&sc->gc_arena[0]); mga_dbuf_free(&sc->gc_arena[1]); mga_dbuf_free(&sc->gc_split);
 	for (int i = 0; i < MGA_WFA_MAX_TIER; ++i) { (void)hipStreamDestroy((hipStream_t)sc->tier_stream[i]); (void)hipEventDestroy((hipEvent_t)sc->ev_done[i]); }
 	(void)hipEventDestroy((hipEvent_t)sc->ev_ready); (void)hipEventDestroy((hipEvent_t)sc->ev_sync);

@@ -1064,6 +1064,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 		h_mzoff[n] = n_mz; /* capacity of the chunk */
 		CK(mga_h2d_s(sc, P->mzoff.p, h_mzoff, (size_t)(n + 1) * 8));
 		CK(mga_dbuf_reserve(&P->mz, (size_t)n_mz * 16 + 16));
+		if (env_int("MGA_SKETCH_2BIT", 0)) CK(mga_dev_pack2(sc, d_seq, q_off[n])); /* A/B: the reads as bit planes for the sketch (k_sketch.hip; DESIGN.md has the measurement) */
 		CK(mga_dev_sketch(sc, n, d_seq, (const int64_t*)P->qoff.p, 0, gi->w, gi->k, (int32_t*)P->cnt.p, (const int64_t*)P->mzoff.p, (mg128_t*)P->mz.p));
 		CK(mga_d2h_s(sc, h_nmz, P->cnt.p, (size_t)n * 4)); CK(mga_ssync(sc));
 		for (i = 0; i < n; ++i) if (h_nmz[i] > qlens[i] / 2 + 64) overflow = 1;

@@ -52,6 +52,7 @@ typedef struct mga_sctx_s {
 	mga_dbuf_t gc_arena[2];    /* per-wave scratch arenas of k_gchain: 1 MiB x resident waves, and the large tier for the reads that outgrow that */
 	int wfa_uncapped;          /* set while the ladder runs the chained fallback's sub-problems: no 1e8-cell cap, unbounded last tier */
 	mga_dbuf_t fb_prob, fb_res; /* sub-problems of the chained fallback and their results */
+	mga_dbuf_t sk_planes; const void *sk_planes_src; /* the packed (bit-plane) form of a read buffer (mga_dev_pack2) and the buffer it was made from: sketch launches on that buffer read it */
 	const int32_t *lc_order;   /* launch order of the NEXT mga_dev_lchain call on this context (device array of n read numbers; consumed by the call) */
 } mga_sctx_t;
 static inline void mga_dev_lchain_order(mga_sctx_t *sc, const int32_t *d_order) { sc->lc_order = d_order; }
@@ -93,6 +94,8 @@ int mga_dev_sketch_items(mga_sctx_t *sc, int n_items, const int32_t *d_items, co
 int mga_dev_scan_i32_to_i64(mga_sctx_t *sc, const int32_t *d_cnt, int64_t n, int64_t *d_off);
 
 /* ---- sketch (k_sketch.hip) ---- */
+/* the read buffer as bit planes (3 x 64 bits per 64 bytes: low bit, high bit, is-ACGT): the sketch launches on d_seq that follow on this context read it instead of the bytes */
+int mga_dev_pack2(mga_sctx_t *sc, const char *d_seq, int64_t n_bytes);
 /* pass 1 (d_mz == NULL): d_cnt[i] = number of minimizers of sequence i.
  * pass 2: writes minimizers of sequence i at d_mz + d_mz_off[i]. */
 int mga_dev_sketch(mga_sctx_t *sc, int n, const char *d_seq, const int64_t *d_off, const uint32_t *d_rid, int w, int k,

@@ -35,6 +35,8 @@ extern "C" int mga_sketch_batch(int n, const char *seq, const int64_t *off, cons
 	if (rid && !d_rid.alloc(n * 4)) return -1;
 	if (mga_h2d(d_seq.p, seq, tot) < 0 || mga_h2d(d_off.p, off, (n + 1) * 8) < 0) return -1;
 	if (rid && mga_h2d(d_rid.p, rid, n * 4) < 0) return -1;
+	struct planes_guard { mga_sctx_t *sc; ~planes_guard() { sc->sk_planes_src = 0; } } pg{SC}; // (the packed form belongs to d_seq, which dies with this call)
+	{ const char *e = getenv("MGA_SKETCH_2BIT"); if (e && atoi(e) > 0 && mga_dev_pack2(SC, d_seq.as<char>(), tot) < 0) return -1; } // the sketch reads bit planes instead of bytes (k_sketch.hip)
 	// long sequences are sketched in pieces (k odd: see k_sketch.hip); piece offsets are folded back into per-sequence offsets
 	const int32_t PIECE = 1 << 16;
 	std::vector<int32_t> items, first_item(n + 1);

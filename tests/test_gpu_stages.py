@@ -34,10 +34,32 @@ def mutate(rng, s, err):
     return bytes(out)
 
 
-@pytest.mark.parametrize("w,k", [(11, 17), (10, 19), (10, 21), (5, 4), (3, 6), (1, 5), (16, 28), (200, 15), (255, 28)])
-def test_sketch_parity(ora, w, k):
+SKETCH_FORMS = ["planes", "v1", "2bit"]
+
+
+def sketch_form(monkeypatch, form):
+    """round 6: k_sketch takes its k-mers from bit planes (ballots of the step's codes; the LDS code ring only around ambiguous bases and at a sequence's start) -- "planes", the
+    default; "v1" is the kernel of rounds 1-5 (MGA_SKETCH_V1=1), "2bit" reads the bases themselves as packed bit planes made by k_pack2 (MGA_SKETCH_2BIT=1): same minimizers"""
+    if form == "v1":
+        monkeypatch.setenv("MGA_SKETCH_V1", "1")
+    elif form == "2bit":
+        monkeypatch.setenv("MGA_SKETCH_2BIT", "1")
+
+
+@pytest.mark.parametrize("form", SKETCH_FORMS)
+@pytest.mark.parametrize("w,k", [(11, 17), (10, 19), (10, 21), (5, 4), (3, 6), (1, 5), (16, 28), (200, 15), (255, 28), (63, 27), (64, 27)])
+def test_sketch_parity(ora, w, k, form, monkeypatch):
+    sketch_form(monkeypatch, form)
     rng = np.random.default_rng(1000 + w * 31 + k)
     seqs = []
+    for gap in (40, 70, 200, 700):   # sparse ambiguous bases: the steps switch between the plane form and the code ring, with k - 1 .. 64 real bases in between
+        s = bytearray(rand_seq(rng, 4000))
+        pos = int(rng.integers(0, gap))
+        while pos < len(s):
+            s[pos:pos + int(rng.integers(1, 3))] = b"N"
+            pos += int(rng.integers(max(1, gap // 2), gap * 2))
+        seqs.append(bytes(s))
+        seqs.append(bytes(s[:64 + k]) + b"N" + bytes(s[:200]))
     for n in [1, 2, k - 1, k, k + w - 2, k + w - 1, k + w, 63, 64, 65, 127, 128, 129, 300, 2000, 10000]:
         if n > 0:
             for alphabet in [b"ACGT", b"ACGTN", b"AC", b"A", b"ACGTacgtNnUuRY"]:
@@ -51,7 +73,9 @@ def test_sketch_parity(ora, w, k):
         assert np.array_equal(got[i], exp), (w, k, len(s), s[:40])
 
 
-def test_sketch_many_reads(ora):
+@pytest.mark.parametrize("form", SKETCH_FORMS)
+def test_sketch_many_reads(ora, form, monkeypatch):
+    sketch_form(monkeypatch, form)
     rng = np.random.default_rng(5)
     seqs = [rand_seq(rng, int(rng.integers(9000, 11000))) for _ in range(300)]
     got = mga.sketch_batch(seqs, 11, 17)
@@ -378,8 +402,10 @@ def test_device_klib_sort(ora):
         assert np.array_equal(got[i]["x"], want["x"]) and np.array_equal(got[i]["y"], want["y"]), (i, len(a), i % 9)
 
 
+@pytest.mark.parametrize("form", SKETCH_FORMS)
 @pytest.mark.parametrize("w,k", [(11, 17), (10, 19), (5, 15), (200, 27)])
-def test_sketch_long_sequences_in_pieces(ora, w, k):
+def test_sketch_long_sequences_in_pieces(ora, w, k, form, monkeypatch):
+    sketch_form(monkeypatch, form)
     """sequences above 64 kb are sketched in pieces that warm up on the preceding w+k+64 bases (k odd); piece boundaries,
     N runs across them and low-complexity stretches must not show"""
     rng = np.random.default_rng(77 + w + k)
