@@ -38,7 +38,7 @@
 //       exactly like the first pass; more than 64 candidates also defers the read to the host.
 // [measured] the rescue fires on ~48 % of 10 kb reads and cost 46 us/read of host CPU, a third of the host budget.
 // profiling aid (MGA_LC_PROF=1): cycles per phase summed over reads: [0] first-pass DP, [1] its backtrack + compaction, [2] rescue sort, [3] rescue DP, [4] rescue backtrack
-__device__ unsigned long long g_lc_prof[16]; // [8..12] counts: anchors, chain ends, walks, walk steps, backtracks
+__device__ unsigned long long g_lc_prof[32]; // [8..12] counts: anchors, chain ends, walks, walk steps, backtracks
 __device__ int g_lc_prof_on;
 // (a read's cycles are summed in LDS and added to the global counters once, when the read is done: [measured, round 6] one atomicAdd per tick from every wavefront on ONE
 // address made the ticks inside the walk -- 15 per read -- cost more than the kernel: every barrier waits for the wave's outstanding atomics too)
@@ -74,11 +74,13 @@ __device__ __forceinline__ int32_t lc_score(uint64_t xi, uint64_t yi, uint64_t x
 }
 
 struct lc_ws_t { int32_t *f, *p, *v, *t; mg128_t *z; };
+#define LC_RQ_LDS 336 // chained anchors up to which the rescue's DP keeps y, priority and marks of every anchor in LDS (5 216 bytes with its candidate lists)
 // the LDS of a read's wavefront, one phase after the other: the marks of the DP's register window, the two forms of the klib sort, the candidate lists of the rescue's DP.
 // 5 344 bytes: 28 single-wave workgroups (7 per SIMD, what the registers allow) fit a CU's 160 KB.
 struct lc_lds_t {
-	union { int32_t tm[128]; klib_lds_t big; klib_small_lds_t small; struct { int32_t cand_j[64], cand_y[64], sorted_j[64]; } rq; };
-	unsigned long long prof[16]; // MGA_LC_PROF: this read's cycles per phase
+	union { int32_t tm[128]; klib_lds_t big; klib_small_lds_t small; struct { int32_t cand_j[64], cand_y[64], sorted_j[64]; } rq;
+	        struct { double pri[LC_RQ_LDS]; int32_t y[LC_RQ_LDS]; uint16_t t[LC_RQ_LDS]; int32_t cand_y[64]; uint16_t cand_j[64], sorted_j[64]; } rql; /* lc_dp_rmq_lds */ };
+	unsigned long long prof[32]; // MGA_LC_PROF: this read's cycles per phase
 };
 __device__ __forceinline__ void lc_sort(mg128_t *a, int32_t n, mg128_t *tmp, int32_t *stk, lc_lds_t *L) // klib's radix_sort_128x, permutation and all; tmp: n elements of scratch
 {
@@ -379,6 +381,143 @@ __device__ __forceinline__ void lc_dp_w(const mg128_t *__restrict__ a, int32_t n
 		if (nfill < 64) ++nfill;
 	}
 	__syncthreads(); // (every store has landed before the backtrack reads f / p / v)
+}
+
+// ---------------- the same with y, priority and marks of every anchor in LDS (round 6; n <= LC_RQ_LDS) ----------------
+// [measured, round 6, profiles/r06f_lchain_phases.txt] lc_dp_rmq() below was 43 % of k_lchain once the first pass and the backtrack had lost their round trips: per anchor
+// ~20 dependent trips to global memory -- the anchor, the first anchor of its x-group, the priorities of the group that became available (store -> barrier), the two windows'
+// first anchors, a block loop over the window for the range minimum and another for the inner candidates, the minimum's record, the candidates' records, the marks
+// (store -> barrier -> load), v of the winner, the result (store -> barrier).  The rescue re-chains a read's CHAINED anchors: 250 on average, so everything the two window
+// loops read fits the wavefront's LDS: y and the priority of every anchor (the priority of anchor i is stored when f[i] is known -- the loops only look below i0, so an anchor
+// whose x-group is still open is never seen early), the marks as 16-bit anchor numbers.  Left in global memory: the anchors' records and f / p / v, read once per anchor for
+// the minimum and once for the <= 64 candidates (p, f, v travel with the record; the winner's v comes from the lane that holds it), and the windows' first anchors, re-read
+// only when a window moves.  Same values, same ties (-> false: the host's tree), same candidate cap.
+__device__ __forceinline__ bool lc_dp_rmq_lds(const mg128_t *__restrict__ a, int32_t n, const lc_rescue_t &R, lc_ws_t W, lc_lds_t *L, int lane)
+{
+	double *lpri = L->rql.pri;
+	int32_t *ly = L->rql.y, *cand_y = L->rql.cand_y;
+	uint16_t *lt = L->rql.t, *cand_j = L->rql.cand_j, *sorted_j = L->rql.sorted_j;
+	int32_t *f = W.f, *p = W.p, *v = W.v;
+	int32_t max_dist = R.max_dist, max_dist_inner = R.max_dist_inner;
+	if (max_dist < R.bw) max_dist = R.bw;
+	if (max_dist_inner <= 0 || max_dist_inner >= max_dist) max_dist_inner = 0;
+	if (n > R.cap) return false; // the reference then evicts by tree size
+	for (int32_t i = lane; i < n; i += 64) lt[i] = 0xffff;
+	mga_wave_sync();
+	int32_t i0 = 0, st = 0, st_in = 0;
+	mg128_t cur = a[0];
+	uint64_t x_i0 = cur.x, xs_st = cur.x, xs_in = cur.x; // x of the anchors i0, st, st_in
+	uint64_t xs_st1 = n > 1 ? a[1].x : cur.x, xs_in1 = xs_st1; // ... and of st + 1, st_in + 1: a window that moves by one anchor per step (the usual case) waits for nothing
+	for (int32_t i = 0; i < n; ++i) {
+		const uint64_t xi = cur.x, yi = cur.y;
+		const int32_t yi32 = (int32_t)yi;
+		if (i + 1 < n) cur = a[i + 1]; // (in flight while this anchor is chained)
+		if (i0 < i && x_i0 != xi) i0 = i, x_i0 = xi; // anchors with a smaller x are available now (lchain.c:279-293); their priorities are in LDS already
+		// windows (lchain.c:294-312); the trees hold [st, i0) and [st_in, i0)
+		while (st < i) { if (xi >> 32 != xs_st >> 32 || xi > xs_st + (uint64_t)(int64_t)max_dist) { ++st; xs_st = xs_st1; xs_st1 = st + 1 < n ? a[st + 1].x : xi; } else break; }
+		if (max_dist_inner > 0)
+			while (st_in < i) { if (xi >> 32 != xs_in >> 32 || xi > xs_in + (uint64_t)(int64_t)max_dist_inner) { ++st_in; xs_in = xs_in1; xs_in1 = st_in + 1 < n ? a[st_in + 1].x : xi; } else break; }
+		int32_t max_f = (int32_t)(yi >> 32 & 0xff), max_j = -1, max_vj = 0;
+		// (1) range-minimum query: keys in [(y_i - max_dist, INT32_MAX), (y_i - 1, 0)] (lchain.c:313-316)
+		const int32_t ylo = yi32 - max_dist, yhi = yi32 - 1;
+		double bp = 0.0;
+		int32_t bj = -1;
+		bool tie = false;
+		for (int32_t j = st + lane; j < i0; j += 64) {
+			const int32_t yj = ly[j];
+			const double pj = lpri[j];
+			if ((yj > ylo && yj < yhi) || (j == 0 && yj == yhi)) {
+				if (bj < 0 || pj < bp) bp = pj, bj = j, tie = false;
+				else if (pj == bp) tie = true;
+			}
+		}
+		const uint64_t has = __ballot(bj >= 0);
+		if (has) {
+			double m = bp;
+			bool hm = bj >= 0;
+			for (int d = 32; d > 0; d >>= 1) {
+				const double om = __shfl_xor(m, d);
+				const bool oh = __shfl_xor((int)hm, d) != 0;
+				if (oh && (!hm || om < m)) m = om, hm = true;
+			}
+			const uint64_t at_min = __ballot(bj >= 0 && bp == m);
+			if (__popcll(at_min) > 1 || __ballot(bj >= 0 && bp == m && tie)) return false; // equal priorities: the AVL shape would decide
+			const int32_t jq = __builtin_amdgcn_readlane(bj, (int)__builtin_ctzll(at_min));
+			bool exact;
+			int32_t width;
+			__syncthreads(); // f / p / v of the anchors before this one have landed (their stores had the LDS phase above to do so)
+			const mg128_t aq = a[jq];
+			const int32_t fq = f[jq], vq = v[jq];
+			const int32_t sc = fq + lc_score_simple(xi, yi, aq.x, aq.y, R.pen_gap, R.pen_skip, &exact, &width);
+			if (width <= R.bw && sc > max_f) max_f = sc, max_j = jq, max_vj = vq;
+			// (2) inner window in descending (y, index) order (lchain.c:321-350)
+			if (!exact && max_dist_inner > 0 && st_in < i0 && yi32 > 0) {
+				const int32_t ymin = yi32 - max_dist_inner;
+				int32_t m_c = 0;
+				for (int32_t j0 = st_in; j0 < i0; j0 += 64) {
+					const int32_t j = j0 + lane;
+					int32_t yj = 0;
+					bool c = false;
+					if (j < i0) { yj = ly[j]; c = yj <= yhi && yj >= ymin; }
+					const uint64_t mc = __ballot(c);
+					const int32_t pos = m_c + __popcll(mc & mga_lanemask_lt());
+					if (c && pos < 64) cand_j[pos] = (uint16_t)j, cand_y[pos] = yj;
+					m_c += __popcll(mc);
+				}
+				if (m_c > 64) return false; // rank sort below handles one wave of candidates
+				mga_wave_sync();
+				if (m_c > 0) {
+					// rank by descending (y, j): keys are unique; every lane reads the others' keys from their registers
+					const int32_t myj = lane < m_c ? (int32_t)cand_j[lane] : -1, myy = lane < m_c ? cand_y[lane] : 0;
+					int32_t rank = 0;
+					for (int32_t k = 0; k < m_c; ++k) {
+						const int32_t ky = __builtin_amdgcn_readlane(myy, k), kj = __builtin_amdgcn_readlane(myj, k);
+						rank += (ky > myy || (ky == myy && kj > myj)) ? 1 : 0;
+					}
+					if (lane < m_c) sorted_j[rank] = (uint16_t)myj;
+					mga_wave_sync();
+					const int32_t j = lane < m_c ? (int32_t)sorted_j[lane] : -1;
+					int32_t sc2 = LC_NONE, pj = -1, vj = 0;
+					bool valid = false;
+					if (j >= 0) {
+						bool ex2;
+						int32_t w2;
+						const mg128_t aj = a[j];
+						const int32_t fj = f[j];
+						pj = p[j], vj = v[j];
+						sc2 = fj + lc_score_simple(xi, yi, aj.x, aj.y, R.pen_gap, R.pen_skip, &ex2, &w2);
+						valid = w2 <= R.bw;
+					}
+					if (valid && pj >= 0) lt[pj] = (uint16_t)i; // marks only reach candidates with a smaller y, i.e. visited later
+					mga_wave_sync();
+					const bool hit_t = valid && lt[j] == (uint16_t)i;
+					const int32_t pm = lc_scan_max(valid ? sc2 : INT32_MIN, INT32_MIN);
+					int32_t exm = lc_prev_lane(pm, INT32_MIN);
+					if (exm < max_f) exm = max_f;
+					const bool improve = valid && sc2 > exm;
+					const uint64_t m_imp = __ballot(improve);
+					int32_t n_skip = 0;
+					const int cut_lane = lc_skip_replay(improve, hit_t && !improve, R.max_skip, &n_skip);
+					const uint64_t before = cut_lane == 64 ? ~0ULL : (1ULL << cut_lane) - 1ULL;
+					const uint64_t imp_b = m_imp & before;
+					if (imp_b) {
+						const int bl = 63 - __clzll(imp_b);
+						max_f = __builtin_amdgcn_readlane(sc2, bl), max_j = __builtin_amdgcn_readlane(j, bl), max_vj = __builtin_amdgcn_readlane(vj, bl);
+					}
+				}
+				mga_wave_sync();
+			}
+		}
+		int32_t vi = max_f;
+		if (max_j >= 0 && max_vj > max_f) vi = max_vj;
+		if (lane == 0) {
+			f[i] = max_f; p[i] = max_j; v[i] = vi;
+			ly[i] = yi32, lpri[i] = -((double)max_f + 0.5 * (double)R.pen_gap * (double)((int32_t)xi + yi32));
+		}
+		mga_wave_sync(); // (LDS: the next anchor's windows; the stores are waited for where the next record is read)
+	}
+	__syncthreads();
+	return true;
 }
 
 // ---------------- RMQ DP of the rescue (lchain.c:275-357); false = this read must be re-chained by the host ----------------
@@ -807,7 +946,8 @@ __device__ __forceinline__ void lc_read_finish(int r, const lc_read_t &X, const 
 		if (step == 1) {
 			__syncthreads();
 			LC_TICK(2);
-			const bool rq_ok = lc_dp_rmq(b, n_v, R, W, L, lane);
+			const bool rq_ok = n_v <= LC_RQ_LDS ? lc_dp_rmq_lds(b, n_v, R, W, L, lane) : lc_dp_rmq(b, n_v, R, W, L, lane);
+			if (g_lc_prof_on && lane == 0) { const int q_ = n_v <= LC_RQ_LDS ? 16 : 17; LP->prof[q_] += 1, LP->prof[q_ + 2] += (unsigned long long)n_v, LP->prof[q_ + 4] += (unsigned long long)((long long)clock64() - tick_); }
 			LC_TICK(3);
 			if (!rq_ok) {
 				__syncthreads();
@@ -856,7 +996,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
 {
 	__shared__ lc_lds_t L;
 	lc_lds_t *LP = &L;
-	if (threadIdx.x < 16) L.prof[threadIdx.x] = 0;
+	if (threadIdx.x < 32) L.prof[threadIdx.x] = 0;
 	const int lane = threadIdx.x;
 	if ((int)blockIdx.x >= n_reads) return;
 	const int r = order ? __builtin_amdgcn_readfirstlane(order[blockIdx.x]) : (int)blockIdx.x; // workgroups are dispatched in index order: the reads with the most anchors first (mapper.c)
@@ -868,7 +1008,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
 	if (dp_win) lc_dp_w(X.a, X.n, X.P, X.W, &L, lane); else lc_dp(X.a, X.n, X.P, X.W, lane);
 	LC_TICK(0);
 	lc_read_finish(r, X, R, q_off, d_nu, d_nb, d_flag, ws_keep, &L, lane, tick_);
-	if (g_lc_prof_on) { mga_wave_sync(); if (lane < 16 && L.prof[lane]) atomicAdd(&g_lc_prof[lane], L.prof[lane]); }
+	if (g_lc_prof_on) { mga_wave_sync(); if (lane < 32 && L.prof[lane]) atomicAdd(&g_lc_prof[lane], L.prof[lane]); }
 }
 
 // the same, TWO reads per wavefront in the first-pass DP (lc_dp2), one after the other in everything behind it
@@ -880,7 +1020,7 @@ __global__ void __launch_bounds__(64) k_lchain2(int n_reads, const mg128_t *__re
 {
 	__shared__ lc_lds_t L;
 	lc_lds_t *LP = &L;
-	if (threadIdx.x < 16) L.prof[threadIdx.x] = 0;
+	if (threadIdx.x < 32) L.prof[threadIdx.x] = 0;
 	const int lane = threadIdx.x, grp = lane >> 5;
 	const int k0 = 2 * (int)blockIdx.x;
 	if (k0 >= n_reads) return;
@@ -907,7 +1047,7 @@ __global__ void __launch_bounds__(64) k_lchain2(int n_reads, const mg128_t *__re
 		lc_read_finish(r, X, R, q_off, d_nu, d_nb, d_flag, ws_keep, &L, lane, tick_);
 		__syncthreads();
 	}
-	if (g_lc_prof_on) { mga_wave_sync(); if (lane < 16 && L.prof[lane]) atomicAdd(&g_lc_prof[lane], L.prof[lane]); }
+	if (g_lc_prof_on) { mga_wave_sync(); if (lane < 32 && L.prof[lane]) atomicAdd(&g_lc_prof[lane], L.prof[lane]); }
 }
 
 // stage test: the sorts of this file on their own (tests/test_gpu_stages.py: test_device_klib_sort)
@@ -954,9 +1094,9 @@ extern "C" int mga_dev_lchain(mga_sctx_t *sc, int n, const mg128_t *d_a, const i
 		static int prof_on = -1;
 		if (prof_on < 0) { const char *e = getenv("MGA_LC_PROF"); prof_on = e && atoi(e) > 0; if (prof_on) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lc_prof_on), &prof_on, sizeof(int)); }
 		if (prof_on) { // print what the previous launches accumulated
-			unsigned long long h[16];
+			unsigned long long h[32];
 			if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lc_prof), sizeof h) == hipSuccess)
-				fprintf(stderr, "[lc-prof] Mcycles so far: dp %.1f backtrack %.1f rescue-sort %.1f rescue-dp %.1f rescue-backtrack %.1f | inside both backtracks: ends %.1f sort %.1f walk %.1f (their rest = compaction); %llu backtracks: anchors %llu ends %llu walks %llu steps %llu; walk = ends' marks %.1f + steps %.1f + marks %.1f\n", h[0] * 1e-6, h[1] * 1e-6, h[2] * 1e-6, h[3] * 1e-6, h[4] * 1e-6, h[5] * 1e-6, h[6] * 1e-6, h[7] * 1e-6, h[12], h[8], h[9], h[10], h[11], h[13] * 1e-6, h[14] * 1e-6, h[15] * 1e-6);
+				fprintf(stderr, "[lc-prof] Mcycles so far: dp %.1f backtrack %.1f rescue-sort %.1f rescue-dp %.1f rescue-backtrack %.1f | inside both backtracks: ends %.1f sort %.1f walk %.1f (their rest = compaction); %llu backtracks: anchors %llu ends %llu walks %llu steps %llu; walk = ends' marks %.1f + steps %.1f + marks %.1f; rescue DPs in LDS %llu (%llu anchors, %.1f Mcycles), in memory %llu (%llu anchors, %.1f Mcycles)\n", h[0] * 1e-6, h[1] * 1e-6, h[2] * 1e-6, h[3] * 1e-6, h[4] * 1e-6, h[5] * 1e-6, h[6] * 1e-6, h[7] * 1e-6, h[12], h[8], h[9], h[10], h[11], h[13] * 1e-6, h[14] * 1e-6, h[15] * 1e-6, h[16], h[18], h[20] * 1e-6, h[17], h[19], h[21] * 1e-6);
 		}
 	}
 	mga_prof_begin(sc->stream, MGA_K_LCHAIN);
@@ -971,7 +1111,7 @@ extern "C" int mga_dev_lchain(mga_sctx_t *sc, int n, const mg128_t *d_a, const i
 		const char *e_win = getenv("MGA_LC_WIN"); // 0: the first-pass DP over global memory (lc_dp), the form of rounds 1-5; default: the last 64 anchors in registers (lc_dp_w)
 		const int dp_win = !(e_win && *e_win && atoi(e_win) == 0);
 		const char *e_wpe = getenv("MGA_LC_WPE");
-		const int wpe = e_wpe && *e_wpe ? atoi(e_wpe) : 7;
+		const int wpe = e_wpe && *e_wpe ? atoi(e_wpe) : 6; // [measured, round 6, profiles/r06f_lchain_phases.txt] 6 waves (80 VGPRs, 8 spilled): 36.6 ms, 7 (72, 21 spilled): 37.0, 5: slower by 2
 #define LC_LAUNCH(W_) hipLaunchKernelGGL(k_lchain<W_>, dim3(n), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, R, d_q_off, d_u, d_b, d_nu, d_nb, d_flag, ws_i32, ws_z, ws_keep, d_order, dp_win)
 		if (!(e_pair && atoi(e_pair) > 0)) { if (wpe <= 5) LC_LAUNCH(5); else if (wpe == 6) LC_LAUNCH(6); else LC_LAUNCH(7); }
 		else hipLaunchKernelGGL(k_lchain2, dim3((n + 1) / 2), dim3(64), 0, (hipStream_t)sc->stream, n, d_a, d_a_off, *par, R, d_q_off, d_u, d_b, d_nu, d_nb, d_flag, ws_i32, ws_z, ws_keep, d_order);
