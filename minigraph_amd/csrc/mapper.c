@@ -1705,7 +1705,6 @@ mga_stream_t *mga_stream_open(const mg_idx_t *gi, const mg_mapopt_t *opt, int n_
 	if (mga_dev_init() < 0) return 0;
 	if (env_int("MGA_SEGV_TRACE", 0)) signal(SIGSEGV, segv_trace);
 	if (g_dbg_pipe < 0) { g_dbg_pipe = env_int("MGA_DEBUG_PIPE", 0); g_gpu_wfa.avail = env_int("MGA_WFA_SLOTS", 2); g_gpu_front.avail = env_int("MGA_FRONT_SLOTS", 1); }
-	const int dev_place = env_int("MGA_DEV_GCHAIN", n_threads <= 12) && !env_int("MGA_HOST_GCHAIN", 0); /* (what map_chunk decides per chunk: graph chaining on the device) */
 	g_cpu_on = g_dbg_pipe > 0;
 	S = MGA_CALLOC(mga_stream_t, 1);
 	S->gi = gi, S->opt = *opt, S->n_threads = n_threads > 0 ? n_threads : 1;
@@ -1714,7 +1713,7 @@ mga_stream_t *mga_stream_open(const mg_idx_t *gi, const mg_mapopt_t *opt, int n_
 	 * in flight, two of them in the front phase, fill those tails with other chunks' kernels -- [measured, bench workload, --placement device, 16 threads] 2.98 / 3.00 Gbp/s
 	 * (4 chunks, one in the front phase) -> 3.24 (6 / 2) -> 3.27-3.30 with the persistent WFA grids at half size; with the chaining on the host threads the same knobs stay
 	 * inside the run-to-run noise (3.51-3.60 vs 3.55-3.65) */
-	S->n_pipe = env_int("MGA_PIPE", dev_place && n_threads > 4 ? 6 : 4); /* round 5, a rank pinned to 2 of 16 cores, two chunks in the front phase: 4 pipeline threads 2.51 Gbp/s, 3: 2.28 (round 4, one chunk in the front phase: 3 was the better one) */ /* [measured, round 4, a rank pinned to 2 of 16 cores] 3 pipeline threads: 2.31 Gbp/s at 0.70 CPU-s per step, 4: 2.23 at 0.82, 2: 2.07; with 16 threads and the chaining on the host 4 is the best (3.27 vs 2.96 vs 2.51) */
+	S->n_pipe = env_int("MGA_PIPE", n_threads > 4 ? 6 : 4); /* round 6, chaining on the host threads, 16 of them (profiles/r06u_knobs.txt): 6 pipeline threads + 2 chunks in the front phase 4.68 Gbp/s, 5 + 2: 4.58, 4 + 1 (the default until then): 4.48-4.51 */ /* round 5, a rank pinned to 2 of 16 cores, two chunks in the front phase: 4 pipeline threads 2.51 Gbp/s, 3: 2.28 (round 4, one chunk in the front phase: 3 was the better one) */ /* [measured, round 4, a rank pinned to 2 of 16 cores] 3 pipeline threads: 2.31 Gbp/s at 0.70 CPU-s per step, 4: 2.23 at 0.82, 2: 2.07; with 16 threads and the chaining on the host 4 is the best (3.27 vs 2.96 vs 2.51) */
 	if (S->n_pipe > MGA_MAX_PIPE) S->n_pipe = MGA_MAX_PIPE;
 	if (S->n_pipe < 1) S->n_pipe = 1;
 	S->chunk = env_int("MGA_CHUNK", 16384); /* [measured] larger launches amortise the tails of the WFA tiers: 4096 -> 8192 reads +5 %, -> 16384 another +5 % */
@@ -1724,7 +1723,7 @@ mga_stream_t *mga_stream_open(const mg_idx_t *gi, const mg_mapopt_t *opt, int n_
 	pthread_cond_init(&S->c_work, 0); pthread_cond_init(&S->c_done, 0); pthread_cond_init(&S->c_space, 0);
 	pthread_mutex_init(&S->tok_front.m, 0); pthread_cond_init(&S->tok_front.c, 0); pthread_mutex_init(&S->tok_wfa.m, 0); pthread_cond_init(&S->tok_wfa.c, 0);
 	S->tok_wfa.avail = env_int("MGA_WFA_SLOTS", 2);                 /* two chunks may be in their WFA phase: the second one fills the tails of the first */
-	S->tok_front.avail = env_int("MGA_FRONT_SLOTS", dev_place ? 2 : 1); /* ... and with the chaining on the device two in the front phase ([measured] + 8 % at 16 threads, + 7 % at 2) */
+	S->tok_front.avail = env_int("MGA_FRONT_SLOTS", 2); /* ... and with the chaining on the device two in the front phase ([measured] + 8 % at 16 threads, + 7 % at 2) */
 	for (i = 0; i < S->n_pipe; ++i) {
 		if ((S->P[i].sc = mga_sctx_create()) == 0) { while (--i >= 0) pipe_ctx_free(&S->P[i]); free(S); return 0; }
 		S->P[i].tok_front = &S->tok_front, S->P[i].tok_wfa = &S->tok_wfa;
