@@ -450,7 +450,7 @@ static int wfs_sweep(mga_sctx_t *sc, const wfs_ladder_t *LD, int arr_pct, int n_
 		if (LD->r[t].kind != 0 || cap[t] <= 0) continue;
 		char *tbuf = (char*)sc->wfa_tbuf[tb_side ? (n_win & 1) : 0].p;
 		if (tb_side && n_win >= 2) MGA_HIP_CHECK(hipStreamWaitEvent(st, (hipEvent_t)sc->ev_done[2 + (n_win & 1)], 0)); // the walk that read this buffer two rungs ago
-		if (mga_dev_wfa_win(sc, rc + t, cap[t], L + base[t], d_prob, d_tseq, d_qseq, d_res, tbuf, LD->r[t].idx, 9 + LD->r[t].idx, rt_of(t)) < 0) return -1;
+		if (mga_dev_wfa_win(sc, rc + t, cap[t], L + base[t], d_prob, d_tseq, d_qseq, d_res, tbuf, LD->r[t].idx, 9 + LD->r[t].idx, rt_of(t), d_pool, pool_cap, d_pool_used, ctl + O_ERR) < 0) return -1;
 		if (tb_side) {
 			MGA_HIP_CHECK(hipEventRecord((hipEvent_t)sc->ev_done[1], st));
 			MGA_HIP_CHECK(hipStreamWaitEvent(tbs, (hipEvent_t)sc->ev_done[1], 0));

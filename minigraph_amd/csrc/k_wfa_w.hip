@@ -377,10 +377,18 @@ template<bool EDGE> __device__ __forceinline__ uint32_t wfp_from_right(uint32_t 
 	return __builtin_amdgcn_alignbit(t, x, 16);
 }
 
+// (defined with k_wfa_tb below)
+__device__ __forceinline__ uint32_t wfw_tb_byte(const uint32_t *__restrict__ reg, int32_t W, int32_t ph, int32_t sc, int32_t idx);
+template<bool WRITE>
+__device__ __forceinline__ int32_t wfw_trace(int32_t tl, int32_t ql, const char *__restrict__ ts, const char *__restrict__ qs, int32_t S, int32_t last,
+											 const uint32_t *__restrict__ reg, int32_t W, int32_t ph, int32_t lo, uint32_t *__restrict__ out, int32_t n_total);
+#define WFP_POOL_BLK 1024 // CIGAR operators a wavefront of k_wfa_fwp takes from the pool at a time for the walks it runs itself (MGA_WFA_FUSE_SLACK in mga_dev.h covers the abandoned tails)
+
 template<int W, int SEQCAP>
 __global__ void __launch_bounds__(64) k_wfa_fwp(const int *__restrict__ n_items_p, int cap, const int32_t *__restrict__ list, const mga_wfa_prob_t *__restrict__ prob,
 												const char *__restrict__ tseq, const char *__restrict__ qseq, mga_wfa_res_t *__restrict__ res,
-												char *__restrict__ tb, long long tb_stride, int *__restrict__ counter, mga_wfa_retry_t rt)
+												char *__restrict__ tb, long long tb_stride, int *__restrict__ counter, mga_wfa_retry_t rt,
+												uint32_t *__restrict__ pool, long long pool_cap, unsigned long long *pool_used, int *__restrict__ err, int fuse)
 {
 	constexpr int JP = (W + 127) / 128; // sets of 128 diagonals (two per lane)
 	constexpr int SEQS = SEQCAP + 16;
@@ -395,12 +403,24 @@ __global__ void __launch_bounds__(64) k_wfa_fwp(const int *__restrict__ n_items_
 	// saw the old index for ever (gpurun's limit, 30 GPU-minutes; a __syncthreads() does not help, for a workgroup of one wavefront it compiles to nothing).
 	bool prev = false, done = false; // (uniform)
 	int32_t s = 0, lst = 0, pi = 0, item = 0;
+	// Round 6 (fuse, MGA_WFA_FUSE_TB=1, not the default -- see mga_dev_wfa_win): the wavefront walks its own alignment as soon as the forward pass ends -- the rows it reads are the ones it just wrote (L2), target and query are the
+	// problem it holds -- and leaves the finished result; k_wfa_tb then finds nothing of this rung to do.  [measured, round 6] k_wfa_tb spent 7.3 of its 18.2 ms per 125 000 reads
+	// on the 1.47 M problems of the three packed rungs: launches as long as their longest walk (a lane per problem, ~60 dependent trips for a score of 250).
+	// The walk is run by ALL lanes on the same values (same loads, same stores: one transaction each) -- a lane-0 region at the loop's end is what the note above warns about.
+	bool walked = false;             // (uniform) this problem's result is final
+	int32_t w_ncig = 0, w_ub = 0;
+	long long w_slot = 0, w_cells = 0;
+	long long blk_off = 0;           // the wavefront's block of the CIGAR pool
+	int32_t blk_left = 0;
 	for (;;) {
 		int32_t item_v = 0;
 		if (lane == 0) {
 			if (prev) {
 				mga_wfa_res_t r;
-				if (done) { r.score = s, r.n_cigar = 0, r.cig_off = (int64_t)(uintptr_t)(tb + (long long)item * tb_stride), r.status = MGA_WFA_TB, r.pad = lst | W << 8, r.n_iter = 0; res[pi] = r; }
+				if (done && walked) {
+					if (w_ncig < 0 || w_ncig > w_ub) { r.status = MGA_WFA_POOL_FULL, r.score = -1, r.n_cigar = 0, r.cig_off = 0, r.pad = 0, r.n_iter = 0; res[pi] = r; atomicAdd(err, 1); } // (pool full, or -- cannot happen -- a walk that left the window: fail loudly)
+					else { r.score = s, r.n_cigar = w_ncig, r.cig_off = w_slot + (w_ub - w_ncig), r.status = MGA_WFA_OK, r.pad = 0, r.n_iter = w_cells; res[pi] = r; }
+				} else if (done) { r.score = s, r.n_cigar = 0, r.cig_off = (int64_t)(uintptr_t)(tb + (long long)item * tb_stride), r.status = MGA_WFA_TB, r.pad = lst | W << 8, r.n_iter = 0; res[pi] = r; }
 				else { r.score = -1, r.n_cigar = 0, r.cig_off = 0, r.status = MGA_WFA_RETRY_TIER, r.pad = 0, r.n_iter = 0; res[pi] = r; mga_wfa_give_up(rt, pi); }
 			}
 			item_v = atomicAdd(counter, 1);
@@ -418,7 +438,7 @@ __global__ void __launch_bounds__(64) k_wfa_fwp(const int *__restrict__ n_items_
 		const char *ts = tseq + t_off, *qs = qseq + q_off;
 		int32_t lo = 0, bnd = 0;
 		if (tl <= SEQCAP && ql <= SEQCAP) { bnd = wfw_window(W, tl, ql, &lo, WFW_SMAX); if (bnd > W + 30) bnd = W + 30; }
-		done = false, s = 0, lst = 0;
+		done = false, walked = false, s = 0, lst = 0;
 		uint32_t *tbp = (uint32_t*)(tb + (long long)item * tb_stride) + 2 * lane; // this lane's two dwords in the current row (set j: + 128 j)
 		if (bnd > 0) {
 			// ---- sequences and match masks (as k_wfa_fw)
@@ -585,6 +605,25 @@ __global__ void __launch_bounds__(64) k_wfa_fwp(const int *__restrict__ n_items_
 						const int32_t dA = lo + 128 * j + 2 * lane, dB = dA + 1, ad = min(dA < 0 ? -dA : dA, dB < 0 ? -dB : dB);
 						if (ad <= rr && 128 * j + 2 * lane < W) { tbp[128 * j] = accA[j] << (8 * (4 - (s & 3))); if (128 * j + 2 * lane + 1 < W) tbp[128 * j + 1] = accB[j] << (8 * (4 - (s & 3))); }
 					}
+				}
+				if (fuse) {
+					__syncthreads(); // (one wavefront: a wait for the rows' stores, no barrier)
+					const int32_t ub = (s >> 1) + 4; // most operators an alignment of this score can have (k_wfa_tb)
+					if (blk_left < ub) {
+						unsigned long long b_ = 0;
+						if (lane == 0) b_ = atomicAdd(pool_used, (unsigned long long)WFP_POOL_BLK);
+						blk_off = (long long)((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(b_ & 0xffffffffULL)) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(b_ >> 32)) << 32);
+						blk_left = WFP_POOL_BLK;
+					}
+					w_slot = blk_off, w_ub = ub;
+					blk_off += ub, blk_left -= ub;
+					w_ncig = -1;
+					if (w_slot + ub <= pool_cap)
+						w_ncig = wfw_trace<true>(tl, ql, ts, qs, s, lst, (const uint32_t*)(tb + (long long)item * tb_stride), W, 0, lo, pool + w_slot, ub);
+					// the reference's cell count for this alignment (n_iter, miniwfa.c:421): its band at score s is the reachable diagonals +- 1, clipped to the matrix
+					w_cells = 0;
+					for (int32_t q = 0; q < s; ++q) { const int32_t w_ = wfw_reach(q) + 1; w_cells += min(w_, tl) + min(w_, ql) + 1; }
+					walked = true;
 				}
 			}
 			(void)bail;
@@ -956,8 +995,14 @@ static int wfw_rows(int W) { const int smax = W + 30 < WFW_SMAX ? W + 30 : WFW_S
 extern "C" int64_t mga_dev_wfa_win_tb_stride(int wt) { return (int64_t)wfw_rows(g_wtier[wt].W) * g_wtier[wt].W * 4; }
 
 extern "C" int mga_dev_wfa_win(mga_sctx_t *sc, const int *d_n, int n, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
-							   mga_wfa_res_t *d_res, char *d_tb, int wt, int slot, mga_wfa_retry_t rt)  /* (launched on the context's own stream) */
+							   mga_wfa_res_t *d_res, char *d_tb, int wt, int slot, mga_wfa_retry_t rt,
+							   uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int *d_err)  /* (launched on the context's own stream) */
 {
+	// MGA_WFA_FUSE_TB=1: a wavefront of the packed rungs walks its own alignment behind its forward pass instead of leaving it to k_wfa_tb.  [measured, round 6,
+	// profiles/r06z_fuse_tb.txt, 125 000 reads, isolated] k_wfa_tb 18.1 -> 11.0 ms, but the three rungs 26.5 + 20.9 + 8.5 -> 34.3 + 25.8 + 10.2 ms: at 2-4 waves per SIMD nothing
+	// hides a walk's ~60 dependent trips, and the wavefront holds its registers and LDS while it waits.  Not the default; the tests run both forms.
+	const char *e_fu = getenv("MGA_WFA_FUSE_TB");
+	const int fuse = (e_fu && *e_fu ? atoi(e_fu) : 0) && d_pool != 0 && d_pool_used != 0 && d_err != 0;
 	if (n <= 0) return 0;
 	if (wt < 0 || wt >= MGA_WFW_N) { mga_set_error("wfa_win: bad tier %d", wt); return -1; }
 	const wfw_tier_t &T = g_wtier[wt];
@@ -982,7 +1027,7 @@ extern "C" int mga_dev_wfa_win(mga_sctx_t *sc, const int *d_n, int n, const int3
 #define LAUNCH(GG, JJ, SEQ) hipLaunchKernelGGL((k_wfa_fw<GG, JJ, SEQ>), dim3(wgs), dim3(64), 0, st, d_n, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_tb, stride, d_counter, rt)
 	// (default mask 7, measured per 125 000 reads, profiles/r05n_packed_sweep.txt: 128: 45.9 -> 26.9 ms, 192: 22.8 -> 21.1 ms, 256: 12.5 -> 8.5 ms)
 #define LAUNCHQ(GG, SEQ) hipLaunchKernelGGL((k_wfa_fwq<GG, SEQ>), dim3(wgs), dim3(64), 0, st, d_n, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_tb, stride, d_counter, rt)
-#define LAUNCHP(WW, SEQ) hipLaunchKernelGGL((k_wfa_fwp<WW, SEQ>), dim3(wgs), dim3(64), 0, st, d_n, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_tb, stride, d_counter, rt)
+#define LAUNCHP(WW, SEQ) hipLaunchKernelGGL((k_wfa_fwp<WW, SEQ>), dim3(wgs), dim3(64), 0, st, d_n, n, d_list, d_prob, d_tseq, d_qseq, d_res, d_tb, stride, d_counter, rt, d_pool, (long long)pool_cap, d_pool_used, d_err, fuse)
 	if (wt == 0) LAUNCH(16, 1, 128);
 	else if (wt == 1) { if (pk_mask & 16) LAUNCHQ(16, 192); else LAUNCH(32, 1, 192); }
 	else if (wt == 2) { if (pk_mask & 8) LAUNCHQ(32, 256); else LAUNCH(64, 1, 256); }

@@ -1346,7 +1346,7 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 		GPU_ACQUIRE(P->tok_wfa ? P->tok_wfa : &g_gpu_wfa);
 		/* CIGAR pool: a global alignment has at most tl + ql operators, so target bases + query bases bound the chunk; + the abandoned block
 		 * tails (<= 512 ops) of every resident wave.  Sized to the bound, the pool cannot overflow whatever the divergence. */
-		pool_cap = n_tb + 4096 + 40000LL * 512 + (int64_t)ptot[5] + 4 * n_prob; /* (+ 4 per problem: k_wfa_tb reserves by an upper bound of the operator count) */
+		pool_cap = n_tb + 4096 + 40000LL * 512 + MGA_WFA_FUSE_SLACK + (int64_t)ptot[5] + 4 * n_prob; /* (+ 4 per problem: k_wfa_tb reserves by an upper bound of the operator count) */
 		for (i = 0; i < b->n_threads; ++i) pool_cap += b->tp[i].wfa_q_bases;
 		CK(mga_dbuf_reserve(&P->pool, (size_t)pool_cap * 4)); CK(mga_dmemset_s(sc, P->used.p, 0, 8));
 		/* the tier ladder runs on the device (k_wfa_sched.hip); the host never walks the problems */

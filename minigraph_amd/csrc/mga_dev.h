@@ -184,7 +184,9 @@ int mga_dev_wfa_reg(mga_sctx_t *sc, const int *d_n, int cap, int first, int slot
  * behind the rung's forward pass, so that ONE region buffer (the largest rung's) serves the whole sweep. */
 int64_t mga_dev_wfa_win_tb_stride(int wt);
 int mga_dev_wfa_win(mga_sctx_t *sc, const int *d_n, int cap, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq,
-					mga_wfa_res_t *d_res, char *d_tb, int wt, int slot, mga_wfa_retry_t rt);
+					mga_wfa_res_t *d_res, char *d_tb, int wt, int slot, mga_wfa_retry_t rt,
+					uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int *d_err /* the packed rungs (128 / 192 / 256 diagonals) walk their own alignments: results final, CIGARs in the pool */);
+#define MGA_WFA_FUSE_SLACK (3LL * 8192 * 1024) /* CIGAR pool: the abandoned tails of the blocks k_wfa_fwp's wavefronts take (three rungs, <= 8192 wavefronts, 1024 operators) */
 int mga_dev_wfa_traceback(mga_sctx_t *sc, void *stream /* NULL: the context's */, const int *d_n, int cap, const int32_t *d_list, const mga_wfa_prob_t *d_prob, const char *d_tseq, const char *d_qseq, mga_wfa_res_t *d_res,
 						  uint32_t *d_pool, int64_t pool_cap, unsigned long long *d_pool_used, int *d_err, int wt /* the rung's window tier: only results of THAT window are walked */);
 int32_t mga_wfw_window(int32_t W, int32_t tl, int32_t ql, int32_t *lo);

@@ -90,7 +90,7 @@ extern "C" int mga_wfa_batch(int n, const char *tseq, const int64_t *t_off, cons
 		if (prob[i].tl <= 0 || prob[i].ql <= 0) { mga_set_error("wfa: problem %d has an empty sequence (the caller handles those, galign.c:98-100)", i); return -1; }
 	}
 	dptr d_t, d_q, d_prob, d_res, d_pool, d_used;
-	int64_t pool_cap = (tt + tq) / 4 + n * 4 + 1024 + 40000LL * 512;
+	int64_t pool_cap = (tt + tq) / 4 + n * 4 + 1024 + 40000LL * 512 + MGA_WFA_FUSE_SLACK;
 	if (!d_t.alloc(tt + 64) || !d_q.alloc(tq + 64) || !d_prob.alloc((size_t)n * sizeof(mga_wfa_prob_t)) ||
 		!d_res.alloc((size_t)n * sizeof(mga_wfa_res_t)) || !d_used.alloc(8)) return -1;
 	if (mga_h2d(d_t.p, tseq, tt) < 0 || mga_h2d(d_q.p, qseq, tq) < 0 || mga_h2d(d_prob.p, prob.data(), (size_t)n * sizeof(mga_wfa_prob_t)) < 0) return -1;

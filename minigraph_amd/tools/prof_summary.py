@@ -89,7 +89,7 @@ def main_sq(paths, title):
     import re
     m = re.search(r"--reads (\d+)", title)
     reads = int(m.group(1)) if m else 125000
-    lc = acc.get("k_lchain")
+    lc = acc.get("k_lchain<6>") or acc.get("k_lchain<7>") or acc.get("k_lchain<5>") or acc.get("k_lchain")
     if lc and lc.get("waves"):   # k_lchain is one wavefront per read: its waves / the reads of a pass = the passes these counters cover (bench.py divides by it)
         print("# passes covered: %d (k_lchain: %d waves / %d reads per pass)" % (round(lc["waves"] / reads), lc["waves"], reads))
     print("# per wave: instructions issued; shares: fraction of the waves' resident cycles (SQ_WAVE_CYCLES): valu = SQ_ACTIVE_INST_VALU, wait = SQ_WAIT_ANY (parked on s_waitcnt / barrier),")

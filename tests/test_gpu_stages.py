@@ -163,9 +163,11 @@ def test_wfa_roundtrip_property():
         assert ti == len(t) and qi == len(q) and pen == sc[i], i
 
 
-@pytest.mark.parametrize("packed", ["0", "5", None, "31"])
+@pytest.mark.parametrize("packed", ["0", "5", None, "31", "7+own_walk"])
 def test_wfa_windowed_tiers_edge_shapes(ora, monkeypatch, packed):
-    """(MGA_WFA_PACKED: every rung on the one-diagonal-per-lane kernel, two of the wide rungs packed, the default, and everything that has a packed form -- the rungs of
+    """(round 6, "7+own_walk" = MGA_WFA_FUSE_TB=1: the packed rungs of 128 / 192 / 256 diagonals walk their own alignments behind the forward pass instead of leaving them to
+    k_wfa_tb -- measured slower, not the default, same results)
+    (MGA_WFA_PACKED: every rung on the one-diagonal-per-lane kernel, two of the wide rungs packed, the default, and everything that has a packed form -- the rungs of
     32 and 64 diagonals with four / two problems per wavefront included)
     the windowed tiers (k_wfa_w.hip: 16 / 32 / 64 / 128 / 192 / 256 diagonals, several problems per wavefront in the narrow ones) are exact only
     below the bound of their window: single gaps of every length around each half-width (the alignment hugs the window's edge, one base further and
@@ -173,6 +175,9 @@ def test_wfa_windowed_tiers_edge_shapes(ora, monkeypatch, packed):
     between 0 and ql - tl), sequences longer than a tier's LDS staging, scores around 256 (the last windowed score), N bases"""
     if packed is None:
         monkeypatch.delenv("MGA_WFA_PACKED", raising=False)
+    elif packed == "7+own_walk":
+        monkeypatch.setenv("MGA_WFA_PACKED", "7")
+        monkeypatch.setenv("MGA_WFA_FUSE_TB", "1")
     else:
         monkeypatch.setenv("MGA_WFA_PACKED", packed)
     rng = np.random.default_rng(41)
