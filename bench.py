@@ -645,6 +645,31 @@ def main():
                              "the family is bound by vector-instruction ISSUE, not by HBM: int_issue prices it against the measured integer issue rate of a SIMD (profiles/r03_valu_rate.txt)",
                         families={k: dict(ms=round(fam[k], 2), launches=launches[k], alg_GBps=round(alg[k] / max(fam[k], 1e-9) / 1e6, 2)) for k in fam},
                         valu_busy=valu_busy, valu_busy_source=valu_src)
+            if traffic is not None and launches[dom] > 0 and alg[dom] > 0:
+                roof["traffic_ratio"] = round(traffic / (alg[dom] / launches[dom]), 2)  # HBM bytes moved per algorithmic byte of the dominant family (1 = nothing re-read or spilled)
+            # per kernel family: HBM bytes of the committed counter passes per pass against the family's algorithmic bytes, and what binds it (vector issue when the kernel uses
+            # more than half of the chip's measured issue rate while it runs, else the latency of its dependent accesses: DESIGN.md 4)
+            try:
+                pj = json.load(open(pf))
+                n_pass_pmc = max(1, int(round(sum(v.get("launches_fetch", 0) for k, v in pj["kernels"].items() if k.startswith("k_lchain")) / max(1, launches["k_lchain"]))))
+                fam_of = lambda k: ("k_wfa" if (k == "k_wfa" or k.startswith("k_wfa_r<") or k.startswith("k_wfa_fw") or k.startswith("k_wfa_tb")) else "k_seed" if k.startswith("k_seed") else
+                                    "k_text" if k.startswith("k_text") else "k_sketch" if k.startswith("k_sketch<") or k == "k_sketch" else "k_lchain" if k.startswith("k_lchain") else None)
+                tr = {}
+                for k, v in pj["kernels"].items():
+                    f_ = fam_of(k)
+                    if f_ and f_ != "k_sketch":   # (k_sketch's counters include the index build over the graph)
+                        tr[f_] = tr.get(f_, 0.0) + (v.get("fetch_kb", 0) + v.get("write_kb", 0)) * 1024.0 / n_pass_pmc
+                busy_of = {"k_wfa": ["k_wfa_w[64]", "k_wfa_w[128]"], "k_lchain": ["k_lchain"], "k_text": ["k_text"], "k_seed": ["k_seed_fill"]}
+                per = {}
+                for f_, b_ in tr.items():
+                    vb = [valu_busy[x]["valu_busy"] for x in busy_of.get(f_, []) if valu_busy and x in valu_busy]
+                    per[f_] = dict(hbm_bytes_per_pass=round(b_), alg_bytes_per_pass=round(alg[f_]), traffic_ratio=round(b_ / alg[f_], 2) if alg[f_] > 0 else None,
+                                   hbm_frac_of_peak=round(b_ / (fam[f_] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if fam[f_] > 0 else None,
+                                   bound=("vector issue" if vb and max(vb) >= 0.5 else "latency of dependent accesses / occupancy"))
+                roof["per_family"] = per
+                roof["per_family_source"] = traffic_src
+            except Exception:
+                pass
             # integer-issue roofline of the WFA family: wavefront cells (the REFERENCE's band: what miniwfa computes for the same gaps) per second against what the vector
             # ALUs can issue.  [measured, minigraph_amd/tools/valu_rate.hip -> profiles/r03_valu_rate.txt] a gfx950 SIMD issues one wave64 v_max_i32 / v_add_u32 /
             # DPP move every 4.15 cycles; a 64-cell slot step of the windowed kernel is ~110 such instructions (ISA count incl. one mask-window extension)
