@@ -695,7 +695,7 @@ def main():
                    resident=resident,
                    kernels_ms_isolated=kernels_ms,
                    wfa_ladder_isolated=(isolated or {}).get("ladder"),
-                   graph_chaining=dict(default=("device (k_gchain + k_plan)" if default_dev else "host threads") + ": %d host threads per rank, device when <= 12" % threads + ("" if args.placement == "auto" else " (FORCED by --placement %s)" % args.placement)),
+                   graph_chaining=dict(default=("device (k_gchain + k_plan)" if default_dev else "host threads for %d %% of the chunks, device for the rest (MGA_DEV_GCHAIN_PCT, default 25)" % (100 - int(os.environ.get("MGA_DEV_GCHAIN_PCT", "25")))) + ": %d host threads per rank, device for every chunk when <= 12" % threads + ("" if args.placement == "auto" else " (FORCED by --placement %s)" % args.placement)),
                    per_read=dict(n_mz=agg["n_mz"] / max(1, total_reads * args.steps), n_hit=agg["n_hit"] / max(1, total_reads * args.steps),
                                  n_wfa=st["n_wfa"] / max(1, st["n_reads"]), wfa_cells=st["wfa_cells"] / max(1, st["n_reads"]),
                                  gaf_bytes=agg["gaf_bytes"] / max(1, total_reads * args.steps)),

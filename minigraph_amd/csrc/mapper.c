@@ -1153,6 +1153,17 @@ static int map_chunk(pipe_ctx_t *P, const mg_idx_t *gi, int n, const int *qlens,
 		 * ([measured] ~3 CPU-s per 100k reads on a 3 Gbp graph) when there are enough of them to keep up.  [measured, cores = threads] 8: 1.42 (host) vs 1.78 Gbp/s
 		 * (device); 10: 1.59 vs 1.83; 16: 2.00 vs 1.84.  MGA_DEV_GCHAIN=1 / 0 forces one or the other; same bytes either way. */
 		dev_gc = rs.enabled && B->dev.d_arc != 0 && env_int("MGA_DEV_GCHAIN", n_threads <= 12) && !env_int("MGA_HOST_GCHAIN", 0);
+		/* Round 6: with many host threads neither side is idle -- the host threads chain the graph for 2.3-2.7 CPU-s per 125 000 reads while the GPU runs 250 ms of kernels --
+		 * so a SHARE of the chunks takes the device placement (k_gchain + k_plan fill the chip's idle wave slots at 2 waves per SIMD) and the rest the host's: both placements
+		 * give the same bytes (every e2e test runs them), a chunk is a unit.  MGA_DEV_GCHAIN_PCT = percentage of chunks on the device when MGA_DEV_GCHAIN is not set
+		 * (default 25: [measured, profiles/r06y_hybrid.txt] the same throughput as 0 on a box whose 16 cores keep up -- 4.40 vs 4.42 Gbp/s -- at 2.9 instead of 4.0 CPU-s per step;
+		 * the final bench run of this round landed on a box where they do not: 3.72 Gbp/s at 4.95 CPU-s with all chunks on the host, 4.05 with all on the device);
+		 * MGA_DEV_GCHAIN=0 / 1 forces one placement as before. */
+		if (rs.enabled && B->dev.d_arc != 0 && getenv("MGA_DEV_GCHAIN") == 0 && !env_int("MGA_HOST_GCHAIN", 0) && n_threads > 12) {
+			static int g_gc_turn = 0;
+			const int pct = env_int("MGA_DEV_GCHAIN_PCT", 25), turn = __sync_fetch_and_add(&g_gc_turn, 1);
+			dev_gc = pct > 0 && ((int64_t)(turn + 1) * pct) / 100 > ((int64_t)turn * pct) / 100;
+		}
 		if (dev_gc) {
 			/* ---- graph chaining: chain records, clean-up, DP + shortest walks, GWFA bridging, ordering, filters -- one wavefront per read ---- */
 			const size_t rec = mga_gc_rec_bytes();

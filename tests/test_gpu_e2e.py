@@ -442,7 +442,9 @@ def test_pipeline_knobs_do_not_change_the_output(monkeypatch):
                                         (40, 4, 8, {"MGA_CUT": "0"}), (40, 4, 8, {"MGA_CUT": "1", "MGA_TAIL": "3"}), (64, 3, 8, {"MGA_TAIL": "2", "MGA_WFA_GRID_PCT": "50", "MGA_WFA_SLOTS": "3"}),
                                         (50, 2, 4, {"MGA_RAMP": "0", "MGA_WFA_GRID_PCT": "1"}), (40, 4, 8, {"MGA_GAF_DIRECT": "0", "MGA_DEV_SPLICE": "0"}),
                                         (23, 6, 5, {"MGA_GAF_DIRECT": "1", "MGA_DEV_SPLICE": "1", "MGA_FRONT_SLOTS": "2", "MGA_WFA_TB_SIDE": "1"}), (64, 4, 8, {"MGA_DEV_GCHAIN": "1", "MGA_DEV_SPLICE": "0"}),
-                                        (33, 8, 3, {"MGA_DEV_GCHAIN": "1", "MGA_GAF_DIRECT": "0"})):
+                                        (33, 8, 3, {"MGA_DEV_GCHAIN": "1", "MGA_GAF_DIRECT": "0"}),
+                                        # round 6: a share of the chunks chained on the device, the rest on the host threads (only with > 12 of them)
+                                        (9, 6, 16, {"MGA_DEV_GCHAIN_PCT": "50"}), (5, 4, 14, {"MGA_DEV_GCHAIN_PCT": "30", "MGA_DEV_GAF": "0"}), (13, 3, 16, {"MGA_DEV_GCHAIN_PCT": "100"})):
         monkeypatch.setenv("MGA_CHUNK", str(chunk))
         monkeypatch.setenv("MGA_PIPE", str(pipe))
         for k, v in extra.items():
