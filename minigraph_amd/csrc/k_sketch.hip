@@ -308,9 +308,11 @@ __global__ void __launch_bounds__(64) k_sketch(int n, const char *__restrict__ s
 		bool moved_out = false;
 		const bool dense = m_ev == m_valid; // (uniform) lane l <-> event T + l
 		if (dense) {
-			if (isev) {
-				for (int q = (t - w + 1 < 0 ? 0 : t - w + 1); q <= t; ++q) { const uint64_t v = ex[q & (RING - 1)]; if (v <= nx) nx = v, N = q; } // window [t-w+1, t]
-			}
+			// window [t-w+1, t]: w entries for every lane (one trip count for the wavefront: no per-lane loop bounds); only at a sequence's start do some not exist yet
+			const int q0 = t - w + 1;
+			if (T >= w - 1) { for (int it = 0; it < w; ++it) { const int q = q0 + it; const uint64_t v = ex[q & (RING - 1)]; const bool ok = v <= nx; nx = ok ? v : nx, N = ok ? q : N; } }
+			else { for (int it = 0; it < w; ++it) { const int q = q0 + it; const uint64_t v = ex[q & (RING - 1)]; const bool ok = q >= 0 && v <= nx; nx = ok ? v : nx, N = ok ? q : N; } }
+			if (!isev) nx = MAXV, N = -1; // (lanes beyond the sequence's end)
 			px = sk_prev64(nx, c_nx), P = lc_prev_lane(N, c_N); // window [t-w, t-1] = the event before's [t'-w+1, t']
 		} else if (isev) {
 			const int lo = t - w < 0 ? 0 : t - w;
