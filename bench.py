@@ -244,6 +244,7 @@ def main():
     ap.add_argument("--resident-steps", type=int, default=2)
     ap.add_argument("--threads", type=int, default=0, help="host threads per rank (0: min(64, usable cores / ranks))")
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--gfx-activity", action="store_true", help="N=1: an UNPROFILED busy share of the GPU over extra headline steps: the driver's accumulated GFX activity counter (rocm-smi --showuse) read before and after them, scaled by the same counter over a 3 s matrix-multiply loop (block `gfx_activity`)")
     ap.add_argument("--workdir", default=None, help="keep the synthetic workload (graph, reads, graph image) in this directory and reuse it when it is already there (sweeps of several bench runs in one session)")
     ap.add_argument("--no-asm", action="store_true", help="N=1: skip the `asm` block (BASELINE configs[4] at one GPU's share: -cx asm, one ~98 Mbp contig per chromosome vs the headline's 3 Gbp graph, file -> file next to the reference, then --call)")
     ap.add_argument("--asm-genome", type=int, default=0, help="asm block on a self-made graph of this many backbone bp (10 chromosomes, 10 contigs) instead of the headline's graph (quick runs)")
@@ -417,6 +418,37 @@ def main():
         os.environ["MGA_DEV_GCHAIN"] = "1" if default_dev else "0"
     dt, st, host_main = timed(args.warmup, args.steps)
     gaf_main = last_gaf()
+    gfx_block = None
+    if args.gfx_activity and dist is None:
+        import re as _re
+
+        def gfx_acc():
+            try:
+                o_ = subprocess.run(["rocm-smi", "--showuse"], capture_output=True, text=True, timeout=30).stdout
+                m_ = _re.search(r"GFX Activity:\s*(\d+)", o_)
+                return int(m_.group(1)) if m_ else None
+            except Exception:
+                return None
+        try:
+            a0, t0_ = gfx_acc(), time.perf_counter()
+            x_ = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
+            while time.perf_counter() - t0_ < 3.0:
+                for _ in range(20):
+                    x_ = (x_ @ x_).clamp_(-1, 1)
+                torch.cuda.synchronize()
+            a1, t1_ = gfx_acc(), time.perf_counter()
+            del x_
+            k_g = max(10, args.steps)
+            b0, u0 = gfx_acc(), time.perf_counter()
+            dt_g, st_g, _h = timed(0, k_g)
+            b1, u1 = gfx_acc(), time.perf_counter()
+            if None not in (a0, a1, b0, b1) and a1 > a0:
+                per_s_busy = (a1 - a0) / (t1_ - t0_)
+                gfx_block = dict(busy_share=round((b1 - b0) / (u1 - u0) / per_s_busy, 3), steps=k_g, value=st_g["n_bases"] / dt_g / 1e9, ms_per_step=dt_g / k_g * 1e3,
+                                 counter_per_s_when_busy=round(per_s_busy, 1), counter_per_s_over_the_steps=round((b1 - b0) / (u1 - u0), 1),
+                                 note="UNPROFILED: the driver's accumulated GFX activity counter (rocm-smi --showuse) over %d headline steps against the same counter over 3 s of back-to-back bf16 matrix products" % k_g)
+        except Exception as e_:
+            gfx_block = dict(error=str(e_))
     file_out = None
     if dist is None and not args.no_file_out:   # SURVEY 8d asks for the same interval on both sides: the reference's step 2 writes its GAF to a file (gmap.c:119-139), so does this leg
         fout[0] = os.path.join(d, "gpu.gaf")
@@ -681,6 +713,7 @@ def main():
                                          frac=cells / (fam["k_wfa"] * 1e-3) / peak_cells,
                                          note="peak = 256 CU x 4 SIMD x 2.4 GHz / 4.15 cycles per wave64 integer instruction [measured] x 64 cells / 110 instructions per slot step; achieved counts the cells of "
                                               "the reference's band (miniwfa.c:421 n_iter) -- the windowed tiers compute about 2.4x fewer to the same alignment, which is why frac is not a utilisation")
+        _gfx_block = gfx_block
         res = dict(metric=METRIC, value=value, unit="Gbp/s",
                    n_gpus=n_gpus, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="u8/int32", data="synthetic",
@@ -774,6 +807,8 @@ def main():
                                        os.path.join(ROOT, "oracle", "_ref", "minigraph_dropin"), n_contig=args.asm_contigs, small_genome=args.asm_genome)
             except Exception as e:
                 res["asm"] = dict(error=repr(e))
+        if _gfx_block is not None:
+            res["gfx_activity"] = _gfx_block
         print(json.dumps(res), flush=True)
     if G is not None:
         G.close()
