@@ -1089,3 +1089,48 @@ def test_asm_200Mbp_four_contigs_gaf_and_sharded_call_vs_reference_binary():
     want = open(ref_bed, "rb").read()
     assert want.count(b"\n") > 1000
     assert open(bed, "rb").read() == want
+
+
+@pytest.mark.parametrize("flags,cli", [(0, []), (0x200000, ["--no-comp-path"]), (0x800, ["--vc"])])
+def test_gaf_lines_on_device_long_walks_mixed_tags_long_names(flags, cli):
+    """round 6: whole GAF lines are written on the device (k_gaf.hip).  A graph of 120 bp segments -- a 8 kb read walks ~70 vertices: the path column is folded across more than
+    one block of 64 vertices -- most of them intervals of ONE rank-0 stable sequence (SN / SO / SR tags: the compact one-interval form, forward and reverse), every 150th
+    without tags (printed by name in the middle of a run of intervals), alternative segments of rank 1 on stable sequences of their own, and read names of 120 characters
+    (copied in pieces, not through the 64-byte stage): the reference's bytes, in the general form, without the compact form and with vertex coordinates"""
+    import numpy as np
+    need_ref()
+    rng = np.random.default_rng(61)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    L, S = 60000, 120
+    back = bytes(rng.choice(acgt, L).tobytes())
+    d = tempfile.mkdtemp()
+    gfa, reads = os.path.join(d, "g.gfa"), os.path.join(d, "r.fa")
+    n = L // S
+    with open(gfa, "wb") as f:
+        for i in range(n):
+            seq = back[i * S:(i + 1) * S]
+            if i % 150 == 149:
+                f.write(b"S\ts%d\t%s\n" % (i, seq))   # no stable-sequence tags: a vertex printed by name
+            else:
+                f.write(b"S\ts%d\t%s\tSN:Z:chrK\tSO:i:%d\tSR:i:0\n" % (i, seq, i * S))
+        for i in range(n - 1):
+            f.write(b"L\ts%d\t+\ts%d\t+\t0M\n" % (i, i + 1))
+        for i in range(5, n - 2, 10):   # a bubble around segment i + 1: an alternative allele of rank 1 on its own stable sequence
+            alt = bytes(rng.choice(acgt, 90).tobytes())
+            f.write(b"S\ta%d\t%s\tSN:Z:alt%d\tSO:i:0\tSR:i:1\n" % (i, alt, i))
+            f.write(b"L\ts%d\t+\ta%d\t+\t0M\nL\ta%d\t+\ts%d\t+\t0M\n" % (i, i, i, i + 2))
+    with open(reads, "wb") as f:
+        for k in range(60):
+            st = int(rng.integers(0, L - 8000))
+            r = _np_mutate(rng, back[st:st + 8000], 0.05)
+            if k % 2:
+                r = r.translate(comp)[::-1]
+            f.write(b">read_%03d_%s\n%s\n" % (k, b"x" * 108, r))
+    ref_out, got = os.path.join(d, "ref.gaf"), os.path.join(d, "got.gaf")
+    run_ref(["-c", "-x", "lr", "-t", "4"] + cli + [gfa, reads], ref_out)
+    mga.map_files(gfa, [reads], got, flags=flags)
+    if open(ref_out, "rb").read() != open(got, "rb").read():
+        raise AssertionError(first_diff(ref_out, got))
+    body = open(got, "rb").read()
+    assert body.count(b"\n") >= 50 and (flags != 0 or (b"\t-\tchrK\t" in body and b"\t+\tchrK\t" in body and (b">chrK:" in body or b"<chrK:" in body) and (b">s149" in body or b"<s149" in body or b">s299" in body or b"<s299" in body))), "the forms this test is about were not printed"
