@@ -96,18 +96,20 @@ def test_file_sink_written_in_parallel_slices(monkeypatch):
         raise AssertionError(first_diff(ref_out, got))
 
 
-def test_long_join_rescue_on_device_matches_host_tree_and_reference(monkeypatch):
+@pytest.mark.parametrize("rlen,nreads,min_dev", [(10000, 1500, 100), (40000, 400, 50)])
+def test_long_join_rescue_on_device_matches_host_tree_and_reference(monkeypatch, rlen, nreads, min_dev):
     """the RMQ rescue (map-algo.c:407-417) runs inside k_lchain; the sequential AVL tree on the host (MGA_HOST_RESCUE=1)
-    and the reference binary must give the same bytes, and the device path must actually have been taken"""
+    and the reference binary must give the same bytes, and the device path must actually have been taken.  Round 6: 10 kb reads re-chain ~250 anchors -- the form with y,
+    priority and marks of every anchor in LDS (<= 336 anchors); 40 kb reads re-chain ~1000 -- the form over global memory"""
     d = tempfile.mkdtemp()
-    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "5000000", "-H", "3", "-n", "1500", "-s", "9", "-S", "77"], stderr=subprocess.DEVNULL)
+    subprocess.check_call([mga.MGSIM, "-p", os.path.join(d, "t"), "-G", "5000000", "-H", "3", "-n", str(nreads), "-l", str(rlen), "-s", "9", "-S", "77"], stderr=subprocess.DEVNULL)
     graph, reads = os.path.join(d, "t.gfa"), os.path.join(d, "t.reads.fa")
     G = mga.Graph(graph, preset="lr", cigar=True, n_threads=8)
     R = mga.Reads(reads)
     mga.get_stats(G, reset=True)
     dev = mga.map_reads(G, R, n_threads=8)
     st = mga.get_stats(G, reset=True)
-    assert st["n_rescue_dev"] > 100, st          # bubbles split ~half of the reads into several chains
+    assert st["n_rescue_dev"] > min_dev, st      # bubbles split ~half of the reads into several chains
     assert st["n_rescue_host"] <= st["n_rescue_dev"] // 10, st
     monkeypatch.setenv("MGA_HOST_RESCUE", "1")
     host = mga.map_reads(G, R, n_threads=8)
